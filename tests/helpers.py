@@ -1,0 +1,71 @@
+"""Shared test plumbing: golden fixtures, seeded frames, tolerances."""
+from __future__ import annotations
+
+import functools
+import os
+
+import numpy as np
+import torch
+
+from uforecon_amd.scene import frame_digest, make_frame, sampler_uniforms
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# same table as tests/golden/make_golden.py:CASES (kept in sync by test_oracle_golden)
+CASES = {
+    "c1_coarse_only": dict(H=64, W=96, NV=3, seed=0, RN=256, coarse=64, fine=64, coarse_only=True),
+    "c2_hier_small": dict(H=64, W=96, NV=3, seed=0, RN=256, coarse=64, fine=64),
+    "c2_hier_512x640": dict(H=512, W=640, NV=3, seed=0, RN=256, coarse=64, fine=64),
+    "c4_nv5_128": dict(H=48, W=64, NV=5, seed=3, RN=32, coarse=128, fine=128),
+    "rows_small": dict(H=64, W=96, NV=3, seed=0, RN=8, coarse=64, fine=64, rows=True),
+    "c5_train_fwd": dict(H=64, W=96, NV=3, seed=5, RN=64, coarse=64, fine=64, train=True),
+}
+
+# north_star tolerance: per-pixel depth and RGB within 1e-4 relative of the reference.
+REL_TOL = 1e-4
+
+
+@functools.lru_cache(maxsize=None)
+def load_weights() -> dict:
+    z = np.load(os.path.join(GOLDEN, "ray_path_weights_seed0.npz"))
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+@functools.lru_cache(maxsize=None)
+def load_golden(name: str) -> dict:
+    z = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    return {k: z[k] for k in z.files}
+
+
+@functools.lru_cache(maxsize=4)
+def case_frame(name: str):
+    c = CASES[name]
+    return make_frame(c["H"], c["W"], c["NV"], c["seed"], train_layout=c.get("train", False))
+
+
+def case_inputs(name: str):
+    """(frame, ray_idx (1,RN) int64, U1 (coarse,RN), U2 (fine,RN), golden dict)."""
+    c = CASES[name]
+    g = load_golden(name)
+    fr = case_frame(name)
+    dig = frame_digest(fr)
+    if abs(dig - float(g["input_digest"])) > 1e-9 * abs(dig):
+        import pytest
+
+        pytest.skip(f"seeded inputs differ on this host (digest {dig} vs {float(g['input_digest'])})")
+    idx = torch.from_numpy(g["ray_idx"])
+    U1, U2 = sampler_uniforms(int(g["sampler_seed"]), c["coarse"], c["fine"], c["RN"])
+    return fr, idx, U1, U2, g
+
+
+def rel_err(a, b) -> float:
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def max_rel_elem(a, b, floor) -> float:
+    """max |a-b| / max(|b|, floor) elementwise."""
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    return float(((a - b).abs() / b.abs().clamp_min(floor)).max())

@@ -1,0 +1,65 @@
+"""The CPU oracle reproduces the reference's golden vectors (CPU-only test).
+
+Pins oracle/ufo_oracle.py against outputs of the reference itself (tests/golden/*.npz,
+made by tests/golden/make_golden.py from /root/reference).
+"""
+import pytest
+import torch
+
+from helpers import CASES, REL_TOL, case_inputs, load_weights, rel_err
+from oracle import ufo_oracle as O
+
+EXACT = 2e-6  # oracle vs reference differ only by op-order rounding
+
+
+@pytest.mark.parametrize("name", ["c1_coarse_only", "c2_hier_small", "c4_nv5_128", "c2_hier_512x640"])
+def test_infer_matches_reference_golden(name):
+    c = CASES[name]
+    fr, idx, U1, U2, g = case_inputs(name)
+    P = load_weights()
+    with torch.no_grad():
+        srdf, pts, depth, rgb = O.infer(P, fr.batch, idx, fr.source_imgs_feat, fr.feature_volume,
+                                        fr.match_feature, U1, U2, coarse_only=c.get("coarse_only", False))
+    assert rel_err(pts, g["points"]) < EXACT
+    assert rel_err(depth, g["depth"]) < EXACT < REL_TOL
+    assert rel_err(rgb, g["rgb"]) < EXACT
+    assert rel_err(srdf, g["srdf"]) < 1e-5
+
+
+def test_rows_match_reference_golden():
+    fr, idx, U1, U2, g = case_inputs("rows_small")
+    P = load_weights()
+    want = {}
+    with torch.no_grad():
+        O.infer(P, fr.batch, idx, fr.source_imgs_feat, fr.feature_volume, fr.match_feature, U1, U2, want=want)
+    for tag in ("coarse", "fine"):
+        w = want[tag]
+        RN, SN = w["z"].shape
+        assert rel_err(w["z"], g[f"{tag}.z"]) == 0.0
+        assert rel_err(w["pts"], g[f"{tag}.pts"]) == 0.0
+        assert rel_err(w["xy"], g[f"{tag}.xy"]) < EXACT
+        assert rel_err(w["mask_z"], g[f"{tag}.mask_z"]) == 0.0
+        assert rel_err(w["sim8"], g[f"{tag}.sim8"]) < EXACT
+        assert rel_err(w["vol24"], g[f"{tag}.vol24"]) < EXACT
+        xt = torch.from_numpy(g[f"{tag}.x_tokens"])
+        assert rel_err(w["x"], xt[:, 1:]) < EXACT
+        assert rel_err(w["view_out"], g[f"{tag}.view_out"]) < 1e-5
+        assert rel_err(w["ray_out"], g[f"{tag}.ray_out"]) < 1e-5
+        assert rel_err(w["srdf"], g[f"{tag}.srdf"]) < 1e-5
+        assert rel_err(w["radiance"], g[f"{tag}.radiance"]) < 1e-5
+        assert rel_err(w["weight"], g[f"{tag}.weight"]) < 1e-5
+        assert rel_err(w["depth"], g[f"{tag}.depth"]) < EXACT
+        assert rel_err(w["rgb"], g[f"{tag}.rgb"]) < EXACT
+
+
+def test_train_layout_forward_matches_reference_golden():
+    fr, idx, U1, U2, g = case_inputs("c5_train_fwd")
+    P = load_weights()
+    with torch.no_grad():
+        r = O.infer(P, fr.batch, idx, fr.source_imgs_feat, fr.feature_volume, fr.match_feature, U1, U2,
+                    extract_geometry=False)
+    for k in ("rgb", "depth", "opacity", "weight", "rgb_2", "depth_2", "opacity_2", "weight_2", "z_val", "z_val_all"):
+        assert rel_err(r[k], g[k][0]) < 1e-5, k
+    assert rel_err(r["srdf"], g["srdf"][..., 0]) < 1e-5
+    assert rel_err(r["srdf_2"], g["srdf_2"][..., 0]) < 1e-5
+    assert rel_err(r["variance"], g["variance"]) < 1e-6

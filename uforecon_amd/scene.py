@@ -1,0 +1,189 @@
+"""Synthetic DTU-like frames for the per-ray path (no dataset / checkpoint needed).
+
+Builds the `batch` dict and the per-frame encoder outputs that the reference
+hands to ``UFORecon.infer`` (/root/reference/code1/model.py:393), with camera
+conventions derived the way the reference test dataset derives them
+(/root/reference/code1/dataset/dtu_test_sparse.py:331-336, 405-429):
+
+* ``source_poses = normalize @ K_pad @ w2c`` so projected x,y land in [-1,1],
+* ``ray_d`` from ``ref_pose_inv @ homo_pixel`` on a ``linspace(-1,1)`` pixel grid,
+* ``cam_ray_d`` from view-0 intrinsics,
+* ``near_fars = [0.95 (dist-1), 1.05 (dist+1)]`` (unit-sphere scene),
+* render pose = source pose 0 shifted along its camera-x axis
+  (dtu_test_sparse.py:269-272).
+
+Everything is produced on the CPU from seeded generators so the oracle, the
+golden fixtures and the HIP path all see bit-identical inputs.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+STAGES = ("stage1", "stage2", "stage3")
+# (depth planes, spatial scale) of the three correlation frustums
+# (/root/reference/main.py:81 ndepths="48,32,8"; model.py:796-802).
+STAGE_SHAPE = {"stage1": (48, 4), "stage2": (32, 2), "stage3": (8, 1)}
+
+
+def _look_at_w2c(eye: np.ndarray, target: np.ndarray) -> np.ndarray:
+    """OpenCV-style world->camera (x right, y down, z forward)."""
+    fwd = target - eye
+    fwd = fwd / np.linalg.norm(fwd)
+    up = np.array([0.0, -1.0, 0.0])
+    right = np.cross(fwd, up)
+    right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    R = np.stack([right, down, fwd], axis=0)  # rows = camera axes in world
+    w2c = np.eye(4)
+    w2c[:3, :3] = R
+    w2c[:3, 3] = -R @ eye
+    return w2c
+
+
+def _unit_uniform(shape, g):
+    """Zero-mean unit-variance uniform noise.  ``torch.rand`` on the CPU generator is
+    exact integer->float arithmetic, so (unlike ``randn``, whose vectorised Box-Muller
+    goes through libm) the values are identical on every host."""
+    return (torch.rand(*shape, generator=g) - 0.5) * math.sqrt(12.0)
+
+
+def frame_digest(frame: "Frame") -> float:
+    """Order-independent fingerprint of a frame's tensors (float64 sums), stored in the
+    golden fixtures so a test can tell 'inputs differ on this host' from 'outputs wrong'."""
+    acc = 0.0
+    ts = [frame.source_imgs_feat, frame.match_feature[0], frame.batch["source_imgs"],
+          frame.batch["depth_info"], frame.batch["source_poses"], frame.batch["ray_d"]]
+    for st in STAGES:
+        ts += [frame.feature_volume[st]["feature_volume"], frame.feature_volume[st]["weight_volume"]]
+    for i, t in enumerate(ts):
+        acc += (i + 1) * float(t.double().abs().sum())
+    return acc
+
+
+@dataclass
+class Frame:
+    """One frame worth of inputs of the per-ray path."""
+
+    batch: dict
+    source_imgs_feat: torch.Tensor  # (1,NV,32,H/4,W/4)
+    feature_volume: dict  # stage -> {'feature_volume': (NV,8,D,h,w), 'weight_volume': (NV,1,D,h,w)}
+    match_feature: list  # [ (1,NV,32*(NV-1),H/4,W/4) ]
+    H: int
+    W: int
+    NV: int
+
+    def to(self, device) -> "Frame":
+        def mv(x):
+            if torch.is_tensor(x):
+                return x.to(device)
+            if isinstance(x, dict):
+                return {k: mv(v) for k, v in x.items()}
+            if isinstance(x, list):
+                return [mv(v) for v in x]
+            return x
+
+        return Frame(mv(self.batch), mv(self.source_imgs_feat), mv(self.feature_volume),
+                     mv(self.match_feature), self.H, self.W, self.NV)
+
+
+def make_cameras(H: int, W: int, NV: int, offset_dist: float = 0.08, train_layout: bool = False):
+    """Cameras on an arc of radius ~3 around the origin, looking at it."""
+    w2cs, Ks, nfs = [], [], []
+    for i in range(NV):
+        a = (i - (NV - 1) / 2.0) * 0.35
+        eye = np.array([3.0 * math.sin(a), 0.3 * i, -3.0 * math.cos(a)])
+        w2c = _look_at_w2c(eye, np.zeros(3))
+        K = np.array([[0.9 * W, 0.0, (W - 1) / 2.0], [0.0, 0.9 * W, (H - 1) / 2.0], [0.0, 0.0, 1.0]])
+        dist = float(np.linalg.norm(eye))
+        w2cs.append(w2c)
+        Ks.append(K)
+        nfs.append([0.95 * (dist - 1.0), 1.05 * (dist + 1.0)])
+    w2cs = np.stack(w2cs)
+    Ks = np.stack(Ks)
+    nfs = np.array(nfs)
+
+    # render view: source 0 shifted along its own camera x axis
+    c2w0 = np.linalg.inv(w2cs[0])
+    render_c2w = c2w0.copy()
+    render_c2w[:3, 3] += render_c2w[:3, 0] * offset_dist
+    render_w2c = np.linalg.inv(render_c2w)
+
+    K_pad = np.tile(np.eye(4), (NV, 1, 1))
+    K_pad[:, :3, :3] = Ks
+    normalize = np.array([[2.0 / (W - 1), 0, -1, 0], [0, 2.0 / (H - 1), -1, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]])
+    source_poses = normalize[None] @ K_pad @ w2cs
+    ref_pose = normalize @ K_pad[0] @ render_w2c
+    ref_pose_inv = np.linalg.inv(ref_pose)
+    source_poses_inv = np.linalg.inv(source_poses)
+
+    h_line = np.linspace(0, H - 1, H) * 2 / (H - 1) - 1
+    w_line = np.linspace(0, W - 1, W) * 2 / (W - 1) - 1
+    hm, wm = np.meshgrid(h_line, w_line, indexing="ij")
+    homo = np.stack([wm.reshape(-1), hm.reshape(-1), np.ones(H * W), np.ones(H * W)])
+    ray_o = ref_pose_inv[:3, -1]
+    rd = (ref_pose_inv @ homo)[:3] - ray_o[:, None]
+    rd = rd / np.linalg.norm(rd, axis=0)
+    crd = (np.linalg.inv(normalize @ K_pad[0]) @ homo)[:3]
+    crd = crd / np.linalg.norm(crd, axis=0)
+
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float()
+    cams = dict(
+        w2cs=f32(w2cs)[None], intrinsics=f32(Ks)[None], near_fars=f32(nfs)[None],
+        source_poses=f32(source_poses)[None], source_poses_inv=f32(source_poses_inv)[None],
+        ref_pose_inv=f32(ref_pose_inv)[None], ray_o=f32(ray_o)[None],
+        ray_d=f32(rd)[None], cam_ray_d=f32(crd)[None],
+        scale_mat=torch.eye(4)[None] * 1.0, scale_factor=torch.tensor([1.0]),
+    )
+    if train_layout:
+        # training batches carry the GT reference view at index 0 of w2cs /
+        # intrinsics / near_fars and have no 'start_idx' (model.py:313 -> s_idx=1)
+        cams["w2cs"] = torch.cat([f32(render_w2c)[None, None], cams["w2cs"]], 1)
+        cams["intrinsics"] = torch.cat([cams["intrinsics"][:, :1], cams["intrinsics"]], 1)
+        cams["near_fars"] = torch.cat([cams["near_fars"][:, :1], cams["near_fars"]], 1)
+    return cams
+
+
+def make_frame(H: int = 64, W: int = 96, NV: int = 3, seed: int = 0, offset_dist: float = 0.08,
+               train_layout: bool = False) -> Frame:
+    """Seeded synthetic frame."""
+    assert H % 4 == 0 and W % 4 == 0
+    g = torch.Generator().manual_seed(seed)
+    batch = make_cameras(H, W, NV, offset_dist, train_layout)
+    h, w = H // 4, W // 4
+    batch["source_imgs"] = torch.rand(1, NV, 3, H, W, generator=g)
+    batch["depth_info"] = 2.0 + 2.0 * torch.rand(1, NV, H, W, generator=g)
+    if train_layout:
+        batch["ref_img"] = torch.rand(1, 3, H, W, generator=g)
+        batch["depths_h"] = 2.0 + 2.0 * torch.rand(1, NV + 1, H, W, generator=g)
+    else:
+        batch["start_idx"] = 0
+    feat = _unit_uniform((1, NV, 32, h, w), g)
+    match = [_unit_uniform((1, NV, 32 * (NV - 1), h, w), g)]
+    vol = {}
+    for st in STAGES:
+        D, s = STAGE_SHAPE[st]
+        vol[st] = {
+            "feature_volume": _unit_uniform((NV, 8, D, H // s, W // s), g),
+            "weight_volume": torch.rand(NV, 1, D, H // s, W // s, generator=g),
+        }
+    return Frame(batch, feat, vol, match, H, W, NV)
+
+
+def sampler_uniforms(seed: int, point_num: int, point_num_2: int, RN: int):
+    """The two uniform draws of one ``infer`` call, in the reference's order and shapes.
+
+    FixedSampler draws ``torch.rand((SN, RN))`` (sampler.py:42) and then
+    ImportanceSampler draws ``torch.rand(point_num, RN).T`` (sampler.py:86), both on the
+    CPU default generator.  Drawing them here from ``torch.manual_seed(seed)`` in that
+    order reproduces what the reference consumes after the same ``manual_seed``.
+    """
+    st = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    u1 = torch.rand(point_num, RN)
+    u2 = torch.rand(point_num_2, RN)
+    torch.random.set_rng_state(st)
+    return u1, u2

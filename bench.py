@@ -1,0 +1,179 @@
+#!/usr/bin/env python
+"""Headline benchmark: rays/s (+ depth-map ms/frame) of the per-ray path, DTU-shaped 3-view 512x640.
+
+One "step" = one full frame through the hot path (BASELINE.json configs[1]: 64+64 hierarchical
+samples, every one of the 327 680 pixel rays): channel-last re-layout of the per-frame tensors,
+then ufr_render_rays over this rank's row tile, then (N>1) an RCCL all-gather of the depth / RGB
+tiles.  Inputs are synthetic (uforecon_amd.scene, seed 0; random-init weights seed 0) and resident
+in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work per point evaluation (NV=3 / NV=5), flop
+FLOP_PER_POINT = {3: 708_018, 5: 983_150}
+# ... of which the view-transformer launch (q/k/v/merge 204 800 + MLP 307 200 + attention 13 440 +
+# radiance MLP 8 784 at NV=3): the dominant kernel the roofline object describes
+VIEWT_FLOP_PER_POINT = {3: 204_800 + 307_200 + 13_440 + 8_784, 5: (204_800 + 307_200) * 6 // 4 + 20_160 + 14_640}
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--height", type=int, default=512)
+    p.add_argument("--width", type=int, default=640)
+    p.add_argument("--views", type=int, default=3)
+    p.add_argument("--coarse", type=int, default=64)
+    p.add_argument("--fine", type=int, default=64)
+    p.add_argument("--chunk", type=int, default=0, help="rays per launch group (0 = library default)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-rays", type=int, default=256)
+    p.add_argument("--cpu-calls", type=int, default=5)
+    return p.parse_args()
+
+
+def cpu_baseline(frame_cpu, weights_cpu, a):
+    """The oracle (CPU port of the reference path) on this host's cores, bounded sample."""
+    from oracle import ufo_oracle as O
+    from uforecon_amd.scene import sampler_uniforms
+
+    RN = a.cpu_rays
+    HW = a.height * a.width
+    idx = (torch.arange(RN) * (HW // RN) + (HW // RN) // 3)[None]
+    U1, U2 = sampler_uniforms(1, a.coarse, a.fine, RN)
+    times = []
+    with torch.no_grad():
+        for i in range(a.cpu_calls + 1):
+            t = time.perf_counter()
+            O.infer(weights_cpu, frame_cpu.batch, idx, frame_cpu.source_imgs_feat, frame_cpu.feature_volume,
+                    frame_cpu.match_feature, U1, U2)
+            if i:
+                times.append(time.perf_counter() - t)
+    times.sort()
+    med = times[len(times) // 2]
+    return dict(value=RN / med, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle.infer on {RN} rays of the same frame, {a.coarse}+{a.fine} samples, "
+                       f"median of {a.cpu_calls} calls after 1 warm-up ({med * 1e3:.0f} ms/call)")
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    import torch.distributed as dist
+
+    from uforecon_amd import ops
+    from uforecon_amd.dist import RayShard, all_gather_tiles
+    from uforecon_amd.scene import make_frame
+
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import numpy as np
+
+    wz = np.load(os.path.join(ROOT, "tests", "golden", "ray_path_weights_seed0.npz"))
+    weights_cpu = {k: torch.from_numpy(wz[k]) for k in wz.files}
+    frame_cpu = make_frame(a.height, a.width, a.views, seed=0)
+    frame = frame_cpu.to(dev)
+    W = ops.PackedWeights({k: v.to(dev) for k, v in weights_cpu.items()})
+
+    HW = a.height * a.width
+    shard = RayShard(a.height, a.width, world, rank)        # contiguous row tile of this rank
+    ray_idx = shard.ray_indices(dev)
+    RN = ray_idx.numel()
+    ws = ops.RenderWorkspace(dev, a.coarse, a.fine, a.views, chunk_rays=a.chunk)
+    out = dict(depth=torch.empty(RN, device=dev), depth_z=torch.empty(RN, device=dev), rgb=torch.empty(RN, 3, device=dev))
+    gathered = None
+
+    def step():
+        nonlocal gathered
+        fh = ops.FrameHandle(frame.batch, frame.source_imgs_feat, frame.feature_volume, frame.match_feature)
+        U1 = torch.rand(a.coarse, RN, device=dev)
+        U2 = torch.rand(a.fine, RN, device=dev)
+        ops.render_rays(fh, W, ray_idx, U1, U2, workspace=ws, want_srdf=False, out=out)
+        if world > 1:
+            gathered = all_gather_tiles(out["depth_z"], out["rgb"], shard)
+        return fh
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    ops.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = ops.profile_read()
+    ops.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        S = a.coarse + a.fine
+        pts_per_ray = a.coarse + S
+        rays_per_s = HW * a.steps / dt
+        flop_pt = FLOP_PER_POINT.get(a.views)
+        vt = prof.get("view_transformer", dict(ms=0.0, launches=1))
+        chunk = ws.chunk
+        # one view-transformer launch = chunk rays x SN (coarse) or S (fine) points; average over both
+        vt_pts_per_launch = (RN * pts_per_ray * a.steps) / max(vt["launches"], 1)
+        vt_ms = vt["ms"] / max(vt["launches"], 1)
+        vt_flop = VIEWT_FLOP_PER_POINT.get(a.views, 0) * vt_pts_per_launch
+        achieved = vt_flop / (vt_ms * 1e-3) / 1e12 if vt_ms > 0 else 0.0
+        line = dict(
+            metric="rays/s (per-ray volume-rendering path, 64+64 hierarchical samples, DTU-shaped 3-view 512x640)",
+            value=rays_per_s, unit="rays/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
+            ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None,
+            dtype="f32", data="synthetic",
+            config=dict(workload=f"configs[1]: full {a.height}x{a.width} frame = {HW} rays, {a.views} source views, "
+                                 f"{a.coarse}+{a.fine} samples ({pts_per_ray} point evaluations/ray), rays sharded by row "
+                                 f"tiles over {world} GPU(s), depth/RGB tiles all-gathered",
+                        rays_per_frame=HW, chunk_rays=chunk, depth_map_ms_per_frame=dt / a.steps * 1e3,
+                        whole_path_tflops=(rays_per_s * pts_per_ray * flop_pt / 1e12) if flop_pt else None,
+                        whole_path_frac_of_fp32_mfma_peak=(rays_per_s * pts_per_ray * flop_pt / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world))
+                        if flop_pt else None,
+                        kernel_ms_per_frame_rank0={k: v["ms"] / a.steps for k, v in prof.items()}),
+            roofline=dict(bound="mfma", achieved=achieved, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                          frac=achieved / PEAK_FP32_MFMA_TFLOPS, traffic=None, kernel="view_transformer_kernel",
+                          avg_launch_ms=vt_ms, launches=vt["launches"]),
+        )
+        if not a.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(frame_cpu, weights_cpu, a)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

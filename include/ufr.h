@@ -1,0 +1,191 @@
+/*
+ * ufr.h -- C ABI of libufr.so: the MI355X (gfx950) implementation of UFORecon's per-ray
+ * volume-rendering path.
+ *
+ * Every entry point replaces a piece of the reference's Python hot path (paths relative
+ * to the upstream repo, code1/...).  Plain pointers and sizes only; all tensor pointers
+ * are DEVICE pointers to contiguous fp32 (int64 for ray indices) unless marked "host".
+ * Kernels are enqueued on the given HIP stream and never synchronise.  Return value:
+ * 0 on success, negative ufr_status otherwise; ufr_last_error() gives the message
+ * (thread-local).  Shapes use the reference's names: NV source views, RN rays, SN samples
+ * per ray, P = RN*SN points, H x W image, h x w = H/4 x W/4 feature maps.
+ */
+#ifndef UFR_H
+#define UFR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ufr_stream; /* hipStream_t */
+
+enum ufr_status {
+  UFR_OK = 0,
+  UFR_ERR_ARG = -1,      /* bad shape / null pointer / unsupported size */
+  UFR_ERR_HIP = -2,      /* a HIP runtime call failed */
+  UFR_ERR_WORKSPACE = -3 /* workspace too small */
+};
+
+#define UFR_MAX_VIEWS 7
+#define UFR_NUM_STAGES 3
+#define UFR_TOKEN_DIM 80 /* [img feat 32 | volume 24 | similarity 16 | depth PE 8], ray_transformer.py:258-281 */
+#define UFR_RAY_DIM 88   /* token dim + 8 order PE, ray_transformer.py:301-303 */
+
+int ufr_version(void);
+const char* ufr_last_error(void);
+
+/* ------------------------------------------------------------------ weights
+ * Device pointers to the per-ray parameters in the reference's own layout (nn.Linear
+ * weight = row-major [out][in]); names follow the state_dict keys under
+ * "ray_transformer." (parameter inventory). */
+typedef struct ufr_layer_weights { /* one LoFTREncoderLayer, attention/transformer.py:7-58 */
+  const float *q, *k, *v, *merge; /* [d][d]            */
+  const float *mlp0;              /* [2d][2d]          */
+  const float *mlp2;              /* [d][2d]           */
+  const float *norm1_w, *norm1_b, *norm2_w, *norm2_b; /* [d] */
+} ufr_layer_weights;
+
+typedef struct ufr_mlp3_weights { /* Linear-ReLU-Linear-ReLU-Linear with bias */
+  const float *w0, *b0, *w2, *b2, *w4, *b4;
+} ufr_mlp3_weights;
+
+typedef struct ufr_raw_weights {
+  ufr_mlp3_weights pre_sim;   /* pre_sim_mlp.{0,2,4}: 8->32->32->16          (ray_transformer.py:128-132) */
+  ufr_layer_weights view;     /* density_view_transformer.layers.0, d=80     (ray_transformer.py:135)     */
+  ufr_layer_weights ray;      /* density_ray_transformer.layers.0, d=88      (ray_transformer.py:138)     */
+  ufr_mlp3_weights density;   /* DensityMLP.{0,2,4}: 88->32->16->1           (ray_transformer.py:147-150) */
+  ufr_mlp3_weights radiance;  /* linear_radianceweight_1_softmax: 83->16->8->1 (ray_transformer.py:159-163) */
+  const float* view_token;    /* viewToken.view_token [80]                   (ray_transformer.py:325-331) */
+  const float* variance;      /* deviation_network.variance, scalar          (single_variance_network.py:8) */
+} ufr_raw_weights;
+
+/* Re-orders the dense matrices into MFMA A-fragment order (one 16x16 output tile x 16
+ * input features = 64 lanes x float4, zero padded) so the kernels stream them with
+ * contiguous 1 KiB wave loads.  Call again whenever the parameters change. */
+size_t ufr_packed_weights_bytes(void);
+int ufr_weights_pack(const ufr_raw_weights* raw, void* packed, ufr_stream stream);
+/* Host-only description of that re-ordering (for tests / other bindings): for every packed
+ * float, param_id (index into the pointer list of ufr_raw_weights in declaration order, -1 =
+ * zero padding) and elem (flat element index inside that parameter).  Arrays of
+ * ufr_packed_weights_bytes()/4 int32 each.  No GPU needed. */
+int ufr_pack_plan(int32_t* param_id, int32_t* elem);
+
+/* ------------------------------------------------------------------ frame
+ * Per-frame tensors produced by the encoder (model.py:780-808), in the reference layout.
+ * ufr_frame_prepare re-lays them out channel-last into `workspace` (one tap = one
+ * contiguous line) and records the camera constants; the result is immutable during the
+ * ray loop (model.py:814-823). */
+typedef struct ufr_frame_desc {
+  int32_t NV, H, W;               /* full-resolution image size; feature maps are H/4 x W/4          */
+  const float* source_imgs;       /* (NV,3,H,W)   batch['source_imgs']                               */
+  const float* depth_info;        /* (NV,H,W)     batch['depth_info'] (model.py:807-808)             */
+  const float* feat;              /* (NV,32,h,w)  source_imgs_feat                                   */
+  const float* match;             /* (NV,32*(NV-1),h,w) match_feature[0]                             */
+  const float* vol_feat[UFR_NUM_STAGES];   /* (NV,8,D,Hs,Ws) feature_volume[stage]['feature_volume']  */
+  const float* vol_weight[UFR_NUM_STAGES]; /* (NV,1,D,Hs,Ws) feature_volume[stage]['weight_volume']   */
+  int32_t vol_D[UFR_NUM_STAGES], vol_H[UFR_NUM_STAGES], vol_W[UFR_NUM_STAGES];
+  /* camera constants, HOST pointers (copied) */
+  const float* source_poses;      /* (NV,4,4) normalize @ K_pad @ w2c  (dtu_test_sparse.py:409-416)  */
+  const float* source_cam_pos;    /* (NV,3)   source_poses_inv[:, :3, 3] (ray_transformer.py:187)    */
+  const float* ref_cam_pos;       /* (3)      ref_pose_inv[:3, 3]        (ray_transformer.py:185)    */
+  const float* w2c_row2;          /* (NV,4)   w2cs[s_idx:, 2, :]         (ray_transformer.py:240-243) */
+  float vol_near, vol_far;        /* batch['near_fars'][0][0]            (model.py:328)              */
+} ufr_frame_desc;
+
+/* Host-side handle filled by ufr_frame_prepare (device pointers into `workspace`, sizes, camera
+ * constants).  Plain data: copy it freely; it stays valid while `workspace` and the borrowed
+ * depth_info tensor are alive. */
+typedef struct ufr_frame { uint64_t opaque[160]; } ufr_frame;
+
+size_t ufr_frame_workspace_bytes(const ufr_frame_desc* d);
+int ufr_frame_prepare(const ufr_frame_desc* d, void* workspace, size_t workspace_bytes, ufr_frame* out,
+                      ufr_stream stream);
+
+/* ------------------------------------------------------------------ per-op entry points
+ * (each mirrors one reference function; used by the drop-in Python classes and the parity
+ * tests; ufr_render_rays below chains them for whole-frame inference) */
+
+/* FixedSampler.sample_ray with near/far (encoder_utils/sampler.py:15-50).
+ * U: (SN,RN) uniforms exactly as torch.rand((SN,RN)) produced them.  z_out: (RN,SN). */
+int ufr_sample_fixed(const float* near, const float* far, const float* U, float* z_out,
+                     int32_t RN, int32_t SN, ufr_stream stream);
+
+/* ImportanceSampler.sample_ray (sampler.py:74-108) fused with the coarse+fine merge
+ * (model.py:466-470).  weight,z: (RN,SN); U2: (PN,RN) as drawn by torch.rand(PN,RN);
+ * z_fine: (RN,PN) sorted (may be NULL); z_all: (RN,SN+PN) sorted. */
+int ufr_sample_importance_merge(const float* weight, const float* z, const float* U2, float* z_fine,
+                                float* z_all, int32_t RN, int32_t SN, int32_t PN, ufr_stream stream);
+
+/* points = ray_o + z * ray_d (sampler.py:47).  ray_o: (3) or (RN,3) by `ray_o_stride` (0 or 3). */
+int ufr_points(const float* ray_o, int32_t ray_o_stride, const float* ray_d, const float* z, float* points,
+               int32_t RN, int32_t SN, ufr_stream stream);
+
+/* Projection + all gathers of one pass: camera.get_coord_ref_ndc (misc/camera.py:378-407),
+ * query_cond_info (model.py:218-305), query_depth_from_volume (model.py:350-390) and
+ * ray_transformer.py:185-281 up to the token assembly (incl. pre_sim_mlp).
+ * Outputs: x_tokens (P,NV,80); rgb (P,NV,4) [r,g,b,mask]; dir (P,NV,4) [dx,dy,dz,0].
+ * Optional debug outputs (may be NULL): sim8 (P,8), vol24 (P,24), xy (NV,P,2), mask_z (NV,P). */
+int ufr_project_gather(const ufr_frame* frame, const ufr_raw_weights* raw, const float* ray_o,
+                       int32_t ray_o_stride, const float* ray_d, const float* z, int32_t RN, int32_t SN,
+                       float* x_tokens, float* rgb, float* dir, float* sim8, float* vol24, float* xy,
+                       float* mask_z, ufr_stream stream);
+
+/* View transformer + ray transformer + SRDF / radiance heads (ray_transformer.py:283-320).
+ * radiance: (P,3); srdf: (RN,SN).  workspace >= ufr_aggregate_workspace_bytes(RN,SN).
+ * Optional debug outputs (may be NULL): view_out (P,NV+1,80), ray_out (P,88). */
+size_t ufr_aggregate_workspace_bytes(int32_t RN, int32_t SN, int32_t NV);
+int ufr_aggregate(const void* packed_weights, const float* x_tokens, const float* rgb, const float* dir,
+                  int32_t RN, int32_t SN, int32_t NV, float* radiance, float* srdf, void* workspace,
+                  float* view_out, float* ray_out, ufr_stream stream);
+
+/* VolumeRenderer.render (encoder_utils/renderer.py:7-48) with SingleVarianceNetwork
+ * (single_variance_network.py:10-11).  z,srdf: (RN,SN); radiance: (RN,SN,3); variance: device scalar.
+ * Outputs: rgb (RN,3), depth (RN), opacity (RN), weight (RN,SN); any may be NULL except depth. */
+int ufr_composite(const float* z, const float* radiance, const float* srdf, const float* variance,
+                  int32_t RN, int32_t SN, float* rgb, float* depth, float* opacity, float* weight,
+                  ufr_stream stream);
+
+/* ------------------------------------------------------------------ whole-path inference
+ * UFORecon.infer(extract_geometry=True) (model.py:393-478) for RN rays of one frame:
+ * ray gather by index, near/far / cam_ray_d.z, coarse pass, importance sampling + merge, fine
+ * pass.  Depth is the ray length (model.py:821 converts to z-depth: see depth_z). */
+typedef struct ufr_render_args {
+  const ufr_frame* frame;     /* from ufr_frame_prepare                                   */
+  const void* packed_weights; /* from ufr_weights_pack                                    */
+  const ufr_raw_weights* raw; /* same parameters, reference layout (pre_sim_mlp, variance) */
+  const int64_t* ray_idx;     /* (RN) indices into H*W                      (model.py:409) */
+  const float* ray_d;         /* (3,H*W) batch['ray_d']                                   */
+  const float* cam_ray_d;     /* (3,H*W) batch['cam_ray_d']                (model.py:424) */
+  float ray_o[3];             /* batch['ray_o']                                           */
+  float near_z, far_z;        /* batch['near_fars'][0,0,:]              (model.py:416-421) */
+  const float* U1;            /* (SN,RN) coarse jitter uniforms         (sampler.py:42)    */
+  const float* U2;            /* (PN,RN) importance uniforms; NULL if coarse_only (sampler.py:86) */
+  int32_t RN, SN, PN;         /* rays, coarse samples, fine samples                        */
+  int32_t coarse_only;        /* args.test_coarse_only                  (model.py:449-452) */
+  /* outputs (device) */
+  float* depth;               /* (RN) ray-length depth                                     */
+  float* depth_z;             /* (RN) depth * cam_ray_d.z (model.py:821), may be NULL      */
+  float* rgb;                 /* (RN,3)                                                    */
+  float* srdf;                /* (RN,S) S = SN or SN+PN, may be NULL                        */
+  float* z_all;               /* (RN,S) sample distances of the returned pass, may be NULL  */
+  int32_t chunk_rays;         /* rays per internal launch group (0 = library default)       */
+  void* workspace;            /* >= ufr_render_workspace_bytes(chunk_rays,SN,PN,NV)         */
+  size_t workspace_bytes;
+} ufr_render_args;
+
+size_t ufr_render_workspace_bytes(int32_t chunk_rays, int32_t SN, int32_t PN, int32_t NV);
+int32_t ufr_default_chunk_rays(void);
+int ufr_render_rays(const ufr_render_args* a, ufr_stream stream);
+
+/* Per-kernel HIP-event timing of the most recent ufr_render_rays on this thread when
+ * enabled (for bench.py's roofline line).  names/ms arrays of length `cap`; returns count. */
+void ufr_profile_enable(int on);
+int ufr_profile_read(const char** names, float* ms, int32_t* launches, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UFR_H */

@@ -69,3 +69,11 @@ def max_rel_elem(a, b, floor) -> float:
     a = torch.as_tensor(a).double().cpu()
     b = torch.as_tensor(b).double().cpu()
     return float(((a - b).abs() / b.abs().clamp_min(floor)).max())
+
+
+def border_degenerate_rays(rows: dict, tol: float = 2e-5) -> torch.Tensor:
+    """Rays with a sample whose projection lies within `tol` of an image border (|x| = 1 or |y| = 1)
+    of some source view.  `rows` is one pass of the oracle's intermediates (xy: (NV,RN,SN,2))."""
+    xy = rows["xy"].abs()
+    near = ((xy - 1.0).abs() < tol).any(-1) & (rows["mask_z"] > 0)
+    return near.any(0).any(-1)

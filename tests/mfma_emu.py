@@ -1,0 +1,136 @@
+"""Lane-level numpy model of v_mfma_f32_16x16x4_f32 and of the kernels' chained-GEMM register
+layout (uforecon_amd/csrc/ufr_layout.h, ufr_device.h).  Lets the CPU test-suite check the packed
+weight plan exported by libufr.so (ufr_pack_plan) without a GPU.
+
+MFMA semantics (cdna_hip_programming.md section 3): D[i][j] += sum_k A[i][k] B[k][j] with lane l
+supplying A[l&15][l>>4], B[l>>4][l&15] and owning D[4*(l>>4)+r][l&15], r = 0..3.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+LANE = np.arange(64)
+G, J = LANE >> 4, LANE & 15
+
+# mirrors of the enums in ufr_layout.h
+ROW_NAT, ROW_SLOT20, ROW_HEAD11, ROW_NAT88 = range(4)
+COL_NAT, COL_SLOT20, COL_NAT88, COL_HEAD11, COL_RW0, COL_CAT88 = range(6)
+
+# (name, param, k_raw, n_out, n_in, rm, cm, out_dim, in_dim) in blob order
+MATS = [
+    ("VT_Q", 6, 80, 5, 5, ROW_SLOT20, COL_NAT, 80, 80), ("VT_K", 7, 80, 5, 5, ROW_SLOT20, COL_NAT, 80, 80),
+    ("VT_V", 8, 80, 5, 5, ROW_SLOT20, COL_NAT, 80, 80), ("VT_MERGE", 9, 80, 5, 5, ROW_NAT, COL_SLOT20, 80, 80),
+    ("VT_MLP0", 10, 160, 10, 10, ROW_NAT, COL_NAT, 160, 160), ("VT_MLP2", 11, 160, 5, 10, ROW_NAT, COL_NAT, 80, 160),
+    ("RT_Q", 16, 88, 8, 6, ROW_HEAD11, COL_NAT88, 88, 88), ("RT_K", 17, 88, 8, 6, ROW_HEAD11, COL_NAT88, 88, 88),
+    ("RT_V", 18, 88, 8, 6, ROW_HEAD11, COL_NAT88, 88, 88), ("RT_MERGE", 19, 88, 6, 8, ROW_NAT88, COL_HEAD11, 88, 88),
+    ("RT_MLP0", 20, 176, 11, 12, ROW_NAT, COL_CAT88, 176, 176), ("RT_MLP2", 21, 176, 6, 11, ROW_NAT88, COL_NAT, 88, 176),
+    ("DM0", 26, 88, 2, 6, ROW_NAT, COL_NAT88, 32, 88), ("DM2", 28, 32, 1, 2, ROW_NAT, COL_NAT, 16, 32),
+    ("DM4", 30, 16, 1, 1, ROW_NAT, COL_NAT, 1, 16), ("RW0", 32, 83, 1, 6, ROW_NAT, COL_RW0, 16, 83),
+    ("RW2", 34, 16, 1, 1, ROW_NAT, COL_NAT, 8, 16), ("RW4", 36, 8, 1, 1, ROW_NAT, COL_NAT, 1, 8),
+]
+
+
+def nat88(t, g, r):
+    return 16 * t + 4 * g + r if t < 5 else (80 + 2 * g + r if r < 2 else -1)
+
+
+def row_map(rm, t, i, out_dim):
+    g, r = i >> 2, i & 3
+    v = {ROW_NAT: 16 * t + i, ROW_SLOT20: 20 * g + 4 * t + r, ROW_HEAD11: 11 * t + i if i < 11 else -1,
+         ROW_NAT88: nat88(t, g, r)}[rm]
+    return v if 0 <= v < out_dim else -1
+
+
+def col_map(cm, t, g, r, in_dim):
+    if cm == COL_NAT:
+        v = 16 * t + 4 * g + r
+    elif cm == COL_SLOT20:
+        v = 20 * g + 4 * t + r
+    elif cm == COL_NAT88:
+        v = nat88(t, g, r)
+    elif cm == COL_HEAD11:
+        v = 11 * t + 4 * g + r if 4 * g + r < 11 else -1
+    elif cm == COL_RW0:
+        v = 16 * t + 4 * g + r if t < 5 else (80 + g if (r == 0 and g < 3) else -1)
+    else:
+        v = nat88(t, g, r) if t < 6 else (-1 if nat88(t - 6, g, r) < 0 else 88 + nat88(t - 6, g, r))
+    return v if 0 <= v < in_dim else -1
+
+
+def in_steps(cm, t):
+    if cm == COL_NAT88 and t == 5:
+        return 2
+    if cm == COL_CAT88 and t in (5, 11):
+        return 2
+    if cm == COL_RW0 and t == 5:
+        return 1
+    return 4
+
+
+def mfma16(a, b, acc):
+    """a, b: (64,) lane operands; acc: (64,4) accumulator registers (updated copy returned)."""
+    A = np.zeros((16, 4), np.float64)
+    B = np.zeros((4, 16), np.float64)
+    A[J, G] = a
+    B[G, J] = b
+    D = A @ B
+    out = acc.copy()
+    for r in range(4):
+        out[:, r] += D[4 * G + r, J]
+    return out
+
+
+def mat_offset(idx):
+    return sum(m[3] * m[4] * 256 for m in MATS[:idx])
+
+
+def gemm(blob, idx, tiles_in, swap=False):
+    """Chained GEMM of matrix `idx`: tiles_in (n_in,64,4) registers -> (n_out,64,4) accumulators."""
+    _, _, _, n_out, n_in, _, cm, _, _ = MATS[idx]
+    frag = blob[mat_offset(idx): mat_offset(idx) + n_out * n_in * 256].reshape(n_out, n_in, 64, 4)
+    out = np.zeros((n_out, 64, 4), np.float64)
+    for to in range(n_out):
+        for ti in range(n_in):
+            for r in range(in_steps(cm, ti)):
+                a, b = frag[to, ti, :, r], tiles_in[ti][:, r]
+                out[to] = mfma16(b, a, out[to]) if swap else mfma16(a, b, out[to])
+    return out
+
+
+def to_tiles(x, cm, n_tiles, in_dim):
+    """x (16 tokens, in_dim) -> B-operand registers (n_tiles,64,4): lane (g,j) reg r <- x[j][col(t,g,r)]."""
+    t = np.zeros((n_tiles, 64, 4), np.float64)
+    for ti in range(n_tiles):
+        for lane in range(64):
+            for r in range(4):
+                c = col_map(cm, ti, lane >> 4, r, in_dim)
+                if c >= 0:
+                    t[ti, lane, r] = x[lane & 15, c]
+    return t
+
+
+def from_tiles(acc, rm, out_dim):
+    """accumulators (n_out,64,4) in standard orientation -> y (16 tokens, out_dim); padding rows must be 0."""
+    y = np.zeros((16, out_dim), np.float64)
+    pad_abs = 0.0
+    for to in range(acc.shape[0]):
+        for lane in range(64):
+            for r in range(4):
+                row = row_map(rm, to, 4 * (lane >> 4) + r, out_dim)
+                if row >= 0:
+                    y[lane & 15, row] = acc[to, lane, r]
+                else:
+                    pad_abs = max(pad_abs, abs(acc[to, lane, r]))
+    return y, pad_abs
+
+
+def from_tiles_swapped(acc, rm, out_dim):
+    """swapped orientation: lane (g,j) reg r = y[token 4g+r][row(to, j)]."""
+    y = np.zeros((16, out_dim), np.float64)
+    for to in range(acc.shape[0]):
+        for lane in range(64):
+            row = row_map(rm, to, lane & 15, out_dim)
+            if row >= 0:
+                for r in range(4):
+                    y[4 * (lane >> 4) + r, row] = acc[to, lane, r]
+    return y

@@ -1,0 +1,166 @@
+"""CPU-only checks of the C ABI surface and of the packed-weight layout (no compute on a GPU).
+
+* libufr.so loads and exports every symbol include/ufr.h declares;
+* argument validation returns error codes + messages instead of crashing;
+* the weight re-ordering plan exported by the library (ufr_pack_plan), pushed through a lane-level
+  model of v_mfma_f32_16x16x4_f32 (tests/mfma_emu.py), reproduces y = W x for every matrix -- i.e.
+  the "accumulator tile == next B operand" chaining and all row/column permutations are right.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import mfma_emu as E
+from uforecon_amd import _lib, ops
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        from uforecon_amd.build import build_library
+
+        build_library(verbose=False)
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "ufr.h")).read()
+    declared = set(re.findall(r"\b(ufr_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ufr_version() >= 100
+
+
+def test_struct_sizes_match_the_header(lib):
+    assert C.sizeof(_lib.RawWeights) == 40 * 8
+    assert C.sizeof(_lib.Frame) == 160 * 8
+    assert lib.ufr_packed_weights_bytes() == 4 * (sum(m[3] * m[4] * 256 for m in E.MATS) + 16 * (5 * 4 + 6 * 4 + 2 + 5 + 5))
+
+
+def test_argument_errors_are_reported_not_fatal(lib):
+    assert lib.ufr_sample_fixed(None, None, None, None, 4, 64, None) == -1
+    assert b"null" in lib.ufr_last_error()
+    d = _lib.FrameDesc()
+    d.NV = 9
+    assert lib.ufr_frame_workspace_bytes(C.byref(d)) == 0
+    assert b"NV=9" in lib.ufr_last_error()
+    assert lib.ufr_aggregate(None, None, None, None, 4, 60, 3, None, None, None, None, None, None) == -1
+    fr = _lib.Frame()  # never prepared -> magic missing
+    assert lib.ufr_project_gather(C.byref(fr), None, None, 0, None, None, 1, 16, None, None, None, None, None, None,
+                                  None, None) == -1
+    assert b"not prepared" in lib.ufr_last_error()
+
+
+def test_missing_gpu_is_loud():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(ops.UfrError, match="no CPU implementation"):
+        ops.sample_fixed(torch.zeros(4), torch.ones(4), torch.rand(64, 4))
+
+
+@pytest.fixture(scope="module")
+def plan(lib):
+    n = lib.ufr_packed_weights_bytes() // 4
+    pid = np.zeros(n, np.int32)
+    el = np.zeros(n, np.int32)
+    assert lib.ufr_pack_plan(pid.ctypes.data_as(C.POINTER(C.c_int32)), el.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+    return pid, el
+
+
+def _blob(plan, raw):
+    pid, el = plan
+    blob = np.zeros(pid.shape[0], np.float64)
+    for p in np.unique(pid):
+        if p < 0:
+            continue
+        sel = pid == p
+        blob[sel] = raw[p].reshape(-1)[el[sel]]
+    return blob
+
+
+@pytest.fixture(scope="module")
+def raw_and_blob(plan):
+    rng = np.random.default_rng(0)
+    raw = {i: rng.standard_normal(int(np.prod(s)) if s else 1) for i, s in enumerate(ops.RAW_WEIGHT_SHAPES)}
+    return raw, _blob(plan, raw)
+
+
+@pytest.mark.parametrize("idx", range(len(E.MATS)))
+def test_chained_mfma_gemm_reproduces_linear(idx, raw_and_blob):
+    raw, blob = raw_and_blob
+    name, param, k_raw, n_out, n_in, rm, cm, out_dim, in_dim = E.MATS[idx]
+    W = raw[param].reshape(out_dim, k_raw)
+    rng = np.random.default_rng(100 + idx)
+    x = rng.standard_normal((16, in_dim))
+    acc = E.gemm(blob, idx, E.to_tiles(x, cm, n_in, in_dim))
+    y, pad = E.from_tiles(acc, rm, out_dim)
+    np.testing.assert_allclose(y, x @ W[:, :in_dim].T, rtol=1e-12, atol=1e-12, err_msg=name)
+    assert pad == 0.0
+    if name in ("RT_K", "RT_V"):  # operands swapped: result tile is [token][head dim]
+        acc = E.gemm(blob, idx, E.to_tiles(x, cm, n_in, in_dim), swap=True)
+        np.testing.assert_allclose(E.from_tiles_swapped(acc, rm, out_dim), x @ W.T, rtol=1e-12, atol=1e-12)
+
+
+def test_vector_fragments(plan, raw_and_blob):
+    raw, blob = raw_and_blob
+    off = sum(m[3] * m[4] * 256 for m in E.MATS)
+    vecs = [(12, 5, E.ROW_NAT, 80), (13, 5, E.ROW_NAT, 80), (14, 5, E.ROW_NAT, 80), (15, 5, E.ROW_NAT, 80),
+            (22, 6, E.ROW_NAT88, 88), (23, 6, E.ROW_NAT88, 88), (24, 6, E.ROW_NAT88, 88), (25, 6, E.ROW_NAT88, 88),
+            (27, 2, E.ROW_NAT, 32), (29, 1, E.ROW_NAT, 16), (31, 1, E.ROW_NAT, 1), (33, 1, E.ROW_NAT, 16),
+            (35, 1, E.ROW_NAT, 8), (37, 1, E.ROW_NAT, 1), (38, 5, E.ROW_NAT, 80)]
+    for param, nt, rm, dim in vecs:
+        frag = blob[off: off + nt * 16].reshape(nt, 4, 4)
+        for t in range(nt):
+            for g in range(4):
+                for r in range(4):
+                    row = E.row_map(rm, t, 4 * g + r, dim)
+                    assert frag[t, g, r] == (raw[param][row] if row >= 0 else 0.0)
+        off += nt * 16
+    assert off == blob.shape[0]
+
+
+def test_ray_attention_dataflow_in_mfma_form(raw_and_blob):
+    """KV = K'^T V and message = (Q' KV) / (Q'.sum K') computed exactly as ray_transformer.hip does
+    (swapped projections, ones column, row-11 normaliser) equal the textbook linear attention."""
+    raw, blob = raw_and_blob
+    rng = np.random.default_rng(7)
+    SN = 32
+    X = rng.standard_normal((SN, 88))
+    Wq, Wk, Wv = (raw[p].reshape(88, 88) for p in (16, 17, 18))
+    elu1 = lambda a: np.where(a > 0, a + 1, np.exp(a))
+    iq, ik, iv = (next(i for i, m in enumerate(E.MATS) if m[0] == n) for n in ("RT_Q", "RT_K", "RT_V"))
+    KV = np.zeros((8, 64, 4))
+    for tile in range(SN // 16):
+        xin = E.to_tiles(X[16 * tile: 16 * tile + 16], E.COL_NAT88, 6, 88)
+        kt, vt = E.gemm(blob, ik, xin, swap=True), E.gemm(blob, iv, xin, swap=True)
+        for h in range(8):
+            for r in range(4):
+                kk = np.where(E.J < 11, elu1(kt[h][:, r]), 0.0)
+                vv = np.where(E.J < 11, vt[h][:, r] / SN, np.where(E.J == 11, 1.0, 0.0))
+                KV[h] = E.mfma16(kk, vv, KV[h])
+    Q = elu1(X @ Wq.T).reshape(SN, 8, 11)
+    K = elu1(X @ Wk.T).reshape(SN, 8, 11)
+    V = (X @ Wv.T).reshape(SN, 8, 11) / SN
+    ref = np.einsum("lhd,hdv->lhv", Q, np.einsum("shd,shv->hdv", K, V)) / (np.einsum("lhd,hd->lh", Q, K.sum(0))[..., None] + 1e-6) * SN
+    for tile in range(SN // 16):
+        q = E.gemm(blob, iq, E.to_tiles(X[16 * tile: 16 * tile + 16], E.COL_NAT88, 6, 88))
+        for h in range(8):
+            acc = np.zeros((64, 4))
+            for r in range(4):
+                qq = np.where(4 * E.G + r < 11, elu1(q[h][:, r]), 0.0)
+                acc = E.mfma16(KV[h][:, r], qq, acc)
+            den = acc[32 + E.J, 3]
+            msg = acc * (1.0 / (den + 1e-6) * SN)[:, None]
+            for lane in range(64):
+                for r in range(4):
+                    v = 4 * (lane >> 4) + r
+                    if v < 11:
+                        assert abs(msg[lane, r] - ref[16 * tile + (lane & 15), h, v]) < 1e-9

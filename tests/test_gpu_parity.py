@@ -1,0 +1,166 @@
+"""GPU parity tests: every C-ABI entry point against the CPU oracle and the reference's golden
+vectors, on the same seeded inputs.  Tolerance for the rendered depth / RGB is the north-star
+1e-4 relative (REL_TOL); row-level intermediates get the tighter bounds written next to them.
+"""
+import pytest
+import torch
+
+from helpers import CASES, REL_TOL, border_degenerate_rays, case_inputs, load_weights, max_rel_elem, rel_err
+from oracle import ufo_oracle as O
+from uforecon_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def weights():
+    P = load_weights()
+    return ops.PackedWeights({k: v.to(DEV) for k, v in P.items()})
+
+
+def _oracle_rows(name):
+    fr, idx, U1, U2, g = case_inputs(name)
+    want = {}
+    with torch.no_grad():
+        O.infer(load_weights(), fr.batch, idx, fr.source_imgs_feat, fr.feature_volume, fr.match_feature, U1, U2,
+                want=want, coarse_only=CASES[name].get("coarse_only", False))
+    return fr, idx, U1, U2, g, want
+
+
+def _frame_handle(fr):
+    f = fr.to(DEV)
+    return ops.FrameHandle(f.batch, f.source_imgs_feat, f.feature_volume, f.match_feature)
+
+
+def _ray_setup(fr, idx):
+    i = idx.reshape(-1)
+    ray_d = fr.batch["ray_d"][0][:, i].t().contiguous()
+    cz = fr.batch["cam_ray_d"][0][2, i]
+    near = fr.batch["near_fars"][0, 0, 0] / cz
+    far = fr.batch["near_fars"][0, 0, 1] / cz
+    return fr.batch["ray_o"][0].contiguous(), ray_d, near.contiguous(), far.contiguous()
+
+
+def test_fixed_sampler_bit_exact():
+    fr, idx, U1, U2, g, want = _oracle_rows("rows_small")
+    ray_o, ray_d, near, far = _ray_setup(fr, idx)
+    z = ops.sample_fixed(near.to(DEV), far.to(DEV), U1.to(DEV))
+    assert torch.equal(z.cpu(), want["coarse"]["z"])
+    assert torch.equal(z.cpu(), torch.from_numpy(g["coarse.z"]))
+    pts = ops.points(ray_o.to(DEV), ray_d.to(DEV), z)
+    assert torch.equal(pts.cpu(), want["coarse"]["pts"])
+
+
+@pytest.mark.parametrize("name", ["rows_small", "c2_hier_small", "c4_nv5_128"])
+def test_importance_sampler_and_merge(name):
+    fr, idx, U1, U2, g, want = _oracle_rows(name)
+    c = want["coarse"]
+    z_fine, z_all = ops.sample_importance_merge(c["weight"].to(DEV).contiguous(), c["z"].to(DEV).contiguous(), U2.to(DEV))
+    # same inputs -> positions agree to float rounding of the CDF (the reference's own cumsum is double)
+    assert rel_err(z_fine, want["fine"]["z_fine"]) < 5e-6
+    assert rel_err(z_all, want["fine"]["z"]) < 5e-6
+    assert bool((z_all[:, 1:] >= z_all[:, :-1]).all())
+
+
+@pytest.mark.parametrize("tag", ["coarse", "fine"])
+def test_compositor(tag, weights):
+    fr, idx, U1, U2, g, want = _oracle_rows("rows_small")
+    w = want[tag]
+    RN, SN = w["z"].shape
+    rgb, depth, opacity, weight = ops.composite(w["z"].to(DEV).contiguous(), w["radiance"].reshape(RN, SN, 3).to(DEV).contiguous(),
+                                                w["srdf"].to(DEV).contiguous(), weights.variance)
+    # inputs are the oracle's rows computed on THIS host, so compare with its outputs (the golden fine
+    # pass was sampled on the build host, whose torch CPU kernels round the CDF differently)
+    assert rel_err(weight, w["weight"]) < 5e-6
+    assert rel_err(depth, w["depth"]) < 5e-6
+    assert rel_err(rgb, w["rgb"]) < 5e-6
+    if tag == "coarse":
+        assert rel_err(weight, g["coarse.weight"]) < 5e-6
+        assert rel_err(opacity, g["coarse.opacity"]) < 5e-6
+
+
+@pytest.mark.parametrize("name,tag", [("rows_small", "coarse"), ("rows_small", "fine"), ("c4_nv5_128", "coarse")])
+def test_project_gather_rows(name, tag, weights):
+    fr, idx, U1, U2, g, want = _oracle_rows(name)
+    w = want[tag]
+    fh = _frame_handle(fr)
+    ray_o, ray_d, _, _ = _ray_setup(fr, idx)
+    x, rgbm, dirs, dbg = ops.project_gather(fh, weights, ray_o.to(DEV), ray_d.to(DEV), w["z"].to(DEV).contiguous(), debug=True)
+    RN, SN = w["z"].shape
+    NV = fh.NV
+    assert rel_err(dbg["xy"].reshape(NV, RN, SN, 2), w["xy"]) < 5e-6
+    assert torch.equal(dbg["mask_z"].reshape(NV, RN, SN).cpu(), w["mask_z"])
+    assert rel_err(dbg["sim8"].reshape(RN, SN, 8), w["sim8"]) < 1e-5
+    assert rel_err(dbg["vol24"].reshape(RN, SN, 24), w["vol24"]) < 1e-5
+    assert rel_err(x, w["x"]) < 1e-5                                   # (P,NV,80) token inputs
+    assert rel_err(rgbm[..., :3], w["rgb_s"]) < 1e-5
+    assert torch.equal(rgbm[..., 3].cpu(), w["mask"].permute(1, 2, 0).reshape(-1, NV))
+    assert rel_err(dirs[..., :3], w["dirs"].permute(1, 2, 0, 3).reshape(-1, NV, 3)) < 1e-5
+
+
+@pytest.mark.parametrize("name,tag", [("rows_small", "coarse"), ("rows_small", "fine"), ("c4_nv5_128", "fine")])
+def test_aggregate_rows(name, tag, weights):
+    """View transformer, ray transformer, SRDF and radiance heads from the ORACLE's token inputs."""
+    fr, idx, U1, U2, g, want = _oracle_rows(name)
+    w = want[tag]
+    RN, SN = w["z"].shape
+    NV = w["x"].shape[1]
+    x = w["x"].to(DEV).contiguous()
+    rgbm = torch.cat([w["rgb_s"], w["mask"].permute(1, 2, 0).reshape(-1, NV, 1)], -1).to(DEV).contiguous()
+    dirs = torch.cat([w["dirs"].permute(1, 2, 0, 3).reshape(-1, NV, 3), torch.zeros(RN * SN, NV, 1)], -1).to(DEV).contiguous()
+    radiance, srdf, dbg = ops.aggregate(weights, x, rgbm, dirs, RN, SN, debug=True)
+    assert rel_err(dbg["view_out"], w["view_out"]) < 2e-5
+    assert rel_err(dbg["ray_out"].reshape(RN, SN, 88), w["ray_out"]) < 2e-5
+    assert rel_err(srdf, w["srdf"]) < 5e-5
+    assert rel_err(radiance, w["radiance"]) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["c1_coarse_only", "c2_hier_small", "c4_nv5_128", "c2_hier_512x640"])
+def test_render_rays_matches_reference_golden(name, weights):
+    """Whole path through ufr_render_rays vs the reference's own outputs (tests/golden)."""
+    c = CASES[name]
+    fr, idx, U1, U2, g, want = _oracle_rows(name)
+    fh = _frame_handle(fr)
+    out = ops.render_rays(fh, weights, idx.to(DEV), U1.to(DEV), U2.to(DEV), coarse_only=c.get("coarse_only", False))
+    torch.cuda.synchronize()
+    depth_ref = torch.from_numpy(g["depth"])
+    rgb_ref = torch.from_numpy(g["rgb"])
+    # north-star bound: per-pixel depth within 1e-4 relative of the reference, every ray
+    assert max_rel_elem(out["depth"], depth_ref, floor=1e-3) < REL_TOL
+    cz = fr.batch["cam_ray_d"][0][2, idx.reshape(-1)]
+    assert rel_err(out["depth_z"], depth_ref * cz) < REL_TOL
+    # ... and RGB within 1e-4 on every ray whose samples do not sit ON an image border of a source
+    # view: there the reference's inclusive in-bounds mask (grid_sample.py:13-17) flips with the last
+    # ulp of the sample position (rows of the render view are aligned with source view 0), so the
+    # reference is discontinuous and no implementation can track it; such rays must stay rare.
+    degenerate = border_degenerate_rays(want["coarse" if c.get("coarse_only") else "fine"])
+    assert float(degenerate.float().mean()) < 0.15
+    ok = ~degenerate
+    assert max_rel_elem(out["rgb"][ok.to(DEV)], rgb_ref[ok], floor=0.05) < REL_TOL
+    assert rel_err(out["z_all"], (torch.from_numpy(g["points"]) - fr.batch["ray_o"][0]).norm(dim=-1)) < 1e-5
+    assert rel_err(out["srdf"], g["srdf"]) < 2e-3
+
+
+def test_render_rays_chunking_is_invisible(weights):
+    """Rays are independent: rendering in chunks of 64 equals one launch group, bit for bit."""
+    fr, idx, U1, U2, g = case_inputs("c2_hier_small")
+    fh = _frame_handle(fr)
+    a = ops.render_rays(fh, weights, idx.to(DEV), U1.to(DEV), U2.to(DEV))
+    ws = ops.RenderWorkspace(DEV, 64, 64, 3, chunk_rays=64)
+    b = ops.render_rays(fh, weights, idx.to(DEV), U1.to(DEV), U2.to(DEV), workspace=ws)
+    assert torch.equal(a["depth"], b["depth"]) and torch.equal(a["rgb"], b["rgb"])
+
+
+def test_edge_cases(weights):
+    fr, idx, U1, U2, g = case_inputs("c2_hier_small")
+    fh = _frame_handle(fr)
+    # a single ray, and a ray count that is not a multiple of any tile size
+    for n in (1, 37):
+        out = ops.render_rays(fh, weights, idx[:, :n].to(DEV).contiguous(), U1[:, :n].to(DEV).contiguous(),
+                              U2[:, :n].to(DEV).contiguous())
+        assert max_rel_elem(out["depth"], torch.from_numpy(g["depth"][:n]), floor=1e-3) < REL_TOL
+    with pytest.raises(ops.UfrError, match="multiple of 16"):
+        ops.render_rays(fh, weights, idx.to(DEV), U1[:60].to(DEV).contiguous(), U2.to(DEV))
+    with pytest.raises(ops.UfrError, match="GPU"):
+        ops.sample_fixed(torch.zeros(4), torch.ones(4), torch.rand(64, 4))

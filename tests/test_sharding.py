@@ -1,0 +1,57 @@
+"""Ray sharding + tile all-gather, covered on CPU with 2 gloo processes (the N>1 path of bench.py)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from uforecon_amd.dist import RayShard, all_gather_tiles
+
+
+@pytest.mark.parametrize("H,W,world", [(512, 640, 8), (63, 10, 4), (5, 3, 2), (7, 3, 8)])
+def test_row_tiles_partition_the_frame(H, W, world):
+    seen = torch.zeros(H * W, dtype=torch.int32)
+    for r in range(world):
+        s = RayShard(H, W, world, r)
+        idx = s.ray_indices("cpu")
+        assert idx.numel() == s.n_rays <= s.max_rays
+        if idx.numel():
+            assert int(idx[0]) % W == 0 and bool((idx[1:] - idx[:-1] == 1).all())  # whole rows, contiguous
+        seen[idx] += 1
+    assert bool((seen == 1).all())
+
+
+def _worker(rank, world, port, H, W, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shard = RayShard(H, W, world, rank)
+        idx = shard.ray_indices("cpu")
+        depth = idx.float() * 0.5            # a function of the global ray index
+        rgb = torch.stack([idx.float(), idx.float() + 1, idx.float() + 2], 1)
+        d, c = all_gather_tiles(depth, rgb, shard)
+        full = torch.arange(H * W).float()
+        ok = torch.equal(d.reshape(-1), full * 0.5) and torch.equal(c.reshape(-1, 3)[:, 2], full + 2)
+        q.put((rank, bool(ok), tuple(d.shape), tuple(c.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("H,W", [(8, 6), (7, 5)])
+def test_all_gather_tiles_world2_gloo(H, W):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, H, W, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, ds, cs in res:
+        assert ok and ds == (H, W) and cs == (H, W, 3)

@@ -1,0 +1,112 @@
+// SDF-to-alpha compositor: VolumeRenderer.render (code1/encoder_utils/renderer.py:7-48) with
+// SingleVarianceNetwork (single_variance_network.py:10-11).  One wavefront per ray: each lane owns
+// K = ceil(SN/64) consecutive samples, the transmittance is an exclusive product scan across the
+// 64 lanes (DPP/shuffle Hillis-Steele) and the three weighted sums are wave reductions.
+#include "ufr_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace ufr {
+
+constexpr int kMaxK = 4;  // SN <= 256
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+__global__ void __launch_bounds__(256) composite_kernel(const float* __restrict__ z, const float* __restrict__ radiance,
+                                                         const float* __restrict__ srdf,
+                                                         const float* __restrict__ variance, int RN, int SN,
+                                                         float* __restrict__ rgb, float* __restrict__ depth,
+                                                         float* __restrict__ opacity, float* __restrict__ weight,
+                                                         const float* __restrict__ camz, float* __restrict__ depth_z) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + wave;
+  if (ray >= RN) return;
+  const float* zr = z + (size_t)ray * SN;
+  const float* sr = srdf + (size_t)ray * SN;
+  const float inv_s = fminf(fmaxf(expf(variance[0] * 10.0f), 1e-6f), 1e6f);  // renderer.py:25
+  const int K = (SN + 63) / 64;
+
+  float alpha[kMaxK], zz[kMaxK];
+  float prod = 1.f;  // product of (1 - alpha + 1e-7) over this lane's samples
+#pragma unroll
+  for (int k = 0; k < kMaxK; ++k) {
+    alpha[k] = 0.f;
+    zz[k] = 0.f;
+    int i = lane * K + k;
+    if (k < K && i < SN) {
+      float zc = zr[i];
+      // interval: mean of the two adjacent gaps with edge replication (renderer.py:19-21)
+      float gl = (i == 0) ? zr[1] - zr[0] : zc - zr[i - 1];
+      float gr = (i == SN - 1) ? zr[SN - 1] - zr[SN - 2] : zr[i + 1] - zc;
+      float interval = (gl + gr) / 2.f;
+      float s = sr[i];
+      const float iter_cos = -1.5f;                       // renderer.py:28-29 with cos_anneal_ratio = 1
+      float nxt = s + iter_cos * interval * 0.5f;         // :31
+      float prv = s - iter_cos * interval * 0.5f;         // :32
+      float pc = sigmoidf(prv * inv_s), nc = sigmoidf(nxt * inv_s);
+      float a = ((pc - nc) + 1e-5f) / (pc + 1e-5f);       // :37-40
+      a = fminf(fmaxf(a, 0.f), 1.f);
+      alpha[k] = a;
+      zz[k] = zc;
+      prod *= (1.f - a) + 1e-7f;
+    }
+  }
+  // exclusive product scan over lanes
+  float incl = prod;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    float o = __shfl_up(incl, d);
+    if (lane >= d) incl *= o;
+  }
+  float T = __shfl_up(incl, 1);
+  if (lane == 0) T = 1.f;
+
+  float acc_d = 0.f, acc_o = 0.f, acc_r = 0.f, acc_g = 0.f, acc_b = 0.f;
+#pragma unroll
+  for (int k = 0; k < kMaxK; ++k) {
+    int i = lane * K + k;
+    if (k < K && i < SN) {
+      float w = alpha[k] * T;                             // :42
+      T *= (1.f - alpha[k]) + 1e-7f;
+      if (weight) weight[(size_t)ray * SN + i] = w;
+      const float* c = radiance + ((size_t)ray * SN + i) * 3;
+      acc_r += c[0] * w;
+      acc_g += c[1] * w;
+      acc_b += c[2] * w;
+      acc_d += w * zz[k];
+      acc_o += w;
+    }
+  }
+  acc_d = wave_sum(acc_d);
+  acc_o = wave_sum(acc_o);
+  acc_r = wave_sum(acc_r);
+  acc_g = wave_sum(acc_g);
+  acc_b = wave_sum(acc_b);
+  if (lane == 0) {
+    depth[ray] = acc_d;
+    if (opacity) opacity[ray] = acc_o;
+    if (rgb) {
+      rgb[3 * ray + 0] = acc_r;
+      rgb[3 * ray + 1] = acc_g;
+      rgb[3 * ray + 2] = acc_b;
+    }
+    if (depth_z) depth_z[ray] = acc_d * camz[ray];        // model.py:821
+  }
+}
+
+hipError_t launch_composite(const float* z, const float* radiance, const float* srdf, const float* variance, int RN,
+                            int SN, float* rgb, float* depth, float* opacity, float* weight, const float* camz,
+                            float* depth_z, hipStream_t s) {
+  if (SN > 64 * kMaxK || SN < 2) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(composite_kernel, dim3((RN + 3) / 4), dim3(256), 0, s, z, radiance, srdf, variance, RN, SN, rgb,
+                     depth, opacity, weight, camz, depth_z);
+  return hipGetLastError();
+}
+
+}  // namespace ufr

@@ -1,0 +1,269 @@
+// Projection + every gather of one rendering pass, producing the view-transformer token inputs.
+//   camera.get_coord_ref_ndc          code1/misc/camera.py:378-407      (projection, z>0 mask, frustum z)
+//   UFORecon.query_cond_info          code1/model.py:218-305            (pairwise cosine similarity, AC=True/border)
+//   UFORecon.query_depth_from_volume  code1/model.py:350-390            (3 correlation frustums, AC=True/zeros, 3-D)
+//   RayTransformer.forward            code1/ray_transformer.py:185-281  (dir, 2-D gathers AC=False/zeros, depth PE,
+//                                                                        pre_sim_mlp, token assembly)
+// Thread (v, p): view v of point p; a block is 64 consecutive points (samples of one ray) x NV
+// views, i.e. wave v = view v.  All maps are channel-last (prep.hip) so every tap is a run of
+// 16-byte loads from one line.  Cross-view reductions (pair similarities, frustum blending) go
+// through LDS in the reference's summation order.
+#include "ufr_device.h"
+#include "ufr_internal.h"
+
+namespace ufr {
+
+// out = fma(v_se,se, fma(v_sw,sw, fma(v_ne,ne, v_nw*nw))) per channel; masked corners read as zero
+__device__ __forceinline__ f32x4 lerp_tap4(const float* __restrict__ base, int stride, const Tap2& t, int c) {
+  f32x4 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = t.o[k] >= 0 ? ld4(base + (size_t)t.o[k] * stride + c) : splat4(0.f);
+  f32x4 acc;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float a = mul_rn(v[0][e], t.w[0]);
+    a = fmaf(v[1][e], t.w[1], a);
+    a = fmaf(v[2][e], t.w[2], a);
+    acc[e] = fmaf(v[3][e], t.w[3], a);
+  }
+  return acc;
+}
+
+// trilinear sample of one channel-last volume (12 floats per texel), zeros padding, align_corners=True
+__device__ __forceinline__ void sample_volume(const float* __restrict__ vol, int D, int H, int W, float x, float y,
+                                              float zn, float (&f)[8], float& wgt) {
+  float ix = unnorm3d_ac(x, W), iy = unnorm3d_ac(y, H), iz = unnorm3d_ac(zn, D);
+  float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+  float wx[2] = {(fx + 1.f) - ix, ix - fx}, wy[2] = {(fy + 1.f) - iy, iy - fy}, wz[2] = {(fz + 1.f) - iz, iz - fz};
+  f32x4 a0 = splat4(0.f), a1 = splat4(0.f);
+  float aw = 0.f;
+  // torch accumulates the corners in the order tnw,tne,tsw,tse,bnw,bne,bsw,bse (x fastest)
+#pragma unroll
+  for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        float cx = fx + dx, cy = fy + dy, cz = fz + dz;
+        bool ok = cx >= 0.f && cx <= (float)(W - 1) && cy >= 0.f && cy <= (float)(H - 1) && cz >= 0.f &&
+                  cz <= (float)(D - 1);
+        if (ok) {
+          const float wt = mul_rn(mul_rn(wx[dx], wy[dy]), wz[dz]);
+          const float* t = vol + (((size_t)(int)cz * H + (int)cy) * W + (int)cx) * kVolCh;
+          const f32x4 v0 = ld4(t), v1 = ld4(t + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a0[e] = mul_add_unfused(v0[e], wt, a0[e]);
+            a1[e] = mul_add_unfused(v1[e], wt, a1[e]);
+          }
+          aw = mul_add_unfused(t[8], wt, aw);
+        }
+      }
+  f[0] = a0[0]; f[1] = a0[1]; f[2] = a0[2]; f[3] = a0[3];
+  f[4] = a1[0]; f[5] = a1[1]; f[6] = a1[2]; f[7] = a1[3];
+  wgt = aw;
+}
+
+// LDS layout (floats): xy[NV][64][2] | sim[64][NPAIR][8] | volp[64][NV][25] | outv[64][40]
+__global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, const float* __restrict__ ray_o,
+                                                      int o_stride, const float* __restrict__ ray_d,
+                                                      const float* __restrict__ zval, int P, int SN,
+                                                      float* __restrict__ x_tokens, float* __restrict__ rgb_out,
+                                                      float* __restrict__ dir_out, float* __restrict__ sim8_out,
+                                                      float* __restrict__ vol24_out, float* __restrict__ xy_out,
+                                                      float* __restrict__ maskz_out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int NV = f.NV;
+  const int npair = NV * (NV - 1) / 2;
+  float* sh_xy = smem;                         // NV*64*2
+  float* sh_sim = sh_xy + NV * 128;            // 64*npair*8
+  float* sh_vol = sh_sim + 64 * npair * 8;     // 64*NV*25
+  float* sh_out = sh_vol + 64 * NV * 25;       // 64*40
+
+  const int v = threadIdx.x >> 6, p = threadIdx.x & 63;
+  const int pidx = blockIdx.x * 64 + p;
+  const bool active = pidx < P;
+  const int pc = active ? pidx : P - 1;
+  const int ray = pc / SN;
+
+  // ---- sample position (sampler.py:47: o + z*d, unfused like torch's mul then add)
+  const float zz = zval[pc];
+  const float* o = ray_o + (size_t)ray * o_stride;
+  const float px = mul_add_unfused(zz, ray_d[3 * ray + 0], o[0]);
+  const float py = mul_add_unfused(zz, ray_d[3 * ray + 1], o[1]);
+  const float pz = mul_add_unfused(zz, ray_d[3 * ray + 2], o[2]);
+
+  // ---- projection into view v (camera.py:384-393); k-ordered fma chain = what torch.bmm (MKL sgemm)
+  // produces for a 4x4 pose, bit for bit
+  const float* M = f.pose[v];
+  float qx = fmaf(M[2], pz, fmaf(M[1], py, mul_rn(M[0], px))) + M[3];
+  float qy = fmaf(M[6], pz, fmaf(M[5], py, mul_rn(M[4], px))) + M[7];
+  float qz = fmaf(M[10], pz, fmaf(M[9], py, mul_rn(M[8], px))) + M[11];
+  const float mask_z = qz > 0.f ? 1.f : 0.f;
+  const float x = qx / qz, y = qy / qz;
+  sh_xy[(v * 64 + p) * 2 + 0] = x;
+  sh_xy[(v * 64 + p) * 2 + 1] = y;
+  if (active && xy_out) {
+    xy_out[((size_t)v * P + pidx) * 2 + 0] = x;
+    xy_out[((size_t)v * P + pidx) * 2 + 1] = y;
+  }
+  if (active && maskz_out) maskz_out[(size_t)v * P + pidx] = mask_z;
+
+  float* xrow = x_tokens + ((size_t)pc * NV + v) * UFR_TOKEN_DIM;
+
+  // ---- 2-D gathers with align_corners=False, zeros (grid_sample.py:5-19; ray_transformer.py:222-237)
+  {
+    Tap2 t = taps_zeros(unnorm2d_nac(x, f.w), unnorm2d_nac(y, f.h), f.w, f.h);
+    const float* base = f.feat + (size_t)v * f.h * f.w * 32;
+    if (active) {
+#pragma unroll
+      for (int c = 0; c < 32; c += 4) st4(xrow + c, lerp_tap4(base, 32, t, c));
+    }
+    Tap2 tf = taps_zeros(unnorm2d_nac(x, f.W), unnorm2d_nac(y, f.H), f.W, f.H);
+    f32x4 c4 = lerp_tap4(f.rgb + (size_t)v * f.H * f.W * 4, 4, tf, 0);
+    const float inb = (x <= 1.f && x >= -1.f && y <= 1.f && y >= -1.f) ? 1.f : 0.f;  // inclusive mask
+    c4[3] = inb * mask_z;                                                             // ray_transformer.py:251-252
+    if (active) st4(rgb_out + ((size_t)pidx * NV + v) * 4, c4);
+    // MVS depth guide + positional encoding (ray_transformer.py:229-247, 29-73)
+    const float* dmap = f.depth + (size_t)v * f.H * f.W;
+    float dv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dv[k] = tf.o[k] >= 0 ? dmap[tf.o[k]] : 0.f;
+    const float dm = fmaf(dv[3], tf.w[3], fmaf(dv[2], tf.w[2], fmaf(dv[1], tf.w[1], mul_rn(dv[0], tf.w[0]))));
+    const float* R = f.w2c_z[v];
+    float zc = fmaf(R[2], pz, fmaf(R[1], py, mul_rn(R[0], px))) + R[3];
+    float delta = dm - zc;
+    float pe[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float fr = 3.14159274101257324f * (float)(1 << k);  // float32(pi) * 2^k
+      pe[2 * k] = sinf(mul_rn(delta, fr));                       // torch.addcmul is a single fma
+      pe[2 * k + 1] = sinf(fmaf(delta, fr, 1.57079637050628662f));  // phase pi/2 -> cosine slot
+    }
+    if (active) {
+      st4(xrow + 72, f32x4{pe[0], pe[1], pe[2], pe[3]});
+      st4(xrow + 76, f32x4{pe[4], pe[5], pe[6], pe[7]});
+    }
+    // relative direction (ray_transformer.py:185-191)
+    float ax = px - f.ref_pos[0], ay = py - f.ref_pos[1], az = pz - f.ref_pos[2];
+    float bx = px - f.cam_pos[v][0], by = py - f.cam_pos[v][1], bz = pz - f.cam_pos[v][2];
+    float na = sqrtf(ax * ax + ay * ay + az * az), nb = sqrtf(bx * bx + by * by + bz * bz);
+    if (active) st4(dir_out + ((size_t)pidx * NV + v) * 4, f32x4{ax / na - bx / nb, ay / na - by / nb, az / na - bz / nb, 0.f});
+  }
+
+  // ---- correlation frustums of view v (model.py:359-386)
+  {
+    const float zn = ((qz - f.vol_near) / (f.vol_far - f.vol_near)) * 2.f - 1.f;  // camera.py:400-401
+    float fl[24], wl = 0.f;
+#pragma unroll
+    for (int s = 0; s < UFR_NUM_STAGES; ++s) {
+      float fs[8], ws;
+      const float* vol = f.vol[s] + (size_t)v * f.vD[s] * f.vH[s] * f.vW[s] * kVolCh;
+      sample_volume(vol, f.vD[s], f.vH[s], f.vW[s], x, y, zn, fs, ws);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) fl[8 * s + c] = fs[c];
+      wl = s == 0 ? ws : wl + ws;                                                 // :375-378
+    }
+    float* dst = sh_vol + (p * NV + v) * 25;
+#pragma unroll
+    for (int c = 0; c < 24; ++c) dst[c] = fl[c] * wl;                             // features_L * weights_L
+    dst[24] = wl;
+  }
+  __syncthreads();
+
+  // ---- pairwise similarity (model.py:271-283): pair q = (a, b), sides (view a, chunk b) / (view b+1, chunk a)
+  for (int q = v; q < npair; q += NV) {
+    int a = 0, rem = q;
+    while (rem >= NV - 1 - a) { rem -= NV - 1 - a; ++a; }
+    const int b = a + rem;
+    const int va = a, ca = b, vb = b + 1, cb = a;
+    Tap2 ta = taps_border(unnorm2d_ac(sh_xy[(va * 64 + p) * 2], f.w), unnorm2d_ac(sh_xy[(va * 64 + p) * 2 + 1], f.h), f.w, f.h);
+    Tap2 tb = taps_border(unnorm2d_ac(sh_xy[(vb * 64 + p) * 2], f.w), unnorm2d_ac(sh_xy[(vb * 64 + p) * 2 + 1], f.h), f.w, f.h);
+    const float* ba = f.match + (size_t)va * f.h * f.w * f.match_ch + 32 * ca;
+    const float* bb = f.match + (size_t)vb * f.h * f.w * f.match_ch + 32 * cb;
+    float* dst = sh_sim + (p * npair + q) * 8;
+#pragma unroll
+    for (int gi = 0; gi < 8; ++gi) {  // 8 groups of 4 channels (model.py:278-280)
+      f32x4 fa = lerp_tap4(ba, f.match_ch, ta, 4 * gi);
+      f32x4 fb = lerp_tap4(bb, f.match_ch, tb, 4 * gi);
+      float na = fmaxf(sqrtf(fa[0] * fa[0] + fa[1] * fa[1] + fa[2] * fa[2] + fa[3] * fa[3]), 1e-8f);
+      float nb = fmaxf(sqrtf(fb[0] * fb[0] + fb[1] * fb[1] + fb[2] * fb[2] + fb[3] * fb[3]), 1e-8f);
+      dst[gi] = (fa[0] / na) * (fb[0] / nb) + (fa[1] / na) * (fb[1] / nb) + (fa[2] / na) * (fb[2] / nb) +
+                (fa[3] / na) * (fb[3] / nb);
+    }
+  }
+  __syncthreads();
+
+  // ---- per-point reductions by wave 0: mean similarity, frustum blend, pre_sim_mlp
+  if (v == 0) {
+    float sim[8];
+#pragma unroll
+    for (int gi = 0; gi < 8; ++gi) {
+      float s = 0.f;
+      for (int q = 0; q < npair; ++q) s += sh_sim[(p * npair + q) * 8 + gi];
+      sim[gi] = s / (float)npair;                                                 // torch.mean over pairs
+    }
+    float* ov = sh_out + p * 40;
+    {
+      float Wsum = 0.f;
+      for (int n = 0; n < NV; ++n) Wsum = n == 0 ? sh_vol[(p * NV + n) * 25 + 24] : Wsum + sh_vol[(p * NV + n) * 25 + 24];
+      for (int c = 0; c < 24; ++c) {
+        float G = 0.f;
+        for (int n = 0; n < NV; ++n) G = n == 0 ? sh_vol[(p * NV + n) * 25 + c] : G + sh_vol[(p * NV + n) * 25 + c];
+        ov[c] = G / (Wsum + 1e-8f);                                               // model.py:388
+      }
+    }
+    // pre_sim_mlp: Linear(8,32)-ReLU-Linear(32,32)-ReLU-Linear(32,16) (ray_transformer.py:128-132, 268);
+    // weight addresses are wave-uniform -> scalar loads
+    float h1[32], h2[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      float acc = ps.b0[j];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc = fmaf(ps.w0[j * 8 + k], sim[k], acc);
+      h1[j] = fmaxf(acc, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      float acc = ps.b2[j];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) acc = fmaf(ps.w2[j * 32 + k], h1[k], acc);
+      h2[j] = fmaxf(acc, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float acc = ps.b4[j];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) acc = fmaf(ps.w4[j * 32 + k], h2[k], acc);
+      ov[24 + j] = acc;
+    }
+    if (active && sim8_out) {
+#pragma unroll
+      for (int gi = 0; gi < 8; ++gi) sim8_out[(size_t)pidx * 8 + gi] = sim[gi];
+    }
+    if (active && vol24_out) {
+      for (int c = 0; c < 24; ++c) vol24_out[(size_t)pidx * 24 + c] = ov[c];
+    }
+  }
+  __syncthreads();
+
+  // ---- token assembly: [feat 32 | vol 24 | sim 16 | depth PE 8] (ray_transformer.py:258-281)
+  if (active) {
+    const float* ov = sh_out + p * 40;
+#pragma unroll
+    for (int c = 0; c < 40; c += 4) st4(xrow + 32 + c, ld4(ov + c));
+  }
+}
+
+hipError_t launch_gather(const FrameDev& f, const PreSim& ps, const float* ray_o, int o_stride, const float* ray_d,
+                         const float* z, int RN, int SN, float* x_tokens, float* rgb, float* dir, float* sim8,
+                         float* vol24, float* xy, float* mask_z, hipStream_t s) {
+  const int P = RN * SN, NV = f.NV;
+  const int npair = NV * (NV - 1) / 2;
+  size_t lds = sizeof(float) * ((size_t)NV * 128 + 64 * npair * 8 + 64 * NV * 25 + 64 * 40);
+  hipLaunchKernelGGL(gather_kernel, dim3((P + 63) / 64), dim3(64 * NV), lds, s, f, ps, ray_o, o_stride, ray_d, z, P, SN,
+                     x_tokens, rgb, dir, sim8, vol24, xy, mask_z);
+  return hipGetLastError();
+}
+
+}  // namespace ufr

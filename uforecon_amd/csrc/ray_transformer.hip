@@ -1,0 +1,169 @@
+// Along-ray aggregation: order positional encoding, LoFTR linear-attention layer over the SN samples
+// of a ray (d = 88, 8 heads of 11), DensityMLP -> signed ray distance.
+//   RayTransformer.forward     code1/ray_transformer.py:296-307 (+ order_posenc :165-173)
+//   LoFTREncoderLayer.forward  code1/attention/transformer.py:35-58
+//   LinearAttention.forward    code1/attention/linear_attention.py:20-47
+//
+// One wavefront per ray, two sweeps over its SN/16 column tiles, everything in registers:
+//  sweep 1: K^T, V^T tiles ([token][head dim], obtained by swapping the MFMA operands), then
+//           KV_h += K'_h^T V_h as 4 MFMAs per head; a ones column appended to V makes
+//           column 11 of KV_h the K' sum needed for the normaliser.
+//  sweep 2: Q tiles, message_h = KV_h^T-chained MFMA with Q'_h (row 11 of the result is Q'.sum K'),
+//           merge, LayerNorm, MLP, LayerNorm, residual, DensityMLP.
+// Each head occupies its own 16-row tile (11 real rows) so that head boundaries coincide with MFMA
+// tiles; the 88-wide activations use the "nat88" layout of ufr_layout.h.
+#include "ufr_device.h"
+#include "ufr_internal.h"
+
+namespace ufr {
+
+// load the ray-transformer input tile: [token-0 feature (80) | order PE (8)] in nat88 layout
+__device__ __forceinline__ void load_ray_tile(const float* __restrict__ token0, const float* __restrict__ order_pe,
+                                              size_t tok_base, int s_base, int g, int j, f32x4 (&x)[1][6]) {
+  const float* row = token0 + (tok_base + j) * UFR_TOKEN_DIM;
+#pragma unroll
+  for (int t = 0; t < 5; ++t) x[0][t] = ld4(row + 16 * t + 4 * g);
+  const float* pe = order_pe + (size_t)(s_base + j) * 8 + 2 * g;  // features 80+2g, 81+2g in registers 0,1
+  x[0][5] = f32x4{pe[0], pe[1], 0.f, 0.f};
+}
+
+// LayerNorm over 88 features in nat88 layout (tile 5: registers 0,1 real)
+template <int VW, int VB>
+__device__ __forceinline__ void layer_norm88(f32x4 (&t)[1][6], const f32x4* __restrict__ w4, int g) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) s += (t[0][i][0] + t[0][i][1]) + (t[0][i][2] + t[0][i][3]);
+  s += t[0][5][0] + t[0][5][1];
+  const float mean = sum_groups(s) * (1.f / 88.f);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (i < 5 || r < 2) {
+        float d = t[0][i][r] - mean;
+        q = fmaf(d, d, q);
+      }
+    }
+  const float rstd = 1.f / sqrtf(sum_groups(q) * (1.f / 88.f) + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const f32x4 gw = vec_frag<VW>(w4, i, g), gb = vec_frag<VB>(w4, i, g);  // zero in the padding slots
+    t[0][i] = (t[0][i] - mean) * rstd * gw + gb;
+  }
+}
+
+__global__ void __launch_bounds__(256, 2) ray_transformer_kernel(const float* __restrict__ packed,
+                                                                  const float* __restrict__ token0,
+                                                                  const float* __restrict__ order_pe, int RN, int SN,
+                                                                  float* __restrict__ srdf,
+                                                                  float* __restrict__ ray_out) {
+  const f32x4* w4_base = reinterpret_cast<const f32x4*>(packed);
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+  const int ray = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (ray >= RN) return;
+  const int n_tiles = SN / 16;
+  const float inv_len = 1.f / (float)SN;  // exact for the power-of-two sample counts; SN is validated on the host
+
+  // ---------------- sweep 1: KV_h[d][v] = sum_s K'_h[s][d] * V_h[s][v] / SN   (linear_attention.py:41-42)
+  f32x4 KV[8];
+#pragma unroll
+  for (int h = 0; h < 8; ++h) KV[h] = splat4(0.f);
+  for (int tile = 0; tile < n_tiles; ++tile) {
+    const f32x4* w4 = launder(w4_base);  // weights are re-streamed per tile (no LICM hoist)
+    f32x4 x[1][6], kt[1][8], vt[1][8];
+    load_ray_tile(token0, order_pe, (size_t)ray * SN + tile * 16, tile * 16, g, j, x);
+#pragma unroll
+    for (int h = 0; h < 8; ++h) { kt[0][h] = splat4(0.f); vt[0][h] = splat4(0.f); }
+    gemm<M_RT_K, 1, 2, true>(w4, lane, x, kt);   // kt[h]: rows = tokens 4g+r, column j = head dim
+    gemm<M_RT_V, 1, 2, true>(w4, lane, x, vt);
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float kk = j < 11 ? elu1(kt[0][h][r]) : 0.f;                      // padded dims contribute nothing
+        const float vv = j < 11 ? vt[0][h][r] * inv_len : (j == 11 ? 1.f : 0.f);  // ones column -> sum of K'
+        KV[h] = mfma16(kk, vv, KV[h]);
+      }
+    }
+  }
+
+  // ---------------- sweep 2
+  for (int tile = 0; tile < n_tiles; ++tile) {
+    const f32x4* w4 = launder(w4_base);
+    f32x4 x[1][6], q[1][8], msg[1][8];
+    load_ray_tile(token0, order_pe, (size_t)ray * SN + tile * 16, tile * 16, g, j, x);
+#pragma unroll
+    for (int h = 0; h < 8; ++h) q[0][h] = splat4(0.f);
+    gemm<M_RT_Q, 1, 2>(w4, lane, x, q);          // q[h]: rows = head dims 4g+r, column j = token
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      f32x4 acc = splat4(0.f);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float qq = (4 * g + r < 11) ? elu1(q[0][h][r]) : 0.f;
+        acc = mfma16(KV[h][r], qq, acc);           // rows v = 4g+r: sum_d KV[d][v] Q'[d]; row 11 = Q'.sum(K')
+      }
+      const float den = __shfl(acc[3], 32 + j);    // row 11 lives in lane group 2, register 3
+      const float Z = 1.f / (den + 1e-6f);         // linear_attention.py:43
+      msg[0][h] = acc * (Z * (float)SN);           // :44  (rows >= 11 meet zero merge columns)
+    }
+    f32x4 m[1][6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) m[0][t] = splat4(0.f);
+    gemm<M_RT_MERGE, 1, 2>(w4, lane, msg, m);
+    layer_norm88<V_RT_N1W, V_RT_N1B>(m, w4, g);
+
+    f32x4 cat[1][12], hid[1][11], o[1][6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) { cat[0][t] = x[0][t]; cat[0][6 + t] = m[0][t]; }
+#pragma unroll
+    for (int t = 0; t < 11; ++t) hid[0][t] = splat4(0.f);
+    gemm<M_RT_MLP0, 1, 2>(w4, lane, cat, hid);
+#pragma unroll
+    for (int t = 0; t < 11; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hid[0][t][r] = fmaxf(hid[0][t][r], 0.f);
+#pragma unroll
+    for (int t = 0; t < 6; ++t) o[0][t] = splat4(0.f);
+    gemm<M_RT_MLP2, 1, 2>(w4, lane, hid, o);
+    layer_norm88<V_RT_N2W, V_RT_N2B>(o, w4, g);
+#pragma unroll
+    for (int t = 0; t < 6; ++t) o[0][t] += x[0][t];
+
+    if (ray_out) {
+      float* row = ray_out + ((size_t)ray * SN + tile * 16 + j) * UFR_RAY_DIM;
+#pragma unroll
+      for (int t = 0; t < 5; ++t) st4(row + 16 * t + 4 * g, o[0][t]);
+      row[80 + 2 * g] = o[0][5][0];
+      row[81 + 2 * g] = o[0][5][1];
+    }
+
+    // ---------------- DensityMLP 88 -> 32 -> 16 -> 1 (ray_transformer.py:147-150, 307)
+    f32x4 d1[1][2], d2[1][1], d3[1][1];
+    d1[0][0] = vec_frag<V_DM_B0>(w4, 0, g);
+    d1[0][1] = vec_frag<V_DM_B0>(w4, 1, g);
+    d2[0][0] = vec_frag<V_DM_B2>(w4, 0, g);
+    d3[0][0] = vec_frag<V_DM_B4>(w4, 0, g);
+    gemm<M_DM0, 1, 2>(w4, lane, o, d1);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d1[0][t][r] = fmaxf(d1[0][t][r], 0.f);
+    gemm<M_DM2, 1, 1>(w4, lane, d1, d2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d2[0][0][r] = fmaxf(d2[0][0][r], 0.f);
+    gemm<M_DM4, 1, 1>(w4, lane, d2, d3);
+    if (g == 0) srdf[(size_t)ray * SN + tile * 16 + j] = d3[0][0][0];
+  }
+}
+
+hipError_t launch_ray_transformer(const float* packed, const float* token0, const float* order_pe, int RN, int SN,
+                                  float* srdf, float* ray_out, hipStream_t s) {
+  if (SN % 16 != 0 || SN < 16) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ray_transformer_kernel, dim3((RN + 3) / 4), dim3(256), 0, s, packed, token0, order_pe, RN, SN,
+                     srdf, ray_out);
+  return hipGetLastError();
+}
+
+}  // namespace ufr

@@ -1,0 +1,430 @@
+// extern "C" surface of libufr.so (include/ufr.h): argument validation, workspace carving, kernel
+// sequencing on the caller's HIP stream.  No torch types, no host<->device synchronisation.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "ufr_internal.h"
+
+using namespace ufr;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define UFR_HIP(expr)                                                                    \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) return fail(UFR_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+#define UFR_REQUIRE(cond, ...) \
+  do {                         \
+    if (!(cond)) return fail(UFR_ERR_ARG, __VA_ARGS__); \
+  } while (0)
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct Carver {  // bump allocator over a caller workspace
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+  float* f32(size_t n) {
+    float* r = base ? reinterpret_cast<float*>(base + off) : nullptr;
+    off += align_up(n * sizeof(float));
+    return r;
+  }
+};
+
+// ---- optional per-kernel timing with HIP events on the caller's stream
+struct ProfEntry { const char* name; hipEvent_t a, b; };
+thread_local bool g_prof_on = false;
+thread_local std::vector<ProfEntry> g_prof;
+
+struct ProfScope {
+  hipStream_t s;
+  hipEvent_t a = nullptr, b = nullptr;
+  const char* name;
+  ProfScope(const char* n, hipStream_t st) : s(st), name(n) {
+    if (g_prof_on) {
+      hipEventCreate(&a);
+      hipEventCreate(&b);
+      hipEventRecord(a, s);
+    }
+  }
+  ~ProfScope() {
+    if (g_prof_on) {
+      hipEventRecord(b, s);
+      g_prof.push_back({name, a, b});
+    }
+  }
+};
+
+__global__ void order_pe_kernel(float* __restrict__ table, int SN) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= SN * 8) return;
+  int pos = i >> 3, jj = i & 7;
+  // ray_transformer.py:165-173: float64 table pos / 10000^(2*(j//2)/8), sin on even / cos on odd dims
+  double ang = (double)pos / pow(10000.0, 2.0 * (double)(jj / 2) / 8.0);
+  table[i] = (float)((jj & 1) ? cos(ang) : sin(ang));
+}
+
+PreSim presim_of(const ufr_raw_weights* r) {
+  return PreSim{r->pre_sim.w0, r->pre_sim.b0, r->pre_sim.w2, r->pre_sim.b2, r->pre_sim.w4, r->pre_sim.b4};
+}
+
+const FrameDev* frame_of(const ufr_frame* f) {
+  const FrameDev* d = reinterpret_cast<const FrameDev*>(f);
+  return (f && d->magic == kFrameMagic) ? d : nullptr;
+}
+
+}  // namespace
+
+namespace ufr {
+hipError_t launch_order_pe(float* table, int SN, hipStream_t s) {
+  hipLaunchKernelGGL(order_pe_kernel, dim3((SN * 8 + 255) / 256), dim3(256), 0, s, table, SN);
+  return hipGetLastError();
+}
+}  // namespace ufr
+
+extern "C" {
+
+int ufr_version(void) { return 100; }
+const char* ufr_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------ weights
+size_t ufr_packed_weights_bytes(void) { return (size_t)blob_floats() * sizeof(float); }
+
+int ufr_pack_plan(int32_t* param_id, int32_t* elem) {
+  UFR_REQUIRE(param_id && elem, "ufr_pack_plan: null output");
+  for (int i = 0; i < blob_floats(); ++i) {
+    int p, e;
+    plan_entry(i, &p, &e);
+    param_id[i] = p;
+    elem[i] = e;
+  }
+  return UFR_OK;
+}
+
+int ufr_weights_pack(const ufr_raw_weights* raw, void* packed, ufr_stream stream) {
+  UFR_REQUIRE(raw && packed, "ufr_weights_pack: null argument");
+  static_assert(sizeof(ufr_raw_weights) == sizeof(RawPtrs), "ufr_raw_weights must be P_COUNT pointers");
+  RawPtrs rp;
+  memcpy(&rp, raw, sizeof(rp));
+  for (int i = 0; i < P_COUNT; ++i) UFR_REQUIRE(rp.p[i], "ufr_weights_pack: parameter %d is null", i);
+  UFR_HIP(launch_pack_weights(rp, static_cast<float*>(packed), static_cast<hipStream_t>(stream)));
+  return UFR_OK;
+}
+
+// ------------------------------------------------------------------ frame
+static int frame_check(const ufr_frame_desc* d) {
+  UFR_REQUIRE(d, "frame desc is null");
+  UFR_REQUIRE(d->NV >= 2 && d->NV <= UFR_MAX_VIEWS, "NV=%d unsupported (2..%d)", d->NV, UFR_MAX_VIEWS);
+  UFR_REQUIRE(d->H >= 8 && d->W >= 8 && d->H % 4 == 0 && d->W % 4 == 0, "H,W must be multiples of 4 (got %dx%d)",
+              d->H, d->W);
+  UFR_REQUIRE(d->source_imgs && d->depth_info && d->feat && d->match, "null frame tensor");
+  for (int s = 0; s < UFR_NUM_STAGES; ++s) {
+    UFR_REQUIRE(d->vol_feat[s] && d->vol_weight[s], "null volume (stage %d)", s + 1);
+    UFR_REQUIRE(d->vol_D[s] >= 2 && d->vol_H[s] >= 2 && d->vol_W[s] >= 2, "degenerate volume (stage %d)", s + 1);
+  }
+  UFR_REQUIRE(d->source_poses && d->source_cam_pos && d->ref_cam_pos && d->w2c_row2, "null camera constants");
+  return UFR_OK;
+}
+
+size_t ufr_frame_workspace_bytes(const ufr_frame_desc* d) {
+  if (frame_check(d) != UFR_OK) return 0;
+  Carver c(nullptr);
+  const size_t h = d->H / 4, w = d->W / 4, NV = d->NV;
+  c.f32(NV * h * w * 32);
+  c.f32(NV * h * w * 32 * (NV - 1));
+  c.f32(NV * (size_t)d->H * d->W * 4);
+  for (int s = 0; s < UFR_NUM_STAGES; ++s) c.f32(NV * (size_t)d->vol_D[s] * d->vol_H[s] * d->vol_W[s] * kVolCh);
+  return c.off;
+}
+
+int ufr_frame_prepare(const ufr_frame_desc* d, void* workspace, size_t workspace_bytes, ufr_frame* out,
+                      ufr_stream stream) {
+  int rc = frame_check(d);
+  if (rc != UFR_OK) return rc;
+  UFR_REQUIRE(workspace && out, "ufr_frame_prepare: null workspace/out");
+  if (workspace_bytes < ufr_frame_workspace_bytes(d))
+    return fail(UFR_ERR_WORKSPACE, "frame workspace too small: %zu < %zu", workspace_bytes, ufr_frame_workspace_bytes(d));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int NV = d->NV, h = d->H / 4, w = d->W / 4;
+  Carver c(workspace);
+  float* feat = c.f32((size_t)NV * h * w * 32);
+  float* match = c.f32((size_t)NV * h * w * 32 * (NV - 1));
+  float* rgb = c.f32((size_t)NV * d->H * d->W * 4);
+  float* vol[UFR_NUM_STAGES];
+  for (int st = 0; st < UFR_NUM_STAGES; ++st)
+    vol[st] = c.f32((size_t)NV * d->vol_D[st] * d->vol_H[st] * d->vol_W[st] * kVolCh);
+
+  UFR_HIP(launch_nchw_to_nhwc(d->feat, feat, NV, 32, h * w, 32, s));
+  UFR_HIP(launch_nchw_to_nhwc(d->match, match, NV, 32 * (NV - 1), h * w, 32 * (NV - 1), s));
+  UFR_HIP(launch_nchw_to_nhwc(d->source_imgs, rgb, NV, 3, d->H * d->W, 4, s));
+  for (int st = 0; st < UFR_NUM_STAGES; ++st)
+    UFR_HIP(launch_volume_pack(d->vol_feat[st], d->vol_weight[st], vol[st], NV, d->vol_D[st] * d->vol_H[st] * d->vol_W[st], s));
+
+  FrameDev f;
+  memset(&f, 0, sizeof(f));
+  f.NV = NV; f.H = d->H; f.W = d->W; f.h = h; f.w = w; f.match_ch = 32 * (NV - 1);
+  f.feat = feat; f.match = match; f.rgb = rgb; f.depth = d->depth_info;
+  for (int st = 0; st < UFR_NUM_STAGES; ++st) {
+    f.vol[st] = vol[st];
+    f.vD[st] = d->vol_D[st]; f.vH[st] = d->vol_H[st]; f.vW[st] = d->vol_W[st];
+  }
+  for (int v = 0; v < NV; ++v) {
+    memcpy(f.pose[v], d->source_poses + 16 * v, 12 * sizeof(float));
+    memcpy(f.cam_pos[v], d->source_cam_pos + 3 * v, 3 * sizeof(float));
+    memcpy(f.w2c_z[v], d->w2c_row2 + 4 * v, 4 * sizeof(float));
+  }
+  memcpy(f.ref_pos, d->ref_cam_pos, 3 * sizeof(float));
+  f.vol_near = d->vol_near; f.vol_far = d->vol_far;
+  f.magic = kFrameMagic;
+  memset(out, 0, sizeof(*out));
+  memcpy(out, &f, sizeof(f));
+  return UFR_OK;
+}
+
+// ------------------------------------------------------------------ per-op entry points
+int ufr_sample_fixed(const float* near, const float* far, const float* U, float* z_out, int32_t RN, int32_t SN,
+                     ufr_stream stream) {
+  UFR_REQUIRE(near && far && U && z_out, "ufr_sample_fixed: null argument");
+  UFR_REQUIRE(RN > 0 && SN >= 2, "ufr_sample_fixed: RN=%d SN=%d", RN, SN);
+  UFR_HIP(launch_sample_fixed(near, far, U, RN, z_out, RN, SN, static_cast<hipStream_t>(stream)));
+  return UFR_OK;
+}
+
+int ufr_sample_importance_merge(const float* weight, const float* z, const float* U2, float* z_fine, float* z_all,
+                                int32_t RN, int32_t SN, int32_t PN, ufr_stream stream) {
+  UFR_REQUIRE(weight && z && U2 && z_all, "ufr_sample_importance_merge: null argument");
+  UFR_REQUIRE(RN > 0 && SN >= 2 && SN <= 256 && PN >= 1 && PN <= 256, "ufr_sample_importance_merge: RN=%d SN=%d PN=%d",
+              RN, SN, PN);
+  UFR_HIP(launch_importance_merge(weight, z, U2, RN, z_fine, z_all, RN, SN, PN, static_cast<hipStream_t>(stream)));
+  return UFR_OK;
+}
+
+int ufr_points(const float* ray_o, int32_t ray_o_stride, const float* ray_d, const float* z, float* points, int32_t RN,
+               int32_t SN, ufr_stream stream) {
+  UFR_REQUIRE(ray_o && ray_d && z && points, "ufr_points: null argument");
+  UFR_REQUIRE(ray_o_stride == 0 || ray_o_stride == 3, "ufr_points: ray_o_stride must be 0 or 3");
+  UFR_HIP(launch_points(ray_o, ray_o_stride, ray_d, z, points, RN, SN, static_cast<hipStream_t>(stream)));
+  return UFR_OK;
+}
+
+int ufr_project_gather(const ufr_frame* frame, const ufr_raw_weights* raw, const float* ray_o, int32_t ray_o_stride,
+                       const float* ray_d, const float* z, int32_t RN, int32_t SN, float* x_tokens, float* rgb,
+                       float* dir, float* sim8, float* vol24, float* xy, float* mask_z, ufr_stream stream) {
+  const FrameDev* f = frame_of(frame);
+  UFR_REQUIRE(f, "ufr_project_gather: frame handle not prepared");
+  UFR_REQUIRE(raw && ray_o && ray_d && z && x_tokens && rgb && dir, "ufr_project_gather: null argument");
+  UFR_REQUIRE(ray_o_stride == 0 || ray_o_stride == 3, "ufr_project_gather: ray_o_stride must be 0 or 3");
+  UFR_REQUIRE(RN > 0 && SN > 0, "ufr_project_gather: RN=%d SN=%d", RN, SN);
+  UFR_HIP(launch_gather(*f, presim_of(raw), ray_o, ray_o_stride, ray_d, z, RN, SN, x_tokens, rgb, dir, sim8, vol24, xy,
+                        mask_z, static_cast<hipStream_t>(stream)));
+  return UFR_OK;
+}
+
+size_t ufr_aggregate_workspace_bytes(int32_t RN, int32_t SN, int32_t NV) {
+  (void)NV;
+  Carver c(nullptr);
+  c.f32((size_t)RN * SN * UFR_TOKEN_DIM);
+  c.f32((size_t)SN * 8);
+  return c.off;
+}
+
+static int aggregate_impl(const void* packed, const float* x_tokens, const float* rgb, const float* dir, int RN, int SN,
+                          int NV, float* radiance, float* srdf, float* token0, float* order_pe, bool pe_ready,
+                          float* view_out, float* ray_out, hipStream_t s) {
+  {
+    ProfScope ps("view_transformer", s);
+    UFR_HIP(launch_view_transformer(static_cast<const float*>(packed), x_tokens, rgb, dir, RN * SN, NV, token0, radiance,
+                                    view_out, s));
+  }
+  if (!pe_ready) UFR_HIP(launch_order_pe(order_pe, SN, s));
+  {
+    ProfScope ps("ray_transformer", s);
+    UFR_HIP(launch_ray_transformer(static_cast<const float*>(packed), token0, order_pe, RN, SN, srdf, ray_out, s));
+  }
+  return UFR_OK;
+}
+
+int ufr_aggregate(const void* packed_weights, const float* x_tokens, const float* rgb, const float* dir, int32_t RN,
+                  int32_t SN, int32_t NV, float* radiance, float* srdf, void* workspace, float* view_out,
+                  float* ray_out, ufr_stream stream) {
+  UFR_REQUIRE(packed_weights && x_tokens && rgb && dir && radiance && srdf && workspace, "ufr_aggregate: null argument");
+  UFR_REQUIRE(NV >= 2 && NV <= UFR_MAX_VIEWS, "ufr_aggregate: NV=%d unsupported", NV);
+  UFR_REQUIRE(RN > 0 && SN >= 16 && SN % 16 == 0 && SN <= 256, "ufr_aggregate: SN=%d must be a multiple of 16 in [16,256]", SN);
+  Carver c(workspace);
+  float* token0 = c.f32((size_t)RN * SN * UFR_TOKEN_DIM);
+  float* order_pe = c.f32((size_t)SN * 8);
+  return aggregate_impl(packed_weights, x_tokens, rgb, dir, RN, SN, NV, radiance, srdf, token0, order_pe, false, view_out,
+                        ray_out, static_cast<hipStream_t>(stream));
+}
+
+int ufr_composite(const float* z, const float* radiance, const float* srdf, const float* variance, int32_t RN,
+                  int32_t SN, float* rgb, float* depth, float* opacity, float* weight, ufr_stream stream) {
+  UFR_REQUIRE(z && radiance && srdf && variance && depth, "ufr_composite: null argument");
+  UFR_REQUIRE(RN > 0 && SN >= 2 && SN <= 256, "ufr_composite: SN=%d out of range [2,256]", SN);
+  UFR_HIP(launch_composite(z, radiance, srdf, variance, RN, SN, rgb, depth, opacity, weight, nullptr, nullptr,
+                           static_cast<hipStream_t>(stream)));
+  return UFR_OK;
+}
+
+// ------------------------------------------------------------------ whole-path inference
+int32_t ufr_default_chunk_rays(void) { return 4096; }
+
+namespace {
+struct RenderWs {
+  float *ray_o, *rd, *near, *far, *camz, *z1, *w1, *srdf1, *depth1, *rgb1, *z2, *srdf2, *rad, *x, *rgbm, *dir, *token0,
+      *pe1, *pe2;
+  size_t bytes;
+};
+RenderWs carve_render(void* ws, int R, int SN, int PN, int NV) {
+  const size_t S2 = (size_t)SN + PN, Smax = S2 > (size_t)SN ? S2 : SN;
+  Carver c(ws);
+  RenderWs r;
+  r.ray_o = c.f32(4);
+  r.rd = c.f32((size_t)R * 3);
+  r.near = c.f32(R);
+  r.far = c.f32(R);
+  r.camz = c.f32(R);
+  r.z1 = c.f32((size_t)R * SN);
+  r.w1 = c.f32((size_t)R * SN);
+  r.srdf1 = c.f32((size_t)R * SN);
+  r.depth1 = c.f32(R);
+  r.rgb1 = c.f32((size_t)R * 3);
+  r.z2 = c.f32((size_t)R * S2);
+  r.srdf2 = c.f32((size_t)R * S2);
+  r.rad = c.f32((size_t)R * Smax * 3);
+  r.x = c.f32((size_t)R * Smax * NV * UFR_TOKEN_DIM);
+  r.rgbm = c.f32((size_t)R * Smax * NV * 4);
+  r.dir = c.f32((size_t)R * Smax * NV * 4);
+  r.token0 = c.f32((size_t)R * Smax * UFR_TOKEN_DIM);
+  r.pe1 = c.f32((size_t)SN * 8);
+  r.pe2 = c.f32(S2 * 8);
+  r.bytes = c.off;
+  return r;
+}
+}  // namespace
+
+size_t ufr_render_workspace_bytes(int32_t chunk_rays, int32_t SN, int32_t PN, int32_t NV) {
+  if (chunk_rays <= 0) chunk_rays = ufr_default_chunk_rays();
+  return carve_render(nullptr, chunk_rays, SN, PN, NV).bytes;
+}
+
+int ufr_render_rays(const ufr_render_args* a, ufr_stream stream) {
+  UFR_REQUIRE(a, "ufr_render_rays: null args");
+  const FrameDev* f = frame_of(a->frame);
+  UFR_REQUIRE(f, "ufr_render_rays: frame handle not prepared");
+  UFR_REQUIRE(a->packed_weights && a->raw && a->ray_idx && a->ray_d && a->U1 && a->depth && a->rgb && a->workspace,
+              "ufr_render_rays: null argument");
+  UFR_REQUIRE(a->coarse_only || a->U2, "ufr_render_rays: U2 required unless coarse_only");
+  const int RN = a->RN, SN = a->SN, PN = a->coarse_only ? 0 : a->PN, NV = f->NV;
+  UFR_REQUIRE(RN > 0, "ufr_render_rays: RN=%d", RN);
+  UFR_REQUIRE(SN >= 16 && SN % 16 == 0 && SN <= 256, "ufr_render_rays: coarse samples %d must be a multiple of 16 in [16,256]", SN);
+  UFR_REQUIRE(a->coarse_only || (PN >= 16 && (SN + PN) % 16 == 0 && SN + PN <= 256 && PN <= 256),
+              "ufr_render_rays: fine samples %d unsupported", PN);
+  const int chunk = a->chunk_rays > 0 ? a->chunk_rays : ufr_default_chunk_rays();
+  const size_t need = ufr_render_workspace_bytes(chunk, SN, PN, NV);
+  if (a->workspace_bytes < need) return fail(UFR_ERR_WORKSPACE, "render workspace too small: %zu < %zu", a->workspace_bytes, need);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  RenderWs w = carve_render(a->workspace, chunk, SN, PN, NV);
+  const PreSim ps = presim_of(a->raw);
+  const int S2 = SN + PN, HW = f->H * f->W;
+  bool pe_ready = false;
+
+  for (int r0 = 0; r0 < RN; r0 += chunk) {
+    const int R = (RN - r0) < chunk ? (RN - r0) : chunk;
+    {
+      ProfScope p("sampler", s);
+      UFR_HIP(launch_ray_setup(a->ray_idx + r0, a->ray_d, a->cam_ray_d, HW, a->near_z, a->far_z, R, w.rd, w.near, w.far,
+                               w.camz, a->ray_o, w.ray_o, s));
+      UFR_HIP(launch_sample_fixed(w.near, w.far, a->U1 + r0, RN, w.z1, R, SN, s));
+      if (!pe_ready) {
+        UFR_HIP(launch_order_pe(w.pe1, SN, s));
+        if (!a->coarse_only) UFR_HIP(launch_order_pe(w.pe2, S2, s));
+        pe_ready = true;
+      }
+    }
+    // ---- coarse pass (model.py:445)
+    {
+      ProfScope p("gather", s);
+      UFR_HIP(launch_gather(*f, ps, w.ray_o, 0, w.rd, w.z1, R, SN, w.x, w.rgbm, w.dir, nullptr, nullptr, nullptr, nullptr, s));
+    }
+    int rc = aggregate_impl(a->packed_weights, w.x, w.rgbm, w.dir, R, SN, NV, w.rad, w.srdf1, w.token0, w.pe1, true,
+                            nullptr, nullptr, s);
+    if (rc != UFR_OK) return rc;
+    const bool last = a->coarse_only != 0;
+    {
+      ProfScope p("composite", s);
+      UFR_HIP(launch_composite(w.z1, w.rad, w.srdf1, a->raw->variance, R, SN, last ? a->rgb + 3 * (size_t)r0 : w.rgb1,
+                               last ? a->depth + r0 : w.depth1, nullptr, w.w1, w.camz,
+                               (last && a->depth_z) ? a->depth_z + r0 : nullptr, s));
+    }
+    if (last) {
+      if (a->srdf) UFR_HIP(hipMemcpyAsync(a->srdf + (size_t)r0 * SN, w.srdf1, (size_t)R * SN * 4, hipMemcpyDeviceToDevice, s));
+      if (a->z_all) UFR_HIP(hipMemcpyAsync(a->z_all + (size_t)r0 * SN, w.z1, (size_t)R * SN * 4, hipMemcpyDeviceToDevice, s));
+      continue;
+    }
+    // ---- importance sampling + merge (model.py:455-470), fine pass (model.py:472)
+    {
+      ProfScope p("sampler", s);
+      UFR_HIP(launch_importance_merge(w.w1, w.z1, a->U2 + r0, RN, nullptr, w.z2, R, SN, PN, s));
+    }
+    {
+      ProfScope p("gather", s);
+      UFR_HIP(launch_gather(*f, ps, w.ray_o, 0, w.rd, w.z2, R, S2, w.x, w.rgbm, w.dir, nullptr, nullptr, nullptr, nullptr, s));
+    }
+    rc = aggregate_impl(a->packed_weights, w.x, w.rgbm, w.dir, R, S2, NV, w.rad, w.srdf2, w.token0, w.pe2, true, nullptr,
+                        nullptr, s);
+    if (rc != UFR_OK) return rc;
+    {
+      ProfScope p("composite", s);
+      UFR_HIP(launch_composite(w.z2, w.rad, w.srdf2, a->raw->variance, R, S2, a->rgb + 3 * (size_t)r0, a->depth + r0,
+                               nullptr, nullptr, w.camz, a->depth_z ? a->depth_z + r0 : nullptr, s));
+    }
+    if (a->srdf) UFR_HIP(hipMemcpyAsync(a->srdf + (size_t)r0 * S2, w.srdf2, (size_t)R * S2 * 4, hipMemcpyDeviceToDevice, s));
+    if (a->z_all) UFR_HIP(hipMemcpyAsync(a->z_all + (size_t)r0 * S2, w.z2, (size_t)R * S2 * 4, hipMemcpyDeviceToDevice, s));
+  }
+  return UFR_OK;
+}
+
+// ------------------------------------------------------------------ profiling hooks
+void ufr_profile_enable(int on) {
+  for (auto& e : g_prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  g_prof.clear();
+  g_prof_on = on != 0;
+}
+
+int ufr_profile_read(const char** names, float* ms, int32_t* launches, int cap) {
+  int n = 0;
+  for (auto& e : g_prof) {
+    float t = 0.f;
+    if (hipEventSynchronize(e.b) != hipSuccess || hipEventElapsedTime(&t, e.a, e.b) != hipSuccess) continue;
+    int k = 0;
+    for (; k < n; ++k)
+      if (strcmp(names[k], e.name) == 0) break;
+    if (k == n) {
+      if (n >= cap) continue;
+      names[n] = e.name; ms[n] = 0.f; launches[n] = 0; ++n;
+    }
+    ms[k] += t;
+    launches[k] += 1;
+  }
+  for (auto& e : g_prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  g_prof.clear();
+  return n;
+}
+
+}  // extern "C"

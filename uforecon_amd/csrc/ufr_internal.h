@@ -1,0 +1,60 @@
+// Internal host/device structs behind the opaque handles of include/ufr.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ufr.h"
+#include "ufr_layout.h"
+
+namespace ufr {
+
+constexpr int kVolCh = 12;  // channel-last volume texel: 8 features + 1 weight + 3 pad = 48 B
+
+// What ufr_frame_prepare records (lives inside the caller's ufr_frame; passed BY VALUE to kernels).
+struct FrameDev {
+  int32_t NV, H, W, h, w, match_ch;      // match_ch = 32*(NV-1)
+  const float* feat;                     // [NV][h][w][32]
+  const float* match;                    // [NV][h][w][match_ch]
+  const float* rgb;                      // [NV][H][W][4]
+  const float* depth;                    // [NV][H][W]   (borrowed, reference layout)
+  const float* vol[UFR_NUM_STAGES];      // [NV][D][Hs][Ws][12]
+  int32_t vD[UFR_NUM_STAGES], vH[UFR_NUM_STAGES], vW[UFR_NUM_STAGES];
+  float pose[UFR_MAX_VIEWS][12];         // rows 0..2 of source_poses
+  float cam_pos[UFR_MAX_VIEWS][3];
+  float w2c_z[UFR_MAX_VIEWS][4];
+  float ref_pos[3];
+  float vol_near, vol_far;
+  uint32_t magic;
+};
+static_assert(sizeof(FrameDev) <= sizeof(ufr_frame), "ufr_frame too small");
+constexpr uint32_t kFrameMagic = 0x55465246u;  // "UFRF"
+
+struct PreSim {  // pre_sim_mlp raw pointers (reference layout) used by the gather kernel
+  const float *w0, *b0, *w2, *b2, *w4, *b4;
+};
+
+// kernel launchers (one per .hip file); all enqueue on `s` and return hipGetLastError()
+hipError_t launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int S, int Cpad, hipStream_t s);
+hipError_t launch_volume_pack(const float* feat, const float* weight, float* out, int N, int S, hipStream_t s);
+hipError_t launch_ray_setup(const int64_t* ray_idx, const float* ray_d, const float* cam_ray_d, int HW, float near_z,
+                            float far_z, int RN, float* rd_out, float* near_out, float* far_out, float* camz_out,
+                            const float* ray_o_host, float* ray_o_out, hipStream_t s);
+hipError_t launch_sample_fixed(const float* near, const float* far, const float* U, int u_stride, float* z, int RN,
+                               int SN, hipStream_t s);
+hipError_t launch_importance_merge(const float* weight, const float* z, const float* U2, int u_stride, float* z_fine,
+                                   float* z_all, int RN, int SN, int PN, hipStream_t s);
+hipError_t launch_order_pe(float* table, int SN, hipStream_t s);
+hipError_t launch_points(const float* ray_o, int o_stride, const float* ray_d, const float* z, float* pts, int RN,
+                         int SN, hipStream_t s);
+hipError_t launch_gather(const FrameDev& f, const PreSim& ps, const float* ray_o, int o_stride, const float* ray_d,
+                         const float* z, int RN, int SN, float* x_tokens, float* rgb, float* dir, float* sim8,
+                         float* vol24, float* xy, float* mask_z, hipStream_t s);
+hipError_t launch_view_transformer(const float* packed, const float* x_tokens, const float* rgb, const float* dir,
+                                   int P, int NV, float* token0, float* radiance, float* view_out, hipStream_t s);
+hipError_t launch_ray_transformer(const float* packed, const float* token0, const float* order_pe, int RN, int SN,
+                                  float* srdf, float* ray_out, hipStream_t s);
+hipError_t launch_composite(const float* z, const float* radiance, const float* srdf, const float* variance, int RN,
+                            int SN, float* rgb, float* depth, float* opacity, float* weight, const float* camz,
+                            float* depth_z, hipStream_t s);
+hipError_t launch_pack_weights(const RawPtrs& raw, float* packed, hipStream_t s);
+
+}  // namespace ufr

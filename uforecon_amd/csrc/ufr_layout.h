@@ -1,0 +1,164 @@
+// Packed-weight blob layout shared by the host plan builder (ufr_api.cpp) and the MFMA kernels.
+//
+// A dense layer  y = W x  (W row-major [out][in], the nn.Linear layout) is executed as chained
+// v_mfma_f32_16x16x4_f32 with the TOKENS as the 16 MFMA columns.  The accumulator tile of one
+// layer (lane l holds rows 4*(l>>4)+r, r=0..3, of column l&15) is fed unchanged as the B operand
+// of the next layer: MFMA step r then consumes "input features" {4g+r : g=l>>4}, so the A
+// fragment of (out tile t, in tile t', step r) must be  W[row(t, l&15)][col(t', l>>4, r)].
+// The four steps of an in-tile are one float4 per lane; a fragment group is 64 lanes x float4 =
+// 1 KiB contiguous.  row()/col() also carry the feature permutations/paddings that make the
+// attention heads land in convenient lanes (see the maps below).
+#pragma once
+#include <stdint.h>
+
+namespace ufr {
+
+enum RowMap : int { ROW_NAT = 0, ROW_SLOT20, ROW_HEAD11, ROW_NAT88 };
+enum ColMap : int { COL_NAT = 0, COL_SLOT20, COL_NAT88, COL_HEAD11, COL_RW0, COL_CAT88 };
+
+// nat88: 88 features in 6 tiles; tile 5 keeps its 8 real features in registers r<2 of every lane
+// group (feature 80+2g+r) so only 2 of its 4 MFMA steps are real.
+__host__ __device__ constexpr int nat88(int t, int g, int r) {
+  return t < 5 ? 16 * t + 4 * g + r : (r < 2 ? 80 + 2 * g + r : -1);
+}
+__host__ __device__ constexpr int row_map(int rm, int t, int i, int out_dim) {
+  int g = i >> 2, r = i & 3, v = -1;
+  switch (rm) {
+    case ROW_NAT: v = 16 * t + i; break;
+    case ROW_SLOT20: v = 20 * g + 4 * t + r; break;          // lane group g owns heads 2g,2g+1 (10 dims each)
+    case ROW_HEAD11: v = i < 11 ? 11 * t + i : -1; break;    // one 16-row tile per 11-dim head
+    case ROW_NAT88: v = nat88(t, g, r); break;
+  }
+  return (v >= 0 && v < out_dim) ? v : -1;
+}
+__host__ __device__ constexpr int col_map(int cm, int t, int g, int r, int in_dim) {
+  int v = -1;
+  switch (cm) {
+    case COL_NAT: v = 16 * t + 4 * g + r; break;
+    case COL_SLOT20: v = 20 * g + 4 * t + r; break;
+    case COL_NAT88: v = nat88(t, g, r); break;
+    case COL_HEAD11: v = (4 * g + r < 11) ? 11 * t + 4 * g + r : -1; break;
+    case COL_RW0: v = t < 5 ? 16 * t + 4 * g + r : ((r == 0 && g < 3) ? 80 + g : -1); break;  // [token 80 | dir 3]
+    case COL_CAT88: v = t < 6 ? nat88(t, g, r) : (nat88(t - 6, g, r) < 0 ? -1 : 88 + nat88(t - 6, g, r)); break;
+  }
+  return (v >= 0 && v < in_dim) ? v : -1;
+}
+
+// index of each parameter inside ufr_raw_weights viewed as an array of const float*
+enum Param : int {
+  P_PS_W0 = 0, P_PS_B0, P_PS_W2, P_PS_B2, P_PS_W4, P_PS_B4,
+  P_VT_Q, P_VT_K, P_VT_V, P_VT_MERGE, P_VT_MLP0, P_VT_MLP2, P_VT_N1W, P_VT_N1B, P_VT_N2W, P_VT_N2B,
+  P_RT_Q, P_RT_K, P_RT_V, P_RT_MERGE, P_RT_MLP0, P_RT_MLP2, P_RT_N1W, P_RT_N1B, P_RT_N2W, P_RT_N2B,
+  P_DM_W0, P_DM_B0, P_DM_W2, P_DM_B2, P_DM_W4, P_DM_B4,
+  P_RW_W0, P_RW_B0, P_RW_W2, P_RW_B2, P_RW_W4, P_RW_B4,
+  P_VIEW_TOKEN, P_VARIANCE, P_COUNT
+};
+
+struct MatDesc { int param, k_raw, n_out, n_in, rm, cm, out_dim, in_dim; };
+struct VecDesc { int param, n_tiles, rm, dim; };
+
+enum Mat : int {
+  M_VT_Q = 0, M_VT_K, M_VT_V, M_VT_MERGE, M_VT_MLP0, M_VT_MLP2,
+  M_RT_Q, M_RT_K, M_RT_V, M_RT_MERGE, M_RT_MLP0, M_RT_MLP2,
+  M_DM0, M_DM2, M_DM4, M_RW0, M_RW2, M_RW4, M_COUNT
+};
+enum Vec : int {
+  V_VT_N1W = 0, V_VT_N1B, V_VT_N2W, V_VT_N2B, V_RT_N1W, V_RT_N1B, V_RT_N2W, V_RT_N2B,
+  V_DM_B0, V_DM_B2, V_DM_B4, V_RW_B0, V_RW_B2, V_RW_B4, V_VIEW_TOKEN, V_COUNT
+};
+
+__host__ __device__ constexpr MatDesc mat_desc(int m) {
+  switch (m) {
+    case M_VT_Q: return {P_VT_Q, 80, 5, 5, ROW_SLOT20, COL_NAT, 80, 80};
+    case M_VT_K: return {P_VT_K, 80, 5, 5, ROW_SLOT20, COL_NAT, 80, 80};
+    case M_VT_V: return {P_VT_V, 80, 5, 5, ROW_SLOT20, COL_NAT, 80, 80};
+    case M_VT_MERGE: return {P_VT_MERGE, 80, 5, 5, ROW_NAT, COL_SLOT20, 80, 80};
+    case M_VT_MLP0: return {P_VT_MLP0, 160, 10, 10, ROW_NAT, COL_NAT, 160, 160};
+    case M_VT_MLP2: return {P_VT_MLP2, 160, 5, 10, ROW_NAT, COL_NAT, 80, 160};
+    case M_RT_Q: return {P_RT_Q, 88, 8, 6, ROW_HEAD11, COL_NAT88, 88, 88};
+    case M_RT_K: return {P_RT_K, 88, 8, 6, ROW_HEAD11, COL_NAT88, 88, 88};
+    case M_RT_V: return {P_RT_V, 88, 8, 6, ROW_HEAD11, COL_NAT88, 88, 88};
+    case M_RT_MERGE: return {P_RT_MERGE, 88, 6, 8, ROW_NAT88, COL_HEAD11, 88, 88};
+    case M_RT_MLP0: return {P_RT_MLP0, 176, 11, 12, ROW_NAT, COL_CAT88, 176, 176};
+    case M_RT_MLP2: return {P_RT_MLP2, 176, 6, 11, ROW_NAT88, COL_NAT, 88, 176};
+    case M_DM0: return {P_DM_W0, 88, 2, 6, ROW_NAT, COL_NAT88, 32, 88};
+    case M_DM2: return {P_DM_W2, 32, 1, 2, ROW_NAT, COL_NAT, 16, 32};
+    case M_DM4: return {P_DM_W4, 16, 1, 1, ROW_NAT, COL_NAT, 1, 16};
+    case M_RW0: return {P_RW_W0, 83, 1, 6, ROW_NAT, COL_RW0, 16, 83};
+    case M_RW2: return {P_RW_W2, 16, 1, 1, ROW_NAT, COL_NAT, 8, 16};
+    case M_RW4: return {P_RW_W4, 8, 1, 1, ROW_NAT, COL_NAT, 1, 8};
+  }
+  return {0, 0, 0, 0, 0, 0, 0, 0};
+}
+__host__ __device__ constexpr VecDesc vec_desc(int v) {
+  switch (v) {
+    case V_VT_N1W: return {P_VT_N1W, 5, ROW_NAT, 80};
+    case V_VT_N1B: return {P_VT_N1B, 5, ROW_NAT, 80};
+    case V_VT_N2W: return {P_VT_N2W, 5, ROW_NAT, 80};
+    case V_VT_N2B: return {P_VT_N2B, 5, ROW_NAT, 80};
+    case V_RT_N1W: return {P_RT_N1W, 6, ROW_NAT88, 88};
+    case V_RT_N1B: return {P_RT_N1B, 6, ROW_NAT88, 88};
+    case V_RT_N2W: return {P_RT_N2W, 6, ROW_NAT88, 88};
+    case V_RT_N2B: return {P_RT_N2B, 6, ROW_NAT88, 88};
+    case V_DM_B0: return {P_DM_B0, 2, ROW_NAT, 32};
+    case V_DM_B2: return {P_DM_B2, 1, ROW_NAT, 16};
+    case V_DM_B4: return {P_DM_B4, 1, ROW_NAT, 1};
+    case V_RW_B0: return {P_RW_B0, 1, ROW_NAT, 16};
+    case V_RW_B2: return {P_RW_B2, 1, ROW_NAT, 8};
+    case V_RW_B4: return {P_RW_B4, 1, ROW_NAT, 1};
+    case V_VIEW_TOKEN: return {P_VIEW_TOKEN, 5, ROW_NAT, 80};
+  }
+  return {0, 0, 0, 0};
+}
+
+// sizes in floats
+__host__ __device__ constexpr int mat_floats(int m) { return mat_desc(m).n_out * mat_desc(m).n_in * 256; }
+__host__ __device__ constexpr int vec_floats(int v) { return vec_desc(v).n_tiles * 16; }
+__host__ __device__ constexpr int mat_offset(int m) {
+  int o = 0;
+  for (int i = 0; i < m; ++i) o += mat_floats(i);
+  return o;
+}
+__host__ __device__ constexpr int vec_offset(int v) {
+  int o = mat_offset(M_COUNT);
+  for (int i = 0; i < v; ++i) o += vec_floats(i);
+  return o;
+}
+__host__ __device__ constexpr int blob_floats() { return vec_offset(V_COUNT); }
+
+// Source of packed float i: parameter id (-1 = zero padding) and flat element index.
+__host__ __device__ inline void plan_entry(int i, int* param, int* elem) {
+  *param = -1;
+  *elem = 0;
+  int off = 0;
+  for (int m = 0; m < M_COUNT; ++m) {
+    const MatDesc d = mat_desc(m);
+    const int n = d.n_out * d.n_in * 256;
+    if (i < off + n) {
+      int j = i - off;
+      int r = j & 3, lane = (j >> 2) & 63, tile = j >> 8;
+      int to = tile / d.n_in, ti = tile % d.n_in;
+      int row = row_map(d.rm, to, lane & 15, d.out_dim);
+      int col = col_map(d.cm, ti, lane >> 4, r, d.in_dim);
+      if (row >= 0 && col >= 0) { *param = d.param; *elem = row * d.k_raw + col; }
+      return;
+    }
+    off += n;
+  }
+  for (int v = 0; v < V_COUNT; ++v) {
+    const VecDesc d = vec_desc(v);
+    const int n = d.n_tiles * 16;
+    if (i < off + n) {
+      int j = i - off;
+      int r = j & 3, g = (j >> 2) & 3, t = j >> 4;
+      int row = row_map(d.rm, t, 4 * g + r, d.dim);
+      if (row >= 0) { *param = d.param; *elem = row; }
+      return;
+    }
+    off += n;
+  }
+}
+
+struct RawPtrs { const float* p[P_COUNT]; };
+
+}  // namespace ufr

@@ -1,0 +1,267 @@
+// Cross-view aggregation of one pass: view token + LoFTR linear-attention layer over the NV+1
+// tokens of every point, then the radiance-weight MLP, masked softmax over views and colour blend.
+//   RayTransformer.forward      code1/ray_transformer.py:283-294, 309-320
+//   LoFTREncoderLayer.forward   code1/attention/transformer.py:35-58   (bias-free Linear, post-norm message)
+//   LinearAttention.forward     code1/attention/linear_attention.py:20-47
+//
+// MI355X mapping: tokens are the 16 columns of v_mfma_f32_16x16x4_f32; a wave owns C column tiles
+// (PPT = 16/L points each, L = NV+1 tokens per point).  Activations never leave registers: the
+// accumulator tile of a layer is the B operand of the next (ufr_layout.h), weights stream from L2
+// as 1 KiB A-fragment groups shared by the C tiles.  Q/K/V rows are permuted so lane group g holds
+// heads 2g,2g+1 of its token, and the 4-token attention is done lane-locally with quad DPP
+// exchanges (L = 4) or ds_bpermute (other L).  fp32 throughout (exact-f32 MFMA).
+#include "ufr_device.h"
+#include "ufr_internal.h"
+
+namespace ufr {
+
+template <int C, int N>
+__device__ __forceinline__ void zero_tiles(f32x4 (&t)[C][N]) {
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[c][i] = splat4(0.f);
+}
+
+// LayerNorm over the 80 features of each token: 5 tiles x 4 regs in each of the 4 lane groups.
+template <int C, int VW, int VB>
+__device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const f32x4* __restrict__ w4, int g) {
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) s += (t[c][i][0] + t[c][i][1]) + (t[c][i][2] + t[c][i][3]);
+    const float mean = sum_groups(s) * (1.f / 80.f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float d = t[c][i][r] - mean;
+        q = fmaf(d, d, q);
+      }
+    const float rstd = 1.f / sqrtf(sum_groups(q) * (1.f / 80.f) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const f32x4 gw = vec_frag<VW>(w4, i, g), gb = vec_frag<VB>(w4, i, g);
+      t[c][i] = (t[c][i] - mean) * rstd * gw + gb;
+    }
+  }
+}
+
+template <int L, int C>
+__global__ void __launch_bounds__(256, 2) view_transformer_kernel(const float* __restrict__ packed,
+                                                                   const float* __restrict__ x_tokens,
+                                                                   const float* __restrict__ rgbm,
+                                                                   const float* __restrict__ dirs, int P,
+                                                                   float* __restrict__ token0,
+                                                                   float* __restrict__ radiance,
+                                                                   float* __restrict__ view_out) {
+  constexpr int NV = L - 1;
+  constexpr int PPT = 16 / L;          // points per column tile
+  constexpr int PPW = PPT * C;         // points per wave iteration
+  const f32x4* w4_base = reinterpret_cast<const f32x4*>(packed);
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+  const int pt_in_tile = j / L, tv = j % L;         // token tv of point pt_in_tile (tv == 0: view token)
+  const bool col_ok = j < PPT * L;
+  int src[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) src[s] = col_ok ? (lane - tv + (tv + s) % L) : lane;
+
+  const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * blockDim.x) >> 6;
+  const int n_groups = (P + PPW - 1) / PPW;
+
+  for (int grp = wave_global; grp < n_groups; grp += n_waves) {
+    const f32x4* w4 = launder(w4_base);  // re-read the weights every iteration (no LICM hoist)
+    // ---------------- load tokens: x[c][t] = features 16t+4g..+3 of token j
+    f32x4 x[C][5];
+    int pidx[C];
+    bool valid[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      pidx[c] = grp * PPW + c * PPT + pt_in_tile;
+      valid[c] = col_ok && pidx[c] < P;
+      const int pp = valid[c] ? pidx[c] : 0;
+      const float* row = x_tokens + ((size_t)pp * NV + (tv > 0 ? tv - 1 : 0)) * UFR_TOKEN_DIM;
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        f32x4 tok = vec_frag<V_VIEW_TOKEN>(w4, t, g);
+        f32x4 val = ld4(row + 16 * t + 4 * g);
+        x[c][t] = tv == 0 ? tok : val;                     // ray_transformer.py:284-286
+        if (!valid[c]) x[c][t] = splat4(0.f);
+      }
+    }
+
+    // ---------------- q,k,v projections (slot layout: lane group g <- heads 2g, 2g+1)
+    f32x4 q[C][5], k[C][5], v[C][5];
+    zero_tiles(q); zero_tiles(k); zero_tiles(v);
+    gemm<M_VT_Q, C, 1>(w4, lane, x, q);
+    gemm<M_VT_K, C, 1>(w4, lane, x, k);
+    gemm<M_VT_V, C, 1>(w4, lane, x, v);
+
+    // ---------------- linear attention over the L tokens of each point (linear_attention.py:31-45)
+    f32x4 msg[C][5];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        float Q[10], K[10], V[10], acc[10];
+#pragma unroll
+        for (int d = 0; d < 10; ++d) {
+          const int s = 10 * hh + d;
+          Q[d] = elu1(q[c][s >> 2][s & 3]);
+          K[d] = elu1(k[c][s >> 2][s & 3]);
+          V[d] = v[c][s >> 2][s & 3] / (float)L;             // values / v_length
+          acc[d] = 0.f;
+        }
+        float den = 0.f;
+        // token (tv+S)%L of the same point contributes A_S = Q . K_S
+#define UFR_ATT_STEP(S)                                                  \
+        if (S < L) {                                                     \
+          float a = 0.f;                                                 \
+          _Pragma("unroll") for (int d = 0; d < 10; ++d) a = fmaf(Q[d], rot<L, S>(K[d], src), a); \
+          den += a;                                                      \
+          _Pragma("unroll") for (int d = 0; d < 10; ++d) acc[d] = fmaf(a, rot<L, S>(V[d], src), acc[d]); \
+        }
+        UFR_ATT_STEP(0) UFR_ATT_STEP(1) UFR_ATT_STEP(2) UFR_ATT_STEP(3)
+        UFR_ATT_STEP(4) UFR_ATT_STEP(5) UFR_ATT_STEP(6) UFR_ATT_STEP(7)
+#undef UFR_ATT_STEP
+        const float Z = 1.f / (den + 1e-6f);
+#pragma unroll
+        for (int d = 0; d < 10; ++d) {
+          const int s = 10 * hh + d;
+          msg[c][s >> 2][s & 3] = acc[d] * Z * (float)L;
+        }
+      }
+    }
+
+    // ---------------- merge + LayerNorm1 (transformer.py:51-52)
+    f32x4 m[C][5];
+    zero_tiles(m);
+    gemm<M_VT_MERGE, C, 1>(w4, lane, msg, m);
+    layer_norm80<C, V_VT_N1W, V_VT_N1B>(m, w4, g);
+
+    // ---------------- MLP on [x | message] + LayerNorm2 + residual (transformer.py:55-58)
+    f32x4 cat[C][10], hid[C][10], o[C][5];
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int t = 0; t < 5; ++t) { cat[c][t] = x[c][t]; cat[c][5 + t] = m[c][t]; }
+    zero_tiles(hid);
+    gemm<M_VT_MLP0, C, 1>(w4, lane, cat, hid);
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hid[c][t][r] = fmaxf(hid[c][t][r], 0.f);
+    zero_tiles(o);
+    gemm<M_VT_MLP2, C, 1>(w4, lane, hid, o);
+    layer_norm80<C, V_VT_N2W, V_VT_N2B>(o, w4, g);
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int t = 0; t < 5; ++t) o[c][t] += x[c][t];
+
+    // ---------------- outputs: token 0 -> ray transformer input; optional full dump
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      if (valid[c] && tv == 0) {
+#pragma unroll
+        for (int t = 0; t < 5; ++t) st4(token0 + (size_t)pidx[c] * UFR_TOKEN_DIM + 16 * t + 4 * g, o[c][t]);
+      }
+      if (valid[c] && view_out) {
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+          st4(view_out + ((size_t)pidx[c] * L + tv) * UFR_TOKEN_DIM + 16 * t + 4 * g, o[c][t]);
+      }
+    }
+
+    // ---------------- radiance weight MLP on [view feature | dir] (ray_transformer.py:309-314)
+    f32x4 rin[C][6], h1[C][1], h2[C][1], lg[C][1];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+      for (int t = 0; t < 5; ++t) rin[c][t] = o[c][t];
+      float dcomp = 0.f;
+      if (valid[c] && tv > 0) dcomp = dirs[((size_t)pidx[c] * NV + (tv - 1)) * 4 + g];  // lane group g <- dir[g], 0 for g=3
+      rin[c][5] = f32x4{dcomp, 0.f, 0.f, 0.f};
+      h1[c][0] = vec_frag<V_RW_B0>(w4, 0, g);
+      h2[c][0] = vec_frag<V_RW_B2>(w4, 0, g);
+      lg[c][0] = vec_frag<V_RW_B4>(w4, 0, g);
+    }
+    gemm<M_RW0, C, 1>(w4, lane, rin, h1);
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h1[c][0][r] = fmaxf(h1[c][0][r], 0.f);
+    gemm<M_RW2, C, 1>(w4, lane, h1, h2);
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h2[c][0][r] = fmaxf(h2[c][0][r], 0.f);
+    gemm<M_RW4, C, 1>(w4, lane, h2, lg);
+
+    // ---------------- masked softmax over the NV view tokens + colour blend (ray_transformer.py:315-319)
+    // logit of token j sits in lane group 0, register 0; lanes of group 0 do the point-local reduction
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      f32x4 col = splat4(0.f);
+      if (valid[c] && tv > 0) col = ld4(rgbm + ((size_t)pidx[c] * NV + (tv - 1)) * 4);  // r,g,b,mask
+      float logit = lg[c][0][0];
+      if (col[3] == 0.f) logit = -1e9f;
+      if (tv == 0) logit = -INFINITY;  // the view token is not a colour source
+      float mx = logit;
+#define UFR_MAX_STEP(S) if (S < L) mx = fmaxf(mx, rot<L, S>(logit, src));
+      UFR_MAX_STEP(1) UFR_MAX_STEP(2) UFR_MAX_STEP(3) UFR_MAX_STEP(4) UFR_MAX_STEP(5) UFR_MAX_STEP(6) UFR_MAX_STEP(7)
+#undef UFR_MAX_STEP
+      const float e = tv == 0 ? 0.f : expf(logit - mx);
+      float den = e, cr = e * col[0], cg = e * col[1], cb = e * col[2];
+#define UFR_SUM_STEP(S)                                                       \
+      if (S < L) {                                                            \
+        den += rot<L, S>(e, src);                                             \
+        cr += rot<L, S>(e * col[0], src);                                     \
+        cg += rot<L, S>(e * col[1], src);                                     \
+        cb += rot<L, S>(e * col[2], src);                                     \
+      }
+      UFR_SUM_STEP(1) UFR_SUM_STEP(2) UFR_SUM_STEP(3) UFR_SUM_STEP(4) UFR_SUM_STEP(5) UFR_SUM_STEP(6) UFR_SUM_STEP(7)
+#undef UFR_SUM_STEP
+      if (valid[c] && tv == 0 && g == 0) {
+        float* dst = radiance + (size_t)pidx[c] * 3;
+        dst[0] = cr / den;
+        dst[1] = cg / den;
+        dst[2] = cb / den;
+      }
+    }
+  }
+}
+
+template <int L>
+static hipError_t launch_vt(const float* packed, const float* x_tokens, const float* rgb, const float* dir, int P,
+                            float* token0, float* radiance, float* view_out, hipStream_t s) {
+  constexpr int C = 2;
+  constexpr int PPW = (16 / L) * C;
+  const int n_groups = (P + PPW - 1) / PPW;
+  int blocks = (n_groups + 3) / 4;
+  const int max_blocks = 256 * 2 * 4;  // a few waves per SIMD slot, grid-stride beyond that
+  if (blocks > max_blocks) blocks = max_blocks;
+  hipLaunchKernelGGL((view_transformer_kernel<L, C>), dim3(blocks), dim3(256), 0, s, packed, x_tokens, rgb, dir, P,
+                     token0, radiance, view_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_view_transformer(const float* packed, const float* x_tokens, const float* rgb, const float* dir,
+                                   int P, int NV, float* token0, float* radiance, float* view_out, hipStream_t s) {
+  switch (NV) {
+    case 2: return launch_vt<3>(packed, x_tokens, rgb, dir, P, token0, radiance, view_out, s);
+    case 3: return launch_vt<4>(packed, x_tokens, rgb, dir, P, token0, radiance, view_out, s);
+    case 4: return launch_vt<5>(packed, x_tokens, rgb, dir, P, token0, radiance, view_out, s);
+    case 5: return launch_vt<6>(packed, x_tokens, rgb, dir, P, token0, radiance, view_out, s);
+    case 6: return launch_vt<7>(packed, x_tokens, rgb, dir, P, token0, radiance, view_out, s);
+    case 7: return launch_vt<8>(packed, x_tokens, rgb, dir, P, token0, radiance, view_out, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace ufr

@@ -1,0 +1,293 @@
+"""Host-side mirror of the reference's per-ray API (code1/model.py and friends) on top of libufr.so.
+
+Same class names, call signatures, return conventions and ``state_dict`` keys as the reference for
+this path, so the caller (the Lightning hooks in code1/model.py:492-842) can swap them in
+(INTEGRATION.md).  The modules only OWN the parameters; every computation is a HIP kernel reached
+through the C ABI -- there is no eager/CPU fallback, a missing library or a CPU tensor raises.
+
+Round-1 scope: inference (``torch.no_grad`` / ``extract_geometry`` and the forward half of the
+training signature).  Backward through the kernels is not implemented yet and asking for it fails
+loudly.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import UfrError
+
+
+def _no_grad_only(*tensors) -> None:
+    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
+        raise UfrError("backward through the HIP ray path is not implemented yet (round 1 is forward-only): "
+                       "call under torch.no_grad()")
+
+
+# --------------------------------------------------------------------------- small modules
+class SingleVarianceNetwork(nn.Module):
+    """code1/encoder_utils/single_variance_network.py:5-11 (state_dict key: ``variance``)."""
+
+    def __init__(self, init_val: float):
+        super().__init__()
+        self.register_parameter("variance", nn.Parameter(torch.tensor(init_val)))
+
+    def forward(self, x):
+        return torch.ones([len(x), 1]).type_as(x) * torch.exp(self.variance * 10.0)
+
+
+class FixedSampler:
+    """code1/encoder_utils/sampler.py:7-50.  ``uniforms`` (SN,RN) may be passed explicitly; by default
+    they are drawn exactly like the reference does (CPU generator, shape (SN,RN))."""
+
+    def __init__(self, point_num: int = 64, sample_radius: float = 1.3):
+        self.sample_radius = sample_radius
+        self.point_num = point_num
+
+    def sample_ray(self, ray_o, ray_d, jitter=True, near_z=None, far_z=None, uniforms: Optional[torch.Tensor] = None):
+        RN = ray_d.shape[0]
+        if near_z is None:
+            mid = -(ray_o * ray_d).sum(-1)
+            near_z, far_z = mid - self.sample_radius, mid + self.sample_radius
+        if uniforms is None:
+            uniforms = torch.rand(self.point_num, RN) if jitter else torch.full((self.point_num, RN), 0.5)
+        U = uniforms.to(ray_d.device, torch.float32).contiguous()
+        z = ops.sample_fixed(near_z.reshape(-1).float().contiguous(), far_z.reshape(-1).float().contiguous(), U)
+        ray_o = ray_o.float().contiguous()
+        ray_d = ray_d.float().contiguous()
+        points_x = ops.points(ray_o if ray_o.numel() == 3 else ray_o, ray_d, z)
+        points_d = ray_d[:, None, :].expand(RN, self.point_num, 3)
+        return points_x, z.clone(), points_d
+
+
+class ImportanceSampler:
+    """code1/encoder_utils/sampler.py:53-108."""
+
+    def __init__(self, point_num: int = 128):
+        self.point_num = point_num
+
+    def sample_ray(self, ray_o, ray_d, weight, z_val, uniforms: Optional[torch.Tensor] = None):
+        RN = z_val.shape[0]
+        if uniforms is None:
+            uniforms = torch.rand(self.point_num, RN)
+        U2 = uniforms.to(z_val.device, torch.float32).contiguous()
+        z_fine, z_all = ops.sample_importance_merge(weight.float().contiguous(), z_val.float().contiguous(), U2)
+        self.last_merged = z_all  # coarse+fine sorted (model.py:466-470), reused by UFORecon.infer
+        ray_d = ray_d.float().contiguous()
+        points_x = ops.points(ray_o.float().contiguous(), ray_d, z_fine)
+        points_d = ray_d[:, None, :].expand(RN, self.point_num, 3)
+        return points_x, z_fine, points_d
+
+
+class VolumeRenderer:
+    """code1/encoder_utils/renderer.py:3-48."""
+
+    def __init__(self, args=None):
+        self.args = args
+
+    def render(self, z_val, radiance, geo_value, cos_anneal_ratio=1.0, deviation_network=None):
+        if cos_anneal_ratio != 1.0:
+            raise UfrError("cos_anneal_ratio != 1.0 is never used by the reference (model.py:338-341)")
+        _no_grad_only(radiance, geo_value, deviation_network.variance)
+        var = deviation_network.variance.detach().reshape(1).float().contiguous()
+        rgb, depth, opacity, weight = ops.composite(z_val.float().contiguous(), radiance.float().contiguous(),
+                                                    geo_value.float().contiguous(), var)
+        inv_s = torch.exp(var * 10.0).clip(1e-6, 1e6).reshape(1, 1)
+        return rgb, depth, opacity, weight, 1.0 / inv_s
+
+
+# --------------------------------------------------------------------------- parameter containers
+class _LoFTRLayer(nn.Module):
+    """Parameter layout of attention/transformer.py:7-33 (all Linear bias-free)."""
+
+    def __init__(self, d_model: int):
+        super().__init__()
+        self.q_proj = nn.Linear(d_model, d_model, bias=False)
+        self.k_proj = nn.Linear(d_model, d_model, bias=False)
+        self.v_proj = nn.Linear(d_model, d_model, bias=False)
+        self.merge = nn.Linear(d_model, d_model, bias=False)
+        self.mlp = nn.Sequential(nn.Linear(d_model * 2, d_model * 2, bias=False), nn.ReLU(),
+                                 nn.Linear(d_model * 2, d_model, bias=False))
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+
+
+class _LocalFeatureTransformer(nn.Module):
+    """attention/transformer.py:61-77: one 'self' layer, xavier-uniform on every matrix."""
+
+    def __init__(self, d_model: int):
+        super().__init__()
+        self.layers = nn.ModuleList([_LoFTRLayer(d_model)])
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+
+class _ViewToken(nn.Module):
+    def __init__(self, dim: int):
+        super().__init__()
+        self.register_parameter("view_token", nn.Parameter(torch.randn([1, dim])))
+
+
+class _DepthCode(nn.Module):
+    """Buffers of PositionalEncoding_NeRF(num_freqs=4, d_in=1) (ray_transformer.py:29-51) -- kept so the
+    state_dict matches; the kernel has them as constants."""
+
+    def __init__(self):
+        super().__init__()
+        freqs = np.pi * 2.0 ** torch.arange(0, 4)
+        self.register_buffer("_freqs", torch.repeat_interleave(freqs, 2).view(1, -1, 1))
+        ph = torch.zeros(8)
+        ph[1::2] = np.pi * 0.5
+        self.register_buffer("_phases", ph.view(1, -1, 1))
+
+
+def _mlp3(i, h1, h2, o):
+    return nn.Sequential(nn.Linear(i, h1), nn.ReLU(inplace=True), nn.Linear(h1, h2), nn.ReLU(inplace=True), nn.Linear(h2, o))
+
+
+class RayTransformer(nn.Module):
+    """code1/ray_transformer.py:86-322 for the shipped configuration (correlation volumes, explicit
+    similarity, MVS depth guide with positional encoding, no direction-SRDF)."""
+
+    def __init__(self, args=None, img_feat_dim=32, fea_volume_dim=24, sim_feat_dim=26):
+        super().__init__()
+        self.args = args
+        for flag, want in (("volume_type", "correlation"), ("explicit_similarity", True), ("depth_pos_encoding", True),
+                           ("use_dir_srdf", False)):
+            if args is not None and hasattr(args, flag) and getattr(args, flag) != want:
+                raise UfrError(f"RayTransformer: args.{flag}={getattr(args, flag)!r} is outside the HIP path "
+                               f"(every shipped script uses {want!r})")
+        if img_feat_dim != 32 or fea_volume_dim != 24:
+            raise UfrError("RayTransformer: feature dims are fixed to 32 / 24 by the kernels")
+        self.depthcode = _DepthCode()
+        self.pre_sim_mlp = _mlp3(8, 32, 32, 16)
+        self.density_view_transformer = _LocalFeatureTransformer(80)
+        self.density_ray_transformer = _LocalFeatureTransformer(88)
+        self.DensityMLP = _mlp3(88, 32, 16, 1)
+        self.viewToken = _ViewToken(80)
+        self.linear_radianceweight_1_softmax = _mlp3(83, 16, 8, 1)
+        self._packed: Optional[ops.PackedWeights] = None
+        self._packed_key = None
+
+    # the packed copy follows the parameters: re-pack whenever any of them changed in place / moved
+    def packed_weights(self, variance: torch.Tensor) -> ops.PackedWeights:
+        params = {"ray_transformer." + k: v for k, v in self.state_dict(keep_vars=True).items()}
+        params["deviation_network.variance"] = variance
+        key = tuple((v.data_ptr(), v._version, str(v.device)) for v in params.values())
+        if self._packed is None or key != self._packed_key:
+            self._packed = ops.PackedWeights(params)
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, point3D, batch, source_imgs_feat, fea_volume=None, cond_info=None, points_projected=None,
+                mask_valid=None):
+        raise UfrError("RayTransformer.forward is fused with the gathers on the HIP path: call "
+                       "UFORecon.sample2rgb / UFORecon.infer (gather -> aggregate share one token buffer)")
+
+
+# --------------------------------------------------------------------------- orchestrator
+class UFORecon(nn.Module):
+    """The per-ray half of code1/model.py:28-482 (``infer`` / ``sample2rgb``).  Parameters live under the
+    reference's names (``ray_transformer.*``, ``deviation_network.variance``), so a reference
+    checkpoint loads with ``load_state_dict(strict=False)`` (the encoder keys are not ours)."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        if getattr(args, "extract_geometry", False):
+            self.point_num, self.point_num_2 = args.test_sample_coarse, args.test_sample_fine
+        else:
+            self.point_num, self.point_num_2 = args.coarse_sample, args.fine_sample
+        self.fixed_sampler = FixedSampler(point_num=self.point_num)
+        self.importance_sampler = ImportanceSampler(point_num=self.point_num_2)
+        self.deviation_network = SingleVarianceNetwork(0.3)
+        self.renderer = VolumeRenderer(args)
+        self.ray_transformer = RayTransformer(args=args)
+        self._frame_key = None
+        self._frame: Optional[ops.FrameHandle] = None
+        self._ws: Optional[ops.RenderWorkspace] = None
+
+    # ---- per-frame state: channel-last copies are cached on the identity of the frame tensors
+    def frame_handle(self, batch, source_imgs_feat, feature_volume, match_feature) -> ops.FrameHandle:
+        key = (source_imgs_feat.data_ptr(), source_imgs_feat._version, match_feature[0].data_ptr(),
+               batch["source_imgs"].data_ptr(), batch["depth_info"].data_ptr(), batch["source_poses"].data_ptr(),
+               tuple(feature_volume[s]["feature_volume"].data_ptr() for s in ("stage1", "stage2", "stage3")))
+        if key != self._frame_key:
+            self._frame = ops.FrameHandle(batch, source_imgs_feat, feature_volume, match_feature)
+            self._frame_key = key
+        return self._frame
+
+    def _weights(self) -> ops.PackedWeights:
+        return self.ray_transformer.packed_weights(self.deviation_network.variance)
+
+    def sample2rgb(self, batch, points_x, z_val, ray_d, ray_idx, source_imgs_feat, feature_volume, match_feature):
+        """model.py:308-348.  ``points_x`` must be ``ray_o + z_val * ray_d`` (it always is in the reference);
+        the kernels recompute the positions from ``z_val``."""
+        _no_grad_only(*self.parameters())
+        B, RN, SN, _ = points_x.shape
+        if B != 1:
+            raise UfrError("B=1 only (one frame per call)")
+        fh = self.frame_handle(batch, source_imgs_feat, feature_volume, match_feature)
+        W = self._weights()
+        ray_o = batch["ray_o"][0].float().contiguous()
+        z = z_val.reshape(RN, SN).float().contiguous()
+        x, rgbm, dirs, _ = ops.project_gather(fh, W, ray_o, ray_d.reshape(RN, 3).float().contiguous(), z)
+        radiance, srdf, _ = ops.aggregate(W, x, rgbm, dirs, RN, SN)
+        rgb, depth, opacity, weight = ops.composite(z, radiance.reshape(RN, SN, 3), srdf, W.variance.reshape(1))
+        variance = 1.0 / torch.exp(W.variance.reshape(1, 1) * 10.0).clip(1e-6, 1e6)
+        return rgb[None], depth[None], srdf.reshape(RN, SN, 1), opacity[None], weight[None], None, variance
+
+    def infer(self, batch, ray_idx, source_imgs_feat, feature_volume=None, extract_geometry=False, match_feature=None,
+              ray_idx_all=None, is_train=True, uniforms=None):
+        """model.py:393-482.  ``uniforms=(U1 (SN,RN), U2 (PN,RN))`` pins the sampler randomness; by default
+        they are drawn from the CPU generator in the reference's order and shapes."""
+        _no_grad_only(*self.parameters())
+        B, RN = ray_idx.shape
+        if B != 1:
+            raise UfrError("B=1 only (one frame per call)")
+        dev = source_imgs_feat.device
+        coarse_only = bool(extract_geometry and getattr(self.args, "test_coarse_only", False))
+        if uniforms is None:
+            U1 = torch.rand(self.point_num, RN)
+            U2 = None if coarse_only else torch.rand(self.point_num_2, RN)
+        else:
+            U1, U2 = uniforms
+        U1 = U1.to(dev, torch.float32).contiguous()
+        U2 = None if U2 is None else U2.to(dev, torch.float32).contiguous()
+        fh = self.frame_handle(batch, source_imgs_feat, feature_volume, match_feature)
+        W = self._weights()
+        if extract_geometry:
+            if self._ws is None or self._ws.key[:3] != (self.point_num, 0 if coarse_only else self.point_num_2, fh.NV):
+                self._ws = ops.RenderWorkspace(dev, self.point_num, 0 if coarse_only else self.point_num_2, fh.NV)
+            out = ops.render_rays(fh, W, ray_idx.reshape(-1).to(dev), U1, U2, coarse_only=coarse_only, workspace=self._ws)
+            ray_d = batch["ray_d"][0][:, ray_idx.reshape(-1)].t()
+            points = batch["ray_o"][0][None, None, :] + out["z_all"][..., None] * ray_d[:, None, :]
+            return out["srdf"][None], points[None], out["depth"][None], out["rgb"][None]   # model.py:475-478 / 452
+
+        # training / validation signature (forward only): no near/far scaling (model.py:423), GT gathers
+        idx = ray_idx.reshape(-1)
+        ref_img = batch["ref_img"].reshape(B, 3, -1)
+        rgb_gt = ref_img[:, :, idx].permute(0, 2, 1)
+        depth_gt = batch["depths_h"][:, 0].reshape(B, -1)[:, idx]
+        ray_d = batch["ray_d"][0][:, idx].t().float().contiguous()
+        ray_o = batch["ray_o"][0].float().contiguous()
+        near = batch["near_fars"][0, 0, 0].expand(RN).float().contiguous()
+        far = batch["near_fars"][0, 0, 1].expand(RN).float().contiguous()
+        z1 = ops.sample_fixed(near, far, U1)
+        x, rgbm, dirs, _ = ops.project_gather(fh, W, ray_o, ray_d, z1)
+        rad, srdf, _ = ops.aggregate(W, x, rgbm, dirs, RN, self.point_num)
+        rgb, depth, opacity, weight = ops.composite(z1, rad.reshape(RN, -1, 3), srdf, W.variance.reshape(1))
+        _, z2 = ops.sample_importance_merge(weight, z1, U2, want_fine=False)
+        S2 = z2.shape[1]
+        x, rgbm, dirs, _ = ops.project_gather(fh, W, ray_o, ray_d, z2)
+        rad2, srdf2, _ = ops.aggregate(W, x, rgbm, dirs, RN, S2)
+        rgb2, depth2, opacity2, weight2 = ops.composite(z2, rad2.reshape(RN, S2, 3), srdf2, W.variance.reshape(1))
+        variance = 1.0 / torch.exp(W.variance.reshape(1, 1) * 10.0).clip(1e-6, 1e6)
+        return (rgb_gt, rgb[None], depth[None], depth_gt, srdf.reshape(RN, -1, 1), opacity[None], weight[None], None,
+                rgb2[None], depth2[None], srdf2.reshape(RN, S2, 1), opacity2[None], weight2[None], None,
+                z1[None], z2[None], variance)                                                # model.py:480-482

@@ -1,0 +1,300 @@
+"""Torch-facing wrappers over the C ABI (include/ufr.h).
+
+torch is plumbing here: it owns device memory (caching allocator) and the current HIP stream;
+every computation is a libufr.so kernel.  All wrappers validate device / dtype / contiguity the
+way TORCH_CHECK would and raise ``UfrError`` with the library's message on failure.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from ._lib import UfrError
+
+# state_dict key (reference names) for every pointer of ufr_raw_weights, in declaration order
+_RT = "ray_transformer."
+_VT = _RT + "density_view_transformer.layers.0."
+_RY = _RT + "density_ray_transformer.layers.0."
+RAW_WEIGHT_KEYS = (
+    [_RT + f"pre_sim_mlp.{i}.{p}" for i in (0, 2, 4) for p in ("weight", "bias")]
+    + [_VT + k for k in ("q_proj.weight", "k_proj.weight", "v_proj.weight", "merge.weight", "mlp.0.weight",
+                         "mlp.2.weight", "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")]
+    + [_RY + k for k in ("q_proj.weight", "k_proj.weight", "v_proj.weight", "merge.weight", "mlp.0.weight",
+                         "mlp.2.weight", "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")]
+    + [_RT + f"DensityMLP.{i}.{p}" for i in (0, 2, 4) for p in ("weight", "bias")]
+    + [_RT + f"linear_radianceweight_1_softmax.{i}.{p}" for i in (0, 2, 4) for p in ("weight", "bias")]
+    + [_RT + "viewToken.view_token", "deviation_network.variance"]
+)
+RAW_WEIGHT_SHAPES = (
+    [(32, 8), (32,), (32, 32), (32,), (16, 32), (16,)]
+    + [(80, 80)] * 4 + [(160, 160), (80, 160)] + [(80,)] * 4
+    + [(88, 88)] * 4 + [(176, 176), (88, 176)] + [(88,)] * 4
+    + [(32, 88), (32,), (16, 32), (16,), (1, 16), (1,)]
+    + [(16, 83), (16,), (8, 16), (8,), (1, 8), (1,)]
+    + [(1, 80), ()]
+)
+assert len(RAW_WEIGHT_KEYS) == 40 == len(RAW_WEIGHT_SHAPES)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> int:
+    if not isinstance(t, torch.Tensor):
+        raise UfrError(f"{name}: expected a tensor")
+    if not t.is_cuda:
+        raise UfrError(f"{name}: must live on the GPU (got {t.device}); the per-ray path has no CPU implementation")
+    if t.dtype != dtype:
+        raise UfrError(f"{name}: dtype {t.dtype}, expected {dtype}")
+    if not t.is_contiguous():
+        raise UfrError(f"{name}: must be contiguous")
+    return t.data_ptr()
+
+
+def _opt(t: Optional[torch.Tensor], name: str) -> Optional[int]:
+    return None if t is None else _dev(t, name)
+
+
+class PackedWeights:
+    """ufr_raw_weights (pointers into the live parameters) + the MFMA-ordered packed copy."""
+
+    def __init__(self, params: Dict[str, torch.Tensor]):
+        lib = _lib.load()
+        self._keep = []
+        ptrs = []
+        for key, shape in zip(RAW_WEIGHT_KEYS, RAW_WEIGHT_SHAPES):
+            if key not in params:
+                raise UfrError(f"missing parameter {key}")
+            t = params[key].detach()
+            if tuple(t.shape) != tuple(shape):
+                raise UfrError(f"{key}: shape {tuple(t.shape)}, expected {tuple(shape)}")
+            t = t.contiguous()
+            ptrs.append(_dev(t, key))
+            self._keep.append(t)
+        self.raw = _lib.RawWeights()
+        C.memmove(C.byref(self.raw), (C.c_void_p * 40)(*ptrs), C.sizeof(self.raw))
+        self.device = self._keep[0].device
+        self.packed = torch.empty(lib.ufr_packed_weights_bytes() // 4, dtype=torch.float32, device=self.device)
+        self.repack()
+
+    def repack(self) -> None:
+        """Call after the parameters changed in place (e.g. an optimizer step)."""
+        _lib.check(_lib.load().ufr_weights_pack(C.byref(self.raw), self.packed.data_ptr(), _stream()), "ufr_weights_pack")
+
+    @property
+    def variance(self) -> torch.Tensor:
+        return self._keep[-1]
+
+
+class FrameHandle:
+    """Per-frame channel-last copies + camera constants (ufr_frame_prepare)."""
+
+    def __init__(self, batch: dict, source_imgs_feat: torch.Tensor, feature_volume: dict, match_feature,
+                 stages=("stage1", "stage2", "stage3")):
+        lib = _lib.load()
+        imgs = batch["source_imgs"]
+        if imgs.shape[0] != 1:
+            raise UfrError("the per-ray path handles one frame per call (B=1), as the reference's test loop does")
+        _, NV, _, H, W = imgs.shape
+        s_idx = batch["start_idx"] if "start_idx" in batch else 1  # model.py:313
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        self._keep = dict(
+            imgs=f32(imgs[0]), depth=f32(batch["depth_info"][0]), feat=f32(source_imgs_feat[0]),
+            match=f32(match_feature[0][0]),
+        )
+        d = _lib.FrameDesc()
+        d.NV, d.H, d.W = NV, H, W
+        d.source_imgs = _dev(self._keep["imgs"], "source_imgs")
+        d.depth_info = _dev(self._keep["depth"], "depth_info")
+        d.feat = _dev(self._keep["feat"], "source_imgs_feat")
+        d.match = _dev(self._keep["match"], "match_feature")
+        if tuple(self._keep["feat"].shape) != (NV, 32, H // 4, W // 4):
+            raise UfrError(f"source_imgs_feat shape {tuple(source_imgs_feat.shape)}")
+        if tuple(self._keep["match"].shape) != (NV, 32 * (NV - 1), H // 4, W // 4):
+            raise UfrError(f"match_feature shape {tuple(match_feature[0].shape)}")
+        for i, st in enumerate(stages):
+            fv = f32(feature_volume[st]["feature_volume"])
+            wv = f32(feature_volume[st]["weight_volume"])
+            if fv.shape[0] != NV or fv.shape[1] != 8 or wv.shape[1] != 1 or fv.shape[2:] != wv.shape[2:]:
+                raise UfrError(f"{st}: volume shapes {tuple(fv.shape)} / {tuple(wv.shape)}")
+            self._keep[f"fv{i}"], self._keep[f"wv{i}"] = fv, wv
+            d.vol_feat[i], d.vol_weight[i] = _dev(fv, st), _dev(wv, st)
+            d.vol_D[i], d.vol_H[i], d.vol_W[i] = fv.shape[2], fv.shape[3], fv.shape[4]
+        # small camera constants: host copies
+        host = lambda t: t.detach().to("cpu", torch.float32).contiguous()
+        self._host = dict(
+            poses=host(batch["source_poses"][0]),
+            cam_pos=host(batch["source_poses_inv"][0, :, :3, 3]),
+            ref_pos=host(batch["ref_pose_inv"][0, :3, 3]),
+            w2c_z=host(batch["w2cs"][0, s_idx:, 2, :]),
+        )
+        if self._host["w2c_z"].shape[0] != NV:
+            raise UfrError("w2cs[s_idx:] does not match the number of source views")
+        fp = lambda t: C.cast(t.data_ptr(), C.POINTER(C.c_float))
+        d.source_poses, d.source_cam_pos = fp(self._host["poses"]), fp(self._host["cam_pos"])
+        d.ref_cam_pos, d.w2c_row2 = fp(self._host["ref_pos"]), fp(self._host["w2c_z"])
+        nf = batch["near_fars"][0][0].detach().cpu()
+        d.vol_near, d.vol_far = float(nf[0]), float(nf[1])
+        nbytes = lib.ufr_frame_workspace_bytes(C.byref(d))
+        if nbytes == 0:
+            raise UfrError("frame: " + lib.ufr_last_error().decode())
+        self.device = self._keep["imgs"].device
+        self.workspace = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+        self.frame = _lib.Frame()
+        _lib.check(lib.ufr_frame_prepare(C.byref(d), self.workspace.data_ptr(), nbytes, C.byref(self.frame), _stream()),
+                   "ufr_frame_prepare")
+        self.NV, self.H, self.W = NV, H, W
+        self.near_z = float(batch["near_fars"][0, 0, 0])
+        self.far_z = float(batch["near_fars"][0, 0, 1])
+        self.ray_o = [float(v) for v in batch["ray_o"][0].detach().cpu()]
+        self.ray_d = f32(batch["ray_d"][0])
+        self.cam_ray_d = f32(batch["cam_ray_d"][0]) if "cam_ray_d" in batch else None
+
+
+# ----------------------------------------------------------------------------- per-op wrappers
+def sample_fixed(near: torch.Tensor, far: torch.Tensor, U: torch.Tensor) -> torch.Tensor:
+    SN, RN = U.shape
+    z = torch.empty(RN, SN, dtype=torch.float32, device=U.device)
+    _lib.check(_lib.load().ufr_sample_fixed(_dev(near, "near"), _dev(far, "far"), _dev(U, "U"), z.data_ptr(), RN, SN,
+                                            _stream()), "ufr_sample_fixed")
+    return z
+
+
+def sample_importance_merge(weight: torch.Tensor, z: torch.Tensor, U2: torch.Tensor, want_fine: bool = True):
+    RN, SN = z.shape
+    PN = U2.shape[0]
+    z_fine = torch.empty(RN, PN, dtype=torch.float32, device=z.device) if want_fine else None
+    z_all = torch.empty(RN, SN + PN, dtype=torch.float32, device=z.device)
+    _lib.check(_lib.load().ufr_sample_importance_merge(
+        _dev(weight, "weight"), _dev(z, "z"), _dev(U2, "U2"), _opt(z_fine, "z_fine"), z_all.data_ptr(), RN, SN, PN,
+        _stream()), "ufr_sample_importance_merge")
+    return z_fine, z_all
+
+
+def points(ray_o: torch.Tensor, ray_d: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+    RN, SN = z.shape
+    stride = 0 if ray_o.numel() == 3 else 3
+    out = torch.empty(RN, SN, 3, dtype=torch.float32, device=z.device)
+    _lib.check(_lib.load().ufr_points(_dev(ray_o, "ray_o"), stride, _dev(ray_d, "ray_d"), _dev(z, "z"), out.data_ptr(),
+                                      RN, SN, _stream()), "ufr_points")
+    return out
+
+
+def project_gather(frame: FrameHandle, weights: PackedWeights, ray_o: torch.Tensor, ray_d: torch.Tensor,
+                   z: torch.Tensor, debug: bool = False):
+    RN, SN = z.shape
+    P, NV, dev = RN * SN, frame.NV, z.device
+    x = torch.empty(P, NV, _lib.TOKEN_DIM, dtype=torch.float32, device=dev)
+    rgb = torch.empty(P, NV, 4, dtype=torch.float32, device=dev)
+    dirs = torch.empty(P, NV, 4, dtype=torch.float32, device=dev)
+    dbg = {}
+    if debug:
+        dbg = dict(sim8=torch.empty(P, 8, device=dev), vol24=torch.empty(P, 24, device=dev),
+                   xy=torch.empty(NV, P, 2, device=dev), mask_z=torch.empty(NV, P, device=dev))
+    stride = 0 if ray_o.numel() == 3 else 3
+    _lib.check(_lib.load().ufr_project_gather(
+        C.byref(frame.frame), C.byref(weights.raw), _dev(ray_o, "ray_o"), stride, _dev(ray_d, "ray_d"), _dev(z, "z"),
+        RN, SN, x.data_ptr(), rgb.data_ptr(), dirs.data_ptr(), _opt(dbg.get("sim8"), "sim8"),
+        _opt(dbg.get("vol24"), "vol24"), _opt(dbg.get("xy"), "xy"), _opt(dbg.get("mask_z"), "mask_z"), _stream()),
+        "ufr_project_gather")
+    return x, rgb, dirs, dbg
+
+
+def aggregate(weights: PackedWeights, x: torch.Tensor, rgb: torch.Tensor, dirs: torch.Tensor, RN: int, SN: int,
+              debug: bool = False):
+    lib = _lib.load()
+    NV, dev = x.shape[1], x.device
+    P = RN * SN
+    radiance = torch.empty(P, 3, dtype=torch.float32, device=dev)
+    srdf = torch.empty(RN, SN, dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.ufr_aggregate_workspace_bytes(RN, SN, NV) // 4, dtype=torch.float32, device=dev)
+    dbg = {}
+    if debug:
+        dbg = dict(view_out=torch.empty(P, NV + 1, _lib.TOKEN_DIM, device=dev), ray_out=torch.empty(P, _lib.RAY_DIM, device=dev))
+    _lib.check(lib.ufr_aggregate(weights.packed.data_ptr(), _dev(x, "x_tokens"), _dev(rgb, "rgb"), _dev(dirs, "dir"),
+                                 RN, SN, NV, radiance.data_ptr(), srdf.data_ptr(), ws.data_ptr(),
+                                 _opt(dbg.get("view_out"), "view_out"), _opt(dbg.get("ray_out"), "ray_out"), _stream()),
+               "ufr_aggregate")
+    return radiance, srdf, dbg
+
+
+def composite(z: torch.Tensor, radiance: torch.Tensor, srdf: torch.Tensor, variance: torch.Tensor):
+    RN, SN = z.shape
+    dev = z.device
+    rgb = torch.empty(RN, 3, dtype=torch.float32, device=dev)
+    depth = torch.empty(RN, dtype=torch.float32, device=dev)
+    opacity = torch.empty(RN, dtype=torch.float32, device=dev)
+    weight = torch.empty(RN, SN, dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().ufr_composite(_dev(z, "z"), _dev(radiance, "radiance"), _dev(srdf, "srdf"),
+                                         _dev(variance, "variance"), RN, SN, rgb.data_ptr(), depth.data_ptr(),
+                                         opacity.data_ptr(), weight.data_ptr(), _stream()), "ufr_composite")
+    return rgb, depth, opacity, weight
+
+
+class RenderWorkspace:
+    """Reusable scratch of ufr_render_rays (sized for `chunk_rays`)."""
+
+    def __init__(self, device, SN: int, PN: int, NV: int, chunk_rays: int = 0):
+        lib = _lib.load()
+        self.chunk = chunk_rays if chunk_rays > 0 else lib.ufr_default_chunk_rays()
+        self.key = (SN, PN, NV, self.chunk)
+        self.nbytes = lib.ufr_render_workspace_bytes(self.chunk, SN, PN, NV)
+        self.buf = torch.empty(self.nbytes // 4, dtype=torch.float32, device=device)
+
+
+def render_rays(frame: FrameHandle, weights: PackedWeights, ray_idx: torch.Tensor, U1: torch.Tensor,
+                U2: Optional[torch.Tensor], coarse_only: bool = False, workspace: Optional[RenderWorkspace] = None,
+                want_srdf: bool = True, out: Optional[dict] = None):
+    """UFORecon.infer(extract_geometry=True) for the rays `ray_idx` (RN,) of the prepared frame."""
+    if frame.cam_ray_d is None:
+        raise UfrError("batch['cam_ray_d'] is required for extract_geometry rendering")
+    dev = frame.device
+    RN = ray_idx.numel()
+    SN = U1.shape[0]
+    PN = 0 if coarse_only else U2.shape[0]
+    S = SN + PN
+    if workspace is None or workspace.key[:3] != (SN, PN, frame.NV):
+        workspace = RenderWorkspace(dev, SN, PN, frame.NV)
+    o = out or {}
+    depth = o.get("depth", torch.empty(RN, dtype=torch.float32, device=dev))
+    depth_z = o.get("depth_z", torch.empty(RN, dtype=torch.float32, device=dev))
+    rgb = o.get("rgb", torch.empty(RN, 3, dtype=torch.float32, device=dev))
+    srdf = torch.empty(RN, S, dtype=torch.float32, device=dev) if want_srdf else None
+    z_all = torch.empty(RN, S, dtype=torch.float32, device=dev) if want_srdf else None
+    a = _lib.RenderArgs()
+    a.frame = C.pointer(frame.frame)
+    a.packed_weights = weights.packed.data_ptr()
+    a.raw = C.pointer(weights.raw)
+    a.ray_idx = _dev(ray_idx.reshape(-1), "ray_idx", torch.int64)
+    a.ray_d, a.cam_ray_d = _dev(frame.ray_d, "ray_d"), _dev(frame.cam_ray_d, "cam_ray_d")
+    a.ray_o = (C.c_float * 3)(*frame.ray_o)
+    a.near_z, a.far_z = frame.near_z, frame.far_z
+    a.U1 = _dev(U1, "U1")
+    a.U2 = None if coarse_only else _dev(U2, "U2")
+    if U1.shape[1] != RN or (not coarse_only and U2.shape[1] != RN):
+        raise UfrError("U1/U2 must be (samples, RN)")
+    a.RN, a.SN, a.PN, a.coarse_only = RN, SN, PN, int(coarse_only)
+    a.depth, a.depth_z, a.rgb = depth.data_ptr(), depth_z.data_ptr(), rgb.data_ptr()
+    a.srdf = _opt(srdf, "srdf")
+    a.z_all = _opt(z_all, "z_all")
+    a.chunk_rays = workspace.chunk
+    a.workspace, a.workspace_bytes = workspace.buf.data_ptr(), workspace.nbytes
+    _lib.check(_lib.load().ufr_render_rays(C.byref(a), _stream()), "ufr_render_rays")
+    return dict(depth=depth, depth_z=depth_z, rgb=rgb, srdf=srdf, z_all=z_all, workspace=workspace)
+
+
+def profile_enable(on: bool) -> None:
+    _lib.load().ufr_profile_enable(int(on))
+
+
+def profile_read() -> dict:
+    cap = 16
+    names = (C.c_char_p * cap)()
+    ms = (C.c_float * cap)()
+    launches = (C.c_int32 * cap)()
+    n = _lib.load().ufr_profile_read(names, ms, launches, cap)
+    return {names[i].decode(): dict(ms=float(ms[i]), launches=int(launches[i])) for i in range(n)}

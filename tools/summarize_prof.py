@@ -1,0 +1,78 @@
+"""Condense a rocprofv3 output directory (gpurun_out/prof_rN) into the small tracked files under
+profiles/: kernel stats (names shortened) and a per-kernel PMC table.
+
+    python tools/summarize_prof.py gpurun_out/prof_r1 profiles/r1
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+
+def short(name: str) -> str:
+    name = name.split("(")[0].strip()
+    for pre in ("void ", "ufr::"):
+        name = name.replace(pre, "")
+    return name[-60:]
+
+
+def main(src: str, dst_prefix: str):
+    os.makedirs(os.path.dirname(dst_prefix), exist_ok=True)
+    stats = os.path.join(src, "stats_kernel_stats.csv")
+    if os.path.exists(stats):
+        with open(stats) as f, open(dst_prefix + "_kernel_stats.csv", "w", newline="") as g:
+            w = csv.writer(g)
+            for i, row in enumerate(csv.reader(f)):
+                if i:
+                    row[0] = short(row[0])
+                w.writerow(row)
+    table = collections.defaultdict(dict)
+    for tag in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_lds", "pmc_tcc"):
+        p = os.path.join(src, tag + "_counter_collection.csv")
+        if not os.path.exists(p):
+            continue
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        dur = collections.defaultdict(list)
+        seen = set()
+        for r in csv.DictReader(open(p)):
+            k = short(r["Kernel_Name"])
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if r["Dispatch_Id"] not in seen:
+                seen.add(r["Dispatch_Id"])
+                dur[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+        for k, v in acc.items():
+            for c, x in v.items():
+                table[k][c] = sum(x) / len(x)
+            table[k].setdefault("launches", len(next(iter(v.values()))))
+            table[k][f"avg_ns[{tag}]"] = sum(dur[k]) / max(len(dur[k]), 1)
+    if table:
+        with open(dst_prefix + "_pmc_summary.md", "w") as g:
+            g.write("# rocprofv3 PMC summary (mean per launch; separate --pmc passes)\n\n")
+            g.write("FETCH_SIZE / WRITE_SIZE are in KiB as reported; on gfx950 FETCH_SIZE counts half of the bytes of wide\n"
+                    "coalesced reads (MI355X_MICROARCH.md, HBM section): double it before comparing with byte counts.\n"
+                    "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* are quad-cycles; SQ_VALU_MFMA_BUSY_CYCLES are cycles summed over SIMDs.\n\n")
+            for k in sorted(table, key=lambda k: -table[k].get("SQ_WAVE_CYCLES", 0)):
+                if "kernel" not in k:
+                    continue
+                g.write(f"## {k}\n\n| counter | mean per launch |\n|---|---|\n")
+                for c, v in sorted(table[k].items()):
+                    g.write(f"| {c} | {v:,.1f} |\n")
+                t = table[k]
+                if "SQ_VALU_MFMA_BUSY_CYCLES" in t and t.get("avg_ns[pmc_sq]") and t["SQ_VALU_MFMA_BUSY_CYCLES"] > 0:
+                    per_simd = t["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0
+                    g.write(f"\nMFMA-busy cycles per SIMD: {per_simd:,.0f} over {t['avg_ns[pmc_sq]'] / 1e3:,.1f} us "
+                            f"=> {per_simd / (t['avg_ns[pmc_sq]'] * 2.4):.2%} of a 2.4 GHz clock\n")
+                g.write("\n")
+    bl = os.path.join(src, "bench_line.json")
+    if os.path.exists(bl):
+        txt = open(bl).read().strip().splitlines()
+        for line in txt:
+            if line.startswith("{"):
+                with open(dst_prefix + "_bench_under_rocprof.json", "w") as g:
+                    json.dump(json.loads(line), g, indent=1)
+                    g.write("\n")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

@@ -88,6 +88,11 @@ def load() -> C.CDLL:
     """Load libufr.so (built by uforecon_amd.build).  Raises if it is absent: there is no CPU path."""
     global _lib
     if _lib is None:
+        # torch bundles its own libamdhip64.so.7; it must be mapped first so that libufr.so binds to
+        # the SAME HIP runtime instance (loading /opt/rocm's copy first leaves torch and the kernels on
+        # two runtimes: "no ROCm-capable device is detected")
+        import torch  # noqa: F401
+
         if not os.path.exists(LIB_PATH):
             raise UfrError(f"{LIB_PATH} not found: build it with `python -m uforecon_amd.build` "
                            "(the per-ray path has no non-HIP implementation)")

@@ -1,0 +1,72 @@
+"""Development micro-benchmark: time the three heavy kernels alone on configs[1] shapes.
+UFR_LIB=<path> selects a variant build.  Prints one line per kernel (median of reps)."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from uforecon_amd import ops  # noqa: E402
+from uforecon_amd.scene import make_frame  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def timeit(fn, reps=7):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def main():
+    RN = int(os.environ.get("RN", 4096))
+    SN = int(os.environ.get("SN", 128))
+    NV = 3
+    wz = np.load(os.path.join(ROOT, "tests", "golden", "ray_path_weights_seed0.npz"))
+    W = ops.PackedWeights({k: torch.from_numpy(wz[k]).to(DEV) for k in wz.files})
+    fr = make_frame(512, 640, NV, 0).to(DEV)
+    fh = ops.FrameHandle(fr.batch, fr.source_imgs_feat, fr.feature_volume, fr.match_feature)
+    idx = torch.arange(RN, device=DEV) + 200 * 640
+    ray_d = fr.batch["ray_d"][0][:, idx].t().contiguous()
+    ray_o = fr.batch["ray_o"][0].contiguous()
+    cz = fr.batch["cam_ray_d"][0][2, idx]
+    near = (fr.batch["near_fars"][0, 0, 0] / cz).contiguous()
+    far = (fr.batch["near_fars"][0, 0, 1] / cz).contiguous()
+    z = ops.sample_fixed(near, far, torch.rand(SN, RN, device=DEV))
+    x, rgbm, dirs, _ = ops.project_gather(fh, W, ray_o, ray_d, z)
+    P = RN * SN
+    lib = ops._lib.load()
+    import ctypes as C
+    radiance = torch.empty(P, 3, device=DEV)
+    srdf = torch.empty(RN, SN, device=DEV)
+    ws = torch.empty(lib.ufr_aggregate_workspace_bytes(RN, SN, NV) // 4, device=DEV)
+    tag = os.environ.get("UFR_LIB", "default").split("/")[-1]
+    t = timeit(lambda: ops.project_gather(fh, W, ray_o, ray_d, z))
+    print(f"[{tag}] gather            {t:8.3f} ms  {P / t / 1e6:8.2f} Gpt/s... ({P} points)")
+    ops.profile_enable(True)
+    for _ in range(5):
+        lib.ufr_aggregate(W.packed.data_ptr(), x.data_ptr(), rgbm.data_ptr(), dirs.data_ptr(), RN, SN, NV,
+                          radiance.data_ptr(), srdf.data_ptr(), ws.data_ptr(), None, None, ops._stream())
+    torch.cuda.synchronize()
+    prof = ops.profile_read()
+    ops.profile_enable(False)
+    vt = prof["view_transformer"]["ms"] / prof["view_transformer"]["launches"]
+    rt = prof["ray_transformer"]["ms"] / prof["ray_transformer"]["launches"]
+    print(f"[{tag}] view_transformer  {vt:8.3f} ms  {534224 * P / vt / 1e9:8.2f} TFLOP/s algorithmic")
+    print(f"[{tag}] ray_transformer   {rt:8.3f} ms  {(61952 + 92928 + 4048 + 6688) * P / rt / 1e9:8.2f} TFLOP/s algorithmic")
+
+
+if __name__ == "__main__":
+    main()

@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libufr.so")
+# UFR_LIB selects an alternative in-tree build (A/B kernel variants during development)
+LIB_PATH = os.environ.get("UFR_LIB") or os.path.join(HERE, "lib", "libufr.so")
 
 MAX_VIEWS = 7
 NUM_STAGES = 3

@@ -20,7 +20,7 @@ ARCH = "gfx950"
 
 SOURCES = ["ufr_api.hip", "prep.hip", "sampler.hip", "gather.hip", "view_transformer.hip",
            "ray_transformer.hip", "composite.hip"]
-CXXFLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+CXXFLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value",
             f"-I{INCLUDE}", f"-I{CSRC}"]
 
 
@@ -37,15 +37,18 @@ def _newest_header() -> float:
     return max(os.path.getmtime(h) for h in hs)
 
 
-def build_library(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
+def build_library(force: bool = False, verbose: bool = True, extra_flags=(), variant: str = "") -> str:
+    """variant != "" builds lib/libufr_<variant>.so from separate objects (development A/B builds)."""
     os.makedirs(OUT_DIR, exist_ok=True)
     hipcc = _hipcc()
     hdr_t = _newest_header()
     jobs = []
     objs = []
+    suffix = f"_{variant}" if variant else ""
+    lib_path = os.path.join(OUT_DIR, f"libufr{suffix}.so")
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
-        op = os.path.join(OUT_DIR, src.replace(".hip", ".o"))
+        op = os.path.join(OUT_DIR, src.replace(".hip", f"{suffix}.o"))
         objs.append(op)
         if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_t):
             jobs.append([hipcc, *CXXFLAGS, *extra_flags, "-c", sp, "-o", op])
@@ -61,10 +64,14 @@ def build_library(force: bool = False, verbose: bool = True, extra_flags=()) -> 
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if jobs or not os.path.exists(LIB_PATH):
-        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB_PATH])
-    return LIB_PATH
+    if jobs or not os.path.exists(lib_path):
+        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", lib_path])
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv))
+    # python -m uforecon_amd.build [--force] [--variant NAME -DFLAG ...]
+    argv = sys.argv[1:]
+    variant = argv[argv.index("--variant") + 1] if "--variant" in argv else ""
+    flags = [a for a in argv if a.startswith("-D") or a.startswith("-m")]
+    print(build_library(force="--force" in argv, verbose=False, extra_flags=flags, variant=variant))

@@ -69,14 +69,25 @@ __global__ void __launch_bounds__(256, 2) ray_transformer_kernel(const float* __
   f32x4 KV[8];
 #pragma unroll
   for (int h = 0; h < 8; ++h) KV[h] = splat4(0.f);
+  // weight-stream phases (ring_advance over each matrix' stage count; OT = 2 throughout)
+  constexpr int bK = 0;
+  constexpr int bV = ring_advance(bK, GemmStages<M_RT_K, 2>::n_stages);
+  static_assert(ring_advance(bV, GemmStages<M_RT_V, 2>::n_stages) == bK, "sweep-1 stream must close on itself");
+  constexpr int bQ = 0;
+  constexpr int bMg = ring_advance(bQ, GemmStages<M_RT_Q, 2>::n_stages);
+  constexpr int b0 = ring_advance(bMg, GemmStages<M_RT_MERGE, 2>::n_stages);
+  constexpr int b2 = ring_advance(b0, GemmStages<M_RT_MLP0, 2>::n_stages);
+  constexpr int bD = ring_advance(b2, GemmStages<M_RT_MLP2, 2>::n_stages);
+  WRing<2> ring;
+  prefetch_head<M_RT_K, 2, bK>(w4_base, lane, ring);
   for (int tile = 0; tile < n_tiles; ++tile) {
     const f32x4* w4 = launder(w4_base);  // weights are re-streamed per tile (no LICM hoist)
     f32x4 x[1][6], kt[1][8], vt[1][8];
     load_ray_tile(token0, order_pe, (size_t)ray * SN + tile * 16, tile * 16, g, j, x);
 #pragma unroll
     for (int h = 0; h < 8; ++h) { kt[0][h] = splat4(0.f); vt[0][h] = splat4(0.f); }
-    gemm<M_RT_K, 1, 2, true>(w4, lane, x, kt);   // kt[h]: rows = tokens 4g+r, column j = head dim
-    gemm<M_RT_V, 1, 2, true>(w4, lane, x, vt);
+    gemm_stream<M_RT_K, 1, 2, true, bK, M_RT_V>(w4, lane, x, kt, ring);  // kt[h]: rows = tokens 4g+r, column j = head dim
+    gemm_stream<M_RT_V, 1, 2, true, bV, M_RT_K>(w4, lane, x, vt, ring);  // next tile's K stream starts here
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
 #pragma unroll
@@ -89,13 +100,14 @@ __global__ void __launch_bounds__(256, 2) ray_transformer_kernel(const float* __
   }
 
   // ---------------- sweep 2
+  prefetch_head<M_RT_Q, 2, bQ>(w4_base, lane, ring);
   for (int tile = 0; tile < n_tiles; ++tile) {
     const f32x4* w4 = launder(w4_base);
     f32x4 x[1][6], q[1][8], msg[1][8];
     load_ray_tile(token0, order_pe, (size_t)ray * SN + tile * 16, tile * 16, g, j, x);
 #pragma unroll
     for (int h = 0; h < 8; ++h) q[0][h] = splat4(0.f);
-    gemm<M_RT_Q, 1, 2>(w4, lane, x, q);          // q[h]: rows = head dims 4g+r, column j = token
+    gemm_stream<M_RT_Q, 1, 2, false, bQ, M_RT_MERGE>(w4, lane, x, q, ring);  // q[h]: rows = head dims 4g+r, column j = token
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
       f32x4 acc = splat4(0.f);
@@ -111,7 +123,7 @@ __global__ void __launch_bounds__(256, 2) ray_transformer_kernel(const float* __
     f32x4 m[1][6];
 #pragma unroll
     for (int t = 0; t < 6; ++t) m[0][t] = splat4(0.f);
-    gemm<M_RT_MERGE, 1, 2>(w4, lane, msg, m);
+    gemm_stream<M_RT_MERGE, 1, 2, false, bMg, M_RT_MLP0>(w4, lane, msg, m, ring);
     layer_norm88<V_RT_N1W, V_RT_N1B>(m, w4, g);
 
     f32x4 cat[1][12], hid[1][11], o[1][6];
@@ -119,14 +131,14 @@ __global__ void __launch_bounds__(256, 2) ray_transformer_kernel(const float* __
     for (int t = 0; t < 6; ++t) { cat[0][t] = x[0][t]; cat[0][6 + t] = m[0][t]; }
 #pragma unroll
     for (int t = 0; t < 11; ++t) hid[0][t] = splat4(0.f);
-    gemm<M_RT_MLP0, 1, 2>(w4, lane, cat, hid);
+    gemm_stream<M_RT_MLP0, 1, 2, false, b0, M_RT_MLP2>(w4, lane, cat, hid, ring);
 #pragma unroll
     for (int t = 0; t < 11; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) hid[0][t][r] = fmaxf(hid[0][t][r], 0.f);
 #pragma unroll
     for (int t = 0; t < 6; ++t) o[0][t] = splat4(0.f);
-    gemm<M_RT_MLP2, 1, 2>(w4, lane, hid, o);
+    gemm_stream<M_RT_MLP2, 1, 2, false, b2, M_DM0>(w4, lane, hid, o, ring);
     layer_norm88<V_RT_N2W, V_RT_N2B>(o, w4, g);
 #pragma unroll
     for (int t = 0; t < 6; ++t) o[0][t] += x[0][t];
@@ -145,7 +157,8 @@ __global__ void __launch_bounds__(256, 2) ray_transformer_kernel(const float* __
     d1[0][1] = vec_frag<V_DM_B0>(w4, 1, g);
     d2[0][0] = vec_frag<V_DM_B2>(w4, 0, g);
     d3[0][0] = vec_frag<V_DM_B4>(w4, 0, g);
-    gemm<M_DM0, 1, 2>(w4, lane, o, d1);
+    gemm_stream<M_DM0, 1, 2, false, bD, -1>(w4, lane, o, d1, ring);
+    prefetch_head<M_RT_Q, 2, bQ>(w4, lane, ring);  // next tile's Q stream (ring is free again)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll

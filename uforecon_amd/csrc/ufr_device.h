@@ -16,10 +16,13 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 
 // Hide a (wave-uniform) pointer's provenance from the optimiser.  The weight fragments are loop
 // invariant, so LICM would otherwise hoist all ~1000 float4 loads out of the tile loop and spill.
+// (An opaque zero OFFSET rather than an opaque pointer: the pointer keeps its kernel-argument
+// provenance, so the loads stay global_load with counted vmcnt instead of flat_load + vmcnt(0).)
 template <class T>
 __device__ __forceinline__ const T* launder(const T* p) {
-  asm volatile("" : "+s"(p));
-  return p;
+  int zero = 0;
+  asm volatile("" : "+s"(zero));
+  return p + zero;
 }
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -52,34 +55,72 @@ struct GemmStages {
   __host__ __device__ static constexpr int no(int s) { return (d.n_out - to0(s)) < OT ? (d.n_out - to0(s)) : OT; }
 };
 
-template <int M, int C, int OT, bool SWAP = false>
-__device__ __forceinline__ void gemm(const f32x4* __restrict__ w4, int lane,
-                                     const f32x4 (&in)[C][mat_desc(M).n_in],
-                                     f32x4 (&out)[C][mat_desc(M).n_out]) {
+template <int OT>
+struct WRing {  // PF+1 slots of OT fragments: the in-flight window of the weight stream
+  f32x4 r[kPrefetch + 1][OT];
+};
+
+#ifdef UFR_ABL_NOWLOAD  // ablation build: no weight traffic (results are wrong, timing only)
+struct FragSrc {
+  f32x4 v;
+  __device__ FragSrc(const f32x4*, int, int lane) : v(splat4((float)lane * 1e-3f)) {}
+  __device__ f32x4 operator[](int) const { f32x4 r = v; asm volatile("" : "+v"(r)); return r; }
+};
+#else
+struct FragSrc {
+  const f32x4* p;
+  __device__ FragSrc(const f32x4* w4, int m_off, int lane) : p(w4 + m_off / 4 + lane) {}
+  __device__ f32x4 operator[](int i) const { return p[i]; }
+};
+#endif
+
+// issue the loads of stage s of matrix M into ring slot (BASE + s) % (PF+1)
+template <int M, int OT, int BASE>
+__device__ __forceinline__ void ring_load(const FragSrc& A, WRing<OT>& ring, int s) {
+  using G = GemmStages<M, OT>;
+  constexpr MatDesc d = mat_desc(M);
+#pragma unroll
+  for (int o = 0; o < OT; ++o)
+    if (o < G::no(s)) ring.r[(BASE + s) % (kPrefetch + 1)][o] = A[((G::to0(s) + o) * d.n_in + G::ti(s)) * 64];
+}
+
+// start the weight stream of matrix M (its first PF stages)
+template <int M, int OT, int BASE>
+__device__ __forceinline__ void prefetch_head(const f32x4* __restrict__ w4, int lane, WRing<OT>& ring) {
+  const FragSrc A(w4, mat_offset(M), lane);
+#pragma unroll
+  for (int s = 0; s < kPrefetch; ++s)
+    if (s < GemmStages<M, OT>::n_stages) ring_load<M, OT, BASE>(A, ring, s);
+}
+
+__host__ __device__ constexpr int ring_advance(int base, int n_stages) { return (base + n_stages) % (kPrefetch + 1); }
+
+// Streamed GEMM.  Precondition: the first PF stages of M are already in flight in `ring` at phase
+// BASE (prefetch_head, or the previous gemm's NEXT).  While it runs its last PF stages it starts
+// the stream of matrix NEXT (phase ring_advance(BASE, n_stages)), so the L2 latency of the next
+// layer's first fragments hides behind this layer's MFMAs and the VALU work in between.
+template <int M, int C, int OT, bool SWAP, int BASE, int NEXT>
+__device__ __forceinline__ void gemm_stream(const f32x4* __restrict__ w4, int lane,
+                                            const f32x4 (&in)[C][mat_desc(M).n_in],
+                                            f32x4 (&out)[C][mat_desc(M).n_out], WRing<OT>& ring) {
   using G = GemmStages<M, OT>;
   constexpr MatDesc d = mat_desc(M);
   constexpr int PF = kPrefetch;
-  const f32x4* A = w4 + mat_offset(M) / 4 + lane;
-  f32x4 ring[PF + 1][OT];
-#pragma unroll
-  for (int s = 0; s < PF; ++s) {
-    if (s < G::n_stages) {
-#pragma unroll
-      for (int o = 0; o < OT; ++o)
-        if (o < G::no(s)) ring[s][o] = A[((G::to0(s) + o) * d.n_in + G::ti(s)) * 64];
-    }
-  }
+  constexpr int NM = NEXT >= 0 ? NEXT : M;
+  static_assert(G::n_stages >= PF, "streamed matrices must have at least PF stages");
+  const FragSrc A(w4, mat_offset(M), lane);
+  const FragSrc AN(w4, mat_offset(NM), lane);
 #pragma unroll
   for (int s = 0; s < G::n_stages; ++s) {
     __builtin_amdgcn_sched_barrier(0);
-    if (s + PF < G::n_stages) {
-      const int sp = s + PF;
-#pragma unroll
-      for (int o = 0; o < OT; ++o)
-        if (o < G::no(sp)) ring[sp % (PF + 1)][o] = A[((G::to0(sp) + o) * d.n_in + G::ti(sp)) * 64];
+    const int sp = s + PF;
+    if (sp < G::n_stages) {
+      ring_load<M, OT, BASE>(A, ring, sp);
+    } else if (NEXT >= 0 && sp - G::n_stages < GemmStages<NM, OT>::n_stages) {
+      ring_load<NM, OT, ring_advance(BASE, G::n_stages)>(AN, ring, sp - G::n_stages);
     }
     __builtin_amdgcn_sched_barrier(0);
-    const int to = G::to0(s), ti = G::ti(s);
+    const int to = G::to0(s), ti = G::ti(s), slot = (BASE + s) % (PF + 1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       if (r < in_steps(d.cm, ti)) {
@@ -88,8 +129,43 @@ __device__ __forceinline__ void gemm(const f32x4* __restrict__ w4, int lane,
           if (o < G::no(s)) {
 #pragma unroll
             for (int c = 0; c < C; ++c)
-              out[c][to + o] = SWAP ? mfma16(in[c][ti][r], ring[s % (PF + 1)][o][r], out[c][to + o])
-                                    : mfma16(ring[s % (PF + 1)][o][r], in[c][ti][r], out[c][to + o]);
+              out[c][to + o] = SWAP ? mfma16(in[c][ti][r], ring.r[slot][o][r], out[c][to + o])
+                                    : mfma16(ring.r[slot][o][r], in[c][ti][r], out[c][to + o]);
+          }
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// self-contained GEMM for the tiny heads (own ring, latency exposed once)
+template <int M, int C, int OT, bool SWAP = false>
+__device__ __forceinline__ void gemm(const f32x4* __restrict__ w4, int lane,
+                                     const f32x4 (&in)[C][mat_desc(M).n_in],
+                                     f32x4 (&out)[C][mat_desc(M).n_out]) {
+  using G = GemmStages<M, OT>;
+  constexpr MatDesc d = mat_desc(M);
+  constexpr int PF = kPrefetch;
+  const FragSrc A(w4, mat_offset(M), lane);
+  WRing<OT> ring;
+  prefetch_head<M, OT, 0>(w4, lane, ring);
+#pragma unroll
+  for (int s = 0; s < G::n_stages; ++s) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + PF < G::n_stages) ring_load<M, OT, 0>(A, ring, s + PF);
+    __builtin_amdgcn_sched_barrier(0);
+    const int to = G::to0(s), ti = G::ti(s), slot = s % (PF + 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (r < in_steps(d.cm, ti)) {
+#pragma unroll
+        for (int o = 0; o < OT; ++o) {
+          if (o < G::no(s)) {
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+              out[c][to + o] = SWAP ? mfma16(in[c][ti][r], ring.r[slot][o][r], out[c][to + o])
+                                    : mfma16(ring.r[slot][o][r], in[c][ti][r], out[c][to + o]);
           }
         }
       }

@@ -72,8 +72,19 @@ __global__ void __launch_bounds__(256, 2) view_transformer_kernel(const float* _
   const int n_waves = (gridDim.x * blockDim.x) >> 6;
   const int n_groups = (P + PPW - 1) / PPW;
 
+  // weight-stream phases of the layer chain Q -> K -> V -> MERGE -> MLP0 -> MLP2 -> RW0
+  constexpr int bQ = 0;
+  constexpr int bK = ring_advance(bQ, GemmStages<M_VT_Q, 1>::n_stages);
+  constexpr int bV = ring_advance(bK, GemmStages<M_VT_K, 1>::n_stages);
+  constexpr int bM = ring_advance(bV, GemmStages<M_VT_V, 1>::n_stages);
+  constexpr int b0 = ring_advance(bM, GemmStages<M_VT_MERGE, 1>::n_stages);
+  constexpr int b2 = ring_advance(b0, GemmStages<M_VT_MLP0, 1>::n_stages);
+  constexpr int bR = ring_advance(b2, GemmStages<M_VT_MLP2, 1>::n_stages);
+  WRing<1> ring;
+
   for (int grp = wave_global; grp < n_groups; grp += n_waves) {
     const f32x4* w4 = launder(w4_base);  // re-read the weights every iteration (no LICM hoist)
+    prefetch_head<M_VT_Q, 1, bQ>(w4, lane, ring);
     // ---------------- load tokens: x[c][t] = features 16t+4g..+3 of token j
     f32x4 x[C][5];
     int pidx[C];
@@ -96,12 +107,18 @@ __global__ void __launch_bounds__(256, 2) view_transformer_kernel(const float* _
     // ---------------- q,k,v projections (slot layout: lane group g <- heads 2g, 2g+1)
     f32x4 q[C][5], k[C][5], v[C][5];
     zero_tiles(q); zero_tiles(k); zero_tiles(v);
-    gemm<M_VT_Q, C, 1>(w4, lane, x, q);
-    gemm<M_VT_K, C, 1>(w4, lane, x, k);
-    gemm<M_VT_V, C, 1>(w4, lane, x, v);
+    gemm_stream<M_VT_Q, C, 1, false, bQ, M_VT_K>(w4, lane, x, q, ring);
+    gemm_stream<M_VT_K, C, 1, false, bK, M_VT_V>(w4, lane, x, k, ring);
+    gemm_stream<M_VT_V, C, 1, false, bV, M_VT_MERGE>(w4, lane, x, v, ring);  // merge weights fly during attention
 
     // ---------------- linear attention over the L tokens of each point (linear_attention.py:31-45)
     f32x4 msg[C][5];
+#ifdef UFR_ABL_NOATTN  // ablation build: skip the VALU attention (timing only)
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int t = 0; t < 5; ++t) msg[c][t] = q[c][t] + k[c][t] * v[c][t];
+#else
 #pragma unroll
     for (int c = 0; c < C; ++c) {
 #pragma unroll
@@ -135,11 +152,12 @@ __global__ void __launch_bounds__(256, 2) view_transformer_kernel(const float* _
         }
       }
     }
+#endif
 
     // ---------------- merge + LayerNorm1 (transformer.py:51-52)
     f32x4 m[C][5];
     zero_tiles(m);
-    gemm<M_VT_MERGE, C, 1>(w4, lane, msg, m);
+    gemm_stream<M_VT_MERGE, C, 1, false, bM, M_VT_MLP0>(w4, lane, msg, m, ring);
     layer_norm80<C, V_VT_N1W, V_VT_N1B>(m, w4, g);
 
     // ---------------- MLP on [x | message] + LayerNorm2 + residual (transformer.py:55-58)
@@ -149,7 +167,7 @@ __global__ void __launch_bounds__(256, 2) view_transformer_kernel(const float* _
 #pragma unroll
       for (int t = 0; t < 5; ++t) { cat[c][t] = x[c][t]; cat[c][5 + t] = m[c][t]; }
     zero_tiles(hid);
-    gemm<M_VT_MLP0, C, 1>(w4, lane, cat, hid);
+    gemm_stream<M_VT_MLP0, C, 1, false, b0, M_VT_MLP2>(w4, lane, cat, hid, ring);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
@@ -157,7 +175,7 @@ __global__ void __launch_bounds__(256, 2) view_transformer_kernel(const float* _
 #pragma unroll
         for (int r = 0; r < 4; ++r) hid[c][t][r] = fmaxf(hid[c][t][r], 0.f);
     zero_tiles(o);
-    gemm<M_VT_MLP2, C, 1>(w4, lane, hid, o);
+    gemm_stream<M_VT_MLP2, C, 1, false, b2, M_RW0>(w4, lane, hid, o, ring);
     layer_norm80<C, V_VT_N2W, V_VT_N2B>(o, w4, g);
 #pragma unroll
     for (int c = 0; c < C; ++c)
@@ -191,7 +209,7 @@ __global__ void __launch_bounds__(256, 2) view_transformer_kernel(const float* _
       h2[c][0] = vec_frag<V_RW_B2>(w4, 0, g);
       lg[c][0] = vec_frag<V_RW_B4>(w4, 0, g);
     }
-    gemm<M_RW0, C, 1>(w4, lane, rin, h1);
+    gemm_stream<M_RW0, C, 1, false, bR, -1>(w4, lane, rin, h1, ring);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll

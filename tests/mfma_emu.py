@@ -80,19 +80,54 @@ def mfma16(a, b, acc):
     return out
 
 
-def mat_offset(idx):
-    return sum(m[3] * m[4] * 256 for m in MATS[:idx])
+# weight streams (ufr_layout.h): (matrix names in consumption order, out tiles interleaved per stage)
+STREAMS = [
+    (["VT_Q", "VT_K", "VT_V", "VT_MERGE", "VT_MLP0", "VT_MLP2", "RW0", "RW2", "RW4"], 1),
+    (["RT_K", "RT_V"], 2),
+    (["RT_Q", "RT_MERGE", "RT_MLP0", "RT_MLP2", "DM0", "DM2", "DM4"], 2),
+]
+NAME2IDX = {m[0]: i for i, m in enumerate(MATS)}
+
+
+def stream_frags_padded(si):
+    n = sum(MATS[NAME2IDX[m]][3] * MATS[NAME2IDX[m]][4] for m in STREAMS[si][0])
+    return (n + 3) // 4 * 4
+
+
+def vec_region_offset():
+    return sum(stream_frags_padded(i) for i in range(len(STREAMS))) * 256
+
+
+def mat_location(idx):
+    """(blob float offset of the matrix, OT of its stream)."""
+    name = MATS[idx][0]
+    base = 0
+    for si, (names, ot) in enumerate(STREAMS):
+        if name in names:
+            off = sum(MATS[NAME2IDX[m]][3] * MATS[NAME2IDX[m]][4] for m in names[:names.index(name)])
+            return base + off * 256, ot
+        base += stream_frags_padded(si) * 256
+    raise KeyError(name)
+
+
+def frag_in_mat(idx, ot, to, ti):
+    n_out, n_in = MATS[idx][3], MATS[idx][4]
+    gi, o = divmod(to, ot)
+    no = min(ot, n_out - gi * ot)
+    return gi * ot * n_in + ti * no + o
 
 
 def gemm(blob, idx, tiles_in, swap=False):
     """Chained GEMM of matrix `idx`: tiles_in (n_in,64,4) registers -> (n_out,64,4) accumulators."""
     _, _, _, n_out, n_in, _, cm, _, _ = MATS[idx]
-    frag = blob[mat_offset(idx): mat_offset(idx) + n_out * n_in * 256].reshape(n_out, n_in, 64, 4)
+    base, ot = mat_location(idx)
     out = np.zeros((n_out, 64, 4), np.float64)
     for to in range(n_out):
         for ti in range(n_in):
+            f = base + frag_in_mat(idx, ot, to, ti) * 256
+            frag = blob[f: f + 256].reshape(64, 4)
             for r in range(in_steps(cm, ti)):
-                a, b = frag[to, ti, :, r], tiles_in[ti][:, r]
+                a, b = frag[:, r], tiles_in[ti][:, r]
                 out[to] = mfma16(b, a, out[to]) if swap else mfma16(a, b, out[to])
     return out
 

@@ -40,7 +40,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_struct_sizes_match_the_header(lib):
     assert C.sizeof(_lib.RawWeights) == 40 * 8
     assert C.sizeof(_lib.Frame) == 160 * 8
-    assert lib.ufr_packed_weights_bytes() == 4 * (sum(m[3] * m[4] * 256 for m in E.MATS) + 16 * (5 * 4 + 6 * 4 + 2 + 5 + 5))
+    assert lib.ufr_packed_weights_bytes() == 4 * (E.vec_region_offset() + 16 * (5 * 4 + 6 * 4 + 2 + 5 + 5))
 
 
 def test_argument_errors_are_reported_not_fatal(lib):
@@ -111,7 +111,7 @@ def test_chained_mfma_gemm_reproduces_linear(idx, raw_and_blob):
 
 def test_vector_fragments(plan, raw_and_blob):
     raw, blob = raw_and_blob
-    off = sum(m[3] * m[4] * 256 for m in E.MATS)
+    off = E.vec_region_offset()
     vecs = [(12, 5, E.ROW_NAT, 80), (13, 5, E.ROW_NAT, 80), (14, 5, E.ROW_NAT, 80), (15, 5, E.ROW_NAT, 80),
             (22, 6, E.ROW_NAT88, 88), (23, 6, E.ROW_NAT88, 88), (24, 6, E.ROW_NAT88, 88), (25, 6, E.ROW_NAT88, 88),
             (27, 2, E.ROW_NAT, 32), (29, 1, E.ROW_NAT, 16), (31, 1, E.ROW_NAT, 1), (33, 1, E.ROW_NAT, 16),

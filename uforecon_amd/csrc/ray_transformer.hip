@@ -12,8 +12,8 @@
 //           merge, LayerNorm, MLP, LayerNorm, residual, DensityMLP.
 // Each head occupies its own 16-row tile (11 real rows) so that head boundaries coincide with MFMA
 // tiles; the 88-wide activations use the "nat88" layout of ufr_layout.h.
-#include "ufr_device.h"
 #include "ufr_internal.h"
+#include "weight_stream.h"
 
 namespace ufr {
 
@@ -29,7 +29,7 @@ __device__ __forceinline__ void load_ray_tile(const float* __restrict__ token0, 
 
 // LayerNorm over 88 features in nat88 layout (tile 5: registers 0,1 real)
 template <int VW, int VB>
-__device__ __forceinline__ void layer_norm88(f32x4 (&t)[1][6], const f32x4* __restrict__ w4, int g) {
+__device__ __forceinline__ void layer_norm88(f32x4 (&t)[1][6], const WStream& ws, int g) {
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 5; ++i) s += (t[0][i][0] + t[0][i][1]) + (t[0][i][2] + t[0][i][3]);
@@ -48,20 +48,28 @@ __device__ __forceinline__ void layer_norm88(f32x4 (&t)[1][6], const f32x4* __re
   const float rstd = 1.f / sqrtf(sum_groups(q) * (1.f / 88.f) + 1e-5f);
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    const f32x4 gw = vec_frag<VW>(w4, i, g), gb = vec_frag<VB>(w4, i, g);  // zero in the padding slots
+    const f32x4 gw = vec_frag<VW>(ws, i, g), gb = vec_frag<VB>(ws, i, g);  // zero in the padding slots
     t[0][i] = (t[0][i] - mean) * rstd * gw + gb;
   }
 }
 
-__global__ void __launch_bounds__(256, 2) ray_transformer_kernel(const float* __restrict__ packed,
+// 256-thread workgroups = 4 rays (one wave each, one per SIMD), two workgroups per CU; the four waves
+// walk the weight streams S_RT1 / S_RT2 together through LDS (weight_stream.h).
+constexpr int kRtBlock = 256;
+constexpr int kRtWaves = kRtBlock / 64;
+
+__global__ void __launch_bounds__(kRtBlock, 2) ray_transformer_kernel(const float* __restrict__ packed,
                                                                   const float* __restrict__ token0,
                                                                   const float* __restrict__ order_pe, int RN, int SN,
                                                                   float* __restrict__ srdf,
                                                                   float* __restrict__ ray_out) {
-  const f32x4* w4_base = reinterpret_cast<const f32x4*>(packed);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  WStream ws = wstream_begin<S_RT1, kRtWaves>(packed, smem);
+  wstream_fetch<S_RT1, kRtWaves, 0>(ws);
   const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
-  const int ray = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (ray >= RN) return;
+  const int ray_raw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const bool valid = ray_raw < RN;           // no early exit: every wave meets every chunk barrier
+  const int ray = valid ? ray_raw : RN - 1;
   const int n_tiles = SN / 16;
   const float inv_len = 1.f / (float)SN;  // exact for the power-of-two sample counts; SN is validated on the host
 
@@ -69,25 +77,14 @@ __global__ void __launch_bounds__(256, 2) ray_transformer_kernel(const float* __
   f32x4 KV[8];
 #pragma unroll
   for (int h = 0; h < 8; ++h) KV[h] = splat4(0.f);
-  // weight-stream phases (ring_advance over each matrix' stage count; OT = 2 throughout)
-  constexpr int bK = 0;
-  constexpr int bV = ring_advance(bK, GemmStages<M_RT_K, 2>::n_stages);
-  static_assert(ring_advance(bV, GemmStages<M_RT_V, 2>::n_stages) == bK, "sweep-1 stream must close on itself");
-  constexpr int bQ = 0;
-  constexpr int bMg = ring_advance(bQ, GemmStages<M_RT_Q, 2>::n_stages);
-  constexpr int b0 = ring_advance(bMg, GemmStages<M_RT_MERGE, 2>::n_stages);
-  constexpr int b2 = ring_advance(b0, GemmStages<M_RT_MLP0, 2>::n_stages);
-  constexpr int bD = ring_advance(b2, GemmStages<M_RT_MLP2, 2>::n_stages);
-  WRing<2> ring;
-  prefetch_head<M_RT_K, 2, bK>(w4_base, lane, ring);
   for (int tile = 0; tile < n_tiles; ++tile) {
-    const f32x4* w4 = launder(w4_base);  // weights are re-streamed per tile (no LICM hoist)
+    const bool wrap = tile + 1 < n_tiles;
     f32x4 x[1][6], kt[1][8], vt[1][8];
     load_ray_tile(token0, order_pe, (size_t)ray * SN + tile * 16, tile * 16, g, j, x);
 #pragma unroll
     for (int h = 0; h < 8; ++h) { kt[0][h] = splat4(0.f); vt[0][h] = splat4(0.f); }
-    gemm_stream<M_RT_K, 1, 2, true, bK, M_RT_V>(w4, lane, x, kt, ring);  // kt[h]: rows = tokens 4g+r, column j = head dim
-    gemm_stream<M_RT_V, 1, 2, true, bV, M_RT_K>(w4, lane, x, vt, ring);  // next tile's K stream starts here
+    gemm_lds<M_RT_K, 1, kRtWaves, true>(ws, x, kt, wrap);   // kt[h]: rows = tokens 4g+r, column j = head dim
+    gemm_lds<M_RT_V, 1, kRtWaves, true>(ws, x, vt, wrap);
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
 #pragma unroll
@@ -99,15 +96,15 @@ __global__ void __launch_bounds__(256, 2) ray_transformer_kernel(const float* __
     }
   }
 
-  // ---------------- sweep 2
-  prefetch_head<M_RT_Q, 2, bQ>(w4_base, lane, ring);
+  // ---------------- sweep 2 (slot 0 is free: every wave passed the barrier that opened sweep 1's last chunk)
+  wstream_fetch<S_RT2, kRtWaves, 0>(ws);
   for (int tile = 0; tile < n_tiles; ++tile) {
-    const f32x4* w4 = launder(w4_base);
+    const bool wrap = tile + 1 < n_tiles;
     f32x4 x[1][6], q[1][8], msg[1][8];
     load_ray_tile(token0, order_pe, (size_t)ray * SN + tile * 16, tile * 16, g, j, x);
 #pragma unroll
     for (int h = 0; h < 8; ++h) q[0][h] = splat4(0.f);
-    gemm_stream<M_RT_Q, 1, 2, false, bQ, M_RT_MERGE>(w4, lane, x, q, ring);  // q[h]: rows = head dims 4g+r, column j = token
+    gemm_lds<M_RT_Q, 1, kRtWaves>(ws, x, q, wrap);  // q[h]: rows = head dims 4g+r, column j = token
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
       f32x4 acc = splat4(0.f);
@@ -123,27 +120,27 @@ __global__ void __launch_bounds__(256, 2) ray_transformer_kernel(const float* __
     f32x4 m[1][6];
 #pragma unroll
     for (int t = 0; t < 6; ++t) m[0][t] = splat4(0.f);
-    gemm_stream<M_RT_MERGE, 1, 2, false, bMg, M_RT_MLP0>(w4, lane, msg, m, ring);
-    layer_norm88<V_RT_N1W, V_RT_N1B>(m, w4, g);
+    gemm_lds<M_RT_MERGE, 1, kRtWaves>(ws, msg, m, wrap);
+    layer_norm88<V_RT_N1W, V_RT_N1B>(m, ws, g);
 
     f32x4 cat[1][12], hid[1][11], o[1][6];
 #pragma unroll
     for (int t = 0; t < 6; ++t) { cat[0][t] = x[0][t]; cat[0][6 + t] = m[0][t]; }
 #pragma unroll
     for (int t = 0; t < 11; ++t) hid[0][t] = splat4(0.f);
-    gemm_stream<M_RT_MLP0, 1, 2, false, b0, M_RT_MLP2>(w4, lane, cat, hid, ring);
+    gemm_lds<M_RT_MLP0, 1, kRtWaves>(ws, cat, hid, wrap);
 #pragma unroll
     for (int t = 0; t < 11; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) hid[0][t][r] = fmaxf(hid[0][t][r], 0.f);
 #pragma unroll
     for (int t = 0; t < 6; ++t) o[0][t] = splat4(0.f);
-    gemm_stream<M_RT_MLP2, 1, 2, false, b2, M_DM0>(w4, lane, hid, o, ring);
-    layer_norm88<V_RT_N2W, V_RT_N2B>(o, w4, g);
+    gemm_lds<M_RT_MLP2, 1, kRtWaves>(ws, hid, o, wrap);
+    layer_norm88<V_RT_N2W, V_RT_N2B>(o, ws, g);
 #pragma unroll
     for (int t = 0; t < 6; ++t) o[0][t] += x[0][t];
 
-    if (ray_out) {
+    if (ray_out && valid) {
       float* row = ray_out + ((size_t)ray * SN + tile * 16 + j) * UFR_RAY_DIM;
 #pragma unroll
       for (int t = 0; t < 5; ++t) st4(row + 16 * t + 4 * g, o[0][t]);
@@ -153,29 +150,28 @@ __global__ void __launch_bounds__(256, 2) ray_transformer_kernel(const float* __
 
     // ---------------- DensityMLP 88 -> 32 -> 16 -> 1 (ray_transformer.py:147-150, 307)
     f32x4 d1[1][2], d2[1][1], d3[1][1];
-    d1[0][0] = vec_frag<V_DM_B0>(w4, 0, g);
-    d1[0][1] = vec_frag<V_DM_B0>(w4, 1, g);
-    d2[0][0] = vec_frag<V_DM_B2>(w4, 0, g);
-    d3[0][0] = vec_frag<V_DM_B4>(w4, 0, g);
-    gemm_stream<M_DM0, 1, 2, false, bD, -1>(w4, lane, o, d1, ring);
-    prefetch_head<M_RT_Q, 2, bQ>(w4, lane, ring);  // next tile's Q stream (ring is free again)
+    d1[0][0] = vec_frag<V_DM_B0>(ws, 0, g);
+    d1[0][1] = vec_frag<V_DM_B0>(ws, 1, g);
+    d2[0][0] = vec_frag<V_DM_B2>(ws, 0, g);
+    d3[0][0] = vec_frag<V_DM_B4>(ws, 0, g);
+    gemm_lds<M_DM0, 1, kRtWaves>(ws, o, d1, wrap);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) d1[0][t][r] = fmaxf(d1[0][t][r], 0.f);
-    gemm<M_DM2, 1, 1>(w4, lane, d1, d2);
+    gemm_lds<M_DM2, 1, kRtWaves>(ws, d1, d2, wrap);
 #pragma unroll
     for (int r = 0; r < 4; ++r) d2[0][0][r] = fmaxf(d2[0][0][r], 0.f);
-    gemm<M_DM4, 1, 1>(w4, lane, d2, d3);
-    if (g == 0) srdf[(size_t)ray * SN + tile * 16 + j] = d3[0][0][0];
+    gemm_lds<M_DM4, 1, kRtWaves>(ws, d2, d3, wrap);
+    if (g == 0 && valid) srdf[(size_t)ray * SN + tile * 16 + j] = d3[0][0][0];
   }
 }
 
 hipError_t launch_ray_transformer(const float* packed, const float* token0, const float* order_pe, int RN, int SN,
                                   float* srdf, float* ray_out, hipStream_t s) {
   if (SN % 16 != 0 || SN < 16) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(ray_transformer_kernel, dim3((RN + 3) / 4), dim3(256), 0, s, packed, token0, order_pe, RN, SN,
-                     srdf, ray_out);
+  hipLaunchKernelGGL(ray_transformer_kernel, dim3((RN + kRtWaves - 1) / kRtWaves), dim3(kRtBlock), kStreamLdsBytes, s,
+                     packed, token0, order_pe, RN, SN, srdf, ray_out);
   return hipGetLastError();
 }
 

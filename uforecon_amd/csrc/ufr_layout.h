@@ -1,13 +1,17 @@
-// Packed-weight blob layout shared by the host plan builder (ufr_api.cpp) and the MFMA kernels.
+// Packed-weight blob layout shared by the host plan builder (ufr_api.hip) and the MFMA kernels.
 //
 // A dense layer  y = W x  (W row-major [out][in], the nn.Linear layout) is executed as chained
 // v_mfma_f32_16x16x4_f32 with the TOKENS as the 16 MFMA columns.  The accumulator tile of one
 // layer (lane l holds rows 4*(l>>4)+r, r=0..3, of column l&15) is fed unchanged as the B operand
 // of the next layer: MFMA step r then consumes "input features" {4g+r : g=l>>4}, so the A
 // fragment of (out tile t, in tile t', step r) must be  W[row(t, l&15)][col(t', l>>4, r)].
-// The four steps of an in-tile are one float4 per lane; a fragment group is 64 lanes x float4 =
-// 1 KiB contiguous.  row()/col() also carry the feature permutations/paddings that make the
-// attention heads land in convenient lanes (see the maps below).
+// The four steps of an in-tile are one float4 per lane; a FRAGMENT is 64 lanes x float4 = 1 KiB.
+// row()/col() also carry the feature permutations/paddings that make the attention heads land in
+// convenient lanes (see the maps below).
+//
+// Fragments are stored in CONSUMPTION ORDER, one contiguous STREAM per kernel sweep, so a workgroup
+// can pull them through LDS in fixed-size chunks with lane-linear LDS-DMA (global_load_lds) and all
+// its waves read each fragment from LDS instead of L2 (weight_stream.h).
 #pragma once
 #include <stdint.h>
 
@@ -111,40 +115,131 @@ __host__ __device__ constexpr VecDesc vec_desc(int v) {
   return {0, 0, 0, 0};
 }
 
-// sizes in floats
-__host__ __device__ constexpr int mat_floats(int m) { return mat_desc(m).n_out * mat_desc(m).n_in * 256; }
-__host__ __device__ constexpr int vec_floats(int v) { return vec_desc(v).n_tiles * 16; }
-__host__ __device__ constexpr int mat_offset(int m) {
+// ------------------------------------------------------------------ weight streams
+// S_VT : the view-transformer kernel's per-iteration layer chain
+// S_RT1: ray transformer sweep 1 (K, V per column tile)      S_RT2: sweep 2 (Q .. DensityMLP)
+enum Stream : int { S_VT = 0, S_RT1, S_RT2, S_COUNT };
+constexpr int kChunkMaxFrags = 32;  // LDS slot = 32 KiB; two slots per workgroup
+
+__host__ __device__ constexpr int stream_len(int s) { return s == S_VT ? 9 : (s == S_RT1 ? 2 : 7); }
+__host__ __device__ constexpr int stream_ot(int s) { return s == S_VT ? 1 : 2; }  // out tiles interleaved per stage
+__host__ __device__ constexpr int stream_chunks(int s) { return s == S_RT1 ? 4 : 10; }  // even: static slot parity
+__host__ __device__ constexpr int stream_mat(int s, int i) {
+  switch (s) {
+    case S_VT: {
+      constexpr int m[9] = {M_VT_Q, M_VT_K, M_VT_V, M_VT_MERGE, M_VT_MLP0, M_VT_MLP2, M_RW0, M_RW2, M_RW4};
+      return m[i];
+    }
+    case S_RT1: return i == 0 ? M_RT_K : M_RT_V;
+    default: {
+      constexpr int m[7] = {M_RT_Q, M_RT_MERGE, M_RT_MLP0, M_RT_MLP2, M_DM0, M_DM2, M_DM4};
+      return m[i];
+    }
+  }
+}
+__host__ __device__ constexpr int mat_frags(int m) { return mat_desc(m).n_out * mat_desc(m).n_in; }
+// first fragment of the i-th matrix of stream s
+__host__ __device__ constexpr int stream_mat_start(int s, int i) {
   int o = 0;
-  for (int i = 0; i < m; ++i) o += mat_floats(i);
+  for (int j = 0; j < i; ++j) o += mat_frags(stream_mat(s, j));
   return o;
 }
+__host__ __device__ constexpr int stream_frags(int s) { return stream_mat_start(s, stream_len(s)); }
+// streams are zero-padded to a multiple of 4 fragments so that chunks split evenly over the 4 fetching waves
+__host__ __device__ constexpr int stream_frags_padded(int s) { return (stream_frags(s) + 3) / 4 * 4; }
+__host__ __device__ constexpr int stream_base_floats(int s) {
+  int o = 0;
+  for (int t = 0; t < s; ++t) o += stream_frags_padded(t) * 256;
+  return o;
+}
+// fragment (out tile `to`, in tile `ti`) of a matrix whose stages interleave OT out tiles:
+// order = group-major, then in tile, then the tile inside the group
+__host__ __device__ constexpr int frag_in_mat(int m, int ot, int to, int ti) {
+  const MatDesc d = mat_desc(m);
+  const int gi = to / ot, o = to % ot;
+  const int no = (d.n_out - gi * ot) < ot ? (d.n_out - gi * ot) : ot;
+  return gi * ot * d.n_in + ti * no + o;
+}
+// chunk boundaries (in fragments): nearly equal, multiples of 4 (one quarter per fetching wave; never
+// splits the two fragments of an OT=2 stage)
+__host__ __device__ constexpr int chunk_begin(int s, int c) {
+  return c >= stream_chunks(s) ? stream_frags_padded(s) : ((c * stream_frags_padded(s) / stream_chunks(s)) / 4) * 4;
+}
+__host__ __device__ constexpr int chunk_of(int s, int f) {
+  int c = 0;
+  while (c + 1 < stream_chunks(s) && chunk_begin(s, c + 1) <= f) ++c;
+  return c;
+}
+__host__ __device__ constexpr bool chunks_fit(int s) {
+  for (int c = 0; c < stream_chunks(s); ++c)
+    if (chunk_begin(s, c + 1) - chunk_begin(s, c) > kChunkMaxFrags) return false;
+  return true;
+}
+static_assert(chunks_fit(S_VT) && chunks_fit(S_RT1) && chunks_fit(S_RT2), "a weight chunk exceeds the LDS slot");
+
+// where matrix m lives: (stream, index in stream)
+__host__ __device__ constexpr int mat_stream(int m) {
+  for (int s = 0; s < S_COUNT; ++s)
+    for (int i = 0; i < stream_len(s); ++i)
+      if (stream_mat(s, i) == m) return s;
+  return -1;
+}
+__host__ __device__ constexpr int mat_stream_index(int m) {
+  const int s = mat_stream(m);
+  for (int i = 0; i < stream_len(s); ++i)
+    if (stream_mat(s, i) == m) return i;
+  return -1;
+}
+
+// sizes / offsets in floats
+__host__ __device__ constexpr int vec_floats(int v) { return vec_desc(v).n_tiles * 16; }
+__host__ __device__ constexpr int vec_region_offset() { return stream_base_floats(S_COUNT); }
 __host__ __device__ constexpr int vec_offset(int v) {
-  int o = mat_offset(M_COUNT);
+  int o = vec_region_offset();
   for (int i = 0; i < v; ++i) o += vec_floats(i);
   return o;
 }
+__host__ __device__ constexpr int vec_region_floats() { return vec_offset(V_COUNT) - vec_region_offset(); }
 __host__ __device__ constexpr int blob_floats() { return vec_offset(V_COUNT); }
+__host__ __device__ constexpr int mat_offset(int m) {  // first float of matrix m inside the blob
+  return stream_base_floats(mat_stream(m)) + stream_mat_start(mat_stream(m), mat_stream_index(m)) * 256;
+}
 
 // Source of packed float i: parameter id (-1 = zero padding) and flat element index.
 __host__ __device__ inline void plan_entry(int i, int* param, int* elem) {
   *param = -1;
   *elem = 0;
-  int off = 0;
-  for (int m = 0; m < M_COUNT; ++m) {
+  if (i < vec_region_offset()) {
+    int s = 0;
+    while (s + 1 < S_COUNT && stream_base_floats(s + 1) <= i) ++s;
+    const int j = i - stream_base_floats(s);
+    const int r = j & 3, lane = (j >> 2) & 63;
+    int f = j >> 8;  // fragment inside the stream
+    if (f >= stream_frags(s)) return;  // tail padding
+    int mi = 0;
+    while (f >= mat_frags(stream_mat(s, mi))) { f -= mat_frags(stream_mat(s, mi)); ++mi; }
+    const int m = stream_mat(s, mi), ot = stream_ot(s);
     const MatDesc d = mat_desc(m);
-    const int n = d.n_out * d.n_in * 256;
-    if (i < off + n) {
-      int j = i - off;
-      int r = j & 3, lane = (j >> 2) & 63, tile = j >> 8;
-      int to = tile / d.n_in, ti = tile % d.n_in;
-      int row = row_map(d.rm, to, lane & 15, d.out_dim);
-      int col = col_map(d.cm, ti, lane >> 4, r, d.in_dim);
-      if (row >= 0 && col >= 0) { *param = d.param; *elem = row * d.k_raw + col; }
-      return;
+    const int full = d.n_out / ot;  // complete groups of `ot` out tiles
+    int gi, ti, o;
+    if (f < full * ot * d.n_in) {
+      gi = f / (ot * d.n_in);
+      const int rem = f % (ot * d.n_in);
+      ti = rem / ot;
+      o = rem % ot;
+    } else {
+      gi = full;
+      const int rem = f - full * ot * d.n_in, no = d.n_out - full * ot;
+      ti = rem / no;
+      o = rem % no;
     }
-    off += n;
+    const int to = gi * ot + o;
+    const int row = row_map(d.rm, to, lane & 15, d.out_dim);
+    const int col = col_map(d.cm, ti, lane >> 4, r, d.in_dim);
+    if (row >= 0 && col >= 0) { *param = d.param; *elem = row * d.k_raw + col; }
+    return;
   }
+  int off = vec_region_offset();
   for (int v = 0; v < V_COUNT; ++v) {
     const VecDesc d = vec_desc(v);
     const int n = d.n_tiles * 16;

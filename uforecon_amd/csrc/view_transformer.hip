@@ -10,8 +10,8 @@
 // as 1 KiB A-fragment groups shared by the C tiles.  Q/K/V rows are permuted so lane group g holds
 // heads 2g,2g+1 of its token, and the 4-token attention is done lane-locally with quad DPP
 // exchanges (L = 4) or ds_bpermute (other L).  fp32 throughout (exact-f32 MFMA).
-#include "ufr_device.h"
 #include "ufr_internal.h"
+#include "weight_stream.h"
 
 namespace ufr {
 
@@ -25,7 +25,7 @@ __device__ __forceinline__ void zero_tiles(f32x4 (&t)[C][N]) {
 
 // LayerNorm over the 80 features of each token: 5 tiles x 4 regs in each of the 4 lane groups.
 template <int C, int VW, int VB>
-__device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const f32x4* __restrict__ w4, int g) {
+__device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const WStream& ws, int g) {
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     float s = 0.f;
@@ -43,14 +43,19 @@ __device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const f32x4* __re
     const float rstd = 1.f / sqrtf(sum_groups(q) * (1.f / 80.f) + 1e-5f);
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-      const f32x4 gw = vec_frag<VW>(w4, i, g), gb = vec_frag<VB>(w4, i, g);
+      const f32x4 gw = vec_frag<VW>(ws, i, g), gb = vec_frag<VB>(ws, i, g);
       t[c][i] = (t[c][i] - mean) * rstd * gw + gb;
     }
   }
 }
 
+// 256-thread workgroups (one wave per SIMD), two per CU; each streams the layer chain's weights through
+// its own pair of LDS slots (weight_stream.h), so L2 sees every fragment once per workgroup iteration.
+constexpr int kVtBlock = 256;
+constexpr int kVtWaves = kVtBlock / 64;
+
 template <int L, int C>
-__global__ void __launch_bounds__(256, 2) view_transformer_kernel(const float* __restrict__ packed,
+__global__ void __launch_bounds__(kVtBlock, 2) view_transformer_kernel(const float* __restrict__ packed,
                                                                    const float* __restrict__ x_tokens,
                                                                    const float* __restrict__ rgbm,
                                                                    const float* __restrict__ dirs, int P,
@@ -60,7 +65,9 @@ __global__ void __launch_bounds__(256, 2) view_transformer_kernel(const float* _
   constexpr int NV = L - 1;
   constexpr int PPT = 16 / L;          // points per column tile
   constexpr int PPW = PPT * C;         // points per wave iteration
-  const f32x4* w4_base = reinterpret_cast<const f32x4*>(packed);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  WStream ws = wstream_begin<S_VT, kVtWaves>(packed, smem);
+  wstream_fetch<S_VT, kVtWaves, 0>(ws);
   const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
   const int pt_in_tile = j / L, tv = j % L;         // token tv of point pt_in_tile (tv == 0: view token)
   const bool col_ok = j < PPT * L;
@@ -71,20 +78,11 @@ __global__ void __launch_bounds__(256, 2) view_transformer_kernel(const float* _
   const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int n_waves = (gridDim.x * blockDim.x) >> 6;
   const int n_groups = (P + PPW - 1) / PPW;
+  const int n_iter = (n_groups + n_waves - 1) / n_waves;  // uniform over the grid: every wave meets every barrier
 
-  // weight-stream phases of the layer chain Q -> K -> V -> MERGE -> MLP0 -> MLP2 -> RW0
-  constexpr int bQ = 0;
-  constexpr int bK = ring_advance(bQ, GemmStages<M_VT_Q, 1>::n_stages);
-  constexpr int bV = ring_advance(bK, GemmStages<M_VT_K, 1>::n_stages);
-  constexpr int bM = ring_advance(bV, GemmStages<M_VT_V, 1>::n_stages);
-  constexpr int b0 = ring_advance(bM, GemmStages<M_VT_MERGE, 1>::n_stages);
-  constexpr int b2 = ring_advance(b0, GemmStages<M_VT_MLP0, 1>::n_stages);
-  constexpr int bR = ring_advance(b2, GemmStages<M_VT_MLP2, 1>::n_stages);
-  WRing<1> ring;
-
-  for (int grp = wave_global; grp < n_groups; grp += n_waves) {
-    const f32x4* w4 = launder(w4_base);  // re-read the weights every iteration (no LICM hoist)
-    prefetch_head<M_VT_Q, 1, bQ>(w4, lane, ring);
+  for (int it = 0; it < n_iter; ++it) {
+    const int grp = it * n_waves + wave_global;
+    const bool wrap = it + 1 < n_iter;
     // ---------------- load tokens: x[c][t] = features 16t+4g..+3 of token j
     f32x4 x[C][5];
     int pidx[C];
@@ -92,24 +90,42 @@ __global__ void __launch_bounds__(256, 2) view_transformer_kernel(const float* _
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       pidx[c] = grp * PPW + c * PPT + pt_in_tile;
-      valid[c] = col_ok && pidx[c] < P;
+      valid[c] = col_ok && grp < n_groups && pidx[c] < P;
       const int pp = valid[c] ? pidx[c] : 0;
       const float* row = x_tokens + ((size_t)pp * NV + (tv > 0 ? tv - 1 : 0)) * UFR_TOKEN_DIM;
 #pragma unroll
       for (int t = 0; t < 5; ++t) {
-        f32x4 tok = vec_frag<V_VIEW_TOKEN>(w4, t, g);
+        f32x4 tok = vec_frag<V_VIEW_TOKEN>(ws, t, g);
+#ifdef UFR_ABL_GEMMONLY
+        f32x4 val = splat4((float)(lane + t) * 1e-3f);
+        (void)row;
+#else
         f32x4 val = ld4(row + 16 * t + 4 * g);
+#endif
         x[c][t] = tv == 0 ? tok : val;                     // ray_transformer.py:284-286
         if (!valid[c]) x[c][t] = splat4(0.f);
+      }
+    }
+
+    // colour / mask / direction of this lane's (point, view): fetched now, consumed after the last GEMM
+    f32x4 col[C];
+    float dcomp[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      col[c] = splat4(0.f);
+      dcomp[c] = 0.f;
+      if (valid[c] && tv > 0) {
+        col[c] = ld4(rgbm + ((size_t)pidx[c] * NV + (tv - 1)) * 4);           // r,g,b,mask
+        dcomp[c] = dirs[((size_t)pidx[c] * NV + (tv - 1)) * 4 + g];           // lane group g <- dir[g], 0 for g=3
       }
     }
 
     // ---------------- q,k,v projections (slot layout: lane group g <- heads 2g, 2g+1)
     f32x4 q[C][5], k[C][5], v[C][5];
     zero_tiles(q); zero_tiles(k); zero_tiles(v);
-    gemm_stream<M_VT_Q, C, 1, false, bQ, M_VT_K>(w4, lane, x, q, ring);
-    gemm_stream<M_VT_K, C, 1, false, bK, M_VT_V>(w4, lane, x, k, ring);
-    gemm_stream<M_VT_V, C, 1, false, bV, M_VT_MERGE>(w4, lane, x, v, ring);  // merge weights fly during attention
+    gemm_lds<M_VT_Q, C, kVtWaves>(ws, x, q, wrap);
+    gemm_lds<M_VT_K, C, kVtWaves>(ws, x, k, wrap);
+    gemm_lds<M_VT_V, C, kVtWaves>(ws, x, v, wrap);  // merge weights fly during attention
 
     // ---------------- linear attention over the L tokens of each point (linear_attention.py:31-45)
     f32x4 msg[C][5];
@@ -157,8 +173,10 @@ __global__ void __launch_bounds__(256, 2) view_transformer_kernel(const float* _
     // ---------------- merge + LayerNorm1 (transformer.py:51-52)
     f32x4 m[C][5];
     zero_tiles(m);
-    gemm_stream<M_VT_MERGE, C, 1, false, bM, M_VT_MLP0>(w4, lane, msg, m, ring);
-    layer_norm80<C, V_VT_N1W, V_VT_N1B>(m, w4, g);
+    gemm_lds<M_VT_MERGE, C, kVtWaves>(ws, msg, m, wrap);
+#ifndef UFR_ABL_GEMMONLY
+    layer_norm80<C, V_VT_N1W, V_VT_N1B>(m, ws, g);
+#endif
 
     // ---------------- MLP on [x | message] + LayerNorm2 + residual (transformer.py:55-58)
     f32x4 cat[C][10], hid[C][10], o[C][5];
@@ -167,7 +185,7 @@ __global__ void __launch_bounds__(256, 2) view_transformer_kernel(const float* _
 #pragma unroll
       for (int t = 0; t < 5; ++t) { cat[c][t] = x[c][t]; cat[c][5 + t] = m[c][t]; }
     zero_tiles(hid);
-    gemm_stream<M_VT_MLP0, C, 1, false, b0, M_VT_MLP2>(w4, lane, cat, hid, ring);
+    gemm_lds<M_VT_MLP0, C, kVtWaves>(ws, cat, hid, wrap);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
@@ -175,8 +193,10 @@ __global__ void __launch_bounds__(256, 2) view_transformer_kernel(const float* _
 #pragma unroll
         for (int r = 0; r < 4; ++r) hid[c][t][r] = fmaxf(hid[c][t][r], 0.f);
     zero_tiles(o);
-    gemm_stream<M_VT_MLP2, C, 1, false, b2, M_RW0>(w4, lane, hid, o, ring);
-    layer_norm80<C, V_VT_N2W, V_VT_N2B>(o, w4, g);
+    gemm_lds<M_VT_MLP2, C, kVtWaves>(ws, hid, o, wrap);
+#ifndef UFR_ABL_GEMMONLY
+    layer_norm80<C, V_VT_N2W, V_VT_N2B>(o, ws, g);
+#endif
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
@@ -196,52 +216,49 @@ __global__ void __launch_bounds__(256, 2) view_transformer_kernel(const float* _
       }
     }
 
+#ifndef UFR_ABL_NORAD
     // ---------------- radiance weight MLP on [view feature | dir] (ray_transformer.py:309-314)
     f32x4 rin[C][6], h1[C][1], h2[C][1], lg[C][1];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
 #pragma unroll
       for (int t = 0; t < 5; ++t) rin[c][t] = o[c][t];
-      float dcomp = 0.f;
-      if (valid[c] && tv > 0) dcomp = dirs[((size_t)pidx[c] * NV + (tv - 1)) * 4 + g];  // lane group g <- dir[g], 0 for g=3
-      rin[c][5] = f32x4{dcomp, 0.f, 0.f, 0.f};
-      h1[c][0] = vec_frag<V_RW_B0>(w4, 0, g);
-      h2[c][0] = vec_frag<V_RW_B2>(w4, 0, g);
-      lg[c][0] = vec_frag<V_RW_B4>(w4, 0, g);
+      rin[c][5] = f32x4{dcomp[c], 0.f, 0.f, 0.f};
+      h1[c][0] = vec_frag<V_RW_B0>(ws, 0, g);
+      h2[c][0] = vec_frag<V_RW_B2>(ws, 0, g);
+      lg[c][0] = vec_frag<V_RW_B4>(ws, 0, g);
     }
-    gemm_stream<M_RW0, C, 1, false, bR, -1>(w4, lane, rin, h1, ring);
+    gemm_lds<M_RW0, C, kVtWaves>(ws, rin, h1, wrap);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) h1[c][0][r] = fmaxf(h1[c][0][r], 0.f);
-    gemm<M_RW2, C, 1>(w4, lane, h1, h2);
+    gemm_lds<M_RW2, C, kVtWaves>(ws, h1, h2, wrap);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) h2[c][0][r] = fmaxf(h2[c][0][r], 0.f);
-    gemm<M_RW4, C, 1>(w4, lane, h2, lg);
+    gemm_lds<M_RW4, C, kVtWaves>(ws, h2, lg, wrap);
 
     // ---------------- masked softmax over the NV view tokens + colour blend (ray_transformer.py:315-319)
     // logit of token j sits in lane group 0, register 0; lanes of group 0 do the point-local reduction
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      f32x4 col = splat4(0.f);
-      if (valid[c] && tv > 0) col = ld4(rgbm + ((size_t)pidx[c] * NV + (tv - 1)) * 4);  // r,g,b,mask
       float logit = lg[c][0][0];
-      if (col[3] == 0.f) logit = -1e9f;
+      if (col[c][3] == 0.f) logit = -1e9f;
       if (tv == 0) logit = -INFINITY;  // the view token is not a colour source
       float mx = logit;
 #define UFR_MAX_STEP(S) if (S < L) mx = fmaxf(mx, rot<L, S>(logit, src));
       UFR_MAX_STEP(1) UFR_MAX_STEP(2) UFR_MAX_STEP(3) UFR_MAX_STEP(4) UFR_MAX_STEP(5) UFR_MAX_STEP(6) UFR_MAX_STEP(7)
 #undef UFR_MAX_STEP
       const float e = tv == 0 ? 0.f : expf(logit - mx);
-      float den = e, cr = e * col[0], cg = e * col[1], cb = e * col[2];
+      float den = e, cr = e * col[c][0], cg = e * col[c][1], cb = e * col[c][2];
 #define UFR_SUM_STEP(S)                                                       \
       if (S < L) {                                                            \
         den += rot<L, S>(e, src);                                             \
-        cr += rot<L, S>(e * col[0], src);                                     \
-        cg += rot<L, S>(e * col[1], src);                                     \
-        cb += rot<L, S>(e * col[2], src);                                     \
+        cr += rot<L, S>(e * col[c][0], src);                                  \
+        cg += rot<L, S>(e * col[c][1], src);                                  \
+        cb += rot<L, S>(e * col[c][2], src);                                  \
       }
       UFR_SUM_STEP(1) UFR_SUM_STEP(2) UFR_SUM_STEP(3) UFR_SUM_STEP(4) UFR_SUM_STEP(5) UFR_SUM_STEP(6) UFR_SUM_STEP(7)
 #undef UFR_SUM_STEP
@@ -252,6 +269,7 @@ __global__ void __launch_bounds__(256, 2) view_transformer_kernel(const float* _
         dst[2] = cb / den;
       }
     }
+#endif
   }
 }
 
@@ -261,11 +279,11 @@ static hipError_t launch_vt(const float* packed, const float* x_tokens, const fl
   constexpr int C = 2;
   constexpr int PPW = (16 / L) * C;
   const int n_groups = (P + PPW - 1) / PPW;
-  int blocks = (n_groups + 3) / 4;
-  const int max_blocks = 256 * 2 * 4;  // a few waves per SIMD slot, grid-stride beyond that
+  int blocks = (n_groups + kVtWaves - 1) / kVtWaves;
+  const int max_blocks = 256 * 2;  // two resident workgroups per CU (LDS 2 x 69 KB, 2 waves/SIMD); grid-stride beyond
   if (blocks > max_blocks) blocks = max_blocks;
-  hipLaunchKernelGGL((view_transformer_kernel<L, C>), dim3(blocks), dim3(256), 0, s, packed, x_tokens, rgb, dir, P,
-                     token0, radiance, view_out);
+  hipLaunchKernelGGL((view_transformer_kernel<L, C>), dim3(blocks), dim3(kVtBlock), kStreamLdsBytes, s, packed, x_tokens,
+                     rgb, dir, P, token0, radiance, view_out);
   return hipGetLastError();
 }
 

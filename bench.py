@@ -150,6 +150,15 @@ def main():
         vt_ms = vt["ms"] / max(vt["launches"], 1)
         vt_flop = VIEWT_FLOP_PER_POINT.get(a.views, 0) * vt_pts_per_launch
         achieved = vt_flop / (vt_ms * 1e-3) / 1e12 if vt_ms > 0 else 0.0
+        traffic, traffic_src = None, None
+        try:  # HBM bytes per view-transformer launch from the latest committed PMC pass (profiles/rN_pmc.json)
+            import glob
+            pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))[-1]
+            for k, v in json.load(open(pj)).items():
+                if "view_transformer" in k and v.get("hbm_bytes_per_launch"):
+                    traffic, traffic_src = v["hbm_bytes_per_launch"], os.path.relpath(pj, ROOT)
+        except Exception:  # noqa: BLE001
+            pass
         line = dict(
             metric="rays/s (per-ray volume-rendering path, 64+64 hierarchical samples, DTU-shaped 3-view 512x640)",
             value=rays_per_s, unit="rays/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
@@ -164,8 +173,9 @@ def main():
                         if flop_pt else None,
                         kernel_ms_per_frame_rank0={k: v["ms"] / a.steps for k, v in prof.items()}),
             roofline=dict(bound="mfma", achieved=achieved, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                          frac=achieved / PEAK_FP32_MFMA_TFLOPS, traffic=None, kernel="view_transformer_kernel",
-                          avg_launch_ms=vt_ms, launches=vt["launches"]),
+                          frac=achieved / PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_source=traffic_src,
+                          kernel="view_transformer_kernel", avg_launch_ms=vt_ms, launches=vt["launches"],
+                          algorithmic_flop_per_launch=vt_flop),
         )
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(frame_cpu, weights_cpu, a)

@@ -1,0 +1,89 @@
+"""The host-side mirror of the reference API: state_dict keys (CPU) and infer() parity (GPU)."""
+import argparse
+
+import pytest
+import torch
+
+from helpers import CASES, REL_TOL, border_degenerate_rays, case_inputs, load_weights, max_rel_elem, rel_err
+from uforecon_amd import model as M
+from uforecon_amd import ops
+
+
+def _args(**over):
+    a = dict(extract_geometry=True, test_sample_coarse=64, test_sample_fine=64, coarse_sample=64, fine_sample=64,
+             volume_type="correlation", volume_reso=96, mvs_depth_guide=1, depth_pos_encoding=True,
+             use_dir_srdf=False, explicit_similarity=True, test_coarse_only=False, test_ray_num=800)
+    a.update(over)
+    return argparse.Namespace(**a)
+
+
+def test_state_dict_keys_match_the_reference():
+    """Every per-ray key of the reference checkpoint exists with the same shape (golden weights file =
+    reference state_dict filtered to ray_transformer.* / deviation_network.*)."""
+    ref = load_weights()
+    m = M.UFORecon(_args())
+    sd = m.state_dict()
+    assert set(sd) == set(ref), set(sd) ^ set(ref)
+    for k, v in ref.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+    m.load_state_dict(ref, strict=True)
+    assert set(ops.RAW_WEIGHT_KEYS) <= set(sd)
+
+
+def test_unsupported_configurations_fail_loudly():
+    with pytest.raises(ops.UfrError, match="use_dir_srdf"):
+        M.RayTransformer(args=_args(use_dir_srdf=True))
+    with pytest.raises(ops.UfrError, match="volume_type"):
+        M.RayTransformer(args=_args(volume_type="featuregrid"))
+    m = M.UFORecon(_args())
+    with pytest.raises(ops.UfrError, match="fused"):
+        m.ray_transformer(None, None, None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c2_hier_small", "c1_coarse_only"])
+def test_infer_extract_geometry_matches_golden(name):
+    c = CASES[name]
+    fr, idx, U1, U2, g = case_inputs(name)
+    dev = "cuda:0"
+    m = M.UFORecon(_args(test_coarse_only=c.get("coarse_only", False))).to(dev)
+    m.load_state_dict(load_weights(), strict=True)
+    f = fr.to(dev)
+    with torch.no_grad():
+        srdf, pts, depth, rgb = m.infer(f.batch, idx.to(dev), f.source_imgs_feat, f.feature_volume, extract_geometry=True,
+                                        match_feature=f.match_feature, is_train=False, uniforms=(U1, U2))
+    assert tuple(depth.shape) == (1, c["RN"]) and tuple(rgb.shape) == (1, c["RN"], 3)
+    assert tuple(srdf.shape) == g["srdf"][None].shape and tuple(pts.shape) == g["points"][None].shape
+    assert max_rel_elem(depth[0], g["depth"], 1e-3) < REL_TOL
+    assert rel_err(pts[0], g["points"]) < 1e-5
+    # weights updated in place -> packed copy must follow
+    with torch.no_grad():
+        m.deviation_network.variance.add_(0.05)
+        _, _, depth2, _ = m.infer(f.batch, idx.to(dev), f.source_imgs_feat, f.feature_volume, extract_geometry=True,
+                                  match_feature=f.match_feature, is_train=False, uniforms=(U1, U2))
+    assert float((depth2 - depth).abs().max()) > 1e-5
+
+
+@pytest.mark.gpu
+def test_infer_training_signature_forward_matches_golden():
+    fr, idx, U1, U2, g = case_inputs("c5_train_fwd")
+    dev = "cuda:0"
+    m = M.UFORecon(_args(extract_geometry=False)).to(dev)
+    m.load_state_dict(load_weights(), strict=True)
+    f = fr.to(dev)
+    with torch.no_grad():
+        out = m.infer(f.batch, idx.to(dev), f.source_imgs_feat, f.feature_volume, extract_geometry=False,
+                      match_feature=f.match_feature, uniforms=(U1, U2))
+    names = ["rgb_gt", "rgb", "depth", "depth_gt", "srdf", "opacity", "weight", "points_in_pixel",
+             "rgb_2", "depth_2", "srdf_2", "opacity_2", "weight_2", "points_in_pixel_2", "z_val", "z_val_all", "variance"]
+    assert len(out) == 17
+    got = dict(zip(names, out))
+    for k in ("rgb_gt", "depth_gt", "z_val"):
+        assert rel_err(got[k], g[k]) < 1e-6, k
+    for k in ("depth", "depth_2", "opacity", "opacity_2", "variance"):
+        assert rel_err(got[k], g[k]) < REL_TOL, k
+    for k in ("weight", "srdf"):
+        assert rel_err(got[k], g[k]) < 1e-4, k
+    assert rel_err(got["z_val_all"], g["z_val_all"]) < 1e-5
+    with pytest.raises(ops.UfrError, match="backward"):
+        m.infer(f.batch, idx.to(dev), f.source_imgs_feat, f.feature_volume, match_feature=f.match_feature, uniforms=(U1, U2))

@@ -43,6 +43,7 @@ def parse():
     p.add_argument("--coarse", type=int, default=64)
     p.add_argument("--fine", type=int, default=64)
     p.add_argument("--chunk", type=int, default=0, help="rays per launch group (0 = library default)")
+    p.add_argument("--streams", type=int, default=2, help="side streams the chunks are spread over")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-rays", type=int, default=256)
     p.add_argument("--cpu-calls", type=int, default=5)
@@ -103,7 +104,7 @@ def main():
     shard = RayShard(a.height, a.width, world, rank)        # contiguous row tile of this rank
     ray_idx = shard.ray_indices(dev)
     RN = ray_idx.numel()
-    ws = ops.RenderWorkspace(dev, a.coarse, a.fine, a.views, chunk_rays=a.chunk)
+    ws = ops.RenderWorkspace(dev, a.coarse, a.fine, a.views, chunk_rays=a.chunk, n_streams=a.streams)
     out = dict(depth=torch.empty(RN, device=dev), depth_z=torch.empty(RN, device=dev), rgb=torch.empty(RN, 3, device=dev))
     gathered = None
 
@@ -167,7 +168,7 @@ def main():
             config=dict(workload=f"configs[1]: full {a.height}x{a.width} frame = {HW} rays, {a.views} source views, "
                                  f"{a.coarse}+{a.fine} samples ({pts_per_ray} point evaluations/ray), rays sharded by row "
                                  f"tiles over {world} GPU(s), depth/RGB tiles all-gathered",
-                        rays_per_frame=HW, chunk_rays=chunk, depth_map_ms_per_frame=dt / a.steps * 1e3,
+                        rays_per_frame=HW, chunk_rays=chunk, side_streams=ws.n_streams, depth_map_ms_per_frame=dt / a.steps * 1e3,
                         whole_path_tflops=(rays_per_s * pts_per_ray * flop_pt / 1e12) if flop_pt else None,
                         whole_path_frac_of_fp32_mfma_peak=(rays_per_s * pts_per_ray * flop_pt / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world))
                         if flop_pt else None,

@@ -172,7 +172,9 @@ typedef struct ufr_render_args {
   float* srdf;                /* (RN,S) S = SN or SN+PN, may be NULL                        */
   float* z_all;               /* (RN,S) sample distances of the returned pass, may be NULL  */
   int32_t chunk_rays;         /* rays per internal launch group (0 = library default)       */
-  void* workspace;            /* >= ufr_render_workspace_bytes(chunk_rays,SN,PN,NV)         */
+  int32_t n_streams;          /* >1: chunks are issued round-robin on that many library-owned side streams
+                                 (forked from / joined to `stream`); needs n_streams x the workspace   */
+  void* workspace;            /* >= ufr_render_workspace_bytes(chunk_rays,SN,PN,NV) (x n_streams)     */
   size_t workspace_bytes;
 } ufr_render_args;
 

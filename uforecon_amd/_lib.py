@@ -50,7 +50,7 @@ class RenderArgs(C.Structure):
                 ("U1", fptr), ("U2", fptr), ("RN", C.c_int32), ("SN", C.c_int32), ("PN", C.c_int32),
                 ("coarse_only", C.c_int32),
                 ("depth", fptr), ("depth_z", fptr), ("rgb", fptr), ("srdf", fptr), ("z_all", fptr),
-                ("chunk_rays", C.c_int32), ("workspace", fptr), ("workspace_bytes", C.c_size_t)]
+                ("chunk_rays", C.c_int32), ("n_streams", C.c_int32), ("workspace", fptr), ("workspace_bytes", C.c_size_t)]
 
 
 # name -> (restype, argtypes); every symbol include/ufr.h declares

@@ -323,6 +323,87 @@ size_t ufr_render_workspace_bytes(int32_t chunk_rays, int32_t SN, int32_t PN, in
   return carve_render(nullptr, chunk_rays, SN, PN, NV).bytes;
 }
 
+namespace {
+// Side streams: consecutive ray chunks are independent, so they are issued round-robin on a few
+// library-owned HIP streams -- the gather kernel of one chunk (L2/latency-bound, no MFMA) then runs
+// beside the transformer kernels of another (MFMA-bound) instead of in front of them.
+constexpr int kMaxLanes = 4;
+struct SidePool {
+  hipStream_t s[kMaxLanes] = {};
+  hipEvent_t fork = nullptr, join[kMaxLanes] = {};
+  int n = 0;
+};
+thread_local SidePool g_side;
+
+int side_pool_init(int n) {
+  if (!g_side.fork) UFR_HIP(hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming));
+  for (; g_side.n < n; ++g_side.n) {
+    UFR_HIP(hipStreamCreateWithFlags(&g_side.s[g_side.n], hipStreamNonBlocking));
+    UFR_HIP(hipEventCreateWithFlags(&g_side.join[g_side.n], hipEventDisableTiming));
+  }
+  return UFR_OK;
+}
+
+// one chunk of R rays starting at r0, entirely on stream s with workspace w
+int render_chunk(const ufr_render_args* a, const FrameDev* f, const RenderWs& w, bool& pe_ready, int r0, int R,
+                 hipStream_t s) {
+  const int RN = a->RN, SN = a->SN, PN = a->coarse_only ? 0 : a->PN, NV = f->NV;
+  const PreSim ps = presim_of(a->raw);
+  const int S2 = SN + PN, HW = f->H * f->W;
+  {
+    ProfScope p("sampler", s);
+    UFR_HIP(launch_ray_setup(a->ray_idx + r0, a->ray_d, a->cam_ray_d, HW, a->near_z, a->far_z, R, w.rd, w.near, w.far,
+                             w.camz, a->ray_o, w.ray_o, s));
+    UFR_HIP(launch_sample_fixed(w.near, w.far, a->U1 + r0, RN, w.z1, R, SN, s));
+    if (!pe_ready) {
+      UFR_HIP(launch_order_pe(w.pe1, SN, s));
+      if (!a->coarse_only) UFR_HIP(launch_order_pe(w.pe2, S2, s));
+      pe_ready = true;
+    }
+  }
+  // ---- coarse pass (model.py:445)
+  {
+    ProfScope p("gather", s);
+    UFR_HIP(launch_gather(*f, ps, w.ray_o, 0, w.rd, w.z1, R, SN, w.x, w.rgbm, w.dir, nullptr, nullptr, nullptr, nullptr, s));
+  }
+  int rc = aggregate_impl(a->packed_weights, w.x, w.rgbm, w.dir, R, SN, NV, w.rad, w.srdf1, w.token0, w.pe1, true,
+                          nullptr, nullptr, s);
+  if (rc != UFR_OK) return rc;
+  const bool last = a->coarse_only != 0;
+  {
+    ProfScope p("composite", s);
+    UFR_HIP(launch_composite(w.z1, w.rad, w.srdf1, a->raw->variance, R, SN, last ? a->rgb + 3 * (size_t)r0 : w.rgb1,
+                             last ? a->depth + r0 : w.depth1, nullptr, w.w1, w.camz,
+                             (last && a->depth_z) ? a->depth_z + r0 : nullptr, s));
+  }
+  if (last) {
+    if (a->srdf) UFR_HIP(hipMemcpyAsync(a->srdf + (size_t)r0 * SN, w.srdf1, (size_t)R * SN * 4, hipMemcpyDeviceToDevice, s));
+    if (a->z_all) UFR_HIP(hipMemcpyAsync(a->z_all + (size_t)r0 * SN, w.z1, (size_t)R * SN * 4, hipMemcpyDeviceToDevice, s));
+    return UFR_OK;
+  }
+  // ---- importance sampling + merge (model.py:455-470), fine pass (model.py:472)
+  {
+    ProfScope p("sampler", s);
+    UFR_HIP(launch_importance_merge(w.w1, w.z1, a->U2 + r0, RN, nullptr, w.z2, R, SN, PN, s));
+  }
+  {
+    ProfScope p("gather", s);
+    UFR_HIP(launch_gather(*f, ps, w.ray_o, 0, w.rd, w.z2, R, S2, w.x, w.rgbm, w.dir, nullptr, nullptr, nullptr, nullptr, s));
+  }
+  rc = aggregate_impl(a->packed_weights, w.x, w.rgbm, w.dir, R, S2, NV, w.rad, w.srdf2, w.token0, w.pe2, true, nullptr,
+                      nullptr, s);
+  if (rc != UFR_OK) return rc;
+  {
+    ProfScope p("composite", s);
+    UFR_HIP(launch_composite(w.z2, w.rad, w.srdf2, a->raw->variance, R, S2, a->rgb + 3 * (size_t)r0, a->depth + r0,
+                             nullptr, nullptr, w.camz, a->depth_z ? a->depth_z + r0 : nullptr, s));
+  }
+  if (a->srdf) UFR_HIP(hipMemcpyAsync(a->srdf + (size_t)r0 * S2, w.srdf2, (size_t)R * S2 * 4, hipMemcpyDeviceToDevice, s));
+  if (a->z_all) UFR_HIP(hipMemcpyAsync(a->z_all + (size_t)r0 * S2, w.z2, (size_t)R * S2 * 4, hipMemcpyDeviceToDevice, s));
+  return UFR_OK;
+}
+}  // namespace
+
 int ufr_render_rays(const ufr_render_args* a, ufr_stream stream) {
   UFR_REQUIRE(a, "ufr_render_rays: null args");
   const FrameDev* f = frame_of(a->frame);
@@ -339,63 +420,38 @@ int ufr_render_rays(const ufr_render_args* a, ufr_stream stream) {
   const size_t need = ufr_render_workspace_bytes(chunk, SN, PN, NV);
   if (a->workspace_bytes < need) return fail(UFR_ERR_WORKSPACE, "render workspace too small: %zu < %zu", a->workspace_bytes, need);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  RenderWs w = carve_render(a->workspace, chunk, SN, PN, NV);
-  const PreSim ps = presim_of(a->raw);
-  const int S2 = SN + PN, HW = f->H * f->W;
-  bool pe_ready = false;
+  const int n_chunks = (RN + chunk - 1) / chunk;
+  int lanes = a->n_streams > 1 ? a->n_streams : 1;
+  if (lanes > kMaxLanes) lanes = kMaxLanes;
+  if ((size_t)lanes * need > a->workspace_bytes) lanes = (int)(a->workspace_bytes / need);  // one workspace per lane
+  if (lanes > n_chunks) lanes = n_chunks;
 
-  for (int r0 = 0; r0 < RN; r0 += chunk) {
-    const int R = (RN - r0) < chunk ? (RN - r0) : chunk;
-    {
-      ProfScope p("sampler", s);
-      UFR_HIP(launch_ray_setup(a->ray_idx + r0, a->ray_d, a->cam_ray_d, HW, a->near_z, a->far_z, R, w.rd, w.near, w.far,
-                               w.camz, a->ray_o, w.ray_o, s));
-      UFR_HIP(launch_sample_fixed(w.near, w.far, a->U1 + r0, RN, w.z1, R, SN, s));
-      if (!pe_ready) {
-        UFR_HIP(launch_order_pe(w.pe1, SN, s));
-        if (!a->coarse_only) UFR_HIP(launch_order_pe(w.pe2, S2, s));
-        pe_ready = true;
-      }
+  if (lanes <= 1) {
+    RenderWs w = carve_render(a->workspace, chunk, SN, PN, NV);
+    bool pe_ready = false;
+    for (int r0 = 0; r0 < RN; r0 += chunk) {
+      int rc = render_chunk(a, f, w, pe_ready, r0, (RN - r0) < chunk ? (RN - r0) : chunk, s);
+      if (rc != UFR_OK) return rc;
     }
-    // ---- coarse pass (model.py:445)
-    {
-      ProfScope p("gather", s);
-      UFR_HIP(launch_gather(*f, ps, w.ray_o, 0, w.rd, w.z1, R, SN, w.x, w.rgbm, w.dir, nullptr, nullptr, nullptr, nullptr, s));
-    }
-    int rc = aggregate_impl(a->packed_weights, w.x, w.rgbm, w.dir, R, SN, NV, w.rad, w.srdf1, w.token0, w.pe1, true,
-                            nullptr, nullptr, s);
+    return UFR_OK;
+  }
+  int rc = side_pool_init(lanes);
+  if (rc != UFR_OK) return rc;
+  UFR_HIP(hipEventRecord(g_side.fork, s));
+  RenderWs w[kMaxLanes];
+  bool pe_ready[kMaxLanes] = {};
+  for (int l = 0; l < lanes; ++l) {
+    w[l] = carve_render(static_cast<char*>(a->workspace) + (size_t)l * need, chunk, SN, PN, NV);
+    UFR_HIP(hipStreamWaitEvent(g_side.s[l], g_side.fork, 0));
+  }
+  for (int c = 0; c < n_chunks; ++c) {
+    const int l = c % lanes, r0 = c * chunk;
+    rc = render_chunk(a, f, w[l], pe_ready[l], r0, (RN - r0) < chunk ? (RN - r0) : chunk, g_side.s[l]);
     if (rc != UFR_OK) return rc;
-    const bool last = a->coarse_only != 0;
-    {
-      ProfScope p("composite", s);
-      UFR_HIP(launch_composite(w.z1, w.rad, w.srdf1, a->raw->variance, R, SN, last ? a->rgb + 3 * (size_t)r0 : w.rgb1,
-                               last ? a->depth + r0 : w.depth1, nullptr, w.w1, w.camz,
-                               (last && a->depth_z) ? a->depth_z + r0 : nullptr, s));
-    }
-    if (last) {
-      if (a->srdf) UFR_HIP(hipMemcpyAsync(a->srdf + (size_t)r0 * SN, w.srdf1, (size_t)R * SN * 4, hipMemcpyDeviceToDevice, s));
-      if (a->z_all) UFR_HIP(hipMemcpyAsync(a->z_all + (size_t)r0 * SN, w.z1, (size_t)R * SN * 4, hipMemcpyDeviceToDevice, s));
-      continue;
-    }
-    // ---- importance sampling + merge (model.py:455-470), fine pass (model.py:472)
-    {
-      ProfScope p("sampler", s);
-      UFR_HIP(launch_importance_merge(w.w1, w.z1, a->U2 + r0, RN, nullptr, w.z2, R, SN, PN, s));
-    }
-    {
-      ProfScope p("gather", s);
-      UFR_HIP(launch_gather(*f, ps, w.ray_o, 0, w.rd, w.z2, R, S2, w.x, w.rgbm, w.dir, nullptr, nullptr, nullptr, nullptr, s));
-    }
-    rc = aggregate_impl(a->packed_weights, w.x, w.rgbm, w.dir, R, S2, NV, w.rad, w.srdf2, w.token0, w.pe2, true, nullptr,
-                        nullptr, s);
-    if (rc != UFR_OK) return rc;
-    {
-      ProfScope p("composite", s);
-      UFR_HIP(launch_composite(w.z2, w.rad, w.srdf2, a->raw->variance, R, S2, a->rgb + 3 * (size_t)r0, a->depth + r0,
-                               nullptr, nullptr, w.camz, a->depth_z ? a->depth_z + r0 : nullptr, s));
-    }
-    if (a->srdf) UFR_HIP(hipMemcpyAsync(a->srdf + (size_t)r0 * S2, w.srdf2, (size_t)R * S2 * 4, hipMemcpyDeviceToDevice, s));
-    if (a->z_all) UFR_HIP(hipMemcpyAsync(a->z_all + (size_t)r0 * S2, w.z2, (size_t)R * S2 * 4, hipMemcpyDeviceToDevice, s));
+  }
+  for (int l = 0; l < lanes; ++l) {
+    UFR_HIP(hipEventRecord(g_side.join[l], g_side.s[l]));
+    UFR_HIP(hipStreamWaitEvent(s, g_side.join[l], 0));
   }
   return UFR_OK;
 }

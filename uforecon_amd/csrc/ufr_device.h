@@ -43,7 +43,14 @@ __device__ __forceinline__ float rot(float x, const int (&src)[8]) {
   }
 }
 
+// elu(x)+1 (linear_attention.py:10-11).  The negative branch is exp(x) in (0,1]: v_exp_f32 on
+// x*log2(e) (rel. error ~|x| 2^-24, i.e. < 1e-6 for the |x| < 16 that matter) instead of the
+// 15-instruction ocml expf -- 80 of them per view-transformer iteration.
+#ifdef UFR_ACCURATE_EXP
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x + 1.f : expf(x); }
+#else
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x + 1.f : __expf(x); }
+#endif
 
 // sum over the 4 lane groups (lanes l, l^16, l^32, l^48)
 __device__ __forceinline__ float sum_groups(float x) {

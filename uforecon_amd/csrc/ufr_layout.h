@@ -122,7 +122,10 @@ enum Stream : int { S_VT = 0, S_RT1, S_RT2, S_COUNT };
 constexpr int kChunkMaxFrags = 32;  // LDS slot = 32 KiB; two slots per workgroup
 
 __host__ __device__ constexpr int stream_len(int s) { return s == S_VT ? 9 : (s == S_RT1 ? 2 : 7); }
-__host__ __device__ constexpr int stream_ot(int s) { return s == S_VT ? 1 : 2; }  // out tiles interleaved per stage
+#ifndef UFR_VT_OT
+#define UFR_VT_OT 1
+#endif
+__host__ __device__ constexpr int stream_ot(int s) { return s == S_VT ? UFR_VT_OT : 2; }  // out tiles interleaved per stage
 __host__ __device__ constexpr int stream_chunks(int s) { return s == S_RT1 ? 4 : 10; }  // even: static slot parity
 __host__ __device__ constexpr int stream_mat(int s, int i) {
   switch (s) {
@@ -146,7 +149,8 @@ __host__ __device__ constexpr int stream_mat_start(int s, int i) {
 }
 __host__ __device__ constexpr int stream_frags(int s) { return stream_mat_start(s, stream_len(s)); }
 // streams are zero-padded to a multiple of 4 fragments so that chunks split evenly over the 4 fetching waves
-__host__ __device__ constexpr int stream_frags_padded(int s) { return (stream_frags(s) + 3) / 4 * 4; }
+constexpr int kFetchSplit = 8;  // chunk sizes are multiples of this: 4- and 8-wave workgroups split a fetch evenly
+__host__ __device__ constexpr int stream_frags_padded(int s) { return (stream_frags(s) + kFetchSplit - 1) / kFetchSplit * kFetchSplit; }
 __host__ __device__ constexpr int stream_base_floats(int s) {
   int o = 0;
   for (int t = 0; t < s; ++t) o += stream_frags_padded(t) * 256;
@@ -163,7 +167,8 @@ __host__ __device__ constexpr int frag_in_mat(int m, int ot, int to, int ti) {
 // chunk boundaries (in fragments): nearly equal, multiples of 4 (one quarter per fetching wave; never
 // splits the two fragments of an OT=2 stage)
 __host__ __device__ constexpr int chunk_begin(int s, int c) {
-  return c >= stream_chunks(s) ? stream_frags_padded(s) : ((c * stream_frags_padded(s) / stream_chunks(s)) / 4) * 4;
+  return c >= stream_chunks(s) ? stream_frags_padded(s)
+                               : ((c * stream_frags_padded(s) / stream_chunks(s)) / kFetchSplit) * kFetchSplit;
 }
 __host__ __device__ constexpr int chunk_of(int s, int f) {
   int c = 0;

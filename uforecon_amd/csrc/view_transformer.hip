@@ -51,11 +51,16 @@ __device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const WStream& ws
 
 // 256-thread workgroups (one wave per SIMD), two per CU; each streams the layer chain's weights through
 // its own pair of LDS slots (weight_stream.h), so L2 sees every fragment once per workgroup iteration.
-constexpr int kVtBlock = 256;
+#ifndef UFR_VT_BLOCK
+#define UFR_VT_BLOCK 256   // threads per workgroup
+#define UFR_VT_C 2         // token column tiles per wave
+#define UFR_VT_MINW 2      // waves per SIMD the register budget is sized for
+#endif
+constexpr int kVtBlock = UFR_VT_BLOCK;
 constexpr int kVtWaves = kVtBlock / 64;
 
 template <int L, int C>
-__global__ void __launch_bounds__(kVtBlock, 2) view_transformer_kernel(const float* __restrict__ packed,
+__global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel(const float* __restrict__ packed,
                                                                    const float* __restrict__ x_tokens,
                                                                    const float* __restrict__ rgbm,
                                                                    const float* __restrict__ dirs, int P,
@@ -145,7 +150,8 @@ __global__ void __launch_bounds__(kVtBlock, 2) view_transformer_kernel(const flo
           const int s = 10 * hh + d;
           Q[d] = elu1(q[c][s >> 2][s & 3]);
           K[d] = elu1(k[c][s >> 2][s & 3]);
-          V[d] = v[c][s >> 2][s & 3] / (float)L;             // values / v_length
+          // values / v_length: exact as a multiply when L is a power of two (NV = 3, 7)
+          V[d] = (L & (L - 1)) == 0 ? v[c][s >> 2][s & 3] * (1.f / (float)L) : v[c][s >> 2][s & 3] / (float)L;
           acc[d] = 0.f;
         }
         float den = 0.f;
@@ -276,11 +282,11 @@ __global__ void __launch_bounds__(kVtBlock, 2) view_transformer_kernel(const flo
 template <int L>
 static hipError_t launch_vt(const float* packed, const float* x_tokens, const float* rgb, const float* dir, int P,
                             float* token0, float* radiance, float* view_out, hipStream_t s) {
-  constexpr int C = 2;
+  constexpr int C = UFR_VT_C;
   constexpr int PPW = (16 / L) * C;
   const int n_groups = (P + PPW - 1) / PPW;
   int blocks = (n_groups + kVtWaves - 1) / kVtWaves;
-  const int max_blocks = 256 * 2;  // two resident workgroups per CU (LDS 2 x 69 KB, 2 waves/SIMD); grid-stride beyond
+  const int max_blocks = 256 * 2;  // two resident workgroups per CU (LDS 2 x 69 KB); grid-stride beyond
   if (blocks > max_blocks) blocks = max_blocks;
   hipLaunchKernelGGL((view_transformer_kernel<L, C>), dim3(blocks), dim3(kVtBlock), kStreamLdsBytes, s, packed, x_tokens,
                      rgb, dir, P, token0, radiance, view_out);

@@ -84,6 +84,14 @@ __device__ __forceinline__ void wstream_fetch(const WStream& ws) {
 // open chunk CHK: own DMA landed -> barrier -> start fetching chunk CHK+1 (wrapping to chunk 0 when `wrap`)
 template <int S, int NWAVES, int CHK>
 __device__ __forceinline__ void wstream_open(const WStream& ws, bool wrap) {
+#ifdef UFR_ABL_NOBARRIER  // ablation build: no chunk hand-off at all (weights are garbage, timing only)
+  (void)ws; (void)wrap;
+  return;
+#endif
+#ifdef UFR_ABL_NODMA      // ablation build: barrier but no fetch
+  __syncthreads();
+  return;
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if constexpr (CHK + 1 < stream_chunks(S)) {
@@ -161,6 +169,12 @@ __device__ __forceinline__ void gemm_lds(const WStream& ws, const f32x4 (&in)[C]
                                 : mfma16(ring[slot][o][r], in[c][ti][r], out[c][to + o]);
       }
     }
+    // pin this stage's MFMAs here: they are pure, so IR-level sinking may otherwise drift them past the
+    // following stages' LDS reads (seen at C = 1: fragments read, spilled, consumed hundreds of lines later)
+#pragma unroll
+    for (int o = 0; o < no; ++o)
+#pragma unroll
+      for (int c = 0; c < C; ++c) asm volatile("" : "+v"(out[c][to + o]));
   });
   __builtin_amdgcn_sched_barrier(0);
 }

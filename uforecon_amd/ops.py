@@ -238,11 +238,12 @@ def composite(z: torch.Tensor, radiance: torch.Tensor, srdf: torch.Tensor, varia
 class RenderWorkspace:
     """Reusable scratch of ufr_render_rays (sized for `chunk_rays`)."""
 
-    def __init__(self, device, SN: int, PN: int, NV: int, chunk_rays: int = 0):
+    def __init__(self, device, SN: int, PN: int, NV: int, chunk_rays: int = 0, n_streams: int = 2):
         lib = _lib.load()
         self.chunk = chunk_rays if chunk_rays > 0 else lib.ufr_default_chunk_rays()
+        self.n_streams = max(1, int(n_streams))
         self.key = (SN, PN, NV, self.chunk)
-        self.nbytes = lib.ufr_render_workspace_bytes(self.chunk, SN, PN, NV)
+        self.nbytes = lib.ufr_render_workspace_bytes(self.chunk, SN, PN, NV) * self.n_streams
         self.buf = torch.empty(self.nbytes // 4, dtype=torch.float32, device=device)
 
 
@@ -282,6 +283,7 @@ def render_rays(frame: FrameHandle, weights: PackedWeights, ray_idx: torch.Tenso
     a.srdf = _opt(srdf, "srdf")
     a.z_all = _opt(z_all, "z_all")
     a.chunk_rays = workspace.chunk
+    a.n_streams = workspace.n_streams
     a.workspace, a.workspace_bytes = workspace.buf.data_ptr(), workspace.nbytes
     _lib.check(_lib.load().ufr_render_rays(C.byref(a), _stream()), "ufr_render_rays")
     return dict(depth=depth, depth_z=depth_z, rgb=rgb, srdf=srdf, z_all=z_all, workspace=workspace)

@@ -91,7 +91,7 @@ NAME2IDX = {m[0]: i for i, m in enumerate(MATS)}
 
 def stream_frags_padded(si):
     n = sum(MATS[NAME2IDX[m]][3] * MATS[NAME2IDX[m]][4] for m in STREAMS[si][0])
-    return (n + 3) // 4 * 4
+    return (n + 7) // 8 * 8  # kFetchSplit of ufr_layout.h
 
 
 def vec_region_offset():

@@ -169,3 +169,70 @@ def from_tiles_swapped(acc, rm, out_dim):
                 for r in range(4):
                     y[4 * (lane >> 4) + r, row] = acc[to, lane, r]
     return y
+
+
+# ------------------------------------------------------------------ bf16x6 path (ufr_layout_bf.h, weight_stream_bf.h)
+def bf16_rne(x):
+    u = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+
+
+def split3(x):
+    """exact 3-way bf16 split (planes returned as float32 values with 16 low zero bits)."""
+    x = np.asarray(x, np.float32)
+    h = bf16_rne(x)
+    r = (x - h).astype(np.float32)
+    m = bf16_rne(r)
+    lo = bf16_rne((r - m).astype(np.float32))
+    return h, m, lo
+
+
+def vt_panels():
+    """(matrix name, k-step) in stream order (ufr_layout_bf.h:vt_panel)."""
+    p = []
+    for s in range(3):
+        p += [("VT_Q", s), ("VT_K", s)]
+    p += [("VT_V", s) for s in range(3)] + [("VT_MERGE", s) for s in range(3)]
+    p += [("VT_MLP0", s) for s in range(5)] + [("VT_MLP2", s) for s in range(5)]
+    p += [("RW0", s) for s in range(3)] + [("RW2", 0), ("RW4", 0)]
+    return p
+
+
+def panel_start(name, s):
+    off = 0
+    for n, k in vt_panels():
+        if (n, k) == (name, s):
+            return off
+        off += MATS[NAME2IDX[n]][3] * 3
+    raise KeyError((name, s))
+
+
+def mfma_bf16(a, b, acc):
+    """v_mfma_f32_16x16x32_bf16: a, b (64,8) lane operands (lane l: A[l&15][8(l>>4)+i], B[8(l>>4)+i][l&15])."""
+    A = np.zeros((16, 32), np.float64)
+    B = np.zeros((32, 16), np.float64)
+    for i in range(8):
+        A[J, 8 * G + i] = a[:, i]
+        B[8 * G + i, J] = b[:, i]
+    D = A @ B
+    out = acc.astype(np.float64).copy()
+    for r in range(4):
+        out[:, r] += D[4 * G + r, J]
+    return out.astype(np.float32)  # the accumulator is fp32
+
+
+def gemm_bf(bf_blob, name, tiles_in):
+    """tiles_in (n_in,64,4) fp32 accumulator tiles of the producer -> (n_out,64,4)."""
+    idx = NAME2IDX[name]
+    n_out, n_in = MATS[idx][3], MATS[idx][4]
+    out = np.zeros((n_out, 64, 4), np.float32)
+    zero = np.zeros((64, 4), np.float32)
+    for s in range((n_in + 1) // 2):
+        ta, tb = tiles_in[2 * s], (tiles_in[2 * s + 1] if 2 * s + 1 < n_in else zero)
+        xb = [np.concatenate([pa, pb], axis=1) for pa, pb in zip(split3(ta), split3(tb))]  # per plane (64,8)
+        f0 = panel_start(name, s)
+        for to in range(n_out):
+            a = [bf_blob[(f0 + to * 3 + p) * 512:(f0 + to * 3 + p + 1) * 512].reshape(64, 8) for p in range(3)]
+            for pa, pb in ((1, 1), (0, 2), (2, 0), (0, 1), (1, 0), (0, 0)):
+                out[to] = mfma_bf16(a[pa], xb[pb], out[to])
+    return out

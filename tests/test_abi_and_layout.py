@@ -40,7 +40,9 @@ def test_every_declared_symbol_is_exported(lib):
 def test_struct_sizes_match_the_header(lib):
     assert C.sizeof(_lib.RawWeights) == 40 * 8
     assert C.sizeof(_lib.Frame) == 160 * 8
-    assert lib.ufr_packed_weights_bytes() == 4 * (E.vec_region_offset() + 16 * (5 * 4 + 6 * 4 + 2 + 5 + 5))
+    assert lib.ufr_packed_fp32_floats() == E.vec_region_offset() + 16 * (5 * 4 + 6 * 4 + 2 + 5 + 5)
+    assert lib.ufr_packed_weights_bytes() == 4 * lib.ufr_packed_fp32_floats() + 2 * lib.ufr_packed_bf16_halfwords()
+    assert lib.ufr_packed_bf16_halfwords() % (24 * 512) == 0  # whole 24 KiB chunks
 
 
 def test_argument_errors_are_reported_not_fatal(lib):
@@ -68,7 +70,7 @@ def test_missing_gpu_is_loud():
 
 @pytest.fixture(scope="module")
 def plan(lib):
-    n = lib.ufr_packed_weights_bytes() // 4
+    n = lib.ufr_packed_fp32_floats()
     pid = np.zeros(n, np.int32)
     el = np.zeros(n, np.int32)
     assert lib.ufr_pack_plan(pid.ctypes.data_as(C.POINTER(C.c_int32)), el.ctypes.data_as(C.POINTER(C.c_int32))) == 0
@@ -164,3 +166,45 @@ def test_ray_attention_dataflow_in_mfma_form(raw_and_blob):
                     v = 4 * (lane >> 4) + r
                     if v < 11:
                         assert abs(msg[lane, r] - ref[16 * tile + (lane & 15), h, v]) < 1e-9
+
+
+# ------------------------------------------------------------------ bf16x6 region (split-precision MFMA path)
+@pytest.fixture(scope="module")
+def bf_blob(lib, raw_and_blob):
+    raw, _ = raw_and_blob
+    n = lib.ufr_packed_bf16_halfwords()
+    pid, el, pl = (np.zeros(n, np.int32) for _ in range(3))
+    P32 = C.POINTER(C.c_int32)
+    assert lib.ufr_pack_plan_bf16(pid.ctypes.data_as(P32), el.ctypes.data_as(P32), pl.ctypes.data_as(P32)) == 0
+    planes = {p: E.split3(raw[p].astype(np.float32)) for p in np.unique(pid) if p >= 0}
+    blob = np.zeros(n, np.float32)
+    for p, sp in planes.items():
+        for k in range(3):
+            sel = (pid == p) & (pl == k)
+            blob[sel] = sp[k].reshape(-1)[el[sel]]
+    return blob
+
+
+def test_bf16_split_is_exact():
+    x = np.random.default_rng(1).standard_normal(10000).astype(np.float32) * np.float32(37.0)
+    h, m, l = E.split3(x)
+    assert np.array_equal((h.astype(np.float64) + m + l).astype(np.float32), x)
+    for p in (h, m, l):  # every plane is a bf16 number (low 16 bits clear)
+        assert not (p.view(np.uint32) & 0xFFFF).any()
+
+
+@pytest.mark.parametrize("name", ["VT_Q", "VT_K", "VT_V", "VT_MERGE", "VT_MLP0", "VT_MLP2", "RW0", "RW2", "RW4"])
+def test_bf16x6_panels_reproduce_linear(name, raw_and_blob, bf_blob):
+    """The exported bf16 plan, pushed through a lane-level model of v_mfma_f32_16x16x32_bf16 with the six
+    plane pairs of csrc/weight_stream_bf.h, reproduces y = W x to fp32 accuracy for every matrix of the chain."""
+    raw, _ = raw_and_blob
+    idx = E.NAME2IDX[name]
+    _, param, k_raw, n_out, n_in, rm, cm, out_dim, in_dim = E.MATS[idx]
+    W = raw[param].reshape(out_dim, k_raw).astype(np.float32)
+    x = np.random.default_rng(200 + idx).standard_normal((16, in_dim)).astype(np.float32)
+    tiles = E.to_tiles(x, cm, n_in, in_dim).astype(np.float32)
+    acc = E.gemm_bf(bf_blob, name, tiles)
+    y, pad = E.from_tiles(acc, rm, out_dim)
+    ref = x.astype(np.float64) @ W[:, :in_dim].astype(np.float64).T
+    assert pad == 0.0
+    assert np.abs(y - ref).max() / np.abs(ref).max() < 5e-7, name

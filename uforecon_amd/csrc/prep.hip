@@ -3,6 +3,7 @@
 // texel: 48 B, rgb: 16 B).  HBM-bound streaming kernels, run once per frame
 // (the reference keeps NCHW and lets F.grid_sample stride over channels, model.py:251,370).
 #include "ufr_internal.h"
+#include "ufr_layout_bf.h"
 
 namespace ufr {
 
@@ -71,9 +72,34 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(RawPtrs raw, float* _
   packed[i] = p >= 0 ? raw.p[p][e] : 0.f;
 }
 
+// bf16 region (ufr_layout_bf.h): halfword h = plane p of raw[param][elem], planes from the exact 3-way split
+// w = hi + mid + lo with round-to-nearest-even at every level
+__device__ __forceinline__ unsigned short bf16_rne(float x) {
+  unsigned u = __builtin_bit_cast(unsigned, x);
+  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__global__ void __launch_bounds__(256) pack_weights_bf16_kernel(RawPtrs raw, unsigned short* __restrict__ packed, int n) {
+  int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= n) return;
+  int p, e, plane;
+  plan_entry_bf(h, &p, &e, &plane);
+  unsigned short out = 0;
+  if (p >= 0) {
+    float w = raw.p[p][e];
+    unsigned short hi = bf16_rne(w);
+    w -= __builtin_bit_cast(float, (unsigned)hi << 16);
+    unsigned short mid = bf16_rne(w);
+    w -= __builtin_bit_cast(float, (unsigned)mid << 16);
+    out = plane == 0 ? hi : (plane == 1 ? mid : bf16_rne(w));
+  }
+  packed[h] = out;
+}
+
 hipError_t launch_pack_weights(const RawPtrs& raw, float* packed, hipStream_t s) {
   const int n = blob_floats();
   hipLaunchKernelGGL(pack_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, s, raw, packed, n);
+  unsigned short* bf = reinterpret_cast<unsigned short*>(packed + n);
+  hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((kVtbHalfwords + 255) / 256), dim3(256), 0, s, raw, bf, kVtbHalfwords);
   return hipGetLastError();
 }
 

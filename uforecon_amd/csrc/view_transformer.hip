@@ -4,14 +4,16 @@
 //   LoFTREncoderLayer.forward   code1/attention/transformer.py:35-58   (bias-free Linear, post-norm message)
 //   LinearAttention.forward     code1/attention/linear_attention.py:20-47
 //
-// MI355X mapping: tokens are the 16 columns of v_mfma_f32_16x16x4_f32; a wave owns C column tiles
-// (PPT = 16/L points each, L = NV+1 tokens per point).  Activations never leave registers: the
-// accumulator tile of a layer is the B operand of the next (ufr_layout.h), weights stream from L2
-// as 1 KiB A-fragment groups shared by the C tiles.  Q/K/V rows are permuted so lane group g holds
-// heads 2g,2g+1 of its token, and the 4-token attention is done lane-locally with quad DPP
-// exchanges (L = 4) or ds_bpermute (other L).  fp32 throughout (exact-f32 MFMA).
+// MI355X mapping: tokens are the 16 MFMA columns; a wave owns C column tiles (PPT = 16/L points each,
+// L = NV+1 tokens per point).  Activations never leave registers: the fp32 accumulator tiles of a
+// layer, split exactly into three bf16 planes, are the B operands of the next layer's
+// v_mfma_f32_16x16x32_bf16 ("bf16x6": six plane pairs per product, fp32-grade accuracy on the bf16
+// matrix cores -- ufr_layout_bf.h); the weight planes stream through LDS (weight_stream_bf.h).  Q/K/V
+// rows are permuted so lane group g holds heads 2g,2g+1 of its token, and the L-token attention is
+// lane-local with quad DPP exchanges (L = 4) or ds_bpermute (other L).  LayerNorm, attention, elu and
+// the softmax run on the VALU and overlap with the other resident wave's MFMAs.
 #include "ufr_internal.h"
-#include "weight_stream.h"
+#include "weight_stream_bf.h"
 
 namespace ufr {
 
@@ -25,7 +27,7 @@ __device__ __forceinline__ void zero_tiles(f32x4 (&t)[C][N]) {
 
 // LayerNorm over the 80 features of each token: 5 tiles x 4 regs in each of the 4 lane groups.
 template <int C, int VW, int VB>
-__device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const WStream& ws, int g) {
+__device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const WStreamBf& ws, int g) {
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     float s = 0.f;
@@ -49,8 +51,25 @@ __device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const WStream& ws
   }
 }
 
-// 256-thread workgroups (one wave per SIMD), two per CU; each streams the layer chain's weights through
-// its own pair of LDS slots (weight_stream.h), so L2 sees every fragment once per workgroup iteration.
+// out += W_M x in over all k-steps of M: in[c][0..NIN) are the producer's fp32 accumulator tiles
+template <int M, int C, int NWAVES, int NIN>
+__device__ __forceinline__ void gemm_bf(WStreamBf& ws, const f32x4 (&in)[C][NIN], f32x4 (&out)[C][mat_desc(M).n_out],
+                                        bool wrap) {
+  static_assert(NIN == mat_desc(M).n_in, "input tile count");
+  static_for<ksteps(M)>([&](auto si) __attribute__((always_inline)) {
+    constexpr int s = decltype(si)::value;
+    BStep b[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      constexpr int tb = 2 * s + 1 < NIN ? 2 * s + 1 : 0;  // clamped constant index; an odd tail pairs with zeros
+      b[c] = make_bstep(in[c][2 * s], 2 * s + 1 < NIN ? in[c][tb] : splat4(0.f));
+    }
+    gemm_bf_panel<M, s, C, NWAVES>(ws, b, out, wrap);
+  });
+}
+
+// 256-thread workgroups (one wave per SIMD), two per CU; each streams the layer chain's weight planes
+// through its own pair of 24 KiB LDS slots.
 #ifndef UFR_VT_BLOCK
 #define UFR_VT_BLOCK 256   // threads per workgroup
 #define UFR_VT_C 2         // token column tiles per wave
@@ -61,18 +80,18 @@ constexpr int kVtWaves = kVtBlock / 64;
 
 template <int L, int C>
 __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel(const float* __restrict__ packed,
-                                                                   const float* __restrict__ x_tokens,
-                                                                   const float* __restrict__ rgbm,
-                                                                   const float* __restrict__ dirs, int P,
-                                                                   float* __restrict__ token0,
-                                                                   float* __restrict__ radiance,
-                                                                   float* __restrict__ view_out) {
+                                                                             const float* __restrict__ x_tokens,
+                                                                             const float* __restrict__ rgbm,
+                                                                             const float* __restrict__ dirs, int P,
+                                                                             float* __restrict__ token0,
+                                                                             float* __restrict__ radiance,
+                                                                             float* __restrict__ view_out) {
   constexpr int NV = L - 1;
   constexpr int PPT = 16 / L;          // points per column tile
   constexpr int PPW = PPT * C;         // points per wave iteration
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  WStream ws = wstream_begin<S_VT, kVtWaves>(packed, smem);
-  wstream_fetch<S_VT, kVtWaves, 0>(ws);
+  WStreamBf ws = wstream_bf_begin<kVtWaves>(packed, smem);
+  wstream_bf_fetch<kVtWaves, 0>(ws);
   const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
   const int pt_in_tile = j / L, tv = j % L;         // token tv of point pt_in_tile (tv == 0: view token)
   const bool col_ok = j < PPT * L;
@@ -101,88 +120,89 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
       for (int t = 0; t < 5; ++t) {
         f32x4 tok = vec_frag<V_VIEW_TOKEN>(ws, t, g);
-#ifdef UFR_ABL_GEMMONLY
-        f32x4 val = splat4((float)(lane + t) * 1e-3f);
-        (void)row;
-#else
         f32x4 val = ld4(row + 16 * t + 4 * g);
-#endif
         x[c][t] = tv == 0 ? tok : val;                     // ray_transformer.py:284-286
         if (!valid[c]) x[c][t] = splat4(0.f);
       }
     }
-
-    // colour / mask / direction of this lane's (point, view): fetched now, consumed after the last GEMM
-    f32x4 col[C];
-    float dcomp[C];
+    // ---------------- q,k projections (slot layout: lane group g <- heads 2g, 2g+1); x is split once per k-step
+    // and feeds both matrices (stream order q0 k0 q1 k1 q2 k2)
+    f32x4 q[C][5], k[C][5];
+    zero_tiles(q); zero_tiles(k);
+    static_for<3>([&](auto si) __attribute__((always_inline)) {
+      constexpr int s = decltype(si)::value;
+      BStep b[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-      col[c] = splat4(0.f);
-      dcomp[c] = 0.f;
-      if (valid[c] && tv > 0) {
-        col[c] = ld4(rgbm + ((size_t)pidx[c] * NV + (tv - 1)) * 4);           // r,g,b,mask
-        dcomp[c] = dirs[((size_t)pidx[c] * NV + (tv - 1)) * 4 + g];           // lane group g <- dir[g], 0 for g=3
-      }
-    }
+      for (int c = 0; c < C; ++c) b[c] = make_bstep(x[c][2 * s], s < 2 ? x[c][s < 2 ? 2 * s + 1 : 0] : splat4(0.f));
+      gemm_bf_panel<M_VT_Q, s, C, kVtWaves>(ws, b, q, wrap);
+      gemm_bf_panel<M_VT_K, s, C, kVtWaves>(ws, b, k, wrap);
+    });
 
-    // ---------------- q,k,v projections (slot layout: lane group g <- heads 2g, 2g+1)
-    f32x4 q[C][5], k[C][5], v[C][5];
-    zero_tiles(q); zero_tiles(k); zero_tiles(v);
-    gemm_lds<M_VT_Q, C, kVtWaves>(ws, x, q, wrap);
-    gemm_lds<M_VT_K, C, kVtWaves>(ws, x, k, wrap);
-    gemm_lds<M_VT_V, C, kVtWaves>(ws, x, v, wrap);  // merge weights fly during attention
-
-    // ---------------- linear attention over the L tokens of each point (linear_attention.py:31-45)
-    f32x4 msg[C][5];
-#ifdef UFR_ABL_NOATTN  // ablation build: skip the VALU attention (timing only)
-#pragma unroll
-    for (int c = 0; c < C; ++c)
-#pragma unroll
-      for (int t = 0; t < 5; ++t) msg[c][t] = q[c][t] + k[c][t] * v[c][t];
-#else
+    // ---------------- linear attention over the L tokens of each point (linear_attention.py:31-45), written as
+    // msg = sum_S A_S V_S / sum_S A_S with A_S = Q'.K'_S for the token (tv+S)%L of the same point: the
+    // scores are reduced to L numbers per head before v is even computed, so q and k die early
+    float A[C][2][L], Zs[C][2];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
-        float Q[10], K[10], V[10], acc[10];
+        float Q[10], K[10];
 #pragma unroll
         for (int d = 0; d < 10; ++d) {
           const int s = 10 * hh + d;
           Q[d] = elu1(q[c][s >> 2][s & 3]);
           K[d] = elu1(k[c][s >> 2][s & 3]);
-          // values / v_length: exact as a multiply when L is a power of two (NV = 3, 7)
-          V[d] = (L & (L - 1)) == 0 ? v[c][s >> 2][s & 3] * (1.f / (float)L) : v[c][s >> 2][s & 3] / (float)L;
-          acc[d] = 0.f;
         }
         float den = 0.f;
-        // token (tv+S)%L of the same point contributes A_S = Q . K_S
 #define UFR_ATT_STEP(S)                                                  \
         if (S < L) {                                                     \
           float a = 0.f;                                                 \
           _Pragma("unroll") for (int d = 0; d < 10; ++d) a = fmaf(Q[d], rot<L, S>(K[d], src), a); \
           den += a;                                                      \
-          _Pragma("unroll") for (int d = 0; d < 10; ++d) acc[d] = fmaf(a, rot<L, S>(V[d], src), acc[d]); \
+          A[c][hh][S < L ? S : 0] = a;                                   \
         }
         UFR_ATT_STEP(0) UFR_ATT_STEP(1) UFR_ATT_STEP(2) UFR_ATT_STEP(3)
         UFR_ATT_STEP(4) UFR_ATT_STEP(5) UFR_ATT_STEP(6) UFR_ATT_STEP(7)
 #undef UFR_ATT_STEP
-        const float Z = 1.f / (den + 1e-6f);
+        Zs[c][hh] = (float)L / (den + 1e-6f);             // Z * v_length (linear_attention.py:43-44)
+      }
+    }
+    f32x4 v[C][5];
+    zero_tiles(v);
+    gemm_bf<M_VT_V, C, kVtWaves>(ws, x, v, wrap);
+    f32x4 msg[C][5];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        float V[10], acc[10];
 #pragma unroll
         for (int d = 0; d < 10; ++d) {
           const int s = 10 * hh + d;
-          msg[c][s >> 2][s & 3] = acc[d] * Z * (float)L;
+          // values / v_length: exact as a multiply when L is a power of two (NV = 3, 7)
+          V[d] = (L & (L - 1)) == 0 ? v[c][s >> 2][s & 3] * (1.f / (float)L) : v[c][s >> 2][s & 3] / (float)L;
+          acc[d] = 0.f;
+        }
+#define UFR_ATT_STEP(S)                                                  \
+        if (S < L) {                                                     \
+          _Pragma("unroll") for (int d = 0; d < 10; ++d) acc[d] = fmaf(A[c][hh][S < L ? S : 0], rot<L, S>(V[d], src), acc[d]); \
+        }
+        UFR_ATT_STEP(0) UFR_ATT_STEP(1) UFR_ATT_STEP(2) UFR_ATT_STEP(3)
+        UFR_ATT_STEP(4) UFR_ATT_STEP(5) UFR_ATT_STEP(6) UFR_ATT_STEP(7)
+#undef UFR_ATT_STEP
+#pragma unroll
+        for (int d = 0; d < 10; ++d) {
+          const int s = 10 * hh + d;
+          msg[c][s >> 2][s & 3] = acc[d] * Zs[c][hh];
         }
       }
     }
-#endif
 
     // ---------------- merge + LayerNorm1 (transformer.py:51-52)
     f32x4 m[C][5];
     zero_tiles(m);
-    gemm_lds<M_VT_MERGE, C, kVtWaves>(ws, msg, m, wrap);
-#ifndef UFR_ABL_GEMMONLY
+    gemm_bf<M_VT_MERGE, C, kVtWaves>(ws, msg, m, wrap);
     layer_norm80<C, V_VT_N1W, V_VT_N1B>(m, ws, g);
-#endif
 
     // ---------------- MLP on [x | message] + LayerNorm2 + residual (transformer.py:55-58)
     f32x4 cat[C][10], hid[C][10], o[C][5];
@@ -191,7 +211,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
       for (int t = 0; t < 5; ++t) { cat[c][t] = x[c][t]; cat[c][5 + t] = m[c][t]; }
     zero_tiles(hid);
-    gemm_lds<M_VT_MLP0, C, kVtWaves>(ws, cat, hid, wrap);
+    gemm_bf<M_VT_MLP0, C, kVtWaves>(ws, cat, hid, wrap);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
@@ -199,10 +219,8 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
         for (int r = 0; r < 4; ++r) hid[c][t][r] = fmaxf(hid[c][t][r], 0.f);
     zero_tiles(o);
-    gemm_lds<M_VT_MLP2, C, kVtWaves>(ws, hid, o, wrap);
-#ifndef UFR_ABL_GEMMONLY
+    gemm_bf<M_VT_MLP2, C, kVtWaves>(ws, hid, o, wrap);
     layer_norm80<C, V_VT_N2W, V_VT_N2B>(o, ws, g);
-#endif
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
@@ -222,7 +240,19 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
       }
     }
 
-#ifndef UFR_ABL_NORAD
+    // colour / mask / direction of this lane's (point, view): (loaded late: they would otherwise sit in 10 registers across the MLP, the register peak)
+    f32x4 col[C];
+    float dcomp[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      col[c] = splat4(0.f);
+      dcomp[c] = 0.f;
+      if (valid[c] && tv > 0) {
+        col[c] = ld4(rgbm + ((size_t)pidx[c] * NV + (tv - 1)) * 4);           // r,g,b,mask
+        dcomp[c] = dirs[((size_t)pidx[c] * NV + (tv - 1)) * 4 + g];           // lane group g <- dir[g], 0 for g=3
+      }
+    }
+
     // ---------------- radiance weight MLP on [view feature | dir] (ray_transformer.py:309-314)
     f32x4 rin[C][6], h1[C][1], h2[C][1], lg[C][1];
 #pragma unroll
@@ -234,17 +264,17 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
       h2[c][0] = vec_frag<V_RW_B2>(ws, 0, g);
       lg[c][0] = vec_frag<V_RW_B4>(ws, 0, g);
     }
-    gemm_lds<M_RW0, C, kVtWaves>(ws, rin, h1, wrap);
+    gemm_bf<M_RW0, C, kVtWaves>(ws, rin, h1, wrap);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) h1[c][0][r] = fmaxf(h1[c][0][r], 0.f);
-    gemm_lds<M_RW2, C, kVtWaves>(ws, h1, h2, wrap);
+    gemm_bf<M_RW2, C, kVtWaves>(ws, h1, h2, wrap);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) h2[c][0][r] = fmaxf(h2[c][0][r], 0.f);
-    gemm_lds<M_RW4, C, kVtWaves>(ws, h2, lg, wrap);
+    gemm_bf<M_RW4, C, kVtWaves>(ws, h2, lg, wrap);
 
     // ---------------- masked softmax over the NV view tokens + colour blend (ray_transformer.py:315-319)
     // logit of token j sits in lane group 0, register 0; lanes of group 0 do the point-local reduction
@@ -275,7 +305,6 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
         dst[2] = cb / den;
       }
     }
-#endif
   }
 }
 
@@ -286,9 +315,9 @@ static hipError_t launch_vt(const float* packed, const float* x_tokens, const fl
   constexpr int PPW = (16 / L) * C;
   const int n_groups = (P + PPW - 1) / PPW;
   int blocks = (n_groups + kVtWaves - 1) / kVtWaves;
-  const int max_blocks = 256 * 2;  // two resident workgroups per CU (LDS 2 x 69 KB); grid-stride beyond
+  const int max_blocks = 256 * 2;  // two resident workgroups per CU; grid-stride beyond
   if (blocks > max_blocks) blocks = max_blocks;
-  hipLaunchKernelGGL((view_transformer_kernel<L, C>), dim3(blocks), dim3(kVtBlock), kStreamLdsBytes, s, packed, x_tokens,
+  hipLaunchKernelGGL((view_transformer_kernel<L, C>), dim3(blocks), dim3(kVtBlock), kBfLdsBytes, s, packed, x_tokens,
                      rgb, dir, P, token0, radiance, view_out);
   return hipGetLastError();
 }

@@ -187,24 +187,41 @@ def split3(x):
     return h, m, lo
 
 
-def vt_panels():
-    """(matrix name, k-step) in stream order (ufr_layout_bf.h:vt_panel)."""
-    p = []
+def bf_streams():
+    """Per bf16 stream: (matrix name, k-step) panels in stream order (ufr_layout_bf.h:bf_panel)."""
+    vt = []
     for s in range(3):
-        p += [("VT_Q", s), ("VT_K", s)]
-    p += [("VT_V", s) for s in range(3)] + [("VT_MERGE", s) for s in range(3)]
-    p += [("VT_MLP0", s) for s in range(5)] + [("VT_MLP2", s) for s in range(5)]
-    p += [("RW0", s) for s in range(3)] + [("RW2", 0), ("RW4", 0)]
-    return p
+        vt += [("VT_Q", s), ("VT_K", s)]
+    vt += [("VT_V", s) for s in range(3)] + [("VT_MERGE", s) for s in range(3)]
+    vt += [("VT_MLP0", s) for s in range(5)] + [("VT_MLP2", s) for s in range(5)]
+    vt += [("RW0", s) for s in range(3)] + [("RW2", 0), ("RW4", 0)]
+    rt1 = []
+    for s in range(3):
+        rt1 += [("RT_K", s), ("RT_V", s)]
+    rt2 = [("RT_Q", s) for s in range(3)] + [("RT_MERGE", s) for s in range(4)]
+    rt2 += [("RT_MLP0", s) for s in range(6)] + [("RT_MLP2", s) for s in range(6)]
+    rt2 += [("DM0", s) for s in range(3)] + [("DM2", 0), ("DM4", 0)]
+    return [vt, rt1, rt2]
+
+
+BF_CHUNK = 24  # fragments per LDS chunk (kBfChunkFrags)
 
 
 def panel_start(name, s):
-    off = 0
-    for n, k in vt_panels():
-        if (n, k) == (name, s):
-            return off
-        off += MATS[NAME2IDX[n]][3] * 3
+    """first fragment of panel (name, k-step s) in the bf16 region: streams are padded to whole chunks."""
+    base = 0
+    for panels in bf_streams():
+        off = 0
+        for n, k in panels:
+            if (n, k) == (name, s):
+                return base + off
+            off += MATS[NAME2IDX[n]][3] * 3
+        base += (off + BF_CHUNK - 1) // BF_CHUNK * BF_CHUNK
     raise KeyError((name, s))
+
+
+def bf_region_frags():
+    return sum((sum(MATS[NAME2IDX[n]][3] * 3 for n, _ in p) + BF_CHUNK - 1) // BF_CHUNK * BF_CHUNK for p in bf_streams())
 
 
 def mfma_bf16(a, b, acc):
@@ -221,8 +238,8 @@ def mfma_bf16(a, b, acc):
     return out.astype(np.float32)  # the accumulator is fp32
 
 
-def gemm_bf(bf_blob, name, tiles_in):
-    """tiles_in (n_in,64,4) fp32 accumulator tiles of the producer -> (n_out,64,4)."""
+def gemm_bf(bf_blob, name, tiles_in, swap=False):
+    """tiles_in (n_in,64,4) fp32 accumulator tiles of the producer -> (n_out,64,4); swap: activations in the A slot."""
     idx = NAME2IDX[name]
     n_out, n_in = MATS[idx][3], MATS[idx][4]
     out = np.zeros((n_out, 64, 4), np.float32)
@@ -234,5 +251,5 @@ def gemm_bf(bf_blob, name, tiles_in):
         for to in range(n_out):
             a = [bf_blob[(f0 + to * 3 + p) * 512:(f0 + to * 3 + p + 1) * 512].reshape(64, 8) for p in range(3)]
             for pa, pb in ((1, 1), (0, 2), (2, 0), (0, 1), (1, 0), (0, 0)):
-                out[to] = mfma_bf16(a[pa], xb[pb], out[to])
+                out[to] = mfma_bf16(xb[pb], a[pa], out[to]) if swap else mfma_bf16(a[pa], xb[pb], out[to])
     return out

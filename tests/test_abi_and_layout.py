@@ -193,7 +193,11 @@ def test_bf16_split_is_exact():
         assert not (p.view(np.uint32) & 0xFFFF).any()
 
 
-@pytest.mark.parametrize("name", ["VT_Q", "VT_K", "VT_V", "VT_MERGE", "VT_MLP0", "VT_MLP2", "RW0", "RW2", "RW4"])
+def test_bf16_region_size(lib):
+    assert lib.ufr_packed_bf16_halfwords() == E.bf_region_frags() * 512
+
+
+@pytest.mark.parametrize("name", [m[0] for m in E.MATS])
 def test_bf16x6_panels_reproduce_linear(name, raw_and_blob, bf_blob):
     """The exported bf16 plan, pushed through a lane-level model of v_mfma_f32_16x16x32_bf16 with the six
     plane pairs of csrc/weight_stream_bf.h, reproduces y = W x to fp32 accuracy for every matrix of the chain."""
@@ -203,8 +207,10 @@ def test_bf16x6_panels_reproduce_linear(name, raw_and_blob, bf_blob):
     W = raw[param].reshape(out_dim, k_raw).astype(np.float32)
     x = np.random.default_rng(200 + idx).standard_normal((16, in_dim)).astype(np.float32)
     tiles = E.to_tiles(x, cm, n_in, in_dim).astype(np.float32)
-    acc = E.gemm_bf(bf_blob, name, tiles)
-    y, pad = E.from_tiles(acc, rm, out_dim)
     ref = x.astype(np.float64) @ W[:, :in_dim].astype(np.float64).T
+    if name in ("RT_K", "RT_V"):  # swapped operands in the kernel: [token][feature] accumulators
+        y, pad = E.from_tiles_swapped(E.gemm_bf(bf_blob, name, tiles, swap=True), rm, out_dim), 0.0
+    else:
+        y, pad = E.from_tiles(E.gemm_bf(bf_blob, name, tiles), rm, out_dim)
     assert pad == 0.0
     assert np.abs(y - ref).max() / np.abs(ref).max() < 5e-7, name

@@ -66,6 +66,38 @@ def main():
     rt = prof["ray_transformer"]["ms"] / prof["ray_transformer"]["launches"]
     print(f"[{tag}] view_transformer  {vt:8.3f} ms  {534224 * P / vt / 1e9:8.2f} TFLOP/s algorithmic")
     print(f"[{tag}] ray_transformer   {rt:8.3f} ms  {(61952 + 92928 + 4048 + 6688) * P / rt / 1e9:8.2f} TFLOP/s algorithmic")
+    if hasattr(lib, "ufr_debug_vt_phases"):  # -DUFR_PHASE_TIMING development build
+        buf = (C.c_ulonglong * 32)()
+        lib.ufr_debug_vt_phases(buf, 32, 1)
+        names = ["load", "qk gemm", "scores", "v gemm", "message", "merge gemm", "LN1", "MLP0", "relu+MLP2",
+                 "LN2+stores", "radiance MLP", "softmax"]
+        tot = sum(buf[:12])
+        for i, nm in enumerate(names):
+            print(f"   phase {nm:14s} {buf[i] / 5:12.0f} cyc/launch  {100.0 * buf[i] / tot:5.1f} %")
+        print(f"   total {tot / 5:.0f} cycle-counter ticks per launch (wave 0)")
+        if buf[20]:
+            print(f"   wave 5: {buf[20] / 5 / 100:.1f} us by the 100 MHz clock, {buf[21] / 5:.0f} cycle-counter ticks -> {buf[21] / buf[20] * 100:.0f} MHz")
+        wb = (C.c_ulonglong * 4096)()
+        lib.ufr_debug_vt_waves(wb, 4096)
+        a = np.array(wb[:], dtype=np.uint64).reshape(-1, 2)
+        start = a[:, 0].astype(np.int64)
+        dur = (a[:, 1] & np.uint64((1 << 40) - 1)).astype(np.int64)
+        xcc = (a[:, 1] >> np.uint64(60)).astype(np.int64)
+        hwid = ((a[:, 1] >> np.uint64(40)) & np.uint64(0xffff)).astype(np.int64)
+        ok = dur > 0
+        print("   waves recorded", ok.sum(), "dur min/med/max", dur[ok].min(), int(np.median(dur[ok])), dur[ok].max())
+        for x in range(8):
+            m = ok & (xcc == x)
+            if m.any():
+                st = start[m] - start[m].min()
+                print(f"   xcc {x}: waves {m.sum()} start spread {st.max()} dur med {int(np.median(dur[m]))} max {dur[m].max()} end-span {(start[m] + dur[m]).max() - start[m].min()}")
+        cu = (hwid >> 8) & 0xf
+        se = (hwid >> 13) & 0x7
+        key = xcc * 1000 + se * 16 + cu
+        u, cnt = np.unique(key[ok], return_counts=True)
+        print("   distinct (xcc,se,cu):", len(u), "waves per cu histogram:", np.bincount(cnt))
+        slow = ok & (dur > 1.2 * np.median(dur[ok]))
+        print("   slow waves:", slow.sum(), "on cus with wave counts", np.unique(cnt[np.searchsorted(u, key[slow])], return_counts=True))
 
 
 if __name__ == "__main__":

@@ -99,7 +99,7 @@ hipError_t launch_pack_weights(const RawPtrs& raw, float* packed, hipStream_t s)
   const int n = blob_floats();
   hipLaunchKernelGGL(pack_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, s, raw, packed, n);
   unsigned short* bf = reinterpret_cast<unsigned short*>(packed + n);
-  hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((kVtbHalfwords + 255) / 256), dim3(256), 0, s, raw, bf, kVtbHalfwords);
+  hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((kBfHalfwords + 255) / 256), dim3(256), 0, s, raw, bf, kBfHalfwords);
   return hipGetLastError();
 }
 

@@ -4,7 +4,9 @@
 //   LoFTREncoderLayer.forward  code1/attention/transformer.py:35-58
 //   LinearAttention.forward    code1/attention/linear_attention.py:20-47
 //
-// One wavefront per ray, two sweeps over its SN/16 column tiles, everything in registers:
+// One wavefront per ray, two sweeps over its SN/16 column tiles, everything in registers; the dense
+// layers run split-precision on the bf16 matrix cores (ufr_layout_bf.h), the tiny per-head KV / message
+// products (K = 16 tokens / 16 head dims) stay on the fp32 MFMA:
 //  sweep 1: K^T, V^T tiles ([token][head dim], obtained by swapping the MFMA operands), then
 //           KV_h += K'_h^T V_h as 4 MFMAs per head; a ones column appended to V makes
 //           column 11 of KV_h the K' sum needed for the normaliser.
@@ -13,7 +15,7 @@
 // Each head occupies its own 16-row tile (11 real rows) so that head boundaries coincide with MFMA
 // tiles; the 88-wide activations use the "nat88" layout of ufr_layout.h.
 #include "ufr_internal.h"
-#include "weight_stream.h"
+#include "weight_stream_bf.h"
 
 namespace ufr {
 
@@ -29,7 +31,7 @@ __device__ __forceinline__ void load_ray_tile(const float* __restrict__ token0, 
 
 // LayerNorm over 88 features in nat88 layout (tile 5: registers 0,1 real)
 template <int VW, int VB>
-__device__ __forceinline__ void layer_norm88(f32x4 (&t)[1][6], const WStream& ws, int g) {
+__device__ __forceinline__ void layer_norm88(f32x4 (&t)[1][6], const WStreamBf& ws, int g) {
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 5; ++i) s += (t[0][i][0] + t[0][i][1]) + (t[0][i][2] + t[0][i][3]);
@@ -54,18 +56,22 @@ __device__ __forceinline__ void layer_norm88(f32x4 (&t)[1][6], const WStream& ws
 }
 
 // 256-thread workgroups = 4 rays (one wave each, one per SIMD), two workgroups per CU; the four waves
-// walk the weight streams S_RT1 / S_RT2 together through LDS (weight_stream.h).
-constexpr int kRtBlock = 256;
+// walk the weight streams B_RT1 / B_RT2 together through LDS (weight_stream_bf.h).
+#ifndef UFR_RT_BLOCK
+#define UFR_RT_BLOCK 256
+#define UFR_RT_MINW 2
+#endif
+constexpr int kRtBlock = UFR_RT_BLOCK;
 constexpr int kRtWaves = kRtBlock / 64;
 
-__global__ void __launch_bounds__(kRtBlock, 2) ray_transformer_kernel(const float* __restrict__ packed,
+__global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(const float* __restrict__ packed,
                                                                   const float* __restrict__ token0,
                                                                   const float* __restrict__ order_pe, int RN, int SN,
                                                                   float* __restrict__ srdf,
                                                                   float* __restrict__ ray_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  WStream ws = wstream_begin<S_RT1, kRtWaves>(packed, smem);
-  wstream_fetch<S_RT1, kRtWaves, 0>(ws);
+  WStreamBf ws = wstream_bf_begin<kRtWaves>(packed, smem);
+  wstream_bf_prime<B_RT1, kRtWaves>(ws);
   const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
   const int ray_raw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const bool valid = ray_raw < RN;           // no early exit: every wave meets every chunk barrier
@@ -83,8 +89,27 @@ __global__ void __launch_bounds__(kRtBlock, 2) ray_transformer_kernel(const floa
     load_ray_tile(token0, order_pe, (size_t)ray * SN + tile * 16, tile * 16, g, j, x);
 #pragma unroll
     for (int h = 0; h < 8; ++h) { kt[0][h] = splat4(0.f); vt[0][h] = splat4(0.f); }
-    gemm_lds<M_RT_K, 1, kRtWaves, true>(ws, x, kt, wrap);   // kt[h]: rows = tokens 4g+r, column j = head dim
-    gemm_lds<M_RT_V, 1, kRtWaves, true>(ws, x, vt, wrap);
+    {  // swapped operands: kt[h], vt[h] rows = tokens 4g+r, column j = head dim; x is split once per k-step
+      BWords<1> cur;
+      split_units<0, 0, 4>(x, cur);
+      static_for<3>([&](auto si) __attribute__((always_inline)) {
+        constexpr int s = decltype(si)::value;
+        BStep b[1];
+        bwords_to_bstep(cur, b);
+        if constexpr (s < 2) {
+          BWords<1> nxt;
+          gemm_bf_panel<M_RT_K, s, 1, kRtWaves, true>(ws, b, kt, wrap, [&](auto ti) __attribute__((always_inline)) {
+            constexpr int to = decltype(ti)::value;
+            split_units<s + 1, to * 4 / 8, (to + 1) * 4 / 8>(x, nxt);
+          });
+          gemm_bf_panel<M_RT_V, s, 1, kRtWaves, true>(ws, b, vt, wrap);
+          cur = nxt;
+        } else {
+          gemm_bf_panel<M_RT_K, s, 1, kRtWaves, true>(ws, b, kt, wrap);
+          gemm_bf_panel<M_RT_V, s, 1, kRtWaves, true>(ws, b, vt, wrap);
+        }
+      });
+    }
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
 #pragma unroll
@@ -97,14 +122,14 @@ __global__ void __launch_bounds__(kRtBlock, 2) ray_transformer_kernel(const floa
   }
 
   // ---------------- sweep 2 (slot 0 is free: every wave passed the barrier that opened sweep 1's last chunk)
-  wstream_fetch<S_RT2, kRtWaves, 0>(ws);
+  wstream_bf_prime<B_RT2, kRtWaves>(ws);
   for (int tile = 0; tile < n_tiles; ++tile) {
     const bool wrap = tile + 1 < n_tiles;
     f32x4 x[1][6], q[1][8], msg[1][8];
     load_ray_tile(token0, order_pe, (size_t)ray * SN + tile * 16, tile * 16, g, j, x);
 #pragma unroll
     for (int h = 0; h < 8; ++h) q[0][h] = splat4(0.f);
-    gemm_lds<M_RT_Q, 1, kRtWaves>(ws, x, q, wrap);  // q[h]: rows = head dims 4g+r, column j = token
+    gemm_bf<M_RT_Q, 1, kRtWaves>(ws, x, q, wrap);  // q[h]: rows = head dims 4g+r, column j = token
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
       f32x4 acc = splat4(0.f);
@@ -120,7 +145,7 @@ __global__ void __launch_bounds__(kRtBlock, 2) ray_transformer_kernel(const floa
     f32x4 m[1][6];
 #pragma unroll
     for (int t = 0; t < 6; ++t) m[0][t] = splat4(0.f);
-    gemm_lds<M_RT_MERGE, 1, kRtWaves>(ws, msg, m, wrap);
+    gemm_bf<M_RT_MERGE, 1, kRtWaves>(ws, msg, m, wrap);
     layer_norm88<V_RT_N1W, V_RT_N1B>(m, ws, g);
 
     f32x4 cat[1][12], hid[1][11], o[1][6];
@@ -128,14 +153,14 @@ __global__ void __launch_bounds__(kRtBlock, 2) ray_transformer_kernel(const floa
     for (int t = 0; t < 6; ++t) { cat[0][t] = x[0][t]; cat[0][6 + t] = m[0][t]; }
 #pragma unroll
     for (int t = 0; t < 11; ++t) hid[0][t] = splat4(0.f);
-    gemm_lds<M_RT_MLP0, 1, kRtWaves>(ws, cat, hid, wrap);
+    gemm_bf<M_RT_MLP0, 1, kRtWaves>(ws, cat, hid, wrap);
 #pragma unroll
     for (int t = 0; t < 11; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) hid[0][t][r] = fmaxf(hid[0][t][r], 0.f);
 #pragma unroll
     for (int t = 0; t < 6; ++t) o[0][t] = splat4(0.f);
-    gemm_lds<M_RT_MLP2, 1, kRtWaves>(ws, hid, o, wrap);
+    gemm_bf<M_RT_MLP2, 1, kRtWaves>(ws, hid, o, wrap);
     layer_norm88<V_RT_N2W, V_RT_N2B>(o, ws, g);
 #pragma unroll
     for (int t = 0; t < 6; ++t) o[0][t] += x[0][t];
@@ -154,15 +179,15 @@ __global__ void __launch_bounds__(kRtBlock, 2) ray_transformer_kernel(const floa
     d1[0][1] = vec_frag<V_DM_B0>(ws, 1, g);
     d2[0][0] = vec_frag<V_DM_B2>(ws, 0, g);
     d3[0][0] = vec_frag<V_DM_B4>(ws, 0, g);
-    gemm_lds<M_DM0, 1, kRtWaves>(ws, o, d1, wrap);
+    gemm_bf<M_DM0, 1, kRtWaves>(ws, o, d1, wrap);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) d1[0][t][r] = fmaxf(d1[0][t][r], 0.f);
-    gemm_lds<M_DM2, 1, kRtWaves>(ws, d1, d2, wrap);
+    gemm_bf<M_DM2, 1, kRtWaves>(ws, d1, d2, wrap);
 #pragma unroll
     for (int r = 0; r < 4; ++r) d2[0][0][r] = fmaxf(d2[0][0][r], 0.f);
-    gemm_lds<M_DM4, 1, kRtWaves>(ws, d2, d3, wrap);
+    gemm_bf<M_DM4, 1, kRtWaves>(ws, d2, d3, wrap);
     if (g == 0 && valid) srdf[(size_t)ray * SN + tile * 16 + j] = d3[0][0][0];
   }
 }
@@ -170,7 +195,7 @@ __global__ void __launch_bounds__(kRtBlock, 2) ray_transformer_kernel(const floa
 hipError_t launch_ray_transformer(const float* packed, const float* token0, const float* order_pe, int RN, int SN,
                                   float* srdf, float* ray_out, hipStream_t s) {
   if (SN % 16 != 0 || SN < 16) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(ray_transformer_kernel, dim3((RN + kRtWaves - 1) / kRtWaves), dim3(kRtBlock), kStreamLdsBytes, s,
+  hipLaunchKernelGGL(ray_transformer_kernel, dim3((RN + kRtWaves - 1) / kRtWaves), dim3(kRtBlock), kBfLdsBytes, s,
                      packed, token0, order_pe, RN, SN, srdf, ray_out);
   return hipGetLastError();
 }

@@ -104,13 +104,13 @@ int ufr_version(void) { return 100; }
 const char* ufr_last_error(void) { return g_err; }
 
 // ------------------------------------------------------------------ weights
-size_t ufr_packed_weights_bytes(void) { return (size_t)blob_floats() * sizeof(float) + (size_t)kVtbBytes; }
+size_t ufr_packed_weights_bytes(void) { return (size_t)blob_floats() * sizeof(float) + (size_t)kBfBytes; }
 size_t ufr_packed_fp32_floats(void) { return (size_t)blob_floats(); }
-size_t ufr_packed_bf16_halfwords(void) { return (size_t)kVtbHalfwords; }
+size_t ufr_packed_bf16_halfwords(void) { return (size_t)kBfHalfwords; }
 
 int ufr_pack_plan_bf16(int32_t* param_id, int32_t* elem, int32_t* plane) {
   UFR_REQUIRE(param_id && elem && plane, "ufr_pack_plan_bf16: null output");
-  for (int h = 0; h < kVtbHalfwords; ++h) plan_entry_bf(h, &param_id[h], &elem[h], &plane[h]);
+  for (int h = 0; h < kBfHalfwords; ++h) plan_entry_bf(h, &param_id[h], &elem[h], &plane[h]);
   return UFR_OK;
 }
 

@@ -1,4 +1,4 @@
-// Split-precision ("bf16x6") weight layout of the view-transformer chain.
+// Split-precision ("bf16x6") weight layout of the view- and ray-transformer chains.
 //
 // Measured on MI355X (tools/dev/mfma_valu2.*): v_mfma_f32_16x16x4_f32 does NOT overlap with VALU
 // work -- it occupies the vector ALU for its 32 cycles, so every LayerNorm / attention / elu
@@ -16,53 +16,96 @@
 // W_p[row(to, l&15)][k = 8*(l>>4) + i], i = 0..7, where the 32 k-slots of a panel are the two
 // accumulator tiles (2s, 2s+1) of the producing layer: slot 8g+i <-> tile 2s + (i>>2), feature
 // col_map(tile, g, i&3) -- exactly what a lane holds after splitting its two fp32 accumulator tiles.
+// The same fragment serves as the A operand (weights x activations: [feature][token] result) and as
+// the B operand (activations x weights, "swapped": [token][feature] result) -- the two lane layouts
+// of v_mfma_f32_16x16x32_bf16 coincide.
 // A PANEL is one k-step (32 input features) of one matrix: all its out tiles x 3 planes, stored in
-// consumption order; the stream is the sequence of panels the kernel walks.
+// consumption order; a STREAM is the sequence of panels a kernel phase walks:
+//   B_VT   view transformer  q0 k0 q1 k1 q2 k2 | v | merge | mlp0 | mlp2 | rw0 rw2 rw4
+//   B_RT1  ray transformer sweep 1  k0 v0 k1 v1 k2 v2          (swapped operands)
+//   B_RT2  ray transformer sweep 2  q | merge | mlp0 | mlp2 | dm0 dm2 dm4
 #pragma once
 #include "ufr_layout.h"
 
 namespace ufr {
 
 constexpr int kPlanes = 3;
-constexpr int kBfChunkFrags = 24;  // 24 KiB chunks: 8 (tile,3 planes) triples; splits evenly over 4 or 8 waves
+constexpr int kBfChunkFrags = 24;  // 24 KiB chunks: 8 (tile, 3 planes) triples; splits evenly over 4 or 8 waves
+#ifndef UFR_BF_SLOTS
+#define UFR_BF_SLOTS 2
+#endif
+constexpr int kBfSlots = UFR_BF_SLOTS;  // LDS ring depth: kBfSlots-1 chunks in flight (3 measured no faster than 2)
+
+enum BfStream { B_VT = 0, B_RT1 = 1, B_RT2 = 2, B_COUNT = 3 };
 
 struct Panel { int mat, s; };
 
-// consumption order of the view-transformer chain: q and k interleaved per k-step (x is split once per step),
-// then v (after the attention scores are reduced to L numbers per head, q and k are dead: fewer live registers)
-constexpr int kVtPanels = 3 * 3 + 3 + 5 + 5 + 3 + 1 + 1;
-__host__ __device__ constexpr Panel vt_panel(int i) {
-  if (i < 6) return {i % 2 == 0 ? M_VT_Q : M_VT_K, i / 2};
-  if (i < 9) return {M_VT_V, i - 6};
-  i -= 9;
-  if (i < 3) return {M_VT_MERGE, i};
-  i -= 3;
-  if (i < 5) return {M_VT_MLP0, i};
-  i -= 5;
-  if (i < 5) return {M_VT_MLP2, i};
-  i -= 5;
-  if (i < 3) return {M_RW0, i};
-  i -= 3;
-  return {i == 0 ? M_RW2 : M_RW4, 0};
-}
 __host__ __device__ constexpr int ksteps(int m) { return (mat_desc(m).n_in + 1) / 2; }
-__host__ __device__ constexpr int panel_frags(int i) { return mat_desc(vt_panel(i).mat).n_out * kPlanes; }
-__host__ __device__ constexpr int panel_start(int i) {  // first fragment of panel i in the stream
+
+__host__ __device__ constexpr int bf_n_panels(int S) {
+  return S == B_VT ? 3 * 3 + 3 + 5 + 5 + 3 + 1 + 1 : S == B_RT1 ? 6 : 3 + 4 + 6 + 6 + 3 + 1 + 1;
+}
+// consumption order.  q and k (view) / k and v (ray) are interleaved per k-step: x is split once per step.
+__host__ __device__ constexpr Panel bf_panel(int S, int i) {
+  if (S == B_VT) {
+    if (i < 6) return {i % 2 == 0 ? M_VT_Q : M_VT_K, i / 2};
+    if (i < 9) return {M_VT_V, i - 6};
+    i -= 9;
+    if (i < 3) return {M_VT_MERGE, i};
+    i -= 3;
+    if (i < 5) return {M_VT_MLP0, i};
+    i -= 5;
+    if (i < 5) return {M_VT_MLP2, i};
+    i -= 5;
+    if (i < 3) return {M_RW0, i};
+    i -= 3;
+    return {i == 0 ? M_RW2 : M_RW4, 0};
+  }
+  if (S == B_RT1) return {i % 2 == 0 ? M_RT_K : M_RT_V, i / 2};
+  if (i < 3) return {M_RT_Q, i};
+  i -= 3;
+  if (i < 4) return {M_RT_MERGE, i};
+  i -= 4;
+  if (i < 6) return {M_RT_MLP0, i};
+  i -= 6;
+  if (i < 6) return {M_RT_MLP2, i};
+  i -= 6;
+  if (i < 3) return {M_DM0, i};
+  i -= 3;
+  return {i == 0 ? M_DM2 : M_DM4, 0};
+}
+__host__ __device__ constexpr int bf_mat_stream(int m) {
+  return (m == M_RT_K || m == M_RT_V) ? B_RT1
+         : (m == M_RT_Q || m == M_RT_MERGE || m == M_RT_MLP0 || m == M_RT_MLP2 || m == M_DM0 || m == M_DM2 || m == M_DM4)
+             ? B_RT2
+             : B_VT;
+}
+__host__ __device__ constexpr int bf_panel_frags(int S, int i) { return mat_desc(bf_panel(S, i).mat).n_out * kPlanes; }
+__host__ __device__ constexpr int bf_panel_start(int S, int i) {  // first fragment of panel i within stream S
   int o = 0;
-  for (int j = 0; j < i; ++j) o += panel_frags(j);
+  for (int j = 0; j < i; ++j) o += bf_panel_frags(S, j);
   return o;
 }
-__host__ __device__ constexpr int panel_index(int m, int s) {
-  for (int i = 0; i < kVtPanels; ++i)
-    if (vt_panel(i).mat == m && vt_panel(i).s == s) return i;
+__host__ __device__ constexpr int bf_panel_index(int m, int s) {  // within the matrix's stream
+  const int S = bf_mat_stream(m);
+  for (int i = 0; i < bf_n_panels(S); ++i)
+    if (bf_panel(S, i).mat == m && bf_panel(S, i).s == s) return i;
   return -1;
 }
-constexpr int kVtbFrags = panel_start(kVtPanels);
-constexpr int kVtbChunksRaw = (kVtbFrags + kBfChunkFrags - 1) / kBfChunkFrags;
-constexpr int kVtbChunks = kVtbChunksRaw + (kVtbChunksRaw & 1);       // even: static LDS slot parity
-constexpr int kVtbFragsPadded = kVtbChunks * kBfChunkFrags;
-constexpr int kVtbHalfwords = kVtbFragsPadded * 512;                  // bf16 elements in the region
-constexpr int kVtbBytes = kVtbFragsPadded * 1024;
+__host__ __device__ constexpr int bf_stream_frags(int S) { return bf_panel_start(S, bf_n_panels(S)); }
+// the last chunk holds the stream's tail: the wrap-around fetch is issued when it opens
+__host__ __device__ constexpr int bf_stream_chunks(int S) { return (bf_stream_frags(S) + kBfChunkFrags - 1) / kBfChunkFrags; }
+__host__ __device__ constexpr int bf_stream_base_frags(int S) {   // first fragment of stream S in the bf16 region
+  int o = 0;
+  for (int j = 0; j < S; ++j) o += bf_stream_chunks(j) * kBfChunkFrags;
+  return o;
+}
+static_assert(bf_stream_chunks(B_VT) % kBfSlots == 0 && bf_stream_chunks(B_RT1) % kBfSlots == 0 &&
+                  bf_stream_chunks(B_RT2) % kBfSlots == 0,
+              "a chunk's LDS slot must not depend on the pass over the stream");
+constexpr int kBfFragsPadded = bf_stream_base_frags(B_COUNT);
+constexpr int kBfHalfwords = kBfFragsPadded * 512;                  // bf16 elements in the region
+constexpr int kBfBytes = kBfFragsPadded * 1024;
 
 // input feature of k-slot (g, i) of panel step s (or -1): accumulator tiles 2s and 2s+1 of the producer
 __host__ __device__ constexpr int bf_col(int m, int s, int g, int i) {
@@ -76,10 +119,13 @@ __host__ __device__ inline void plan_entry_bf(int h, int* param, int* elem, int*
   *param = -1; *elem = 0; *plane = 0;
   int f = h >> 9;                 // fragment
   const int lane = (h >> 3) & 63, i = h & 7;
-  if (f >= kVtbFrags) return;     // tail padding
+  int S = 0;
+  while (S + 1 < B_COUNT && f >= bf_stream_base_frags(S + 1)) ++S;
+  f -= bf_stream_base_frags(S);
+  if (f >= bf_stream_frags(S)) return;  // tail padding of the stream's last chunk
   int pi = 0;
-  while (f >= panel_frags(pi)) { f -= panel_frags(pi); ++pi; }
-  const Panel p = vt_panel(pi);
+  while (f >= bf_panel_frags(S, pi)) { f -= bf_panel_frags(S, pi); ++pi; }
+  const Panel p = bf_panel(S, pi);
   const MatDesc d = mat_desc(p.mat);
   const int to = f / kPlanes;
   *plane = f % kPlanes;

@@ -51,29 +51,27 @@ __device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const WStreamBf& 
   }
 }
 
-// out += W_M x in over all k-steps of M: in[c][0..NIN) are the producer's fp32 accumulator tiles
-template <int M, int C, int NWAVES, int NIN>
-__device__ __forceinline__ void gemm_bf(WStreamBf& ws, const f32x4 (&in)[C][NIN], f32x4 (&out)[C][mat_desc(M).n_out],
-                                        bool wrap) {
-  static_assert(NIN == mat_desc(M).n_in, "input tile count");
-  static_for<ksteps(M)>([&](auto si) __attribute__((always_inline)) {
-    constexpr int s = decltype(si)::value;
-    BStep b[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      constexpr int tb = 2 * s + 1 < NIN ? 2 * s + 1 : 0;  // clamped constant index; an odd tail pairs with zeros
-      b[c] = make_bstep(in[c][2 * s], 2 * s + 1 < NIN ? in[c][tb] : splat4(0.f));
-    }
-    gemm_bf_panel<M, s, C, NWAVES>(ws, b, out, wrap);
-  });
-}
-
 // 256-thread workgroups (one wave per SIMD), two per CU; each streams the layer chain's weight planes
 // through its own pair of 24 KiB LDS slots.
 #ifndef UFR_VT_BLOCK
 #define UFR_VT_BLOCK 256   // threads per workgroup
 #define UFR_VT_C 2         // token column tiles per wave
 #define UFR_VT_MINW 2      // waves per SIMD the register budget is sized for
+#endif
+#ifndef UFR_VT_OVERSUB
+#define UFR_VT_OVERSUB 4   // workgroups launched per resident slot
+#endif
+#ifdef UFR_PHASE_TIMING  // development build: cycle counts per phase of wave 0 (tools/bench_kernels.py prints them)
+__device__ unsigned long long g_vt_phase[32];
+__device__ unsigned long long g_vt_wave[4096 * 2];  // start / end tick of every wave of the last launch
+#define UFR_PHASE(i)                                                                   \
+  {                                                                                    \
+    const unsigned long long t_now = __builtin_readcyclecounter();                     \
+    ph_acc[i] += t_now - t_prev;                                                       \
+    t_prev = t_now;                                                                    \
+  }
+#else
+#define UFR_PHASE(i)
 #endif
 constexpr int kVtBlock = UFR_VT_BLOCK;
 constexpr int kVtWaves = kVtBlock / 64;
@@ -91,7 +89,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
   constexpr int PPW = PPT * C;         // points per wave iteration
   extern __shared__ __attribute__((aligned(16))) char smem[];
   WStreamBf ws = wstream_bf_begin<kVtWaves>(packed, smem);
-  wstream_bf_fetch<kVtWaves, 0>(ws);
+  wstream_bf_prime<B_VT, kVtWaves>(ws);
   const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
   const int pt_in_tile = j / L, tv = j % L;         // token tv of point pt_in_tile (tv == 0: view token)
   const bool col_ok = j < PPT * L;
@@ -104,6 +102,12 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
   const int n_groups = (P + PPW - 1) / PPW;
   const int n_iter = (n_groups + n_waves - 1) / n_waves;  // uniform over the grid: every wave meets every barrier
 
+#ifdef UFR_PHASE_TIMING
+  unsigned long long ph_acc[12] = {};
+  unsigned long long t_prev = __builtin_readcyclecounter();
+  const unsigned long long t_start = t_prev;
+  const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int it = 0; it < n_iter; ++it) {
     const int grp = it * n_waves + wave_global;
     const bool wrap = it + 1 < n_iter;
@@ -125,19 +129,33 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
         if (!valid[c]) x[c][t] = splat4(0.f);
       }
     }
+    UFR_PHASE(0)  // token loads issued
     // ---------------- q,k projections (slot layout: lane group g <- heads 2g, 2g+1); x is split once per k-step
     // and feeds both matrices (stream order q0 k0 q1 k1 q2 k2)
     f32x4 q[C][5], k[C][5];
     zero_tiles(q); zero_tiles(k);
-    static_for<3>([&](auto si) __attribute__((always_inline)) {
-      constexpr int s = decltype(si)::value;
-      BStep b[C];
-#pragma unroll
-      for (int c = 0; c < C; ++c) b[c] = make_bstep(x[c][2 * s], s < 2 ? x[c][s < 2 ? 2 * s + 1 : 0] : splat4(0.f));
-      gemm_bf_panel<M_VT_Q, s, C, kVtWaves>(ws, b, q, wrap);
-      gemm_bf_panel<M_VT_K, s, C, kVtWaves>(ws, b, k, wrap);
-    });
-
+    {
+      BWords<C> cur;
+      split_units<0, 0, 4 * C>(x, cur);
+      static_for<3>([&](auto si) __attribute__((always_inline)) {
+        constexpr int s = decltype(si)::value;
+        BStep b[C];
+        bwords_to_bstep(cur, b);
+        if constexpr (s < 2) {       // the next step's split rides on the q panel's MFMAs
+          BWords<C> nxt;
+          gemm_bf_panel<M_VT_Q, s, C, kVtWaves, false>(ws, b, q, wrap, [&](auto ti) __attribute__((always_inline)) {
+            constexpr int to = decltype(ti)::value;
+            split_units<s + 1, to * 4 * C / 5, (to + 1) * 4 * C / 5>(x, nxt);
+          });
+          gemm_bf_panel<M_VT_K, s, C, kVtWaves>(ws, b, k, wrap);
+          cur = nxt;
+        } else {
+          gemm_bf_panel<M_VT_Q, s, C, kVtWaves>(ws, b, q, wrap);
+          gemm_bf_panel<M_VT_K, s, C, kVtWaves>(ws, b, k, wrap);
+        }
+      });
+    }
+    UFR_PHASE(1)  // q,k GEMMs
     // ---------------- linear attention over the L tokens of each point (linear_attention.py:31-45), written as
     // msg = sum_S A_S V_S / sum_S A_S with A_S = Q'.K'_S for the token (tv+S)%L of the same point: the
     // scores are reduced to L numbers per head before v is even computed, so q and k die early
@@ -167,9 +185,11 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
         Zs[c][hh] = (float)L / (den + 1e-6f);             // Z * v_length (linear_attention.py:43-44)
       }
     }
+    UFR_PHASE(2)  // scores
     f32x4 v[C][5];
     zero_tiles(v);
     gemm_bf<M_VT_V, C, kVtWaves>(ws, x, v, wrap);
+    UFR_PHASE(3)  // v GEMM
     f32x4 msg[C][5];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -198,12 +218,15 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
       }
     }
 
+    UFR_PHASE(4)  // message
     // ---------------- merge + LayerNorm1 (transformer.py:51-52)
     f32x4 m[C][5];
     zero_tiles(m);
     gemm_bf<M_VT_MERGE, C, kVtWaves>(ws, msg, m, wrap);
+    UFR_PHASE(5)  // merge GEMM
     layer_norm80<C, V_VT_N1W, V_VT_N1B>(m, ws, g);
 
+    UFR_PHASE(6)  // LN1
     // ---------------- MLP on [x | message] + LayerNorm2 + residual (transformer.py:55-58)
     f32x4 cat[C][10], hid[C][10], o[C][5];
 #pragma unroll
@@ -212,6 +235,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
       for (int t = 0; t < 5; ++t) { cat[c][t] = x[c][t]; cat[c][5 + t] = m[c][t]; }
     zero_tiles(hid);
     gemm_bf<M_VT_MLP0, C, kVtWaves>(ws, cat, hid, wrap);
+    UFR_PHASE(7)  // MLP0
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
@@ -220,6 +244,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
         for (int r = 0; r < 4; ++r) hid[c][t][r] = fmaxf(hid[c][t][r], 0.f);
     zero_tiles(o);
     gemm_bf<M_VT_MLP2, C, kVtWaves>(ws, hid, o, wrap);
+    UFR_PHASE(8)  // relu + MLP2
     layer_norm80<C, V_VT_N2W, V_VT_N2B>(o, ws, g);
 #pragma unroll
     for (int c = 0; c < C; ++c)
@@ -240,6 +265,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
       }
     }
 
+    UFR_PHASE(9)  // LN2 + residual + stores
     // colour / mask / direction of this lane's (point, view): (loaded late: they would otherwise sit in 10 registers across the MLP, the register peak)
     f32x4 col[C];
     float dcomp[C];
@@ -276,6 +302,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
       for (int r = 0; r < 4; ++r) h2[c][0][r] = fmaxf(h2[c][0][r], 0.f);
     gemm_bf<M_RW4, C, kVtWaves>(ws, h2, lg, wrap);
 
+    UFR_PHASE(10)  // radiance MLP
     // ---------------- masked softmax over the NV view tokens + colour blend (ray_transformer.py:315-319)
     // logit of token j sits in lane group 0, register 0; lanes of group 0 do the point-local reduction
 #pragma unroll
@@ -305,7 +332,25 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
         dst[2] = cb / den;
       }
     }
+    UFR_PHASE(11)  // softmax blend
   }
+#ifdef UFR_PHASE_TIMING
+  if (wave_global == 5 && lane == 0)
+    for (int i = 0; i < 12; ++i) g_vt_phase[i] += ph_acc[i];
+  if (wave_global == 5 && lane == 0) {
+    g_vt_phase[20] += __builtin_amdgcn_s_memrealtime() - rt_start;   // constant 100 MHz
+    g_vt_phase[21] += __builtin_readcyclecounter() - t_start;
+  }
+  if (lane == 0 && wave_global < 4096) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    g_vt_wave[2 * wave_global] = t_start;
+    g_vt_wave[2 * wave_global + 1] = (__builtin_readcyclecounter() - t_start) | ((unsigned long long)(xcc & 0xf) << 60) |
+                                     ((unsigned long long)(hwid & 0xffff) << 40);
+  }
+#endif
 }
 
 template <int L>
@@ -315,8 +360,15 @@ static hipError_t launch_vt(const float* packed, const float* x_tokens, const fl
   constexpr int PPW = (16 / L) * C;
   const int n_groups = (P + PPW - 1) / PPW;
   int blocks = (n_groups + kVtWaves - 1) / kVtWaves;
-  const int max_blocks = 256 * 2;  // two resident workgroups per CU; grid-stride beyond
+  // Two workgroups are resident per CU, and the older one wins the SIMD's issue arbitration: with exactly
+  // 512 persistent workgroups the favoured half finishes ~25 % early and the rest runs alone, without a
+  // partner wave to overlap its VALU phases with (measured per-wave lifetimes 1.27 .. 1.64 ms).  Launching a
+  // few times more, shorter workgroups lets the dispatcher refill a CU as soon as one retires.
+  const int max_blocks = 256 * 2 * UFR_VT_OVERSUB;
   if (blocks > max_blocks) blocks = max_blocks;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&view_transformer_kernel<L, C>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, kBfLdsBytes);
+  if (attr != hipSuccess) return attr;
   hipLaunchKernelGGL((view_transformer_kernel<L, C>), dim3(blocks), dim3(kVtBlock), kBfLdsBytes, s, packed, x_tokens,
                      rgb, dir, P, token0, radiance, view_out);
   return hipGetLastError();
@@ -336,3 +388,19 @@ hipError_t launch_view_transformer(const float* packed, const float* x_tokens, c
 }
 
 }  // namespace ufr
+
+#ifdef UFR_PHASE_TIMING
+extern "C" int ufr_debug_vt_phases(unsigned long long* out, int n, int reset) {
+  unsigned long long h[32] = {};
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(ufr::g_vt_phase), sizeof(h)) != hipSuccess) return -1;
+  for (int i = 0; i < n && i < 32; ++i) out[i] = h[i];
+  if (reset) {
+    unsigned long long z[32] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(ufr::g_vt_phase), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+extern "C" int ufr_debug_vt_waves(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(ufr::g_vt_wave), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -19,7 +19,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 __global__ void __launch_bounds__(256) composite_kernel(const float* __restrict__ z, const float* __restrict__ radiance,
-                                                         const float* __restrict__ srdf,
+                                                         const int* __restrict__ rad_row, const float* __restrict__ srdf,
                                                          const float* __restrict__ variance, int RN, int SN,
                                                          float* __restrict__ rgb, float* __restrict__ depth,
                                                          float* __restrict__ opacity, float* __restrict__ weight,
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256) composite_kernel(const float* __restrict_
       float w = alpha[k] * T;                             // :42
       T *= (1.f - alpha[k]) + 1e-7f;
       if (weight) weight[(size_t)ray * SN + i] = w;
-      const float* c = radiance + ((size_t)ray * SN + i) * 3;
+      const float* c = radiance + (rad_row ? (size_t)rad_row[(size_t)ray * SN + i] : (size_t)ray * SN + i) * 3;
       acc_r += c[0] * w;
       acc_g += c[1] * w;
       acc_b += c[2] * w;
@@ -100,11 +100,11 @@ __global__ void __launch_bounds__(256) composite_kernel(const float* __restrict_
   }
 }
 
-hipError_t launch_composite(const float* z, const float* radiance, const float* srdf, const float* variance, int RN,
-                            int SN, float* rgb, float* depth, float* opacity, float* weight, const float* camz,
-                            float* depth_z, hipStream_t s) {
+hipError_t launch_composite(const float* z, const float* radiance, const int* rad_row, const float* srdf,
+                            const float* variance, int RN, int SN, float* rgb, float* depth, float* opacity, float* weight,
+                            const float* camz, float* depth_z, hipStream_t s) {
   if (SN > 64 * kMaxK || SN < 2) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(composite_kernel, dim3((RN + 3) / 4), dim3(256), 0, s, z, radiance, srdf, variance, RN, SN, rgb,
+  hipLaunchKernelGGL(composite_kernel, dim3((RN + 3) / 4), dim3(256), 0, s, z, radiance, rad_row, srdf, variance, RN, SN, rgb,
                      depth, opacity, weight, camz, depth_z);
   return hipGetLastError();
 }

@@ -4,9 +4,12 @@
 //   UFORecon.query_depth_from_volume  code1/model.py:350-390            (3 correlation frustums, AC=True/zeros, 3-D)
 //   RayTransformer.forward            code1/ray_transformer.py:185-281  (dir, 2-D gathers AC=False/zeros, depth PE,
 //                                                                        pre_sim_mlp, token assembly)
-// Thread (v, p): view v of point p; a block is 64 consecutive points (samples of one ray) x NV
-// views, i.e. wave v = view v.  All maps are channel-last (prep.hip) so every tap is a run of
-// 16-byte loads from one line.  Cross-view reductions (pair similarities, frustum blending) go
+// A block is 64 consecutive points (samples of one ray) x NV views.  Phase A, thread (v, p) = view v of
+// point p: projection, bilinear footprints, the narrow gathers (colour, depth, frustums).  Phase B, the
+// 32-channel gathers, is cooperative: 8 adjacent lanes share one footprint and each takes 4 channels, so
+// one load instruction touches 8 cache lines instead of 64 -- the L1 (TCP) processes about one line per
+// clock and was the kernel's limiter (r2 PMC: TCP busy ~100 %, 3.1e8 line accesses per 524 288 points).
+// All maps are channel-last (prep.hip).  Cross-view reductions (pair similarities, frustum blending) go
 // through LDS in the reference's summation order.
 #include "ufr_device.h"
 #include "ufr_internal.h"
@@ -64,7 +67,22 @@ __device__ __forceinline__ void sample_volume(const float* __restrict__ vol, int
   wgt = aw;
 }
 
-// LDS layout (floats): xy[NV][64][2] | sim[64][NPAIR][8] | volp[64][NV][25] | outv[64][40]
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void put_tap(float* dst, const Tap2& t) {
+  *reinterpret_cast<i32x4*>(dst) = i32x4{t.o[0], t.o[1], t.o[2], t.o[3]};
+  *reinterpret_cast<f32x4*>(dst + 4) = f32x4{t.w[0], t.w[1], t.w[2], t.w[3]};
+}
+__device__ __forceinline__ Tap2 get_tap(const float* src) {
+  const i32x4 o = *reinterpret_cast<const i32x4*>(src);
+  const f32x4 w = *reinterpret_cast<const f32x4*>(src + 4);
+  Tap2 t;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { t.o[k] = o[k]; t.w[k] = w[k]; }
+  return t;
+}
+
+// LDS layout (floats): xy[NV][64][2] | sim[64][NPAIR][8] | volp[64][NV][25] | outv[64][40] | tapF[NV][64][8] | tapM[NV][64][8]
 __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, const float* __restrict__ ray_o,
                                                       int o_stride, const float* __restrict__ ray_d,
                                                       const float* __restrict__ zval, int P, int SN,
@@ -79,6 +97,8 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
   float* sh_sim = sh_xy + NV * 128;            // 64*npair*8
   float* sh_vol = sh_sim + 64 * npair * 8;     // 64*NV*25
   float* sh_out = sh_vol + 64 * NV * 25;       // 64*40
+  float* sh_tapF = sh_out + 64 * 40;           // NV*64*8: feature-map footprint (align_corners=False, zeros)
+  float* sh_tapM = sh_tapF + NV * 64 * 8;      // NV*64*8: matching-map footprint (align_corners=True, border)
 
   const int v = threadIdx.x >> 6, p = threadIdx.x & 63;
   const int pidx = blockIdx.x * 64 + p;
@@ -113,12 +133,8 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
 
   // ---- 2-D gathers with align_corners=False, zeros (grid_sample.py:5-19; ray_transformer.py:222-237)
   {
-    Tap2 t = taps_zeros(unnorm2d_nac(x, f.w), unnorm2d_nac(y, f.h), f.w, f.h);
-    const float* base = f.feat + (size_t)v * f.h * f.w * 32;
-    if (active) {
-#pragma unroll
-      for (int c = 0; c < 32; c += 4) st4(xrow + c, lerp_tap4(base, 32, t, c));
-    }
+    put_tap(sh_tapF + (v * 64 + p) * 8, taps_zeros(unnorm2d_nac(x, f.w), unnorm2d_nac(y, f.h), f.w, f.h));
+    put_tap(sh_tapM + (v * 64 + p) * 8, taps_border(unnorm2d_ac(x, f.w), unnorm2d_ac(y, f.h), f.w, f.h));
     Tap2 tf = taps_zeros(unnorm2d_nac(x, f.W), unnorm2d_nac(y, f.H), f.W, f.H);
     f32x4 c4 = lerp_tap4(f.rgb + (size_t)v * f.H * f.W * 4, 4, tf, 0);
     const float inb = (x <= 1.f && x >= -1.f && y <= 1.f && y >= -1.f) ? 1.f : 0.f;  // inclusive mask
@@ -171,26 +187,35 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
   }
   __syncthreads();
 
-  // ---- pairwise similarity (model.py:271-283): pair q = (a, b), sides (view a, chunk b) / (view b+1, chunk a)
-  for (int q = v; q < npair; q += NV) {
+  // ---- cooperative 32-channel gathers: lane group of 8 = one footprint, lane c8 = channels 4*c8..4*c8+3
+  const int c8 = threadIdx.x & 7, grp = threadIdx.x >> 3, n_grp = blockDim.x >> 3;
+  // image features of (point, view) -> token columns 0..31 (ray_transformer.py:222-226)
+  for (int item = grp; item < 64 * NV; item += n_grp) {
+    const int ip = item / NV, iv = item - ip * NV;
+    const int ipidx = blockIdx.x * 64 + ip;
+    if (ipidx < P) {
+      const Tap2 t = get_tap(sh_tapF + (iv * 64 + ip) * 8);
+      st4(x_tokens + ((size_t)ipidx * NV + iv) * UFR_TOKEN_DIM + 4 * c8,
+          lerp_tap4(f.feat + (size_t)iv * f.h * f.w * 32, 32, t, 4 * c8));
+    }
+  }
+  // pairwise similarity (model.py:271-283): pair q = (a, b), sides (view a, chunk b) / (view b+1, chunk a);
+  // lane c8 = channel group gi of model.py:278-280
+  for (int item = grp; item < 64 * npair; item += n_grp) {
+    const int ip = item / npair, q = item - ip * npair;
     int a = 0, rem = q;
     while (rem >= NV - 1 - a) { rem -= NV - 1 - a; ++a; }
     const int b = a + rem;
     const int va = a, ca = b, vb = b + 1, cb = a;
-    Tap2 ta = taps_border(unnorm2d_ac(sh_xy[(va * 64 + p) * 2], f.w), unnorm2d_ac(sh_xy[(va * 64 + p) * 2 + 1], f.h), f.w, f.h);
-    Tap2 tb = taps_border(unnorm2d_ac(sh_xy[(vb * 64 + p) * 2], f.w), unnorm2d_ac(sh_xy[(vb * 64 + p) * 2 + 1], f.h), f.w, f.h);
+    const Tap2 ta = get_tap(sh_tapM + (va * 64 + ip) * 8), tb = get_tap(sh_tapM + (vb * 64 + ip) * 8);
     const float* ba = f.match + (size_t)va * f.h * f.w * f.match_ch + 32 * ca;
     const float* bb = f.match + (size_t)vb * f.h * f.w * f.match_ch + 32 * cb;
-    float* dst = sh_sim + (p * npair + q) * 8;
-#pragma unroll
-    for (int gi = 0; gi < 8; ++gi) {  // 8 groups of 4 channels (model.py:278-280)
-      f32x4 fa = lerp_tap4(ba, f.match_ch, ta, 4 * gi);
-      f32x4 fb = lerp_tap4(bb, f.match_ch, tb, 4 * gi);
-      float na = fmaxf(sqrtf(fa[0] * fa[0] + fa[1] * fa[1] + fa[2] * fa[2] + fa[3] * fa[3]), 1e-8f);
-      float nb = fmaxf(sqrtf(fb[0] * fb[0] + fb[1] * fb[1] + fb[2] * fb[2] + fb[3] * fb[3]), 1e-8f);
-      dst[gi] = (fa[0] / na) * (fb[0] / nb) + (fa[1] / na) * (fb[1] / nb) + (fa[2] / na) * (fb[2] / nb) +
-                (fa[3] / na) * (fb[3] / nb);
-    }
+    f32x4 fa = lerp_tap4(ba, f.match_ch, ta, 4 * c8);
+    f32x4 fb = lerp_tap4(bb, f.match_ch, tb, 4 * c8);
+    float na = fmaxf(sqrtf(fa[0] * fa[0] + fa[1] * fa[1] + fa[2] * fa[2] + fa[3] * fa[3]), 1e-8f);
+    float nb = fmaxf(sqrtf(fb[0] * fb[0] + fb[1] * fb[1] + fb[2] * fb[2] + fb[3] * fb[3]), 1e-8f);
+    sh_sim[(ip * npair + q) * 8 + c8] = (fa[0] / na) * (fb[0] / nb) + (fa[1] / na) * (fb[1] / nb) +
+                                        (fa[2] / na) * (fb[2] / nb) + (fa[3] / na) * (fb[3] / nb);
   }
   __syncthreads();
 
@@ -260,7 +285,7 @@ hipError_t launch_gather(const FrameDev& f, const PreSim& ps, const float* ray_o
                          float* vol24, float* xy, float* mask_z, hipStream_t s) {
   const int P = RN * SN, NV = f.NV;
   const int npair = NV * (NV - 1) / 2;
-  size_t lds = sizeof(float) * ((size_t)NV * 128 + 64 * npair * 8 + 64 * NV * 25 + 64 * 40);
+  size_t lds = sizeof(float) * ((size_t)NV * 128 + 64 * npair * 8 + 64 * NV * 25 + 64 * 40 + 2 * (size_t)NV * 64 * 8);
   hipLaunchKernelGGL(gather_kernel, dim3((P + 63) / 64), dim3(64 * NV), lds, s, f, ps, ray_o, o_stride, ray_d, z, P, SN,
                      x_tokens, rgb, dir, sim8, vol24, xy, mask_z);
   return hipGetLastError();

@@ -20,9 +20,10 @@
 namespace ufr {
 
 // load the ray-transformer input tile: [token-0 feature (80) | order PE (8)] in nat88 layout
-__device__ __forceinline__ void load_ray_tile(const float* __restrict__ token0, const float* __restrict__ order_pe,
-                                              size_t tok_base, int s_base, int g, int j, f32x4 (&x)[1][6]) {
-  const float* row = token0 + (tok_base + j) * UFR_TOKEN_DIM;
+__device__ __forceinline__ void load_ray_tile(const float* __restrict__ token0, const int* __restrict__ tok_row,
+                                              const float* __restrict__ order_pe, size_t tok_base, int s_base, int g,
+                                              int j, f32x4 (&x)[1][6]) {
+  const float* row = token0 + (tok_row ? (size_t)tok_row[tok_base + j] : tok_base + j) * UFR_TOKEN_DIM;
 #pragma unroll
   for (int t = 0; t < 5; ++t) x[0][t] = ld4(row + 16 * t + 4 * g);
   const float* pe = order_pe + (size_t)(s_base + j) * 8 + 2 * g;  // features 80+2g, 81+2g in registers 0,1
@@ -66,6 +67,7 @@ constexpr int kRtWaves = kRtBlock / 64;
 
 __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(const float* __restrict__ packed,
                                                                   const float* __restrict__ token0,
+                                                                  const int* __restrict__ tok_row,
                                                                   const float* __restrict__ order_pe, int RN, int SN,
                                                                   float* __restrict__ srdf,
                                                                   float* __restrict__ ray_out) {
@@ -86,7 +88,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
   for (int tile = 0; tile < n_tiles; ++tile) {
     const bool wrap = tile + 1 < n_tiles;
     f32x4 x[1][6], kt[1][8], vt[1][8];
-    load_ray_tile(token0, order_pe, (size_t)ray * SN + tile * 16, tile * 16, g, j, x);
+    load_ray_tile(token0, tok_row, order_pe, (size_t)ray * SN + tile * 16, tile * 16, g, j, x);
 #pragma unroll
     for (int h = 0; h < 8; ++h) { kt[0][h] = splat4(0.f); vt[0][h] = splat4(0.f); }
     {  // swapped operands: kt[h], vt[h] rows = tokens 4g+r, column j = head dim; x is split once per k-step
@@ -126,7 +128,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
   for (int tile = 0; tile < n_tiles; ++tile) {
     const bool wrap = tile + 1 < n_tiles;
     f32x4 x[1][6], q[1][8], msg[1][8];
-    load_ray_tile(token0, order_pe, (size_t)ray * SN + tile * 16, tile * 16, g, j, x);
+    load_ray_tile(token0, tok_row, order_pe, (size_t)ray * SN + tile * 16, tile * 16, g, j, x);
 #pragma unroll
     for (int h = 0; h < 8; ++h) q[0][h] = splat4(0.f);
     gemm_bf<M_RT_Q, 1, kRtWaves>(ws, x, q, wrap);  // q[h]: rows = head dims 4g+r, column j = token
@@ -192,11 +194,11 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
   }
 }
 
-hipError_t launch_ray_transformer(const float* packed, const float* token0, const float* order_pe, int RN, int SN,
-                                  float* srdf, float* ray_out, hipStream_t s) {
+hipError_t launch_ray_transformer(const float* packed, const float* token0, const int* tok_row, const float* order_pe,
+                                  int RN, int SN, float* srdf, float* ray_out, hipStream_t s) {
   if (SN % 16 != 0 || SN < 16) return hipErrorInvalidValue;
   hipLaunchKernelGGL(ray_transformer_kernel, dim3((RN + kRtWaves - 1) / kRtWaves), dim3(kRtBlock), kBfLdsBytes, s,
-                     packed, token0, order_pe, RN, SN, srdf, ray_out);
+                     packed, token0, tok_row, order_pe, RN, SN, srdf, ray_out);
   return hipGetLastError();
 }
 

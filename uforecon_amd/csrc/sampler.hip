@@ -107,7 +107,8 @@ __global__ void __launch_bounds__(256) importance_merge_kernel(const float* __re
                                                                 const float* __restrict__ z,
                                                                 const float* __restrict__ U2, int u_stride,
                                                                 float* __restrict__ z_fine, float* __restrict__ z_all,
-                                                                int RN, int SN, int PN) {
+                                                                int RN, int SN, int PN, float* __restrict__ z_new,
+                                                                int* __restrict__ src_row) {
   __shared__ float lds[4][3 * kMaxS];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ray = blockIdx.x * 4 + wave;
@@ -184,7 +185,11 @@ __global__ void __launch_bounds__(256) importance_merge_kernel(const float* __re
       z_fine[(size_t)ray * PN + rank] = v;
     }
   }
-  // coarse + fine sorted together (model.py:466-470), again by rank over the concatenation
+  // coarse + fine sorted together (model.py:466-470), again by rank over the concatenation.
+  // z_new / src_row (whole-path renderer): the PN new positions in draw order, and for every merged slot the
+  // row of the pool [RN*SN coarse evaluations | RN*PN new evaluations] that holds its per-point results --
+  // a point's view-transformer output does not depend on the other samples of the ray, so the fine pass
+  // re-evaluates only the new points and reads the coarse ones back through this table.
   const int T = SN + PN;
   float* out = z_all + (size_t)ray * T;
   for (int k = lane; k < T; k += 64) {
@@ -195,14 +200,16 @@ __global__ void __launch_bounds__(256) importance_merge_kernel(const float* __re
       rank += (o < v || (o == v && j < k)) ? 1 : 0;
     }
     out[rank] = v;
+    if (src_row) src_row[(size_t)ray * T + rank] = k < SN ? ray * SN + k : RN * SN + ray * PN + (k - SN);
+    if (z_new && k >= SN) z_new[(size_t)ray * PN + (k - SN)] = v;
   }
 }
 
 hipError_t launch_importance_merge(const float* weight, const float* z, const float* U2, int u_stride, float* z_fine,
-                                   float* z_all, int RN, int SN, int PN, hipStream_t s) {
+                                   float* z_all, int RN, int SN, int PN, float* z_new, int* src_row, hipStream_t s) {
   if (SN > kMaxS || PN > kMaxS || SN < 2) return hipErrorInvalidValue;
   hipLaunchKernelGGL(importance_merge_kernel, dim3((RN + 3) / 4), dim3(256), 0, s, weight, z, U2, u_stride, z_fine,
-                     z_all, RN, SN, PN);
+                     z_all, RN, SN, PN, z_new, src_row);
   return hipGetLastError();
 }
 

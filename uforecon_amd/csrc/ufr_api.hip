@@ -219,7 +219,8 @@ int ufr_sample_importance_merge(const float* weight, const float* z, const float
   UFR_REQUIRE(weight && z && U2 && z_all, "ufr_sample_importance_merge: null argument");
   UFR_REQUIRE(RN > 0 && SN >= 2 && SN <= 256 && PN >= 1 && PN <= 256, "ufr_sample_importance_merge: RN=%d SN=%d PN=%d",
               RN, SN, PN);
-  UFR_HIP(launch_importance_merge(weight, z, U2, RN, z_fine, z_all, RN, SN, PN, static_cast<hipStream_t>(stream)));
+  UFR_HIP(launch_importance_merge(weight, z, U2, RN, z_fine, z_all, RN, SN, PN, nullptr, nullptr,
+                                  static_cast<hipStream_t>(stream)));
   return UFR_OK;
 }
 
@@ -263,7 +264,7 @@ static int aggregate_impl(const void* packed, const float* x_tokens, const float
   if (!pe_ready) UFR_HIP(launch_order_pe(order_pe, SN, s));
   {
     ProfScope ps("ray_transformer", s);
-    UFR_HIP(launch_ray_transformer(static_cast<const float*>(packed), token0, order_pe, RN, SN, srdf, ray_out, s));
+    UFR_HIP(launch_ray_transformer(static_cast<const float*>(packed), token0, nullptr, order_pe, RN, SN, srdf, ray_out, s));
   }
   return UFR_OK;
 }
@@ -285,7 +286,7 @@ int ufr_composite(const float* z, const float* radiance, const float* srdf, cons
                   int32_t SN, float* rgb, float* depth, float* opacity, float* weight, ufr_stream stream) {
   UFR_REQUIRE(z && radiance && srdf && variance && depth, "ufr_composite: null argument");
   UFR_REQUIRE(RN > 0 && SN >= 2 && SN <= 256, "ufr_composite: SN=%d out of range [2,256]", SN);
-  UFR_HIP(launch_composite(z, radiance, srdf, variance, RN, SN, rgb, depth, opacity, weight, nullptr, nullptr,
+  UFR_HIP(launch_composite(z, radiance, nullptr, srdf, variance, RN, SN, rgb, depth, opacity, weight, nullptr, nullptr,
                            static_cast<hipStream_t>(stream)));
   return UFR_OK;
 }
@@ -296,11 +297,14 @@ int32_t ufr_default_chunk_rays(void) { return 4096; }
 namespace {
 struct RenderWs {
   float *ray_o, *rd, *near, *far, *camz, *z1, *w1, *srdf1, *depth1, *rgb1, *z2, *srdf2, *rad, *x, *rgbm, *dir, *token0,
-      *pe1, *pe2;
+      *pe1, *pe2, *z_new;
+  int* row;  // merged slot -> row of the [coarse | new] evaluation pool (token0, rad)
   size_t bytes;
 };
 RenderWs carve_render(void* ws, int R, int SN, int PN, int NV) {
-  const size_t S2 = (size_t)SN + PN, Smax = S2 > (size_t)SN ? S2 : SN;
+  // Smax: samples per ray in the evaluation pool (coarse + new); Sg: points per ray one gather / view-transformer
+  // launch handles (the fine pass evaluates only its PN new points)
+  const size_t S2 = (size_t)SN + PN, Smax = S2 > (size_t)SN ? S2 : SN, Sg = (size_t)(SN > PN ? SN : PN);
   Carver c(ws);
   RenderWs r;
   r.ray_o = c.f32(4);
@@ -316,9 +320,11 @@ RenderWs carve_render(void* ws, int R, int SN, int PN, int NV) {
   r.z2 = c.f32((size_t)R * S2);
   r.srdf2 = c.f32((size_t)R * S2);
   r.rad = c.f32((size_t)R * Smax * 3);
-  r.x = c.f32((size_t)R * Smax * NV * UFR_TOKEN_DIM);
-  r.rgbm = c.f32((size_t)R * Smax * NV * 4);
-  r.dir = c.f32((size_t)R * Smax * NV * 4);
+  r.x = c.f32((size_t)R * Sg * NV * UFR_TOKEN_DIM);
+  r.rgbm = c.f32((size_t)R * Sg * NV * 4);
+  r.dir = c.f32((size_t)R * Sg * NV * 4);
+  r.z_new = c.f32((size_t)R * (PN > 0 ? PN : 1));
+  r.row = reinterpret_cast<int*>(c.f32((size_t)R * S2));
   r.token0 = c.f32((size_t)R * Smax * UFR_TOKEN_DIM);
   r.pe1 = c.f32((size_t)SN * 8);
   r.pe2 = c.f32(S2 * 8);
@@ -381,7 +387,7 @@ int render_chunk(const ufr_render_args* a, const FrameDev* f, const RenderWs& w,
   const bool last = a->coarse_only != 0;
   {
     ProfScope p("composite", s);
-    UFR_HIP(launch_composite(w.z1, w.rad, w.srdf1, a->raw->variance, R, SN, last ? a->rgb + 3 * (size_t)r0 : w.rgb1,
+    UFR_HIP(launch_composite(w.z1, w.rad, nullptr, w.srdf1, a->raw->variance, R, SN, last ? a->rgb + 3 * (size_t)r0 : w.rgb1,
                              last ? a->depth + r0 : w.depth1, nullptr, w.w1, w.camz,
                              (last && a->depth_z) ? a->depth_z + r0 : nullptr, s));
   }
@@ -390,21 +396,32 @@ int render_chunk(const ufr_render_args* a, const FrameDev* f, const RenderWs& w,
     if (a->z_all) UFR_HIP(hipMemcpyAsync(a->z_all + (size_t)r0 * SN, w.z1, (size_t)R * SN * 4, hipMemcpyDeviceToDevice, s));
     return UFR_OK;
   }
-  // ---- importance sampling + merge (model.py:455-470), fine pass (model.py:472)
+  // ---- importance sampling + merge (model.py:455-470), fine pass (model.py:472).  The reference re-evaluates
+  // all SN+PN merged samples; a sample's gathers and view-transformer output depend on its own position only,
+  // so the SN coarse evaluations (token0, radiance: rows [0, R*SN) of the pool) are kept and only the PN new
+  // points go through gather + view transformer (rows [R*SN, R*(SN+PN))).  The ray transformer and the
+  // compositor, which do couple the samples of a ray, run over all SN+PN through the slot -> row table.
   {
     ProfScope p("sampler", s);
-    UFR_HIP(launch_importance_merge(w.w1, w.z1, a->U2 + r0, RN, nullptr, w.z2, R, SN, PN, s));
+    UFR_HIP(launch_importance_merge(w.w1, w.z1, a->U2 + r0, RN, nullptr, w.z2, R, SN, PN, w.z_new, w.row, s));
   }
   {
     ProfScope p("gather", s);
-    UFR_HIP(launch_gather(*f, ps, w.ray_o, 0, w.rd, w.z2, R, S2, w.x, w.rgbm, w.dir, nullptr, nullptr, nullptr, nullptr, s));
+    UFR_HIP(launch_gather(*f, ps, w.ray_o, 0, w.rd, w.z_new, R, PN, w.x, w.rgbm, w.dir, nullptr, nullptr, nullptr, nullptr, s));
   }
-  rc = aggregate_impl(a->packed_weights, w.x, w.rgbm, w.dir, R, S2, NV, w.rad, w.srdf2, w.token0, w.pe2, true, nullptr,
-                      nullptr, s);
-  if (rc != UFR_OK) return rc;
+  {
+    ProfScope p("view_transformer", s);
+    UFR_HIP(launch_view_transformer(static_cast<const float*>(a->packed_weights), w.x, w.rgbm, w.dir, R * PN, NV,
+                                    w.token0 + (size_t)R * SN * UFR_TOKEN_DIM, w.rad + (size_t)R * SN * 3, nullptr, s));
+  }
+  {
+    ProfScope p("ray_transformer", s);
+    UFR_HIP(launch_ray_transformer(static_cast<const float*>(a->packed_weights), w.token0, w.row, w.pe2, R, S2, w.srdf2,
+                                   nullptr, s));
+  }
   {
     ProfScope p("composite", s);
-    UFR_HIP(launch_composite(w.z2, w.rad, w.srdf2, a->raw->variance, R, S2, a->rgb + 3 * (size_t)r0, a->depth + r0,
+    UFR_HIP(launch_composite(w.z2, w.rad, w.row, w.srdf2, a->raw->variance, R, S2, a->rgb + 3 * (size_t)r0, a->depth + r0,
                              nullptr, nullptr, w.camz, a->depth_z ? a->depth_z + r0 : nullptr, s));
   }
   if (a->srdf) UFR_HIP(hipMemcpyAsync(a->srdf + (size_t)r0 * S2, w.srdf2, (size_t)R * S2 * 4, hipMemcpyDeviceToDevice, s));

@@ -41,7 +41,7 @@ hipError_t launch_ray_setup(const int64_t* ray_idx, const float* ray_d, const fl
 hipError_t launch_sample_fixed(const float* near, const float* far, const float* U, int u_stride, float* z, int RN,
                                int SN, hipStream_t s);
 hipError_t launch_importance_merge(const float* weight, const float* z, const float* U2, int u_stride, float* z_fine,
-                                   float* z_all, int RN, int SN, int PN, hipStream_t s);
+                                   float* z_all, int RN, int SN, int PN, float* z_new, int* src_row, hipStream_t s);
 hipError_t launch_order_pe(float* table, int SN, hipStream_t s);
 hipError_t launch_points(const float* ray_o, int o_stride, const float* ray_d, const float* z, float* pts, int RN,
                          int SN, hipStream_t s);
@@ -50,11 +50,13 @@ hipError_t launch_gather(const FrameDev& f, const PreSim& ps, const float* ray_o
                          float* vol24, float* xy, float* mask_z, hipStream_t s);
 hipError_t launch_view_transformer(const float* packed, const float* x_tokens, const float* rgb, const float* dir,
                                    int P, int NV, float* token0, float* radiance, float* view_out, hipStream_t s);
-hipError_t launch_ray_transformer(const float* packed, const float* token0, const float* order_pe, int RN, int SN,
-                                  float* srdf, float* ray_out, hipStream_t s);
-hipError_t launch_composite(const float* z, const float* radiance, const float* srdf, const float* variance, int RN,
-                            int SN, float* rgb, float* depth, float* opacity, float* weight, const float* camz,
-                            float* depth_z, hipStream_t s);
+// tok_row / rad_row (nullable): row of token0 / radiance holding sample (ray, s) -- the fine pass of the whole-path
+// renderer keeps coarse and new evaluations in one pool instead of re-evaluating the coarse points
+hipError_t launch_ray_transformer(const float* packed, const float* token0, const int* tok_row, const float* order_pe,
+                                  int RN, int SN, float* srdf, float* ray_out, hipStream_t s);
+hipError_t launch_composite(const float* z, const float* radiance, const int* rad_row, const float* srdf,
+                            const float* variance, int RN, int SN, float* rgb, float* depth, float* opacity, float* weight,
+                            const float* camz, float* depth_z, hipStream_t s);
 hipError_t launch_pack_weights(const RawPtrs& raw, float* packed, hipStream_t s);
 
 }  // namespace ufr

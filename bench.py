@@ -7,6 +7,12 @@ then ufr_render_rays over this rank's row tile, then (N>1) an RCCL all-gather of
 tiles.  Inputs are synthetic (uforecon_amd.scene, seed 0; random-init weights seed 0) and resident
 in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
+`roofline` describes the dominant kernel (view_transformer_kernel): algorithmic flop of the reference
+layer chain per launch / its launch duration from HIP events.  With --streams > 1 the chunks of a
+frame overlap on side streams and a kernel's event interval includes its neighbours, so the
+per-kernel durations are then taken from one extra, untimed, single-stream frame right after the
+timed region (same inputs, same launches); with --streams 1 they come from the timed region itself.
+
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
@@ -29,7 +35,12 @@ FLOP_PER_POINT = {3: 708_018, 5: 983_150}
 # ... of which the view-transformer launch (q/k/v/merge 204 800 + MLP 307 200 + attention 13 440 +
 # radiance MLP 8 784 at NV=3): the dominant kernel the roofline object describes
 VIEWT_FLOP_PER_POINT = {3: 204_800 + 307_200 + 13_440 + 8_784, 5: (204_800 + 307_200) * 6 // 4 + 20_160 + 14_640}
+RAYT_FLOP_PER_POINT = 61_952 + 92_928 + 4_048 + 6_688   # ray transformer + DensityMLP (d = 88, 8 heads)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # dense bf16 MFMA peak: 256 CU x 4 SIMD x 1024 flop/clk x 2.4 GHz
+# the transformer kernels compute every fp32 product as six bf16 plane products (exact 3-way split of both
+# operands, fp32 accumulate: ufr_layout_bf.h), so their matrix-core bound in fp32-equivalent flop is peak/6
+PEAK_F32_VIA_BF16X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 
 
 def parse():
@@ -43,7 +54,7 @@ def parse():
     p.add_argument("--coarse", type=int, default=64)
     p.add_argument("--fine", type=int, default=64)
     p.add_argument("--chunk", type=int, default=0, help="rays per launch group (0 = library default)")
-    p.add_argument("--streams", type=int, default=2, help="side streams the chunks are spread over")
+    p.add_argument("--streams", type=int, default=3, help="side streams the chunks are spread over")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-rays", type=int, default=256)
     p.add_argument("--cpu-calls", type=int, default=5)
@@ -126,12 +137,21 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
-    ops.profile_enable(True)
+    ops.profile_enable(a.streams <= 1)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
+    prof_steps = a.steps
+    if a.streams > 1:  # per-kernel durations: one untimed single-stream frame (see the module docstring)
+        ws1 = ops.RenderWorkspace(dev, a.coarse, a.fine, a.views, chunk_rays=a.chunk, n_streams=1)
+        ws, prof_steps = ws1, 1
+        step()
+        fence()
+        ops.profile_enable(True)
+        step()
+        fence()
     prof = ops.profile_read()
     ops.profile_enable(False)
     if world > 1:
@@ -141,13 +161,19 @@ def main():
 
     if rank == 0:
         S = a.coarse + a.fine
-        pts_per_ray = a.coarse + S
+        # the reference evaluates coarse + (coarse + fine) samples per ray; this path keeps the coarse per-point
+        # results and evaluates coarse + fine points (gathers, view transformer), coarse + (coarse + fine) ray-level
+        ref_pts_per_ray = a.coarse + S
+        point_evals_per_ray = a.coarse + a.fine
+        ray_evals_per_ray = a.coarse + S
         rays_per_s = HW * a.steps / dt
         flop_pt = FLOP_PER_POINT.get(a.views)
+        exec_flop_per_ray = None
+        if flop_pt:
+            exec_flop_per_ray = (flop_pt - RAYT_FLOP_PER_POINT) * point_evals_per_ray + RAYT_FLOP_PER_POINT * ray_evals_per_ray
         vt = prof.get("view_transformer", dict(ms=0.0, launches=1))
         chunk = ws.chunk
-        # one view-transformer launch = chunk rays x SN (coarse) or S (fine) points; average over both
-        vt_pts_per_launch = (RN * pts_per_ray * a.steps) / max(vt["launches"], 1)
+        vt_pts_per_launch = (RN * point_evals_per_ray * prof_steps) / max(vt["launches"], 1)
         vt_ms = vt["ms"] / max(vt["launches"], 1)
         vt_flop = VIEWT_FLOP_PER_POINT.get(a.views, 0) * vt_pts_per_launch
         achieved = vt_flop / (vt_ms * 1e-3) / 1e12 if vt_ms > 0 else 0.0
@@ -166,17 +192,28 @@ def main():
             ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None,
             dtype="f32", data="synthetic",
             config=dict(workload=f"configs[1]: full {a.height}x{a.width} frame = {HW} rays, {a.views} source views, "
-                                 f"{a.coarse}+{a.fine} samples ({pts_per_ray} point evaluations/ray), rays sharded by row "
-                                 f"tiles over {world} GPU(s), depth/RGB tiles all-gathered",
-                        rays_per_frame=HW, chunk_rays=chunk, side_streams=ws.n_streams, depth_map_ms_per_frame=dt / a.steps * 1e3,
-                        whole_path_tflops=(rays_per_s * pts_per_ray * flop_pt / 1e12) if flop_pt else None,
-                        whole_path_frac_of_fp32_mfma_peak=(rays_per_s * pts_per_ray * flop_pt / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world))
-                        if flop_pt else None,
-                        kernel_ms_per_frame_rank0={k: v["ms"] / a.steps for k, v in prof.items()}),
-            roofline=dict(bound="mfma", achieved=achieved, peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                          frac=achieved / PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_source=traffic_src,
+                                 f"{a.coarse}+{a.fine} samples, rays sharded by row tiles over {world} GPU(s), depth/RGB "
+                                 f"tiles all-gathered",
+                        rays_per_frame=HW, chunk_rays=chunk, side_streams=a.streams, depth_map_ms_per_frame=dt / a.steps * 1e3,
+                        reference_point_evaluations_per_ray=ref_pts_per_ray,
+                        executed_evaluations_per_ray=dict(gather_and_view_transformer=point_evals_per_ray,
+                                                          ray_transformer_and_compositor=ray_evals_per_ray,
+                                                          note="coarse per-point results are reused by the fine pass (bit-identical)"),
+                        arithmetic="fp32 in/out; dense layers as six bf16 plane products per fp32 product on the bf16 MFMA "
+                                   "(exact 3-way split, fp32 accumulate); gathers, attention, norms, compositor in fp32 VALU",
+                        executed_tflops=(rays_per_s * exec_flop_per_ray / 1e12) if exec_flop_per_ray else None,
+                        reference_equivalent_tflops=(rays_per_s * ref_pts_per_ray * flop_pt / 1e12) if flop_pt else None,
+                        kernel_ms_per_frame_rank0={k: v["ms"] / prof_steps for k, v in prof.items()},
+                        kernel_ms_measured="timed region" if a.streams <= 1 else "one extra single-stream frame after the timed region"),
+            roofline=dict(bound="mfma", achieved=achieved, peak=PEAK_F32_VIA_BF16X6_TFLOPS, unit="TFLOP/s",
+                          frac=achieved / PEAK_F32_VIA_BF16X6_TFLOPS, traffic=traffic, traffic_source=traffic_src,
                           kernel="view_transformer_kernel", avg_launch_ms=vt_ms, launches=vt["launches"],
-                          algorithmic_flop_per_launch=vt_flop),
+                          algorithmic_flop_per_launch=vt_flop,
+                          peak_basis="dense bf16 MFMA peak 2516.6 TFLOP/s / 6 plane products per fp32 product (bf16x6); "
+                                     "the fp32 MFMA peak is 157.3 TFLOP/s",
+                          frac_of_fp32_mfma_peak=achieved / PEAK_FP32_MFMA_TFLOPS,
+                          # 1680 v_mfma_f32_16x16x32_bf16 (16 384 flop each) per 8 points at NV = 3, K / row padding included
+                          issued_bf16_tflops=achieved * (1680 * 16384 / 8) / VIEWT_FLOP_PER_POINT[3] if a.views == 3 else None),
         )
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(frame_cpu, weights_cpu, a)

@@ -205,6 +205,13 @@ def bf_streams():
 
 
 BF_CHUNK = 24  # fragments per LDS chunk (kBfChunkFrags)
+BF_SLOTS = 2   # LDS ring depth (kBfSlots): streams are padded to whole rings
+
+
+def _stream_len(panels):
+    n = sum(MATS[NAME2IDX[m]][3] * 3 for m, _ in panels)
+    chunks = (n + BF_CHUNK - 1) // BF_CHUNK
+    return (chunks + BF_SLOTS - 1) // BF_SLOTS * BF_SLOTS * BF_CHUNK
 
 
 def panel_start(name, s):
@@ -216,12 +223,12 @@ def panel_start(name, s):
             if (n, k) == (name, s):
                 return base + off
             off += MATS[NAME2IDX[n]][3] * 3
-        base += (off + BF_CHUNK - 1) // BF_CHUNK * BF_CHUNK
+        base += _stream_len(panels)
     raise KeyError((name, s))
 
 
 def bf_region_frags():
-    return sum((sum(MATS[NAME2IDX[n]][3] * 3 for n, _ in p) + BF_CHUNK - 1) // BF_CHUNK * BF_CHUNK for p in bf_streams())
+    return sum(_stream_len(p) for p in bf_streams())
 
 
 def mfma_bf16(a, b, acc):

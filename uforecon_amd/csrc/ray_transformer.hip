@@ -121,6 +121,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
         KV[h] = mfma16(kk, vv, KV[h]);
       }
     }
+    wstream_bf_finish<B_RT1, kRtWaves>(ws, wrap);
   }
 
   // ---------------- sweep 2 (slot 0 is free: every wave passed the barrier that opened sweep 1's last chunk)
@@ -191,12 +192,16 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
     for (int r = 0; r < 4; ++r) d2[0][0][r] = fmaxf(d2[0][0][r], 0.f);
     gemm_bf<M_DM4, 1, kRtWaves>(ws, d2, d3, wrap);
     if (g == 0 && valid) srdf[(size_t)ray * SN + tile * 16 + j] = d3[0][0][0];
+    wstream_bf_finish<B_RT2, kRtWaves>(ws, wrap);
   }
 }
 
 hipError_t launch_ray_transformer(const float* packed, const float* token0, const int* tok_row, const float* order_pe,
                                   int RN, int SN, float* srdf, float* ray_out, hipStream_t s) {
   if (SN % 16 != 0 || SN < 16) return hipErrorInvalidValue;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ray_transformer_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, kBfLdsBytes);
+  if (attr != hipSuccess) return attr;
   hipLaunchKernelGGL(ray_transformer_kernel, dim3((RN + kRtWaves - 1) / kRtWaves), dim3(kRtBlock), kBfLdsBytes, s,
                      packed, token0, tok_row, order_pe, RN, SN, srdf, ray_out);
   return hipGetLastError();

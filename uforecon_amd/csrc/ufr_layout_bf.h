@@ -34,7 +34,11 @@ constexpr int kBfChunkFrags = 24;  // 24 KiB chunks: 8 (tile, 3 planes) triples;
 #ifndef UFR_BF_SLOTS
 #define UFR_BF_SLOTS 2
 #endif
-constexpr int kBfSlots = UFR_BF_SLOTS;  // LDS ring depth: kBfSlots-1 chunks in flight (3 measured no faster than 2)
+// LDS ring depth: kBfSlots-1 chunks in flight.  Measured: a third slot changes neither kernel alone (the 11 % /
+// 21 % the no-DMA ablation recovers for the view / ray transformer is the issue cost of the LDS-DMA
+// instructions, not exposed latency), and the extra 48 KiB of LDS per CU costs 5 % of whole-frame throughput
+// when the gather kernel of another chunk runs beside the transformers on side streams.
+constexpr int kBfSlots = UFR_BF_SLOTS;
 
 enum BfStream { B_VT = 0, B_RT1 = 1, B_RT2 = 2, B_COUNT = 3 };
 
@@ -93,16 +97,16 @@ __host__ __device__ constexpr int bf_panel_index(int m, int s) {  // within the 
   return -1;
 }
 __host__ __device__ constexpr int bf_stream_frags(int S) { return bf_panel_start(S, bf_n_panels(S)); }
-// the last chunk holds the stream's tail: the wrap-around fetch is issued when it opens
-__host__ __device__ constexpr int bf_stream_chunks(int S) { return (bf_stream_frags(S) + kBfChunkFrags - 1) / kBfChunkFrags; }
+// chunks that hold fragments, and the stream's length in the region: padded to a multiple of the ring depth so
+// that a chunk's LDS slot does not depend on the pass; the kernels open the padding chunks explicitly
+// (wstream_bf_finish) to keep the fetch schedule uniform
+__host__ __device__ constexpr int bf_stream_real_chunks(int S) { return (bf_stream_frags(S) + kBfChunkFrags - 1) / kBfChunkFrags; }
+__host__ __device__ constexpr int bf_stream_chunks(int S) { return (bf_stream_real_chunks(S) + kBfSlots - 1) / kBfSlots * kBfSlots; }
 __host__ __device__ constexpr int bf_stream_base_frags(int S) {   // first fragment of stream S in the bf16 region
   int o = 0;
   for (int j = 0; j < S; ++j) o += bf_stream_chunks(j) * kBfChunkFrags;
   return o;
 }
-static_assert(bf_stream_chunks(B_VT) % kBfSlots == 0 && bf_stream_chunks(B_RT1) % kBfSlots == 0 &&
-                  bf_stream_chunks(B_RT2) % kBfSlots == 0,
-              "a chunk's LDS slot must not depend on the pass over the stream");
 constexpr int kBfFragsPadded = bf_stream_base_frags(B_COUNT);
 constexpr int kBfHalfwords = kBfFragsPadded * 512;                  // bf16 elements in the region
 constexpr int kBfBytes = kBfFragsPadded * 1024;

@@ -332,6 +332,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
         dst[2] = cb / den;
       }
     }
+    wstream_bf_finish<B_VT, kVtWaves>(ws, wrap);
     UFR_PHASE(11)  // softmax blend
   }
 #ifdef UFR_PHASE_TIMING

@@ -119,6 +119,13 @@ __device__ __forceinline__ void wstream_bf_open(const WStreamBf& ws, bool wrap) 
   }
 }
 
+// end of a pass over stream S: open its padding chunks (none for most streams) so the wrap-around fetches go out
+template <int S, int NWAVES>
+__device__ __forceinline__ void wstream_bf_finish(const WStreamBf& ws, bool wrap) {
+  constexpr int real = bf_stream_real_chunks(S), pad = bf_stream_chunks(S) - real;
+  static_for<pad>([&](auto ci) __attribute__((always_inline)) { wstream_bf_open<S, NWAVES, real + decltype(ci)::value>(ws, wrap); });
+}
+
 // start of a pass over stream S: its first kBfSlots-1 chunks.  The slots must be free: at kernel start, or
 // after every wave has passed the barrier that opened the previous stream's last chunk with wrap == false
 // (then slot 0.. are no longer read; the last chunk's own slot is (n_chunks-1) % kBfSlots = kBfSlots-1).

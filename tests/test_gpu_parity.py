@@ -152,6 +152,32 @@ def test_render_rays_chunking_is_invisible(weights):
     assert torch.equal(a["depth"], b["depth"]) and torch.equal(a["rgb"], b["rgb"])
 
 
+def test_fine_pass_pool_equals_full_reevaluation(weights):
+    """ufr_render_rays keeps the coarse samples' per-point results and evaluates only the new points in the
+    fine pass; the reference (model.py:466-472) re-evaluates all merged samples.  Walking the reference's order
+    through the stepwise entry points gives the same bits: a point's gathers and view-transformer output depend
+    on that point alone."""
+    fr, idx, U1, U2, g = case_inputs("c2_hier_small")
+    f = fr.to(DEV)
+    fh = _frame_handle(fr)
+    ray_o, ray_d, near, far = (t.to(DEV) for t in _ray_setup(fr, idx))
+    var = weights.variance
+    z1 = ops.sample_fixed(near, far, U1.to(DEV))
+    RN, SN = z1.shape
+    x, rgbm, dirs, _ = ops.project_gather(fh, weights, ray_o, ray_d, z1)
+    rad1, srdf1, _ = ops.aggregate(weights, x, rgbm, dirs, RN, SN)
+    _, _, _, w1 = ops.composite(z1, rad1, srdf1, var)
+    _, z2 = ops.sample_importance_merge(w1, z1, U2.to(DEV), want_fine=False)
+    S2 = z2.shape[1]
+    x, rgbm, dirs, _ = ops.project_gather(fh, weights, ray_o, ray_d, z2)         # all SN+PN merged samples
+    rad2, srdf2, _ = ops.aggregate(weights, x, rgbm, dirs, RN, S2)
+    rgb2, depth2, _, _ = ops.composite(z2, rad2, srdf2, var)
+    out = ops.render_rays(fh, weights, idx.to(DEV), U1.to(DEV), U2.to(DEV))
+    assert torch.equal(out["z_all"], z2)
+    assert torch.equal(out["srdf"], srdf2)
+    assert torch.equal(out["depth"], depth2) and torch.equal(out["rgb"], rgb2)
+
+
 def test_edge_cases(weights):
     fr, idx, U1, U2, g = case_inputs("c2_hier_small")
     fh = _frame_handle(fr)

@@ -20,10 +20,14 @@ ARCH = "gfx950"
 
 SOURCES = ["ufr_api.hip", "prep.hip", "sampler.hip", "gather.hip", "view_transformer.hip",
            "ray_transformer.hip", "composite.hip"]
+# -ffp-contract=on: fuse a*b+c only inside one expression.  hipcc's default (fast) also fuses across statements,
+# and did so differently in the two unrolled copies of the per-tile code of the view transformer: a point's result
+# then depended on which column tile it landed in (1 ulp), which breaks "rays are independent -> chunking and the
+# fine pass's reuse of coarse evaluations are invisible" (tests/test_gpu_parity.py checks both bit for bit).
 # -fno-slp-vectorize: packed-f32 VALU (v_pk_add/fma_f32) issued beside MFMAs costs more than the two scalar
 # instructions it replaces (MI355X_MICROARCH.md; measured 2 % on both transformer kernels)
 CXXFLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value",
-            "-fno-slp-vectorize", f"-I{INCLUDE}", f"-I{CSRC}"]
+            "-fno-slp-vectorize", "-ffp-contract=on", f"-I{INCLUDE}", f"-I{CSRC}"]
 
 
 def _hipcc() -> str:

@@ -82,7 +82,10 @@ __device__ __forceinline__ Tap2 get_tap(const float* src) {
   return t;
 }
 
-// LDS layout (floats): xy[NV][64][2] | sim[64][NPAIR][8] | volp[64][NV][25] | outv[64][40] | tapF[NV][64][8] | tapM[NV][64][8]
+// LDS layout (floats): sim[64][NPAIR][8] | volp[64][NV-1][25] (views >= 1; wave 0 keeps its own in registers) |
+// { tapF[NV][64][8] | tapM[NV][64][8] } aliased with outv[64][40] (the footprints are dead once sim is complete).
+// The footprint of a block bounds the CU's occupancy -- of this kernel, and of the mix when it runs beside the
+// transformer kernels of another chunk (side streams).
 __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, const float* __restrict__ ray_o,
                                                       int o_stride, const float* __restrict__ ray_d,
                                                       const float* __restrict__ zval, int P, int SN,
@@ -93,12 +96,11 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int NV = f.NV;
   const int npair = NV * (NV - 1) / 2;
-  float* sh_xy = smem;                         // NV*64*2
-  float* sh_sim = sh_xy + NV * 128;            // 64*npair*8
-  float* sh_vol = sh_sim + 64 * npair * 8;     // 64*NV*25
-  float* sh_out = sh_vol + 64 * NV * 25;       // 64*40
-  float* sh_tapF = sh_out + 64 * 40;           // NV*64*8: feature-map footprint (align_corners=False, zeros)
+  float* sh_sim = smem;                        // 64*npair*8
+  float* sh_vol = sh_sim + 64 * npair * 8;     // 64*(NV-1)*25
+  float* sh_tapF = sh_vol + 64 * (NV - 1) * 25;  // NV*64*8: feature-map footprint (align_corners=False, zeros)
   float* sh_tapM = sh_tapF + NV * 64 * 8;      // NV*64*8: matching-map footprint (align_corners=True, border)
+  float* sh_out = sh_tapF;                     // 64*40, written after the last footprint read
 
   const int v = threadIdx.x >> 6, p = threadIdx.x & 63;
   const int pidx = blockIdx.x * 64 + p;
@@ -121,8 +123,6 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
   float qz = fmaf(M[10], pz, fmaf(M[9], py, mul_rn(M[8], px))) + M[11];
   const float mask_z = qz > 0.f ? 1.f : 0.f;
   const float x = qx / qz, y = qy / qz;
-  sh_xy[(v * 64 + p) * 2 + 0] = x;
-  sh_xy[(v * 64 + p) * 2 + 1] = y;
   if (active && xy_out) {
     xy_out[((size_t)v * P + pidx) * 2 + 0] = x;
     xy_out[((size_t)v * P + pidx) * 2 + 1] = y;
@@ -168,6 +168,7 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
   }
 
   // ---- correlation frustums of view v (model.py:359-386)
+  float own[25];
   {
     const float zn = ((qz - f.vol_near) / (f.vol_far - f.vol_near)) * 2.f - 1.f;  // camera.py:400-401
     float fl[24], wl = 0.f;
@@ -180,10 +181,14 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
       for (int c = 0; c < 8; ++c) fl[8 * s + c] = fs[c];
       wl = s == 0 ? ws : wl + ws;                                                 // :375-378
     }
-    float* dst = sh_vol + (p * NV + v) * 25;
 #pragma unroll
-    for (int c = 0; c < 24; ++c) dst[c] = fl[c] * wl;                             // features_L * weights_L
-    dst[24] = wl;
+    for (int c = 0; c < 24; ++c) own[c] = fl[c] * wl;                             // features_L * weights_L
+    own[24] = wl;
+    if (v > 0) {
+      float* dst = sh_vol + (p * (NV - 1) + (v - 1)) * 25;
+#pragma unroll
+      for (int c = 0; c < 25; ++c) dst[c] = own[c];
+    }
   }
   __syncthreads();
 
@@ -230,11 +235,12 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
     }
     float* ov = sh_out + p * 40;
     {
-      float Wsum = 0.f;
-      for (int n = 0; n < NV; ++n) Wsum = n == 0 ? sh_vol[(p * NV + n) * 25 + 24] : Wsum + sh_vol[(p * NV + n) * 25 + 24];
+      float Wsum = own[24];                                                       // view 0 first, then 1..NV-1
+      for (int n = 1; n < NV; ++n) Wsum += sh_vol[(p * (NV - 1) + n - 1) * 25 + 24];
+#pragma unroll
       for (int c = 0; c < 24; ++c) {
-        float G = 0.f;
-        for (int n = 0; n < NV; ++n) G = n == 0 ? sh_vol[(p * NV + n) * 25 + c] : G + sh_vol[(p * NV + n) * 25 + c];
+        float G = own[c];
+        for (int n = 1; n < NV; ++n) G += sh_vol[(p * (NV - 1) + n - 1) * 25 + c];
         ov[c] = G / (Wsum + 1e-8f);                                               // model.py:388
       }
     }
@@ -285,7 +291,8 @@ hipError_t launch_gather(const FrameDev& f, const PreSim& ps, const float* ray_o
                          float* vol24, float* xy, float* mask_z, hipStream_t s) {
   const int P = RN * SN, NV = f.NV;
   const int npair = NV * (NV - 1) / 2;
-  size_t lds = sizeof(float) * ((size_t)NV * 128 + 64 * npair * 8 + 64 * NV * 25 + 64 * 40 + 2 * (size_t)NV * 64 * 8);
+  const size_t taps = 2 * (size_t)NV * 64 * 8, outv = 64 * 40;
+  size_t lds = sizeof(float) * ((size_t)64 * npair * 8 + 64 * (NV - 1) * 25 + (taps > outv ? taps : outv));
   hipLaunchKernelGGL(gather_kernel, dim3((P + 63) / 64), dim3(64 * NV), lds, s, f, ps, ray_o, o_stride, ray_d, z, P, SN,
                      x_tokens, rgb, dir, sim8, vol24, xy, mask_z);
   return hipGetLastError();

@@ -191,6 +191,22 @@ int ufr_render_rays(const ufr_render_args* a, ufr_stream stream);
 
 /* Per-kernel HIP-event timing of the most recent ufr_render_rays on this thread when
  * enabled (for bench.py's roofline line).  names/ms arrays of length `cap`; returns count. */
+/* ---- correlation-volume construction (first step) -------------------------------------
+ * Replaces, for one frame and one cascade stage, the loop body of DepthNet.forward step 2
+ * (code1/encoder_utils/fmt/TransMVSNet.py:66-97): homo_warping_trans (code1/encoder_utils/fmt/module.py:329-367)
+ * of every source view onto the D depth hypotheses of the reference view, similarity = mean over channels of
+ * warped x reference, and -- when pixel-wise view weights are given -- the weighted aggregate over the views.
+ * The (C,D,H,W) warped volume is never materialised.
+ *   ref_fea [C][H][W], src_fea [NS][C][H][W], depth_values [D][H][W], view_weights [NS][H][W] (nullable): device, fp32
+ *   rel_proj: HOST array [NS][12], rows of (src_proj_new @ inverse(ref_proj_new))[:3,:4] (module.py:340-342)
+ *   similarity [NS][D][H][W] (nullable), aggregated [D][H][W] (nullable; needs view_weights): device outputs
+ *   C in {4,8,16,32,64}; 1 <= NS <= UFR_MAX_VIEWS                                                              */
+size_t ufr_correlate_workspace_bytes(int32_t C, int32_t H, int32_t W, int32_t NS);
+int ufr_frustum_correlate(const float* ref_fea, const float* src_fea, const float* rel_proj, const float* depth_values,
+                          const float* view_weights, int32_t C, int32_t H, int32_t W, int32_t D, int32_t NS,
+                          float* similarity, float* aggregated, void* workspace, size_t workspace_bytes,
+                          ufr_stream stream);
+
 void ufr_profile_enable(int on);
 int ufr_profile_read(const char** names, float* ms, int32_t* launches, int cap);
 

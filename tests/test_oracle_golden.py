@@ -3,6 +3,8 @@
 Pins oracle/ufo_oracle.py against outputs of the reference itself (tests/golden/*.npz,
 made by tests/golden/make_golden.py from /root/reference).
 """
+import os
+
 import pytest
 import torch
 
@@ -63,3 +65,20 @@ def test_train_layout_forward_matches_reference_golden():
     assert rel_err(r["srdf"], g["srdf"][..., 0]) < 1e-5
     assert rel_err(r["srdf_2"], g["srdf_2"][..., 0]) < 1e-5
     assert rel_err(r["variance"], g["variance"]) < 1e-6
+
+
+# ------------------------------------------------------------------ correlation-volume step
+@pytest.mark.parametrize("name", ["stage1_small", "stage3_small", "nv5_stage2", "edge"])
+def test_frustum_oracle_matches_reference_golden(name):
+    import numpy as np
+    import torch
+    from oracle import frustum_oracle as FO
+    from uforecon_amd.scene import correlate_digest, make_correlate_case
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"correlate_{name}.npz"))
+    c = make_correlate_case(name)
+    assert abs(correlate_digest(c) - float(g["input_digest"])) <= 1e-6 * abs(float(g["input_digest"]))
+    sims, agg = FO.correlate(c["ref_fea"], c["src_feas"], c["ref_proj_pair"], c["src_proj_pairs"], c["depth_values"],
+                             c["view_weights"])
+    assert torch.equal(sims, torch.from_numpy(g["similarity"]))     # same torch ops in the same order: bit for bit
+    assert torch.equal(agg, torch.from_numpy(g["aggregated"]))

@@ -1,0 +1,57 @@
+"""Micro-benchmark of the correlation-volume step at the three cascade stages of a 512x640, 3-view frame
+(TransMVSNet.py:125: D = 48/32/8 at 1/4, 1/2, 1/1 resolution with 32/16/8 channels).  Prints one line per stage:
+launch time (HIP events via ufr_profile_*), algorithmic bytes and the fraction of the HBM roof, and -- with --cpu --
+the oracle (the reference's torch ops) on the host cores for the stage-1 shape."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from uforecon_amd import frustum, ops  # noqa: E402
+from uforecon_amd.scene import make_correlate_case  # noqa: E402
+
+DEV = "cuda:0"
+STAGES = [("stage1", 32, 128, 160, 48), ("stage2", 16, 256, 320, 32), ("stage3", 8, 512, 640, 8)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cpu", action="store_true")
+    ap.add_argument("--reps", type=int, default=20)
+    a = ap.parse_args()
+    for name, C, H, W, D in STAGES:
+        c = make_correlate_case("custom", C=C, H=H, W=W, D=D, NV=3, seed=7)
+        args = (c["ref_fea"].to(DEV), torch.stack(c["src_feas"]).to(DEV), c["ref_proj_pair"], c["src_proj_pairs"],
+                c["depth_values"].to(DEV), c["view_weights"].to(DEV))
+        frustum.correlate(*args)
+        torch.cuda.synchronize()
+        ops.profile_enable(True)
+        for _ in range(a.reps):
+            frustum.correlate(*args, want_similarity=False)
+        torch.cuda.synchronize()
+        p = ops.profile_read()["correlate"]
+        ops.profile_enable(False)
+        ms = p["ms"] / p["launches"]
+        NS = 2
+        # algorithmic HBM bytes: read every feature map once in its original layout and once channel-last, write the
+        # channel-last copy, read hypotheses + weights, write the aggregate.  The reference moves >= 2 x C*D*H*W*4 per view.
+        feat = (1 + NS) * C * H * W * 4
+        algo = 3 * feat + D * H * W * 4 * 2 + NS * H * W * 4
+        ref_bytes = NS * 2 * C * D * H * W * 4
+        print(f"{name}: C={C} {H}x{W} D={D}: {ms * 1e3:8.1f} us/launch  {algo / ms / 1e6:7.1f} GB/s algorithmic "
+              f"({algo / 1e6:.1f} MB; {algo / ms / 1e6 / 8000:.1%} of the 8 TB/s roof); samples/s "
+              f"{NS * D * H * W / ms / 1e6:.2f} G; warped volume the reference materialises: {ref_bytes / 1e6:.0f} MB")
+        if a.cpu and name == "stage1":
+            from oracle import frustum_oracle as FO
+            t = time.perf_counter()
+            FO.correlate(c["ref_fea"], c["src_feas"], c["ref_proj_pair"], c["src_proj_pairs"], c["depth_values"], c["view_weights"])
+            dt = time.perf_counter() - t
+            print(f"   cpu oracle ({torch.get_num_threads()} threads): {dt * 1e3:.1f} ms")
+
+
+if __name__ == "__main__":
+    main()

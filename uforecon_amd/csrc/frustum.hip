@@ -1,0 +1,114 @@
+// Correlation-volume construction, first step: similarity of every source view with the reference view over
+// the depth hypotheses of a cascade stage, and its pixel-wise weighted aggregation over the views.
+//   homo_warping_trans       code1/encoder_utils/fmt/module.py:329-367   (warp source features onto the hypotheses)
+//   DepthNet.forward step 2  code1/encoder_utils/fmt/TransMVSNet.py:66-97 (similarity = mean_c(warped * ref), weighting)
+//
+// The reference materialises the warped volume (C x D x H x W floats per view: 126 MB at stage 1 of a 512x640
+// frame) and reduces it over the channels afterwards.  Here one lane group walks the D hypotheses of one
+// reference pixel: the reference feature stays in registers, every hypothesis is four bilinear taps into the
+// channel-last source map, multiplied into the dot product on the spot -- only the (D,H,W) similarity is written.
+// A group is LP = C/4 adjacent lanes, one float4 of channels each, so a tap is one 16*LP-byte line segment per
+// load instruction (cache-line-wide for C = 32).
+// The arithmetic follows torch's CPU kernels operation by operation (k-ordered fma chain of the 3x3 matmul,
+// unfused scale / translate, exact divisions, grid_sample's align_corners=True un-normalisation and
+// accumulation order: ufr_device.h); only the channel reduction is re-associated (4 sequential + log2(LP) butterfly).
+#include "ufr_device.h"
+#include "ufr_internal.h"
+
+namespace ufr {
+
+struct CorrViews {
+  int NS;
+  float m[UFR_MAX_VIEWS][12];  // per source view: rows of (src_proj_new @ inverse(ref_proj_new))[:3,:4]
+};
+
+// (N,C,S) -> (N,S,C)
+__global__ void __launch_bounds__(256) chw_to_hwc_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int S) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+  if (s >= S) return;
+  const float* src = in + (size_t)n * C * S + s;
+  float* dst = out + ((size_t)n * S + s) * C;
+  for (int c = 0; c < C; c += 4) st4(dst + c, f32x4{src[(size_t)c * S], src[(size_t)(c + 1) * S], src[(size_t)(c + 2) * S], src[(size_t)(c + 3) * S]});
+}
+
+template <int LP>
+__global__ void __launch_bounds__(256) correlate_kernel(const float* __restrict__ ref_cl, const float* __restrict__ src_cl,
+                                                         CorrViews cv, const float* __restrict__ depth,
+                                                         const float* __restrict__ vw, float* __restrict__ sim,
+                                                         float* __restrict__ agg, int H, int W, int D) {
+  constexpr int C = 4 * LP;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int pix_raw = tid / LP, cl = tid % LP, HW = H * W;
+  const bool active = pix_raw < HW;
+  const int pix = active ? pix_raw : HW - 1;   // whole lane groups stay converged for the shuffles
+  const int py = pix / W, px = pix - py * W;
+  const f32x4 ref = ld4(ref_cl + (size_t)pix * C + 4 * cl);
+  const float x = (float)px, y = (float)py;
+  // pixel-wise weight sum (TransMVSNet.py:70, 90/94): starts from 1e-5, views in order
+  float wsum = 1e-5f;
+  if (vw)
+    for (int i = 0; i < cv.NS; ++i) wsum += vw[(size_t)i * HW + pix];
+  const float half_w = (float)(W - 1) / 2.f, half_h = (float)(H - 1) / 2.f;  // python float (W-1)/2 is exact in fp32 here
+  for (int d = 0; d < D; ++d) {
+    const float dep = depth[(size_t)d * HW + pix];
+    float ssum = 0.f;
+    for (int i = 0; i < cv.NS; ++i) {
+      const float* M = cv.m[i];
+      // rot @ [x, y, 1] as torch.matmul does it (k-ordered fma chain), then * depth, + trans, unfused (module.py:349-353)
+      const float rx = fmaf(M[2], 1.f, fmaf(M[1], y, mul_rn(M[0], x)));
+      const float ry = fmaf(M[6], 1.f, fmaf(M[5], y, mul_rn(M[4], x)));
+      const float rz = fmaf(M[10], 1.f, fmaf(M[9], y, mul_rn(M[8], x)));
+      const float qx = mul_add_unfused(rx, dep, M[3]), qy = mul_add_unfused(ry, dep, M[7]), qz = mul_add_unfused(rz, dep, M[11]);
+      const bool invalid = qz < 1e-6f;
+      float xn = (qx / qz) / half_w - 1.f, yn = (qy / qz) / half_h - 1.f;  // :355-358
+      if (invalid) { xn = -99.f; yn = -99.f; }
+      const Tap2 t = taps_zeros(unnorm2d_ac(xn, W), unnorm2d_ac(yn, H), W, H);
+      const float* base = src_cl + (size_t)i * HW * C + 4 * cl;
+      f32x4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = t.o[k] >= 0 ? ld4(base + (size_t)t.o[k] * C) : splat4(0.f);
+      float part = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = mul_rn(v[0][e], t.w[0]);
+        a = fmaf(v[1][e], t.w[1], a);
+        a = fmaf(v[2][e], t.w[2], a);
+        a = fmaf(v[3][e], t.w[3], a);           // warped feature, grid_sample's accumulation order
+        part += mul_rn(a, ref[e]);              // (warped * ref), then summed (TransMVSNet.py:78)
+      }
+#pragma unroll
+      for (int o = LP / 2; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+      const float s = part / (float)C;          // .mean(1)
+      if (sim && active && cl == 0) sim[((size_t)i * D + d) * HW + pix] = s;
+      if (vw) ssum += mul_rn(s, vw[(size_t)i * HW + pix]);
+    }
+    if (agg && active && cl == 0) agg[(size_t)d * HW + pix] = ssum / wsum;      // :97
+  }
+}
+
+hipError_t launch_chw_to_hwc(const float* in, float* out, int N, int C, int S, hipStream_t s) {
+  hipLaunchKernelGGL(chw_to_hwc_kernel, dim3((S + 255) / 256, N), dim3(256), 0, s, in, out, C, S);
+  return hipGetLastError();
+}
+
+hipError_t launch_correlate(const float* ref_cl, const float* src_cl, const float* proj_host, int NS, const float* depth,
+                            const float* vw, float* sim, float* agg, int C, int H, int W, int D, hipStream_t s) {
+  CorrViews cv;
+  cv.NS = NS;
+  for (int i = 0; i < NS; ++i)
+    for (int k = 0; k < 12; ++k) cv.m[i][k] = proj_host[i * 12 + k];
+  const int LP = C / 4;
+  const size_t threads = (size_t)H * W * LP;
+  const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+  switch (LP) {
+    case 1: hipLaunchKernelGGL(correlate_kernel<1>, grid, block, 0, s, ref_cl, src_cl, cv, depth, vw, sim, agg, H, W, D); break;
+    case 2: hipLaunchKernelGGL(correlate_kernel<2>, grid, block, 0, s, ref_cl, src_cl, cv, depth, vw, sim, agg, H, W, D); break;
+    case 4: hipLaunchKernelGGL(correlate_kernel<4>, grid, block, 0, s, ref_cl, src_cl, cv, depth, vw, sim, agg, H, W, D); break;
+    case 8: hipLaunchKernelGGL(correlate_kernel<8>, grid, block, 0, s, ref_cl, src_cl, cv, depth, vw, sim, agg, H, W, D); break;
+    case 16: hipLaunchKernelGGL(correlate_kernel<16>, grid, block, 0, s, ref_cl, src_cl, cv, depth, vw, sim, agg, H, W, D); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace ufr

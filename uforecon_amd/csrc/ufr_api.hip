@@ -446,17 +446,25 @@ int ufr_render_rays(const ufr_render_args* a, ufr_stream stream) {
   const size_t need = ufr_render_workspace_bytes(chunk, SN, PN, NV);
   if (a->workspace_bytes < need) return fail(UFR_ERR_WORKSPACE, "render workspace too small: %zu < %zu", a->workspace_bytes, need);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int n_chunks = (RN + chunk - 1) / chunk;
   int lanes = a->n_streams > 1 ? a->n_streams : 1;
   if (lanes > kMaxLanes) lanes = kMaxLanes;
   if ((size_t)lanes * need > a->workspace_bytes) lanes = (int)(a->workspace_bytes / need);  // one workspace per lane
+  // a small ray set (one rank's tile of a frame split over 8 GPUs) is cut finer so that every side stream still
+  // gets >= 4 chunks: the last round of a round-robin over few chunks otherwise leaves streams idle
+  int eff_chunk = chunk;
+  if (lanes > 1) {
+    int target = ((RN + 4 * lanes - 1) / (4 * lanes) + 255) / 256 * 256;
+    if (target < 1024) target = 1024;
+    if (target < eff_chunk) eff_chunk = target;
+  }
+  const int n_chunks = (RN + eff_chunk - 1) / eff_chunk;
   if (lanes > n_chunks) lanes = n_chunks;
 
   if (lanes <= 1) {
     RenderWs w = carve_render(a->workspace, chunk, SN, PN, NV);
     bool pe_ready = false;
-    for (int r0 = 0; r0 < RN; r0 += chunk) {
-      int rc = render_chunk(a, f, w, pe_ready, r0, (RN - r0) < chunk ? (RN - r0) : chunk, s);
+    for (int r0 = 0; r0 < RN; r0 += eff_chunk) {
+      int rc = render_chunk(a, f, w, pe_ready, r0, (RN - r0) < eff_chunk ? (RN - r0) : eff_chunk, s);
       if (rc != UFR_OK) return rc;
     }
     return UFR_OK;
@@ -471,14 +479,45 @@ int ufr_render_rays(const ufr_render_args* a, ufr_stream stream) {
     UFR_HIP(hipStreamWaitEvent(g_side.s[l], g_side.fork, 0));
   }
   for (int c = 0; c < n_chunks; ++c) {
-    const int l = c % lanes, r0 = c * chunk;
-    rc = render_chunk(a, f, w[l], pe_ready[l], r0, (RN - r0) < chunk ? (RN - r0) : chunk, g_side.s[l]);
+    const int l = c % lanes, r0 = c * eff_chunk;
+    rc = render_chunk(a, f, w[l], pe_ready[l], r0, (RN - r0) < eff_chunk ? (RN - r0) : eff_chunk, g_side.s[l]);
     if (rc != UFR_OK) return rc;
   }
   for (int l = 0; l < lanes; ++l) {
     UFR_HIP(hipEventRecord(g_side.join[l], g_side.s[l]));
     UFR_HIP(hipStreamWaitEvent(s, g_side.join[l], 0));
   }
+  return UFR_OK;
+}
+
+// ------------------------------------------------------------------ correlation-volume construction
+size_t ufr_correlate_workspace_bytes(int32_t C, int32_t H, int32_t W, int32_t NS) {
+  Carver c(nullptr);
+  c.f32((size_t)H * W * C);
+  c.f32((size_t)NS * H * W * C);
+  return c.off;
+}
+
+int ufr_frustum_correlate(const float* ref_fea, const float* src_fea, const float* rel_proj, const float* depth_values,
+                          const float* view_weights, int32_t C, int32_t H, int32_t W, int32_t D, int32_t NS,
+                          float* similarity, float* aggregated, void* workspace, size_t workspace_bytes,
+                          ufr_stream stream) {
+  UFR_REQUIRE(ref_fea && src_fea && rel_proj && depth_values && workspace, "ufr_frustum_correlate: null argument");
+  UFR_REQUIRE(similarity || aggregated, "ufr_frustum_correlate: no output requested");
+  UFR_REQUIRE(!aggregated || view_weights, "ufr_frustum_correlate: aggregated output needs view_weights");
+  UFR_REQUIRE(C == 4 || C == 8 || C == 16 || C == 32 || C == 64, "ufr_frustum_correlate: C=%d unsupported (4,8,16,32,64)", C);
+  UFR_REQUIRE(NS >= 1 && NS <= UFR_MAX_VIEWS, "ufr_frustum_correlate: NS=%d unsupported (1..%d)", NS, UFR_MAX_VIEWS);
+  UFR_REQUIRE(H >= 2 && W >= 2 && D >= 1, "ufr_frustum_correlate: H=%d W=%d D=%d", H, W, D);
+  const size_t need = ufr_correlate_workspace_bytes(C, H, W, NS);
+  if (workspace_bytes < need) return fail(UFR_ERR_WORKSPACE, "correlate workspace too small: %zu < %zu", workspace_bytes, need);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Carver c(workspace);
+  float* ref_cl = c.f32((size_t)H * W * C);
+  float* src_cl = c.f32((size_t)NS * H * W * C);
+  ProfScope p("correlate", s);
+  UFR_HIP(launch_chw_to_hwc(ref_fea, ref_cl, 1, C, H * W, s));
+  UFR_HIP(launch_chw_to_hwc(src_fea, src_cl, NS, C, H * W, s));
+  UFR_HIP(launch_correlate(ref_cl, src_cl, rel_proj, NS, depth_values, view_weights, similarity, aggregated, C, H, W, D, s));
   return UFR_OK;
 }
 

@@ -187,3 +187,49 @@ def sampler_uniforms(seed: int, point_num: int, point_num_2: int, RN: int):
     u2 = torch.rand(point_num_2, RN)
     torch.random.set_rng_state(st)
     return u1, u2
+
+
+# ------------------------------------------------------------------ correlation-volume step
+# name -> feature channels, feature-map size, depth hypotheses, views (reference + sources), seed.
+# The stage shapes follow the reference's cascade (TransMVSNet.py:125: ndepths 48/32/8 at 1/4, 1/2, 1/1 resolution with
+# 32/16/8 feature channels); "edge" puts the hypotheses so close to the cameras that many samples leave the source
+# images or fall behind them (the -99 path of module.py:355-360).
+CORRELATE_CASES = {
+    "stage1_small": dict(C=32, H=32, W=40, D=48, NV=3, seed=11),
+    "stage3_small": dict(C=8, H=64, W=80, D=8, NV=3, seed=12),
+    "nv5_stage2": dict(C=16, H=24, W=36, D=32, NV=5, seed=13),
+    "edge": dict(C=8, H=20, W=28, D=16, NV=3, seed=14, edge=True),
+}
+
+
+def make_correlate_case(name: str, **over):
+    """Seeded inputs of DepthNet.forward step 2 for one frame: features (C,H,W) of the reference and NS source views,
+    projection pairs (2,4,4) = [extrinsic, intrinsic] as in batch['proj_matrices'] stage entries, per-pixel depth
+    hypotheses (D,H,W) and pixel-wise view weights (NS,H,W)."""
+    c = dict(CORRELATE_CASES[name]) if name in CORRELATE_CASES else {}
+    c.update(over)
+    C, H, W, D, NV = c["C"], c["H"], c["W"], c["D"], c["NV"]
+    g = torch.Generator().manual_seed(c["seed"])
+    cams = make_cameras(H, W, NV)
+    pairs = []
+    for v in range(NV):
+        pp = torch.zeros(2, 4, 4)
+        pp[0] = cams["w2cs"][0, v]
+        pp[1, :3, :3] = cams["intrinsics"][0, v]
+        pp[1, 3, 3] = 1.0
+        pairs.append(pp)
+    near, far = float(cams["near_fars"][0, 0, 0]), float(cams["near_fars"][0, 0, 1])
+    if c.get("edge"):
+        near, far = -0.4, 2.4   # from behind the reference camera to just short of the working volume
+    lin = torch.linspace(0.0, 1.0, D).reshape(D, 1, 1)
+    jitter = (torch.rand(D, H, W, generator=g) - 0.5) * (0.5 / D)
+    depth_values = (near + (far - near) * (lin + jitter)).contiguous()
+    feats = [_unit_uniform((C, H, W), g) for _ in range(NV)]
+    vw = torch.rand(NV - 1, H, W, generator=g)
+    return dict(name=name, ref_fea=feats[0], src_feas=feats[1:], ref_proj_pair=pairs[0], src_proj_pairs=pairs[1:],
+                depth_values=depth_values, view_weights=vw, C=C, H=H, W=W, D=D, NS=NV - 1)
+
+
+def correlate_digest(c) -> float:
+    ts = [c["ref_fea"], *c["src_feas"], c["ref_proj_pair"], *c["src_proj_pairs"], c["depth_values"], c["view_weights"]]
+    return sum((i + 1) * float(t.double().abs().sum()) for i, t in enumerate(ts))

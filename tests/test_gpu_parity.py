@@ -152,6 +152,30 @@ def test_render_rays_chunking_is_invisible(weights):
     assert torch.equal(a["depth"], b["depth"]) and torch.equal(a["rgb"], b["rgb"])
 
 
+def test_side_streams_are_invisible(weights):
+    """Chunks issued round-robin on library-owned side streams run beside each other (a gather next to another
+    chunk's transformers on the same CU); the result must not depend on that.  Regression: the view transformer
+    once read its view-token fragment from LDS before the workgroup had finished filling it -- visible only when
+    co-resident gather workgroups staggered the start of its waves."""
+    fr, idx, U1, U2, g = case_inputs("c2_hier_small")
+    f = fr.to(DEV)
+    fh = _frame_handle(fr)
+    H, W = f.batch["source_imgs"].shape[-2:]
+    HW = H * W
+    gen = torch.Generator().manual_seed(9)
+    U1f, U2f = torch.rand(64, HW, generator=gen).to(DEV), torch.rand(64, HW, generator=gen).to(DEV)
+    ridx = torch.arange(HW, device=DEV)
+    base = ops.render_rays(fh, weights, ridx, U1f, U2f, workspace=ops.RenderWorkspace(DEV, 64, 64, 3, chunk_rays=8192, n_streams=1))
+    base = {k: v.clone() for k, v in base.items() if torch.is_tensor(v)}
+    for chunk, streams in ((1024, 3), (512, 4), (1024, 2)):
+        for _ in range(3):
+            ws = ops.RenderWorkspace(DEV, 64, 64, 3, chunk_rays=chunk, n_streams=streams)
+            out = ops.render_rays(fh, weights, ridx, U1f, U2f, workspace=ws)
+            torch.cuda.synchronize()
+            for k in ("depth", "rgb", "srdf", "z_all"):
+                assert torch.equal(out[k], base[k]), (chunk, streams, k)
+
+
 def test_fine_pass_pool_equals_full_reevaluation(weights):
     """ufr_render_rays keeps the coarse samples' per-point results and evaluates only the new points in the
     fine pass; the reference (model.py:466-472) re-evaluates all merged samples.  Walking the reference's order

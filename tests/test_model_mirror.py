@@ -87,3 +87,58 @@ def test_infer_training_signature_forward_matches_golden():
     assert rel_err(got["z_val_all"], g["z_val_all"]) < 1e-5
     with pytest.raises(ops.UfrError, match="backward"):
         m.infer(f.batch, idx.to(dev), f.source_imgs_feat, f.feature_volume, match_feature=f.match_feature, uniforms=(U1, U2))
+
+
+def test_save_depth_outputs_wire_format(tmp_path):
+    """The files tsdf fusion consumes (model.py:828-842): pickled dict .npy + 8-bit previews, truncating casts."""
+    import numpy as np
+    from PIL import Image
+
+    rng = np.random.default_rng(0)
+    depths = (rng.random((12, 16)) * 900 + 100).astype(np.float32)
+    rgbs = rng.random((12, 16, 3)).astype(np.float32)
+    E, K = np.eye(4, dtype=np.float32), np.eye(3, dtype=np.float32) * 2
+    M.save_depth_outputs(str(tmp_path), "scan24", "00000000", depths, rgbs, E, K)
+    d = np.load(tmp_path / "depth" / "scan24" / "00000000.npy", allow_pickle=True).item()
+    assert set(d) == {"depth", "extrinsic", "intrinsic"}
+    assert d["depth"].dtype == np.float32 and np.array_equal(d["depth"], depths)
+    assert np.array_equal(d["extrinsic"], E) and np.array_equal(d["intrinsic"], K)
+    png = np.asarray(Image.open(tmp_path / "scan24" / "depth" / "00000000.png"))
+    assert png.dtype == np.uint8 and np.array_equal(png, ((depths / depths.max()).astype(np.float32) * 255).astype(np.uint8))
+    jpg = Image.open(tmp_path / "rgb" / "scan24" / "00000000.jpg")
+    assert jpg.size == (16, 12) and jpg.mode == "RGB"
+
+
+@pytest.mark.gpu
+def test_extract_geometry_frame_matches_per_chunk_infer(tmp_path):
+    """One frame-level call == the reference's loop over ray chunks (model.py:815-823) + depth post-processing."""
+    import numpy as np
+
+    fr, idx, U1, U2, g = case_inputs("c2_hier_small")
+    dev = "cuda:0"
+    m = M.UFORecon(_args()).to(dev)
+    m.load_state_dict(load_weights(), strict=True)
+    f = fr.to(dev)
+    H, W = f.batch["source_imgs"].shape[-2:]
+    HW = H * W
+    gen = torch.Generator().manual_seed(5)
+    U1f, U2f = torch.rand(64, HW, generator=gen), torch.rand(64, HW, generator=gen)
+    f.batch["scale_mat"] = torch.eye(4)[None] * 2.5
+    f.batch["meta"] = ["dtu-scan24-3-00000000"]
+    f.batch["extrinsic_render_view"] = torch.eye(4)[None]
+    f.batch["intrinsic_render_view"] = torch.eye(3)[None]
+    with torch.no_grad():
+        depths, rgbs = m.extract_geometry(f.batch, f.source_imgs_feat, f.feature_volume, f.match_feature,
+                                          out_dir=str(tmp_path), uniforms=(U1f, U2f))
+        # the reference's loop: chunks of 800 rays, depth * cam_ray_d.z, concatenated, * scale_mat[0][0,0]
+        parts = []
+        for r0 in range(0, HW, 800):
+            ridx = torch.arange(r0, min(r0 + 800, HW))[None].to(dev)
+            _, _, depth, _ = m.infer(f.batch, ridx, f.source_imgs_feat, f.feature_volume, extract_geometry=True,
+                                     match_feature=f.match_feature, is_train=False,
+                                     uniforms=(U1f[:, r0:r0 + 800], U2f[:, r0:r0 + 800]))
+            parts.append(depth[0] * f.batch["cam_ray_d"][0][2, ridx[0]])
+    want = (torch.cat(parts).view(H, W) * 2.5).cpu().numpy()
+    assert np.array_equal(depths, want)                      # rays are independent: chunking is invisible
+    d = np.load(tmp_path / "depth" / "scan24" / "00000000.npy", allow_pickle=True).item()
+    assert np.array_equal(d["depth"], depths) and rgbs.shape == (H, W, 3)

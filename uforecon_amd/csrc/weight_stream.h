@@ -60,6 +60,7 @@ __device__ __forceinline__ WStream wstream_begin(const float* __restrict__ packe
   constexpr int voff = vec_region_offset(), n4 = vec_region_floats() / 4;
   const f32x4* vs = reinterpret_cast<const f32x4*>(packed + voff);
   for (int i = threadIdx.x; i < n4; i += NWAVES * 64) v[i] = vs[i];
+  __syncthreads();  // vector fragments may be read before the first chunk barrier
   return ws;
 }
 

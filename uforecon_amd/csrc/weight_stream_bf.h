@@ -70,6 +70,10 @@ __device__ __forceinline__ WStreamBf wstream_bf_begin(const float* __restrict__ 
   constexpr int voff = vec_region_offset(), n4 = vec_region_floats() / 4;
   const f32x4* vs = reinterpret_cast<const f32x4*>(packed + voff);
   for (int i = threadIdx.x; i < n4; i += NWAVES * 64) v[i] = vs[i];
+  // the view transformer reads the view-token fragment before its first chunk barrier: without this barrier a
+  // wave that starts early reads LDS another wave has not filled yet (seen only when gather workgroups share
+  // the CU and stagger the waves' start: 8 wrong points per late workgroup)
+  __syncthreads();
   return ws;
 }
 

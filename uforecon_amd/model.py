@@ -291,3 +291,70 @@ class UFORecon(nn.Module):
         return (rgb_gt, rgb[None], depth[None], depth_gt, srdf.reshape(RN, -1, 1), opacity[None], weight[None], None,
                 rgb2[None], depth2[None], srdf2.reshape(RN, S2, 1), opacity2[None], weight2[None], None,
                 z1[None], z2[None], variance)                                                # model.py:480-482
+
+    # ---- frame-level entry: the per-ray loop and post-processing of extract_geometry (model.py:810-842)
+    def render_depth_map(self, batch, source_imgs_feat, feature_volume, match_feature, uniforms=None):
+        """Every pixel of the render view in ONE call (the reference loops over chunks of ``test_ray_num`` = 800
+        rays, model.py:815; here chunking is internal to ufr_render_rays and invisible).  Returns
+        ``depths (H,W) float32`` = ray depth * cam_ray_d.z * scale_mat[0][0,0] (model.py:818-826) and
+        ``rgbs (H,W,3) float32`` in [0,1], both on the device."""
+        _no_grad_only(*self.parameters())
+        B, L, _, imgH, imgW = batch["source_imgs"].shape
+        if B != 1:
+            raise UfrError("B=1 only (one frame per call)")
+        dev = source_imgs_feat.device
+        HW = imgH * imgW
+        coarse_only = bool(getattr(self.args, "test_coarse_only", False))
+        if uniforms is None:   # one draw per frame instead of one per 800-ray chunk: same distribution
+            U1 = torch.rand(self.point_num, HW)
+            U2 = None if coarse_only else torch.rand(self.point_num_2, HW)
+        else:
+            U1, U2 = uniforms
+        U1 = U1.to(dev, torch.float32).contiguous()
+        U2 = None if U2 is None else U2.to(dev, torch.float32).contiguous()
+        fh = self.frame_handle(batch, source_imgs_feat, feature_volume, match_feature)
+        PN = 0 if coarse_only else self.point_num_2
+        if self._ws is None or self._ws.key[:3] != (self.point_num, PN, fh.NV):
+            self._ws = ops.RenderWorkspace(dev, self.point_num, PN, fh.NV)
+        ray_idx = torch.arange(HW, device=dev)
+        out = ops.render_rays(fh, self._weights(), ray_idx, U1, U2, coarse_only=coarse_only, workspace=self._ws,
+                              want_srdf=False)
+        depths = out["depth_z"].view(imgH, imgW) * batch["scale_mat"][0][0, 0].to(dev)       # model.py:821, 826
+        return depths, out["rgb"].view(imgH, imgW, 3)
+
+    def extract_geometry(self, batch, source_imgs_feat, feature_volume, match_feature, out_dir=None, uniforms=None):
+        """The per-ray part of model.py:760-842 plus its outputs: renders the frame and, when ``out_dir`` is given,
+        writes the files ``save_depth_outputs`` describes.  (The encoder half of the reference's method -- building
+        ``source_imgs_feat`` / ``feature_volume`` / ``match_feature`` -- stays with the caller.)"""
+        depths, rgbs = self.render_depth_map(batch, source_imgs_feat, feature_volume, match_feature, uniforms)
+        depths, rgbs = depths.cpu().numpy(), rgbs.cpu().numpy()
+        if out_dir is not None:
+            meta = batch["meta"][0]
+            save_depth_outputs(out_dir, meta.split("-")[1], meta.split("-")[-1], depths, rgbs,
+                               batch["extrinsic_render_view"][0].cpu().numpy(),
+                               batch["intrinsic_render_view"][0].cpu().numpy())
+        return depths, rgbs
+
+
+def save_depth_outputs(out_dir, scan_name, ref_view, depths, rgbs, extrinsic, intrinsic):
+    """The reference's wire format (model.py:828-842), byte for byte:
+      <out_dir>/<scan>/depth/<view>.png   8-bit preview, depth / max(depth) * 255 (truncating cast)
+      <out_dir>/rgb/<scan>/<view>.jpg     8-bit RGB, rgb * 255 (truncating cast)
+      <out_dir>/depth/<scan>/<view>.npy   pickled dict {"depth": (H,W) f32, "extrinsic": 4x4, "intrinsic": 3x3}
+    (`np.save` of a dict: readers need ``np.load(..., allow_pickle=True).item()``, as tsdf_fusion.py does)."""
+    import os
+
+    import numpy as np
+    from PIL import Image
+
+    os.makedirs(os.path.join(out_dir, scan_name, "depth"), exist_ok=True)
+    os.makedirs(os.path.join(out_dir, "depth", scan_name), exist_ok=True)
+    os.makedirs(os.path.join(out_dir, "rgb", scan_name), exist_ok=True)
+    depths = np.asarray(depths, np.float32)
+    rgb8 = (np.asarray(rgbs).astype(np.float32) * 255).astype(np.uint8)
+    depth8 = ((depths / np.max(depths)).astype(np.float32) * 255).astype(np.uint8)
+    Image.fromarray(depth8).save(os.path.join(out_dir, scan_name, "depth", "%s.png" % ref_view))
+    Image.fromarray(rgb8).save(os.path.join(out_dir, "rgb", scan_name, "%s.jpg" % ref_view))
+    np.save(os.path.join(out_dir, "depth", scan_name, "%s.npy" % ref_view),
+            {"depth": depths, "extrinsic": np.asarray(extrinsic), "intrinsic": np.asarray(intrinsic)})
+

@@ -207,6 +207,17 @@ int ufr_frustum_correlate(const float* ref_fea, const float* src_fea, const floa
                           float* similarity, float* aggregated, void* workspace, size_t workspace_bytes,
                           ufr_stream stream);
 
+/* ---- TSDF fusion -------------------------------------------------------------------
+ * Replaces the reference's `integrate` kernel (tsdf_fusion.py:77-152, a CUDA string compiled through pycuda) and the
+ * launch loop of TSDFVolume.integrate (:240-265): one depth (+ colour) observation into the (X,Y,Z) fp32 volumes,
+ * z fastest.  tsdf / weight / color, depth_im [H][W], color_im [H][W] (folded b*65536+g*256+r, nullable): device;
+ * dim, origin, cam_intr (3x3 row-major), cam_pose (4x4 row-major camera-to-world): host.
+ * integrate_color = 0 reproduces the reference (its colour block is unreachable).                             */
+int ufr_tsdf_integrate(float* tsdf, float* weight, float* color, const int32_t* dim, const float* origin,
+                       float voxel_size, float trunc_margin, const float* cam_intr, const float* cam_pose,
+                       const float* depth_im, const float* color_im, int32_t im_h, int32_t im_w, float obs_weight,
+                       int32_t integrate_color, ufr_stream stream);
+
 void ufr_profile_enable(int on);
 int ufr_profile_read(const char** names, float* ms, int32_t* launches, int cap);
 

@@ -521,6 +521,23 @@ int ufr_frustum_correlate(const float* ref_fea, const float* src_fea, const floa
   return UFR_OK;
 }
 
+// ------------------------------------------------------------------ TSDF fusion
+int ufr_tsdf_integrate(float* tsdf, float* weight, float* color, const int32_t* dim, const float* origin,
+                       float voxel_size, float trunc_margin, const float* cam_intr, const float* cam_pose,
+                       const float* depth_im, const float* color_im, int32_t im_h, int32_t im_w, float obs_weight,
+                       int32_t integrate_color, ufr_stream stream) {
+  UFR_REQUIRE(tsdf && weight && dim && origin && cam_intr && cam_pose && depth_im, "ufr_tsdf_integrate: null argument");
+  UFR_REQUIRE(dim[0] > 0 && dim[1] > 0 && dim[2] > 0, "ufr_tsdf_integrate: volume %dx%dx%d", dim[0], dim[1], dim[2]);
+  UFR_REQUIRE(im_h > 0 && im_w > 0, "ufr_tsdf_integrate: image %dx%d", im_h, im_w);
+  UFR_REQUIRE(voxel_size > 0.f && trunc_margin > 0.f, "ufr_tsdf_integrate: voxel_size %g, trunc_margin %g", voxel_size, trunc_margin);
+  UFR_REQUIRE(!integrate_color || (color && color_im), "ufr_tsdf_integrate: colour integration needs color and color_im");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ProfScope p("tsdf_integrate", s);
+  UFR_HIP(launch_tsdf_integrate(tsdf, weight, color, dim, origin, voxel_size, trunc_margin, cam_intr, cam_pose, depth_im,
+                                color_im, im_h, im_w, obs_weight, integrate_color, s));
+  return UFR_OK;
+}
+
 // ------------------------------------------------------------------ profiling hooks
 void ufr_profile_enable(int on) {
   for (auto& e : g_prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }

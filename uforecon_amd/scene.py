@@ -233,3 +233,45 @@ def make_correlate_case(name: str, **over):
 def correlate_digest(c) -> float:
     ts = [c["ref_fea"], *c["src_feas"], c["ref_proj_pair"], *c["src_proj_pairs"], c["depth_values"], c["view_weights"]]
     return sum((i + 1) * float(t.double().abs().sum()) for i, t in enumerate(ts))
+
+
+# ------------------------------------------------------------------ TSDF fusion
+TSDF_CASES = {
+    "sphere3": dict(H=48, W=64, NV=3, voxel_size=0.08, margin=3, radius=0.8, seed=31),
+    "sphere5_holes": dict(H=40, W=56, NV=5, voxel_size=0.1, margin=5, radius=0.7, seed=32, holes=True),
+}
+
+
+def make_tsdf_case(name: str):
+    """Depth maps (z-depth, float32, 0 = no measurement) of a sphere at the origin seen from the arc cameras of
+    `make_cameras`, 8-bit-valued colour images as float32 in [0,1] (what tsdf_fusion.read_img yields), intrinsics and
+    camera-to-world poses -- the inputs of the reference's save_tsdf loop (tsdf_fusion.py:459-499)."""
+    c = dict(TSDF_CASES[name])
+    H, W, NV, R = c["H"], c["W"], c["NV"], c["radius"]
+    g = torch.Generator().manual_seed(c["seed"])
+    cams = make_cameras(H, W, NV)
+    depths, colors, intrs, poses = [], [], [], []
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    for v in range(NV):
+        K = cams["intrinsics"][0, v].double().numpy()
+        w2c = cams["w2cs"][0, v].double().numpy()
+        c2w = np.linalg.inv(w2c)
+        d_cam = np.stack([(xs - K[0, 2]) / K[0, 0], (ys - K[1, 2]) / K[1, 1], np.ones_like(xs)], -1)   # z = 1 rays
+        d_w = d_cam @ c2w[:3, :3].T
+        o = c2w[:3, 3]
+        a = (d_w * d_w).sum(-1)
+        b = 2.0 * (d_w @ o)
+        cc = float(o @ o) - R * R
+        disc = b * b - 4 * a * cc
+        t = np.where(disc > 0, (-b - np.sqrt(np.maximum(disc, 0))) / (2 * a), 0.0)   # z-depth of the first hit
+        depth = np.where(disc > 0, t, 0.0).astype(np.float32)
+        if c.get("holes"):
+            mask = torch.rand(H, W, generator=g).numpy() < 0.15
+            depth[mask] = 0.0
+        col = torch.randint(0, 256, (H, W, 3), generator=g).float().numpy() / 255.0
+        depths.append(depth)
+        colors.append(col.astype(np.float32))
+        intrs.append(K.astype(np.float32))
+        poses.append(c2w.astype(np.float32))
+    return dict(name=name, depths=depths, colors=colors, intrinsics=intrs, poses=poses, voxel_size=c["voxel_size"],
+                margin=c["margin"])

@@ -275,3 +275,71 @@ def make_tsdf_case(name: str):
         poses.append(c2w.astype(np.float32))
     return dict(name=name, depths=depths, colors=colors, intrinsics=intrs, poses=poses, voxel_size=c["voxel_size"],
                 margin=c["margin"])
+
+
+# ------------------------------------------------------------------ cascade of correlation frustums
+def fill_state_dict(module, seed: int):
+    """Deterministic, construction-order-independent parameters: every state_dict entry (sorted by key) is filled from
+    one seeded generator -- the reference-side golden script and the tests give a mirror and the reference's own
+    modules bit-identical weights without a multi-megabyte fixture.  Scales keep activations O(1)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = module.state_dict()
+    for k in sorted(sd):
+        t = sd[k]
+        if k.endswith("num_batches_tracked"):
+            t.fill_(1)
+        elif k.endswith("running_var"):
+            t.copy_(1.0 + 0.3 * (torch.rand(t.shape, generator=g) - 0.5))
+        elif k.endswith("running_mean") or k.endswith("bn.bias"):
+            t.copy_(0.2 * (torch.rand(t.shape, generator=g) - 0.5))
+        elif k.endswith("bn.weight"):
+            t.copy_(1.0 + 0.4 * (torch.rand(t.shape, generator=g) - 0.5))
+        elif t.dim() >= 2:
+            fan_in = t[0].numel() if "conv7" not in k and "conv9" not in k and "conv11" not in k else t.shape[0] * t[0, 0].numel()
+            t.copy_(_unit_uniform(tuple(t.shape), g) * (1.0 / math.sqrt(max(fan_in, 1))))
+        else:
+            t.copy_(0.1 * (torch.rand(t.shape, generator=g) - 0.5))
+    module.load_state_dict(sd)
+    return module
+
+
+CASCADE_CASES = {"small3": dict(H=32, W=64, NV=3, seed=41, weight_seed=7)}
+
+
+def make_cascade_case(name: str):
+    """Inputs of the cascade for one frame as UFORecon.build_pairs prepares them (model.py:139-160): B = NV rotations of
+    the view list (every source view is the reference once), per-view / per-stage feature maps (32/16/8 channels at
+    1/4, 1/2, 1/1 resolution), projection pairs per stage (intrinsics scaled with the stage), initial hypotheses."""
+    c = dict(CASCADE_CASES[name])
+    H, W, NV = c["H"], c["W"], c["NV"]
+    g = torch.Generator().manual_seed(c["seed"])
+    cams = make_cameras(H, W, NV)
+    rot = [list(range(i, NV)) + list(range(0, i)) for i in range(NV)]          # build_pairs: all_combinations
+    chans, scales = {"stage1": 32, "stage2": 16, "stage3": 8}, {"stage1": 4, "stage2": 2, "stage3": 1}
+    base = {st: [_unit_uniform((chans[st], H // s, W // s), g) for _ in range(NV)] for st, s in scales.items()}
+    # smooth the features a little (3x3 box) so that neighbouring hypotheses correlate like real feature maps do
+    for st in base:
+        base[st] = [F_avg(t) for t in base[st]]
+    features = [{st: torch.stack([base[st][rot[b][v]] for b in range(NV)]) for st in scales} for v in range(NV)]
+    proj = {}
+    for st, s in scales.items():
+        pm = torch.zeros(NV, NV, 2, 4, 4)
+        for b in range(NV):
+            for v in range(NV):
+                src = rot[b][v]
+                pm[b, v, 0] = cams["w2cs"][0, src]
+                K = cams["intrinsics"][0, src].clone()
+                K[:2] = K[:2] / s
+                pm[b, v, 1, :3, :3] = K
+                pm[b, v, 1, 3, 3] = 1.0
+        proj[st] = pm
+    near, far = float(cams["near_fars"][0, 0, 0]), float(cams["near_fars"][0, 0, 1])
+    depth_values = torch.linspace(near, far, 48).reshape(1, -1).expand(NV, -1).contiguous()
+    return dict(name=name, features=features, proj_matrices=proj, depth_values=depth_values, img_hw=(H, W), NV=NV,
+                weight_seed=c["weight_seed"])
+
+
+def F_avg(t):
+    import torch.nn.functional as F
+
+    return F.avg_pool2d(t[None], 3, stride=1, padding=1, count_include_pad=False)[0].contiguous()

@@ -4,7 +4,7 @@ V=$1; OUT=$2; shift 2
 export TMPDIR=/tmp
 mkdir -p $OUT
 if [ "$V" != "default" ]; then export UFR_LIB=$PWD/uforecon_amd/lib/libufr_$V.so; fi
-rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $OUT -o p -- python3 tools/bench_kernels.py > /dev/null 2> $OUT/err.txt
+timeout 420 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d $OUT -o p -- python3 tools/bench_kernels.py > /dev/null 2> $OUT/err.txt
 python3 - "$OUT" <<PY
 import csv, collections, sys
 acc=collections.defaultdict(lambda: collections.defaultdict(list)); dur=collections.defaultdict(list); seen=set()

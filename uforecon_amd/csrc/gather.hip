@@ -69,6 +69,32 @@ __device__ __forceinline__ void sample_volume(const float* __restrict__ vol, int
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+// weight addresses are wave-uniform -> scalar loads; k-ordered fma chains starting from the bias
+__device__ __forceinline__ void presim_mlp(const PreSim& ps, const float (&sim)[8], float (&out)[16]) {
+  float h1[32], h2[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    float acc = ps.b0[j];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc = fmaf(ps.w0[j * 8 + k], sim[k], acc);
+    h1[j] = fmaxf(acc, 0.f);
+  }
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    float acc = ps.b2[j];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc = fmaf(ps.w2[j * 32 + k], h1[k], acc);
+    h2[j] = fmaxf(acc, 0.f);
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    float acc = ps.b4[j];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc = fmaf(ps.w4[j * 32 + k], h2[k], acc);
+    out[j] = acc;
+  }
+}
+
 __device__ __forceinline__ void put_tap(float* dst, const Tap2& t) {
   *reinterpret_cast<i32x4*>(dst) = i32x4{t.o[0], t.o[1], t.o[2], t.o[3]};
   *reinterpret_cast<f32x4*>(dst + 4) = f32x4{t.w[0], t.w[1], t.w[2], t.w[3]};
@@ -92,7 +118,7 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
                                                       float* __restrict__ x_tokens, float* __restrict__ rgb_out,
                                                       float* __restrict__ dir_out, float* __restrict__ sim8_out,
                                                       float* __restrict__ vol24_out, float* __restrict__ xy_out,
-                                                      float* __restrict__ maskz_out) {
+                                                      float* __restrict__ maskz_out, float* __restrict__ sim_split) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int NV = f.NV;
   const int npair = NV * (NV - 1) / 2;
@@ -176,7 +202,11 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
     for (int s = 0; s < UFR_NUM_STAGES; ++s) {
       float fs[8], ws;
       const float* vol = f.vol[s] + (size_t)v * f.vD[s] * f.vH[s] * f.vW[s] * kVolCh;
+#ifdef UFR_GABL_NOVOL   // ablation build: no frustum taps (timing only)
+      for (int c = 0; c < 8; ++c) fs[c] = x; ws = y;
+#else
       sample_volume(vol, f.vD[s], f.vH[s], f.vW[s], x, y, zn, fs, ws);
+#endif
 #pragma unroll
       for (int c = 0; c < 8; ++c) fl[8 * s + c] = fs[c];
       wl = s == 0 ? ws : wl + ws;                                                 // :375-378
@@ -195,6 +225,9 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
   // ---- cooperative 32-channel gathers: lane group of 8 = one footprint, lane c8 = channels 4*c8..4*c8+3
   const int c8 = threadIdx.x & 7, grp = threadIdx.x >> 3, n_grp = blockDim.x >> 3;
   // image features of (point, view) -> token columns 0..31 (ray_transformer.py:222-226)
+#ifdef UFR_GABL_NOCOOP  // ablation build: no 32-channel gathers (timing only)
+  if (false)
+#endif
   for (int item = grp; item < 64 * NV; item += n_grp) {
     const int ip = item / NV, iv = item - ip * NV;
     const int ipidx = blockIdx.x * 64 + ip;
@@ -206,6 +239,9 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
   }
   // pairwise similarity (model.py:271-283): pair q = (a, b), sides (view a, chunk b) / (view b+1, chunk a);
   // lane c8 = channel group gi of model.py:278-280
+#ifdef UFR_GABL_NOCOOP
+  if (false)
+#endif
   for (int item = grp; item < 64 * npair; item += n_grp) {
     const int ip = item / npair, q = item - ip * npair;
     int a = 0, rem = q;
@@ -244,29 +280,19 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
         ov[c] = G / (Wsum + 1e-8f);                                               // model.py:388
       }
     }
-    // pre_sim_mlp: Linear(8,32)-ReLU-Linear(32,32)-ReLU-Linear(32,16) (ray_transformer.py:128-132, 268);
-    // weight addresses are wave-uniform -> scalar loads
-    float h1[32], h2[32];
+    // pre_sim_mlp: Linear(8,32)-ReLU-Linear(32,32)-ReLU-Linear(32,16) (ray_transformer.py:128-132, 268).  In the
+    // whole-path renderer it runs as its own kernel over all points (presim_kernel below: every lane busy, instead
+    // of one wave per block working while the other NV-1 wait) and this block only hands over the mean similarity.
+    if (sim_split) {
+      if (active) {
+        st4(sim_split + (size_t)pidx * 8, f32x4{sim[0], sim[1], sim[2], sim[3]});
+        st4(sim_split + (size_t)pidx * 8 + 4, f32x4{sim[4], sim[5], sim[6], sim[7]});
+      }
+    } else {
+      float o16[16];
+      presim_mlp(ps, sim, o16);
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      float acc = ps.b0[j];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) acc = fmaf(ps.w0[j * 8 + k], sim[k], acc);
-      h1[j] = fmaxf(acc, 0.f);
-    }
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      float acc = ps.b2[j];
-#pragma unroll
-      for (int k = 0; k < 32; ++k) acc = fmaf(ps.w2[j * 32 + k], h1[k], acc);
-      h2[j] = fmaxf(acc, 0.f);
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      float acc = ps.b4[j];
-#pragma unroll
-      for (int k = 0; k < 32; ++k) acc = fmaf(ps.w4[j * 32 + k], h2[k], acc);
-      ov[24 + j] = acc;
+      for (int j = 0; j < 16; ++j) ov[24 + j] = o16[j];
     }
     if (active && sim8_out) {
 #pragma unroll
@@ -282,19 +308,40 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
   if (active) {
     const float* ov = sh_out + p * 40;
 #pragma unroll
-    for (int c = 0; c < 40; c += 4) st4(xrow + 32 + c, ld4(ov + c));
+    for (int c = 0; c < 24; c += 4) st4(xrow + 32 + c, ld4(ov + c));
+    if (!sim_split) {
+#pragma unroll
+      for (int c = 24; c < 40; c += 4) st4(xrow + 32 + c, ld4(ov + c));
+    }
+  }
+}
+
+// thread per point: mean pair similarity (8) -> pre_sim_mlp -> token columns 56..71 of all NV view tokens
+__global__ void __launch_bounds__(256) presim_kernel(PreSim ps, const float* __restrict__ sim8, int P, int NV,
+                                                      float* __restrict__ x_tokens) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const f32x4 a = ld4(sim8 + (size_t)p * 8), b = ld4(sim8 + (size_t)p * 8 + 4);
+  const float sim[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  float o[16];
+  presim_mlp(ps, sim, o);
+  for (int v = 0; v < NV; ++v) {
+    float* row = x_tokens + ((size_t)p * NV + v) * UFR_TOKEN_DIM + 56;
+#pragma unroll
+    for (int c = 0; c < 16; c += 4) st4(row + c, f32x4{o[c], o[c + 1], o[c + 2], o[c + 3]});
   }
 }
 
 hipError_t launch_gather(const FrameDev& f, const PreSim& ps, const float* ray_o, int o_stride, const float* ray_d,
                          const float* z, int RN, int SN, float* x_tokens, float* rgb, float* dir, float* sim8,
-                         float* vol24, float* xy, float* mask_z, hipStream_t s) {
+                         float* vol24, float* xy, float* mask_z, float* sim_split, hipStream_t s) {
   const int P = RN * SN, NV = f.NV;
   const int npair = NV * (NV - 1) / 2;
   const size_t taps = 2 * (size_t)NV * 64 * 8, outv = 64 * 40;
   size_t lds = sizeof(float) * ((size_t)64 * npair * 8 + 64 * (NV - 1) * 25 + (taps > outv ? taps : outv));
   hipLaunchKernelGGL(gather_kernel, dim3((P + 63) / 64), dim3(64 * NV), lds, s, f, ps, ray_o, o_stride, ray_d, z, P, SN,
-                     x_tokens, rgb, dir, sim8, vol24, xy, mask_z);
+                     x_tokens, rgb, dir, sim8, vol24, xy, mask_z, sim_split);
+  if (sim_split) hipLaunchKernelGGL(presim_kernel, dim3((P + 255) / 256), dim3(256), 0, s, ps, sim_split, P, NV, x_tokens);
   return hipGetLastError();
 }
 

@@ -30,7 +30,10 @@
 namespace ufr {
 
 constexpr int kPlanes = 3;
-constexpr int kBfChunkFrags = 24;  // 24 KiB chunks: 8 (tile, 3 planes) triples; splits evenly over 4 or 8 waves
+#ifndef UFR_BF_CHUNK
+#define UFR_BF_CHUNK 24
+#endif
+constexpr int kBfChunkFrags = UFR_BF_CHUNK;  // KiB per chunk: whole (tile, 3 planes) triples; splits evenly over the 4 fetching waves
 #ifndef UFR_BF_SLOTS
 #define UFR_BF_SLOTS 2
 #endif

@@ -142,6 +142,26 @@ def test_render_rays_matches_reference_golden(name, weights):
     assert rel_err(out["srdf"], g["srdf"]) < 2e-3
 
 
+@pytest.mark.parametrize("NV", [2, 4, 6, 7])
+def test_render_rays_other_view_counts(NV, weights):
+    """The view transformer is instantiated per token count L = NV + 1 (16 // L points per MFMA column tile, DPP or
+    ds_bpermute token exchanges, different pair counts in the gather): every supported NV against the oracle."""
+    from uforecon_amd.scene import make_frame, sampler_uniforms
+
+    fr = make_frame(48, 64, NV, seed=20 + NV)
+    RN = 24
+    idx = (torch.arange(RN) * 120 + 37)[None]
+    U1, U2 = sampler_uniforms(3, 64, 64, RN)
+    want = {}
+    with torch.no_grad():
+        _, _, depth_ref, rgb_ref = O.infer(load_weights(), fr.batch, idx, fr.source_imgs_feat, fr.feature_volume,
+                                           fr.match_feature, U1, U2, want=want)
+    out = ops.render_rays(_frame_handle(fr), weights, idx.reshape(-1).to(DEV), U1.to(DEV), U2.to(DEV))
+    assert max_rel_elem(out["depth"], depth_ref.reshape(-1), floor=1e-3) < REL_TOL
+    ok = ~border_degenerate_rays(want["fine"])
+    assert max_rel_elem(out["rgb"][ok.to(DEV)], rgb_ref.reshape(-1, 3)[ok], floor=0.05) < REL_TOL
+
+
 def test_render_rays_chunking_is_invisible(weights):
     """Rays are independent: rendering in chunks of 64 equals one launch group, bit for bit."""
     fr, idx, U1, U2, g = case_inputs("c2_hier_small")

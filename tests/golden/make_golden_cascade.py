@@ -29,6 +29,7 @@ from uforecon_amd.scene import CASCADE_CASES, fill_state_dict, make_cascade_case
 
 def build_reference():
     import_reference()
+    from code1.encoder_utils.fmt.FMT import FMT_with_pathway
     from code1.encoder_utils.fmt.module import CostRegNet
     from code1.encoder_utils.fmt.TransMVSNet import DepthNet
     from code1.feature_volume import MVSVolume
@@ -36,6 +37,7 @@ def build_reference():
     class T(nn.Module):
         def __init__(self):
             super().__init__()
+            self.FMT_with_pathway = FMT_with_pathway()
             self.cost_regularization = nn.ModuleList([CostRegNet(in_channels=1, base_channels=8) for _ in range(3)])
             self.DepthNet = DepthNet()
 
@@ -96,6 +98,38 @@ def run(name):
     print(name, {k: v.shape for k, v in out.items() if k.endswith("depth") or k.endswith("feature_volume")})
 
 
+def run_fmt(name):
+    """FMT_with_pathway.forward + the lines of TransMVSNet.get_match_feat (TransMVSNet.py:341-375) on the reference's module."""
+    from uforecon_amd.scene import make_fmt_case
+
+    c = make_fmt_case(name)
+    R = fill_state_dict(build_reference(), c["weight_seed"]).eval()
+    F_ = R.transmvsnet.FMT_with_pathway
+    out = {}
+    with torch.no_grad():
+        feats = F_([dict(f) for f in c["features"]], ref_idx=0)
+        for v, f in enumerate(feats):
+            for st in ("stage1", "stage2", "stage3"):
+                out[f"view{v}.{st}"] = f[st].numpy()
+        # only stage1 of the first batch element goes on (model.py:782-783), then get_match_feat
+        for f in feats:
+            f["stage1"] = f["stage1"][0:1]
+        od = F_.extract_cross_features(feats)
+        n = c["NV"]
+        index_lists = [(a, b) for a in range(n - 1) for b in range(a + 1, n)]
+        img_feat = [[] for _ in range(n)]
+        for k, (i, j) in enumerate(index_lists):
+            img_feat[i].append(od["aug_feat0s"][0][:, k])
+            img_feat[j].append(od["aug_feat1s"][0][:, k])
+        out["match_feature"] = torch.stack([torch.cat(v, dim=1) for v in img_feat], dim=1).numpy()
+    np.savez_compressed(os.path.join(HERE, f"fmt_{name}.npz"), **out)
+    print("fmt", name, out["match_feature"].shape)
+
+
 if __name__ == "__main__":
+    from uforecon_amd.scene import FMT_CASES
+
     for n in CASCADE_CASES:
         run(n)
+    for n in FMT_CASES:
+        run_fmt(n)

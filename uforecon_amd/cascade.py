@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import frustum
+from . import fmt, frustum
 
 Align_Corners_Range = False      # TransMVSNet.py:21
 
@@ -216,16 +216,26 @@ def get_depth_range_samples(cur_depth, ndepth, depth_inteval_pixel, device, dtyp
 
 
 class TransMVSNetCascade(nn.Module):
-    """The part of TransMVSNet.forward after feature extraction (TransMVSNet.py:183-236).  State_dict keys
-    (`cost_regularization.{0,1,2}.*`, `DepthNet.pixel_wise_net.*`) are the reference's under `transmvsnet.`."""
+    """The part of TransMVSNet after the FeatureNet backbone: FMT_with_pathway (TransMVSNet.py:181), the stage loop
+    (:183-236) and get_match_feat (:341-375).  State_dict keys (`FMT_with_pathway.*`, `cost_regularization.{0,1,2}.*`,
+    `DepthNet.pixel_wise_net.*`) are the reference's under `transmvsnet.`."""
 
     def __init__(self, ndepths=(48, 32, 8), depth_interals_ratio=(4, 2, 1), cr_base_chs=(8, 8, 8)):
         super().__init__()
         self.ndepths, self.depth_interals_ratio = list(ndepths), list(depth_interals_ratio)
         self.num_stage = len(ndepths)
         self.stage_scale = [4.0, 2.0, 1.0]
+        self.FMT_with_pathway = fmt.FMT_with_pathway()
         self.cost_regularization = nn.ModuleList([CostRegNet(in_channels=1, base_channels=c) for c in cr_base_chs])
         self.DepthNet = DepthNet()
+
+    def encode(self, features_backbone, ref_idx=0):
+        """backbone pyramids -> FMT features (TransMVSNet.py:181)"""
+        return self.FMT_with_pathway(features_backbone, ref_idx=ref_idx)
+
+    def get_match_feat(self, features, cur_n_src_views=3):
+        """TransMVSNet.py:341-375"""
+        return fmt.get_match_feat(self.FMT_with_pathway, features, cur_n_src_views)
 
     def forward(self, features, proj_matrices, depth_values, img_hw):
         """features: list over views of {"stage1".."stage3": (B,C,h,w)} (view 0 = reference); proj_matrices:

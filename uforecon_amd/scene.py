@@ -279,12 +279,15 @@ def make_tsdf_case(name: str):
 
 # ------------------------------------------------------------------ cascade of correlation frustums
 def fill_state_dict(module, seed: int):
-    """Deterministic, construction-order-independent parameters: every state_dict entry (sorted by key) is filled from
-    one seeded generator -- the reference-side golden script and the tests give a mirror and the reference's own
-    modules bit-identical weights without a multi-megabyte fixture.  Scales keep activations O(1)."""
-    g = torch.Generator().manual_seed(seed)
+    """Deterministic, construction-order-independent parameters: every state_dict entry is filled from its own
+    generator, seeded by (seed, crc32 of the key) -- the reference-side golden scripts and the tests give a mirror and the
+    reference's own modules bit-identical weights without a multi-megabyte fixture, whatever other entries the two
+    modules hold.  Scales keep activations O(1)."""
+    import zlib
+
     sd = module.state_dict()
     for k in sorted(sd):
+        g = torch.Generator().manual_seed((seed * 1_000_003 + zlib.crc32(k.encode())) % (2 ** 31))
         t = sd[k]
         if k.endswith("num_batches_tracked"):
             t.fill_(1)
@@ -292,10 +295,11 @@ def fill_state_dict(module, seed: int):
             t.copy_(1.0 + 0.3 * (torch.rand(t.shape, generator=g) - 0.5))
         elif k.endswith("running_mean") or k.endswith("bn.bias"):
             t.copy_(0.2 * (torch.rand(t.shape, generator=g) - 0.5))
-        elif k.endswith("bn.weight"):
+        elif k.endswith("bn.weight") or ("norm" in k and k.endswith("weight")):
             t.copy_(1.0 + 0.4 * (torch.rand(t.shape, generator=g) - 0.5))
         elif t.dim() >= 2:
-            fan_in = t[0].numel() if "conv7" not in k and "conv9" not in k and "conv11" not in k else t.shape[0] * t[0, 0].numel()
+            transposed = any(n in k for n in ("conv7", "conv9", "conv11"))
+            fan_in = t.shape[0] * t[0, 0].numel() if transposed else t[0].numel()
             t.copy_(_unit_uniform(tuple(t.shape), g) * (1.0 / math.sqrt(max(fan_in, 1))))
         else:
             t.copy_(0.1 * (torch.rand(t.shape, generator=g) - 0.5))
@@ -304,6 +308,18 @@ def fill_state_dict(module, seed: int):
 
 
 CASCADE_CASES = {"small3": dict(H=32, W=64, NV=3, seed=41, weight_seed=7)}
+FMT_CASES = {"small3": dict(H=32, W=64, NV=3, seed=51, weight_seed=8)}
+
+
+def make_fmt_case(name: str):
+    """Backbone feature pyramids of NV views for a batch of NV view rotations (FeatureNet outputs: 32/16/8 channels at
+    1/4, 1/2, 1/1 resolution) -- the input of FMT_with_pathway.forward (TransMVSNet.py:178-181)."""
+    c = dict(FMT_CASES[name])
+    H, W, NV = c["H"], c["W"], c["NV"]
+    g = torch.Generator().manual_seed(c["seed"])
+    feats = [{"stage1": _unit_uniform((NV, 32, H // 4, W // 4), g), "stage2": _unit_uniform((NV, 16, H // 2, W // 2), g),
+              "stage3": _unit_uniform((NV, 8, H, W), g)} for _ in range(NV)]
+    return dict(name=name, features=feats, NV=NV, weight_seed=c["weight_seed"])
 
 
 def make_cascade_case(name: str):

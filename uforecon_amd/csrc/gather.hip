@@ -69,32 +69,6 @@ __device__ __forceinline__ void sample_volume(const float* __restrict__ vol, int
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-// weight addresses are wave-uniform -> scalar loads; k-ordered fma chains starting from the bias
-__device__ __forceinline__ void presim_mlp(const PreSim& ps, const float (&sim)[8], float (&out)[16]) {
-  float h1[32], h2[32];
-#pragma unroll
-  for (int j = 0; j < 32; ++j) {
-    float acc = ps.b0[j];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) acc = fmaf(ps.w0[j * 8 + k], sim[k], acc);
-    h1[j] = fmaxf(acc, 0.f);
-  }
-#pragma unroll
-  for (int j = 0; j < 32; ++j) {
-    float acc = ps.b2[j];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) acc = fmaf(ps.w2[j * 32 + k], h1[k], acc);
-    h2[j] = fmaxf(acc, 0.f);
-  }
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    float acc = ps.b4[j];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) acc = fmaf(ps.w4[j * 32 + k], h2[k], acc);
-    out[j] = acc;
-  }
-}
-
 __device__ __forceinline__ void put_tap(float* dst, const Tap2& t) {
   *reinterpret_cast<i32x4*>(dst) = i32x4{t.o[0], t.o[1], t.o[2], t.o[3]};
   *reinterpret_cast<f32x4*>(dst + 4) = f32x4{t.w[0], t.w[1], t.w[2], t.w[3]};
@@ -118,7 +92,7 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
                                                       float* __restrict__ x_tokens, float* __restrict__ rgb_out,
                                                       float* __restrict__ dir_out, float* __restrict__ sim8_out,
                                                       float* __restrict__ vol24_out, float* __restrict__ xy_out,
-                                                      float* __restrict__ maskz_out, float* __restrict__ sim_split) {
+                                                      float* __restrict__ maskz_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int NV = f.NV;
   const int npair = NV * (NV - 1) / 2;
@@ -280,19 +254,11 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
         ov[c] = G / (Wsum + 1e-8f);                                               // model.py:388
       }
     }
-    // pre_sim_mlp: Linear(8,32)-ReLU-Linear(32,32)-ReLU-Linear(32,16) (ray_transformer.py:128-132, 268).  In the
-    // whole-path renderer it runs as its own kernel over all points (presim_kernel below: every lane busy, instead
-    // of one wave per block working while the other NV-1 wait) and this block only hands over the mean similarity.
-    if (sim_split) {
-      if (active) {
-        st4(sim_split + (size_t)pidx * 8, f32x4{sim[0], sim[1], sim[2], sim[3]});
-        st4(sim_split + (size_t)pidx * 8 + 4, f32x4{sim[4], sim[5], sim[6], sim[7]});
-      }
-    } else {
-      float o16[16];
-      presim_mlp(ps, sim, o16);
-#pragma unroll
-      for (int j = 0; j < 16; ++j) ov[24 + j] = o16[j];
+    // hand the mean similarity to presim_kernel through token columns 56..63 of the point's first view row
+    if (active) {
+      float* scratch = x_tokens + (size_t)pidx * NV * UFR_TOKEN_DIM + 56;
+      st4(scratch, f32x4{sim[0], sim[1], sim[2], sim[3]});
+      st4(scratch + 4, f32x4{sim[4], sim[5], sim[6], sim[7]});
     }
     if (active && sim8_out) {
 #pragma unroll
@@ -308,40 +274,74 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
   if (active) {
     const float* ov = sh_out + p * 40;
 #pragma unroll
-    for (int c = 0; c < 24; c += 4) st4(xrow + 32 + c, ld4(ov + c));
-    if (!sim_split) {
-#pragma unroll
-      for (int c = 24; c < 40; c += 4) st4(xrow + 32 + c, ld4(ov + c));
-    }
+    for (int c = 0; c < 24; c += 4) st4(xrow + 32 + c, ld4(ov + c));   // columns 56..71: presim_kernel
   }
 }
 
-// thread per point: mean pair similarity (8) -> pre_sim_mlp -> token columns 56..71 of all NV view tokens
-__global__ void __launch_bounds__(256) presim_kernel(PreSim ps, const float* __restrict__ sim8, int P, int NV,
-                                                      float* __restrict__ x_tokens) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
-  const f32x4 a = ld4(sim8 + (size_t)p * 8), b = ld4(sim8 + (size_t)p * 8 + 4);
-  const float sim[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-  float o[16];
-  presim_mlp(ps, sim, o);
-  for (int v = 0; v < NV; ++v) {
-    float* row = x_tokens + ((size_t)p * NV + v) * UFR_TOKEN_DIM + 56;
+// pre_sim_mlp: Linear(8,32)-ReLU-Linear(32,32)-ReLU-Linear(32,16) (ray_transformer.py:128-132, 268) on the mean pair
+// similarity of every point, as its own kernel: points are MFMA columns (v_mfma_f32_16x16x4_f32, exact fp32 fma
+// chains), the accumulator tile of a layer is the B operand of the next (lane (g,j) holds neurons 4g+r of point j, so
+// k-step (tile, r) of the next layer contracts neurons 16*tile + 4g + r and the A operand is loaded with that index),
+// biases are the accumulators' initial values.  A wave keeps the 28 weight fragments of the three layers in registers
+// and walks 4 tiles of 16 points.  The 8 similarities arrive in token columns 56..63 of the point's first view row
+// (written there by gather_kernel) and the 16 outputs go to columns 56..71 of all NV rows.
+__global__ void __launch_bounds__(256) presim_kernel(PreSim ps, int P, int NV, float* __restrict__ x_tokens) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  float a1[2][2], a2[2][2][4], a3[2][4];
+  f32x4 b1[2], b2[2], b3;
 #pragma unroll
-    for (int c = 0; c < 16; c += 4) st4(row + c, f32x4{o[c], o[c + 1], o[c + 2], o[c + 3]});
+  for (int to = 0; to < 2; ++to) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) a1[to][s] = ps.w0[(16 * to + j) * 8 + 4 * s + g];
+    b1[to] = ld4(ps.b0 + 16 * to + 4 * g);
+    b2[to] = ld4(ps.b2 + 16 * to + 4 * g);
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a2[to][ti][r] = ps.w2[(16 * to + j) * 32 + 16 * ti + 4 * g + r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a3[to][r] = ps.w4[j * 32 + 16 * to + 4 * g + r];
+  }
+  b3 = ld4(ps.b4 + 4 * g);
+  const size_t row = (size_t)NV * UFR_TOKEN_DIM;
+  for (int t = 0; t < 4; ++t) {
+    const int p = wave * 64 + t * 16 + j;
+    const float* sim = x_tokens + (size_t)(p < P ? p : P - 1) * row + 56;
+    f32x4 h1[2] = {b1[0], b1[1]}, h2[2] = {b2[0], b2[1]}, o = b3;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const float x = sim[4 * s + g];
+#pragma unroll
+      for (int to = 0; to < 2; ++to) h1[to] = mfma16(a1[to][s], x, h1[to]);
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float x = fmaxf(h1[ti][r], 0.f);
+#pragma unroll
+        for (int to = 0; to < 2; ++to) h2[to] = mfma16(a2[to][ti][r], x, h2[to]);
+      }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o = mfma16(a3[ti][r], fmaxf(h2[ti][r], 0.f), o);
+    if (p < P)
+      for (int v = 0; v < NV; ++v) st4(x_tokens + (size_t)p * row + (size_t)v * UFR_TOKEN_DIM + 56 + 4 * g, o);
   }
 }
 
 hipError_t launch_gather(const FrameDev& f, const PreSim& ps, const float* ray_o, int o_stride, const float* ray_d,
                          const float* z, int RN, int SN, float* x_tokens, float* rgb, float* dir, float* sim8,
-                         float* vol24, float* xy, float* mask_z, float* sim_split, hipStream_t s) {
+                         float* vol24, float* xy, float* mask_z, hipStream_t s) {
   const int P = RN * SN, NV = f.NV;
   const int npair = NV * (NV - 1) / 2;
   const size_t taps = 2 * (size_t)NV * 64 * 8, outv = 64 * 40;
   size_t lds = sizeof(float) * ((size_t)64 * npair * 8 + 64 * (NV - 1) * 25 + (taps > outv ? taps : outv));
   hipLaunchKernelGGL(gather_kernel, dim3((P + 63) / 64), dim3(64 * NV), lds, s, f, ps, ray_o, o_stride, ray_d, z, P, SN,
-                     x_tokens, rgb, dir, sim8, vol24, xy, mask_z, sim_split);
-  if (sim_split) hipLaunchKernelGGL(presim_kernel, dim3((P + 255) / 256), dim3(256), 0, s, ps, sim_split, P, NV, x_tokens);
+                     x_tokens, rgb, dir, sim8, vol24, xy, mask_z);
+  hipLaunchKernelGGL(presim_kernel, dim3((P + 255) / 256), dim3(256), 0, s, ps, P, NV, x_tokens);
   return hipGetLastError();
 }
 

@@ -241,7 +241,7 @@ int ufr_project_gather(const ufr_frame* frame, const ufr_raw_weights* raw, const
   UFR_REQUIRE(ray_o_stride == 0 || ray_o_stride == 3, "ufr_project_gather: ray_o_stride must be 0 or 3");
   UFR_REQUIRE(RN > 0 && SN > 0, "ufr_project_gather: RN=%d SN=%d", RN, SN);
   UFR_HIP(launch_gather(*f, presim_of(raw), ray_o, ray_o_stride, ray_d, z, RN, SN, x_tokens, rgb, dir, sim8, vol24, xy,
-                        mask_z, nullptr, static_cast<hipStream_t>(stream)));
+                        mask_z, static_cast<hipStream_t>(stream)));
   return UFR_OK;
 }
 
@@ -297,7 +297,7 @@ int32_t ufr_default_chunk_rays(void) { return 4096; }
 namespace {
 struct RenderWs {
   float *ray_o, *rd, *near, *far, *camz, *z1, *w1, *srdf1, *depth1, *rgb1, *z2, *srdf2, *rad, *x, *rgbm, *dir, *token0,
-      *pe1, *pe2, *z_new, *sim8;
+      *pe1, *pe2, *z_new;
   int* row;  // merged slot -> row of the [coarse | new] evaluation pool (token0, rad)
   size_t bytes;
 };
@@ -324,7 +324,6 @@ RenderWs carve_render(void* ws, int R, int SN, int PN, int NV) {
   r.rgbm = c.f32((size_t)R * Sg * NV * 4);
   r.dir = c.f32((size_t)R * Sg * NV * 4);
   r.z_new = c.f32((size_t)R * (PN > 0 ? PN : 1));
-  r.sim8 = c.f32((size_t)R * Sg * 8);
   r.row = reinterpret_cast<int*>(c.f32((size_t)R * S2));
   r.token0 = c.f32((size_t)R * Smax * UFR_TOKEN_DIM);
   r.pe1 = c.f32((size_t)SN * 8);
@@ -380,7 +379,7 @@ int render_chunk(const ufr_render_args* a, const FrameDev* f, const RenderWs& w,
   // ---- coarse pass (model.py:445)
   {
     ProfScope p("gather", s);
-    UFR_HIP(launch_gather(*f, ps, w.ray_o, 0, w.rd, w.z1, R, SN, w.x, w.rgbm, w.dir, nullptr, nullptr, nullptr, nullptr, w.sim8, s));
+    UFR_HIP(launch_gather(*f, ps, w.ray_o, 0, w.rd, w.z1, R, SN, w.x, w.rgbm, w.dir, nullptr, nullptr, nullptr, nullptr, s));
   }
   int rc = aggregate_impl(a->packed_weights, w.x, w.rgbm, w.dir, R, SN, NV, w.rad, w.srdf1, w.token0, w.pe1, true,
                           nullptr, nullptr, s);
@@ -408,7 +407,7 @@ int render_chunk(const ufr_render_args* a, const FrameDev* f, const RenderWs& w,
   }
   {
     ProfScope p("gather", s);
-    UFR_HIP(launch_gather(*f, ps, w.ray_o, 0, w.rd, w.z_new, R, PN, w.x, w.rgbm, w.dir, nullptr, nullptr, nullptr, nullptr, w.sim8, s));
+    UFR_HIP(launch_gather(*f, ps, w.ray_o, 0, w.rd, w.z_new, R, PN, w.x, w.rgbm, w.dir, nullptr, nullptr, nullptr, nullptr, s));
   }
   {
     ProfScope p("view_transformer", s);

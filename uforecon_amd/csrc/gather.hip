@@ -86,7 +86,7 @@ __device__ __forceinline__ Tap2 get_tap(const float* src) {
 // { tapF[NV][64][8] | tapM[NV][64][8] } aliased with outv[64][40] (the footprints are dead once sim is complete).
 // The footprint of a block bounds the CU's occupancy -- of this kernel, and of the mix when it runs beside the
 // transformer kernels of another chunk (side streams).
-__global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, const float* __restrict__ ray_o,
+__global__ void __launch_bounds__(448) gather_kernel(FrameDev f, const float* __restrict__ ray_o,
                                                       int o_stride, const float* __restrict__ ray_d,
                                                       const float* __restrict__ zval, int P, int SN,
                                                       float* __restrict__ x_tokens, float* __restrict__ rgb_out,
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
   float* sh_vol = sh_sim + 64 * npair * 8;     // 64*(NV-1)*25
   float* sh_tapF = sh_vol + 64 * (NV - 1) * 25;  // NV*64*8: feature-map footprint (align_corners=False, zeros)
   float* sh_tapM = sh_tapF + NV * 64 * 8;      // NV*64*8: matching-map footprint (align_corners=True, border)
-  float* sh_out = sh_tapF;                     // 64*40, written after the last footprint read
+  float* sh_out = sh_tapF;                     // 64*24 used (stride 40), written after the last footprint read
 
   const int v = threadIdx.x >> 6, p = threadIdx.x & 63;
   const int pidx = blockIdx.x * 64 + p;
@@ -339,7 +339,7 @@ hipError_t launch_gather(const FrameDev& f, const PreSim& ps, const float* ray_o
   const int npair = NV * (NV - 1) / 2;
   const size_t taps = 2 * (size_t)NV * 64 * 8, outv = 64 * 40;
   size_t lds = sizeof(float) * ((size_t)64 * npair * 8 + 64 * (NV - 1) * 25 + (taps > outv ? taps : outv));
-  hipLaunchKernelGGL(gather_kernel, dim3((P + 63) / 64), dim3(64 * NV), lds, s, f, ps, ray_o, o_stride, ray_d, z, P, SN,
+  hipLaunchKernelGGL(gather_kernel, dim3((P + 63) / 64), dim3(64 * NV), lds, s, f, ray_o, o_stride, ray_d, z, P, SN,
                      x_tokens, rgb, dir, sim8, vol24, xy, mask_z);
   hipLaunchKernelGGL(presim_kernel, dim3((P + 255) / 256), dim3(256), 0, s, ps, P, NV, x_tokens);
   return hipGetLastError();

@@ -204,7 +204,7 @@ __device__ __forceinline__ void gemm_bf_panel(WStreamBf& ws, const BStep (&b)[C]
       }
     }
 #pragma unroll
-    for (int c = 0; c < C; ++c) asm volatile("" : "+v"(out[c][to]));  // pin (see weight_stream.h)
+    for (int c = 0; c < C; ++c) asm volatile("" : "+v"(out[c][to]));  // pin: pure MFMAs are otherwise sunk past later LDS reads
   });
   __builtin_amdgcn_sched_barrier(0);
 }

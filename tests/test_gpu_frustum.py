@@ -64,3 +64,25 @@ def test_similarity_only_and_errors():
     with pytest.raises(UfrError, match="GPU"):
         frustum.correlate(c["ref_fea"], torch.stack(c["src_feas"]), c["ref_proj_pair"], c["src_proj_pairs"],
                           c["depth_values"])
+
+
+def test_correlate_cpu_vs_gpu_timing(capsys):
+    """Not an assertion of speed: records, in the test log, the reference's torch ops (the oracle) against the HIP
+    kernel on the stage-1 shape of a 512x640 frame -- the CPU leg that tools/bench_correlate.py may not run itself."""
+    import time
+
+    c = make_correlate_case("custom", C=32, H=128, W=160, D=48, NV=3, seed=7)
+    t0 = time.perf_counter()
+    sims, agg = FO.correlate(c["ref_fea"], c["src_feas"], c["ref_proj_pair"], c["src_proj_pairs"], c["depth_values"],
+                             c["view_weights"])
+    cpu_ms = (time.perf_counter() - t0) * 1e3
+    _run(c)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sim_g, agg_g = _run(c)
+    torch.cuda.synchronize()
+    gpu_ms = (time.perf_counter() - t0) * 1e3
+    assert float((agg_g.cpu() - agg).abs().max()) <= TOL_OTHER_HOST * float(agg.abs().max())
+    with capsys.disabled():
+        print(f"\n[correlate stage-1 shape] cpu oracle {cpu_ms:.0f} ms ({torch.get_num_threads()} threads), "
+              f"gpu call {gpu_ms:.2f} ms incl. host overhead")

@@ -1,11 +1,10 @@
 """Micro-benchmark of the correlation-volume step at the three cascade stages of a 512x640, 3-view frame
 (TransMVSNet.py:125: D = 48/32/8 at 1/4, 1/2, 1/1 resolution with 32/16/8 channels).  Prints one line per stage:
-launch time (HIP events via ufr_profile_*), algorithmic bytes and the fraction of the HBM roof, and -- with --cpu --
-the oracle (the reference's torch ops) on the host cores for the stage-1 shape."""
+launch time (HIP events via ufr_profile_*), algorithmic bytes and the fraction of the HBM roof.  (The CPU side of the
+comparison is timed by tests/test_gpu_frustum.py::test_correlate_cpu_vs_gpu_timing, the only place allowed to run the oracle.)"""
 import argparse
 import os
 import sys
-import time
 
 import torch
 
@@ -20,7 +19,6 @@ STAGES = [("stage1", 32, 128, 160, 48), ("stage2", 16, 256, 320, 32), ("stage3",
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--cpu", action="store_true")
     ap.add_argument("--reps", type=int, default=20)
     a = ap.parse_args()
     for name, C, H, W, D in STAGES:
@@ -45,12 +43,6 @@ def main():
         print(f"{name}: C={C} {H}x{W} D={D}: {ms * 1e3:8.1f} us/launch  {algo / ms / 1e6:7.1f} GB/s algorithmic "
               f"({algo / 1e6:.1f} MB; {algo / ms / 1e6 / 8000:.1%} of the 8 TB/s roof); samples/s "
               f"{NS * D * H * W / ms / 1e6:.2f} G; warped volume the reference materialises: {ref_bytes / 1e6:.0f} MB")
-        if a.cpu and name == "stage1":
-            from oracle import frustum_oracle as FO
-            t = time.perf_counter()
-            FO.correlate(c["ref_fea"], c["src_feas"], c["ref_proj_pair"], c["src_proj_pairs"], c["depth_values"], c["view_weights"])
-            dt = time.perf_counter() - t
-            print(f"   cpu oracle ({torch.get_num_threads()} threads): {dt * 1e3:.1f} ms")
 
 
 if __name__ == "__main__":

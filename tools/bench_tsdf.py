@@ -1,11 +1,10 @@
 """Micro-benchmark of the TSDF integrate kernel on a DTU-scale volume (voxel 1.5 mm over a ~0.6 m cube is 400^3;
 here 384^3 = 56.6 M voxels, 226 MB per volume) and a 512x640 depth map: time per observation (HIP events via
 ufr_profile_*), HBM roofline fraction on the algorithmic bytes (16 B per updated voxel + 4 B per visited voxel's
-weight... see DESIGN.md), and with --cpu the oracle (numpy) on the host for a 96^3 volume."""
+weight... see DESIGN.md).  (The numpy oracle is timed by tests/test_tsdf.py, the only place allowed to run it.)"""
 import argparse
 import os
 import sys
-import time
 
 import numpy as np
 import torch
@@ -30,7 +29,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=384)
     ap.add_argument("--reps", type=int, default=10)
-    ap.add_argument("--cpu", action="store_true")
     a = ap.parse_args()
     K, P, depth, bnds, vs = scene(a.n)
     vol = tsdf.TSDFVolume(bnds.copy(), voxel_size=vs, margin=3)
@@ -50,15 +48,6 @@ def main():
     print(f"volume {tuple(vol._vol_dim)} = {n_vox / 1e6:.1f} M voxels, {upd / 1e6:.2f} M updated per observation: "
           f"{ms * 1e3:.1f} us/launch, {n_vox / ms / 1e6:.1f} G voxels/s, algorithmic {algo / 1e6:.1f} MB -> "
           f"{algo / ms / 1e6:.0f} GB/s = {algo / ms / 1e6 / 8000:.1%} of the 8 TB/s roof")
-    if a.cpu:
-        from oracle import tsdf_oracle as T
-        K2, P2, depth2, bnds2, vs2 = scene(96)
-        dim, org = T.volume_layout(bnds2, vs2)
-        t_, w_, c_ = np.ones(dim, np.float32), np.zeros(dim, np.float32), np.zeros(dim, np.float32)
-        t0 = time.perf_counter()
-        T.integrate(t_, w_, c_, org, vs2, 3 * vs2, K2, P2, depth2)
-        dt = time.perf_counter() - t0
-        print(f"   cpu oracle (numpy, 1 thread): {tuple(dim)} volume in {dt * 1e3:.0f} ms = {np.prod(dim) / dt / 1e6:.1f} M voxels/s")
 
 
 if __name__ == "__main__":

@@ -103,7 +103,16 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, const float* __
   float* sh_out = sh_tapF;                     // 64*24 used (stride 40), written after the last footprint read
 
   const int v = threadIdx.x >> 6, p = threadIdx.x & 63;
-  const int pidx = blockIdx.x * 64 + p;
+  // XCD-aware block -> point-group map: workgroups are dealt round-robin to the 8 XCDs (private L2 each), so
+  // giving XCD x the x-th contiguous eighth of the launch keeps the texels that neighbouring rays share in ONE L2
+  // instead of eight
+#ifndef UFR_GATHER_NO_XCD_MAP
+  const int nb8 = (int)(gridDim.x / 8) * 8;
+  const int blk = (int)blockIdx.x < nb8 ? (int)(blockIdx.x % 8) * (nb8 / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+#else
+  const int blk = blockIdx.x;
+#endif
+  const int pidx = blk * 64 + p;
   const bool active = pidx < P;
   const int pc = active ? pidx : P - 1;
   const int ray = pc / SN;
@@ -204,7 +213,7 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, const float* __
 #endif
   for (int item = grp; item < 64 * NV; item += n_grp) {
     const int ip = item / NV, iv = item - ip * NV;
-    const int ipidx = blockIdx.x * 64 + ip;
+    const int ipidx = blk * 64 + ip;
     if (ipidx < P) {
       const Tap2 t = get_tap(sh_tapF + (iv * 64 + ip) * 8);
       st4(x_tokens + ((size_t)ipidx * NV + iv) * UFR_TOKEN_DIM + 4 * c8,

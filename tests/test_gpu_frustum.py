@@ -71,7 +71,13 @@ def test_correlate_cpu_vs_gpu_timing(capsys):
     kernel on the stage-1 shape of a 512x640 frame -- the CPU leg that tools/bench_correlate.py may not run itself."""
     import time
 
+    from uforecon_amd.scene import F_avg
+
     c = make_correlate_case("custom", C=32, H=128, W=160, D=48, NV=3, seed=7)
+    # band-limited features, like real feature maps: white noise would turn the 1-ulp coordinate differences between this
+    # host's BLAS and the build container's (see TOL_OTHER_HOST) into similarity differences that grow with the image width
+    c["ref_fea"] = F_avg(F_avg(c["ref_fea"]))
+    c["src_feas"] = [F_avg(F_avg(t)) for t in c["src_feas"]]
     t0 = time.perf_counter()
     sims, agg = FO.correlate(c["ref_fea"], c["src_feas"], c["ref_proj_pair"], c["src_proj_pairs"], c["depth_values"],
                              c["view_weights"])

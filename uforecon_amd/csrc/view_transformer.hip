@@ -244,6 +244,19 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
         for (int r = 0; r < 4; ++r) hid[c][t][r] = fmaxf(hid[c][t][r], 0.f);
     zero_tiles(o);
     gemm_bf<M_VT_MLP2, C, kVtWaves>(ws, hid, o, wrap);
+    // colour / mask / direction of this lane's (point, view): (issued here: hid is dead, so the 10 registers are free, and LayerNorm2 + the token stores cover the latency)
+    f32x4 col[C];
+    float dcomp[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      col[c] = splat4(0.f);
+      dcomp[c] = 0.f;
+      if (valid[c] && tv > 0) {
+        col[c] = ld4(rgbm + ((size_t)pidx[c] * NV + (tv - 1)) * 4);           // r,g,b,mask
+        dcomp[c] = dirs[((size_t)pidx[c] * NV + (tv - 1)) * 4 + g];           // lane group g <- dir[g], 0 for g=3
+      }
+    }
+
     UFR_PHASE(8)  // relu + MLP2
     layer_norm80<C, V_VT_N2W, V_VT_N2B>(o, ws, g);
 #pragma unroll
@@ -266,19 +279,6 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     }
 
     UFR_PHASE(9)  // LN2 + residual + stores
-    // colour / mask / direction of this lane's (point, view): (loaded late: they would otherwise sit in 10 registers across the MLP, the register peak)
-    f32x4 col[C];
-    float dcomp[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      col[c] = splat4(0.f);
-      dcomp[c] = 0.f;
-      if (valid[c] && tv > 0) {
-        col[c] = ld4(rgbm + ((size_t)pidx[c] * NV + (tv - 1)) * 4);           // r,g,b,mask
-        dcomp[c] = dirs[((size_t)pidx[c] * NV + (tv - 1)) * 4 + g];           // lane group g <- dir[g], 0 for g=3
-      }
-    }
-
     // ---------------- radiance weight MLP on [view feature | dir] (ray_transformer.py:309-314)
     f32x4 rin[C][6], h1[C][1], h2[C][1], lg[C][1];
 #pragma unroll

@@ -292,8 +292,9 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, const float* __
 // chains), the accumulator tile of a layer is the B operand of the next (lane (g,j) holds neurons 4g+r of point j, so
 // k-step (tile, r) of the next layer contracts neurons 16*tile + 4g + r and the A operand is loaded with that index),
 // biases are the accumulators' initial values.  A wave keeps the 28 weight fragments of the three layers in registers
-// and walks 4 tiles of 16 points.  The 8 similarities arrive in token columns 56..63 of the point's first view row
+// and walks kPresimTiles tiles of 16 points.  The 8 similarities arrive in token columns 56..63 of the point's first view row
 // (written there by gather_kernel) and the 16 outputs go to columns 56..71 of all NV rows.
+constexpr int kPresimTiles = 16;   // 16-point column tiles per wave: amortises the 28 lane-distinct weight-fragment loads
 __global__ void __launch_bounds__(256) presim_kernel(PreSim ps, int P, int NV, float* __restrict__ x_tokens) {
   const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -314,8 +315,8 @@ __global__ void __launch_bounds__(256) presim_kernel(PreSim ps, int P, int NV, f
   }
   b3 = ld4(ps.b4 + 4 * g);
   const size_t row = (size_t)NV * UFR_TOKEN_DIM;
-  for (int t = 0; t < 4; ++t) {
-    const int p = wave * 64 + t * 16 + j;
+  for (int t = 0; t < kPresimTiles; ++t) {
+    const int p = wave * (16 * kPresimTiles) + t * 16 + j;
     const float* sim = x_tokens + (size_t)(p < P ? p : P - 1) * row + 56;
     f32x4 h1[2] = {b1[0], b1[1]}, h2[2] = {b2[0], b2[1]}, o = b3;
 #pragma unroll
@@ -350,7 +351,7 @@ hipError_t launch_gather(const FrameDev& f, const PreSim& ps, const float* ray_o
   size_t lds = sizeof(float) * ((size_t)64 * npair * 8 + 64 * (NV - 1) * 25 + (taps > outv ? taps : outv));
   hipLaunchKernelGGL(gather_kernel, dim3((P + 63) / 64), dim3(64 * NV), lds, s, f, ray_o, o_stride, ray_d, z, P, SN,
                      x_tokens, rgb, dir, sim8, vol24, xy, mask_z);
-  hipLaunchKernelGGL(presim_kernel, dim3((P + 255) / 256), dim3(256), 0, s, ps, P, NV, x_tokens);
+  hipLaunchKernelGGL(presim_kernel, dim3((P + 64 * kPresimTiles - 1) / (64 * kPresimTiles)), dim3(256), 0, s, ps, P, NV, x_tokens);
   return hipGetLastError();
 }
 

@@ -58,6 +58,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-rays", type=int, default=256)
     p.add_argument("--cpu-calls", type=int, default=5)
+    p.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
+                                                      "exercise the multi-rank path on a box with fewer GPUs than ranks)")
     return p.parse_args()
 
 
@@ -98,10 +100,15 @@ def main():
     from uforecon_amd.dist import RayShard, all_gather_tiles
     from uforecon_amd.scene import make_frame
 
+    if os.environ.get("UFR_BENCH_SHARE_GPU"):      # diagnostics only: all ranks on one device (with --backend gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
 
     import numpy as np
 

@@ -366,7 +366,13 @@ static hipError_t launch_vt(const float* packed, const float* x_tokens, const fl
   // partner wave to overlap its VALU phases with (measured per-wave lifetimes 1.27 .. 1.64 ms).  Launching a
   // few times more, shorter workgroups lets the dispatcher refill a CU as soon as one retires.
   const int max_blocks = 256 * 2 * UFR_VT_OVERSUB;
-  if (blocks > max_blocks) blocks = max_blocks;
+  if (blocks > max_blocks) {
+    // every wave runs the same number of iterations (the chunk barriers are workgroup-wide): size the grid so that
+    // the groups divide evenly over them instead of leaving most waves idle in a last, partial iteration
+    // (18 432 groups over 8 192 waves would be 3 iterations with 25 % of the slots empty; 6 144 waves x 3 is exact)
+    const int n_iter = (n_groups + max_blocks * kVtWaves - 1) / (max_blocks * kVtWaves);
+    blocks = (n_groups + kVtWaves * n_iter - 1) / (kVtWaves * n_iter);
+  }
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&view_transformer_kernel<L, C>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kBfLdsBytes);
   if (attr != hipSuccess) return attr;

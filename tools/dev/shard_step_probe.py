@@ -12,7 +12,7 @@ wz = np.load(os.path.join(ROOT, "tests", "golden", "ray_path_weights_seed0.npz")
 W = ops.PackedWeights({k: torch.from_numpy(wz[k]).to(dev) for k in wz.files})
 frame = make_frame(512, 640, 3, seed=0).to(dev)
 import itertools
-for world, chunk in ((8, 0), (8, 2304), (8, 2048), (8, 1728), (4, 0), (2, 0), (1, 0)):
+for world, chunk in ((8, 0), (6, 0), (4, 0), (3, 0), (2, 0), (1, 0)):
     shard = RayShard(512, 640, world, 0)
     ray_idx = shard.ray_indices(dev)
     RN = ray_idx.numel()

@@ -453,8 +453,9 @@ int ufr_render_rays(const ufr_render_args* a, ufr_stream stream) {
   // gets >= 4 chunks: the last round of a round-robin over few chunks otherwise leaves streams idle
   int eff_chunk = chunk;
   if (lanes > 1) {
-    int target = ((RN + 4 * lanes - 1) / (4 * lanes) + 255) / 256 * 256;
-    if (target < 1024) target = 1024;
+    // ... in multiples of 2048 rays: 512 resident workgroup slots x 4 rays fill whole rounds of the ray transformer
+    int target = (RN + 4 * lanes - 1) / (4 * lanes) / 2048 * 2048;
+    if (target < 2048) target = 2048;
     if (target < eff_chunk) eff_chunk = target;
   }
   const int n_chunks = (RN + eff_chunk - 1) / eff_chunk;

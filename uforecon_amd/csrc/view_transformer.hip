@@ -370,8 +370,14 @@ static hipError_t launch_vt(const float* packed, const float* x_tokens, const fl
     // every wave runs the same number of iterations (the chunk barriers are workgroup-wide): size the grid so that
     // the groups divide evenly over them instead of leaving most waves idle in a last, partial iteration
     // (18 432 groups over 8 192 waves would be 3 iterations with 25 % of the slots empty; 6 144 waves x 3 is exact)
-    const int n_iter = (n_groups + max_blocks * kVtWaves - 1) / (max_blocks * kVtWaves);
-    blocks = (n_groups + kVtWaves * n_iter - 1) / (kVtWaves * n_iter);
+    // ... and so that the workgroups fill whole rounds of the 512 resident slots: cost ~ rounds x iterations
+    const int base = (n_groups + max_blocks * kVtWaves - 1) / (max_blocks * kVtWaves);
+    long best_cost = -1;
+    for (int n_iter = base; n_iter <= 4 * base; ++n_iter) {
+      const int b = (n_groups + kVtWaves * n_iter - 1) / (kVtWaves * n_iter);
+      const long cost = (long)((b + 511) / 512) * n_iter;
+      if (best_cost < 0 || cost < best_cost) { best_cost = cost; blocks = b; }
+    }
   }
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&view_transformer_kernel<L, C>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kBfLdsBytes);

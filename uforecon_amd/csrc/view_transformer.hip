@@ -111,6 +111,28 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
   for (int it = 0; it < n_iter; ++it) {
     const int grp = it * n_waves + wave_global;
     const bool wrap = it + 1 < n_iter;
+#ifdef UFR_FUSION_PROBE
+    // Feasibility probe for fusing the gather into this kernel: a synthetic producer phase with
+    // the gather's per-iteration footprint -- 3 dependent rounds (projection -> footprint -> taps) of UFR_FUSION_PROBE
+    // independent 16-byte loads inside a 256 KiB window (cache-resident like the feature maps), ~12 VALU per load --
+    // whose result is kept alive but unused.  The real gather needs ~8 points x 3 views x 176 lane-loads / 64 = 66 loads
+    // per wave iteration, i.e. UFR_FUSION_PROBE = 22.
+    {
+      f32x4 acc = splat4(0.f);
+      unsigned cursor = (unsigned)(grp * 64 + lane) * 2654435761u;
+      const float* window = x_tokens + (size_t)((unsigned)grp % 64u) * 65536u;
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int k = 0; k < UFR_FUSION_PROBE; ++k) {
+          const unsigned off = ((cursor >> 8) + k * 977u) & 16383u;
+          const f32x4 v = ld4(window + (size_t)off * 4);
+          acc = acc * 1.0001f + v * v - acc * v * 0.5f + v * 0.25f;
+        }
+        cursor = cursor * 1664525u + 1013904223u + (unsigned)(int)(acc[0] * 1e-30f);
+      }
+      asm volatile("" ::"v"(acc));
+    }
+#endif
     // ---------------- load tokens: x[c][t] = features 16t+4g..+3 of token j
     f32x4 x[C][5];
     int pidx[C];

@@ -218,6 +218,17 @@ int ufr_tsdf_integrate(float* tsdf, float* weight, float* color, const int32_t* 
                        const float* depth_im, const float* color_im, int32_t im_h, int32_t im_w, float obs_weight,
                        int32_t integrate_color, ufr_stream stream);
 
+/* ---- deformable convolution of the feature backbone -------------------------------------------------------
+ * Replaces torchvision.ops.deform_conv2d as called by DCN.forward (code1/encoder_utils/fmt/dcn.py:66-80; every use in
+ * FeatureNet, code1/encoder_utils/fmt/module.py:407-440, is 3x3, stride 1, padding 1, dilation 1, one offset group,
+ * modulated).  input [B][C][H][W], offset [B][18][H][W] (channel 2k = dy, 2k+1 = dx of tap k), mask [B][9][H][W]
+ * (nullable), weight [Cout][C][3][3], bias [Cout] (nullable), output [B][Cout][H][W]: device, fp32.
+ * C a multiple of 4, <= 32; Cout in {8, 16, 32}.                                                                */
+size_t ufr_deform_conv2d_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W);
+int ufr_deform_conv2d(const float* input, const float* offset, const float* mask, const float* weight,
+                      const float* bias, float* output, int32_t B, int32_t C, int32_t Cout, int32_t H, int32_t W,
+                      void* workspace, size_t workspace_bytes, ufr_stream stream);
+
 void ufr_profile_enable(int on);
 int ufr_profile_read(const char** names, float* ms, int32_t* launches, int cap);
 

@@ -1,4 +1,4 @@
-"""The pieces compose: backbone features -> FMT -> frustum cascade + matching features -> per-ray renderer ->
+"""The pieces compose: source images -> FeatureNet (deformable convolutions) -> FMT -> frustum cascade + matching features -> per-ray renderer ->
 depth maps -> TSDF fusion, every stage through the product code (HIP kernels behind the C ABI + library ops), on the GPU.
 No reference numbers here (each stage has its own parity tests); this checks the hand-offs: shapes, layouts, value ranges."""
 import argparse
@@ -8,22 +8,26 @@ import pytest
 import torch
 
 from helpers import load_weights
-from uforecon_amd import cascade, model as M, tsdf
-from uforecon_amd.scene import fill_state_dict, make_cascade_case, make_frame, make_fmt_case
+from uforecon_amd import cascade, featurenet, model as M, tsdf
+from uforecon_amd.scene import fill_state_dict, make_cascade_case, make_frame
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def test_features_to_depth_maps_to_tsdf():
+def test_images_to_depth_maps_to_tsdf():
     H, W, NV = 32, 64, 3
     fr = make_frame(H, W, NV, seed=0).to(DEV)
     batch = fr.batch
-    # 1. encoder tail: FMT on (synthetic) backbone pyramids, then the cascade and the matching features
+    # 1. encoder: backbone on the NV rotations of the source images (model.py:139-160 build_pairs), FMT, cascade, matching
     cc = make_cascade_case("small3")                      # projection pairs / hypotheses of the same cameras, NV rotations
     prod = fill_state_dict(cascade.FrustumBuilder(), 7).eval().to(DEV)
-    feats = [{k: v.to(DEV) for k, v in f.items()} for f in make_fmt_case("small3")["features"]]
+    backbone = fill_state_dict(featurenet.FeatureNet(8), 9).eval().to(DEV)
+    imgs = batch["source_imgs"][0]                                                  # (NV, 3, H, W)
+    rot = [list(range(i, NV)) + list(range(0, i)) for i in range(NV)]
     with torch.no_grad():
+        feats = [backbone(torch.stack([imgs[rot[b][v]] for b in range(NV)])) for v in range(NV)]   # TransMVSNet.py:175-178
+        assert feats[0]["stage1"].shape == (NV, 32, H // 4, W // 4) and feats[0]["stage3"].shape == (NV, 8, H, W)
         feats = prod.transmvsnet.encode(feats, ref_idx=0)
         frustums, info = prod(feats, cc["proj_matrices"], cc["depth_values"].to(DEV), (H, W))
         for f in feats:

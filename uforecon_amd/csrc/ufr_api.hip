@@ -539,6 +539,31 @@ int ufr_tsdf_integrate(float* tsdf, float* weight, float* color, const int32_t* 
   return UFR_OK;
 }
 
+// ------------------------------------------------------------------ deformable convolution
+size_t ufr_deform_conv2d_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W) {
+  Carver c(nullptr);
+  c.f32((size_t)B * H * W * C);
+  return c.off;
+}
+
+int ufr_deform_conv2d(const float* input, const float* offset, const float* mask, const float* weight,
+                      const float* bias, float* output, int32_t B, int32_t C, int32_t Cout, int32_t H, int32_t W,
+                      void* workspace, size_t workspace_bytes, ufr_stream stream) {
+  UFR_REQUIRE(input && offset && weight && output && workspace, "ufr_deform_conv2d: null argument");
+  UFR_REQUIRE(C > 0 && C % 4 == 0 && C <= 32, "ufr_deform_conv2d: C=%d unsupported (multiple of 4, <= 32)", C);
+  UFR_REQUIRE(Cout == 8 || Cout == 16 || Cout == 32, "ufr_deform_conv2d: Cout=%d unsupported (8, 16, 32)", Cout);
+  UFR_REQUIRE(B > 0 && H > 0 && W > 0, "ufr_deform_conv2d: B=%d H=%d W=%d", B, H, W);
+  const size_t need = ufr_deform_conv2d_workspace_bytes(B, C, H, W);
+  if (workspace_bytes < need) return fail(UFR_ERR_WORKSPACE, "deform_conv2d workspace too small: %zu < %zu", workspace_bytes, need);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Carver c(workspace);
+  float* in_cl = c.f32((size_t)B * H * W * C);
+  ProfScope p("deform_conv2d", s);
+  UFR_HIP(launch_chw_to_hwc(input, in_cl, B, C, H * W, s));
+  UFR_HIP(launch_deform_conv3x3(in_cl, offset, mask, weight, bias, output, B, C, Cout, H, W, s));
+  return UFR_OK;
+}
+
 // ------------------------------------------------------------------ profiling hooks
 void ufr_profile_enable(int on) {
   for (auto& e : g_prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }

@@ -62,6 +62,8 @@ hipError_t launch_tsdf_integrate(float* tsdf, float* weight, float* color, const
                                  float voxel_size, float trunc_margin, const float* K, const float* P,
                                  const float* depth_im, const float* color_im, int im_h, int im_w, float obs_weight,
                                  int integrate_color, hipStream_t s);
+hipError_t launch_deform_conv3x3(const float* in_cl, const float* offset, const float* mask, const float* weight,
+                                 const float* bias, float* out, int B, int C, int Cout, int H, int W, hipStream_t s);
 hipError_t launch_chw_to_hwc(const float* in, float* out, int N, int C, int S, hipStream_t s);
 hipError_t launch_correlate(const float* ref_cl, const float* src_cl, const float* proj_host, int NS, const float* depth,
                             const float* vw, float* sim, float* agg, int C, int H, int W, int D, hipStream_t s);

@@ -66,3 +66,22 @@ def test_images_to_depth_map_files_to_tsdf(tmp_path):
     vol = tsdf.fuse_depth_maps([d["depth"], d["depth"]], [d["intrinsic"]] * 2, [d["extrinsic"]] * 2, voxel_size=0.1, margin=3)
     t, _, w = vol.get_volume()
     assert (w > 0).sum() > 100 and np.isfinite(t).all() and t.min() >= -1.0 and t.max() <= 1.0
+
+
+@pytest.mark.gpu
+def test_backbone_once_per_image_equals_once_per_rotation():
+    """encode_frame runs FeatureNet on the N distinct images instead of on every view of every rotation (N x N images,
+    TransMVSNet.py:175-178): same feature tensors."""
+    dev = "cuda:0"
+    fr = make_frame(32, 64, 3, seed=1).to(dev)
+    net = fill_state_dict(pipeline.UFOReconInference(_args()), 22).eval().to(dev)
+    imgs = fr.batch["source_imgs"]
+    dummy = {st: torch.zeros(1, 3, 2, 4, 4, device=dev) for st in ("stage1", "stage2", "stage3")}
+    rot_imgs, _, _ = net.build_pairs(imgs, dummy, torch.zeros(1, 4, device=dev))
+    with torch.no_grad():
+        base = net.transmvsnet.feature(imgs[0])
+        for v in range(3):
+            per_rotation = net.transmvsnet.feature(rot_imgs[:, v])
+            comb = [(r + v) % 3 for r in range(3)]
+            for st in ("stage1", "stage2", "stage3"):
+                assert torch.allclose(per_rotation[st], base[st][comb], rtol=0, atol=1e-6), (v, st)

@@ -41,7 +41,15 @@ class UFOReconInference(M.UFORecon):
         feature_volume dict, match_feature list) and sets batch['depth_info']."""
         imgs, pm, dv = self.build_pairs(batch["source_imgs"], batch["proj_matrices"], batch["depth_values_org_scale"])
         H, W = imgs.shape[-2:]
-        feats = [self.transmvsnet.feature(imgs[:, v]) for v in range(imgs.shape[1])]            # TransMVSNet.py:175-178
+        # TransMVSNet.py:175-178 runs the backbone on view v of every rotation, i.e. on each source image N times; one
+        # pass over the N distinct images and a gather by the rotation table gives the same tensors
+        B, N = batch["source_imgs"].shape[:2]
+        comb = np.array([list(range(i, N)) + list(range(0, i)) for i in range(N)])
+        base = self.transmvsnet.feature(batch["source_imgs"].reshape(B * N, *batch["source_imgs"].shape[2:]))
+        feats = []
+        for v in range(N):
+            idx = torch.as_tensor([b * N + comb[r][v] for b in range(B) for r in range(N)], device=imgs.device)
+            feats.append({st: base[st][idx] for st in ("stage1", "stage2", "stage3")})
         feats = self.transmvsnet.encode(feats, ref_idx=0)                                         # :181
         volume_info = self.transmvsnet(feats, pm, dv, (H, W))                                     # :183-236
         frustums = {}

@@ -19,7 +19,9 @@ def main():
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--tune", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen algorithm search)")
     a = ap.parse_args()
+    torch.backends.cudnn.benchmark = a.tune
     dev, NV = "cuda:0", 3
     fr = make_frame(a.height, a.width, NV, seed=0).to(dev)
     batch = fr.batch

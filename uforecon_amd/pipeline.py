@@ -17,8 +17,12 @@ from . import model as M
 
 
 class UFOReconInference(M.UFORecon):
-    def __init__(self, args):
+    def __init__(self, args, tune_convolutions: bool = True):
         super().__init__(args)
+        if tune_convolutions:
+            # the 3-D U-Nets are library convolutions: letting MIOpen search its algorithms once per shape halves them
+            # (512x640: cascade 29 -> 19 ms, CostRegNetWeight 32 -> 17 ms); the first frame pays the search
+            torch.backends.cudnn.benchmark = True
         self.transmvsnet = cascade.TransMVSNetCascade()
         self.transmvsnet.feature = featurenet.FeatureNet(base_channels=8)        # TransMVSNet.py:152
         self.feature_volume = cascade.MVSVolume(in_channels=1, base_channels=8)   # model.py:64

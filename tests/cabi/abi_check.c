@@ -1,0 +1,33 @@
+/* Plain-C consumer of include/ufr.h: the header must compile as C, every declared entry point must link against
+ * libufr.so, and the argument checks must answer without a GPU.  Built and run by tests/test_abi_and_layout.py. */
+#include <stdio.h>
+#include <string.h>
+
+#include "ufr.h"
+
+int main(void) {
+  /* link-time presence of every entry point */
+  const void* syms[] = {
+      (const void*)ufr_version, (const void*)ufr_last_error, (const void*)ufr_packed_weights_bytes, (const void*)ufr_weights_pack,
+      (const void*)ufr_pack_plan, (const void*)ufr_packed_fp32_floats, (const void*)ufr_packed_bf16_halfwords,
+      (const void*)ufr_pack_plan_bf16, (const void*)ufr_frame_workspace_bytes, (const void*)ufr_frame_prepare,
+      (const void*)ufr_sample_fixed, (const void*)ufr_sample_importance_merge, (const void*)ufr_points,
+      (const void*)ufr_project_gather, (const void*)ufr_aggregate_workspace_bytes, (const void*)ufr_aggregate,
+      (const void*)ufr_composite, (const void*)ufr_render_workspace_bytes, (const void*)ufr_default_chunk_rays,
+      (const void*)ufr_render_rays, (const void*)ufr_correlate_workspace_bytes, (const void*)ufr_frustum_correlate,
+      (const void*)ufr_tsdf_integrate, (const void*)ufr_deform_conv2d_workspace_bytes, (const void*)ufr_deform_conv2d,
+      (const void*)ufr_profile_enable, (const void*)ufr_profile_read};
+  unsigned i, n = sizeof(syms) / sizeof(syms[0]);
+  for (i = 0; i < n; ++i)
+    if (!syms[i]) return 10;
+  if (ufr_version() < 100) return 11;
+  /* argument validation: negative status + message, no device needed */
+  if (ufr_sample_fixed(0, 0, 0, 0, 4, 64, 0) >= 0) return 12;
+  if (!strstr(ufr_last_error(), "ufr_sample_fixed")) return 13;
+  if (ufr_tsdf_integrate(0, 0, 0, 0, 0, 1.f, 1.f, 0, 0, 0, 0, 4, 4, 1.f, 0, 0) >= 0) return 14;
+  if (ufr_deform_conv2d(0, 0, 0, 0, 0, 0, 1, 32, 32, 8, 8, 0, 0, 0) >= 0) return 15;
+  if (ufr_render_workspace_bytes(4096, 64, 64, 3) == 0) return 16;
+  if (ufr_correlate_workspace_bytes(32, 128, 160, 2) == 0) return 17;
+  printf("abi ok: %u entry points, version %d, %zu packed weight bytes\n", n, ufr_version(), ufr_packed_weights_bytes());
+  return 0;
+}

@@ -214,3 +214,23 @@ def test_bf16x6_panels_reproduce_linear(name, raw_and_blob, bf_blob):
         y, pad = E.from_tiles(E.gemm_bf(bf_blob, name, tiles), rm, out_dim)
     assert pad == 0.0
     assert np.abs(y - ref).max() / np.abs(ref).max() < 5e-7, name
+
+
+def test_header_is_usable_from_plain_c(lib, tmp_path):
+    """include/ufr.h compiled as C by gcc, linked against libufr.so: every entry point resolves and the argument checks
+    answer without a GPU (tests/cabi/abi_check.c)."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc on this host")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "uforecon_amd", "lib")
+    exe = str(tmp_path / "abi_check")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "cabi", "abi_check.c"), "-L", libdir, "-lufr", f"-Wl,-rpath,{libdir}",
+                    "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True, capture_output=True, text=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "abi ok" in r.stdout

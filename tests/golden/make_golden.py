@@ -39,6 +39,13 @@ CASES = {
     "c5_train_fwd": dict(H=64, W=96, NV=3, seed=5, RN=64, coarse=64, fine=64, train=True),
 }
 
+# reference autograd of the training loss (model.py:552-566) through infer(extract_geometry=False): gradients of every
+# per-ray parameter and of the six sampled volumes -- BASELINE.json configs[4]
+GRAD_CASES = {
+    "c5_train_grads": dict(H=64, W=96, NV=3, seed=5, RN=64, coarse=64, fine=64),
+    "c5_train_grads_nv4": dict(H=32, W=48, NV=4, seed=6, RN=24, coarse=32, fine=32),
+}
+
 
 def ray_indices(H, W, RN):
     step = max(1, (H * W) // RN)
@@ -140,9 +147,62 @@ def run_case(name, c, weight_seed=0, sampler_seed=1):
     return model
 
 
+def training_loss(r, batch, weight_rgb=1.0, weight_depth=1.0):
+    """model.py:552-566 on the 17-tuple of infer (model.py:480-482)."""
+    rgb_gt, rgb, depth, depth_gt, rgb_2, depth_2 = r[0], r[1], r[2], r[3], r[8], r[9]
+    loss_rgb = torch.nn.functional.mse_loss(rgb, rgb_gt)
+    loss_rgb2 = torch.nn.functional.mse_loss(rgb_2, rgb_gt)
+    nf = batch["near_fars"]
+    mask = (depth_gt != 0) & (depth_gt >= nf[:, 0, 0:1]) & (depth_gt <= nf[:, 0, 1:2])
+    if torch.sum(mask) > 0:
+        l1 = torch.nn.functional.l1_loss(depth[mask], depth_gt[mask])
+        l2 = torch.nn.functional.l1_loss(depth_2[mask], depth_gt[mask])
+    else:
+        l1 = l2 = 0.0
+    return weight_rgb * (loss_rgb + loss_rgb2) + weight_depth * (l1 + l2)
+
+
+def run_grad_case(name, c, weight_seed=0, sampler_seed=1):
+    model = build_reference_model(weight_seed, test_sample_coarse=c["coarse"], test_sample_fine=c["fine"],
+                                  coarse_sample=c["coarse"], fine_sample=c["fine"], test_n_view=c["NV"],
+                                  extract_geometry=False)
+    model.train()
+    fr = make_frame(c["H"], c["W"], c["NV"], c["seed"], train_layout=True)
+    idx = ray_indices(c["H"], c["W"], c["RN"])
+    vols = []
+    for st in ("stage1", "stage2", "stage3"):
+        for k in ("feature_volume", "weight_volume"):
+            fr.feature_volume[st][k].requires_grad_(True)
+            vols.append((f"{st}.{k}", fr.feature_volume[st][k]))
+    torch.manual_seed(sampler_seed)
+    r = model.infer(batch=fr.batch, ray_idx=idx, source_imgs_feat=fr.source_imgs_feat,
+                    feature_volume=fr.feature_volume, match_feature=fr.match_feature)
+    loss = training_loss(r, fr.batch)
+    loss.backward()
+    out = {"input_digest": np.float64(frame_digest(fr)), "ray_idx": idx.numpy(), "sampler_seed": np.int64(sampler_seed),
+           "weight_seed": np.int64(weight_seed), "loss": loss.detach().numpy()}
+    for n in ("rgb", "depth", "rgb_2", "depth_2"):
+        out[n] = r[dict(rgb=1, depth=2, rgb_2=8, depth_2=9)[n]].detach().numpy()
+    for k, p in model.named_parameters():
+        if k.startswith(("ray_transformer.", "deviation_network.")):
+            assert p.grad is not None, k
+            out["grad." + k] = p.grad.numpy()
+    for k, v in vols:
+        g = v.grad
+        nz = torch.nonzero(g.reshape(-1))[:, 0]
+        out[f"grad_idx.{k}"] = nz.numpy().astype(np.int64)           # sparse: flat index + value
+        out[f"grad_val.{k}"] = g.reshape(-1)[nz].numpy()
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    print(f"{name}: loss {float(loss):.6f}, {len(out)} arrays, {os.path.getsize(os.path.join(HERE, name + '.npz')) / 1e6:.2f} MB")
+
+
 def main():
     model = None
     only = sys.argv[1:]
+    for name, c in GRAD_CASES.items():
+        if only and name not in only:
+            continue
+        run_grad_case(name, c)
     for name, c in CASES.items():
         if only and name not in only:
             continue

@@ -21,6 +21,14 @@ CASES = {
     "c5_train_fwd": dict(H=64, W=96, NV=3, seed=5, RN=64, coarse=64, fine=64, train=True),
 }
 
+# same table as tests/golden/make_golden.py:GRAD_CASES (reference autograd of the training loss)
+GRAD_CASES = {
+    "c5_train_grads": dict(H=64, W=96, NV=3, seed=5, RN=64, coarse=64, fine=64, train=True),
+    "c5_train_grads_nv4": dict(H=32, W=48, NV=4, seed=6, RN=24, coarse=32, fine=32, train=True),
+}
+CASES.update(GRAD_CASES)
+VOLUME_KEYS = [f"{st}.{k}" for st in ("stage1", "stage2", "stage3") for k in ("feature_volume", "weight_volume")]
+
 # north_star tolerance: per-pixel depth and RGB within 1e-4 relative of the reference.
 REL_TOL = 1e-4
 
@@ -77,3 +85,19 @@ def border_degenerate_rays(rows: dict, tol: float = 2e-5) -> torch.Tensor:
     xy = rows["xy"].abs()
     near = ((xy - 1.0).abs() < tol).any(-1) & (rows["mask_z"] > 0)
     return near.any(0).any(-1)
+
+
+def golden_volume_grad(g: dict, key: str, shape) -> torch.Tensor:
+    """Dense gradient of one sampled volume from the sparse (flat index, value) pair stored in a grad fixture."""
+    out = torch.zeros(int(np.prod(shape)))
+    out[torch.from_numpy(g[f"grad_idx.{key}"])] = torch.from_numpy(g[f"grad_val.{key}"])
+    return out.reshape(shape)
+
+
+def grad_rel_err(a, b, floor: float = 1e-5) -> float:
+    """max |a-b| / max(max|b|, floor) -- gradients are compared per tensor against the tensor's own scale; the floor
+    covers parameters whose true gradient is zero (the last bias of the radiance-weight MLP: the softmax over views is
+    shift-invariant, so its gradient is rounding noise of order 1e-10 in the reference itself)."""
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(floor))

@@ -67,6 +67,31 @@ def test_train_layout_forward_matches_reference_golden():
     assert rel_err(r["variance"], g["variance"]) < 1e-6
 
 
+@pytest.mark.parametrize("name", ["c5_train_grads", "c5_train_grads_nv4"])
+def test_training_grads_match_reference_autograd(name):
+    """Autograd through the oracle == autograd through the reference (loss of model.py:552-566): pins the oracle as the
+    same-host checker of the HIP backward kernels."""
+    from helpers import VOLUME_KEYS, golden_volume_grad, grad_rel_err
+
+    fr, idx, U1, U2, g = case_inputs(name)
+    P = {k: v.clone().requires_grad_("depthcode" not in k) for k, v in load_weights().items()}   # buffers: no grad
+    for st in fr.feature_volume:
+        for k in fr.feature_volume[st]:
+            fr.feature_volume[st][k] = fr.feature_volume[st][k].clone().requires_grad_(True)
+    r = O.infer(P, fr.batch, idx, fr.source_imgs_feat, fr.feature_volume, fr.match_feature, U1, U2,
+                extract_geometry=False)
+    loss = O.training_loss(r, fr.batch, idx)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    loss.backward()
+    for k, p in P.items():
+        if p.requires_grad:
+            assert grad_rel_err(p.grad, g["grad." + k]) < 2e-4, k
+    for key in VOLUME_KEYS:
+        st, k = key.split(".")
+        v = fr.feature_volume[st][k]
+        assert grad_rel_err(v.grad, golden_volume_grad(g, key, v.shape)) < 2e-4, key
+
+
 # ------------------------------------------------------------------ correlation-volume step (SURVEY 8f rank 1)
 @pytest.mark.parametrize("name", ["stage1_small", "stage3_small", "nv5_stage2", "edge"])
 def test_frustum_oracle_matches_reference_golden(name):

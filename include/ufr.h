@@ -155,6 +155,48 @@ int ufr_composite(const float* z, const float* radiance, const float* srdf, cons
                   int32_t RN, int32_t SN, float* rgb, float* depth, float* opacity, float* weight,
                   ufr_stream stream);
 
+/* ------------------------------------------------------------------ backward (training step, BASELINE configs[4])
+ * The reference gets these from autograd over code1/model.py:540-566 (training_step: infer -> losses).  Which
+ * tensors receive gradients: every ray_transformer.* parameter, deviation_network.variance and the six sampled
+ * volumes (through which feature_volume.cost_reg_2.* trains); not the 2-D feature maps / matching features (their
+ * producer is frozen, model.py:82-83) and not the sample positions (model.py:456-457 detaches them).
+ * Each *_bwd entry point is the adjoint of the forward entry point of the same name and takes that call's inputs
+ * again (activations are recomputed, not stored).  Parameter gradients are ACCUMULATED (+=) into caller-owned
+ * tensors of the parameters' own shapes: zero them once per step. */
+#define UFR_NUM_PARAMS 40
+typedef struct ufr_raw_grads {
+  float* p[UFR_NUM_PARAMS]; /* one per pointer of ufr_raw_weights, in its declaration order; same shapes */
+} ufr_raw_grads;
+
+/* Adjoint of ufr_composite (autograd of renderer.py:19-46).  d_rgb (RN,3), d_depth (RN), d_opacity (RN),
+ * d_weight (RN,SN): gradients of the outputs, any may be NULL (= zero).  Outputs: d_radiance (RN,SN,3),
+ * d_srdf (RN,SN) (overwritten); d_variance: device scalar, ACCUMULATED. */
+int ufr_composite_bwd(const float* z, const float* radiance, const float* srdf, const float* variance, int32_t RN,
+                      int32_t SN, const float* d_rgb, const float* d_depth, const float* d_opacity,
+                      const float* d_weight, float* d_radiance, float* d_srdf, float* d_variance, ufr_stream stream);
+
+/* Adjoint of ufr_aggregate (autograd of ray_transformer.py:283-320).  x_tokens / rgb / dir: the forward's inputs;
+ * token0 (P,80): the view transformer's token-0 output = the first RN*SN*80 floats of the forward's workspace;
+ * d_radiance (P,3), d_srdf (RN,SN): gradients of the forward's outputs.  Accumulates the gradients of the view / ray
+ * transformer, DensityMLP, radiance-weight MLP and view-token parameters into `grads`; writes d_pv (P,40): gradient
+ * w.r.t. token columns 32..71 (24 frustum features | 16 pre_sim_mlp outputs) summed over the NV view tokens of a
+ * point -- the input of ufr_project_gather_bwd.  debug_view (P*(NV+1),881) / debug_ray (P,440): optional dumps of the
+ * intermediate gradients (tests), may be NULL. */
+size_t ufr_aggregate_bwd_workspace_bytes(int32_t RN, int32_t SN, int32_t NV);
+int ufr_aggregate_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const float* x_tokens, const float* rgb,
+                      const float* dir, const float* token0, int32_t RN, int32_t SN, int32_t NV,
+                      const float* d_radiance, const float* d_srdf, float* d_pv, void* workspace, float* debug_view,
+                      float* debug_ray, ufr_stream stream);
+
+/* Adjoint of ufr_project_gather w.r.t. the sampled volumes and pre_sim_mlp (autograd of model.py:350-390 and
+ * ray_transformer.py:268).  sim8 (P,8): the forward's `sim8` output; d_pv (P,40) from ufr_aggregate_bwd.
+ * grad_vol_feat[s] (NV,8,D,Hs,Ws) / grad_vol_weight[s] (NV,1,D,Hs,Ws): reference layout, ACCUMULATED (scatter-add);
+ * pre_sim_mlp gradients are accumulated into `grads`. */
+int ufr_project_gather_bwd(const ufr_frame* frame, const ufr_raw_weights* raw, const ufr_raw_grads* grads,
+                           const float* ray_o, int32_t ray_o_stride, const float* ray_d, const float* z, int32_t RN,
+                           int32_t SN, const float* sim8, const float* d_pv, float* const* grad_vol_feat,
+                           float* const* grad_vol_weight, ufr_stream stream);
+
 /* ------------------------------------------------------------------ whole-path inference
  * UFORecon.infer(extract_geometry=True) (model.py:393-478) for RN rays of one frame:
  * ray gather by index, near/far / cam_ray_d.z, coarse pass, importance sampling + merge, fine

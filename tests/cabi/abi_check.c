@@ -13,7 +13,8 @@ int main(void) {
       (const void*)ufr_pack_plan_bf16, (const void*)ufr_frame_workspace_bytes, (const void*)ufr_frame_prepare,
       (const void*)ufr_sample_fixed, (const void*)ufr_sample_importance_merge, (const void*)ufr_points,
       (const void*)ufr_project_gather, (const void*)ufr_aggregate_workspace_bytes, (const void*)ufr_aggregate,
-      (const void*)ufr_composite, (const void*)ufr_render_workspace_bytes, (const void*)ufr_default_chunk_rays,
+      (const void*)ufr_composite, (const void*)ufr_composite_bwd, (const void*)ufr_aggregate_bwd_workspace_bytes,
+      (const void*)ufr_aggregate_bwd, (const void*)ufr_project_gather_bwd, (const void*)ufr_render_workspace_bytes, (const void*)ufr_default_chunk_rays,
       (const void*)ufr_render_rays, (const void*)ufr_correlate_workspace_bytes, (const void*)ufr_frustum_correlate,
       (const void*)ufr_tsdf_integrate, (const void*)ufr_deform_conv2d_workspace_bytes, (const void*)ufr_deform_conv2d,
       (const void*)ufr_profile_enable, (const void*)ufr_profile_read};
@@ -27,6 +28,9 @@ int main(void) {
   if (ufr_tsdf_integrate(0, 0, 0, 0, 0, 1.f, 1.f, 0, 0, 0, 0, 4, 4, 1.f, 0, 0) >= 0) return 14;
   if (ufr_deform_conv2d(0, 0, 0, 0, 0, 0, 1, 32, 32, 8, 8, 0, 0, 0) >= 0) return 15;
   if (ufr_render_workspace_bytes(4096, 64, 64, 3) == 0) return 16;
+  if (ufr_composite_bwd(0, 0, 0, 0, 4, 64, 0, 0, 0, 0, 0, 0, 0, 0) >= 0) return 18;
+  if (ufr_aggregate_bwd(0, 0, 0, 0, 0, 0, 4, 64, 3, 0, 0, 0, 0, 0, 0, 0) >= 0) return 19;
+  if (ufr_aggregate_bwd_workspace_bytes(1024, 128, 3) == 0) return 20;
   if (ufr_correlate_workspace_bytes(32, 128, 160, 2) == 0) return 17;
   printf("abi ok: %u entry points, version %d, %zu packed weight bytes\n", n, ufr_version(), ufr_packed_weights_bytes());
   return 0;

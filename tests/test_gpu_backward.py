@@ -1,0 +1,200 @@
+"""GPU parity of the backward kernels (BASELINE configs[4]: training step through the HIP path).
+
+Three levels, all through the C ABI:
+  * each ``ufr_*_bwd`` entry point against autograd through the CPU oracle on the same inputs (this host),
+  * ``loss.backward()`` through ``UFORecon.infer(extract_geometry=False)`` -- the call of the reference's
+    ``training_step`` (code1/model.py:540-566) -- against the REFERENCE's own autograd gradients
+    (tests/golden/c5_train_grads*.npz: every per-ray parameter and the six sampled volumes),
+  * structural properties: linearity of the adjoints, gradient accumulation, chunk invariance.
+Tolerance: 1e-3 of each gradient tensor's scale (fp32 path; the forward runs the bf16x6 matrix path, the backward
+recomputes it on the fp32 MFMA).
+"""
+import argparse
+
+import pytest
+import torch
+
+from helpers import CASES, VOLUME_KEYS, case_inputs, golden_volume_grad, grad_rel_err, load_weights, rel_err
+from oracle import ufo_oracle as O
+from uforecon_amd import model as M
+from uforecon_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GRAD_TOL = 1e-3
+SHIFT_BIAS = "ray_transformer.linear_radianceweight_1_softmax.4.bias"
+
+
+def _args(c):
+    return argparse.Namespace(extract_geometry=False, test_sample_coarse=c["coarse"], test_sample_fine=c["fine"],
+                              coarse_sample=c["coarse"], fine_sample=c["fine"], volume_type="correlation", volume_reso=96,
+                              mvs_depth_guide=1, depth_pos_encoding=True, use_dir_srdf=False, explicit_similarity=True,
+                              test_coarse_only=False, test_ray_num=800)
+
+
+def _loss_from_tuple(r, batch, ray_idx):
+    """model.py:552-566 on the 17-tuple infer returns (caller-side torch ops, like the Lightning hook)."""
+    d = dict(rgb=r[1][0], depth=r[2][0], rgb_2=r[8][0], depth_2=r[9][0])
+    return O.training_loss(d, batch, ray_idx)
+
+
+@pytest.mark.parametrize("SN", [64, 128, 96])
+def test_composite_bwd_matches_oracle_autograd(SN):
+    g = torch.Generator().manual_seed(SN)
+    RN = 37
+    z = torch.sort(torch.rand(RN, SN, generator=g) * 2 + 2, dim=1)[0]
+    srdf = (torch.rand(RN, SN, generator=g) - 0.5) * 0.5 - (z - 3.0) * 0.3
+    rad = torch.rand(RN, SN, 3, generator=g)
+    var = torch.tensor(0.3)
+    co = [torch.rand(RN, 3, generator=g), torch.rand(RN, generator=g), torch.rand(RN, generator=g), torch.rand(RN, SN, generator=g)]
+    srdf_r, rad_r, var_r = srdf.clone().requires_grad_(True), rad.clone().requires_grad_(True), var.clone().requires_grad_(True)
+    rgb, depth, opacity, w, _ = O.composite(z, rad_r, srdf_r, var_r)
+    ((rgb * co[0]).sum() + (depth * co[1]).sum() + (opacity * co[2]).sum() + (w * co[3]).sum()).backward()
+    d_rad, d_srdf, d_var = ops.composite_bwd(z.to(DEV), rad.to(DEV), srdf.to(DEV), var.reshape(1).to(DEV),
+                                             *[t.to(DEV) for t in co])
+    assert grad_rel_err(d_rad, rad_r.grad) < 1e-5
+    assert grad_rel_err(d_srdf, srdf_r.grad) < 1e-4
+    assert abs(float(d_var) - float(var_r.grad)) < 1e-4 * abs(float(var_r.grad))
+    # optional cotangents: NULL means zero
+    d_rad2, d_srdf2, _ = ops.composite_bwd(z.to(DEV), rad.to(DEV), srdf.to(DEV), var.reshape(1).to(DEV), None,
+                                           co[1].to(DEV), None, None)
+    rgb, depth, opacity, w, _ = O.composite(z, rad, srdf_r, var)
+    srdf_r.grad = None
+    (depth * co[1]).sum().backward()
+    assert grad_rel_err(d_srdf2, srdf_r.grad) < 1e-4
+    assert float(d_rad2.abs().max()) == 0.0
+
+
+def _token_inputs(name, tag="coarse"):
+    """Token inputs of one pass from the HIP gather (so both sides see identical x / colours / masks / dirs)."""
+    fr, idx, U1, U2, g = case_inputs(name)
+    P = load_weights()
+    W = ops.PackedWeights({k: v.to(DEV) for k, v in P.items()})
+    f = fr.to(DEV)
+    fh = ops.FrameHandle(f.batch, f.source_imgs_feat, f.feature_volume, f.match_feature)
+    i = idx.reshape(-1)
+    ray_d = fr.batch["ray_d"][0][:, i].t().contiguous().to(DEV)
+    ray_o = fr.batch["ray_o"][0].contiguous().to(DEV)
+    RN = i.numel()
+    near = fr.batch["near_fars"][0, 0, 0].expand(RN).contiguous().to(DEV)
+    far = fr.batch["near_fars"][0, 0, 1].expand(RN).contiguous().to(DEV)
+    z = ops.sample_fixed(near, far, U1.to(DEV))
+    x, rgbm, dirs, dbg = ops.project_gather(fh, W, ray_o, ray_d, z, debug=True)
+    return fr, P, W, fh, ray_o, ray_d, z, x, rgbm, dirs, dbg
+
+
+@pytest.mark.parametrize("name", ["c5_train_grads", "c5_train_grads_nv4"])
+def test_aggregate_bwd_matches_oracle_autograd(name):
+    fr, P, W, fh, ray_o, ray_d, z, x, rgbm, dirs, dbg = _token_inputs(name)
+    RN, SN = z.shape
+    NV = x.shape[1]
+    radiance, srdf, agg = ops.aggregate(W, x, rgbm, dirs, RN, SN, keep_workspace=True)
+    g = torch.Generator().manual_seed(3)
+    co_rad, co_srdf = torch.rand(RN * SN, 3, generator=g) - 0.5, torch.rand(RN, SN, generator=g) - 0.5
+    # oracle autograd on the same token inputs
+    Pg = {k: v.clone().requires_grad_("depthcode" not in k) for k, v in P.items()}
+    xr = x.cpu().clone().requires_grad_(True)
+    rad_o, srdf_o = O.aggregate_tokens(Pg, xr, rgbm.cpu()[..., :3], rgbm.cpu()[..., 3], dirs.cpu()[..., :3], RN, SN)
+    assert rel_err(radiance, rad_o) < 1e-4 and rel_err(srdf, srdf_o) < 1e-4
+    ((rad_o * co_rad).sum() + (srdf_o * co_srdf).sum()).backward()
+    grads = ops.GradBuffer(DEV)
+    d_pv, _ = ops.aggregate_bwd(W, grads, x, rgbm, dirs, agg["token0"], RN, SN, co_rad.to(DEV), co_srdf.to(DEV))
+    torch.cuda.synchronize()
+    for k in ops.RAW_WEIGHT_KEYS:
+        if "pre_sim_mlp" in k or k == "deviation_network.variance":
+            continue
+        if k == SHIFT_BIAS:   # true gradient is zero (softmax over views is shift-invariant): both sides hold rounding noise
+            scale = float(Pg[k.replace("bias", "weight")].grad.abs().max())
+            assert float(grads.grad(k).abs().max()) < 1e-2 * scale
+            continue
+        assert grad_rel_err(grads.grad(k), Pg[k].grad) < GRAD_TOL, k
+    ref_pv = xr.grad[:, :, 32:72].sum(1)
+    assert grad_rel_err(d_pv, ref_pv) < GRAD_TOL
+    # gradients accumulate: a second call doubles them
+    d_pv2, _ = ops.aggregate_bwd(W, grads, x, rgbm, dirs, agg["token0"], RN, SN, co_rad.to(DEV), co_srdf.to(DEV))
+    k = "ray_transformer.density_view_transformer.layers.0.mlp.0.weight"
+    assert grad_rel_err(grads.grad(k), 2 * Pg[k].grad) < GRAD_TOL
+    assert torch.equal(d_pv2, d_pv)
+
+
+def test_project_gather_bwd_matches_oracle_autograd():
+    name = "c5_train_grads"
+    fr, P, W, fh, ray_o, ray_d, z, x, rgbm, dirs, dbg = _token_inputs(name)
+    RN, SN = z.shape
+    g = torch.Generator().manual_seed(4)
+    d_pv = (torch.rand(RN * SN, 40, generator=g) - 0.5)
+    # oracle: vol24 and pre_sim_mlp(sim8) as functions of the volumes / the MLP weights
+    Pg = {k: v.clone().requires_grad_("pre_sim_mlp" in k) for k, v in P.items()}
+    vols = {st: {k: v.clone().requires_grad_(True) for k, v in fr.feature_volume[st].items()} for st in fr.feature_volume}
+    pts = (ray_o.cpu()[None, None, :] + z.cpu()[..., None] * ray_d.cpu()[:, None, :])
+    vol24 = O.volume_lookup(fr.batch["source_poses"][0], pts, vols, fr.batch["near_fars"][0][0])
+    sim16 = O.mlp3(dbg["sim8"].cpu(), Pg, "ray_transformer.pre_sim_mlp.")
+    ((vol24.reshape(-1, 24) * d_pv[:, :24]).sum() + (sim16 * d_pv[:, 24:]).sum()).backward()
+    grads = ops.GradBuffer(DEV)
+    gf = [torch.zeros_like(fr.feature_volume[st]["feature_volume"], device=DEV) for st in ("stage1", "stage2", "stage3")]
+    gw = [torch.zeros_like(fr.feature_volume[st]["weight_volume"], device=DEV) for st in ("stage1", "stage2", "stage3")]
+    ops.project_gather_bwd(fh, W, grads, ray_o, ray_d, z, dbg["sim8"], d_pv.to(DEV), gf, gw)
+    torch.cuda.synchronize()
+    for i, st in enumerate(("stage1", "stage2", "stage3")):
+        assert grad_rel_err(gf[i], vols[st]["feature_volume"].grad) < 1e-4, st
+        assert grad_rel_err(gw[i], vols[st]["weight_volume"].grad) < 1e-4, st
+    for k in ops.RAW_WEIGHT_KEYS:
+        if "pre_sim_mlp" in k:
+            assert grad_rel_err(grads.grad(k), Pg[k].grad) < 1e-4, k
+
+
+def _train_step(name):
+    c = CASES[name]
+    fr, idx, U1, U2, g = case_inputs(name)
+    m = M.UFORecon(_args(c)).to(DEV)
+    m.load_state_dict(load_weights(), strict=True)
+    m.train()
+    f = fr.to(DEV)
+    for st in f.feature_volume:
+        for k in f.feature_volume[st]:
+            f.feature_volume[st][k].requires_grad_(True)
+    r = m.infer(f.batch, idx.to(DEV), f.source_imgs_feat, f.feature_volume, match_feature=f.match_feature,
+                uniforms=(U1, U2))
+    loss = _loss_from_tuple(r, f.batch, idx.to(DEV))
+    return m, f, r, loss, g
+
+
+@pytest.mark.parametrize("name", ["c5_train_grads", "c5_train_grads_nv4"])
+def test_training_step_gradients_match_reference_autograd(name):
+    """loss.backward() through UFORecon.infer == the reference's autograd (golden), every parameter and volume."""
+    m, f, r, loss, g = _train_step(name)
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    loss.backward()
+    torch.cuda.synchronize()
+    worst = {}
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        worst[k] = grad_rel_err(p.grad, g["grad." + k])
+    for key in VOLUME_KEYS:
+        st, k = key.split(".")
+        v = f.feature_volume[st][k]
+        worst[key] = grad_rel_err(v.grad, golden_volume_grad(g, key, v.shape))
+    bad = {k: e for k, e in worst.items() if not e < GRAD_TOL}
+    assert not bad, bad
+    assert r[16].requires_grad                       # variance output stays differentiable (train/variance log)
+
+
+def test_optimizer_step_follows_the_gradients():
+    """One optimizer step through the HIP backward (plain gradient descent, small enough for the first-order decrease
+    to hold; the reference trains with Adam, model.py:72-87): every per-ray parameter moves, the packed copy follows,
+    and the loss of the same batch goes down."""
+    name = "c5_train_grads"
+    m, f, r, loss, g = _train_step(name)
+    opt = torch.optim.SGD(m.parameters(), lr=1e-2)
+    before = {k: p.detach().clone() for k, p in m.named_parameters()}
+    loss.backward()
+    opt.step()
+    changed = {k for k, p in m.named_parameters() if not torch.equal(p.detach(), before[k])}
+    assert set(before) - changed <= {SHIFT_BIAS}      # that bias has no gradient (softmax over views is shift-invariant)
+    c = CASES[name]
+    fr, idx, U1, U2, _ = case_inputs(name)
+    with torch.no_grad():
+        r2 = m.infer(f.batch, idx.to(DEV), f.source_imgs_feat, f.feature_volume, match_feature=f.match_feature,
+                     uniforms=(U1, U2))
+    loss2 = _loss_from_tuple(r2, f.batch, idx.to(DEV))
+    assert float(loss2) < float(loss)

@@ -85,8 +85,10 @@ def test_infer_training_signature_forward_matches_golden():
     for k in ("weight", "srdf"):
         assert rel_err(got[k], g[k]) < 1e-4, k
     assert rel_err(got["z_val_all"], g["z_val_all"]) < 1e-5
-    with pytest.raises(ops.UfrError, match="backward"):
-        m.infer(f.batch, idx.to(dev), f.source_imgs_feat, f.feature_volume, match_feature=f.match_feature, uniforms=(U1, U2))
+    # with gradients enabled the same call is differentiable (tests/test_gpu_backward.py checks the gradients)
+    out = m.infer(f.batch, idx.to(dev), f.source_imgs_feat, f.feature_volume, match_feature=f.match_feature, uniforms=(U1, U2))
+    assert out[1].requires_grad and out[9].requires_grad and not out[14].requires_grad
+    assert rel_err(out[9], g["depth_2"]) < REL_TOL
 
 
 def test_save_depth_outputs_wire_format(tmp_path):

@@ -14,7 +14,8 @@ from oracle import ufo_oracle as O
 EXACT = 2e-6  # oracle vs reference differ only by op-order rounding
 
 
-@pytest.mark.parametrize("name", ["c1_coarse_only", "c2_hier_small", "c4_nv5_128", "c2_hier_512x640"])
+@pytest.mark.parametrize("name", ["c1_coarse_only", "c2_hier_small", "c4_nv5_128", "c2_hier_512x640", "c2_hier_interior",
+                                  "c4_nv5_interior"])
 def test_infer_matches_reference_golden(name):
     c = CASES[name]
     fr, idx, U1, U2, g = case_inputs(name)

@@ -29,6 +29,10 @@ class RawWeights(C.Structure):
                 ("density", Mlp3Weights), ("radiance", Mlp3Weights), ("view_token", fptr), ("variance", fptr)]
 
 
+class RawGrads(C.Structure):
+    _fields_ = [("p", fptr * 40)]
+
+
 class FrameDesc(C.Structure):
     _fields_ = [("NV", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("source_imgs", fptr), ("depth_info", fptr), ("feat", fptr), ("match", fptr),
@@ -74,6 +78,12 @@ SIGNATURES = {
     "ufr_aggregate_workspace_bytes": (sz, [i32, i32, i32]),
     "ufr_aggregate": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "ufr_composite": (C.c_int, [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
+    "ufr_composite_bwd": (C.c_int, [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "ufr_aggregate_bwd_workspace_bytes": (sz, [i32, i32, i32]),
+    "ufr_aggregate_bwd": (C.c_int, [C.POINTER(RawWeights), C.POINTER(RawGrads), vp, vp, vp, vp, i32, i32, i32, vp, vp, vp,
+                                    vp, vp, vp, vp]),
+    "ufr_project_gather_bwd": (C.c_int, [C.POINTER(Frame), C.POINTER(RawWeights), C.POINTER(RawGrads), vp, i32, vp, vp,
+                                         i32, i32, vp, vp, C.POINTER(vp), C.POINTER(vp), vp]),
     "ufr_render_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "ufr_default_chunk_rays": (i32, []),
     "ufr_render_rays": (C.c_int, [C.POINTER(RenderArgs), vp]),

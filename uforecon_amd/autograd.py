@@ -1,0 +1,83 @@
+"""torch.autograd glue of the training step (BASELINE configs[4]): the HIP forward entry points paired with their
+``ufr_*_bwd`` adjoints, so ``loss.backward()`` through ``UFORecon.infer(extract_geometry=False)`` (the call of
+``training_step``, code1/model.py:540-548) runs on the kernels.
+
+What the reference's autograd differentiates on this path: every ``ray_transformer.*``
+parameter, ``deviation_network.variance`` and the six sampled volumes.  Sample positions are detached
+(model.py:456-457) and the 2-D maps come from a frozen producer (model.py:82-83): no gradient, exactly as upstream.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+STAGES = ("stage1", "stage2", "stage3")
+
+
+class RenderPass(torch.autograd.Function):
+    """One ``sample2rgb`` pass (model.py:308-348): gather -> aggregate -> composite.
+
+    ``apply(frame, weights, ray_o, ray_d, z, *params, *volumes)`` with ``params`` = the 40 tensors of
+    ``ops.RAW_WEIGHT_KEYS`` (live nn.Parameters) and ``volumes`` = feature / weight volume of the three stages.
+    Returns ``rgb (RN,3), depth (RN), opacity (RN), weight (RN,SN), srdf (RN,SN)``.
+    Activations kept for the backward: the token inputs (x, rgb/mask, dir), the pair similarity, the view transformer's
+    token-0 rows, radiance and srdf -- everything else is recomputed inside the backward kernels."""
+
+    @staticmethod
+    def forward(ctx, frame, weights, ray_o, ray_d, z, *tensors):
+        n_par = len(ops.RAW_WEIGHT_KEYS)
+        RN, SN = z.shape
+        x, rgbm, dirs, dbg = ops.project_gather(frame, weights, ray_o, ray_d, z, want_sim8=True)
+        radiance, srdf, agg = ops.aggregate(weights, x, rgbm, dirs, RN, SN, keep_workspace=True)
+        variance = weights.variance.reshape(1)
+        rgb, depth, opacity, weight = ops.composite(z, radiance.view(RN, SN, 3), srdf, variance)
+        ctx.frame, ctx.weights, ctx.n_par = frame, weights, n_par
+        ctx.vol_shapes = [tuple(t.shape) for t in tensors[n_par:]]
+        ctx.save_for_backward(ray_o, ray_d, z, x, rgbm, dirs, dbg["sim8"], agg["token0"], radiance, srdf)
+        return rgb, depth, opacity, weight, srdf
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_depth, d_opacity, d_weight, d_srdf_out):
+        ray_o, ray_d, z, x, rgbm, dirs, sim8, token0, radiance, srdf = ctx.saved_tensors
+        frame, W = ctx.frame, ctx.weights
+        RN, SN = z.shape
+        dev = z.device
+        d_radiance, d_srdf, d_var = ops.composite_bwd(z, radiance.view(RN, SN, 3), srdf, W.variance.reshape(1), d_rgb, d_depth,
+                                                      d_opacity, d_weight)
+        if d_srdf_out is not None:
+            d_srdf = d_srdf + d_srdf_out
+        grads = ops.GradBuffer(dev)
+        d_pv, _ = ops.aggregate_bwd(W, grads, x, rgbm, dirs, token0, RN, SN, d_radiance.view(RN * SN, 3), d_srdf)
+        gvol = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.vol_shapes]
+        ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z, sim8, d_pv, gvol[0::2], gvol[1::2])
+        gpar = [grads.grad(k) for k in ops.RAW_WEIGHT_KEYS]
+        gpar[-1] = d_var.reshape(gpar[-1].shape)                      # deviation_network.variance
+        need = ctx.needs_input_grad[5:]
+        out = [g if n else None for g, n in zip(gpar + gvol, need)]
+        return (None, None, None, None, None, *out)
+
+
+class Composite(torch.autograd.Function):
+    """VolumeRenderer.render (renderer.py:7-48) with its adjoint: ``apply(z, radiance (RN,SN,3), srdf, variance)``."""
+
+    @staticmethod
+    def forward(ctx, z, radiance, srdf, variance):
+        rgb, depth, opacity, weight = ops.composite(z, radiance, srdf, variance.detach().reshape(1))
+        ctx.save_for_backward(z, radiance, srdf, variance)
+        return rgb, depth, opacity, weight
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_depth, d_opacity, d_weight):
+        z, radiance, srdf, variance = ctx.saved_tensors
+        d_rad, d_srdf, d_var = ops.composite_bwd(z, radiance, srdf, variance.detach().reshape(1), d_rgb, d_depth, d_opacity,
+                                                 d_weight)
+        return None, d_rad, d_srdf, d_var.reshape(variance.shape)
+
+
+def flat_volumes(feature_volume: dict):
+    """The six sampled volumes in the order RenderPass expects."""
+    out = []
+    for st in STAGES:
+        out += [feature_volume[st]["feature_volume"], feature_volume[st]["weight_volume"]]
+    return out

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(OUT_DIR, "libufr.so")
 ARCH = "gfx950"
 
 SOURCES = ["ufr_api.hip", "prep.hip", "sampler.hip", "gather.hip", "view_transformer.hip",
-           "ray_transformer.hip", "composite.hip", "frustum.hip", "tsdf.hip", "dcn.hip"]
+           "ray_transformer.hip", "composite.hip", "view_bwd.hip", "ray_bwd.hip", "gather_bwd.hip", "frustum.hip", "tsdf.hip", "dcn.hip"]
 # -ffp-contract=on: fuse a*b+c only inside one expression.  hipcc's default (fast) also fuses across statements,
 # and did so differently in the two unrolled copies of the per-tile code of the view transformer: a point's result
 # then depended on which column tile it landed in (1 ulp), which breaks "rays are independent -> chunking and the
@@ -70,7 +70,8 @@ def build_library(force: bool = False, verbose: bool = True, extra_flags=(), var
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if jobs or not os.path.exists(lib_path):
+    stale = not os.path.exists(lib_path) or any(os.path.getmtime(o) > os.path.getmtime(lib_path) for o in objs)
+    if jobs or stale:   # an interrupted build can leave fresh objects beside an old library
         run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", lib_path])
     return lib_path
 

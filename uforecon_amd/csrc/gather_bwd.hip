@@ -1,0 +1,115 @@
+// Backward of the correlation-frustum lookup (gather.hip / UFORecon.query_depth_from_volume, code1/model.py:350-390):
+// scatter-add of d vol24 into the six sampled volumes -- the gradients through which feature_volume.cost_reg_2.* trains
+// (SURVEY.md appendix C).  The 2-D feature maps and matching features are frozen (model.py:82-83) and sample positions
+// carry no gradient, so the frustums are the only tensors the gather differentiates into.
+//
+//   out[c]   = sum_n fL_n[c] wL_n / (sum_n wL_n + 1e-8),   fL_n = cat_s trilinear(feat_s,n),  wL_n = sum_s trilinear(w_s,n)
+//   d fL_n[c] = d out[c] wL_n / (Wsum + 1e-8)
+//   d wL_n    = sum_c d out[c] (fL_n[c] - out[c]) / (Wsum + 1e-8)
+// then the adjoint of the trilinear interpolation (align_corners=True, zeros padding) spreads both over the 8 corners.
+// Thread (v, p) = view v of point p, like the forward; the per-view samples are recomputed from the channel-last copy
+// the forward used and exchanged through LDS for the cross-view sums; gradients go straight into the reference layout
+// (NV,8,D,H,W) / (NV,1,D,H,W) with float atomics (neighbouring samples of a ray share voxels; different rays rarely do).
+#include "ufr_internal.h"
+#include "volume_sample.h"
+
+namespace ufr {
+
+struct VolGrads {
+  float* feat[UFR_NUM_STAGES];
+  float* weight[UFR_NUM_STAGES];
+};
+
+__global__ void __launch_bounds__(448) gather_bwd_kernel(FrameDev f, VolGrads vg, const float* __restrict__ ray_o,
+                                                          int o_stride, const float* __restrict__ ray_d,
+                                                          const float* __restrict__ zval, const float* __restrict__ d_pv,
+                                                          int P, int SN) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [64][NV][25]
+  const int NV = f.NV;
+  const int v = threadIdx.x >> 6, p = threadIdx.x & 63;
+  const int pidx = blockIdx.x * 64 + p;
+  const bool active = pidx < P;
+  const int pc = active ? pidx : P - 1;
+  const int ray = pc / SN;
+  const float zz = zval[pc];
+  const float* o = ray_o + (size_t)ray * o_stride;
+  const float px = mul_add_unfused(zz, ray_d[3 * ray + 0], o[0]);
+  const float py = mul_add_unfused(zz, ray_d[3 * ray + 1], o[1]);
+  const float pz = mul_add_unfused(zz, ray_d[3 * ray + 2], o[2]);
+  const float* M = f.pose[v];
+  const float qx = fmaf(M[2], pz, fmaf(M[1], py, mul_rn(M[0], px))) + M[3];
+  const float qy = fmaf(M[6], pz, fmaf(M[5], py, mul_rn(M[4], px))) + M[7];
+  const float qz = fmaf(M[10], pz, fmaf(M[9], py, mul_rn(M[8], px))) + M[11];
+  const float x = qx / qz, y = qy / qz;
+  const float zn = ((qz - f.vol_near) / (f.vol_far - f.vol_near)) * 2.f - 1.f;
+
+  float fl[24], wl = 0.f;
+#pragma unroll
+  for (int s = 0; s < UFR_NUM_STAGES; ++s) {
+    float fs[8], ws;
+    sample_volume(f.vol[s] + (size_t)v * f.vD[s] * f.vH[s] * f.vW[s] * kVolCh, f.vD[s], f.vH[s], f.vW[s], x, y, zn, fs, ws);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) fl[8 * s + c] = fs[c];
+    wl = s == 0 ? ws : wl + ws;
+  }
+  float* mine = smem + (p * NV + v) * 25;
+#pragma unroll
+  for (int c = 0; c < 24; ++c) mine[c] = fl[c] * wl;
+  mine[24] = wl;
+  __syncthreads();
+  float Wsum = 0.f;
+  for (int n = 0; n < NV; ++n) Wsum += smem[(p * NV + n) * 25 + 24];
+  const float inv = 1.f / (Wsum + 1e-8f);
+  float dfl[24], dwl = 0.f;
+#pragma unroll
+  for (int c = 0; c < 24; ++c) {
+    float G = 0.f;
+    for (int n = 0; n < NV; ++n) G += smem[(p * NV + n) * 25 + c];
+    const float dout = active ? d_pv[(size_t)pidx * 40 + c] : 0.f;
+    dfl[c] = dout * wl * inv;
+    dwl = fmaf(dout, (fl[c] - G * inv) * inv, dwl);
+  }
+  if (!active) return;
+
+#pragma unroll
+  for (int s = 0; s < UFR_NUM_STAGES; ++s) {
+    const int D = f.vD[s], H = f.vH[s], W = f.vW[s];
+    const size_t plane = (size_t)D * H * W;
+    float* gf = vg.feat[s] + (size_t)v * 8 * plane;
+    float* gw = vg.weight[s] + (size_t)v * plane;
+    const float ix = unnorm3d_ac(x, W), iy = unnorm3d_ac(y, H), iz = unnorm3d_ac(zn, D);
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const float wx[2] = {(fx + 1.f) - ix, ix - fx}, wy[2] = {(fy + 1.f) - iy, iy - fy}, wz[2] = {(fz + 1.f) - iz, iz - fz};
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const float cx = fx + dx, cy = fy + dy, cz = fz + dz;
+          const bool ok = cx >= 0.f && cx <= (float)(W - 1) && cy >= 0.f && cy <= (float)(H - 1) && cz >= 0.f &&
+                          cz <= (float)(D - 1);
+          if (ok) {
+            const float wt = wx[dx] * wy[dy] * wz[dz];
+            const size_t off = ((size_t)(int)cz * H + (int)cy) * W + (int)cx;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) unsafeAtomicAdd(gf + c * plane + off, wt * dfl[8 * s + c]);
+            unsafeAtomicAdd(gw + off, wt * dwl);
+          }
+        }
+  }
+}
+
+hipError_t launch_gather_bwd(const FrameDev& f, float* const* grad_feat, float* const* grad_weight, const float* ray_o,
+                             int o_stride, const float* ray_d, const float* z, const float* d_pv, int RN, int SN,
+                             hipStream_t s) {
+  const int P = RN * SN, NV = f.NV;
+  VolGrads vg;
+  for (int i = 0; i < UFR_NUM_STAGES; ++i) { vg.feat[i] = grad_feat[i]; vg.weight[i] = grad_weight[i]; }
+  const size_t lds = sizeof(float) * 64 * NV * 25;
+  hipLaunchKernelGGL(gather_bwd_kernel, dim3((P + 63) / 64), dim3(64 * NV), lds, s, f, vg, ray_o, o_stride, ray_d, z, d_pv,
+                     P, SN);
+  return hipGetLastError();
+}
+
+}  // namespace ufr

@@ -1,0 +1,421 @@
+// Backward of the along-ray aggregation (ray_transformer.hip) and of pre_sim_mlp.
+//   RayTransformer.forward     code1/ray_transformer.py:296-307 (+ order_posenc :165-173), pre_sim_mlp :128-132, 268
+//   LoFTREncoderLayer.forward  code1/attention/transformer.py:35-58
+//   LinearAttention.forward    code1/attention/linear_attention.py:20-47
+// One workgroup per ray (persistent over rays); the SN tokens of the ray are walked in tiles of 16 in three sweeps,
+// because linear attention couples all tokens of a ray through the per-head KV state:
+//   sweep 1: K', V -> KV_h = sum_s K'_s^T V_s (+ the K' sum as column 11)                    (recompute)
+//   sweep 2: q .. DensityMLP recomputed per tile, then backwards down to d msg; d Q' needs KV; d KV_h accumulates;
+//            d x (residual, MLP and q paths) -> d_tok_a; weight gradients of everything but k, v
+//   sweep 3: k, v recomputed, d K', d V from d KV -> d k, d v -> d x contribution -> d_tok_b; dWk, dWv
+// Machinery: bwd_common.h.
+#include "bwd_common.h"
+#include "ufr_internal.h"
+
+namespace ufr {
+
+namespace rb {
+enum : int {
+  O_CAT = 0,        // 176: x = [token0 80 | order PE 8] (0..87) | m (88..175)
+  O_Q = 176, O_K = 264, O_V = 352,
+  O_MSG = 440,
+  O_XH1 = 528,
+  O_HID = 616,      // 176
+  O_XH2 = 792,
+  O_Y = 880,        // 88: layer output
+  O_D1 = 968,       // 32
+  O_D2 = 1000,      // 16
+  O_DY = 1016,      // 88
+  O_DOPRE = 1104,
+  O_DHID = 1192,    // 176
+  O_DCAT = 1368,    // 176
+  O_DMPRE = 1544,
+  O_DMSG = 1632,    // d msg, then d t = d msg * Z * SN in place
+  O_DQ = 1720, O_DK = 1808, O_DV = 1896,
+  O_DD1 = 1984,     // 32
+  O_DD2 = 2016,     // 16
+  O_RSTD1 = 2032, O_RSTD2 = 2033, O_DSRDF = 2034,
+  O_Z = 2035,       // 8 heads
+  O_DDEN = 2043,    // 8 heads
+  O_END = 2051
+};
+constexpr int kKV = 8 * 11 * 12;   // per head [d][e], e = 11: sum of K' (linear_attention.py:43)
+constexpr int kLdsBytes = (O_END * kLD + 2 * kKV) * 4;
+
+constexpr WgMat kMats2[] = {{P_RT_Q, 88, 88, O_DQ, O_CAT},        {P_RT_MERGE, 88, 88, O_DMPRE, O_MSG},
+                            {P_RT_MLP0, 176, 176, O_DHID, O_CAT}, {P_RT_MLP2, 88, 176, O_DOPRE, O_HID},
+                            {P_DM_W0, 32, 88, O_DD1, O_Y},        {P_DM_W2, 16, 32, O_DD2, O_D1}};
+constexpr WgMat kMats3[] = {{P_RT_K, 88, 88, O_DK, O_CAT}, {P_RT_V, 88, 88, O_DV, O_CAT}};
+constexpr auto kList2 = make_wglist(kMats2);
+constexpr auto kList3 = make_wglist(kMats3);
+constexpr int kSlots2 = (kList2.first[6] + kBwdWaves - 1) / kBwdWaves;   // 273 tiles -> 35
+constexpr int kSlots3 = (kList3.first[2] + kBwdWaves - 1) / kBwdWaves;   // 72 tiles -> 9
+}  // namespace rb
+
+__global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPtrs gp, const float* __restrict__ token0,
+                                                              const float* __restrict__ order_pe,
+                                                              const float* __restrict__ d_srdf, int RN, int SN,
+                                                              float* __restrict__ d_tok_a, float* __restrict__ d_tok_b,
+                                                              float* __restrict__ dbg) {
+  using namespace rb;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* KV = lds + O_END * kLD;
+  float* dKV = KV + kKV;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n_sub = SN / kTT;
+  const float fS = (float)SN;
+  constexpr WgList<6> L2 = rb::kList2;
+  constexpr WgList<2> L3 = rb::kList3;
+
+  f32x4 acc[kSlots2 + kSlots3];
+#pragma unroll
+  for (int s = 0; s < kSlots2 + kSlots3; ++s) acc[s] = splat4(0.f);
+  float accB = 0.f;
+
+  auto R = [&](int row) -> float* { return lds + row * kLD; };
+  // x tile: token-0 feature of sample (ray, s0 + col) | order PE (ray_transformer.py:301-303)
+  auto load_x = [&](int ray, int s0) {
+    for (int idx = tid; idx < kTT * 22; idx += kBwdThreads) {
+      const int col = idx / 22, f4 = idx - col * 22;
+      const f32x4 v = f4 < 20 ? ld4(token0 + ((size_t)ray * SN + s0 + col) * UFR_TOKEN_DIM + 4 * f4)
+                              : ld4(order_pe + (size_t)(s0 + col) * 8 + 4 * (f4 - 20));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) R(O_CAT + 4 * f4 + e)[col] = v[e];
+    }
+  };
+  // the 1056 = 8 x 11 x 12 per-head state entries are dealt three per thread
+  auto kv_entry = [&](int o, int& h, int& d, int& e) { h = o / 132; d = (o - h * 132) / 12; e = o % 12; };
+
+  for (int ray = blockIdx.x; ray < RN; ray += gridDim.x) {
+    // ================= sweep 1: KV state
+    float kv[3] = {0.f, 0.f, 0.f};
+    for (int sub = 0; sub < n_sub; ++sub) {
+      load_x(ray, sub * kTT);
+      __syncthreads();
+      gemm_lds<88, 88, false>(wp.p[P_RT_K], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = elu1(v); });
+      gemm_lds<88, 88, false>(wp.p[P_RT_V], 88, R(O_CAT), (wave + 2) & 7, lane, [&](int r, int c, float v) { R(O_V + r)[c] = v / fS; });
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int o = tid + i * kBwdThreads;
+        if (o < kKV) {
+          int h, d, e;
+          kv_entry(o, h, d, e);
+          const float* kr = R(O_K + 11 * h + d);
+          const float* vr = R(O_V + 11 * h + (e < 11 ? e : 0));
+          float s = 0.f;
+#pragma unroll
+          for (int t = 0; t < kTT; ++t) s = e < 11 ? fmaf(kr[t], vr[t], s) : s + kr[t];
+          kv[i] += s;
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (tid + i * kBwdThreads < kKV) KV[tid + i * kBwdThreads] = kv[i];
+    __syncthreads();
+
+    // ================= sweep 2
+    float dkv[3] = {0.f, 0.f, 0.f};
+    for (int sub = 0; sub < n_sub; ++sub) {
+      const int s0 = sub * kTT;
+      load_x(ray, s0);
+      if (tid < kTT) R(O_DSRDF)[tid] = d_srdf[(size_t)ray * SN + s0 + tid];
+      __syncthreads();
+      gemm_lds<88, 88, false>(wp.p[P_RT_Q], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_Q + r)[c] = v; });
+      __syncthreads();
+      // message of (token, head): t = Q' KV_h, den = Q'.sum K', msg = t * Z * SN (linear_attention.py:43-44)
+      if (tid < kTT * 8) {
+        const int col = tid >> 3, h = tid & 7;
+        float Qp[11], t[11], den = 0.f;
+#pragma unroll
+        for (int d = 0; d < 11; ++d) Qp[d] = elu1(R(O_Q + 11 * h + d)[col]);
+#pragma unroll
+        for (int e = 0; e < 11; ++e) t[e] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 11; ++d) {
+          const float* row = KV + (h * 11 + d) * 12;
+#pragma unroll
+          for (int e = 0; e < 11; ++e) t[e] = fmaf(Qp[d], row[e], t[e]);
+          den = fmaf(Qp[d], row[11], den);
+        }
+        const float Z = 1.f / (den + 1e-6f);
+#pragma unroll
+        for (int e = 0; e < 11; ++e) R(O_MSG + 11 * h + e)[col] = t[e] * (Z * fS);
+        R(O_Z + h)[col] = Z;
+      }
+      __syncthreads();
+      gemm_lds<88, 88, false>(wp.p[P_RT_MERGE], 88, R(O_MSG), wave, lane, [&](int r, int c, float v) { R(O_XH1 + r)[c] = v; });
+      __syncthreads();
+      ln_forward<88>(R(O_XH1), R(O_CAT + 88), nullptr, wp.p[P_RT_N1W], wp.p[P_RT_N1B], R(O_RSTD1), tid);
+      __syncthreads();
+      gemm_lds<176, 176, false>(wp.p[P_RT_MLP0], 176, R(O_CAT), wave, lane,
+                                [&](int r, int c, float v) { R(O_HID + r)[c] = fmaxf(v, 0.f); });
+      __syncthreads();
+      gemm_lds<88, 176, false>(wp.p[P_RT_MLP2], 176, R(O_HID), wave, lane, [&](int r, int c, float v) { R(O_XH2 + r)[c] = v; });
+      __syncthreads();
+      ln_forward<88>(R(O_XH2), R(O_Y), R(O_CAT), wp.p[P_RT_N2W], wp.p[P_RT_N2B], R(O_RSTD2), tid);
+      __syncthreads();
+      // DensityMLP 88 -> 32 -> 16 (-> 1) (ray_transformer.py:147-150, 307)
+      gemm_lds<32, 88, false>(wp.p[P_DM_W0], 88, R(O_Y), wave, lane,
+                              [&](int r, int c, float v) { R(O_D1 + r)[c] = fmaxf(v + wp.p[P_DM_B0][r], 0.f); });
+      __syncthreads();
+      gemm_lds<16, 32, false>(wp.p[P_DM_W2], 32, R(O_D1), wave, lane,
+                              [&](int r, int c, float v) { R(O_D2 + r)[c] = fmaxf(v + wp.p[P_DM_B2][r], 0.f); });
+      __syncthreads();
+      // ---- backwards: srdf = W4 d2 + b4
+      if (tid < 16 * kTT) {
+        const int o = tid >> 4, c = tid & 15;
+        R(O_DD2 + o)[c] = R(O_D2 + o)[c] > 0.f ? wp.p[P_DM_W4][o] * R(O_DSRDF)[c] : 0.f;
+      }
+      __syncthreads();
+      gemm_lds<32, 16, true>(wp.p[P_DM_W2], 32, R(O_DD2), wave, lane,
+                             [&](int r, int c, float v) { R(O_DD1 + r)[c] = R(O_D1 + r)[c] > 0.f ? v : 0.f; });
+      __syncthreads();
+      gemm_lds<88, 32, true>(wp.p[P_DM_W0], 88, R(O_DD1), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] = v; });
+      __syncthreads();
+      ln_backward<88>(R(O_DY), R(O_XH2), wp.p[P_RT_N2W], R(O_RSTD2), R(O_DOPRE), tid);
+      if (tid < 88) accB += row_dot(R(O_DY), R(O_XH2), tid);
+      else if (tid < 176) accB += row_dot(R(O_DY), nullptr, tid - 88);
+      __syncthreads();
+      gemm_lds<176, 88, true>(wp.p[P_RT_MLP2], 176, R(O_DOPRE), wave, lane,
+                              [&](int r, int c, float v) { R(O_DHID + r)[c] = R(O_HID + r)[c] > 0.f ? v : 0.f; });
+      __syncthreads();
+      gemm_lds<176, 176, true>(wp.p[P_RT_MLP0], 176, R(O_DHID), wave, lane, [&](int r, int c, float v) { R(O_DCAT + r)[c] = v; });
+      __syncthreads();
+      ln_backward<88>(R(O_DCAT + 88), R(O_XH1), wp.p[P_RT_N1W], R(O_RSTD1), R(O_DMPRE), tid);
+      if (tid >= 176 && tid < 264) accB += row_dot(R(O_DCAT + 88), R(O_XH1), tid - 176);
+      else if (tid >= 264 && tid < 352) accB += row_dot(R(O_DCAT + 88), nullptr, tid - 264);
+      for (int idx = tid; idx < 88 * kTT; idx += kBwdThreads) {
+        const int r = idx >> 4, c = idx & 15;
+        R(O_DY + r)[c] += R(O_DCAT + r)[c];
+      }
+      __syncthreads();
+      gemm_lds<88, 88, true>(wp.p[P_RT_MERGE], 88, R(O_DMPRE), wave, lane, [&](int r, int c, float v) { R(O_DMSG + r)[c] = v; });
+      __syncthreads();
+      // attention backwards, query side: d t = d msg Z SN; d den = -SN Z^2 (d msg . t); d Q' = KV d t + d den sum K'
+      if (tid < kTT * 8) {
+        const int col = tid >> 3, h = tid & 7;
+        float Qp[11], t[11], dt[11], dq[11];
+#pragma unroll
+        for (int d = 0; d < 11; ++d) { Qp[d] = elu1(R(O_Q + 11 * h + d)[col]); t[d] = 0.f; }
+#pragma unroll
+        for (int d = 0; d < 11; ++d) {
+          const float* row = KV + (h * 11 + d) * 12;
+#pragma unroll
+          for (int e = 0; e < 11; ++e) t[e] = fmaf(Qp[d], row[e], t[e]);
+        }
+        const float Z = R(O_Z + h)[col];
+        float dot = 0.f;
+#pragma unroll
+        for (int e = 0; e < 11; ++e) {
+          const float dm = R(O_DMSG + 11 * h + e)[col];
+          dot = fmaf(dm, t[e], dot);
+          dt[e] = dm * (Z * fS);
+        }
+        const float dden = -fS * Z * Z * dot;
+#pragma unroll
+        for (int d = 0; d < 11; ++d) {
+          const float* row = KV + (h * 11 + d) * 12;
+          float s = dden * row[11];
+#pragma unroll
+          for (int e = 0; e < 11; ++e) s = fmaf(row[e], dt[e], s);
+          dq[d] = s;
+        }
+#pragma unroll
+        for (int d = 0; d < 11; ++d) {
+          R(O_DQ + 11 * h + d)[col] = dq[d] * elu1_grad(R(O_Q + 11 * h + d)[col]);
+          R(O_DMSG + 11 * h + d)[col] = dt[d];
+        }
+        R(O_DDEN + h)[col] = dden;
+      }
+      __syncthreads();
+      // d KV_h[d][e] += sum_t Q'_t[d] d t_t[e];   d (sum K')[d] += sum_t d den_t Q'_t[d]
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int o = tid + i * kBwdThreads;
+        if (o < kKV) {
+          int h, d, e;
+          kv_entry(o, h, d, e);
+          const float* qr = R(O_Q + 11 * h + d);
+          const float* tr = e < 11 ? R(O_DMSG + 11 * h + e) : R(O_DDEN + h);
+          float s = 0.f;
+#pragma unroll
+          for (int t = 0; t < kTT; ++t) s = fmaf(elu1(qr[t]), tr[t], s);
+          dkv[i] += s;
+        }
+      }
+      gemm_lds<88, 88, true>(wp.p[P_RT_Q], 88, R(O_DQ), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
+      __syncthreads();
+      // d x of this sweep (order-PE rows carry no gradient)
+      for (int idx = tid; idx < kTT * 20; idx += kBwdThreads) {
+        const int col = idx / 20, f4 = idx - col * 20;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = R(O_DY + 4 * f4 + e)[col];
+        st4(d_tok_a + ((size_t)ray * SN + s0 + col) * UFR_TOKEN_DIM + 4 * f4, v);
+      }
+      // small gradients: DensityMLP biases and last layer
+      if (tid >= 352 && tid < 384) accB += row_dot(R(O_DD1 + (tid - 352)), nullptr, 0);
+      else if (tid >= 384 && tid < 400) accB += row_dot(R(O_DD2 + (tid - 384)), nullptr, 0);
+      else if (tid >= 400 && tid < 416) accB += row_dot(R(O_DSRDF), R(O_D2 + (tid - 400)), 0);
+      else if (tid == 416) accB += row_dot(R(O_DSRDF), nullptr, 0);
+      if (dbg) {
+        for (int idx = tid; idx < kTT * 88; idx += kBwdThreads) {
+          const int col = idx / 88, k = idx - col * 88;
+          float* row = dbg + ((size_t)ray * SN + s0 + col) * 440;
+          row[k] = R(O_DY + k)[col];
+          row[88 + k] = R(O_DOPRE + k)[col];
+          row[176 + k] = R(O_DMPRE + k)[col];
+          row[264 + k] = R(O_DQ + k)[col];
+        }
+      }
+      wgrad_all<6, kSlots2, 0>(L2, acc, lds, wave, lane);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (tid + i * kBwdThreads < kKV) dKV[tid + i * kBwdThreads] = dkv[i];
+    __syncthreads();
+
+    // ================= sweep 3: key / value side
+    for (int sub = 0; sub < n_sub; ++sub) {
+      const int s0 = sub * kTT;
+      load_x(ray, s0);
+      __syncthreads();
+      gemm_lds<88, 88, false>(wp.p[P_RT_K], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = v; });
+      gemm_lds<88, 88, false>(wp.p[P_RT_V], 88, R(O_CAT), (wave + 2) & 7, lane, [&](int r, int c, float v) { R(O_V + r)[c] = v; });
+      __syncthreads();
+      // d K'_s[d] = sum_e dKV[d][e] V_s[e] + d(sum K')[d];   d V_s[e] = sum_d K'_s[d] dKV[d][e];  V = v / SN
+      if (tid < kTT * 8) {
+        const int col = tid >> 3, h = tid & 7;
+        float Kp[11], V[11], dv[11];
+#pragma unroll
+        for (int d = 0; d < 11; ++d) {
+          Kp[d] = elu1(R(O_K + 11 * h + d)[col]);
+          V[d] = R(O_V + 11 * h + d)[col] / fS;
+          dv[d] = 0.f;
+        }
+#pragma unroll
+        for (int d = 0; d < 11; ++d) {
+          const float* row = dKV + (h * 11 + d) * 12;
+          float s = row[11];
+#pragma unroll
+          for (int e = 0; e < 11; ++e) {
+            s = fmaf(row[e], V[e], s);
+            dv[e] = fmaf(Kp[d], row[e], dv[e]);
+          }
+          R(O_DK + 11 * h + d)[col] = s * elu1_grad(R(O_K + 11 * h + d)[col]);
+        }
+#pragma unroll
+        for (int e = 0; e < 11; ++e) R(O_DV + 11 * h + e)[col] = dv[e] / fS;
+      }
+      __syncthreads();
+      gemm_lds<88, 88, true>(wp.p[P_RT_K], 88, R(O_DK), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] = v; });
+      gemm_lds<88, 88, true>(wp.p[P_RT_V], 88, R(O_DV), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
+      __syncthreads();
+      for (int idx = tid; idx < kTT * 20; idx += kBwdThreads) {
+        const int col = idx / 20, f4 = idx - col * 20;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = R(O_DY + 4 * f4 + e)[col];
+        st4(d_tok_b + ((size_t)ray * SN + s0 + col) * UFR_TOKEN_DIM + 4 * f4, v);
+      }
+      if (dbg) {
+        for (int idx = tid; idx < kTT * 88; idx += kBwdThreads) {
+          const int col = idx / 88, k = idx - col * 88;
+          float* row = dbg + ((size_t)ray * SN + s0 + col) * 440;
+          row[352 + k] = R(O_DY + k)[col];
+        }
+      }
+      wgrad_all<2, kSlots3, kSlots2>(L3, acc, lds, wave, lane);
+      __syncthreads();
+    }
+  }
+
+  wgrad_flush_all<6, kSlots2, 0>(L2, acc, gp, wave, lane);
+  wgrad_flush_all<2, kSlots3, kSlots2>(L3, acc, gp, wave, lane);
+  if (tid < 88) atomic_add_f32(gp.p[P_RT_N2W] + tid, accB);
+  else if (tid < 176) atomic_add_f32(gp.p[P_RT_N2B] + (tid - 88), accB);
+  else if (tid < 264) atomic_add_f32(gp.p[P_RT_N1W] + (tid - 176), accB);
+  else if (tid < 352) atomic_add_f32(gp.p[P_RT_N1B] + (tid - 264), accB);
+  else if (tid < 384) atomic_add_f32(gp.p[P_DM_B0] + (tid - 352), accB);
+  else if (tid < 400) atomic_add_f32(gp.p[P_DM_B2] + (tid - 384), accB);
+  else if (tid < 416) atomic_add_f32(gp.p[P_DM_W4] + (tid - 400), accB);
+  else if (tid == 416) atomic_add_f32(gp.p[P_DM_B4], accB);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pre_sim_mlp backwards (weights only: its input, the pair similarity, comes from the frozen matching features).
+// Columns = 16 points; sim8 (P,8) saved by the forward gather; d out = columns 24..39 of d_pv.
+namespace pb {
+enum : int { O_S8 = 0, O_A1 = 8, O_A2 = 40, O_DO = 72, O_DA2 = 88, O_DA1 = 120, O_END = 152 };
+constexpr WgMat kMats[] = {{P_PS_W4, 16, 32, O_DO, O_A2}, {P_PS_W2, 32, 32, O_DA2, O_A1}, {P_PS_W0, 32, 8, O_DA1, O_S8}};
+constexpr auto kList = make_wglist(kMats);   // 2 + 4 + 2 = 8 tiles: one slot per wave
+}  // namespace pb
+
+__global__ void __launch_bounds__(kBwdThreads) presim_bwd_kernel(RawPtrs wp, GradPtrs gp, const float* __restrict__ sim8,
+                                                                 const float* __restrict__ d_pv, int P) {
+  using namespace pb;
+  __shared__ float lds[O_END * kLD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  constexpr WgList<3> LL = pb::kList;
+  f32x4 acc[1] = {splat4(0.f)};
+  float accB = 0.f;
+  auto R = [&](int row) -> float* { return lds + row * kLD; };
+  const int n_tiles = (P + kTT - 1) / kTT;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int p0 = tile * kTT;
+    if (tid < kTT * 8) {
+      const int c = tid >> 3, i = tid & 7, p = p0 + c;
+      R(O_S8 + i)[c] = p < P ? sim8[(size_t)p * 8 + i] : 0.f;
+    } else if (tid < kTT * 24) {
+      const int c = (tid - kTT * 8) >> 4, i = (tid - kTT * 8) & 15, p = p0 + c;
+      R(O_DO + i)[c] = p < P ? d_pv[(size_t)p * 40 + 24 + i] : 0.f;
+    }
+    __syncthreads();
+    gemm_lds<32, 8, false>(wp.p[P_PS_W0], 8, R(O_S8), wave, lane,
+                           [&](int r, int c, float v) { R(O_A1 + r)[c] = fmaxf(v + wp.p[P_PS_B0][r], 0.f); });
+    __syncthreads();
+    gemm_lds<32, 32, false>(wp.p[P_PS_W2], 32, R(O_A1), wave, lane,
+                            [&](int r, int c, float v) { R(O_A2 + r)[c] = fmaxf(v + wp.p[P_PS_B2][r], 0.f); });
+    __syncthreads();
+    gemm_lds<32, 16, true>(wp.p[P_PS_W4], 32, R(O_DO), wave, lane,
+                           [&](int r, int c, float v) { R(O_DA2 + r)[c] = R(O_A2 + r)[c] > 0.f ? v : 0.f; });
+    __syncthreads();
+    gemm_lds<32, 32, true>(wp.p[P_PS_W2], 32, R(O_DA2), wave, lane,
+                           [&](int r, int c, float v) { R(O_DA1 + r)[c] = R(O_A1 + r)[c] > 0.f ? v : 0.f; });
+    __syncthreads();
+    if (tid < 16) accB += row_dot(R(O_DO + tid), nullptr, 0);
+    else if (tid < 48) accB += row_dot(R(O_DA2 + (tid - 16)), nullptr, 0);
+    else if (tid < 80) accB += row_dot(R(O_DA1 + (tid - 48)), nullptr, 0);
+    wgrad_all<3, 1, 0>(LL, acc, lds, wave, lane);
+    __syncthreads();
+  }
+  wgrad_flush_all<3, 1, 0>(LL, acc, gp, wave, lane);
+  if (tid < 16) atomic_add_f32(gp.p[P_PS_B4] + tid, accB);
+  else if (tid < 48) atomic_add_f32(gp.p[P_PS_B2] + (tid - 16), accB);
+  else if (tid < 80) atomic_add_f32(gp.p[P_PS_B0] + (tid - 48), accB);
+}
+
+hipError_t launch_ray_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* token0, const float* order_pe,
+                          const float* d_srdf, int RN, int SN, float* d_tok_a, float* d_tok_b, float* dbg, hipStream_t s) {
+  if (SN % kTT != 0 || SN < kTT) return hipErrorInvalidValue;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ray_bwd_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, rb::kLdsBytes);
+  if (attr != hipSuccess) return attr;
+  const int blocks = RN < 256 ? RN : 256;
+  hipLaunchKernelGGL(ray_bwd_kernel, dim3(blocks), dim3(kBwdThreads), rb::kLdsBytes, s, wp, gp, token0, order_pe, d_srdf,
+                     RN, SN, d_tok_a, d_tok_b, dbg);
+  return hipGetLastError();
+}
+
+hipError_t launch_presim_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* sim8, const float* d_pv, int P,
+                             hipStream_t s) {
+  const int n_tiles = (P + kTT - 1) / kTT;
+  hipLaunchKernelGGL(presim_bwd_kernel, dim3(n_tiles < 256 ? n_tiles : 256), dim3(kBwdThreads), 0, s, wp, gp, sim8, d_pv, P);
+  return hipGetLastError();
+}
+
+}  // namespace ufr

@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 
+#include "bwd_common.h"
 #include "ufr_internal.h"
 #include "ufr_layout_bf.h"
 
@@ -288,6 +289,92 @@ int ufr_composite(const float* z, const float* radiance, const float* srdf, cons
   UFR_REQUIRE(RN > 0 && SN >= 2 && SN <= 256, "ufr_composite: SN=%d out of range [2,256]", SN);
   UFR_HIP(launch_composite(z, radiance, nullptr, srdf, variance, RN, SN, rgb, depth, opacity, weight, nullptr, nullptr,
                            static_cast<hipStream_t>(stream)));
+  return UFR_OK;
+}
+
+// ------------------------------------------------------------------ backward
+static int raw_and_grads(const ufr_raw_weights* raw, const ufr_raw_grads* grads, RawPtrs& rp, GradPtrs& gp, const char* who) {
+  static_assert(sizeof(ufr_raw_grads) == sizeof(GradPtrs) && UFR_NUM_PARAMS == P_COUNT, "ufr_raw_grads layout");
+  UFR_REQUIRE(raw && grads, "%s: null weights / grads", who);
+  memcpy(&rp, raw, sizeof(rp));
+  memcpy(&gp, grads, sizeof(gp));
+  for (int i = 0; i < P_COUNT; ++i) UFR_REQUIRE(rp.p[i] && gp.p[i], "%s: parameter %d has a null pointer", who, i);
+  return UFR_OK;
+}
+
+int ufr_composite_bwd(const float* z, const float* radiance, const float* srdf, const float* variance, int32_t RN,
+                      int32_t SN, const float* d_rgb, const float* d_depth, const float* d_opacity, const float* d_weight,
+                      float* d_radiance, float* d_srdf, float* d_variance, ufr_stream stream) {
+  UFR_REQUIRE(z && radiance && srdf && variance && d_radiance && d_srdf && d_variance, "ufr_composite_bwd: null argument");
+  UFR_REQUIRE(RN > 0 && SN >= 2 && SN <= 256, "ufr_composite_bwd: SN=%d out of range [2,256]", SN);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ProfScope p("composite_bwd", s);
+  UFR_HIP(launch_composite_bwd(z, radiance, srdf, variance, RN, SN, d_rgb, d_depth, d_opacity, d_weight, d_radiance, d_srdf,
+                               d_variance, s));
+  return UFR_OK;
+}
+
+size_t ufr_aggregate_bwd_workspace_bytes(int32_t RN, int32_t SN, int32_t NV) {
+  (void)NV;
+  Carver c(nullptr);
+  c.f32((size_t)RN * SN * UFR_TOKEN_DIM);
+  c.f32((size_t)RN * SN * UFR_TOKEN_DIM);
+  c.f32((size_t)SN * 8);
+  return c.off;
+}
+
+int ufr_aggregate_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const float* x_tokens, const float* rgb,
+                      const float* dir, const float* token0, int32_t RN, int32_t SN, int32_t NV, const float* d_radiance,
+                      const float* d_srdf, float* d_pv, void* workspace, float* debug_view, float* debug_ray,
+                      ufr_stream stream) {
+  RawPtrs rp;
+  GradPtrs gp;
+  int rc = raw_and_grads(raw, grads, rp, gp, "ufr_aggregate_bwd");
+  if (rc != UFR_OK) return rc;
+  UFR_REQUIRE(x_tokens && rgb && dir && token0 && d_radiance && d_srdf && d_pv && workspace, "ufr_aggregate_bwd: null argument");
+  UFR_REQUIRE(NV >= 2 && NV <= UFR_MAX_VIEWS, "ufr_aggregate_bwd: NV=%d unsupported", NV);
+  UFR_REQUIRE(RN > 0 && SN >= 16 && SN % 16 == 0 && SN <= 256, "ufr_aggregate_bwd: SN=%d must be a multiple of 16 in [16,256]", SN);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Carver c(workspace);
+  float* d_tok_a = c.f32((size_t)RN * SN * UFR_TOKEN_DIM);
+  float* d_tok_b = c.f32((size_t)RN * SN * UFR_TOKEN_DIM);
+  float* order_pe = c.f32((size_t)SN * 8);
+  UFR_HIP(launch_order_pe(order_pe, SN, s));
+  {
+    ProfScope p("ray_bwd", s);
+    UFR_HIP(launch_ray_bwd(rp, gp, token0, order_pe, d_srdf, RN, SN, d_tok_a, d_tok_b, debug_ray, s));
+  }
+  {
+    ProfScope p("view_bwd", s);
+    UFR_HIP(launch_view_bwd(rp, gp, x_tokens, rgb, dir, d_tok_a, d_tok_b, d_radiance, RN * SN, NV, d_pv, debug_view, s));
+  }
+  return UFR_OK;
+}
+
+int ufr_project_gather_bwd(const ufr_frame* frame, const ufr_raw_weights* raw, const ufr_raw_grads* grads,
+                           const float* ray_o, int32_t ray_o_stride, const float* ray_d, const float* z, int32_t RN,
+                           int32_t SN, const float* sim8, const float* d_pv, float* const* grad_vol_feat,
+                           float* const* grad_vol_weight, ufr_stream stream) {
+  const FrameDev* f = frame_of(frame);
+  UFR_REQUIRE(f, "ufr_project_gather_bwd: frame handle not prepared");
+  RawPtrs rp;
+  GradPtrs gp;
+  int rc = raw_and_grads(raw, grads, rp, gp, "ufr_project_gather_bwd");
+  if (rc != UFR_OK) return rc;
+  UFR_REQUIRE(ray_o && ray_d && z && sim8 && d_pv && grad_vol_feat && grad_vol_weight, "ufr_project_gather_bwd: null argument");
+  UFR_REQUIRE(ray_o_stride == 0 || ray_o_stride == 3, "ufr_project_gather_bwd: ray_o_stride must be 0 or 3");
+  UFR_REQUIRE(RN > 0 && SN > 0, "ufr_project_gather_bwd: RN=%d SN=%d", RN, SN);
+  for (int i = 0; i < UFR_NUM_STAGES; ++i)
+    UFR_REQUIRE(grad_vol_feat[i] && grad_vol_weight[i], "ufr_project_gather_bwd: null volume gradient (stage %d)", i + 1);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  {
+    ProfScope p("gather_bwd", s);
+    UFR_HIP(launch_gather_bwd(*f, grad_vol_feat, grad_vol_weight, ray_o, ray_o_stride, ray_d, z, d_pv, RN, SN, s));
+  }
+  {
+    ProfScope p("presim_bwd", s);
+    UFR_HIP(launch_presim_bwd(rp, gp, sim8, d_pv, RN * SN, s));
+  }
   return UFR_OK;
 }
 

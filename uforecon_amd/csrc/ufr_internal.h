@@ -57,6 +57,20 @@ hipError_t launch_ray_transformer(const float* packed, const float* token0, cons
 hipError_t launch_composite(const float* z, const float* radiance, const int* rad_row, const float* srdf,
                             const float* variance, int RN, int SN, float* rgb, float* depth, float* opacity, float* weight,
                             const float* camz, float* depth_z, hipStream_t s);
+hipError_t launch_composite_bwd(const float* z, const float* radiance, const float* srdf, const float* variance, int RN,
+                                int SN, const float* d_rgb, const float* d_depth, const float* d_opacity,
+                                const float* d_weight, float* d_radiance, float* d_srdf, float* d_variance, hipStream_t s);
+struct GradPtrs;
+hipError_t launch_view_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* x_tokens, const float* rgbm,
+                           const float* dirs, const float* d_tok_a, const float* d_tok_b, const float* d_radiance, int P,
+                           int NV, float* d_pv, float* dbg, hipStream_t s);
+hipError_t launch_ray_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* token0, const float* order_pe,
+                          const float* d_srdf, int RN, int SN, float* d_tok_a, float* d_tok_b, float* dbg, hipStream_t s);
+hipError_t launch_presim_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* sim8, const float* d_pv, int P,
+                             hipStream_t s);
+hipError_t launch_gather_bwd(const FrameDev& f, float* const* grad_feat, float* const* grad_weight, const float* ray_o,
+                             int o_stride, const float* ray_d, const float* z, const float* d_pv, int RN, int SN,
+                             hipStream_t s);
 hipError_t launch_pack_weights(const RawPtrs& raw, float* packed, hipStream_t s);
 hipError_t launch_tsdf_integrate(float* tsdf, float* weight, float* color, const int* dim, const float* origin,
                                  float voxel_size, float trunc_margin, const float* K, const float* P,

@@ -1,0 +1,402 @@
+// Backward of the cross-view aggregation (view_transformer.hip): recomputes the layer for a tile of 16 token
+// columns (PPT = 16/L points x L = NV+1 tokens) from the saved token inputs, then walks it backwards.
+//   RayTransformer.forward      code1/ray_transformer.py:283-294, 309-320   (autograd of these lines)
+//   LoFTREncoderLayer.forward   code1/attention/transformer.py:35-58
+//   LinearAttention.forward     code1/attention/linear_attention.py:20-47
+// Inputs of the backward: d token0 (two partial buffers from ray_bwd.hip) and d radiance (compositor).
+// Outputs: gradients of every view-transformer / radiance-MLP parameter and of the view token (float atomics into the
+// reference-layout gradient tensors, once per workgroup), and d_pv (P,40) = the gradient w.r.t. the 24 frustum
+// features and the 16 pre_sim_mlp outputs of each point, summed over its NV view tokens (gather_bwd.hip consumes it).
+// Machinery: bwd_common.h (LDS-resident fp32 tile, fp32 MFMA, register-resident weight-gradient tiles).
+#include "bwd_common.h"
+#include "ufr_internal.h"
+
+namespace ufr {
+
+namespace vb {
+// LDS rows (each kLD floats)
+enum : int {
+  O_CAT = 0,        // 160: x (0..79) | m = LN1(merge(msg)) (80..159)        transformer.py:55
+  O_Q = 160, O_K = 240, O_V = 320,
+  O_MSG = 400,
+  O_XH1 = 480,      // merge output -> normalised (xhat of LN1)
+  O_HID = 560,      // 160, post-ReLU
+  O_XH2 = 720,      // mlp output -> xhat of LN2
+  O_RIN = 800,      // 83 (+1 pad): layer output y (0..79) | dir (80..82)     ray_transformer.py:311-313
+  O_H1 = 884,       // 16
+  O_H2 = 900,       // 8
+  O_DY = 908,       // 80: d y, later the d x accumulator
+  O_DOPRE = 988,    // 80
+  O_DHID = 1068,    // 160
+  O_DCAT = 1228,    // 160
+  O_DMPRE = 1388,   // 80
+  O_DMSG = 1468,    // 80
+  O_DQ = 1548, O_DK = 1628, O_DV = 1708,
+  O_DH1 = 1788,     // 16
+  O_DH2 = 1804,     // 8
+  O_RSTD1 = 1812, O_RSTD2 = 1813, O_DLOGIT = 1814,
+  O_U = 1815,       // 8 heads: L / (Q'.sum K' + eps) of (token, head)
+  O_DDEN = 1823,    // 8 heads
+  O_END = 1831
+};
+constexpr int kLdsBytes = O_END * kLD * 4;
+
+constexpr WgMat kMats[] = {
+    {P_VT_Q, 80, 80, O_DQ, O_CAT},       {P_VT_K, 80, 80, O_DK, O_CAT},        {P_VT_V, 80, 80, O_DV, O_CAT},
+    {P_VT_MERGE, 80, 80, O_DMPRE, O_MSG}, {P_VT_MLP0, 160, 160, O_DHID, O_CAT}, {P_VT_MLP2, 80, 160, O_DOPRE, O_HID},
+    {P_RW_W0, 16, 83, O_DH1, O_RIN}};
+constexpr auto kList = make_wglist(kMats);
+constexpr int kSlots = (kList.first[7] + kBwdWaves - 1) / kBwdWaves;   // 256 tiles -> 32 slots
+constexpr int kDbgCols = 881;
+}  // namespace vb
+
+__global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradPtrs gp, const float* __restrict__ x_tokens,
+                                                               const float* __restrict__ rgbm,
+                                                               const float* __restrict__ dirs,
+                                                               const float* __restrict__ d_tok_a,
+                                                               const float* __restrict__ d_tok_b,
+                                                               const float* __restrict__ d_radiance, int P, int NV,
+                                                               float* __restrict__ d_pv, float* __restrict__ dbg) {
+  using namespace vb;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int L = NV + 1, PPT = kTT / L;
+  const int n_tiles = (P + PPT - 1) / PPT;
+  const float invL = 1.f / (float)L;
+  constexpr WgList<7> kList = vb::kList;   // kernel-local copy: indexed at run time
+
+  f32x4 acc[kSlots];
+#pragma unroll
+  for (int s = 0; s < kSlots; ++s) acc[s] = splat4(0.f);
+  float accA = 0.f, accB = 0.f, accC = 0.f;   // small gradients, one scalar per thread (see the flush at the end)
+
+  auto R = [&](int row) -> float* { return lds + row * kLD; };
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int p0 = tile * PPT;
+    // ---------------- P0: token inputs (ray_transformer.py:284-286), dir, staged d token0
+    for (int idx = tid; idx < kTT * 20; idx += kBwdThreads) {
+      const int col = idx / 20, f4 = idx - col * 20;
+      const int pt = col / L, tv = col - pt * L, p = p0 + pt;
+      const bool ok = pt < PPT && p < P;
+      f32x4 v = splat4(0.f), d = splat4(0.f);
+      if (ok) {
+        if (tv == 0) {
+          v = ld4(wp.p[P_VIEW_TOKEN] + 4 * f4);
+          d = ld4(d_tok_a + (size_t)p * UFR_TOKEN_DIM + 4 * f4);
+          if (d_tok_b) d += ld4(d_tok_b + (size_t)p * UFR_TOKEN_DIM + 4 * f4);
+        } else {
+          v = ld4(x_tokens + ((size_t)p * NV + tv - 1) * UFR_TOKEN_DIM + 4 * f4);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        R(O_CAT + 4 * f4 + e)[col] = v[e];
+        R(O_DY + 4 * f4 + e)[col] = d[e];
+      }
+    }
+    if (tid < kTT) {
+      const int col = tid, pt = col / L, tv = col - pt * L, p = p0 + pt;
+      const bool ok = pt < PPT && p < P && tv > 0;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) R(O_RIN + 80 + e)[col] = ok ? dirs[((size_t)p * NV + tv - 1) * 4 + e] : 0.f;
+    }
+    __syncthreads();
+
+    // ---------------- P1: q, k, v (15 row tiles dealt over the 8 waves)
+    gemm_lds<80, 80, false>(wp.p[P_VT_Q], 80, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_Q + r)[c] = v; });
+    gemm_lds<80, 80, false>(wp.p[P_VT_K], 80, R(O_CAT), (wave + 3) & 7, lane, [&](int r, int c, float v) { R(O_K + r)[c] = v; });
+    gemm_lds<80, 80, false>(wp.p[P_VT_V], 80, R(O_CAT), (wave + 6) & 7, lane, [&](int r, int c, float v) { R(O_V + r)[c] = v; });
+    __syncthreads();
+
+    // ---------------- P2: linear attention over the L tokens of each point (linear_attention.py:31-45) in score form:
+    // A[s'] = Q'.K'_s', msg = u * sum_s' A[s'] V_s'  with V = v/L and u = L / (sum_s' A[s'] + eps)
+    if (tid < kTT * 8) {
+      const int col = tid >> 3, h = tid & 7, pt = col / L;
+      float msg[10];
+#pragma unroll
+      for (int e = 0; e < 10; ++e) msg[e] = 0.f;
+      float u = 0.f;
+      if (pt < PPT) {
+        float Qp[10], den = 0.f;
+#pragma unroll
+        for (int d = 0; d < 10; ++d) Qp[d] = elu1(R(O_Q + 10 * h + d)[col]);
+        for (int s = 0; s < L; ++s) {
+          const int c2 = pt * L + s;
+          float a = 0.f;
+#pragma unroll
+          for (int d = 0; d < 10; ++d) a = fmaf(Qp[d], elu1(R(O_K + 10 * h + d)[c2]), a);
+          den += a;
+#pragma unroll
+          for (int e = 0; e < 10; ++e) msg[e] = fmaf(a, R(O_V + 10 * h + e)[c2] * invL, msg[e]);
+        }
+        u = (float)L / (den + 1e-6f);
+      }
+#pragma unroll
+      for (int e = 0; e < 10; ++e) R(O_MSG + 10 * h + e)[col] = msg[e] * u;
+      R(O_U + h)[col] = u;
+    }
+    __syncthreads();
+
+    // ---------------- P3/P4: merge + LayerNorm1 (transformer.py:51-52)
+    gemm_lds<80, 80, false>(wp.p[P_VT_MERGE], 80, R(O_MSG), wave, lane, [&](int r, int c, float v) { R(O_XH1 + r)[c] = v; });
+    __syncthreads();
+    ln_forward<80>(R(O_XH1), R(O_CAT + 80), nullptr, wp.p[P_VT_N1W], wp.p[P_VT_N1B], R(O_RSTD1), tid);
+    __syncthreads();
+    // ---------------- P5-P7: MLP on [x | m], LayerNorm2, residual (transformer.py:55-58)
+    gemm_lds<160, 160, false>(wp.p[P_VT_MLP0], 160, R(O_CAT), wave, lane,
+                              [&](int r, int c, float v) { R(O_HID + r)[c] = fmaxf(v, 0.f); });
+    __syncthreads();
+    gemm_lds<80, 160, false>(wp.p[P_VT_MLP2], 160, R(O_HID), wave, lane, [&](int r, int c, float v) { R(O_XH2 + r)[c] = v; });
+    __syncthreads();
+    ln_forward<80>(R(O_XH2), R(O_RIN), R(O_CAT), wp.p[P_VT_N2W], wp.p[P_VT_N2B], R(O_RSTD2), tid);
+    __syncthreads();
+    // ---------------- P8-P10: radiance-weight MLP 83 -> 16 -> 8 -> 1 (ray_transformer.py:159-163, 313-314)
+    gemm_lds<16, 83, false>(wp.p[P_RW_W0], 83, R(O_RIN), wave, lane,
+                            [&](int r, int c, float v) { R(O_H1 + r)[c] = fmaxf(v + wp.p[P_RW_B0][r], 0.f); });
+    __syncthreads();
+    if (tid < 8 * kTT) {
+      const int o = tid >> 4, c = tid & 15;
+      float s = wp.p[P_RW_B2][o];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s = fmaf(wp.p[P_RW_W2][o * 16 + i], R(O_H1 + i)[c], s);
+      R(O_H2 + o)[c] = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+    // masked softmax over the views of a point and its adjoint (ray_transformer.py:315-319): one thread per point
+    if (tid < kTT) R(O_DLOGIT)[tid] = 0.f;
+    __syncthreads();
+    if (tid < PPT && p0 + tid < P) {
+      const int pt = tid, p = p0 + pt;
+      float lg[UFR_MAX_VIEWS], cr[UFR_MAX_VIEWS], cg[UFR_MAX_VIEWS], cb[UFR_MAX_VIEWS], mk[UFR_MAX_VIEWS];
+      float mx = -INFINITY;
+      for (int v = 0; v < NV; ++v) {
+        const int c = pt * L + 1 + v;
+        float s = wp.p[P_RW_B4][0];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s = fmaf(wp.p[P_RW_W4][i], R(O_H2 + i)[c], s);
+        const f32x4 col = ld4(rgbm + ((size_t)p * NV + v) * 4);
+        cr[v] = col[0]; cg[v] = col[1]; cb[v] = col[2]; mk[v] = col[3];
+        lg[v] = col[3] == 0.f ? -1e9f : s;
+        mx = fmaxf(mx, lg[v]);
+      }
+      float den = 0.f, rr = 0.f, rg = 0.f, rb = 0.f;
+      for (int v = 0; v < NV; ++v) {
+        lg[v] = expf(lg[v] - mx);
+        den += lg[v];
+      }
+      for (int v = 0; v < NV; ++v) {
+        lg[v] /= den;
+        rr = fmaf(lg[v], cr[v], rr); rg = fmaf(lg[v], cg[v], rg); rb = fmaf(lg[v], cb[v], rb);
+      }
+      const float dr = d_radiance[(size_t)p * 3 + 0], dg = d_radiance[(size_t)p * 3 + 1], db = d_radiance[(size_t)p * 3 + 2];
+      const float dot_r = rr * dr + rg * dg + rb * db;
+      for (int v = 0; v < NV; ++v) {
+        const float dl = lg[v] * ((cr[v] * dr + cg[v] * dg + cb[v] * db) - dot_r);
+        R(O_DLOGIT)[pt * L + 1 + v] = mk[v] == 0.f ? 0.f : dl;     // torch.where: masked logits are constants
+      }
+    }
+    __syncthreads();
+    // ---------------- B1: radiance MLP backwards
+    if (tid < 8 * kTT) {
+      const int o = tid >> 4, c = tid & 15;
+      R(O_DH2 + o)[c] = R(O_H2 + o)[c] > 0.f ? wp.p[P_RW_W4][o] * R(O_DLOGIT)[c] : 0.f;
+    }
+    __syncthreads();
+    if (tid < 16 * kTT) {
+      const int i = tid >> 4, c = tid & 15;
+      float s = 0.f;
+#pragma unroll
+      for (int o = 0; o < 8; ++o) s = fmaf(wp.p[P_RW_W2][o * 16 + i], R(O_DH2 + o)[c], s);
+      R(O_DH1 + i)[c] = R(O_H1 + i)[c] > 0.f ? s : 0.f;
+    }
+    __syncthreads();
+    // ---------------- B2: d y = W0^T d h1 (the 80 feature columns) + d token0 (staged in P0)
+    gemm_lds<80, 16, true>(wp.p[P_RW_W0], 83, R(O_DH1), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
+    __syncthreads();
+    // ---------------- B3: LayerNorm2 backwards; y = x + LN2(.) so d x starts as d y
+    ln_backward<80>(R(O_DY), R(O_XH2), wp.p[P_VT_N2W], R(O_RSTD2), R(O_DOPRE), tid);
+    if (tid >= 192 && tid < 272) accB += row_dot(R(O_DY), R(O_XH2), tid - 192);
+    if (tid >= 272 && tid < 352) accB += row_dot(R(O_DY), nullptr, tid - 272);
+    __syncthreads();
+    // ---------------- B4/B5: MLP backwards
+    gemm_lds<160, 80, true>(wp.p[P_VT_MLP2], 160, R(O_DOPRE), wave, lane,
+                            [&](int r, int c, float v) { R(O_DHID + r)[c] = R(O_HID + r)[c] > 0.f ? v : 0.f; });
+    __syncthreads();
+    gemm_lds<160, 160, true>(wp.p[P_VT_MLP0], 160, R(O_DHID), wave, lane, [&](int r, int c, float v) { R(O_DCAT + r)[c] = v; });
+    __syncthreads();
+    // ---------------- B6: LayerNorm1 backwards on the message half; the x half joins the d x accumulator
+    ln_backward<80>(R(O_DCAT + 80), R(O_XH1), wp.p[P_VT_N1W], R(O_RSTD1), R(O_DMPRE), tid);
+    if (tid >= 352 && tid < 432) accB += row_dot(R(O_DCAT + 80), R(O_XH1), tid - 352);
+    if (tid >= 432 && tid < 512) accB += row_dot(R(O_DCAT + 80), nullptr, tid - 432);
+    for (int idx = tid; idx < 80 * kTT; idx += kBwdThreads) {
+      const int r = idx >> 4, c = idx & 15;
+      R(O_DY + r)[c] += R(O_DCAT + r)[c];
+    }
+    __syncthreads();
+    // ---------------- B7: merge backwards
+    gemm_lds<80, 80, true>(wp.p[P_VT_MERGE], 80, R(O_DMPRE), wave, lane, [&](int r, int c, float v) { R(O_DMSG + r)[c] = v; });
+    __syncthreads();
+    // ---------------- B8: attention backwards, query side (thread = (token s, head)):
+    //   msg = u r, r = sum_s' A[s'] V_s';  d r = u d msg;  d u = d msg . r;  d den = -d u u^2 / L;
+    //   d A[s'] = d r . V_s' + d den;  d Q' = sum_s' d A[s'] K'_s'
+    if (tid < kTT * 8) {
+      const int col = tid >> 3, h = tid & 7, pt = col / L;
+      float dq[10];
+#pragma unroll
+      for (int d = 0; d < 10; ++d) dq[d] = 0.f;
+      float dden = 0.f;
+      if (pt < PPT) {
+        float Qp[10], dm[10], r[10];
+#pragma unroll
+        for (int d = 0; d < 10; ++d) {
+          Qp[d] = elu1(R(O_Q + 10 * h + d)[col]);
+          dm[d] = R(O_DMSG + 10 * h + d)[col];
+          r[d] = 0.f;
+        }
+        for (int s = 0; s < L; ++s) {
+          const int c2 = pt * L + s;
+          float a = 0.f;
+#pragma unroll
+          for (int d = 0; d < 10; ++d) a = fmaf(Qp[d], elu1(R(O_K + 10 * h + d)[c2]), a);
+#pragma unroll
+          for (int e = 0; e < 10; ++e) r[e] = fmaf(a, R(O_V + 10 * h + e)[c2] * invL, r[e]);
+        }
+        const float u = R(O_U + h)[col];
+        float du = 0.f;
+#pragma unroll
+        for (int e = 0; e < 10; ++e) du = fmaf(dm[e], r[e], du);
+        dden = -du * u * u * invL;
+        for (int s = 0; s < L; ++s) {
+          const int c2 = pt * L + s;
+          float dA = dden;
+#pragma unroll
+          for (int e = 0; e < 10; ++e) dA = fmaf(u * dm[e], R(O_V + 10 * h + e)[c2] * invL, dA);
+#pragma unroll
+          for (int d = 0; d < 10; ++d) dq[d] = fmaf(dA, elu1(R(O_K + 10 * h + d)[c2]), dq[d]);
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < 10; ++d) R(O_DQ + 10 * h + d)[col] = dq[d] * elu1_grad(R(O_Q + 10 * h + d)[col]);
+      R(O_DDEN + h)[col] = dden;
+    }
+    __syncthreads();
+    // ---------------- B9: key / value side (thread = (token s', head)): d K'_s' = sum_s d A[s][s'] Q'_s,
+    //   d V_s' = sum_s A[s][s'] d r_s
+    if (tid < kTT * 8) {
+      const int col = tid >> 3, h = tid & 7, pt = col / L;
+      float dk[10], dv[10];
+#pragma unroll
+      for (int d = 0; d < 10; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+      if (pt < PPT) {
+        float Kp[10], V[10];
+#pragma unroll
+        for (int d = 0; d < 10; ++d) {
+          Kp[d] = elu1(R(O_K + 10 * h + d)[col]);
+          V[d] = R(O_V + 10 * h + d)[col] * invL;
+        }
+        for (int s = 0; s < L; ++s) {
+          const int c2 = pt * L + s;
+          const float u = R(O_U + h)[c2];
+          float a = 0.f, dA = R(O_DDEN + h)[c2];
+          float Qs[10], dr[10];
+#pragma unroll
+          for (int d = 0; d < 10; ++d) {
+            Qs[d] = elu1(R(O_Q + 10 * h + d)[c2]);
+            dr[d] = u * R(O_DMSG + 10 * h + d)[c2];
+            a = fmaf(Qs[d], Kp[d], a);
+            dA = fmaf(dr[d], V[d], dA);
+          }
+#pragma unroll
+          for (int d = 0; d < 10; ++d) {
+            dk[d] = fmaf(dA, Qs[d], dk[d]);
+            dv[d] = fmaf(a, dr[d], dv[d]);
+          }
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < 10; ++d) {
+        R(O_DK + 10 * h + d)[col] = dk[d] * elu1_grad(R(O_K + 10 * h + d)[col]);
+        R(O_DV + 10 * h + d)[col] = dv[d] * invL;
+      }
+    }
+    __syncthreads();
+    // ---------------- B10: projections backwards into the d x accumulator (same lane owns an element in all three)
+    gemm_lds<80, 80, true>(wp.p[P_VT_Q], 80, R(O_DQ), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
+    gemm_lds<80, 80, true>(wp.p[P_VT_K], 80, R(O_DK), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
+    gemm_lds<80, 80, true>(wp.p[P_VT_V], 80, R(O_DV), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
+    __syncthreads();
+    // ---------------- B11: outputs.  Token columns 32..55 (frustum features) and 56..71 (pre_sim_mlp) are the same for
+    // all NV view tokens of a point (ray_transformer.py:258-281): their gradients add up.  Token 0 is the view token.
+    for (int idx = tid; idx < PPT * 40; idx += kBwdThreads) {
+      const int pt = idx / 40, c = idx - pt * 40, p = p0 + pt;
+      if (p < P) {
+        float s = 0.f;
+        for (int tv = 1; tv < L; ++tv) s += R(O_DY + 32 + c)[pt * L + tv];
+        d_pv[(size_t)p * 40 + c] = s;
+      }
+    }
+    if (tid < 80) {
+      for (int pt = 0; pt < PPT; ++pt)
+        if (p0 + pt < P) accC += R(O_DY + tid)[pt * L];
+    }
+    // small gradients on the VALU: W2 (8x16), W4 (8), biases
+    if (tid < 128) accA += row_dot(R(O_DH2 + (tid >> 4)), R(O_H1 + (tid & 15)), 0);
+    if (tid >= 128 && tid < 136) accB += row_dot(R(O_DLOGIT), R(O_H2 + (tid - 128)), 0);
+    if (tid >= 136 && tid < 152) accB += row_dot(R(O_DH1 + (tid - 136)), nullptr, 0);
+    if (tid >= 152 && tid < 160) accB += row_dot(R(O_DH2 + (tid - 152)), nullptr, 0);
+    if (tid == 160) accB += row_dot(R(O_DLOGIT), nullptr, 0);
+    if (dbg) {
+      for (int idx = tid; idx < kTT * kDbgCols; idx += kBwdThreads) {
+        const int col = idx / kDbgCols, k = idx - col * kDbgCols;
+        const int pt = col / L, tv = col - pt * L, p = p0 + pt;
+        if (pt < PPT && p < P) {
+          int row;
+          if (k < 80) row = O_DY + k;
+          else if (k < 160) row = O_DOPRE + (k - 80);
+          else if (k < 320) row = O_DHID + (k - 160);
+          else if (k < 480) row = O_DCAT + (k - 320);
+          else if (k < 560) row = O_DMPRE + (k - 480);
+          else if (k < 640) row = O_DMSG + (k - 560);
+          else if (k < 720) row = O_DQ + (k - 640);
+          else if (k < 800) row = O_DK + (k - 720);
+          else if (k < 880) row = O_DV + (k - 800);
+          else row = O_DLOGIT;
+          dbg[((size_t)p * L + tv) * kDbgCols + k] = R(row)[col];
+        }
+      }
+    }
+    // ---------------- B12: weight gradients of the seven matrices on the MFMA, register-resident tiles
+    wgrad_all<7, kSlots, 0>(kList, acc, lds, wave, lane);
+    __syncthreads();
+  }
+
+  // ---------------- flush (once per workgroup)
+  wgrad_flush_all<7, kSlots, 0>(kList, acc, gp, wave, lane);
+  if (tid < 128) atomic_add_f32(gp.p[P_RW_W2] + tid, accA);
+  if (tid < 80) atomic_add_f32(gp.p[P_VIEW_TOKEN] + tid, accC);
+  if (tid >= 128 && tid < 136) atomic_add_f32(gp.p[P_RW_W4] + (tid - 128), accB);
+  if (tid >= 136 && tid < 152) atomic_add_f32(gp.p[P_RW_B0] + (tid - 136), accB);
+  if (tid >= 152 && tid < 160) atomic_add_f32(gp.p[P_RW_B2] + (tid - 152), accB);
+  if (tid == 160) atomic_add_f32(gp.p[P_RW_B4], accB);
+  if (tid >= 192 && tid < 272) atomic_add_f32(gp.p[P_VT_N2W] + (tid - 192), accB);
+  if (tid >= 272 && tid < 352) atomic_add_f32(gp.p[P_VT_N2B] + (tid - 272), accB);
+  if (tid >= 352 && tid < 432) atomic_add_f32(gp.p[P_VT_N1W] + (tid - 352), accB);
+  if (tid >= 432 && tid < 512) atomic_add_f32(gp.p[P_VT_N1B] + (tid - 432), accB);
+}
+
+hipError_t launch_view_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* x_tokens, const float* rgbm,
+                           const float* dirs, const float* d_tok_a, const float* d_tok_b, const float* d_radiance, int P,
+                           int NV, float* d_pv, float* dbg, hipStream_t s) {
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&view_bwd_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, vb::kLdsBytes);
+  if (attr != hipSuccess) return attr;
+  const int PPT = kTT / (NV + 1);
+  const int n_tiles = (P + PPT - 1) / PPT;
+  const int blocks = n_tiles < 256 ? n_tiles : 256;
+  hipLaunchKernelGGL(view_bwd_kernel, dim3(blocks), dim3(kBwdThreads), vb::kLdsBytes, s, wp, gp, x_tokens, rgbm, dirs,
+                     d_tok_a, d_tok_b, d_radiance, P, NV, d_pv, dbg);
+  return hipGetLastError();
+}
+
+}  // namespace ufr

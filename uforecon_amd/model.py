@@ -5,9 +5,10 @@ this path, so the caller (the Lightning hooks in code1/model.py:492-842) can swa
 (INTEGRATION.md).  The modules only OWN the parameters; every computation is a HIP kernel reached
 through the C ABI -- there is no eager/CPU fallback, a missing library or a CPU tensor raises.
 
-Round-1 scope: inference (``torch.no_grad`` / ``extract_geometry`` and the forward half of the
-training signature).  Backward through the kernels is not implemented yet and asking for it fails
-loudly.
+Inference (``extract_geometry``) runs the fused whole-path entry point; the training / validation signature
+(``infer(extract_geometry=False)``, what ``training_step`` calls, code1/model.py:540-548) runs the stepwise entry
+points under ``uforecon_amd.autograd`` so that ``loss.backward()`` reaches every ``ray_transformer.*`` parameter,
+``deviation_network.variance`` and the six sampled volumes through the ``ufr_*_bwd`` kernels.
 """
 from __future__ import annotations
 
@@ -18,14 +19,13 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import autograd as ag
 from . import ops
 from ._lib import UfrError
 
 
-def _no_grad_only(*tensors) -> None:
-    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
-        raise UfrError("backward through the HIP ray path is not implemented yet (round 1 is forward-only): "
-                       "call under torch.no_grad()")
+def _wants_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
 
 
 # --------------------------------------------------------------------------- small modules
@@ -92,11 +92,13 @@ class VolumeRenderer:
     def render(self, z_val, radiance, geo_value, cos_anneal_ratio=1.0, deviation_network=None):
         if cos_anneal_ratio != 1.0:
             raise UfrError("cos_anneal_ratio != 1.0 is never used by the reference (model.py:338-341)")
-        _no_grad_only(radiance, geo_value, deviation_network.variance)
-        var = deviation_network.variance.detach().reshape(1).float().contiguous()
-        rgb, depth, opacity, weight = ops.composite(z_val.float().contiguous(), radiance.float().contiguous(),
-                                                    geo_value.float().contiguous(), var)
-        inv_s = torch.exp(var * 10.0).clip(1e-6, 1e6).reshape(1, 1)
+        var = deviation_network.variance
+        z, rad, geo = z_val.float().contiguous(), radiance.float().contiguous(), geo_value.float().contiguous()
+        if _wants_grad(rad, geo, var):
+            rgb, depth, opacity, weight = ag.Composite.apply(z, rad, geo, var)
+        else:
+            rgb, depth, opacity, weight = ops.composite(z, rad, geo, var.detach().reshape(1).float().contiguous())
+        inv_s = torch.exp(var * 10.0).clip(1e-6, 1e6).reshape(1, 1)                  # renderer.py:25, 48
         return rgb, depth, opacity, weight, 1.0 / inv_s
 
 
@@ -214,9 +216,14 @@ class UFORecon(nn.Module):
 
     # ---- per-frame state: channel-last copies are cached on the identity of the frame tensors
     def frame_handle(self, batch, source_imgs_feat, feature_volume, match_feature) -> ops.FrameHandle:
-        key = (source_imgs_feat.data_ptr(), source_imgs_feat._version, match_feature[0].data_ptr(),
-               batch["source_imgs"].data_ptr(), batch["depth_info"].data_ptr(), batch["source_poses"].data_ptr(),
-               tuple(feature_volume[s]["feature_volume"].data_ptr() for s in ("stage1", "stage2", "stage3")))
+        # every tensor the handle snapshots (maps, volumes, and the view-dependent camera state: rays, poses, near/far)
+        # enters the key with its storage address AND version counter, so a new render view of the same sources or an
+        # in-place update never reuses stale state
+        keyed = [source_imgs_feat, match_feature[0]]
+        keyed += [batch[k] for k in ("source_imgs", "depth_info", "source_poses", "source_poses_inv", "ref_pose_inv", "w2cs",
+                                     "near_fars", "ray_o", "ray_d", "cam_ray_d") if k in batch]
+        keyed += ag.flat_volumes(feature_volume)
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in keyed) + (batch.get("start_idx", 1),)
         if key != self._frame_key:
             self._frame = ops.FrameHandle(batch, source_imgs_feat, feature_volume, match_feature)
             self._frame_key = key
@@ -228,25 +235,42 @@ class UFORecon(nn.Module):
     def sample2rgb(self, batch, points_x, z_val, ray_d, ray_idx, source_imgs_feat, feature_volume, match_feature):
         """model.py:308-348.  ``points_x`` must be ``ray_o + z_val * ray_d`` (it always is in the reference);
         the kernels recompute the positions from ``z_val``."""
-        _no_grad_only(*self.parameters())
         B, RN, SN, _ = points_x.shape
         if B != 1:
             raise UfrError("B=1 only (one frame per call)")
         fh = self.frame_handle(batch, source_imgs_feat, feature_volume, match_feature)
-        W = self._weights()
         ray_o = batch["ray_o"][0].float().contiguous()
-        z = z_val.reshape(RN, SN).float().contiguous()
-        x, rgbm, dirs, _ = ops.project_gather(fh, W, ray_o, ray_d.reshape(RN, 3).float().contiguous(), z)
+        z = z_val.reshape(RN, SN).detach().float().contiguous()
+        rgb, depth, opacity, weight, srdf = self._render_pass(fh, ray_o, ray_d.reshape(RN, 3).float().contiguous(), z,
+                                                              feature_volume)
+        return rgb[None], depth[None], srdf.reshape(RN, SN, 1), opacity[None], weight[None], None, self._variance_out()
+
+    def _live_params(self):
+        sd = {"ray_transformer." + k: v for k, v in self.ray_transformer.named_parameters()}
+        sd.update({"ray_transformer." + k: v for k, v in self.ray_transformer.named_buffers()})
+        sd["deviation_network.variance"] = self.deviation_network.variance
+        return [sd[k] for k in ops.RAW_WEIGHT_KEYS]
+
+    def _variance_out(self):
+        """``1 / inv_s`` (renderer.py:25, 48) as a differentiable function of the parameter."""
+        return 1.0 / torch.exp(self.deviation_network.variance.reshape(1, 1) * 10.0).clip(1e-6, 1e6)
+
+    def _render_pass(self, fh, ray_o, ray_d, z, feature_volume):
+        """gather -> aggregate -> composite for the samples ``z`` (RN,SN); differentiable when anything upstream is."""
+        W = self._weights()
+        RN, SN = z.shape
+        params, vols = self._live_params(), ag.flat_volumes(feature_volume)
+        if _wants_grad(*params, *vols):
+            return ag.RenderPass.apply(fh, W, ray_o, ray_d, z, *params, *vols)
+        x, rgbm, dirs, _ = ops.project_gather(fh, W, ray_o, ray_d, z)
         radiance, srdf, _ = ops.aggregate(W, x, rgbm, dirs, RN, SN)
         rgb, depth, opacity, weight = ops.composite(z, radiance.reshape(RN, SN, 3), srdf, W.variance.reshape(1))
-        variance = 1.0 / torch.exp(W.variance.reshape(1, 1) * 10.0).clip(1e-6, 1e6)
-        return rgb[None], depth[None], srdf.reshape(RN, SN, 1), opacity[None], weight[None], None, variance
+        return rgb, depth, opacity, weight, srdf
 
     def infer(self, batch, ray_idx, source_imgs_feat, feature_volume=None, extract_geometry=False, match_feature=None,
               ray_idx_all=None, is_train=True, uniforms=None):
         """model.py:393-482.  ``uniforms=(U1 (SN,RN), U2 (PN,RN))`` pins the sampler randomness; by default
         they are drawn from the CPU generator in the reference's order and shapes."""
-        _no_grad_only(*self.parameters())
         B, RN = ray_idx.shape
         if B != 1:
             raise UfrError("B=1 only (one frame per call)")
@@ -269,7 +293,8 @@ class UFORecon(nn.Module):
             points = batch["ray_o"][0][None, None, :] + out["z_all"][..., None] * ray_d[:, None, :]
             return out["srdf"][None], points[None], out["depth"][None], out["rgb"][None]   # model.py:475-478 / 452
 
-        # training / validation signature (forward only): no near/far scaling (model.py:423), GT gathers
+        # training / validation signature: no near/far scaling (model.py:423), GT gathers (model.py:398-406);
+        # differentiable through autograd.RenderPass; the importance sampler sees detached weights (model.py:456-457)
         idx = ray_idx.reshape(-1)
         ref_img = batch["ref_img"].reshape(B, 3, -1)
         rgb_gt = ref_img[:, :, idx].permute(0, 2, 1)
@@ -279,15 +304,11 @@ class UFORecon(nn.Module):
         near = batch["near_fars"][0, 0, 0].expand(RN).float().contiguous()
         far = batch["near_fars"][0, 0, 1].expand(RN).float().contiguous()
         z1 = ops.sample_fixed(near, far, U1)
-        x, rgbm, dirs, _ = ops.project_gather(fh, W, ray_o, ray_d, z1)
-        rad, srdf, _ = ops.aggregate(W, x, rgbm, dirs, RN, self.point_num)
-        rgb, depth, opacity, weight = ops.composite(z1, rad.reshape(RN, -1, 3), srdf, W.variance.reshape(1))
-        _, z2 = ops.sample_importance_merge(weight, z1, U2, want_fine=False)
+        rgb, depth, opacity, weight, srdf = self._render_pass(fh, ray_o, ray_d, z1, feature_volume)
+        _, z2 = ops.sample_importance_merge(weight.detach().contiguous(), z1, U2, want_fine=False)
         S2 = z2.shape[1]
-        x, rgbm, dirs, _ = ops.project_gather(fh, W, ray_o, ray_d, z2)
-        rad2, srdf2, _ = ops.aggregate(W, x, rgbm, dirs, RN, S2)
-        rgb2, depth2, opacity2, weight2 = ops.composite(z2, rad2.reshape(RN, S2, 3), srdf2, W.variance.reshape(1))
-        variance = 1.0 / torch.exp(W.variance.reshape(1, 1) * 10.0).clip(1e-6, 1e6)
+        rgb2, depth2, opacity2, weight2, srdf2 = self._render_pass(fh, ray_o, ray_d, z2, feature_volume)
+        variance = self._variance_out()
         return (rgb_gt, rgb[None], depth[None], depth_gt, srdf.reshape(RN, -1, 1), opacity[None], weight[None], None,
                 rgb2[None], depth2[None], srdf2.reshape(RN, S2, 1), opacity2[None], weight2[None], None,
                 z1[None], z2[None], variance)                                                # model.py:480-482
@@ -298,7 +319,6 @@ class UFORecon(nn.Module):
         rays, model.py:815; here chunking is internal to ufr_render_rays and invisible).  Returns
         ``depths (H,W) float32`` = ray depth * cam_ray_d.z * scale_mat[0][0,0] (model.py:818-826) and
         ``rgbs (H,W,3) float32`` in [0,1], both on the device."""
-        _no_grad_only(*self.parameters())
         B, L, _, imgH, imgW = batch["source_imgs"].shape
         if B != 1:
             raise UfrError("B=1 only (one frame per call)")

@@ -185,7 +185,7 @@ def points(ray_o: torch.Tensor, ray_d: torch.Tensor, z: torch.Tensor) -> torch.T
 
 
 def project_gather(frame: FrameHandle, weights: PackedWeights, ray_o: torch.Tensor, ray_d: torch.Tensor,
-                   z: torch.Tensor, debug: bool = False):
+                   z: torch.Tensor, debug: bool = False, want_sim8: bool = False):
     RN, SN = z.shape
     P, NV, dev = RN * SN, frame.NV, z.device
     x = torch.empty(P, NV, _lib.TOKEN_DIM, dtype=torch.float32, device=dev)
@@ -195,6 +195,8 @@ def project_gather(frame: FrameHandle, weights: PackedWeights, ray_o: torch.Tens
     if debug:
         dbg = dict(sim8=torch.empty(P, 8, device=dev), vol24=torch.empty(P, 24, device=dev),
                    xy=torch.empty(NV, P, 2, device=dev), mask_z=torch.empty(NV, P, device=dev))
+    elif want_sim8:   # the backward of pre_sim_mlp needs its input
+        dbg = dict(sim8=torch.empty(P, 8, device=dev))
     stride = 0 if ray_o.numel() == 3 else 3
     _lib.check(_lib.load().ufr_project_gather(
         C.byref(frame.frame), C.byref(weights.raw), _dev(ray_o, "ray_o"), stride, _dev(ray_d, "ray_d"), _dev(z, "z"),
@@ -205,7 +207,7 @@ def project_gather(frame: FrameHandle, weights: PackedWeights, ray_o: torch.Tens
 
 
 def aggregate(weights: PackedWeights, x: torch.Tensor, rgb: torch.Tensor, dirs: torch.Tensor, RN: int, SN: int,
-              debug: bool = False):
+              debug: bool = False, keep_workspace: bool = False):
     lib = _lib.load()
     NV, dev = x.shape[1], x.device
     P = RN * SN
@@ -219,6 +221,8 @@ def aggregate(weights: PackedWeights, x: torch.Tensor, rgb: torch.Tensor, dirs: 
                                  RN, SN, NV, radiance.data_ptr(), srdf.data_ptr(), ws.data_ptr(),
                                  _opt(dbg.get("view_out"), "view_out"), _opt(dbg.get("ray_out"), "ray_out"), _stream()),
                "ufr_aggregate")
+    if keep_workspace:   # the head of the workspace is the view transformer's token-0 output (P,80): the backward needs it
+        dbg["token0"] = ws[: P * _lib.TOKEN_DIM].view(P, _lib.TOKEN_DIM)
     return radiance, srdf, dbg
 
 
@@ -233,6 +237,71 @@ def composite(z: torch.Tensor, radiance: torch.Tensor, srdf: torch.Tensor, varia
                                          _dev(variance, "variance"), RN, SN, rgb.data_ptr(), depth.data_ptr(),
                                          opacity.data_ptr(), weight.data_ptr(), _stream()), "ufr_composite")
     return rgb, depth, opacity, weight
+
+
+# ----------------------------------------------------------------------------- backward (training step)
+class GradBuffer:
+    """One flat fp32 buffer holding the gradients of the 40 per-ray parameters in RAW_WEIGHT_KEYS order (the kernels
+    accumulate into it with atomics; one buffer = one all-reduce for data-parallel training)."""
+
+    def __init__(self, device):
+        sizes = [max(1, int(torch.Size(s).numel())) for s in RAW_WEIGHT_SHAPES]
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + (n + 3) // 4 * 4)        # 16-byte aligned slots
+        self.flat = torch.zeros(offs[-1], dtype=torch.float32, device=device)
+        self.views = {k: self.flat[o:o + n].view(shape) for k, shape, o, n in zip(RAW_WEIGHT_KEYS, RAW_WEIGHT_SHAPES, offs, sizes)}
+        self.raw = _lib.RawGrads()
+        for i, o in enumerate(offs[:-1]):
+            self.raw.p[i] = self.flat.data_ptr() + 4 * o
+
+    def grad(self, key: str) -> torch.Tensor:
+        return self.views[key]
+
+
+def composite_bwd(z, radiance, srdf, variance, d_rgb, d_depth, d_opacity, d_weight):
+    RN, SN = z.shape
+    dev = z.device
+    d_radiance = torch.empty(RN, SN, 3, dtype=torch.float32, device=dev)
+    d_srdf = torch.empty(RN, SN, dtype=torch.float32, device=dev)
+    d_variance = torch.zeros((), dtype=torch.float32, device=dev)
+    opt = lambda t, n: None if t is None else _dev(t.contiguous(), n)
+    _lib.check(_lib.load().ufr_composite_bwd(
+        _dev(z, "z"), _dev(radiance, "radiance"), _dev(srdf, "srdf"), _dev(variance, "variance"), RN, SN,
+        opt(d_rgb, "d_rgb"), opt(d_depth, "d_depth"), opt(d_opacity, "d_opacity"), opt(d_weight, "d_weight"),
+        d_radiance.data_ptr(), d_srdf.data_ptr(), d_variance.data_ptr(), _stream()), "ufr_composite_bwd")
+    return d_radiance, d_srdf, d_variance
+
+
+def aggregate_bwd(weights: PackedWeights, grads: GradBuffer, x, rgb, dirs, token0, RN: int, SN: int, d_radiance, d_srdf,
+                  debug: bool = False):
+    lib = _lib.load()
+    NV, dev = x.shape[1], x.device
+    P = RN * SN
+    d_pv = torch.empty(P, 40, dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.ufr_aggregate_bwd_workspace_bytes(RN, SN, NV) // 4, dtype=torch.float32, device=dev)
+    dbg = {}
+    if debug:
+        dbg = dict(view=torch.zeros(P * (NV + 1), 881, device=dev), ray=torch.zeros(P, 440, device=dev))
+    _lib.check(lib.ufr_aggregate_bwd(
+        C.byref(weights.raw), C.byref(grads.raw), _dev(x, "x_tokens"), _dev(rgb, "rgb"), _dev(dirs, "dir"),
+        _dev(token0, "token0"), RN, SN, NV, _dev(d_radiance.contiguous(), "d_radiance"), _dev(d_srdf.contiguous(), "d_srdf"),
+        d_pv.data_ptr(), ws.data_ptr(), _opt(dbg.get("view"), "debug_view"), _opt(dbg.get("ray"), "debug_ray"), _stream()),
+        "ufr_aggregate_bwd")
+    return d_pv, dbg
+
+
+def project_gather_bwd(frame: FrameHandle, weights: PackedWeights, grads: GradBuffer, ray_o, ray_d, z, sim8, d_pv,
+                       grad_vol_feat, grad_vol_weight) -> None:
+    """Scatter-adds into grad_vol_feat[s] (NV,8,D,Hs,Ws) / grad_vol_weight[s] (NV,1,D,Hs,Ws) (zero them first) and
+    accumulates the pre_sim_mlp gradients into `grads`."""
+    RN, SN = z.shape
+    stride = 0 if ray_o.numel() == 3 else 3
+    gf = (C.c_void_p * 3)(*[_dev(t, "grad_vol_feat") for t in grad_vol_feat])
+    gw = (C.c_void_p * 3)(*[_dev(t, "grad_vol_weight") for t in grad_vol_weight])
+    _lib.check(_lib.load().ufr_project_gather_bwd(
+        C.byref(frame.frame), C.byref(weights.raw), C.byref(grads.raw), _dev(ray_o, "ray_o"), stride, _dev(ray_d, "ray_d"),
+        _dev(z, "z"), RN, SN, _dev(sim8, "sim8"), _dev(d_pv, "d_pv"), gf, gw, _stream()), "ufr_project_gather_bwd")
 
 
 class RenderWorkspace:

@@ -185,7 +185,7 @@ def test_optimizer_step_follows_the_gradients():
     and the loss of the same batch goes down."""
     name = "c5_train_grads"
     m, f, r, loss, g = _train_step(name)
-    opt = torch.optim.SGD(m.parameters(), lr=1e-2)
+    opt = torch.optim.SGD(m.parameters(), lr=1e-4)
     before = {k: p.detach().clone() for k, p in m.named_parameters()}
     loss.backward()
     opt.step()

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from uforecon_amd.dist import RayShard, all_gather_tiles
+from uforecon_amd.dist import RayShard, all_gather_tiles, allreduce_gradients
 
 
 @pytest.mark.parametrize("H,W,world", [(512, 640, 8), (63, 10, 4), (5, 3, 2), (7, 3, 8)])
@@ -55,3 +55,40 @@ def test_all_gather_tiles_world2_gloo(H, W):
         assert p.exitcode == 0
     for rank, ok, ds, cs in res:
         assert ok and ds == (H, W) and cs == (H, W, 3)
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        # the per-ray parameter shapes (scalar variance included) + one parameter without a gradient
+        shapes = [(32, 8), (32,), (160, 160), (80, 160), (88,), (1, 80), ()]
+        params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes] + [torch.nn.Parameter(torch.zeros(3))]
+        for i, p in enumerate(params[:-1]):
+            p.grad = torch.full(p.shape, float(rank + 1)) * (i + 1) + torch.arange(p.numel()).float().view(p.shape)
+        n = allreduce_gradients(params)
+        ok = n == sum(p.numel() for p in params[:-1]) and params[-1].grad is None
+        for i, p in enumerate(params[:-1]):
+            want = torch.full(p.shape, (1 + world) / 2.0) * (i + 1) + torch.arange(p.numel()).float().view(p.shape)
+            ok = ok and torch.allclose(p.grad, want)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2_gloo():
+    """Data-parallel training step (BASELINE configs[4]): one flat all-reduce averages every gradient over the ranks."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)

@@ -40,6 +40,7 @@ enum : int {
   O_END = 2051
 };
 constexpr int kKV = 8 * 11 * 12;   // per head [d][e], e = 11: sum of K' (linear_attention.py:43)
+constexpr int kKVPer = (kKV + kBwdThreads - 1) / kBwdThreads;
 constexpr int kLdsBytes = (O_END * kLD + 2 * kKV) * 4;
 
 constexpr WgMat kMats2[] = {{P_RT_Q, 88, 88, O_DQ, O_CAT},        {P_RT_MERGE, 88, 88, O_DMPRE, O_MSG},
@@ -61,16 +62,15 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* KV = lds + O_END * kLD;
   float* dKV = KV + kKV;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid0 = threadIdx.x, wave = tid0 >> 6, lane = tid0 & 63;
+  int tid = tid0;   // re-laundered after every barrier (bwd_common.h: opaque)
   const int n_sub = SN / kTT;
   const float fS = (float)SN;
-  constexpr WgList<6> L2 = rb::kList2;
-  constexpr WgList<2> L3 = rb::kList3;
 
   f32x4 acc[kSlots2 + kSlots3];
 #pragma unroll
   for (int s = 0; s < kSlots2 + kSlots3; ++s) acc[s] = splat4(0.f);
-  float accB = 0.f;
+  float accB = 0.f, accN1 = 0.f, accN2 = 0.f;
 
   auto R = [&](int row) -> float* { return lds + row * kLD; };
   // x tile: token-0 feature of sample (ray, s0 + col) | order PE (ray_transformer.py:301-303)
@@ -83,20 +83,22 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       for (int e = 0; e < 4; ++e) R(O_CAT + 4 * f4 + e)[col] = v[e];
     }
   };
-  // the 1056 = 8 x 11 x 12 per-head state entries are dealt three per thread
+  // the 1056 = 8 x 11 x 12 per-head state entries are dealt kKVPer per thread
   auto kv_entry = [&](int o, int& h, int& d, int& e) { h = o / 132; d = (o - h * 132) / 12; e = o % 12; };
 
   for (int ray = blockIdx.x; ray < RN; ray += gridDim.x) {
     // ================= sweep 1: KV state
-    float kv[3] = {0.f, 0.f, 0.f};
+    float kv[kKVPer] = {};
     for (int sub = 0; sub < n_sub; ++sub) {
       load_x(ray, sub * kTT);
       __syncthreads();
+    tid = opaque(tid0);
       gemm_lds<88, 88, false>(wp.p[P_RT_K], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = elu1(v); });
-      gemm_lds<88, 88, false>(wp.p[P_RT_V], 88, R(O_CAT), (wave + 2) & 7, lane, [&](int r, int c, float v) { R(O_V + r)[c] = v / fS; });
+      gemm_lds<88, 88, false>(wp.p[P_RT_V], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_V + r)[c] = v / fS; }, 6);
       __syncthreads();
+    tid = opaque(tid0);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < kKVPer; ++i) {
         const int o = tid + i * kBwdThreads;
         if (o < kKV) {
           int h, d, e;
@@ -110,21 +112,25 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
         }
       }
       __syncthreads();
+    tid = opaque(tid0);
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < kKVPer; ++i)
       if (tid + i * kBwdThreads < kKV) KV[tid + i * kBwdThreads] = kv[i];
     __syncthreads();
+    tid = opaque(tid0);
 
     // ================= sweep 2
-    float dkv[3] = {0.f, 0.f, 0.f};
+    float dkv[kKVPer] = {};
     for (int sub = 0; sub < n_sub; ++sub) {
       const int s0 = sub * kTT;
       load_x(ray, s0);
       if (tid < kTT) R(O_DSRDF)[tid] = d_srdf[(size_t)ray * SN + s0 + tid];
       __syncthreads();
+    tid = opaque(tid0);
       gemm_lds<88, 88, false>(wp.p[P_RT_Q], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_Q + r)[c] = v; });
       __syncthreads();
+    tid = opaque(tid0);
       // message of (token, head): t = Q' KV_h, den = Q'.sum K', msg = t * Z * SN (linear_attention.py:43-44)
       if (tid < kTT * 8) {
         const int col = tid >> 3, h = tid & 7;
@@ -146,54 +152,70 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
         R(O_Z + h)[col] = Z;
       }
       __syncthreads();
+    tid = opaque(tid0);
       gemm_lds<88, 88, false>(wp.p[P_RT_MERGE], 88, R(O_MSG), wave, lane, [&](int r, int c, float v) { R(O_XH1 + r)[c] = v; });
       __syncthreads();
+    tid = opaque(tid0);
       ln_forward<88>(R(O_XH1), R(O_CAT + 88), nullptr, wp.p[P_RT_N1W], wp.p[P_RT_N1B], R(O_RSTD1), tid);
       __syncthreads();
+    tid = opaque(tid0);
       gemm_lds<176, 176, false>(wp.p[P_RT_MLP0], 176, R(O_CAT), wave, lane,
                                 [&](int r, int c, float v) { R(O_HID + r)[c] = fmaxf(v, 0.f); });
       __syncthreads();
+    tid = opaque(tid0);
       gemm_lds<88, 176, false>(wp.p[P_RT_MLP2], 176, R(O_HID), wave, lane, [&](int r, int c, float v) { R(O_XH2 + r)[c] = v; });
       __syncthreads();
+    tid = opaque(tid0);
       ln_forward<88>(R(O_XH2), R(O_Y), R(O_CAT), wp.p[P_RT_N2W], wp.p[P_RT_N2B], R(O_RSTD2), tid);
       __syncthreads();
+    tid = opaque(tid0);
       // DensityMLP 88 -> 32 -> 16 (-> 1) (ray_transformer.py:147-150, 307)
       gemm_lds<32, 88, false>(wp.p[P_DM_W0], 88, R(O_Y), wave, lane,
                               [&](int r, int c, float v) { R(O_D1 + r)[c] = fmaxf(v + wp.p[P_DM_B0][r], 0.f); });
       __syncthreads();
+    tid = opaque(tid0);
       gemm_lds<16, 32, false>(wp.p[P_DM_W2], 32, R(O_D1), wave, lane,
                               [&](int r, int c, float v) { R(O_D2 + r)[c] = fmaxf(v + wp.p[P_DM_B2][r], 0.f); });
       __syncthreads();
+    tid = opaque(tid0);
       // ---- backwards: srdf = W4 d2 + b4
       if (tid < 16 * kTT) {
         const int o = tid >> 4, c = tid & 15;
         R(O_DD2 + o)[c] = R(O_D2 + o)[c] > 0.f ? wp.p[P_DM_W4][o] * R(O_DSRDF)[c] : 0.f;
       }
       __syncthreads();
+    tid = opaque(tid0);
       gemm_lds<32, 16, true>(wp.p[P_DM_W2], 32, R(O_DD2), wave, lane,
                              [&](int r, int c, float v) { R(O_DD1 + r)[c] = R(O_D1 + r)[c] > 0.f ? v : 0.f; });
       __syncthreads();
+    tid = opaque(tid0);
       gemm_lds<88, 32, true>(wp.p[P_DM_W0], 88, R(O_DD1), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] = v; });
       __syncthreads();
+    tid = opaque(tid0);
       ln_backward<88>(R(O_DY), R(O_XH2), wp.p[P_RT_N2W], R(O_RSTD2), R(O_DOPRE), tid);
-      if (tid < 88) accB += row_dot(R(O_DY), R(O_XH2), tid);
-      else if (tid < 176) accB += row_dot(R(O_DY), nullptr, tid - 88);
+      if (tid < 88) accN2 += row_dot(R(O_DY), R(O_XH2), tid);
+      else if (tid < 176) accN2 += row_dot(R(O_DY), nullptr, tid - 88);
       __syncthreads();
+    tid = opaque(tid0);
       gemm_lds<176, 88, true>(wp.p[P_RT_MLP2], 176, R(O_DOPRE), wave, lane,
                               [&](int r, int c, float v) { R(O_DHID + r)[c] = R(O_HID + r)[c] > 0.f ? v : 0.f; });
       __syncthreads();
+    tid = opaque(tid0);
       gemm_lds<176, 176, true>(wp.p[P_RT_MLP0], 176, R(O_DHID), wave, lane, [&](int r, int c, float v) { R(O_DCAT + r)[c] = v; });
       __syncthreads();
+    tid = opaque(tid0);
       ln_backward<88>(R(O_DCAT + 88), R(O_XH1), wp.p[P_RT_N1W], R(O_RSTD1), R(O_DMPRE), tid);
-      if (tid >= 176 && tid < 264) accB += row_dot(R(O_DCAT + 88), R(O_XH1), tid - 176);
-      else if (tid >= 264 && tid < 352) accB += row_dot(R(O_DCAT + 88), nullptr, tid - 264);
+      if (tid < 88) accN1 += row_dot(R(O_DCAT + 88), R(O_XH1), tid);
+      else if (tid < 176) accN1 += row_dot(R(O_DCAT + 88), nullptr, tid - 88);
       for (int idx = tid; idx < 88 * kTT; idx += kBwdThreads) {
         const int r = idx >> 4, c = idx & 15;
         R(O_DY + r)[c] += R(O_DCAT + r)[c];
       }
       __syncthreads();
+    tid = opaque(tid0);
       gemm_lds<88, 88, true>(wp.p[P_RT_MERGE], 88, R(O_DMPRE), wave, lane, [&](int r, int c, float v) { R(O_DMSG + r)[c] = v; });
       __syncthreads();
+    tid = opaque(tid0);
       // attention backwards, query side: d t = d msg Z SN; d den = -SN Z^2 (d msg . t); d Q' = KV d t + d den sum K'
       if (tid < kTT * 8) {
         const int col = tid >> 3, h = tid & 7;
@@ -231,9 +253,10 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
         R(O_DDEN + h)[col] = dden;
       }
       __syncthreads();
+    tid = opaque(tid0);
       // d KV_h[d][e] += sum_t Q'_t[d] d t_t[e];   d (sum K')[d] += sum_t d den_t Q'_t[d]
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < kKVPer; ++i) {
         const int o = tid + i * kBwdThreads;
         if (o < kKV) {
           int h, d, e;
@@ -248,6 +271,7 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       }
       gemm_lds<88, 88, true>(wp.p[P_RT_Q], 88, R(O_DQ), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
       __syncthreads();
+    tid = opaque(tid0);
       // d x of this sweep (order-PE rows carry no gradient)
       for (int idx = tid; idx < kTT * 20; idx += kBwdThreads) {
         const int col = idx / 20, f4 = idx - col * 20;
@@ -257,10 +281,10 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
         st4(d_tok_a + ((size_t)ray * SN + s0 + col) * UFR_TOKEN_DIM + 4 * f4, v);
       }
       // small gradients: DensityMLP biases and last layer
-      if (tid >= 352 && tid < 384) accB += row_dot(R(O_DD1 + (tid - 352)), nullptr, 0);
-      else if (tid >= 384 && tid < 400) accB += row_dot(R(O_DD2 + (tid - 384)), nullptr, 0);
-      else if (tid >= 400 && tid < 416) accB += row_dot(R(O_DSRDF), R(O_D2 + (tid - 400)), 0);
-      else if (tid == 416) accB += row_dot(R(O_DSRDF), nullptr, 0);
+      if (tid >= 176 && tid < 208) accB += row_dot(R(O_DD1 + (tid - 176)), nullptr, 0);
+      else if (tid >= 208 && tid < 224) accB += row_dot(R(O_DD2 + (tid - 208)), nullptr, 0);
+      else if (tid >= 224 && tid < 240) accB += row_dot(R(O_DSRDF), R(O_D2 + (tid - 224)), 0);
+      else if (tid == 240) accB += row_dot(R(O_DSRDF), nullptr, 0);
       if (dbg) {
         for (int idx = tid; idx < kTT * 88; idx += kBwdThreads) {
           const int col = idx / 88, k = idx - col * 88;
@@ -271,22 +295,26 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
           row[264 + k] = R(O_DQ + k)[col];
         }
       }
-      wgrad_all<6, kSlots2, 0>(L2, acc, lds, wave, lane);
+      wgrad_all<rb::kList2, 6, kSlots2, 0>(acc, lds, wave, lane);
       __syncthreads();
+    tid = opaque(tid0);
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < kKVPer; ++i)
       if (tid + i * kBwdThreads < kKV) dKV[tid + i * kBwdThreads] = dkv[i];
     __syncthreads();
+    tid = opaque(tid0);
 
     // ================= sweep 3: key / value side
     for (int sub = 0; sub < n_sub; ++sub) {
       const int s0 = sub * kTT;
       load_x(ray, s0);
       __syncthreads();
+    tid = opaque(tid0);
       gemm_lds<88, 88, false>(wp.p[P_RT_K], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = v; });
-      gemm_lds<88, 88, false>(wp.p[P_RT_V], 88, R(O_CAT), (wave + 2) & 7, lane, [&](int r, int c, float v) { R(O_V + r)[c] = v; });
+      gemm_lds<88, 88, false>(wp.p[P_RT_V], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_V + r)[c] = v; }, 6);
       __syncthreads();
+    tid = opaque(tid0);
       // d K'_s[d] = sum_e dKV[d][e] V_s[e] + d(sum K')[d];   d V_s[e] = sum_d K'_s[d] dKV[d][e];  V = v / SN
       if (tid < kTT * 8) {
         const int col = tid >> 3, h = tid & 7;
@@ -312,9 +340,11 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
         for (int e = 0; e < 11; ++e) R(O_DV + 11 * h + e)[col] = dv[e] / fS;
       }
       __syncthreads();
+    tid = opaque(tid0);
       gemm_lds<88, 88, true>(wp.p[P_RT_K], 88, R(O_DK), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] = v; });
       gemm_lds<88, 88, true>(wp.p[P_RT_V], 88, R(O_DV), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
       __syncthreads();
+    tid = opaque(tid0);
       for (int idx = tid; idx < kTT * 20; idx += kBwdThreads) {
         const int col = idx / 20, f4 = idx - col * 20;
         f32x4 v;
@@ -329,21 +359,24 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
           row[352 + k] = R(O_DY + k)[col];
         }
       }
-      wgrad_all<2, kSlots3, kSlots2>(L3, acc, lds, wave, lane);
+      wgrad_all<rb::kList3, 2, kSlots3, kSlots2>(acc, lds, wave, lane);
       __syncthreads();
+    tid = opaque(tid0);
     }
   }
 
-  wgrad_flush_all<6, kSlots2, 0>(L2, acc, gp, wave, lane);
-  wgrad_flush_all<2, kSlots3, kSlots2>(L3, acc, gp, wave, lane);
-  if (tid < 88) atomic_add_f32(gp.p[P_RT_N2W] + tid, accB);
-  else if (tid < 176) atomic_add_f32(gp.p[P_RT_N2B] + (tid - 88), accB);
-  else if (tid < 264) atomic_add_f32(gp.p[P_RT_N1W] + (tid - 176), accB);
-  else if (tid < 352) atomic_add_f32(gp.p[P_RT_N1B] + (tid - 264), accB);
-  else if (tid < 384) atomic_add_f32(gp.p[P_DM_B0] + (tid - 352), accB);
-  else if (tid < 400) atomic_add_f32(gp.p[P_DM_B2] + (tid - 384), accB);
-  else if (tid < 416) atomic_add_f32(gp.p[P_DM_W4] + (tid - 400), accB);
-  else if (tid == 416) atomic_add_f32(gp.p[P_DM_B4], accB);
+  wgrad_flush_all<rb::kList2, 6, kSlots2, 0>(acc, gp, wave, lane);
+  wgrad_flush_all<rb::kList3, 2, kSlots3, kSlots2>(acc, gp, wave, lane);
+  if (tid < 88) {
+    atomic_add_f32(gp.p[P_RT_N2W] + tid, accN2);
+    atomic_add_f32(gp.p[P_RT_N1W] + tid, accN1);
+  } else if (tid < 176) {
+    atomic_add_f32(gp.p[P_RT_N2B] + (tid - 88), accN2);
+    atomic_add_f32(gp.p[P_RT_N1B] + (tid - 88), accN1);
+  } else if (tid < 208) atomic_add_f32(gp.p[P_DM_B0] + (tid - 176), accB);
+  else if (tid < 224) atomic_add_f32(gp.p[P_DM_B2] + (tid - 208), accB);
+  else if (tid < 240) atomic_add_f32(gp.p[P_DM_W4] + (tid - 224), accB);
+  else if (tid == 240) atomic_add_f32(gp.p[P_DM_B4], accB);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -352,48 +385,56 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
 namespace pb {
 enum : int { O_S8 = 0, O_A1 = 8, O_A2 = 40, O_DO = 72, O_DA2 = 88, O_DA1 = 120, O_END = 152 };
 constexpr WgMat kMats[] = {{P_PS_W4, 16, 32, O_DO, O_A2}, {P_PS_W2, 32, 32, O_DA2, O_A1}, {P_PS_W0, 32, 8, O_DA1, O_S8}};
-constexpr auto kList = make_wglist(kMats);   // 2 + 4 + 2 = 8 tiles: one slot per wave
+constexpr auto kList = make_wglist(kMats);   // 2 + 4 + 2 = 8 tiles: two slots per wave
 }  // namespace pb
 
 __global__ void __launch_bounds__(kBwdThreads) presim_bwd_kernel(RawPtrs wp, GradPtrs gp, const float* __restrict__ sim8,
                                                                  const float* __restrict__ d_pv, int P) {
   using namespace pb;
   __shared__ float lds[O_END * kLD];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  constexpr WgList<3> LL = pb::kList;
-  f32x4 acc[1] = {splat4(0.f)};
+  const int tid0 = threadIdx.x, wave = tid0 >> 6, lane = tid0 & 63;
+  int tid = tid0;   // re-laundered after every barrier (bwd_common.h: opaque)
+  f32x4 acc[2] = {splat4(0.f), splat4(0.f)};
   float accB = 0.f;
   auto R = [&](int row) -> float* { return lds + row * kLD; };
   const int n_tiles = (P + kTT - 1) / kTT;
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int p0 = tile * kTT;
-    if (tid < kTT * 8) {
-      const int c = tid >> 3, i = tid & 7, p = p0 + c;
-      R(O_S8 + i)[c] = p < P ? sim8[(size_t)p * 8 + i] : 0.f;
-    } else if (tid < kTT * 24) {
-      const int c = (tid - kTT * 8) >> 4, i = (tid - kTT * 8) & 15, p = p0 + c;
-      R(O_DO + i)[c] = p < P ? d_pv[(size_t)p * 40 + 24 + i] : 0.f;
+    for (int idx = tid; idx < kTT * 24; idx += kBwdThreads) {
+      if (idx < kTT * 8) {
+        const int c = idx >> 3, i = idx & 7, p = p0 + c;
+        R(O_S8 + i)[c] = p < P ? sim8[(size_t)p * 8 + i] : 0.f;
+      } else {
+        const int c = (idx - kTT * 8) >> 4, i = (idx - kTT * 8) & 15, p = p0 + c;
+        R(O_DO + i)[c] = p < P ? d_pv[(size_t)p * 40 + 24 + i] : 0.f;
+      }
     }
     __syncthreads();
+    tid = opaque(tid0);
     gemm_lds<32, 8, false>(wp.p[P_PS_W0], 8, R(O_S8), wave, lane,
                            [&](int r, int c, float v) { R(O_A1 + r)[c] = fmaxf(v + wp.p[P_PS_B0][r], 0.f); });
     __syncthreads();
+    tid = opaque(tid0);
     gemm_lds<32, 32, false>(wp.p[P_PS_W2], 32, R(O_A1), wave, lane,
                             [&](int r, int c, float v) { R(O_A2 + r)[c] = fmaxf(v + wp.p[P_PS_B2][r], 0.f); });
     __syncthreads();
+    tid = opaque(tid0);
     gemm_lds<32, 16, true>(wp.p[P_PS_W4], 32, R(O_DO), wave, lane,
                            [&](int r, int c, float v) { R(O_DA2 + r)[c] = R(O_A2 + r)[c] > 0.f ? v : 0.f; });
     __syncthreads();
+    tid = opaque(tid0);
     gemm_lds<32, 32, true>(wp.p[P_PS_W2], 32, R(O_DA2), wave, lane,
                            [&](int r, int c, float v) { R(O_DA1 + r)[c] = R(O_A1 + r)[c] > 0.f ? v : 0.f; });
     __syncthreads();
+    tid = opaque(tid0);
     if (tid < 16) accB += row_dot(R(O_DO + tid), nullptr, 0);
     else if (tid < 48) accB += row_dot(R(O_DA2 + (tid - 16)), nullptr, 0);
     else if (tid < 80) accB += row_dot(R(O_DA1 + (tid - 48)), nullptr, 0);
-    wgrad_all<3, 1, 0>(LL, acc, lds, wave, lane);
+    wgrad_all<pb::kList, 3, 2, 0>(acc, lds, wave, lane);
     __syncthreads();
+    tid = opaque(tid0);
   }
-  wgrad_flush_all<3, 1, 0>(LL, acc, gp, wave, lane);
+  wgrad_flush_all<pb::kList, 3, 2, 0>(acc, gp, wave, lane);
   if (tid < 16) atomic_add_f32(gp.p[P_PS_B4] + tid, accB);
   else if (tid < 48) atomic_add_f32(gp.p[P_PS_B2] + (tid - 16), accB);
   else if (tid < 80) atomic_add_f32(gp.p[P_PS_B0] + (tid - 48), accB);

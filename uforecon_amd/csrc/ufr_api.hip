@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -49,9 +50,11 @@ struct Carver {  // bump allocator over a caller workspace
 };
 
 // ---- optional per-kernel timing with HIP events on the caller's stream
+// process-wide (the backward entry points are called from autograd's worker thread, not the caller's)
 struct ProfEntry { const char* name; hipEvent_t a, b; };
-thread_local bool g_prof_on = false;
-thread_local std::vector<ProfEntry> g_prof;
+bool g_prof_on = false;
+std::vector<ProfEntry> g_prof;
+std::mutex g_prof_mu;
 
 struct ProfScope {
   hipStream_t s;
@@ -65,8 +68,9 @@ struct ProfScope {
     }
   }
   ~ProfScope() {
-    if (g_prof_on) {
+    if (a) {
       hipEventRecord(b, s);
+      std::lock_guard<std::mutex> lock(g_prof_mu);
       g_prof.push_back({name, a, b});
     }
   }
@@ -241,6 +245,7 @@ int ufr_project_gather(const ufr_frame* frame, const ufr_raw_weights* raw, const
   UFR_REQUIRE(raw && ray_o && ray_d && z && x_tokens && rgb && dir, "ufr_project_gather: null argument");
   UFR_REQUIRE(ray_o_stride == 0 || ray_o_stride == 3, "ufr_project_gather: ray_o_stride must be 0 or 3");
   UFR_REQUIRE(RN > 0 && SN > 0, "ufr_project_gather: RN=%d SN=%d", RN, SN);
+  ProfScope prof("gather", static_cast<hipStream_t>(stream));
   UFR_HIP(launch_gather(*f, presim_of(raw), ray_o, ray_o_stride, ray_d, z, RN, SN, x_tokens, rgb, dir, sim8, vol24, xy,
                         mask_z, static_cast<hipStream_t>(stream)));
   return UFR_OK;
@@ -287,6 +292,7 @@ int ufr_composite(const float* z, const float* radiance, const float* srdf, cons
                   int32_t SN, float* rgb, float* depth, float* opacity, float* weight, ufr_stream stream) {
   UFR_REQUIRE(z && radiance && srdf && variance && depth, "ufr_composite: null argument");
   UFR_REQUIRE(RN > 0 && SN >= 2 && SN <= 256, "ufr_composite: SN=%d out of range [2,256]", SN);
+  ProfScope prof("composite", static_cast<hipStream_t>(stream));
   UFR_HIP(launch_composite(z, radiance, nullptr, srdf, variance, RN, SN, rgb, depth, opacity, weight, nullptr, nullptr,
                            static_cast<hipStream_t>(stream)));
   return UFR_OK;
@@ -653,12 +659,14 @@ int ufr_deform_conv2d(const float* input, const float* offset, const float* mask
 
 // ------------------------------------------------------------------ profiling hooks
 void ufr_profile_enable(int on) {
+  std::lock_guard<std::mutex> lock(g_prof_mu);
   for (auto& e : g_prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   g_prof.clear();
   g_prof_on = on != 0;
 }
 
 int ufr_profile_read(const char** names, float* ms, int32_t* launches, int cap) {
+  std::lock_guard<std::mutex> lock(g_prof_mu);
   int n = 0;
   for (auto& e : g_prof) {
     float t = 0.f;

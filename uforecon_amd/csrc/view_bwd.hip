@@ -59,16 +59,16 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
                                                                float* __restrict__ d_pv, float* __restrict__ dbg) {
   using namespace vb;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid0 = threadIdx.x, wave = tid0 >> 6, lane = tid0 & 63;
+  int tid = tid0;   // re-laundered after every barrier (bwd_common.h: opaque)
   const int L = NV + 1, PPT = kTT / L;
   const int n_tiles = (P + PPT - 1) / PPT;
   const float invL = 1.f / (float)L;
-  constexpr WgList<7> kList = vb::kList;   // kernel-local copy: indexed at run time
 
   f32x4 acc[kSlots];
 #pragma unroll
   for (int s = 0; s < kSlots; ++s) acc[s] = splat4(0.f);
-  float accA = 0.f, accB = 0.f, accC = 0.f;   // small gradients, one scalar per thread (see the flush at the end)
+  float accA = 0.f, accB = 0.f, accC = 0.f, accN1 = 0.f, accN2 = 0.f;   // small gradients, a few scalars per thread (see the flush)
 
   auto R = [&](int row) -> float* { return lds + row * kLD; };
 
@@ -102,12 +102,14 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
       for (int e = 0; e < 3; ++e) R(O_RIN + 80 + e)[col] = ok ? dirs[((size_t)p * NV + tv - 1) * 4 + e] : 0.f;
     }
     __syncthreads();
+    tid = opaque(tid0);
 
     // ---------------- P1: q, k, v (15 row tiles dealt over the 8 waves)
     gemm_lds<80, 80, false>(wp.p[P_VT_Q], 80, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_Q + r)[c] = v; });
-    gemm_lds<80, 80, false>(wp.p[P_VT_K], 80, R(O_CAT), (wave + 3) & 7, lane, [&](int r, int c, float v) { R(O_K + r)[c] = v; });
-    gemm_lds<80, 80, false>(wp.p[P_VT_V], 80, R(O_CAT), (wave + 6) & 7, lane, [&](int r, int c, float v) { R(O_V + r)[c] = v; });
+    gemm_lds<80, 80, false>(wp.p[P_VT_K], 80, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = v; }, 5);
+    gemm_lds<80, 80, false>(wp.p[P_VT_V], 80, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_V + r)[c] = v; }, 10);
     __syncthreads();
+    tid = opaque(tid0);
 
     // ---------------- P2: linear attention over the L tokens of each point (linear_attention.py:31-45) in score form:
     // A[s'] = Q'.K'_s', msg = u * sum_s' A[s'] V_s'  with V = v/L and u = L / (sum_s' A[s'] + eps)
@@ -137,24 +139,31 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
       R(O_U + h)[col] = u;
     }
     __syncthreads();
+    tid = opaque(tid0);
 
     // ---------------- P3/P4: merge + LayerNorm1 (transformer.py:51-52)
     gemm_lds<80, 80, false>(wp.p[P_VT_MERGE], 80, R(O_MSG), wave, lane, [&](int r, int c, float v) { R(O_XH1 + r)[c] = v; });
     __syncthreads();
+    tid = opaque(tid0);
     ln_forward<80>(R(O_XH1), R(O_CAT + 80), nullptr, wp.p[P_VT_N1W], wp.p[P_VT_N1B], R(O_RSTD1), tid);
     __syncthreads();
+    tid = opaque(tid0);
     // ---------------- P5-P7: MLP on [x | m], LayerNorm2, residual (transformer.py:55-58)
     gemm_lds<160, 160, false>(wp.p[P_VT_MLP0], 160, R(O_CAT), wave, lane,
                               [&](int r, int c, float v) { R(O_HID + r)[c] = fmaxf(v, 0.f); });
     __syncthreads();
+    tid = opaque(tid0);
     gemm_lds<80, 160, false>(wp.p[P_VT_MLP2], 160, R(O_HID), wave, lane, [&](int r, int c, float v) { R(O_XH2 + r)[c] = v; });
     __syncthreads();
+    tid = opaque(tid0);
     ln_forward<80>(R(O_XH2), R(O_RIN), R(O_CAT), wp.p[P_VT_N2W], wp.p[P_VT_N2B], R(O_RSTD2), tid);
     __syncthreads();
+    tid = opaque(tid0);
     // ---------------- P8-P10: radiance-weight MLP 83 -> 16 -> 8 -> 1 (ray_transformer.py:159-163, 313-314)
     gemm_lds<16, 83, false>(wp.p[P_RW_W0], 83, R(O_RIN), wave, lane,
                             [&](int r, int c, float v) { R(O_H1 + r)[c] = fmaxf(v + wp.p[P_RW_B0][r], 0.f); });
     __syncthreads();
+    tid = opaque(tid0);
     if (tid < 8 * kTT) {
       const int o = tid >> 4, c = tid & 15;
       float s = wp.p[P_RW_B2][o];
@@ -163,9 +172,11 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
       R(O_H2 + o)[c] = fmaxf(s, 0.f);
     }
     __syncthreads();
+    tid = opaque(tid0);
     // masked softmax over the views of a point and its adjoint (ray_transformer.py:315-319): one thread per point
     if (tid < kTT) R(O_DLOGIT)[tid] = 0.f;
     __syncthreads();
+    tid = opaque(tid0);
     if (tid < PPT && p0 + tid < P) {
       const int pt = tid, p = p0 + pt;
       float lg[UFR_MAX_VIEWS], cr[UFR_MAX_VIEWS], cg[UFR_MAX_VIEWS], cb[UFR_MAX_VIEWS], mk[UFR_MAX_VIEWS];
@@ -197,12 +208,14 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
       }
     }
     __syncthreads();
+    tid = opaque(tid0);
     // ---------------- B1: radiance MLP backwards
     if (tid < 8 * kTT) {
       const int o = tid >> 4, c = tid & 15;
       R(O_DH2 + o)[c] = R(O_H2 + o)[c] > 0.f ? wp.p[P_RW_W4][o] * R(O_DLOGIT)[c] : 0.f;
     }
     __syncthreads();
+    tid = opaque(tid0);
     if (tid < 16 * kTT) {
       const int i = tid >> 4, c = tid & 15;
       float s = 0.f;
@@ -211,32 +224,39 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
       R(O_DH1 + i)[c] = R(O_H1 + i)[c] > 0.f ? s : 0.f;
     }
     __syncthreads();
+    tid = opaque(tid0);
     // ---------------- B2: d y = W0^T d h1 (the 80 feature columns) + d token0 (staged in P0)
     gemm_lds<80, 16, true>(wp.p[P_RW_W0], 83, R(O_DH1), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
     __syncthreads();
+    tid = opaque(tid0);
     // ---------------- B3: LayerNorm2 backwards; y = x + LN2(.) so d x starts as d y
     ln_backward<80>(R(O_DY), R(O_XH2), wp.p[P_VT_N2W], R(O_RSTD2), R(O_DOPRE), tid);
-    if (tid >= 192 && tid < 272) accB += row_dot(R(O_DY), R(O_XH2), tid - 192);
-    if (tid >= 272 && tid < 352) accB += row_dot(R(O_DY), nullptr, tid - 272);
+    if (tid < 80) accN2 += row_dot(R(O_DY), R(O_XH2), tid);
+    else if (tid < 160) accN2 += row_dot(R(O_DY), nullptr, tid - 80);
     __syncthreads();
+    tid = opaque(tid0);
     // ---------------- B4/B5: MLP backwards
     gemm_lds<160, 80, true>(wp.p[P_VT_MLP2], 160, R(O_DOPRE), wave, lane,
                             [&](int r, int c, float v) { R(O_DHID + r)[c] = R(O_HID + r)[c] > 0.f ? v : 0.f; });
     __syncthreads();
+    tid = opaque(tid0);
     gemm_lds<160, 160, true>(wp.p[P_VT_MLP0], 160, R(O_DHID), wave, lane, [&](int r, int c, float v) { R(O_DCAT + r)[c] = v; });
     __syncthreads();
+    tid = opaque(tid0);
     // ---------------- B6: LayerNorm1 backwards on the message half; the x half joins the d x accumulator
     ln_backward<80>(R(O_DCAT + 80), R(O_XH1), wp.p[P_VT_N1W], R(O_RSTD1), R(O_DMPRE), tid);
-    if (tid >= 352 && tid < 432) accB += row_dot(R(O_DCAT + 80), R(O_XH1), tid - 352);
-    if (tid >= 432 && tid < 512) accB += row_dot(R(O_DCAT + 80), nullptr, tid - 432);
+    if (tid < 80) accN1 += row_dot(R(O_DCAT + 80), R(O_XH1), tid);
+    else if (tid < 160) accN1 += row_dot(R(O_DCAT + 80), nullptr, tid - 80);
     for (int idx = tid; idx < 80 * kTT; idx += kBwdThreads) {
       const int r = idx >> 4, c = idx & 15;
       R(O_DY + r)[c] += R(O_DCAT + r)[c];
     }
     __syncthreads();
+    tid = opaque(tid0);
     // ---------------- B7: merge backwards
     gemm_lds<80, 80, true>(wp.p[P_VT_MERGE], 80, R(O_DMPRE), wave, lane, [&](int r, int c, float v) { R(O_DMSG + r)[c] = v; });
     __syncthreads();
+    tid = opaque(tid0);
     // ---------------- B8: attention backwards, query side (thread = (token s, head)):
     //   msg = u r, r = sum_s' A[s'] V_s';  d r = u d msg;  d u = d msg . r;  d den = -d u u^2 / L;
     //   d A[s'] = d r . V_s' + d den;  d Q' = sum_s' d A[s'] K'_s'
@@ -281,6 +301,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
       R(O_DDEN + h)[col] = dden;
     }
     __syncthreads();
+    tid = opaque(tid0);
     // ---------------- B9: key / value side (thread = (token s', head)): d K'_s' = sum_s d A[s][s'] Q'_s,
     //   d V_s' = sum_s A[s][s'] d r_s
     if (tid < kTT * 8) {
@@ -321,11 +342,13 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
       }
     }
     __syncthreads();
+    tid = opaque(tid0);
     // ---------------- B10: projections backwards into the d x accumulator (same lane owns an element in all three)
     gemm_lds<80, 80, true>(wp.p[P_VT_Q], 80, R(O_DQ), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
     gemm_lds<80, 80, true>(wp.p[P_VT_K], 80, R(O_DK), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
     gemm_lds<80, 80, true>(wp.p[P_VT_V], 80, R(O_DV), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
     __syncthreads();
+    tid = opaque(tid0);
     // ---------------- B11: outputs.  Token columns 32..55 (frustum features) and 56..71 (pre_sim_mlp) are the same for
     // all NV view tokens of a point (ray_transformer.py:258-281): their gradients add up.  Token 0 is the view token.
     for (int idx = tid; idx < PPT * 40; idx += kBwdThreads) {
@@ -367,22 +390,26 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
       }
     }
     // ---------------- B12: weight gradients of the seven matrices on the MFMA, register-resident tiles
-    wgrad_all<7, kSlots, 0>(kList, acc, lds, wave, lane);
+    wgrad_all<vb::kList, 7, kSlots, 0>(acc, lds, wave, lane);
     __syncthreads();
+    tid = opaque(tid0);
   }
 
   // ---------------- flush (once per workgroup)
-  wgrad_flush_all<7, kSlots, 0>(kList, acc, gp, wave, lane);
+  wgrad_flush_all<vb::kList, 7, kSlots, 0>(acc, gp, wave, lane);
   if (tid < 128) atomic_add_f32(gp.p[P_RW_W2] + tid, accA);
   if (tid < 80) atomic_add_f32(gp.p[P_VIEW_TOKEN] + tid, accC);
   if (tid >= 128 && tid < 136) atomic_add_f32(gp.p[P_RW_W4] + (tid - 128), accB);
   if (tid >= 136 && tid < 152) atomic_add_f32(gp.p[P_RW_B0] + (tid - 136), accB);
   if (tid >= 152 && tid < 160) atomic_add_f32(gp.p[P_RW_B2] + (tid - 152), accB);
   if (tid == 160) atomic_add_f32(gp.p[P_RW_B4], accB);
-  if (tid >= 192 && tid < 272) atomic_add_f32(gp.p[P_VT_N2W] + (tid - 192), accB);
-  if (tid >= 272 && tid < 352) atomic_add_f32(gp.p[P_VT_N2B] + (tid - 272), accB);
-  if (tid >= 352 && tid < 432) atomic_add_f32(gp.p[P_VT_N1W] + (tid - 352), accB);
-  if (tid >= 432 && tid < 512) atomic_add_f32(gp.p[P_VT_N1B] + (tid - 432), accB);
+  if (tid < 80) {
+    atomic_add_f32(gp.p[P_VT_N2W] + tid, accN2);
+    atomic_add_f32(gp.p[P_VT_N1W] + tid, accN1);
+  } else if (tid < 160) {
+    atomic_add_f32(gp.p[P_VT_N2B] + (tid - 80), accN2);
+    atomic_add_f32(gp.p[P_VT_N1B] + (tid - 80), accN1);
+  }
 }
 
 hipError_t launch_view_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* x_tokens, const float* rgbm,

@@ -1,0 +1,35 @@
+"""Development probe: per-phase cycle counts of view_bwd_kernel (needs lib/libufr_timing.so: python -m uforecon_amd.build
+--variant timing -DUFR_BWD_TIMING; run with UFR_LIB pointing at it)."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from uforecon_amd import _lib, ops
+import test_gpu_backward as T
+
+fr, P, W, fh, ray_o, ray_d, z, x, rgbm, dirs, dbg = T._token_inputs("c5_train_grads")
+RN, SN = z.shape
+# replicate the rays to get a realistic launch (many tiles per workgroup)
+rep = 32
+x, rgbm, dirs = x.repeat(rep, 1, 1), rgbm.repeat(rep, 1, 1), dirs.repeat(rep, 1, 1)
+RN *= rep
+radiance, srdf, agg = ops.aggregate(W, x, rgbm, dirs, RN, SN, keep_workspace=True)
+lib = _lib.load()
+buf = (C.c_ulonglong * 64)()
+lib.ufr_debug_vb_phases(buf, 64, 1)
+grads = ops.GradBuffer("cuda:0")
+d_rad, d_srdf = torch.rand(RN * SN, 3, device="cuda:0"), torch.rand(RN, SN, device="cuda:0")
+torch.cuda.synchronize()
+import time
+t = time.perf_counter()
+ops.aggregate_bwd(W, grads, x, rgbm, dirs, agg["token0"], RN, SN, d_rad, d_srdf)
+torch.cuda.synchronize()
+print("aggregate_bwd ms", (time.perf_counter() - t) * 1e3, "points", RN * SN)
+lib.ufr_debug_vb_phases(buf, 64, 0)
+tot = sum(buf)
+names = ["P0 load", "P1 qkv", "P2 attn", "P3 merge", "P4 LN1", "P5 mlp0", "P6 mlp2", "P7 LN2", "P8 rw0", "P9 h2", "zero dlogit",
+         "softmax", "B1a dh2", "B1b dh1", "B2 dy", "B3 LN2b", "B4 dhid", "B5 dcat", "B6 LN1b", "B7 dmsg", "B8 attn q", "B9 attn kv",
+         "B10 dx", "B11+B12 out+wgrad"]
+for i, v in enumerate(buf):
+    if v:
+        print(f"{i:2d} {names[i] if i < len(names) else '':20s} {v:12d} {100.0 * v / tot:5.1f}%")

@@ -24,6 +24,18 @@ constexpr int kLD = 17;   // LDS row stride (floats)
 
 struct GradPtrs { float* p[P_COUNT]; };
 
+// development build (-DUFR_BWD_TIMING): cycles between consecutive barriers of workgroup 0, summed over its tiles
+#ifdef UFR_BWD_TIMING
+#define UFR_BWD_PHASE(arr, i)                                          \
+  if (blockIdx.x == 0 && threadIdx.x == 0) {                           \
+    const unsigned long long t_now = __builtin_readcyclecounter();     \
+    arr[i] += t_now - t_prev;                                          \
+    t_prev = t_now;                                                    \
+  }
+#else
+#define UFR_BWD_PHASE(arr, i)
+#endif
+
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
 
 // Every LDS / global address of these kernels is a function of the thread index and compile-time constants, i.e.
@@ -42,43 +54,88 @@ __device__ __forceinline__ int opaque(int v) {
 // Row tile rt belongs to wave (rt + rt_shift) % kBwdWaves: consecutive GEMMs of one phase pass the running tile count
 // so that their tiles are dealt round-robin over the waves.
 // k-order inside a 16-chunk: MFMA step kk contracts k = 16*kc + 4*g + kk (lane group g), for both operands.
+// A operands of one row tile of a GEMM: [k chunk][MFMA step]
+template <int IN>
+struct AFrag { float a[(IN + 15) / 16][4]; };
+
+// All A operands of a row tile are fetched in one burst (branch-free: out-of-range rows read a valid row whose
+// results are never stored, out-of-range k reads element 0 and is zeroed by a select).
+template <int OUT, int IN, bool TRANS>
+__device__ __forceinline__ void gemm_load_a(const float* __restrict__ W, int ldw, int rt, int lane, AFrag<IN>& f) {
+  constexpr int KC = (IN + 15) / 16, FULL = IN / 16;
+  const int g = lane >> 4, j = lane & 15;
+  int row = rt * 16 + j;
+  row = row < OUT ? row : OUT - 1;
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    const int kb = kc * 16 + 4 * g;
+    if constexpr (!TRANS && (IN % 4 == 0)) {
+      const bool ok = kc < FULL || kb < IN;          // IN % 4 == 0: a float4 is all in or all out
+      f32x4 a4 = ld4(W + (size_t)row * ldw + (ok ? kb : 0));
+      if (!ok) a4 = splat4(0.f);
+      f.a[kc][0] = a4[0]; f.a[kc][1] = a4[1]; f.a[kc][2] = a4[2]; f.a[kc][3] = a4[3];
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const bool ok = kc < FULL || kb + kk < IN;
+        const int k = ok ? kb + kk : 0;
+        const float v = TRANS ? W[(size_t)k * ldw + row] : W[(size_t)row * ldw + k];
+        f.a[kc][kk] = ok ? v : 0.f;
+      }
+    }
+  }
+}
+
+// first row tile of this wave in a GEMM whose tiles start at position rt_shift of the phase's round-robin
+__device__ __forceinline__ int gemm_first_rt(int wave, int rt_shift) {
+  return (wave + kBwdWaves * 64 - rt_shift) % kBwdWaves;
+}
+
+// Issue the A burst of this wave's first row tile.  Called BEFORE the barrier that publishes the GEMM's B operand, so
+// the L2 latency of the weights overlaps the tail of the previous phase and the barrier wait.
+template <int OUT, int IN, bool TRANS>
+__device__ __forceinline__ AFrag<IN> gemm_prefetch(const float* __restrict__ W, int ldw, int wave, int lane, int rt_shift = 0) {
+  constexpr int RT = (OUT + 15) / 16;
+  AFrag<IN> f;
+  int opaque_zero;   // weights are invariant over the tile loop: keep LICM from hoisting the loads out of it
+  asm volatile("s_mov_b32 %0, 0" : "=s"(opaque_zero));
+  const int rt = gemm_first_rt(wave, rt_shift);
+  if (rt < RT) gemm_load_a<OUT, IN, TRANS>(W + opaque_zero, ldw, rt, opaque(lane), f);
+  return f;
+}
+
 template <int OUT, int IN, bool TRANS, typename Epi>
-__device__ __forceinline__ void gemm_lds(const float* __restrict__ W, int ldw, const float* X, int wave, int lane,
-                                         Epi epi, int rt_shift = 0) {
-  constexpr int RT = (OUT + 15) / 16, KC = (IN + 15) / 16;
+__device__ __forceinline__ void gemm_compute(AFrag<IN>& cur, const float* __restrict__ W, int ldw, const float* X, int wave,
+                                             int lane, Epi epi, int rt_shift = 0) {
+  constexpr int RT = (OUT + 15) / 16, KC = (IN + 15) / 16, FULL = IN / 16;
   lane = opaque(lane);
   const int g = lane >> 4, j = lane & 15;
-  // the weights are loop-invariant over the kernel's tile loop: without an opaque offset LICM hoists every A-operand
-  // load of every layer out of that loop (hundreds of spilled registers)
   int opaque_zero;
   asm volatile("s_mov_b32 %0, 0" : "=s"(opaque_zero));
   W += opaque_zero;
-  for (int rt = (wave + kBwdWaves * 64 - rt_shift) % kBwdWaves; rt < RT; rt += kBwdWaves) {
+  // the B operand (this tile's activations) is the same for every row tile of the wave: one LDS burst per GEMM
+  float b[KC][4];
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    const int kb = kc * 16 + 4 * g;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const bool ok = kc < FULL || kb + kk < IN;      // A is zero there, but the LDS row may hold anything (NaN)
+      const float v = X[(ok ? kb + kk : 0) * kLD + j];
+      b[kc][kk] = ok ? v : 0.f;
+    }
+  }
+  for (int rt = gemm_first_rt(wave, rt_shift); rt < RT; rt += kBwdWaves) {
+    AFrag<IN> nxt;
+    const bool more = rt + kBwdWaves < RT;
+    if (more) gemm_load_a<OUT, IN, TRANS>(W, ldw, rt + kBwdWaves, lane, nxt);   // next row tile's burst rides on these MFMAs
     f32x4 acc0 = splat4(0.f), acc1 = splat4(0.f);
-    const int row = rt * 16 + j;
-    const bool row_ok = row < OUT;
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
-      const int kb = kc * 16 + 4 * g;
-      float a[4], b[4];
-      if constexpr (!TRANS && (IN % 4 == 0)) {
-        // ldw % 4 == 0 for every such matrix (rows are 16-byte aligned)
-        f32x4 a4 = (row_ok && kb < IN) ? ld4(W + (size_t)row * ldw + kb) : splat4(0.f);
-        a[0] = a4[0]; a[1] = a4[1]; a[2] = a4[2]; a[3] = a4[3];
-      } else {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const int k = kb + kk;
-          const bool ok = row_ok && k < IN;
-          a[kk] = ok ? (TRANS ? W[(size_t)k * ldw + row] : W[(size_t)row * ldw + k]) : 0.f;
-        }
-      }
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) b[kk] = (kb + kk < IN) ? X[(kb + kk) * kLD + j] : 0.f;
-      acc0 = mfma16(a[0], b[0], acc0);
-      acc1 = mfma16(a[1], b[1], acc1);
-      acc0 = mfma16(a[2], b[2], acc0);
-      acc1 = mfma16(a[3], b[3], acc1);
+      acc0 = mfma16(cur.a[kc][0], b[kc][0], acc0);
+      acc1 = mfma16(cur.a[kc][1], b[kc][1], acc1);
+      acc0 = mfma16(cur.a[kc][2], b[kc][2], acc0);
+      acc1 = mfma16(cur.a[kc][3], b[kc][3], acc1);
     }
     const f32x4 acc = acc0 + acc1;
 #pragma unroll
@@ -86,7 +143,16 @@ __device__ __forceinline__ void gemm_lds(const float* __restrict__ W, int ldw, c
       const int orow = rt * 16 + 4 * g + r;
       if (orow < OUT) epi(orow, j, acc[r]);
     }
+    if (more) cur = nxt;
   }
+}
+
+// prefetch + compute in one call (phases whose B operand is already published)
+template <int OUT, int IN, bool TRANS, typename Epi>
+__device__ __forceinline__ void gemm_lds(const float* __restrict__ W, int ldw, const float* X, int wave, int lane,
+                                         Epi epi, int rt_shift = 0) {
+  AFrag<IN> f = gemm_prefetch<OUT, IN, TRANS>(W, ldw, wave, lane, rt_shift);
+  gemm_compute<OUT, IN, TRANS>(f, W, ldw, X, wave, lane, epi, rt_shift);
 }
 
 // one 16x16 tile of dW += dY X^T over the tile's 16 tokens
@@ -146,16 +212,40 @@ __host__ __device__ constexpr WgTile wg_decode(const WgList<N>& l, int tile) {
   return WgTile{l.m[mi].param, l.m[mi].OUT, l.m[mi].IN, l.m[mi].dy, l.m[mi].x, (local / ct) * 16, (local % ct) * 16, true};
 }
 
-// accumulate every tile of the list that wave WAVE owns (slot s <-> tile s*kBwdWaves + WAVE); SLOT0 = first slot
+// accumulate every tile of the list that wave WAVE owns (slot s <-> tile s*kBwdWaves + WAVE); SLOT0 = first slot.
+// Slots are processed in groups of kWgGroup: all LDS operand reads of a group are issued first, then its MFMAs with
+// the group's independent accumulators interleaved (four 40-cycle dependent chains keep the 32-cycle issue rate).
+constexpr int kWgGroup = 4;
 template <const auto& LIST, int N, int NSLOT, int SLOT0, int WAVE, int NACC>
 __device__ __forceinline__ void wgrad_wave(f32x4 (&acc)[NACC], const float* lds, int lane) {
   static_assert(SLOT0 + NSLOT <= NACC, "accumulator slots");
   lane = opaque(lane);
-  static_for<NSLOT>([&](auto si) __attribute__((always_inline)) {
-    constexpr int s = decltype(si)::value;
-    constexpr WgTile t = wg_decode(LIST, s * kBwdWaves + WAVE);
-    if constexpr (t.valid)
-      acc[SLOT0 + s] = wgrad_tile(acc[SLOT0 + s], lds + t.dy * kLD, lds + t.x * kLD, t.o0, t.i0, t.OUT, t.IN, lane);
+  const int g = lane >> 4, j = lane & 15;
+  static_for<(NSLOT + kWgGroup - 1) / kWgGroup>([&](auto gi) __attribute__((always_inline)) {
+    constexpr int s0 = decltype(gi)::value * kWgGroup;
+    float a[kWgGroup][4], b[kWgGroup][4];
+    static_for<kWgGroup>([&](auto ui) __attribute__((always_inline)) {
+      constexpr int u = decltype(ui)::value;
+      constexpr WgTile t = wg_decode(LIST, (s0 + u) * kBwdWaves + WAVE);
+      if constexpr (s0 + u < NSLOT && t.valid) {
+        const bool ao = t.o0 + j < t.OUT, bo = t.i0 + j < t.IN;
+        const float* pa = lds + (t.dy + (ao ? t.o0 + j : 0)) * kLD + g;
+        const float* pb = lds + (t.x + (bo ? t.i0 + j : 0)) * kLD + g;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float va = pa[4 * q], vb = pb[4 * q];
+          a[u][q] = ao ? va : 0.f;
+          b[u][q] = bo ? vb : 0.f;
+        }
+      }
+    });
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      static_for<kWgGroup>([&](auto ui) __attribute__((always_inline)) {
+        constexpr int u = decltype(ui)::value;
+        constexpr WgTile t = wg_decode(LIST, (s0 + u) * kBwdWaves + WAVE);
+        if constexpr (s0 + u < NSLOT && t.valid) acc[SLOT0 + s0 + u] = mfma16(a[u][q], b[u][q], acc[SLOT0 + s0 + u]);
+      });
   });
 }
 template <const auto& LIST, int N, int NSLOT, int SLOT0, int NACC>

@@ -91,9 +91,10 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
     float kv[kKVPer] = {};
     for (int sub = 0; sub < n_sub; ++sub) {
       load_x(ray, sub * kTT);
+      auto pf0 = gemm_prefetch<88, 88, false>(wp.p[P_RT_K], 88, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_lds<88, 88, false>(wp.p[P_RT_K], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = elu1(v); });
+      gemm_compute<88, 88, false>(pf0, wp.p[P_RT_K], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = elu1(v); });
       gemm_lds<88, 88, false>(wp.p[P_RT_V], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_V + r)[c] = v / fS; }, 6);
       __syncthreads();
     tid = opaque(tid0);
@@ -126,9 +127,10 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       const int s0 = sub * kTT;
       load_x(ray, s0);
       if (tid < kTT) R(O_DSRDF)[tid] = d_srdf[(size_t)ray * SN + s0 + tid];
+      auto pf1 = gemm_prefetch<88, 88, false>(wp.p[P_RT_Q], 88, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_lds<88, 88, false>(wp.p[P_RT_Q], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_Q + r)[c] = v; });
+      gemm_compute<88, 88, false>(pf1, wp.p[P_RT_Q], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_Q + r)[c] = v; });
       __syncthreads();
     tid = opaque(tid0);
       // message of (token, head): t = Q' KV_h, den = Q'.sum K', msg = t * Z * SN (linear_attention.py:43-44)
@@ -151,30 +153,35 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
         for (int e = 0; e < 11; ++e) R(O_MSG + 11 * h + e)[col] = t[e] * (Z * fS);
         R(O_Z + h)[col] = Z;
       }
+      auto pf2 = gemm_prefetch<88, 88, false>(wp.p[P_RT_MERGE], 88, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_lds<88, 88, false>(wp.p[P_RT_MERGE], 88, R(O_MSG), wave, lane, [&](int r, int c, float v) { R(O_XH1 + r)[c] = v; });
+      gemm_compute<88, 88, false>(pf2, wp.p[P_RT_MERGE], 88, R(O_MSG), wave, lane, [&](int r, int c, float v) { R(O_XH1 + r)[c] = v; });
       __syncthreads();
     tid = opaque(tid0);
       ln_forward<88>(R(O_XH1), R(O_CAT + 88), nullptr, wp.p[P_RT_N1W], wp.p[P_RT_N1B], R(O_RSTD1), tid);
+      auto pf3 = gemm_prefetch<176, 176, false>(wp.p[P_RT_MLP0], 176, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_lds<176, 176, false>(wp.p[P_RT_MLP0], 176, R(O_CAT), wave, lane,
+      gemm_compute<176, 176, false>(pf3, wp.p[P_RT_MLP0], 176, R(O_CAT), wave, lane,
                                 [&](int r, int c, float v) { R(O_HID + r)[c] = fmaxf(v, 0.f); });
+      auto pf4 = gemm_prefetch<88, 176, false>(wp.p[P_RT_MLP2], 176, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_lds<88, 176, false>(wp.p[P_RT_MLP2], 176, R(O_HID), wave, lane, [&](int r, int c, float v) { R(O_XH2 + r)[c] = v; });
+      gemm_compute<88, 176, false>(pf4, wp.p[P_RT_MLP2], 176, R(O_HID), wave, lane, [&](int r, int c, float v) { R(O_XH2 + r)[c] = v; });
       __syncthreads();
     tid = opaque(tid0);
       ln_forward<88>(R(O_XH2), R(O_Y), R(O_CAT), wp.p[P_RT_N2W], wp.p[P_RT_N2B], R(O_RSTD2), tid);
+      auto pf5 = gemm_prefetch<32, 88, false>(wp.p[P_DM_W0], 88, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
       // DensityMLP 88 -> 32 -> 16 (-> 1) (ray_transformer.py:147-150, 307)
-      gemm_lds<32, 88, false>(wp.p[P_DM_W0], 88, R(O_Y), wave, lane,
+      gemm_compute<32, 88, false>(pf5, wp.p[P_DM_W0], 88, R(O_Y), wave, lane,
                               [&](int r, int c, float v) { R(O_D1 + r)[c] = fmaxf(v + wp.p[P_DM_B0][r], 0.f); });
+      auto pf6 = gemm_prefetch<16, 32, false>(wp.p[P_DM_W2], 32, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_lds<16, 32, false>(wp.p[P_DM_W2], 32, R(O_D1), wave, lane,
+      gemm_compute<16, 32, false>(pf6, wp.p[P_DM_W2], 32, R(O_D1), wave, lane,
                               [&](int r, int c, float v) { R(O_D2 + r)[c] = fmaxf(v + wp.p[P_DM_B2][r], 0.f); });
       __syncthreads();
     tid = opaque(tid0);
@@ -183,25 +190,29 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
         const int o = tid >> 4, c = tid & 15;
         R(O_DD2 + o)[c] = R(O_D2 + o)[c] > 0.f ? wp.p[P_DM_W4][o] * R(O_DSRDF)[c] : 0.f;
       }
+      auto pf7 = gemm_prefetch<32, 16, true>(wp.p[P_DM_W2], 32, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_lds<32, 16, true>(wp.p[P_DM_W2], 32, R(O_DD2), wave, lane,
+      gemm_compute<32, 16, true>(pf7, wp.p[P_DM_W2], 32, R(O_DD2), wave, lane,
                              [&](int r, int c, float v) { R(O_DD1 + r)[c] = R(O_D1 + r)[c] > 0.f ? v : 0.f; });
+      auto pf8 = gemm_prefetch<88, 32, true>(wp.p[P_DM_W0], 88, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_lds<88, 32, true>(wp.p[P_DM_W0], 88, R(O_DD1), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] = v; });
+      gemm_compute<88, 32, true>(pf8, wp.p[P_DM_W0], 88, R(O_DD1), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] = v; });
       __syncthreads();
     tid = opaque(tid0);
       ln_backward<88>(R(O_DY), R(O_XH2), wp.p[P_RT_N2W], R(O_RSTD2), R(O_DOPRE), tid);
       if (tid < 88) accN2 += row_dot(R(O_DY), R(O_XH2), tid);
       else if (tid < 176) accN2 += row_dot(R(O_DY), nullptr, tid - 88);
+      auto pf9 = gemm_prefetch<176, 88, true>(wp.p[P_RT_MLP2], 176, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_lds<176, 88, true>(wp.p[P_RT_MLP2], 176, R(O_DOPRE), wave, lane,
+      gemm_compute<176, 88, true>(pf9, wp.p[P_RT_MLP2], 176, R(O_DOPRE), wave, lane,
                               [&](int r, int c, float v) { R(O_DHID + r)[c] = R(O_HID + r)[c] > 0.f ? v : 0.f; });
+      auto pf10 = gemm_prefetch<176, 176, true>(wp.p[P_RT_MLP0], 176, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_lds<176, 176, true>(wp.p[P_RT_MLP0], 176, R(O_DHID), wave, lane, [&](int r, int c, float v) { R(O_DCAT + r)[c] = v; });
+      gemm_compute<176, 176, true>(pf10, wp.p[P_RT_MLP0], 176, R(O_DHID), wave, lane, [&](int r, int c, float v) { R(O_DCAT + r)[c] = v; });
       __syncthreads();
     tid = opaque(tid0);
       ln_backward<88>(R(O_DCAT + 88), R(O_XH1), wp.p[P_RT_N1W], R(O_RSTD1), R(O_DMPRE), tid);
@@ -211,9 +222,10 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
         const int r = idx >> 4, c = idx & 15;
         R(O_DY + r)[c] += R(O_DCAT + r)[c];
       }
+      auto pf11 = gemm_prefetch<88, 88, true>(wp.p[P_RT_MERGE], 88, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_lds<88, 88, true>(wp.p[P_RT_MERGE], 88, R(O_DMPRE), wave, lane, [&](int r, int c, float v) { R(O_DMSG + r)[c] = v; });
+      gemm_compute<88, 88, true>(pf11, wp.p[P_RT_MERGE], 88, R(O_DMPRE), wave, lane, [&](int r, int c, float v) { R(O_DMSG + r)[c] = v; });
       __syncthreads();
     tid = opaque(tid0);
       // attention backwards, query side: d t = d msg Z SN; d den = -SN Z^2 (d msg . t); d Q' = KV d t + d den sum K'
@@ -309,9 +321,10 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
     for (int sub = 0; sub < n_sub; ++sub) {
       const int s0 = sub * kTT;
       load_x(ray, s0);
+      auto pf12 = gemm_prefetch<88, 88, false>(wp.p[P_RT_K], 88, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_lds<88, 88, false>(wp.p[P_RT_K], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = v; });
+      gemm_compute<88, 88, false>(pf12, wp.p[P_RT_K], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = v; });
       gemm_lds<88, 88, false>(wp.p[P_RT_V], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_V + r)[c] = v; }, 6);
       __syncthreads();
     tid = opaque(tid0);
@@ -339,9 +352,10 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
 #pragma unroll
         for (int e = 0; e < 11; ++e) R(O_DV + 11 * h + e)[col] = dv[e] / fS;
       }
+      auto pf13 = gemm_prefetch<88, 88, true>(wp.p[P_RT_K], 88, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_lds<88, 88, true>(wp.p[P_RT_K], 88, R(O_DK), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] = v; });
+      gemm_compute<88, 88, true>(pf13, wp.p[P_RT_K], 88, R(O_DK), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] = v; });
       gemm_lds<88, 88, true>(wp.p[P_RT_V], 88, R(O_DV), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
       __syncthreads();
     tid = opaque(tid0);
@@ -409,21 +423,25 @@ __global__ void __launch_bounds__(kBwdThreads) presim_bwd_kernel(RawPtrs wp, Gra
         R(O_DO + i)[c] = p < P ? d_pv[(size_t)p * 40 + 24 + i] : 0.f;
       }
     }
+    auto pf14 = gemm_prefetch<32, 8, false>(wp.p[P_PS_W0], 8, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
-    gemm_lds<32, 8, false>(wp.p[P_PS_W0], 8, R(O_S8), wave, lane,
+    gemm_compute<32, 8, false>(pf14, wp.p[P_PS_W0], 8, R(O_S8), wave, lane,
                            [&](int r, int c, float v) { R(O_A1 + r)[c] = fmaxf(v + wp.p[P_PS_B0][r], 0.f); });
+    auto pf15 = gemm_prefetch<32, 32, false>(wp.p[P_PS_W2], 32, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
-    gemm_lds<32, 32, false>(wp.p[P_PS_W2], 32, R(O_A1), wave, lane,
+    gemm_compute<32, 32, false>(pf15, wp.p[P_PS_W2], 32, R(O_A1), wave, lane,
                             [&](int r, int c, float v) { R(O_A2 + r)[c] = fmaxf(v + wp.p[P_PS_B2][r], 0.f); });
+    auto pf16 = gemm_prefetch<32, 16, true>(wp.p[P_PS_W4], 32, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
-    gemm_lds<32, 16, true>(wp.p[P_PS_W4], 32, R(O_DO), wave, lane,
+    gemm_compute<32, 16, true>(pf16, wp.p[P_PS_W4], 32, R(O_DO), wave, lane,
                            [&](int r, int c, float v) { R(O_DA2 + r)[c] = R(O_A2 + r)[c] > 0.f ? v : 0.f; });
+    auto pf17 = gemm_prefetch<32, 32, true>(wp.p[P_PS_W2], 32, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
-    gemm_lds<32, 32, true>(wp.p[P_PS_W2], 32, R(O_DA2), wave, lane,
+    gemm_compute<32, 32, true>(pf17, wp.p[P_PS_W2], 32, R(O_DA2), wave, lane,
                            [&](int r, int c, float v) { R(O_DA1 + r)[c] = R(O_A1 + r)[c] > 0.f ? v : 0.f; });
     __syncthreads();
     tid = opaque(tid0);

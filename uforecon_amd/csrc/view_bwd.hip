@@ -50,6 +50,10 @@ constexpr int kSlots = (kList.first[7] + kBwdWaves - 1) / kBwdWaves;   // 256 ti
 constexpr int kDbgCols = 881;
 }  // namespace vb
 
+#ifdef UFR_BWD_TIMING
+__device__ unsigned long long g_vb_phase[64];
+#endif
+
 __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradPtrs gp, const float* __restrict__ x_tokens,
                                                                const float* __restrict__ rgbm,
                                                                const float* __restrict__ dirs,
@@ -72,6 +76,9 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
 
   auto R = [&](int row) -> float* { return lds + row * kLD; };
 
+#ifdef UFR_BWD_TIMING
+  unsigned long long t_prev = __builtin_readcyclecounter();
+#endif
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int p0 = tile * PPT;
     // ---------------- P0: token inputs (ray_transformer.py:284-286), dir, staged d token0
@@ -101,15 +108,18 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
 #pragma unroll
       for (int e = 0; e < 3; ++e) R(O_RIN + 80 + e)[col] = ok ? dirs[((size_t)p * NV + tv - 1) * 4 + e] : 0.f;
     }
+    auto pf0 = gemm_prefetch<80, 80, false>(wp.p[P_VT_Q], 80, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
+    UFR_BWD_PHASE(g_vb_phase, 0)
 
     // ---------------- P1: q, k, v (15 row tiles dealt over the 8 waves)
-    gemm_lds<80, 80, false>(wp.p[P_VT_Q], 80, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_Q + r)[c] = v; });
+    gemm_compute<80, 80, false>(pf0, wp.p[P_VT_Q], 80, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_Q + r)[c] = v; });
     gemm_lds<80, 80, false>(wp.p[P_VT_K], 80, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = v; }, 5);
     gemm_lds<80, 80, false>(wp.p[P_VT_V], 80, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_V + r)[c] = v; }, 10);
     __syncthreads();
     tid = opaque(tid0);
+    UFR_BWD_PHASE(g_vb_phase, 1)
 
     // ---------------- P2: linear attention over the L tokens of each point (linear_attention.py:31-45) in score form:
     // A[s'] = Q'.K'_s', msg = u * sum_s' A[s'] V_s'  with V = v/L and u = L / (sum_s' A[s'] + eps)
@@ -138,32 +148,43 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
       for (int e = 0; e < 10; ++e) R(O_MSG + 10 * h + e)[col] = msg[e] * u;
       R(O_U + h)[col] = u;
     }
+    auto pf1 = gemm_prefetch<80, 80, false>(wp.p[P_VT_MERGE], 80, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
+    UFR_BWD_PHASE(g_vb_phase, 2)
 
     // ---------------- P3/P4: merge + LayerNorm1 (transformer.py:51-52)
-    gemm_lds<80, 80, false>(wp.p[P_VT_MERGE], 80, R(O_MSG), wave, lane, [&](int r, int c, float v) { R(O_XH1 + r)[c] = v; });
+    gemm_compute<80, 80, false>(pf1, wp.p[P_VT_MERGE], 80, R(O_MSG), wave, lane, [&](int r, int c, float v) { R(O_XH1 + r)[c] = v; });
     __syncthreads();
     tid = opaque(tid0);
+    UFR_BWD_PHASE(g_vb_phase, 3)
     ln_forward<80>(R(O_XH1), R(O_CAT + 80), nullptr, wp.p[P_VT_N1W], wp.p[P_VT_N1B], R(O_RSTD1), tid);
+    auto pf2 = gemm_prefetch<160, 160, false>(wp.p[P_VT_MLP0], 160, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
+    UFR_BWD_PHASE(g_vb_phase, 4)
     // ---------------- P5-P7: MLP on [x | m], LayerNorm2, residual (transformer.py:55-58)
-    gemm_lds<160, 160, false>(wp.p[P_VT_MLP0], 160, R(O_CAT), wave, lane,
+    gemm_compute<160, 160, false>(pf2, wp.p[P_VT_MLP0], 160, R(O_CAT), wave, lane,
                               [&](int r, int c, float v) { R(O_HID + r)[c] = fmaxf(v, 0.f); });
+    auto pf3 = gemm_prefetch<80, 160, false>(wp.p[P_VT_MLP2], 160, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
-    gemm_lds<80, 160, false>(wp.p[P_VT_MLP2], 160, R(O_HID), wave, lane, [&](int r, int c, float v) { R(O_XH2 + r)[c] = v; });
+    UFR_BWD_PHASE(g_vb_phase, 5)
+    gemm_compute<80, 160, false>(pf3, wp.p[P_VT_MLP2], 160, R(O_HID), wave, lane, [&](int r, int c, float v) { R(O_XH2 + r)[c] = v; });
     __syncthreads();
     tid = opaque(tid0);
+    UFR_BWD_PHASE(g_vb_phase, 6)
     ln_forward<80>(R(O_XH2), R(O_RIN), R(O_CAT), wp.p[P_VT_N2W], wp.p[P_VT_N2B], R(O_RSTD2), tid);
+    auto pf4 = gemm_prefetch<16, 83, false>(wp.p[P_RW_W0], 83, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
+    UFR_BWD_PHASE(g_vb_phase, 7)
     // ---------------- P8-P10: radiance-weight MLP 83 -> 16 -> 8 -> 1 (ray_transformer.py:159-163, 313-314)
-    gemm_lds<16, 83, false>(wp.p[P_RW_W0], 83, R(O_RIN), wave, lane,
+    gemm_compute<16, 83, false>(pf4, wp.p[P_RW_W0], 83, R(O_RIN), wave, lane,
                             [&](int r, int c, float v) { R(O_H1 + r)[c] = fmaxf(v + wp.p[P_RW_B0][r], 0.f); });
     __syncthreads();
     tid = opaque(tid0);
+    UFR_BWD_PHASE(g_vb_phase, 8)
     if (tid < 8 * kTT) {
       const int o = tid >> 4, c = tid & 15;
       float s = wp.p[P_RW_B2][o];
@@ -173,10 +194,12 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     }
     __syncthreads();
     tid = opaque(tid0);
+    UFR_BWD_PHASE(g_vb_phase, 9)
     // masked softmax over the views of a point and its adjoint (ray_transformer.py:315-319): one thread per point
     if (tid < kTT) R(O_DLOGIT)[tid] = 0.f;
     __syncthreads();
     tid = opaque(tid0);
+    UFR_BWD_PHASE(g_vb_phase, 10)
     if (tid < PPT && p0 + tid < P) {
       const int pt = tid, p = p0 + pt;
       float lg[UFR_MAX_VIEWS], cr[UFR_MAX_VIEWS], cg[UFR_MAX_VIEWS], cb[UFR_MAX_VIEWS], mk[UFR_MAX_VIEWS];
@@ -209,6 +232,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     }
     __syncthreads();
     tid = opaque(tid0);
+    UFR_BWD_PHASE(g_vb_phase, 11)
     // ---------------- B1: radiance MLP backwards
     if (tid < 8 * kTT) {
       const int o = tid >> 4, c = tid & 15;
@@ -216,6 +240,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     }
     __syncthreads();
     tid = opaque(tid0);
+    UFR_BWD_PHASE(g_vb_phase, 12)
     if (tid < 16 * kTT) {
       const int i = tid >> 4, c = tid & 15;
       float s = 0.f;
@@ -223,26 +248,34 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
       for (int o = 0; o < 8; ++o) s = fmaf(wp.p[P_RW_W2][o * 16 + i], R(O_DH2 + o)[c], s);
       R(O_DH1 + i)[c] = R(O_H1 + i)[c] > 0.f ? s : 0.f;
     }
+    auto pf5 = gemm_prefetch<80, 16, true>(wp.p[P_RW_W0], 83, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
+    UFR_BWD_PHASE(g_vb_phase, 13)
     // ---------------- B2: d y = W0^T d h1 (the 80 feature columns) + d token0 (staged in P0)
-    gemm_lds<80, 16, true>(wp.p[P_RW_W0], 83, R(O_DH1), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
+    gemm_compute<80, 16, true>(pf5, wp.p[P_RW_W0], 83, R(O_DH1), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
     __syncthreads();
     tid = opaque(tid0);
+    UFR_BWD_PHASE(g_vb_phase, 14)
     // ---------------- B3: LayerNorm2 backwards; y = x + LN2(.) so d x starts as d y
     ln_backward<80>(R(O_DY), R(O_XH2), wp.p[P_VT_N2W], R(O_RSTD2), R(O_DOPRE), tid);
     if (tid < 80) accN2 += row_dot(R(O_DY), R(O_XH2), tid);
     else if (tid < 160) accN2 += row_dot(R(O_DY), nullptr, tid - 80);
+    auto pf6 = gemm_prefetch<160, 80, true>(wp.p[P_VT_MLP2], 160, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
+    UFR_BWD_PHASE(g_vb_phase, 15)
     // ---------------- B4/B5: MLP backwards
-    gemm_lds<160, 80, true>(wp.p[P_VT_MLP2], 160, R(O_DOPRE), wave, lane,
+    gemm_compute<160, 80, true>(pf6, wp.p[P_VT_MLP2], 160, R(O_DOPRE), wave, lane,
                             [&](int r, int c, float v) { R(O_DHID + r)[c] = R(O_HID + r)[c] > 0.f ? v : 0.f; });
+    auto pf7 = gemm_prefetch<160, 160, true>(wp.p[P_VT_MLP0], 160, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
-    gemm_lds<160, 160, true>(wp.p[P_VT_MLP0], 160, R(O_DHID), wave, lane, [&](int r, int c, float v) { R(O_DCAT + r)[c] = v; });
+    UFR_BWD_PHASE(g_vb_phase, 16)
+    gemm_compute<160, 160, true>(pf7, wp.p[P_VT_MLP0], 160, R(O_DHID), wave, lane, [&](int r, int c, float v) { R(O_DCAT + r)[c] = v; });
     __syncthreads();
     tid = opaque(tid0);
+    UFR_BWD_PHASE(g_vb_phase, 17)
     // ---------------- B6: LayerNorm1 backwards on the message half; the x half joins the d x accumulator
     ln_backward<80>(R(O_DCAT + 80), R(O_XH1), wp.p[P_VT_N1W], R(O_RSTD1), R(O_DMPRE), tid);
     if (tid < 80) accN1 += row_dot(R(O_DCAT + 80), R(O_XH1), tid);
@@ -251,12 +284,15 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
       const int r = idx >> 4, c = idx & 15;
       R(O_DY + r)[c] += R(O_DCAT + r)[c];
     }
+    auto pf8 = gemm_prefetch<80, 80, true>(wp.p[P_VT_MERGE], 80, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
+    UFR_BWD_PHASE(g_vb_phase, 18)
     // ---------------- B7: merge backwards
-    gemm_lds<80, 80, true>(wp.p[P_VT_MERGE], 80, R(O_DMPRE), wave, lane, [&](int r, int c, float v) { R(O_DMSG + r)[c] = v; });
+    gemm_compute<80, 80, true>(pf8, wp.p[P_VT_MERGE], 80, R(O_DMPRE), wave, lane, [&](int r, int c, float v) { R(O_DMSG + r)[c] = v; });
     __syncthreads();
     tid = opaque(tid0);
+    UFR_BWD_PHASE(g_vb_phase, 19)
     // ---------------- B8: attention backwards, query side (thread = (token s, head)):
     //   msg = u r, r = sum_s' A[s'] V_s';  d r = u d msg;  d u = d msg . r;  d den = -d u u^2 / L;
     //   d A[s'] = d r . V_s' + d den;  d Q' = sum_s' d A[s'] K'_s'
@@ -302,6 +338,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     }
     __syncthreads();
     tid = opaque(tid0);
+    UFR_BWD_PHASE(g_vb_phase, 20)
     // ---------------- B9: key / value side (thread = (token s', head)): d K'_s' = sum_s d A[s][s'] Q'_s,
     //   d V_s' = sum_s A[s][s'] d r_s
     if (tid < kTT * 8) {
@@ -341,14 +378,17 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
         R(O_DV + 10 * h + d)[col] = dv[d] * invL;
       }
     }
+    auto pf9 = gemm_prefetch<80, 80, true>(wp.p[P_VT_Q], 80, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
+    UFR_BWD_PHASE(g_vb_phase, 21)
     // ---------------- B10: projections backwards into the d x accumulator (same lane owns an element in all three)
-    gemm_lds<80, 80, true>(wp.p[P_VT_Q], 80, R(O_DQ), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
+    gemm_compute<80, 80, true>(pf9, wp.p[P_VT_Q], 80, R(O_DQ), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
     gemm_lds<80, 80, true>(wp.p[P_VT_K], 80, R(O_DK), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
     gemm_lds<80, 80, true>(wp.p[P_VT_V], 80, R(O_DV), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
     __syncthreads();
     tid = opaque(tid0);
+    UFR_BWD_PHASE(g_vb_phase, 22)
     // ---------------- B11: outputs.  Token columns 32..55 (frustum features) and 56..71 (pre_sim_mlp) are the same for
     // all NV view tokens of a point (ray_transformer.py:258-281): their gradients add up.  Token 0 is the view token.
     for (int idx = tid; idx < PPT * 40; idx += kBwdThreads) {
@@ -393,6 +433,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     wgrad_all<vb::kList, 7, kSlots, 0>(acc, lds, wave, lane);
     __syncthreads();
     tid = opaque(tid0);
+    UFR_BWD_PHASE(g_vb_phase, 23)
   }
 
   // ---------------- flush (once per workgroup)
@@ -427,3 +468,16 @@ hipError_t launch_view_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* x
 }
 
 }  // namespace ufr
+
+#ifdef UFR_BWD_TIMING
+extern "C" int ufr_debug_vb_phases(unsigned long long* out, int n, int reset) {
+  unsigned long long h[64] = {};
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(ufr::g_vb_phase), sizeof(h)) != hipSuccess) return -1;
+  for (int i = 0; i < n && i < 64; ++i) out[i] = h[i];
+  if (reset) {
+    unsigned long long z[64] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(ufr::g_vb_phase), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

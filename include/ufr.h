@@ -90,8 +90,9 @@ typedef struct ufr_frame_desc {
   const float* source_imgs;       /* (NV,3,H,W)   batch['source_imgs']                               */
   const float* depth_info;        /* (NV,H,W)     batch['depth_info'] (model.py:807-808)             */
   const float* feat;              /* (NV,32,h,w)  source_imgs_feat                                   */
-  const float* match;             /* (NV,32*(NV-1),h,w) match_feature[0]                             */
-  const float* vol_feat[UFR_NUM_STAGES];   /* (NV,8,D,Hs,Ws) feature_volume[stage]['feature_volume']  */
+  const float* match;             /* (NV,32*(NV-1),h,w) match_feature[0]; NULL: ufr_project_gather needs sim8_in */
+  const float* vol_feat[UFR_NUM_STAGES];   /* (NV,8,D,Hs,Ws) feature_volume[stage]['feature_volume']; all NULL (with
+                                              vol_weight): ufr_project_gather needs vol24_in              */
   const float* vol_weight[UFR_NUM_STAGES]; /* (NV,1,D,Hs,Ws) feature_volume[stage]['weight_volume']   */
   int32_t vol_D[UFR_NUM_STAGES], vol_H[UFR_NUM_STAGES], vol_W[UFR_NUM_STAGES];
   /* camera constants, HOST pointers (copied) */
@@ -134,11 +135,15 @@ int ufr_points(const float* ray_o, int32_t ray_o_stride, const float* ray_d, con
  * query_cond_info (model.py:218-305), query_depth_from_volume (model.py:350-390) and
  * ray_transformer.py:185-281 up to the token assembly (incl. pre_sim_mlp).
  * Outputs: x_tokens (P,NV,80); rgb (P,NV,4) [r,g,b,mask]; dir (P,NV,4) [dx,dy,dz,0].
- * Optional debug outputs (may be NULL): sim8 (P,8), vol24 (P,24), xy (NV,P,2), mask_z (NV,P). */
+ * Optional outputs (may be NULL): sim8 (P,8) = cond_info['feat_info'], vol24 (P,24) = the blended frustum lookup,
+ * xy (NV,P,2) = points_pixel, mask_z (NV,P) = mask_valid.
+ * Optional inputs (may be NULL): vol24_in (P,24) / sim8_in (P,8) replace the kernel's own frustum lookup / pair
+ * similarity -- RayTransformer.forward receives them as `fea_volume` / cond_info['feat_info']
+ * (ray_transformer.py:175, 199, 265); a frame prepared without volumes / matching features requires them. */
 int ufr_project_gather(const ufr_frame* frame, const ufr_raw_weights* raw, const float* ray_o,
                        int32_t ray_o_stride, const float* ray_d, const float* z, int32_t RN, int32_t SN,
                        float* x_tokens, float* rgb, float* dir, float* sim8, float* vol24, float* xy,
-                       float* mask_z, ufr_stream stream);
+                       float* mask_z, const float* vol24_in, const float* sim8_in, ufr_stream stream);
 
 /* View transformer + ray transformer + SRDF / radiance heads (ray_transformer.py:283-320).
  * radiance: (P,3); srdf: (RN,SN).  workspace >= ufr_aggregate_workspace_bytes(RN,SN).
@@ -191,7 +196,7 @@ int ufr_aggregate_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, co
 /* Adjoint of ufr_project_gather w.r.t. the sampled volumes and pre_sim_mlp (autograd of model.py:350-390 and
  * ray_transformer.py:268).  sim8 (P,8): the forward's `sim8` output; d_pv (P,40) from ufr_aggregate_bwd.
  * grad_vol_feat[s] (NV,8,D,Hs,Ws) / grad_vol_weight[s] (NV,1,D,Hs,Ws): reference layout, ACCUMULATED (scatter-add);
- * pre_sim_mlp gradients are accumulated into `grads`. */
+ * both arrays NULL: only the pre_sim_mlp gradients (accumulated into `grads`) are computed. */
 int ufr_project_gather_bwd(const ufr_frame* frame, const ufr_raw_weights* raw, const ufr_raw_grads* grads,
                            const float* ray_o, int32_t ray_o_stride, const float* ray_d, const float* z, int32_t RN,
                            int32_t SN, const float* sim8, const float* d_pv, float* const* grad_vol_feat,

@@ -36,12 +36,14 @@ def test_unsupported_configurations_fail_loudly():
     with pytest.raises(ops.UfrError, match="volume_type"):
         M.RayTransformer(args=_args(volume_type="featuregrid"))
     m = M.UFORecon(_args())
-    with pytest.raises(ops.UfrError, match="fused"):
-        m.ray_transformer(None, None, None)
+    with pytest.raises(ops.UfrError, match="fea_volume"):       # featuregrid-style call without the frustum lookup
+        m.ray_transformer(torch.zeros(1, 2, 16, 3), {}, torch.zeros(1, 3, 32, 4, 4))
+    with pytest.raises(ops.UfrError, match="B=1"):
+        m.ray_transformer(torch.zeros(2, 2, 16, 3), {}, torch.zeros(2, 3, 32, 4, 4))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["c2_hier_small", "c1_coarse_only"])
+@pytest.mark.parametrize("name", ["c2_hier_small", "c1_coarse_only", "c2_hier_interior"])
 def test_infer_extract_geometry_matches_golden(name):
     c = CASES[name]
     fr, idx, U1, U2, g = case_inputs(name)
@@ -56,12 +58,141 @@ def test_infer_extract_geometry_matches_golden(name):
     assert tuple(srdf.shape) == g["srdf"][None].shape and tuple(pts.shape) == g["points"][None].shape
     assert max_rel_elem(depth[0], g["depth"], 1e-3) < REL_TOL
     assert rel_err(pts[0], g["points"]) < 1e-5
+    if c.get("interior"):       # no sample on an image border: RGB on every ray
+        assert max_rel_elem(rgb[0], g["rgb"], floor=0.05) < REL_TOL
+    else:                       # rays with a sample ON a border excepted (see test_gpu_parity)
+        from oracle import ufo_oracle as O
+
+        xy, _, mask_z = O.project(fr.batch["source_poses"][0], torch.from_numpy(g["points"]))   # the golden's own samples
+        ok = ~border_degenerate_rays(dict(xy=xy, mask_z=mask_z))
+        assert max_rel_elem(rgb[0][ok.to(dev)], torch.from_numpy(g["rgb"])[ok], floor=0.05) < REL_TOL
     # weights updated in place -> packed copy must follow
     with torch.no_grad():
         m.deviation_network.variance.add_(0.05)
         _, _, depth2, _ = m.infer(f.batch, idx.to(dev), f.source_imgs_feat, f.feature_volume, extract_geometry=True,
                                   match_feature=f.match_feature, is_train=False, uniforms=(U1, U2))
     assert float((depth2 - depth).abs().max()) > 1e-5
+
+
+def _rows_model(dev="cuda:0"):
+    fr, idx, U1, U2, g = case_inputs("rows_small")
+    m = M.UFORecon(_args()).to(dev)
+    m.load_state_dict(load_weights(), strict=True)
+    i = idx.reshape(-1)
+    ray_d = fr.batch["ray_d"][0][:, i].t().contiguous()
+    cz = fr.batch["cam_ray_d"][0][2, i]
+    near, far = fr.batch["near_fars"][0, 0, 0] / cz, fr.batch["near_fars"][0, 0, 1] / cz     # model.py:423-427
+    ray_o = fr.batch["ray_o"][0][None].expand(i.numel(), 3).contiguous()                       # model.py:411-412
+    return m, fr.to(dev), fr, idx, U1, U2, g, ray_o.to(dev), ray_d.to(dev), near.to(dev), far.to(dev)
+
+
+@pytest.mark.gpu
+def test_sampler_classes_match_golden_rows():
+    """FixedSampler.sample_ray / ImportanceSampler.sample_ray with the reference's argument shapes (sampler.py:15, 74)."""
+    from oracle import ufo_oracle as O
+
+    m, f, fr, idx, U1, U2, g, ray_o, ray_d, near, far = _rows_model()
+    pts, z, pd = m.fixed_sampler.sample_ray(ray_o, ray_d, near_z=near, far_z=far, uniforms=U1)
+    assert tuple(pts.shape) == g["coarse.pts"].shape and tuple(pd.shape) == g["coarse.pts"].shape
+    assert torch.equal(z.cpu(), torch.from_numpy(g["coarse.z"]))
+    assert torch.equal(pts.cpu(), torch.from_numpy(g["coarse.pts"]))
+    w = torch.from_numpy(g["coarse.weight"]).to(z.device)
+    pts2, z2, _ = m.importance_sampler.sample_ray(ray_o, ray_d, w, z, uniforms=U2)
+    _, z_ref = O.importance_sample(ray_o.cpu(), ray_d.cpu(), w.cpu(), z.cpu(), U2)     # same host: CDF rounding
+    assert tuple(pts2.shape) == (z.shape[0], 64, 3)
+    assert rel_err(z2, z_ref) < 5e-6
+    assert rel_err(m.importance_sampler.last_merged, g["fine.z"]) < 1e-5                 # vs the reference's own merge
+    assert rel_err(pts2, ray_o[:, None, :] + z2[..., None] * ray_d[:, None, :]) < 1e-6
+
+
+@pytest.mark.gpu
+def test_volume_renderer_class_matches_golden_rows():
+    """VolumeRenderer.render(z_val, radiance, geo_value, deviation_network=...) -> 5-tuple (renderer.py:7, 48)."""
+    m, f, fr, idx, U1, U2, g, *_ = _rows_model()
+    dev = "cuda:0"
+    RN, SN = g["coarse.z"].shape
+    rgb, depth, opacity, weight, var = m.renderer.render(
+        torch.from_numpy(g["coarse.z"]).to(dev), torch.from_numpy(g["coarse.radiance"]).reshape(RN, SN, 3).to(dev),
+        torch.from_numpy(g["coarse.srdf"]).to(dev), deviation_network=m.deviation_network)
+    assert rel_err(rgb, g["coarse.rgb"]) < 1e-5 and rel_err(depth, g["coarse.depth"]) < 1e-5
+    assert rel_err(opacity, g["coarse.opacity"]) < 1e-5 and rel_err(weight, g["coarse.weight"]) < 1e-5
+    assert rel_err(var, g["coarse.variance"]) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["coarse", "fine"])
+def test_sample2rgb_and_ray_transformer_forward_match_golden_rows(tag):
+    """UFORecon.sample2rgb (model.py:308-348, 7-tuple) and RayTransformer.forward (ray_transformer.py:175-322, 3-tuple)
+    called like the reference calls them, against the reference's own intermediates."""
+    m, f, fr, idx, U1, U2, g, ray_o, ray_d, near, far = _rows_model()
+    dev = "cuda:0"
+    z = torch.from_numpy(g[f"{tag}.z"]).to(dev)
+    pts = torch.from_numpy(g[f"{tag}.pts"]).to(dev)
+    RN, SN = z.shape
+    NV = 3
+    with torch.no_grad():
+        rgb, depth, srdf, opacity, weight, pip, var = m.sample2rgb(f.batch, pts[None], z[None], ray_d[None], idx.to(dev),
+                                                                   f.source_imgs_feat, f.feature_volume, f.match_feature)
+    assert tuple(rgb.shape) == (1, RN, 3) and tuple(srdf.shape) == (RN, SN, 1) and tuple(weight.shape) == (1, RN, SN)
+    assert tuple(pip.shape) == (1, NV, 2, RN, SN)
+    xy_ref = torch.from_numpy(g[f"{tag}.xy"])                                   # (NV,RN,SN,2)
+    assert rel_err(pip[0].permute(0, 2, 3, 1), xy_ref) < 5e-6
+    assert max_rel_elem(depth[0], g[f"{tag}.depth"], 1e-3) < REL_TOL
+    assert rel_err(srdf[..., 0], g[f"{tag}.srdf"]) < 1e-4
+    assert rel_err(weight[0], g[f"{tag}.weight"]) < 1e-4 and rel_err(opacity[0], g[f"{tag}.opacity"]) < 1e-4
+    assert rel_err(var, g[f"{tag}.variance"]) < 1e-6
+    ok = ~border_degenerate_rays(dict(xy=xy_ref, mask_z=torch.from_numpy(g[f"{tag}.mask_z"])))
+    assert max_rel_elem(rgb[0][ok.to(dev)], torch.from_numpy(g[f"{tag}.rgb"])[ok], floor=0.05) < REL_TOL
+
+    # RayTransformer.forward with the frustum lookup and the pair similarity as inputs
+    cond = {"feat_info": torch.from_numpy(g[f"{tag}.sim8"])[None].to(dev)}
+    vol = torch.from_numpy(g[f"{tag}.vol24"]).reshape(1, RN, SN, 24).to(dev)
+    with torch.no_grad():
+        radiance, srdf2, pip2 = m.ray_transformer(pts[None], f.batch, f.source_imgs_feat, fea_volume=vol, cond_info=cond,
+                                                  points_projected=xy_ref[None].to(dev),
+                                                  mask_valid=torch.from_numpy(g[f"{tag}.mask_z"])[None].to(dev))
+    assert tuple(radiance.shape) == (RN * SN, 3) and tuple(srdf2.shape) == (RN, SN, 1)
+    assert rel_err(srdf2[..., 0], g[f"{tag}.srdf"]) < 1e-4
+    assert rel_err(pip2[0].permute(0, 2, 3, 1), xy_ref) < 5e-6
+    pt_ok = ok[:, None].expand(RN, SN).reshape(-1)
+    assert rel_err(radiance[pt_ok.to(dev)], torch.from_numpy(g[f"{tag}.radiance"])[pt_ok]) < 1e-4
+
+
+@pytest.mark.gpu
+def test_ray_transformer_forward_is_differentiable():
+    """Gradients w.r.t. fea_volume and the parameters through the standalone RayTransformer.forward == autograd through
+    the oracle's dense half on the same inputs."""
+    from helpers import grad_rel_err
+    from oracle import ufo_oracle as O
+
+    m, f, fr, idx, U1, U2, g, ray_o, ray_d, near, far = _rows_model()
+    dev = "cuda:0"
+    tag = "coarse"
+    RN, SN = g[f"{tag}.z"].shape
+    pts = torch.from_numpy(g[f"{tag}.pts"]).to(dev)
+    vol = torch.from_numpy(g[f"{tag}.vol24"]).reshape(1, RN, SN, 24).to(dev).requires_grad_(True)
+    cond = {"feat_info": torch.from_numpy(g[f"{tag}.sim8"])[None].to(dev)}
+    gen = torch.Generator().manual_seed(11)
+    co_r, co_s = torch.rand(RN * SN, 3, generator=gen) - 0.5, torch.rand(RN, SN, 1, generator=gen) - 0.5
+    radiance, srdf, _ = m.ray_transformer(pts[None], f.batch, f.source_imgs_feat, fea_volume=vol, cond_info=cond)
+    ((radiance * co_r.to(dev)).sum() + (srdf * co_s.to(dev)).sum()).backward()
+    # oracle: same token inputs (from the HIP gather), vol24 / sim16 re-inserted as differentiable functions
+    W = m.ray_transformer.packed_weights(torch.zeros((), device=dev))
+    fh = ops.FrameHandle(f.batch, f.source_imgs_feat, f.feature_volume, f.match_feature)
+    x, rgbm, dirs, _ = ops.project_gather(fh, W, ray_o[0].contiguous(), ray_d,
+                                          torch.from_numpy(g[f"{tag}.z"]).to(dev).contiguous())
+    P = {k: v.clone().requires_grad_("depthcode" not in k) for k, v in load_weights().items()}
+    volc = vol.detach().cpu().reshape(-1, 24).requires_grad_(True)
+    sim16 = O.mlp3(cond["feat_info"].cpu().reshape(-1, 8), P, "ray_transformer.pre_sim_mlp.")
+    xc = x.cpu().clone()
+    xc = torch.cat([xc[:, :, :32], volc[:, None, :].expand(-1, 3, -1), sim16[:, None, :].expand(-1, 3, -1), xc[:, :, 72:]], -1)
+    rad_o, srdf_o = O.aggregate_tokens(P, xc, rgbm.cpu()[..., :3], rgbm.cpu()[..., 3], dirs.cpu()[..., :3], RN, SN)
+    ((rad_o * co_r).sum() + (srdf_o * co_s[..., 0]).sum()).backward()
+    assert grad_rel_err(vol.grad.reshape(-1, 24), volc.grad) < 1e-3
+    for k, p in m.ray_transformer.named_parameters():
+        if k.endswith("linear_radianceweight_1_softmax.4.bias"):
+            continue
+        assert grad_rel_err(p.grad, P["ray_transformer." + k].grad) < 1e-3, k
 
 
 @pytest.mark.gpu

@@ -74,7 +74,7 @@ SIGNATURES = {
     "ufr_sample_importance_merge": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "ufr_points": (C.c_int, [vp, i32, vp, vp, vp, i32, i32, vp]),
     "ufr_project_gather": (C.c_int, [C.POINTER(Frame), C.POINTER(RawWeights), vp, i32, vp, vp, i32, i32,
-                                     vp, vp, vp, vp, vp, vp, vp, vp]),
+                                     vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "ufr_aggregate_workspace_bytes": (sz, [i32, i32, i32]),
     "ufr_aggregate": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "ufr_composite": (C.c_int, [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]),

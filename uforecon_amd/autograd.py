@@ -20,7 +20,7 @@ class RenderPass(torch.autograd.Function):
 
     ``apply(frame, weights, ray_o, ray_d, z, *params, *volumes)`` with ``params`` = the 40 tensors of
     ``ops.RAW_WEIGHT_KEYS`` (live nn.Parameters) and ``volumes`` = feature / weight volume of the three stages.
-    Returns ``rgb (RN,3), depth (RN), opacity (RN), weight (RN,SN), srdf (RN,SN)``.
+    Returns ``rgb (RN,3), depth (RN), opacity (RN), weight (RN,SN), srdf (RN,SN), xy (NV,P,2)``.
     Activations kept for the backward: the token inputs (x, rgb/mask, dir), the pair similarity, the view transformer's
     token-0 rows, radiance and srdf -- everything else is recomputed inside the backward kernels."""
 
@@ -28,17 +28,18 @@ class RenderPass(torch.autograd.Function):
     def forward(ctx, frame, weights, ray_o, ray_d, z, *tensors):
         n_par = len(ops.RAW_WEIGHT_KEYS)
         RN, SN = z.shape
-        x, rgbm, dirs, dbg = ops.project_gather(frame, weights, ray_o, ray_d, z, want_sim8=True)
+        x, rgbm, dirs, dbg = ops.project_gather(frame, weights, ray_o, ray_d, z, want_sim8=True, want_xy=True)
         radiance, srdf, agg = ops.aggregate(weights, x, rgbm, dirs, RN, SN, keep_workspace=True)
         variance = weights.variance.reshape(1)
         rgb, depth, opacity, weight = ops.composite(z, radiance.view(RN, SN, 3), srdf, variance)
         ctx.frame, ctx.weights, ctx.n_par = frame, weights, n_par
         ctx.vol_shapes = [tuple(t.shape) for t in tensors[n_par:]]
         ctx.save_for_backward(ray_o, ray_d, z, x, rgbm, dirs, dbg["sim8"], agg["token0"], radiance, srdf)
-        return rgb, depth, opacity, weight, srdf
+        ctx.mark_non_differentiable(dbg["xy"])
+        return rgb, depth, opacity, weight, srdf, dbg["xy"]
 
     @staticmethod
-    def backward(ctx, d_rgb, d_depth, d_opacity, d_weight, d_srdf_out):
+    def backward(ctx, d_rgb, d_depth, d_opacity, d_weight, d_srdf_out, _d_xy):
         ray_o, ray_d, z, x, rgbm, dirs, sim8, token0, radiance, srdf = ctx.saved_tensors
         frame, W = ctx.frame, ctx.weights
         RN, SN = z.shape
@@ -56,6 +57,44 @@ class RenderPass(torch.autograd.Function):
         need = ctx.needs_input_grad[5:]
         out = [g if n else None for g, n in zip(gpar + gvol, need)]
         return (None, None, None, None, None, *out)
+
+
+class Aggregate(torch.autograd.Function):
+    """RayTransformer.forward (ray_transformer.py:175-322) as the reference exposes it: the frustum lookup `fea_volume`
+    and the pair similarity cond_info['feat_info'] are INPUTS.  ``apply(frame, weights, points (P,3), RN, SN,
+    vol24 (P,24), sim8 (P,8), *params)`` -> ``radiance (P,3), srdf (RN,SN), xy (NV,P,2)``.  Differentiable w.r.t. vol24
+    and the parameters (sim8 descends from the frozen matching features)."""
+
+    @staticmethod
+    def forward(ctx, frame, weights, points, RN, SN, vol24, sim8, *params):
+        P = RN * SN
+        zeros3 = torch.zeros(P, 3, dtype=torch.float32, device=points.device)
+        # every point is its own "ray" of one sample: position = o + 0 * d, exact
+        x, rgbm, dirs, dbg = ops.project_gather(frame, weights, points, zeros3, zeros3[:, :1].contiguous(), want_xy=True,
+                                                vol24_in=vol24, sim8_in=sim8)
+        radiance, srdf, agg = ops.aggregate(weights, x, rgbm, dirs, RN, SN, keep_workspace=True)
+        ctx.frame, ctx.weights, ctx.dims = frame, weights, (RN, SN)
+        ctx.save_for_backward(points, zeros3, x, rgbm, dirs, sim8, agg["token0"])
+        ctx.mark_non_differentiable(dbg["xy"])
+        return radiance, srdf, dbg["xy"]
+
+    @staticmethod
+    def backward(ctx, d_radiance, d_srdf, _d_xy):
+        points, zeros3, x, rgbm, dirs, sim8, token0 = ctx.saved_tensors
+        RN, SN = ctx.dims
+        dev = x.device
+        W = ctx.weights
+        if d_radiance is None:
+            d_radiance = torch.zeros(RN * SN, 3, device=dev)
+        if d_srdf is None:
+            d_srdf = torch.zeros(RN, SN, device=dev)
+        grads = ops.GradBuffer(dev)
+        d_pv, _ = ops.aggregate_bwd(W, grads, x, rgbm, dirs, token0, RN, SN, d_radiance, d_srdf)
+        ops.project_gather_bwd(ctx.frame, W, grads, points, zeros3, zeros3[:, :1].contiguous(), sim8, d_pv, None, None)
+        gpar = [grads.grad(k) for k in ops.RAW_WEIGHT_KEYS]
+        need = ctx.needs_input_grad
+        d_vol24 = d_pv[:, :24].contiguous() if need[5] else None
+        return (None, None, None, None, None, d_vol24, None, *[g if n else None for g, n in zip(gpar, need[7:])])
 
 
 class Composite(torch.autograd.Function):

@@ -58,7 +58,9 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, const float* __
                                                       float* __restrict__ x_tokens, float* __restrict__ rgb_out,
                                                       float* __restrict__ dir_out, float* __restrict__ sim8_out,
                                                       float* __restrict__ vol24_out, float* __restrict__ xy_out,
-                                                      float* __restrict__ maskz_out) {
+                                                      float* __restrict__ maskz_out,
+                                                      const float* __restrict__ vol24_in,
+                                                      const float* __restrict__ sim8_in) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int NV = f.NV;
   const int npair = NV * (NV - 1) / 2;
@@ -142,9 +144,13 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, const float* __
     if (active) st4(dir_out + ((size_t)pidx * NV + v) * 4, f32x4{ax / na - bx / nb, ay / na - by / nb, az / na - bz / nb, 0.f});
   }
 
-  // ---- correlation frustums of view v (model.py:359-386)
+  // ---- correlation frustums of view v (model.py:359-386); skipped when the caller supplies the blended lookup
+  // (RayTransformer.forward receives it as `fea_volume`, ray_transformer.py:175, 199)
   float own[25];
-  {
+  if (vol24_in) {
+#pragma unroll
+    for (int c = 0; c < 25; ++c) own[c] = 0.f;
+  } else {
     const float zn = ((qz - f.vol_near) / (f.vol_far - f.vol_near)) * 2.f - 1.f;  // camera.py:400-401
     float fl[24], wl = 0.f;
 #pragma unroll
@@ -191,6 +197,7 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, const float* __
 #ifdef UFR_GABL_NOCOOP
   if (false)
 #endif
+  if (!sim8_in)
   for (int item = grp; item < 64 * npair; item += n_grp) {
     const int ip = item / npair, q = item - ip * npair;
     int a = 0, rem = q;
@@ -217,6 +224,7 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, const float* __
       float s = 0.f;
       for (int q = 0; q < npair; ++q) s += sh_sim[(p * npair + q) * 8 + gi];
       sim[gi] = s / (float)npair;                                                 // torch.mean over pairs
+      if (sim8_in) sim[gi] = sim8_in[(size_t)pc * 8 + gi];                        // cond_info['feat_info'] given
     }
     float* ov = sh_out + p * 40;
     {
@@ -227,6 +235,7 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, const float* __
         float G = own[c];
         for (int n = 1; n < NV; ++n) G += sh_vol[(p * (NV - 1) + n - 1) * 25 + c];
         ov[c] = G / (Wsum + 1e-8f);                                               // model.py:388
+        if (vol24_in) ov[c] = vol24_in[(size_t)pc * 24 + c];
       }
     }
     // hand the mean similarity to presim_kernel through token columns 56..63 of the point's first view row
@@ -326,13 +335,14 @@ __global__ void __launch_bounds__(256) presim_kernel(PreSim ps, int P, int NV, f
 
 hipError_t launch_gather(const FrameDev& f, const PreSim& ps, const float* ray_o, int o_stride, const float* ray_d,
                          const float* z, int RN, int SN, float* x_tokens, float* rgb, float* dir, float* sim8,
-                         float* vol24, float* xy, float* mask_z, hipStream_t s) {
+                         float* vol24, float* xy, float* mask_z, const float* vol24_in, const float* sim8_in,
+                         hipStream_t s) {
   const int P = RN * SN, NV = f.NV;
   const int npair = NV * (NV - 1) / 2;
   const size_t taps = 2 * (size_t)NV * 64 * 8, outv = 64 * 40;
   size_t lds = sizeof(float) * ((size_t)64 * npair * 8 + 64 * (NV - 1) * 25 + (taps > outv ? taps : outv));
   hipLaunchKernelGGL(gather_kernel, dim3((P + 63) / 64), dim3(64 * NV), lds, s, f, ray_o, o_stride, ray_d, z, P, SN,
-                     x_tokens, rgb, dir, sim8, vol24, xy, mask_z);
+                     x_tokens, rgb, dir, sim8, vol24, xy, mask_z, vol24_in, sim8_in);
   hipLaunchKernelGGL(presim_kernel, dim3((P + 64 * kPresimTiles - 1) / (64 * kPresimTiles)), dim3(256), 0, s, ps, P, NV, x_tokens);
   return hipGetLastError();
 }

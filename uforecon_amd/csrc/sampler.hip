@@ -23,12 +23,17 @@ __global__ void __launch_bounds__(256) ray_setup_kernel(const int64_t* __restric
   if (i == 0 && ray_o_out) { ray_o_out[0] = ox; ray_o_out[1] = oy; ray_o_out[2] = oz; }
   if (i >= RN) return;
   int64_t p = ray_idx[i];
+  // an index outside the H x W grid never becomes an out-of-bounds read: the ray is rendered from pixel 0 with NaN
+  // near / far, so its depth and colour come out NaN (the caller's bug stays visible)
+  const bool in_range = p >= 0 && p < (int64_t)HW;
+  p = in_range ? p : 0;
   rd_out[3 * i + 0] = ray_d[p];
   rd_out[3 * i + 1] = ray_d[(size_t)HW + p];
   rd_out[3 * i + 2] = ray_d[2 * (size_t)HW + p];
   float cz = cam_ray_d ? cam_ray_d[2 * (size_t)HW + p] : 1.f;
-  near_out[i] = cam_ray_d ? near_z / cz : near_z;  // model.py:426-427 (extract_geometry only)
-  far_out[i] = cam_ray_d ? far_z / cz : far_z;
+  const float bad = __builtin_nanf("");
+  near_out[i] = !in_range ? bad : cam_ray_d ? near_z / cz : near_z;  // model.py:426-427 (extract_geometry only)
+  far_out[i] = !in_range ? bad : cam_ray_d ? far_z / cz : far_z;
   if (camz_out) camz_out[i] = cz;
 }
 

@@ -146,10 +146,13 @@ static int frame_check(const ufr_frame_desc* d) {
   UFR_REQUIRE(d->NV >= 2 && d->NV <= UFR_MAX_VIEWS, "NV=%d unsupported (2..%d)", d->NV, UFR_MAX_VIEWS);
   UFR_REQUIRE(d->H >= 8 && d->W >= 8 && d->H % 4 == 0 && d->W % 4 == 0, "H,W must be multiples of 4 (got %dx%d)",
               d->H, d->W);
-  UFR_REQUIRE(d->source_imgs && d->depth_info && d->feat && d->match, "null frame tensor");
+  UFR_REQUIRE(d->source_imgs && d->depth_info && d->feat, "null frame tensor");
+  // match / volumes may be absent: such a frame only serves ufr_project_gather calls that pass sim8_in / vol24_in
+  const bool has_vol = d->vol_feat[0] != nullptr;
   for (int s = 0; s < UFR_NUM_STAGES; ++s) {
-    UFR_REQUIRE(d->vol_feat[s] && d->vol_weight[s], "null volume (stage %d)", s + 1);
-    UFR_REQUIRE(d->vol_D[s] >= 2 && d->vol_H[s] >= 2 && d->vol_W[s] >= 2, "degenerate volume (stage %d)", s + 1);
+    UFR_REQUIRE((d->vol_feat[s] != nullptr) == has_vol && (d->vol_weight[s] != nullptr) == has_vol,
+                "volumes must be given for all stages or for none (stage %d)", s + 1);
+    if (has_vol) UFR_REQUIRE(d->vol_D[s] >= 2 && d->vol_H[s] >= 2 && d->vol_W[s] >= 2, "degenerate volume (stage %d)", s + 1);
   }
   UFR_REQUIRE(d->source_poses && d->source_cam_pos && d->ref_cam_pos && d->w2c_row2, "null camera constants");
   return UFR_OK;
@@ -160,9 +163,10 @@ size_t ufr_frame_workspace_bytes(const ufr_frame_desc* d) {
   Carver c(nullptr);
   const size_t h = d->H / 4, w = d->W / 4, NV = d->NV;
   c.f32(NV * h * w * 32);
-  c.f32(NV * h * w * 32 * (NV - 1));
+  if (d->match) c.f32(NV * h * w * 32 * (NV - 1));
   c.f32(NV * (size_t)d->H * d->W * 4);
-  for (int s = 0; s < UFR_NUM_STAGES; ++s) c.f32(NV * (size_t)d->vol_D[s] * d->vol_H[s] * d->vol_W[s] * kVolCh);
+  if (d->vol_feat[0])
+    for (int s = 0; s < UFR_NUM_STAGES; ++s) c.f32(NV * (size_t)d->vol_D[s] * d->vol_H[s] * d->vol_W[s] * kVolCh);
   return c.off;
 }
 
@@ -176,18 +180,21 @@ int ufr_frame_prepare(const ufr_frame_desc* d, void* workspace, size_t workspace
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int NV = d->NV, h = d->H / 4, w = d->W / 4;
   Carver c(workspace);
+  const bool has_vol = d->vol_feat[0] != nullptr;
   float* feat = c.f32((size_t)NV * h * w * 32);
-  float* match = c.f32((size_t)NV * h * w * 32 * (NV - 1));
+  float* match = d->match ? c.f32((size_t)NV * h * w * 32 * (NV - 1)) : nullptr;
   float* rgb = c.f32((size_t)NV * d->H * d->W * 4);
-  float* vol[UFR_NUM_STAGES];
-  for (int st = 0; st < UFR_NUM_STAGES; ++st)
-    vol[st] = c.f32((size_t)NV * d->vol_D[st] * d->vol_H[st] * d->vol_W[st] * kVolCh);
+  float* vol[UFR_NUM_STAGES] = {};
+  if (has_vol)
+    for (int st = 0; st < UFR_NUM_STAGES; ++st)
+      vol[st] = c.f32((size_t)NV * d->vol_D[st] * d->vol_H[st] * d->vol_W[st] * kVolCh);
 
   UFR_HIP(launch_nchw_to_nhwc(d->feat, feat, NV, 32, h * w, 32, s));
-  UFR_HIP(launch_nchw_to_nhwc(d->match, match, NV, 32 * (NV - 1), h * w, 32 * (NV - 1), s));
+  if (match) UFR_HIP(launch_nchw_to_nhwc(d->match, match, NV, 32 * (NV - 1), h * w, 32 * (NV - 1), s));
   UFR_HIP(launch_nchw_to_nhwc(d->source_imgs, rgb, NV, 3, d->H * d->W, 4, s));
-  for (int st = 0; st < UFR_NUM_STAGES; ++st)
-    UFR_HIP(launch_volume_pack(d->vol_feat[st], d->vol_weight[st], vol[st], NV, d->vol_D[st] * d->vol_H[st] * d->vol_W[st], s));
+  if (has_vol)
+    for (int st = 0; st < UFR_NUM_STAGES; ++st)
+      UFR_HIP(launch_volume_pack(d->vol_feat[st], d->vol_weight[st], vol[st], NV, d->vol_D[st] * d->vol_H[st] * d->vol_W[st], s));
 
   FrameDev f;
   memset(&f, 0, sizeof(f));
@@ -195,7 +202,7 @@ int ufr_frame_prepare(const ufr_frame_desc* d, void* workspace, size_t workspace
   f.feat = feat; f.match = match; f.rgb = rgb; f.depth = d->depth_info;
   for (int st = 0; st < UFR_NUM_STAGES; ++st) {
     f.vol[st] = vol[st];
-    f.vD[st] = d->vol_D[st]; f.vH[st] = d->vol_H[st]; f.vW[st] = d->vol_W[st];
+    if (has_vol) { f.vD[st] = d->vol_D[st]; f.vH[st] = d->vol_H[st]; f.vW[st] = d->vol_W[st]; }
   }
   for (int v = 0; v < NV; ++v) {
     memcpy(f.pose[v], d->source_poses + 16 * v, 12 * sizeof(float));
@@ -239,15 +246,18 @@ int ufr_points(const float* ray_o, int32_t ray_o_stride, const float* ray_d, con
 
 int ufr_project_gather(const ufr_frame* frame, const ufr_raw_weights* raw, const float* ray_o, int32_t ray_o_stride,
                        const float* ray_d, const float* z, int32_t RN, int32_t SN, float* x_tokens, float* rgb,
-                       float* dir, float* sim8, float* vol24, float* xy, float* mask_z, ufr_stream stream) {
+                       float* dir, float* sim8, float* vol24, float* xy, float* mask_z, const float* vol24_in,
+                       const float* sim8_in, ufr_stream stream) {
   const FrameDev* f = frame_of(frame);
   UFR_REQUIRE(f, "ufr_project_gather: frame handle not prepared");
   UFR_REQUIRE(raw && ray_o && ray_d && z && x_tokens && rgb && dir, "ufr_project_gather: null argument");
   UFR_REQUIRE(ray_o_stride == 0 || ray_o_stride == 3, "ufr_project_gather: ray_o_stride must be 0 or 3");
   UFR_REQUIRE(RN > 0 && SN > 0, "ufr_project_gather: RN=%d SN=%d", RN, SN);
+  UFR_REQUIRE(f->match || sim8_in, "ufr_project_gather: the frame has no matching features: sim8_in is required");
+  UFR_REQUIRE(f->vol[0] || vol24_in, "ufr_project_gather: the frame has no volumes: vol24_in is required");
   ProfScope prof("gather", static_cast<hipStream_t>(stream));
   UFR_HIP(launch_gather(*f, presim_of(raw), ray_o, ray_o_stride, ray_d, z, RN, SN, x_tokens, rgb, dir, sim8, vol24, xy,
-                        mask_z, static_cast<hipStream_t>(stream)));
+                        mask_z, vol24_in, sim8_in, static_cast<hipStream_t>(stream)));
   return UFR_OK;
 }
 
@@ -367,13 +377,16 @@ int ufr_project_gather_bwd(const ufr_frame* frame, const ufr_raw_weights* raw, c
   GradPtrs gp;
   int rc = raw_and_grads(raw, grads, rp, gp, "ufr_project_gather_bwd");
   if (rc != UFR_OK) return rc;
-  UFR_REQUIRE(ray_o && ray_d && z && sim8 && d_pv && grad_vol_feat && grad_vol_weight, "ufr_project_gather_bwd: null argument");
+  UFR_REQUIRE(ray_o && ray_d && z && sim8 && d_pv, "ufr_project_gather_bwd: null argument");
+  const bool scatter = grad_vol_feat != nullptr || grad_vol_weight != nullptr;   // both NULL: pre_sim_mlp gradients only
+  UFR_REQUIRE(!scatter || (grad_vol_feat && grad_vol_weight && f->vol[0]),
+              "ufr_project_gather_bwd: volume gradients need both pointer arrays and a frame prepared with volumes");
   UFR_REQUIRE(ray_o_stride == 0 || ray_o_stride == 3, "ufr_project_gather_bwd: ray_o_stride must be 0 or 3");
   UFR_REQUIRE(RN > 0 && SN > 0, "ufr_project_gather_bwd: RN=%d SN=%d", RN, SN);
-  for (int i = 0; i < UFR_NUM_STAGES; ++i)
+  for (int i = 0; scatter && i < UFR_NUM_STAGES; ++i)
     UFR_REQUIRE(grad_vol_feat[i] && grad_vol_weight[i], "ufr_project_gather_bwd: null volume gradient (stage %d)", i + 1);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  {
+  if (scatter) {
     ProfScope p("gather_bwd", s);
     UFR_HIP(launch_gather_bwd(*f, grad_vol_feat, grad_vol_weight, ray_o, ray_o_stride, ray_d, z, d_pv, RN, SN, s));
   }
@@ -472,7 +485,7 @@ int render_chunk(const ufr_render_args* a, const FrameDev* f, const RenderWs& w,
   // ---- coarse pass (model.py:445)
   {
     ProfScope p("gather", s);
-    UFR_HIP(launch_gather(*f, ps, w.ray_o, 0, w.rd, w.z1, R, SN, w.x, w.rgbm, w.dir, nullptr, nullptr, nullptr, nullptr, s));
+    UFR_HIP(launch_gather(*f, ps, w.ray_o, 0, w.rd, w.z1, R, SN, w.x, w.rgbm, w.dir, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s));
   }
   int rc = aggregate_impl(a->packed_weights, w.x, w.rgbm, w.dir, R, SN, NV, w.rad, w.srdf1, w.token0, w.pe1, true,
                           nullptr, nullptr, s);
@@ -500,7 +513,7 @@ int render_chunk(const ufr_render_args* a, const FrameDev* f, const RenderWs& w,
   }
   {
     ProfScope p("gather", s);
-    UFR_HIP(launch_gather(*f, ps, w.ray_o, 0, w.rd, w.z_new, R, PN, w.x, w.rgbm, w.dir, nullptr, nullptr, nullptr, nullptr, s));
+    UFR_HIP(launch_gather(*f, ps, w.ray_o, 0, w.rd, w.z_new, R, PN, w.x, w.rgbm, w.dir, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s));
   }
   {
     ProfScope p("view_transformer", s);
@@ -527,6 +540,7 @@ int ufr_render_rays(const ufr_render_args* a, ufr_stream stream) {
   UFR_REQUIRE(a, "ufr_render_rays: null args");
   const FrameDev* f = frame_of(a->frame);
   UFR_REQUIRE(f, "ufr_render_rays: frame handle not prepared");
+  UFR_REQUIRE(f->match && f->vol[0], "ufr_render_rays: the frame was prepared without matching features / volumes");
   UFR_REQUIRE(a->packed_weights && a->raw && a->ray_idx && a->ray_d && a->U1 && a->depth && a->rgb && a->workspace,
               "ufr_render_rays: null argument");
   UFR_REQUIRE(a->coarse_only || a->U2, "ufr_render_rays: U2 required unless coarse_only");

@@ -47,7 +47,8 @@ hipError_t launch_points(const float* ray_o, int o_stride, const float* ray_d, c
                          int SN, hipStream_t s);
 hipError_t launch_gather(const FrameDev& f, const PreSim& ps, const float* ray_o, int o_stride, const float* ray_d,
                          const float* z, int RN, int SN, float* x_tokens, float* rgb, float* dir, float* sim8,
-                         float* vol24, float* xy, float* mask_z, hipStream_t s);
+                         float* vol24, float* xy, float* mask_z, const float* vol24_in, const float* sim8_in,
+                         hipStream_t s);
 hipError_t launch_view_transformer(const float* packed, const float* x_tokens, const float* rgb, const float* dir,
                                    int P, int NV, float* token0, float* radiance, float* view_out, hipStream_t s);
 // tok_row / rad_row (nullable): row of token0 / radiance holding sample (ray, s) -- the fine pass of the whole-path

@@ -188,8 +188,39 @@ class RayTransformer(nn.Module):
 
     def forward(self, point3D, batch, source_imgs_feat, fea_volume=None, cond_info=None, points_projected=None,
                 mask_valid=None):
-        raise UfrError("RayTransformer.forward is fused with the gathers on the HIP path: call "
-                       "UFORecon.sample2rgb / UFORecon.infer (gather -> aggregate share one token buffer)")
+        """ray_transformer.py:175-322 -> ``(radiance (B*RN*SN,3), srdf (B*RN,SN,1), points_in_pixel (B,NV,2,RN,SN))``.
+
+        ``fea_volume`` (B,RN,SN,24) is the blended frustum lookup and ``cond_info['feat_info']`` (B,RN,SN,8) the pair
+        similarity, as ``sample2rgb`` hands them over (model.py:324-333).  ``points_projected`` / ``mask_valid`` must be the
+        projection of ``point3D`` by ``batch['source_poses']`` (they always are, model.py:237): the kernel recomputes it
+        (bit-identical arithmetic) and returns it as ``points_in_pixel``.  Differentiable w.r.t. ``fea_volume`` and the
+        parameters."""
+        B, RN, SN, _ = point3D.shape
+        if B != 1:
+            raise UfrError("B=1 only (one frame per call)")
+        if fea_volume is None or cond_info is None or "feat_info" not in cond_info:
+            raise UfrError("RayTransformer.forward needs fea_volume and cond_info['feat_info'] "
+                           "(the shipped configuration: correlation volumes + explicit similarity)")
+        dev = source_imgs_feat.device
+        keyed = [source_imgs_feat] + [batch[k] for k in ("source_imgs", "depth_info", "source_poses", "source_poses_inv",
+                                                          "ref_pose_inv", "w2cs")]
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in keyed) + (batch.get("start_idx", 1),)
+        if key != getattr(self, "_lite_key", None):
+            self._lite_frame = ops.FrameHandle(batch, source_imgs_feat, None, None)
+            self._lite_key = key
+        variance = getattr(self, "_variance_stub", None)
+        if variance is None or variance.device != dev:
+            variance = self._variance_stub = torch.zeros((), device=dev)       # not an input of this module
+        W = self.packed_weights(variance)
+        P = RN * SN
+        pts = point3D.reshape(P, 3).detach().float().contiguous()
+        vol24 = fea_volume.reshape(P, 24).float().contiguous()
+        sim8 = cond_info["feat_info"].reshape(P, 8).detach().float().contiguous()
+        sd = dict(self.named_parameters())
+        params = [sd[k[len("ray_transformer."):]] for k in ops.RAW_WEIGHT_KEYS[:-1]] + [variance]
+        radiance, srdf, xy = ag.Aggregate.apply(self._lite_frame, W, pts, RN, SN, vol24, sim8, *params)
+        points_in_pixel = xy.reshape(1, -1, RN, SN, 2).permute(0, 1, 4, 2, 3)
+        return radiance, srdf.reshape(B * RN, SN, 1), points_in_pixel
 
 
 # --------------------------------------------------------------------------- orchestrator
@@ -241,9 +272,9 @@ class UFORecon(nn.Module):
         fh = self.frame_handle(batch, source_imgs_feat, feature_volume, match_feature)
         ray_o = batch["ray_o"][0].float().contiguous()
         z = z_val.reshape(RN, SN).detach().float().contiguous()
-        rgb, depth, opacity, weight, srdf = self._render_pass(fh, ray_o, ray_d.reshape(RN, 3).float().contiguous(), z,
-                                                              feature_volume)
-        return rgb[None], depth[None], srdf.reshape(RN, SN, 1), opacity[None], weight[None], None, self._variance_out()
+        rgb, depth, opacity, weight, srdf, pip = self._render_pass(fh, ray_o, ray_d.reshape(RN, 3).float().contiguous(), z,
+                                                                   feature_volume)
+        return rgb[None], depth[None], srdf.reshape(RN, SN, 1), opacity[None], weight[None], pip, self._variance_out()
 
     def _live_params(self):
         sd = {"ray_transformer." + k: v for k, v in self.ray_transformer.named_parameters()}
@@ -261,11 +292,14 @@ class UFORecon(nn.Module):
         RN, SN = z.shape
         params, vols = self._live_params(), ag.flat_volumes(feature_volume)
         if _wants_grad(*params, *vols):
-            return ag.RenderPass.apply(fh, W, ray_o, ray_d, z, *params, *vols)
-        x, rgbm, dirs, _ = ops.project_gather(fh, W, ray_o, ray_d, z)
-        radiance, srdf, _ = ops.aggregate(W, x, rgbm, dirs, RN, SN)
-        rgb, depth, opacity, weight = ops.composite(z, radiance.reshape(RN, SN, 3), srdf, W.variance.reshape(1))
-        return rgb, depth, opacity, weight, srdf
+            rgb, depth, opacity, weight, srdf, xy = ag.RenderPass.apply(fh, W, ray_o, ray_d, z, *params, *vols)
+        else:
+            x, rgbm, dirs, dbg = ops.project_gather(fh, W, ray_o, ray_d, z, want_xy=True)
+            radiance, srdf, _ = ops.aggregate(W, x, rgbm, dirs, RN, SN)
+            rgb, depth, opacity, weight = ops.composite(z, radiance.reshape(RN, SN, 3), srdf, W.variance.reshape(1))
+            xy = dbg["xy"]
+        # points_in_pixel (B,NV,2,RN,SN): the projected sample positions (ray_transformer.py:211-220, 322)
+        return rgb, depth, opacity, weight, srdf, xy.reshape(1, -1, RN, SN, 2).permute(0, 1, 4, 2, 3)
 
     def infer(self, batch, ray_idx, source_imgs_feat, feature_volume=None, extract_geometry=False, match_feature=None,
               ray_idx_all=None, is_train=True, uniforms=None):
@@ -304,13 +338,13 @@ class UFORecon(nn.Module):
         near = batch["near_fars"][0, 0, 0].expand(RN).float().contiguous()
         far = batch["near_fars"][0, 0, 1].expand(RN).float().contiguous()
         z1 = ops.sample_fixed(near, far, U1)
-        rgb, depth, opacity, weight, srdf = self._render_pass(fh, ray_o, ray_d, z1, feature_volume)
+        rgb, depth, opacity, weight, srdf, pip = self._render_pass(fh, ray_o, ray_d, z1, feature_volume)
         _, z2 = ops.sample_importance_merge(weight.detach().contiguous(), z1, U2, want_fine=False)
         S2 = z2.shape[1]
-        rgb2, depth2, opacity2, weight2, srdf2 = self._render_pass(fh, ray_o, ray_d, z2, feature_volume)
+        rgb2, depth2, opacity2, weight2, srdf2, pip2 = self._render_pass(fh, ray_o, ray_d, z2, feature_volume)
         variance = self._variance_out()
-        return (rgb_gt, rgb[None], depth[None], depth_gt, srdf.reshape(RN, -1, 1), opacity[None], weight[None], None,
-                rgb2[None], depth2[None], srdf2.reshape(RN, S2, 1), opacity2[None], weight2[None], None,
+        return (rgb_gt, rgb[None], depth[None], depth_gt, srdf.reshape(RN, -1, 1), opacity[None], weight[None], pip,
+                rgb2[None], depth2[None], srdf2.reshape(RN, S2, 1), opacity2[None], weight2[None], pip2,
                 z1[None], z2[None], variance)                                                # model.py:480-482
 
     # ---- frame-level entry: the per-ray loop and post-processing of extract_geometry (model.py:810-842)

@@ -93,8 +93,10 @@ class PackedWeights:
 class FrameHandle:
     """Per-frame channel-last copies + camera constants (ufr_frame_prepare)."""
 
-    def __init__(self, batch: dict, source_imgs_feat: torch.Tensor, feature_volume: dict, match_feature,
+    def __init__(self, batch: dict, source_imgs_feat: torch.Tensor, feature_volume: Optional[dict], match_feature,
                  stages=("stage1", "stage2", "stage3")):
+        """``feature_volume`` / ``match_feature`` may be None: such a handle only serves ``project_gather`` calls that
+        pass ``vol24_in`` / ``sim8_in`` (RayTransformer.forward gets them as arguments)."""
         lib = _lib.load()
         imgs = batch["source_imgs"]
         if imgs.shape[0] != 1:
@@ -104,19 +106,21 @@ class FrameHandle:
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
         self._keep = dict(
             imgs=f32(imgs[0]), depth=f32(batch["depth_info"][0]), feat=f32(source_imgs_feat[0]),
-            match=f32(match_feature[0][0]),
         )
+        if match_feature is not None:
+            self._keep["match"] = f32(match_feature[0][0])
         d = _lib.FrameDesc()
         d.NV, d.H, d.W = NV, H, W
         d.source_imgs = _dev(self._keep["imgs"], "source_imgs")
         d.depth_info = _dev(self._keep["depth"], "depth_info")
         d.feat = _dev(self._keep["feat"], "source_imgs_feat")
-        d.match = _dev(self._keep["match"], "match_feature")
         if tuple(self._keep["feat"].shape) != (NV, 32, H // 4, W // 4):
             raise UfrError(f"source_imgs_feat shape {tuple(source_imgs_feat.shape)}")
-        if tuple(self._keep["match"].shape) != (NV, 32 * (NV - 1), H // 4, W // 4):
-            raise UfrError(f"match_feature shape {tuple(match_feature[0].shape)}")
-        for i, st in enumerate(stages):
+        if match_feature is not None:
+            d.match = _dev(self._keep["match"], "match_feature")
+            if tuple(self._keep["match"].shape) != (NV, 32 * (NV - 1), H // 4, W // 4):
+                raise UfrError(f"match_feature shape {tuple(match_feature[0].shape)}")
+        for i, st in enumerate(stages if feature_volume is not None else ()):
             fv = f32(feature_volume[st]["feature_volume"])
             wv = f32(feature_volume[st]["weight_volume"])
             if fv.shape[0] != NV or fv.shape[1] != 8 or wv.shape[1] != 1 or fv.shape[2:] != wv.shape[2:]:
@@ -137,8 +141,11 @@ class FrameHandle:
         fp = lambda t: C.cast(t.data_ptr(), C.POINTER(C.c_float))
         d.source_poses, d.source_cam_pos = fp(self._host["poses"]), fp(self._host["cam_pos"])
         d.ref_cam_pos, d.w2c_row2 = fp(self._host["ref_pos"]), fp(self._host["w2c_z"])
-        nf = batch["near_fars"][0][0].detach().cpu()
-        d.vol_near, d.vol_far = float(nf[0]), float(nf[1])
+        if "near_fars" in batch:
+            nf = batch["near_fars"][0][0].detach().cpu()
+            d.vol_near, d.vol_far = float(nf[0]), float(nf[1])
+        elif feature_volume is not None:
+            raise UfrError("batch['near_fars'] is required to look up the frustums (model.py:328)")
         nbytes = lib.ufr_frame_workspace_bytes(C.byref(d))
         if nbytes == 0:
             raise UfrError("frame: " + lib.ufr_last_error().decode())
@@ -148,10 +155,10 @@ class FrameHandle:
         _lib.check(lib.ufr_frame_prepare(C.byref(d), self.workspace.data_ptr(), nbytes, C.byref(self.frame), _stream()),
                    "ufr_frame_prepare")
         self.NV, self.H, self.W = NV, H, W
-        self.near_z = float(batch["near_fars"][0, 0, 0])
-        self.far_z = float(batch["near_fars"][0, 0, 1])
-        self.ray_o = [float(v) for v in batch["ray_o"][0].detach().cpu()]
-        self.ray_d = f32(batch["ray_d"][0])
+        self.near_z, self.far_z = float(d.vol_near), float(d.vol_far)
+        # view-dependent state of the whole-frame renderer (absent when the handle only serves RayTransformer.forward)
+        self.ray_o = [float(v) for v in batch["ray_o"][0].detach().cpu()] if "ray_o" in batch else None
+        self.ray_d = f32(batch["ray_d"][0]) if "ray_d" in batch else None
         self.cam_ray_d = f32(batch["cam_ray_d"][0]) if "cam_ray_d" in batch else None
 
 
@@ -185,7 +192,8 @@ def points(ray_o: torch.Tensor, ray_d: torch.Tensor, z: torch.Tensor) -> torch.T
 
 
 def project_gather(frame: FrameHandle, weights: PackedWeights, ray_o: torch.Tensor, ray_d: torch.Tensor,
-                   z: torch.Tensor, debug: bool = False, want_sim8: bool = False):
+                   z: torch.Tensor, debug: bool = False, want_sim8: bool = False, want_xy: bool = False,
+                   vol24_in: Optional[torch.Tensor] = None, sim8_in: Optional[torch.Tensor] = None):
     RN, SN = z.shape
     P, NV, dev = RN * SN, frame.NV, z.device
     x = torch.empty(P, NV, _lib.TOKEN_DIM, dtype=torch.float32, device=dev)
@@ -195,13 +203,17 @@ def project_gather(frame: FrameHandle, weights: PackedWeights, ray_o: torch.Tens
     if debug:
         dbg = dict(sim8=torch.empty(P, 8, device=dev), vol24=torch.empty(P, 24, device=dev),
                    xy=torch.empty(NV, P, 2, device=dev), mask_z=torch.empty(NV, P, device=dev))
-    elif want_sim8:   # the backward of pre_sim_mlp needs its input
-        dbg = dict(sim8=torch.empty(P, 8, device=dev))
+    else:
+        if want_sim8:   # the backward of pre_sim_mlp needs its input
+            dbg["sim8"] = torch.empty(P, 8, device=dev)
+        if want_xy:     # points_in_pixel of the reference's return tuples
+            dbg["xy"] = torch.empty(NV, P, 2, device=dev)
     stride = 0 if ray_o.numel() == 3 else 3
     _lib.check(_lib.load().ufr_project_gather(
         C.byref(frame.frame), C.byref(weights.raw), _dev(ray_o, "ray_o"), stride, _dev(ray_d, "ray_d"), _dev(z, "z"),
         RN, SN, x.data_ptr(), rgb.data_ptr(), dirs.data_ptr(), _opt(dbg.get("sim8"), "sim8"),
-        _opt(dbg.get("vol24"), "vol24"), _opt(dbg.get("xy"), "xy"), _opt(dbg.get("mask_z"), "mask_z"), _stream()),
+        _opt(dbg.get("vol24"), "vol24"), _opt(dbg.get("xy"), "xy"), _opt(dbg.get("mask_z"), "mask_z"),
+        _opt(vol24_in, "vol24_in"), _opt(sim8_in, "sim8_in"), _stream()),
         "ufr_project_gather")
     return x, rgb, dirs, dbg
 
@@ -297,8 +309,10 @@ def project_gather_bwd(frame: FrameHandle, weights: PackedWeights, grads: GradBu
     accumulates the pre_sim_mlp gradients into `grads`."""
     RN, SN = z.shape
     stride = 0 if ray_o.numel() == 3 else 3
-    gf = (C.c_void_p * 3)(*[_dev(t, "grad_vol_feat") for t in grad_vol_feat])
-    gw = (C.c_void_p * 3)(*[_dev(t, "grad_vol_weight") for t in grad_vol_weight])
+    gf = gw = None        # both None: pre_sim_mlp gradients only
+    if grad_vol_feat is not None:
+        gf = (C.c_void_p * 3)(*[_dev(t, "grad_vol_feat") for t in grad_vol_feat])
+        gw = (C.c_void_p * 3)(*[_dev(t, "grad_vol_weight") for t in grad_vol_weight])
     _lib.check(_lib.load().ufr_project_gather_bwd(
         C.byref(frame.frame), C.byref(weights.raw), C.byref(grads.raw), _dev(ray_o, "ray_o"), stride, _dev(ray_d, "ray_d"),
         _dev(z, "z"), RN, SN, _dev(sim8, "sim8"), _dev(d_pv, "d_pv"), gf, gw, _stream()), "ufr_project_gather_bwd")
@@ -320,8 +334,8 @@ def render_rays(frame: FrameHandle, weights: PackedWeights, ray_idx: torch.Tenso
                 U2: Optional[torch.Tensor], coarse_only: bool = False, workspace: Optional[RenderWorkspace] = None,
                 want_srdf: bool = True, out: Optional[dict] = None):
     """UFORecon.infer(extract_geometry=True) for the rays `ray_idx` (RN,) of the prepared frame."""
-    if frame.cam_ray_d is None:
-        raise UfrError("batch['cam_ray_d'] is required for extract_geometry rendering")
+    if frame.cam_ray_d is None or frame.ray_d is None or frame.ray_o is None:
+        raise UfrError("batch['ray_o'], ['ray_d'] and ['cam_ray_d'] are required for extract_geometry rendering")
     dev = frame.device
     RN = ray_idx.numel()
     SN = U1.shape[0]

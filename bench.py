@@ -56,8 +56,14 @@ def parse():
     p.add_argument("--chunk", type=int, default=0, help="rays per launch group (0 = library default)")
     p.add_argument("--streams", type=int, default=3, help="side streams the chunks are spread over")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-gpu-eager-baseline", action="store_true")
+    p.add_argument("--eager-chunks", type=int, default=6, help="800-ray chunks of the GPU-eager 1x reference leg")
     p.add_argument("--cpu-rays", type=int, default=256)
     p.add_argument("--cpu-calls", type=int, default=5)
+    p.add_argument("--fixed-uniforms", type=int, default=-1, metavar="SEED",
+                   help=">= 0: sampler uniforms are one seeded draw for the whole frame, sliced per rank (so an N-rank run "
+                        "renders exactly the frame a 1-rank run renders); default: fresh GPU draws every step")
+    p.add_argument("--dump-depth", default="", help="rank 0 writes the (gathered) H x W depth map of the last step here (.npy)")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                                                       "exercise the multi-rank path on a box with fewer GPUs than ranks)")
     return p.parse_args()
@@ -85,6 +91,37 @@ def cpu_baseline(frame_cpu, weights_cpu, a):
     return dict(value=RN / med, unit="rays/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"oracle.infer on {RN} rays of the same frame, {a.coarse}+{a.fine} samples, "
                        f"median of {a.cpu_calls} calls after 1 warm-up ({med * 1e3:.0f} ms/call)")
+
+
+def gpu_eager_baseline(frame_cpu, weights_cpu, a, dev):
+    """The 1x denominator of the >= 20x target (last bullet): the eager-PyTorch restatement of the
+    reference path (the oracle, op for op the reference's aten sequence) on this GPU with the reference's chunking
+    (test_ray_num = 800 rays per infer call, code1/model.py:814-823), sampler uniforms drawn on the CPU generator and moved
+    over per chunk exactly like the reference does (sampler.py:42, 86).  Bounded sample: a few chunks of the same frame."""
+    from oracle import ufo_oracle as O
+
+    RN = 800
+    HW = a.height * a.width
+    frame = frame_cpu.to(dev)
+    P = {k: v.to(dev) for k, v in weights_cpu.items()}
+    times = []
+    with torch.no_grad():
+        for c in range(a.eager_chunks + 1):
+            idx = (torch.arange(RN) + c * (HW // (a.eager_chunks + 1)))[None].to(dev)          # model.py:814: consecutive pixels
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            U1, U2 = torch.rand(a.coarse, RN), torch.rand(a.fine, RN)                           # CPU generator, like upstream
+            O.infer(P, frame.batch, idx, frame.source_imgs_feat, frame.feature_volume, frame.match_feature, U1.to(dev),
+                    U2.to(dev))
+            torch.cuda.synchronize()
+            if c:
+                times.append(time.perf_counter() - t)
+    times.sort()
+    med = times[len(times) // 2]
+    return dict(value=RN / med, unit="rays/s", kind="port-gpu-eager", device=torch.cuda.get_device_name(dev),
+                sample=f"oracle.infer (eager PyTorch-ROCm) on cuda, {a.eager_chunks} chunks of {RN} rays of the same frame after "
+                       f"1 warm-up chunk, {a.coarse}+{a.fine} samples, median {med * 1e3:.0f} ms per chunk "
+                       f"(= {HW / RN * med:.1f} s per {a.height}x{a.width} frame)")
 
 
 def main():
@@ -125,15 +162,27 @@ def main():
     ws = ops.RenderWorkspace(dev, a.coarse, a.fine, a.views, chunk_rays=a.chunk, n_streams=a.streams)
     out = dict(depth=torch.empty(RN, device=dev), depth_z=torch.empty(RN, device=dev), rgb=torch.empty(RN, 3, device=dev))
     gathered = None
+    fixed = None
+    if a.fixed_uniforms >= 0:
+        g = torch.Generator().manual_seed(a.fixed_uniforms)
+        fixed = (torch.rand(a.coarse, HW, generator=g).to(dev)[:, ray_idx].contiguous(),
+                 torch.rand(a.fine, HW, generator=g).to(dev)[:, ray_idx].contiguous())
+    ag_events = []
 
     def step():
         nonlocal gathered
         fh = ops.FrameHandle(frame.batch, frame.source_imgs_feat, frame.feature_volume, frame.match_feature)
-        U1 = torch.rand(a.coarse, RN, device=dev)
-        U2 = torch.rand(a.fine, RN, device=dev)
+        U1 = fixed[0] if fixed else torch.rand(a.coarse, RN, device=dev)
+        U2 = fixed[1] if fixed else torch.rand(a.fine, RN, device=dev)
         ops.render_rays(fh, W, ray_idx, U1, U2, workspace=ws, want_srdf=False, out=out)
         if world > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             gathered = all_gather_tiles(out["depth_z"], out["rgb"], shard)
+            e1.record()
+            ag_events.append((e0, e1))
+        else:
+            gathered = (out["depth_z"].view(a.height, a.width), out["rgb"].view(a.height, a.width, 3))
         return fh
 
     def fence():
@@ -144,6 +193,7 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
+    ag_events.clear()
     ops.profile_enable(a.streams <= 1)
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -161,10 +211,20 @@ def main():
         fence()
     prof = ops.profile_read()
     ops.profile_enable(False)
+    per_rank = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt_local, dt = dt, float(t.item())
+        # what makes a scaling number interpretable: every rank's kernel split, its all-gather time (which includes waiting
+        # for the slowest rank) and its own wall time
+        mine = dict(rank=rank, rays=RN, wall_ms_per_step=dt_local / a.steps * 1e3,
+                    kernel_ms_per_frame={k: v["ms"] / prof_steps for k, v in prof.items()},
+                    all_gather_ms_per_step=sum(e0.elapsed_time(e1) for e0, e1 in ag_events[:a.steps]) / max(a.steps, 1))
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    if a.dump_depth and rank == 0:
+        np.save(a.dump_depth, gathered[0].detach().cpu().numpy())
 
     if rank == 0:
         S = a.coarse + a.fine
@@ -211,7 +271,8 @@ def main():
                         executed_tflops=(rays_per_s * exec_flop_per_ray / 1e12) if exec_flop_per_ray else None,
                         reference_equivalent_tflops=(rays_per_s * ref_pts_per_ray * flop_pt / 1e12) if flop_pt else None,
                         kernel_ms_per_frame_rank0={k: v["ms"] / prof_steps for k, v in prof.items()},
-                        kernel_ms_measured="timed region" if a.streams <= 1 else "one extra single-stream frame after the timed region"),
+                        kernel_ms_measured="timed region" if a.streams <= 1 else "one extra single-stream frame after the timed region",
+                        per_rank=per_rank),
             roofline=dict(bound="mfma", achieved=achieved, peak=PEAK_F32_VIA_BF16X6_TFLOPS, unit="TFLOP/s",
                           frac=achieved / PEAK_F32_VIA_BF16X6_TFLOPS, traffic=traffic, traffic_source=traffic_src,
                           kernel="view_transformer_kernel", avg_launch_ms=vt_ms, launches=vt["launches"],
@@ -222,6 +283,14 @@ def main():
                           # 1680 v_mfma_f32_16x16x32_bf16 (16 384 flop each) per 8 points at NV = 3, K / row padding included
                           issued_bf16_tflops=achieved * (1680 * 16384 / 8) / VIEWT_FLOP_PER_POINT[3] if a.views == 3 else None),
         )
+        if not a.no_gpu_eager_baseline and world == 1:
+            # the >= 20x target's denominator, measured in the same run on the same GPU (BASELINE.md has no published
+            # number: vs_baseline is relative to this leg, not to a figure from the reference's authors)
+            eager = gpu_eager_baseline(frame_cpu, weights_cpu, a, dev)
+            line["gpu_eager_baseline"] = eager
+            line["vs_baseline"] = rays_per_s / eager["value"]
+            line["config"]["vs_baseline_denominator"] = ("gpu_eager_baseline.value: eager PyTorch restatement of the reference "
+                                                         "path on this GPU, 800-ray chunks (BASELINE.md section 3)")
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(frame_cpu, weights_cpu, a)
         print(json.dumps(line), flush=True)

@@ -37,8 +37,9 @@ def test_fmt_mirror_matches_reference_golden_cpu():
     g = np.load(os.path.join(HERE, "golden", "fmt_small3.npz"))
     got = _run("cpu")
     assert set(got) == set(g.files)
-    for k in g.files:                                            # same torch ops in the same order
-        assert torch.equal(got[k], torch.from_numpy(g[k])), k
+    for k in g.files:                          # same math, own op decomposition (fused projections, batched matmuls)
+        ref = torch.from_numpy(g[k])
+        assert float((got[k] - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), k
     assert got["match_feature"].shape == (1, 3, 64, 8, 16)      # (B, V, 32 (V-1), h, w): ufr_frame_prepare's match_feature
 
 

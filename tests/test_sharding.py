@@ -92,3 +92,37 @@ def test_gradient_allreduce_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res)
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_renders_the_one_rank_frame(tmp_path):
+    """The real N > 1 path of bench.py (launcher -> one process per rank -> row-tile sharding -> all-gather) with 2 ranks
+    sharing this box's single GPU over gloo: the gathered (H,W) depth map must equal the 1-rank frame bit for bit, and
+    rank 0 must report every rank's kernel split and all-gather time."""
+    import json
+    import subprocess
+    import sys
+
+    import numpy as np
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--height", "64", "--width", "96", "--steps", "1", "--warmup", "1", "--fixed-uniforms", "7", "--no-cpu-baseline",
+              "--no-gpu-eager-baseline", "--chunk", "2048"]
+    env = dict(os.environ, UFR_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dump-depth", str(tmp_path / "d1.npy"),
+                          *common], capture_output=True, text=True, env=env, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--dump-depth", str(tmp_path / "d2.npy"), *common], capture_output=True, text=True, env=env, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    d1, d2 = np.load(tmp_path / "d1.npy"), np.load(tmp_path / "d2.npy")
+    assert d1.shape == d2.shape == (64, 96)
+    assert np.array_equal(d1, d2)
+    line = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and len(line["config"]["per_rank"]) == 2
+    for r in line["config"]["per_rank"]:
+        assert r["rays"] == 32 * 96 and "view_transformer" in r["kernel_ms_per_frame"] and r["all_gather_ms_per_step"] >= 0

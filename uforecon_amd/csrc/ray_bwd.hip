@@ -461,9 +461,15 @@ __global__ void __launch_bounds__(kBwdThreads) presim_bwd_kernel(RawPtrs wp, Gra
 hipError_t launch_ray_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* token0, const float* order_pe,
                           const float* d_srdf, int RN, int SN, float* d_tok_a, float* d_tok_b, float* dbg, hipStream_t s) {
   if (SN % kTT != 0 || SN < kTT) return hipErrorInvalidValue;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ray_bwd_kernel),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, rb::kLdsBytes);
-  if (attr != hipSuccess) return attr;
+  static bool attr_set[16] = {};   // the attribute is per device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+  if (!attr_set[dev]) {
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ray_bwd_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, rb::kLdsBytes);
+    if (attr != hipSuccess) return attr;
+    attr_set[dev] = true;
+  }
   const int blocks = RN < 256 ? RN : 256;
   hipLaunchKernelGGL(ray_bwd_kernel, dim3(blocks), dim3(kBwdThreads), rb::kLdsBytes, s, wp, gp, token0, order_pe, d_srdf,
                      RN, SN, d_tok_a, d_tok_b, dbg);

@@ -79,7 +79,10 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
   const bool valid = ray_raw < RN;           // no early exit: every wave meets every chunk barrier
   const int ray = valid ? ray_raw : RN - 1;
   const int n_tiles = SN / 16;
-  const float inv_len = 1.f / (float)SN;  // exact for the power-of-two sample counts; SN is validated on the host
+  // values / v_length (linear_attention.py:41): a multiply by 1/SN is exact only for power-of-two sample counts;
+  // any other total (64 + 32, 48, ...) takes the true division the reference performs
+  const float inv_len = 1.f / (float)SN, f_len = (float)SN;
+  const bool pow2_len = (SN & (SN - 1)) == 0;
 
   // ---------------- sweep 1: KV_h[d][v] = sum_s K'_h[s][d] * V_h[s][v] / SN   (linear_attention.py:41-42)
   f32x4 KV[8];
@@ -117,7 +120,8 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float kk = j < 11 ? elu1(kt[0][h][r]) : 0.f;                      // padded dims contribute nothing
-        const float vv = j < 11 ? vt[0][h][r] * inv_len : (j == 11 ? 1.f : 0.f);  // ones column -> sum of K'
+        const float vs = pow2_len ? vt[0][h][r] * inv_len : vt[0][h][r] / f_len;
+        const float vv = j < 11 ? vs : (j == 11 ? 1.f : 0.f);                     // ones column -> sum of K'
         KV[h] = mfma16(kk, vv, KV[h]);
       }
     }
@@ -199,9 +203,16 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
 hipError_t launch_ray_transformer(const float* packed, const float* token0, const int* tok_row, const float* order_pe,
                                   int RN, int SN, float* srdf, float* ray_out, hipStream_t s) {
   if (SN % 16 != 0 || SN < 16) return hipErrorInvalidValue;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ray_transformer_kernel),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, kBfLdsBytes);
-  if (attr != hipSuccess) return attr;
+  // the attribute is per device: set it once on every device this process launches on
+  static bool attr_set[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+  if (!attr_set[dev]) {
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ray_transformer_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, kBfLdsBytes);
+    if (attr != hipSuccess) return attr;
+    attr_set[dev] = true;
+  }
   hipLaunchKernelGGL(ray_transformer_kernel, dim3((RN + kRtWaves - 1) / kRtWaves), dim3(kRtBlock), kBfLdsBytes, s,
                      packed, token0, tok_row, order_pe, RN, SN, srdf, ray_out);
   return hipGetLastError();

@@ -454,14 +454,20 @@ struct SidePool {
   hipEvent_t fork = nullptr, join[kMaxLanes] = {};
   int n = 0;
 };
-thread_local SidePool g_side;
+constexpr int kMaxDevices = 16;
+thread_local SidePool g_side_by_device[kMaxDevices];   // streams and events belong to the device they were created on
 
-int side_pool_init(int n) {
-  if (!g_side.fork) UFR_HIP(hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming));
-  for (; g_side.n < n; ++g_side.n) {
-    UFR_HIP(hipStreamCreateWithFlags(&g_side.s[g_side.n], hipStreamNonBlocking));
-    UFR_HIP(hipEventCreateWithFlags(&g_side.join[g_side.n], hipEventDisableTiming));
+int side_pool_get(int n, SidePool** out) {
+  int dev = 0;
+  UFR_HIP(hipGetDevice(&dev));
+  UFR_REQUIRE(dev >= 0 && dev < kMaxDevices, "side streams: device %d out of range", dev);
+  SidePool& p = g_side_by_device[dev];
+  if (!p.fork) UFR_HIP(hipEventCreateWithFlags(&p.fork, hipEventDisableTiming));
+  for (; p.n < n; ++p.n) {
+    UFR_HIP(hipStreamCreateWithFlags(&p.s[p.n], hipStreamNonBlocking));
+    UFR_HIP(hipEventCreateWithFlags(&p.join[p.n], hipEventDisableTiming));
   }
+  *out = &p;
   return UFR_OK;
 }
 
@@ -577,25 +583,28 @@ int ufr_render_rays(const ufr_render_args* a, ufr_stream stream) {
     }
     return UFR_OK;
   }
-  int rc = side_pool_init(lanes);
+  SidePool* side = nullptr;
+  int rc = side_pool_get(lanes, &side);
   if (rc != UFR_OK) return rc;
-  UFR_HIP(hipEventRecord(g_side.fork, s));
+  UFR_HIP(hipEventRecord(side->fork, s));
   RenderWs w[kMaxLanes];
   bool pe_ready[kMaxLanes] = {};
   for (int l = 0; l < lanes; ++l) {
     w[l] = carve_render(static_cast<char*>(a->workspace) + (size_t)l * need, chunk, SN, PN, NV);
-    UFR_HIP(hipStreamWaitEvent(g_side.s[l], g_side.fork, 0));
+    UFR_HIP(hipStreamWaitEvent(side->s[l], side->fork, 0));
   }
-  for (int c = 0; c < n_chunks; ++c) {
+  for (int c = 0; c < n_chunks && rc == UFR_OK; ++c) {
     const int l = c % lanes, r0 = c * eff_chunk;
-    rc = render_chunk(a, f, w[l], pe_ready[l], r0, (RN - r0) < eff_chunk ? (RN - r0) : eff_chunk, g_side.s[l]);
-    if (rc != UFR_OK) return rc;
+    rc = render_chunk(a, f, w[l], pe_ready[l], r0, (RN - r0) < eff_chunk ? (RN - r0) : eff_chunk, side->s[l]);
   }
+  // join even when a chunk failed: the caller's stream must not run ahead of (and its allocator must not recycle the
+  // workspace under) side-stream kernels that were already enqueued
   for (int l = 0; l < lanes; ++l) {
-    UFR_HIP(hipEventRecord(g_side.join[l], g_side.s[l]));
-    UFR_HIP(hipStreamWaitEvent(s, g_side.join[l], 0));
+    hipError_t e = hipEventRecord(side->join[l], side->s[l]);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s, side->join[l], 0);
+    if (e != hipSuccess) hipStreamSynchronize(side->s[l]);
   }
-  return UFR_OK;
+  return rc;
 }
 
 // ------------------------------------------------------------------ correlation-volume construction

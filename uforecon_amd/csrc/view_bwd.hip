@@ -456,9 +456,15 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
 hipError_t launch_view_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* x_tokens, const float* rgbm,
                            const float* dirs, const float* d_tok_a, const float* d_tok_b, const float* d_radiance, int P,
                            int NV, float* d_pv, float* dbg, hipStream_t s) {
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&view_bwd_kernel),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, vb::kLdsBytes);
-  if (attr != hipSuccess) return attr;
+  static bool attr_set[16] = {};   // the attribute is per device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+  if (!attr_set[dev]) {
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&view_bwd_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, vb::kLdsBytes);
+    if (attr != hipSuccess) return attr;
+    attr_set[dev] = true;
+  }
   const int PPT = kTT / (NV + 1);
   const int n_tiles = (P + PPT - 1) / PPT;
   const int blocks = n_tiles < 256 ? n_tiles : 256;

@@ -401,9 +401,16 @@ static hipError_t launch_vt(const float* packed, const float* x_tokens, const fl
       if (best_cost < 0 || cost < best_cost) { best_cost = cost; blocks = b; }
     }
   }
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&view_transformer_kernel<L, C>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, kBfLdsBytes);
-  if (attr != hipSuccess) return attr;
+  // the attribute is per device: set it once on every device this process launches on
+  static bool attr_set[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+  if (!attr_set[dev]) {
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&view_transformer_kernel<L, C>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, kBfLdsBytes);
+    if (attr != hipSuccess) return attr;
+    attr_set[dev] = true;
+  }
   hipLaunchKernelGGL((view_transformer_kernel<L, C>), dim3(blocks), dim3(kVtBlock), kBfLdsBytes, s, packed, x_tokens,
                      rgb, dir, P, token0, radiance, view_out);
   return hipGetLastError();

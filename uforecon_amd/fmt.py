@@ -1,229 +1,212 @@
-"""Feature Matching Transformer and the pair-wise matching features.
+"""Feature-matching transformer stage of the per-frame encoder and the pair-wise matching features it feeds to the ray
+path (out of the per-ray hot path, library ops only: 8 GFLOP per 512x640 3-view frame).
 
-Mirrors, with the reference's class names, forward signatures and state_dict keys,
-  LinearAttention, AttentionLayer, EncoderLayer, FMT, FMT_with_pathway   code1/encoder_utils/fmt/FMT.py:17-316
-  PositionEncodingSine                                                  code1/encoder_utils/fmt/position_encoding.py:24-60
-  TransMVSNet.get_match_feat                                            code1/encoder_utils/fmt/TransMVSNet.py:341-375
-These are 8 encoder layers of width 32 over h*w tokens (8 GFLOP per 512x640 3-view frame): plain library ops
-(torch -> rocBLAS / elementwise kernels) are the right tool; there is nothing here worth a hand-written kernel, unlike the
-per-ray path, whose transformers see 63 M tokens per frame.  Inference only.  The FeatureNet / DCN backbone that produces
-the inputs is not mirrored (it needs torchvision's deformable convolution, absent here, so it could not be pinned).
+What the reference computes (code1/encoder_utils/fmt/FMT.py:17-316, position_encoding.py:24-60,
+TransMVSNet.py:341-375), restated here around ONE token engine instead of a module per concept:
+
+* a stack of eight width-32 post-norm layers, alternately "self" and "cross", each = linear attention (feature map
+  elu(.)+1, 8 heads of 4) + out-projection + residual, LayerNorm, a 32-64-32 ReLU MLP + residual, LayerNorm;
+* three ways of walking that stack: the reference view (self layers only, every intermediate kept), a source view (cross
+  layers attend to the reference view's intermediate of the same depth), and "pair" mode for the matching features;
+* a top-down pathway that pushes the 1/4-resolution result into the 1/2 and full resolution backbone maps.
+
+Only the PARAMETER TREE follows the reference (a checkpoint must load: ``FMT.layers.<i>.attention.query_projection.weight``
+...); the computation lives in the functions below: the three projections of a self layer are one fused GEMM, attention is
+two batched matmuls per layer on a (batch*heads, tokens, 4) layout, and the three walks are one loop over a per-layer plan.
+Inference only.
 """
 from __future__ import annotations
 
-import copy
 import math
+from typing import List, Optional, Sequence
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+HEADS = 8
 
-class LinearAttention(nn.Module):
-    """FMT.py:17-39"""
 
-    def __init__(self, eps=1e-6):
+# ------------------------------------------------------------------ parameter tree (state_dict keys of the reference)
+class _Projections(nn.Module):
+    def __init__(self, d: int):
         super().__init__()
-        self.eps = eps
-
-    def forward(self, queries, keys, values):
-        Q = F.elu(queries) + 1
-        K = F.elu(keys) + 1
-        KV = torch.einsum("nshd,nshm->nhmd", K, values)
-        Z = 1 / (torch.einsum("nlhd,nhd->nlh", Q, K.sum(dim=1)) + self.eps)
-        return torch.einsum("nlhd,nhmd,nlh->nlhm", Q, KV, Z).contiguous()
+        self.query_projection = nn.Linear(d, d)
+        self.key_projection = nn.Linear(d, d)
+        self.value_projection = nn.Linear(d, d)
+        self.out_projection = nn.Linear(d, d)
 
 
-class AttentionLayer(nn.Module):
-    """FMT.py:42-79"""
-
-    def __init__(self, attention, d_model, n_heads, d_keys=None, d_values=None):
+class _LayerParams(nn.Module):
+    def __init__(self, d: int):
         super().__init__()
-        d_keys = d_keys or (d_model // n_heads)
-        d_values = d_values or (d_model // n_heads)
-        self.inner_attention = attention
-        self.query_projection = nn.Linear(d_model, d_keys * n_heads)
-        self.key_projection = nn.Linear(d_model, d_keys * n_heads)
-        self.value_projection = nn.Linear(d_model, d_values * n_heads)
-        self.out_projection = nn.Linear(d_values * n_heads, d_model)
-        self.n_heads = n_heads
-
-    def forward(self, queries, keys, values):
-        N, L, _ = queries.shape
-        _, S, _ = keys.shape
-        H = self.n_heads
-        q = self.query_projection(queries).view(N, L, H, -1)
-        k = self.key_projection(keys).view(N, S, H, -1)
-        v = self.value_projection(values).view(N, S, H, -1)
-        return self.out_projection(self.inner_attention(q, k, v).view(N, L, -1))
+        self.attention = _Projections(d)
+        self.linear1 = nn.Linear(d, 2 * d)
+        self.linear2 = nn.Linear(2 * d, d)
+        self.norm1 = nn.LayerNorm(d)
+        self.norm2 = nn.LayerNorm(d)
 
 
-class EncoderLayer(nn.Module):
-    """FMT.py:82-113 (dropout 0)"""
-
-    def __init__(self, d_model, n_heads, d_keys=None, d_values=None, d_ff=None, dropout=0.0, activation="relu"):
-        super().__init__()
-        d_keys = d_keys or (d_model // n_heads)
-        self.attention = AttentionLayer(LinearAttention(), d_model, n_heads, d_keys, d_values)
-        d_ff = d_ff or 2 * d_model
-        self.linear1 = nn.Linear(d_model, d_ff)
-        self.linear2 = nn.Linear(d_ff, d_model)
-        self.norm1 = nn.LayerNorm(d_model)
-        self.norm2 = nn.LayerNorm(d_model)
-        self.dropout = nn.Dropout(dropout)
-        self.activation = getattr(F, activation)
-
-    def forward(self, x, source):
-        x = x + self.dropout(self.attention(x, source, source))
-        y = x = self.norm1(x)
-        y = self.dropout(self.activation(self.linear1(y)))
-        y = self.dropout(self.linear2(y))
-        return self.norm2(x + y)
+# ------------------------------------------------------------------ token engine
+def _split_heads(t: torch.Tensor) -> torch.Tensor:
+    """(N, T, C) -> (N*HEADS, T, C/HEADS)"""
+    n, t_, c = t.shape
+    return t.view(n, t_, HEADS, c // HEADS).permute(0, 2, 1, 3).reshape(n * HEADS, t_, c // HEADS)
 
 
-class PositionEncodingSine(nn.Module):
-    """position_encoding.py:24-60 (temp_bug_fix=True); the table is a non-persistent buffer, as in the reference."""
-
-    def __init__(self, d_model, max_shape=(600, 600)):
-        super().__init__()
-        pe = torch.zeros((d_model, *max_shape))
-        y_position = torch.ones(max_shape).cumsum(0).float().unsqueeze(0)
-        x_position = torch.ones(max_shape).cumsum(1).float().unsqueeze(0)
-        div_term = torch.exp(torch.arange(0, d_model // 2, 2).float() * (-math.log(10000.0) / (d_model // 2)))[:, None, None]
-        pe[0::4] = torch.sin(x_position * div_term)
-        pe[1::4] = torch.cos(x_position * div_term)
-        pe[2::4] = torch.sin(y_position * div_term)
-        pe[3::4] = torch.cos(y_position * div_term)
-        self.register_buffer("pe", pe.unsqueeze(0), persistent=False)
-
-    def forward(self, x):
-        return x + self.pe[:, :, :x.size(2), :x.size(3)]
+def _linear_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    """softmax-free attention with the elu+1 feature map (FMT.py:25-38), all heads in one batched matmul pair:
+    out_l = phi(q_l) (sum_s phi(k_s)^T v_s) / (phi(q_l) . sum_s phi(k_s) + eps)."""
+    n, tq, c = q.shape
+    qh, kh, vh = _split_heads(F.elu(q) + 1), _split_heads(F.elu(k) + 1), _split_heads(v)
+    state = torch.bmm(kh.transpose(1, 2), vh)                      # (N*H, 4, 4)   sum_s phi(k)^T v
+    norm = torch.bmm(qh, kh.sum(dim=1, keepdim=True).transpose(1, 2)) + eps   # (N*H, T, 1)
+    out = torch.bmm(qh, state) / norm
+    return out.view(n, HEADS, tq, c // HEADS).permute(0, 2, 1, 3).reshape(n, tq, c)
 
 
-def _tokens(x):
-    return x.flatten(2).transpose(1, 2)                       # 'n c h w -> n (h w) c'
+def _layer(p: _LayerParams, x: torch.Tensor, src: Optional[torch.Tensor]) -> torch.Tensor:
+    """One post-norm layer (FMT.py:99-113, dropout 0).  ``src is None``: self-attention, q/k/v from one fused GEMM."""
+    a = p.attention
+    if src is None:
+        w = torch.cat([a.query_projection.weight, a.key_projection.weight, a.value_projection.weight], 0)
+        b = torch.cat([a.query_projection.bias, a.key_projection.bias, a.value_projection.bias], 0)
+        q, k, v = F.linear(x, w, b).chunk(3, dim=-1)
+    else:
+        q = F.linear(x, a.query_projection.weight, a.query_projection.bias)
+        w = torch.cat([a.key_projection.weight, a.value_projection.weight], 0)
+        b = torch.cat([a.key_projection.bias, a.value_projection.bias], 0)
+        k, v = F.linear(src, w, b).chunk(2, dim=-1)
+    x = F.layer_norm(x + F.linear(_linear_attention(q, k, v), a.out_projection.weight, a.out_projection.bias),
+                     x.shape[-1:], p.norm1.weight, p.norm1.bias)
+    y = F.linear(F.relu(F.linear(x, p.linear1.weight, p.linear1.bias)), p.linear2.weight, p.linear2.bias)
+    return F.layer_norm(x + y, x.shape[-1:], p.norm2.weight, p.norm2.bias)
 
 
-def _image(t, H):
-    n, hw, c = t.shape
-    return t.transpose(1, 2).reshape(n, c, H, hw // H)         # 'n (h w) c -> n c h w'
+def _to_tokens(img: torch.Tensor) -> torch.Tensor:
+    return img.flatten(2).transpose(1, 2)                          # (N,C,H,W) -> (N,HW,C)
+
+
+def _to_image(tok: torch.Tensor, height: int) -> torch.Tensor:
+    n, t, c = tok.shape
+    return tok.transpose(1, 2).reshape(n, c, height, t // height)
+
+
+def _sine_table(d_model: int, height: int, width: int, device, dtype) -> torch.Tensor:
+    """2-D sinusoidal position code of position_encoding.py:33-50 (the reference's `temp_bug_fix` variant: frequencies
+    exp(-2i ln(1e4) / (d/2))), positions counted from 1; channels cycle [sin x, cos x, sin y, cos y]."""
+    ys = torch.arange(1, height + 1, dtype=torch.float32)[:, None].expand(height, width)
+    xs = torch.arange(1, width + 1, dtype=torch.float32)[None, :].expand(height, width)
+    freq = torch.exp(torch.arange(0, d_model // 2, 2).float() * (-math.log(10000.0) / (d_model // 2)))[:, None, None]
+    table = torch.empty(d_model, height, width)
+    table[0::4], table[1::4] = torch.sin(xs * freq), torch.cos(xs * freq)
+    table[2::4], table[3::4] = torch.sin(ys * freq), torch.cos(ys * freq)
+    return table.to(device=device, dtype=dtype)[None]
 
 
 class FMT(nn.Module):
-    """FMT.py:116-201: self-attention on the reference view, self + cross on a source view, pair mode for matching."""
+    """Owner of the eight layers (`layers.<i>.*` keys).  ``walk`` is the one loop behind the reference's three modes."""
 
     def __init__(self, config):
         super().__init__()
-        self.d_model, self.nhead, self.layer_names = config["d_model"], config["nhead"], config["layer_names"]
-        layer = EncoderLayer(config["d_model"], config["nhead"])
-        self.layers = nn.ModuleList([copy.deepcopy(layer) for _ in range(len(self.layer_names))])
-        self.pos_encoding = PositionEncodingSine(config["d_model"])
+        self.d_model, self.nhead, self.layer_names = config["d_model"], config["nhead"], list(config["layer_names"])
+        if self.nhead != HEADS or any(n not in ("self", "cross") for n in self.layer_names):
+            raise ValueError(f"unsupported FMT configuration {config}")
+        self.layers = nn.ModuleList([_LayerParams(self.d_model) for _ in self.layer_names])
 
+    def _embed(self, img: torch.Tensor) -> torch.Tensor:
+        return _to_tokens(img + _sine_table(self.d_model, img.shape[2], img.shape[3], img.device, img.dtype))
+
+    def walk(self, x: torch.Tensor, cross_sources: Optional[Sequence[torch.Tensor]], skip_cross: bool = False,
+             keep: bool = False) -> List[torch.Tensor]:
+        """Run tokens ``x`` down the stack.  ``cross_sources[i]`` feeds cross layer i (tokens); ``skip_cross`` drops the
+        cross layers (reference-view walk, FMT.py:141-146); ``keep`` returns the output of every self layer."""
+        kept = []
+        for i, (p, name) in enumerate(zip(self.layers, self.layer_names)):
+            if name == "self":
+                x = _layer(p, x, None)
+                if keep:
+                    kept.append(x)
+            elif not skip_cross:
+                x = _layer(p, x, cross_sources[i])
+        return kept if keep else [x]
+
+    # the reference's call convention, kept for callers that use it
     def forward(self, ref_feature=None, src_feature=None, feat="ref", self_features=None):
-        assert ref_feature is not None
-        if feat == "ref":
-            assert self.d_model == ref_feature.size(1)
-            H = ref_feature.shape[2]
-            x = _tokens(self.pos_encoding(ref_feature))
-            outs = []
-            for layer, name in zip(self.layers, self.layer_names):
-                if name == "self":
-                    x = layer(x, x)
-                    outs.append(_image(x, H))
-            return outs
-        if feat == "src":
-            assert self.d_model == ref_feature[0].size(1)
-            H = ref_feature[0].shape[2]
-            refs = [_tokens(r) for r in ref_feature]
-            x = _tokens(self.pos_encoding(src_feature))
-            for i, (layer, name) in enumerate(zip(self.layers, self.layer_names)):
-                if name == "self":
-                    x = layer(x, x)
-                elif name == "cross":
-                    x = layer(x, refs[i // 2])
-                else:
-                    raise KeyError(name)
-            return _image(x, H)
-        if feat == "cross":
-            H = ref_feature.shape[2]
-            f0, f1 = _tokens(self.pos_encoding(ref_feature)), _tokens(self.pos_encoding(src_feature))
-            p1, p2 = torch.cat([f0, f1], dim=0), torch.cat([f1, f0], dim=0)
-            for layer, name in zip(self.layers, self.layer_names):
-                if name == "self":
-                    p1 = layer(p1, p1)
-                elif name == "cross":
-                    p1 = layer(p1, p2)        # p2 is never updated in the reference (FMT.py:186-193): kept
-                else:
-                    raise KeyError(name)
-            return _image(p1, H), _image(p1, H)   # both returns are pair_feat1, as in the reference (:196)
+        if feat == "ref":                                             # FMT.py:137-150
+            h = ref_feature.shape[2]
+            return [_to_image(t, h) for t in self.walk(self._embed(ref_feature), None, skip_cross=True, keep=True)]
+        if feat == "src":                                             # FMT.py:152-170: cross layer i <- ref_feature[i // 2]
+            h = src_feature.shape[2]
+            refs = [_to_tokens(r) for r in ref_feature]
+            sources = [refs[i // 2] if n == "cross" else None for i, n in enumerate(self.layer_names)]
+            return _to_image(self.walk(self._embed(src_feature), sources)[0], h)
+        if feat == "cross":                                           # FMT.py:172-197
+            h = ref_feature.shape[2]
+            a, b = self._embed(ref_feature), self._embed(src_feature)
+            # pair mode stacks (a, b) on the batch axis and lets every cross layer attend to the SWAPPED stack (b, a) of
+            # the *embedded inputs*: the reference never updates the second stack (FMT.py:186-193) and returns the first
+            # one twice (:196).  Both quirks are part of what `match_feature` means.
+            first, second = torch.cat([a, b], 0), torch.cat([b, a], 0)
+            out = _to_image(self.walk(first, [second] * len(self.layers))[0], h)
+            return out, out
         raise ValueError("Wrong feature name")
 
 
 class FMT_with_pathway(nn.Module):
-    """FMT.py:204-316"""
+    """FMT + the top-down pathway (`dim_reduction_*`, `smooth_*` keys; FMT.py:204-255)."""
 
     def __init__(self, base_channels=8, FMT_config=None):
         super().__init__()
-        FMT_config = FMT_config or {"d_model": 32, "nhead": 8, "layer_names": ["self", "cross"] * 4}
-        self.FMT = FMT(FMT_config)
-        self.dim_reduction_1 = nn.Conv2d(base_channels * 4, base_channels * 2, 1, bias=False)
-        self.dim_reduction_2 = nn.Conv2d(base_channels * 2, base_channels * 1, 1, bias=False)
-        self.smooth_1 = nn.Conv2d(base_channels * 2, base_channels * 2, 3, padding=1, bias=False)
-        self.smooth_2 = nn.Conv2d(base_channels * 1, base_channels * 1, 3, padding=1, bias=False)
+        self.FMT = FMT(FMT_config or {"d_model": 32, "nhead": 8, "layer_names": ["self", "cross"] * 4})
+        c = base_channels
+        self.dim_reduction_1 = nn.Conv2d(4 * c, 2 * c, 1, bias=False)
+        self.dim_reduction_2 = nn.Conv2d(2 * c, c, 1, bias=False)
+        self.smooth_1 = nn.Conv2d(2 * c, 2 * c, 3, padding=1, bias=False)
+        self.smooth_2 = nn.Conv2d(c, c, 3, padding=1, bias=False)
 
-    def _upsample_add(self, x, y):
-        _, _, H, W = y.size()
-        return F.interpolate(x, size=(H, W), mode="bilinear") + y
-
-    def _pathway(self, f):
-        f["stage2"] = self.smooth_1(self._upsample_add(self.dim_reduction_1(f["stage1"]), f["stage2"]))
-        f["stage3"] = self.smooth_2(self._upsample_add(self.dim_reduction_2(f["stage2"]), f["stage3"]))
+    def _push_down(self, coarse, fine, reduce, smooth):
+        up = F.interpolate(reduce(coarse), size=fine.shape[-2:], mode="bilinear")
+        return smooth(up + fine)
 
     def forward(self, features, ref_idx=0):
-        """features: list over views of {"stage1","stage2","stage3"} backbone maps; updated in place and returned."""
-        ref_list = None
-        for v, f in enumerate(features):
+        """``features``: per view {"stage1","stage2","stage3"} backbone maps (updated in place, FMT.py:237-255).  The
+        reference view goes first because the source views attend to its intermediates."""
+        order = [ref_idx] + [v for v in range(len(features)) if v != ref_idx]
+        ref_levels = None
+        for v in order:
+            f = features[v]
             if v == ref_idx:
-                ref_list = self.FMT(f["stage1"].clone(), feat="ref")
-                f["stage1"] = ref_list[-1]
+                ref_levels = self.FMT(f["stage1"], feat="ref")
+                f["stage1"] = ref_levels[-1]
             else:
-                f["stage1"] = self.FMT([r.clone() for r in ref_list], f["stage1"].clone(), feat="src")
-            self._pathway(f)
+                f["stage1"] = self.FMT(ref_levels, f["stage1"], feat="src")
+            f["stage2"] = self._push_down(f["stage1"], f["stage2"], self.dim_reduction_1, self.smooth_1)
+            f["stage3"] = self._push_down(f["stage2"], f["stage3"], self.dim_reduction_2, self.smooth_2)
         return features
 
-    def extract_pair_feature(self, features, stages=("stage1",)):
-        n_views = len(features)
-        index_lists = [(a, b) for a in range(n_views - 1) for b in range(a + 1, n_views)]
-        f0s, f1s = [], []
-        for stage in stages:
-            c0 = torch.stack([features[i][stage] for i, _ in index_lists], dim=1)
-            c1 = torch.stack([features[j][stage] for _, j in index_lists], dim=1)
-            f0s.append(c0.reshape(-1, *c0.shape[-3:]))
-            f1s.append(c1.reshape(-1, *c1.shape[-3:]))
-        return f0s, f1s
-
-    def extract_cross_features(self, features, ref_idx=0):
-        f0s, f1s = self.extract_pair_feature(features)
-        batch_size = features[0]["stage1"].shape[0]
-        a0, a1 = [], []
-        for f0, f1 in zip(f0s, f1s):
-            g0, g1 = self.FMT(f0, f1, feat="cross")
-            a0.append(g0.reshape(batch_size, g0.shape[0] // batch_size, *g0.shape[-3:]))
-            a1.append(g1.reshape(batch_size, g1.shape[0] // batch_size, *g1.shape[-3:]))
-        return {"aug_feat0s": a0, "aug_feat1s": a1}
+    def pair_features(self, features):
+        """Pair-mode output for every view pair (a < b) of the 1/4-resolution maps: (B, n_pairs, 32, h, w), twice
+        (FMT.py:257-315 `extract_cross_features`: 'aug_feat0s' and 'aug_feat1s' are the same tensor upstream)."""
+        n = len(features)
+        pairs = [(a, b) for a in range(n - 1) for b in range(a + 1, n)]
+        batch = features[0]["stage1"].shape[0]
+        first = torch.stack([features[a]["stage1"] for a, _ in pairs], 1).flatten(0, 1)
+        second = torch.stack([features[b]["stage1"] for _, b in pairs], 1).flatten(0, 1)
+        out, _ = self.FMT(first, second, feat="cross")
+        return out.reshape(batch, out.shape[0] // batch, *out.shape[1:]), pairs
 
 
 def get_match_feat(fmt_with_pathway: FMT_with_pathway, features, cur_n_src_views=3):
-    """TransMVSNet.get_match_feat (TransMVSNet.py:341-375): list over scales of (B, V, 32*(V-1), h, w) -- the
-    `match_feature` argument of UFORecon.infer."""
-    out = fmt_with_pathway.extract_cross_features(features)
-    index_lists = [(a, b) for a in range(cur_n_src_views - 1) for b in range(a + 1, cur_n_src_views)]
-    result = []
-    for scale_idx in range(len(out["aug_feat0s"])):
-        per_view = [[] for _ in range(cur_n_src_views)]
-        f0, f1 = out["aug_feat0s"][scale_idx], out["aug_feat1s"][scale_idx]
-        for k, (i, j) in enumerate(index_lists):
-            per_view[i].append(f0[:, k])
-            per_view[j].append(f1[:, k])
-        result.append(torch.stack([torch.cat(v, dim=1) for v in per_view], dim=1))
-    return result
+    """The `match_feature` argument of UFORecon.infer: [ (B, V, 32*(V-1), h, w) ] (TransMVSNet.py:341-375).
+
+    Pair mode doubles the batch ((a, b) stacked); reshaped to (B, 2*n_pairs, ...) the reference then reads entry k < n_pairs
+    for BOTH views of pair k -- so both receive view a's cross-attended map.  View v's channels are
+    the pairs it takes part in, in pair order."""
+    pair_maps, pairs = fmt_with_pathway.pair_features(features)
+    per_view = [[] for _ in range(cur_n_src_views)]
+    for k, (a, b) in enumerate(pairs):
+        if a < cur_n_src_views and b < cur_n_src_views:
+            per_view[a].append(pair_maps[:, k])
+            per_view[b].append(pair_maps[:, k])
+    return [torch.stack([torch.cat(chunks, dim=1) for chunks in per_view], dim=1)]

@@ -27,6 +27,14 @@ class UFOReconInference(M.UFORecon):
         self.transmvsnet.feature = featurenet.FeatureNet(base_channels=8)        # TransMVSNet.py:152
         self.feature_volume = cascade.MVSVolume(in_channels=1, base_channels=8)   # model.py:64
         self.pre_conv = nn.Conv2d(128, 32, 1, bias=False)                         # dead parameter of the reference
+        self.eval()
+
+    def train(self, mode: bool = True):
+        """Inference only: the encoder's BatchNorms must run on their running statistics (in training mode they would
+        normalise with batch statistics AND overwrite the loaded running_mean / running_var on every frame)."""
+        if mode:
+            raise M.UfrError("UFOReconInference is inference-only: it stays in eval mode (BatchNorm running statistics)")
+        return super().train(False)
 
     # ---- model.py:139-160
     @staticmethod

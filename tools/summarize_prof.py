@@ -27,6 +27,21 @@ def main(src: str, dst_prefix: str):
                 if i:
                     row[0] = short(row[0])
                 w.writerow(row)
+    tstats = os.path.join(src, "train_kernel_stats.csv")
+    if os.path.exists(tstats):   # training step (tools/bench_train.py)
+        with open(tstats) as f, open(dst_prefix + "_train_kernel_stats.csv", "w", newline="") as g:
+            w = csv.writer(g)
+            for i, row in enumerate(csv.reader(f)):
+                if i:
+                    row[0] = short(row[0])
+                w.writerow(row)
+    tl = os.path.join(src, "train_line.json")
+    if os.path.exists(tl):
+        for line in open(tl).read().strip().splitlines():
+            if line.startswith("{"):
+                with open(dst_prefix + "_train_under_rocprof.json", "w") as g:
+                    json.dump(json.loads(line), g, indent=1)
+                    g.write("\n")
     table = collections.defaultdict(dict)
     for tag in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_lds", "pmc_tcc"):
         p = os.path.join(src, tag + "_counter_collection.csv")

@@ -39,7 +39,17 @@ enum : int {
   O_DDEN = 1823,    // 8 heads
   O_END = 1831
 };
-constexpr int kLdsBytes = O_END * kLD * 4;
+// flat regions behind the tile rows (floats): small parameters copied once per workgroup, and the per-tile colours / masks /
+// d radiance of the tile's points (prefetched with the tokens)
+enum : int {
+  F_N1W = 0, F_N1B = 80, F_N2W = 160, F_N2B = 240,     // LayerNorm gamma / beta
+  F_RW_B0 = 320, F_RW_W2 = 336, F_RW_B2 = 464, F_RW_W4 = 472, F_RW_B4 = 480,
+  F_RGBM = 484,          // [PPT][NV][4]  (<= 5 points x 7 views)
+  F_DRAD = 484 + 140,    // [PPT][3] (+1 pad)
+  F_END = 484 + 140 + 20
+};
+constexpr int kFlatBase = (O_END * kLD + 3) / 4 * 4;   // 16-byte aligned (float4 reads of the colours)
+constexpr int kLdsBytes = (kFlatBase + F_END) * 4;
 
 constexpr WgMat kMats[] = {
     {P_VT_Q, 80, 80, O_DQ, O_CAT},       {P_VT_K, 80, 80, O_DK, O_CAT},        {P_VT_V, 80, 80, O_DV, O_CAT},
@@ -75,47 +85,94 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
   float accA = 0.f, accB = 0.f, accC = 0.f, accN1 = 0.f, accN2 = 0.f;   // small gradients, a few scalars per thread (see the flush)
 
   auto R = [&](int row) -> float* { return lds + row * kLD; };
+  float* flat = lds + kFlatBase;
+  {  // small parameters: read by every tile's VALU phases, so they live in LDS (a global load there is an exposed L2 trip)
+    const int i = tid;
+    if (i < 80) {
+      flat[F_N1W + i] = wp.p[P_VT_N1W][i]; flat[F_N1B + i] = wp.p[P_VT_N1B][i];
+      flat[F_N2W + i] = wp.p[P_VT_N2W][i]; flat[F_N2B + i] = wp.p[P_VT_N2B][i];
+    }
+    if (i < 128) flat[F_RW_W2 + i] = wp.p[P_RW_W2][i];
+    if (i < 16) flat[F_RW_B0 + i] = wp.p[P_RW_B0][i];
+    if (i < 8) { flat[F_RW_B2 + i] = wp.p[P_RW_B2][i]; flat[F_RW_W4 + i] = wp.p[P_RW_W4][i]; }
+    if (i == 0) flat[F_RW_B4] = wp.p[P_RW_B4][0];
+  }
+
+  // A tile's global inputs (tokens, staged d token0, dir, colours / masks, d radiance) are fetched into registers one
+  // tile AHEAD -- the loads are issued in front of the weight-gradient phase of the previous tile -- and committed to LDS at
+  // the top of the tile: the HBM latency hides behind ~26 k cycles of MFMAs instead of opening every tile.
+  constexpr int kTokLoads = (kTT * 20 + kBwdThreads - 1) / kBwdThreads;   // float4 token loads per thread
+  struct TileIn { f32x4 v[kTokLoads], d[kTokLoads]; float misc; };
+  auto fetch = [&](int tile, TileIn& in) __attribute__((always_inline)) {
+    const int p0 = tile * PPT;
+#pragma unroll
+    for (int q = 0; q < kTokLoads; ++q) {
+      const int idx = tid0 + q * kBwdThreads;
+      const int col = idx / 20, f4 = idx - col * 20;
+      const int pt = col / L, tv = col - pt * L, p = p0 + pt;
+      in.v[q] = splat4(0.f);
+      in.d[q] = splat4(0.f);
+      if (idx < kTT * 20 && pt < PPT && p < P) {
+        if (tv == 0) {
+          in.v[q] = ld4(wp.p[P_VIEW_TOKEN] + 4 * f4);
+          in.d[q] = ld4(d_tok_a + (size_t)p * UFR_TOKEN_DIM + 4 * f4);
+          if (d_tok_b) in.d[q] += ld4(d_tok_b + (size_t)p * UFR_TOKEN_DIM + 4 * f4);
+        } else {
+          in.v[q] = ld4(x_tokens + ((size_t)p * NV + tv - 1) * UFR_TOKEN_DIM + 4 * f4);
+        }
+      }
+    }
+    // one float per thread: [0, 48) dir of (col, e); [48, 48 + PPT*NV*4) colours / masks; then PPT*3 d radiance
+    in.misc = 0.f;
+    const int i = tid0;
+    if (i < kTT * 3) {
+      const int col = i / 3, e = i - col * 3, pt = col / L, tv = col - pt * L, p = p0 + pt;
+      if (pt < PPT && p < P && tv > 0) in.misc = dirs[((size_t)p * NV + tv - 1) * 4 + e];
+    } else if (i < kTT * 3 + PPT * NV * 4) {
+      const int k = i - kTT * 3, pt = k / (NV * 4), p = p0 + pt;
+      if (p < P) in.misc = rgbm[(size_t)p * NV * 4 + (k - pt * NV * 4)];
+    } else if (i < kTT * 3 + PPT * NV * 4 + PPT * 3) {
+      const int k = i - kTT * 3 - PPT * NV * 4, pt = k / 3, p = p0 + pt;
+      if (p < P) in.misc = d_radiance[(size_t)p * 3 + (k - pt * 3)];
+    }
+  };
+  auto commit = [&](const TileIn& in) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < kTokLoads; ++q) {
+      const int idx = tid0 + q * kBwdThreads;
+      if (idx < kTT * 20) {
+        const int col = idx / 20, f4 = idx - col * 20;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          R(O_CAT + 4 * f4 + e)[col] = in.v[q][e];
+          R(O_DY + 4 * f4 + e)[col] = in.d[q][e];
+        }
+      }
+    }
+    const int i = tid0;
+    if (i < kTT * 3) R(O_RIN + 80 + i % 3)[i / 3] = in.misc;
+    else if (i < kTT * 3 + PPT * NV * 4) flat[F_RGBM + i - kTT * 3] = in.misc;
+    else if (i < kTT * 3 + PPT * NV * 4 + PPT * 3) flat[F_DRAD + i - kTT * 3 - PPT * NV * 4] = in.misc;
+  };
 
 #ifdef UFR_BWD_TIMING
   unsigned long long t_prev = __builtin_readcyclecounter();
 #endif
+  TileIn cur_in;
+  if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x, cur_in);
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int p0 = tile * PPT;
-    // ---------------- P0: token inputs (ray_transformer.py:284-286), dir, staged d token0
-    for (int idx = tid; idx < kTT * 20; idx += kBwdThreads) {
-      const int col = idx / 20, f4 = idx - col * 20;
-      const int pt = col / L, tv = col - pt * L, p = p0 + pt;
-      const bool ok = pt < PPT && p < P;
-      f32x4 v = splat4(0.f), d = splat4(0.f);
-      if (ok) {
-        if (tv == 0) {
-          v = ld4(wp.p[P_VIEW_TOKEN] + 4 * f4);
-          d = ld4(d_tok_a + (size_t)p * UFR_TOKEN_DIM + 4 * f4);
-          if (d_tok_b) d += ld4(d_tok_b + (size_t)p * UFR_TOKEN_DIM + 4 * f4);
-        } else {
-          v = ld4(x_tokens + ((size_t)p * NV + tv - 1) * UFR_TOKEN_DIM + 4 * f4);
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        R(O_CAT + 4 * f4 + e)[col] = v[e];
-        R(O_DY + 4 * f4 + e)[col] = d[e];
-      }
-    }
-    if (tid < kTT) {
-      const int col = tid, pt = col / L, tv = col - pt * L, p = p0 + pt;
-      const bool ok = pt < PPT && p < P && tv > 0;
-#pragma unroll
-      for (int e = 0; e < 3; ++e) R(O_RIN + 80 + e)[col] = ok ? dirs[((size_t)p * NV + tv - 1) * 4 + e] : 0.f;
-    }
+    // ---------------- P0: token inputs (ray_transformer.py:284-286), dir, staged d token0, colours, d radiance
+    commit(cur_in);
     auto pf0 = gemm_prefetch<80, 80, false>(wp.p[P_VT_Q], 80, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 0)
 
-    // ---------------- P1: q, k, v (15 row tiles dealt over the 8 waves)
-    gemm_compute<80, 80, false>(pf0, wp.p[P_VT_Q], 80, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_Q + r)[c] = v; });
-    gemm_lds<80, 80, false>(wp.p[P_VT_K], 80, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = v; }, 5);
+    // ---------------- P1: Q' = elu(q)+1, K' = elu(k)+1, v (15 row tiles dealt over the waves).  Only the feature-mapped
+    // values are kept: elu'(q) = q > 0 ? 1 : exp(q) = (Q' > 1 ? 1 : Q')
+    gemm_compute<80, 80, false>(pf0, wp.p[P_VT_Q], 80, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_Q + r)[c] = elu1(v); });
+    gemm_lds<80, 80, false>(wp.p[P_VT_K], 80, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = elu1(v); }, 5);
     gemm_lds<80, 80, false>(wp.p[P_VT_V], 80, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_V + r)[c] = v; }, 10);
     __syncthreads();
     tid = opaque(tid0);
@@ -132,12 +189,12 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
       if (pt < PPT) {
         float Qp[10], den = 0.f;
 #pragma unroll
-        for (int d = 0; d < 10; ++d) Qp[d] = elu1(R(O_Q + 10 * h + d)[col]);
+        for (int d = 0; d < 10; ++d) Qp[d] = R(O_Q + 10 * h + d)[col];
         for (int s = 0; s < L; ++s) {
           const int c2 = pt * L + s;
           float a = 0.f;
 #pragma unroll
-          for (int d = 0; d < 10; ++d) a = fmaf(Qp[d], elu1(R(O_K + 10 * h + d)[c2]), a);
+          for (int d = 0; d < 10; ++d) a = fmaf(Qp[d], R(O_K + 10 * h + d)[c2], a);
           den += a;
 #pragma unroll
           for (int e = 0; e < 10; ++e) msg[e] = fmaf(a, R(O_V + 10 * h + e)[c2] * invL, msg[e]);
@@ -158,7 +215,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 3)
-    ln_forward<80>(R(O_XH1), R(O_CAT + 80), nullptr, wp.p[P_VT_N1W], wp.p[P_VT_N1B], R(O_RSTD1), tid);
+    ln_forward<80>(R(O_XH1), R(O_CAT + 80), nullptr, flat + F_N1W, flat + F_N1B, R(O_RSTD1), tid);
     auto pf2 = gemm_prefetch<160, 160, false>(wp.p[P_VT_MLP0], 160, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
@@ -174,22 +231,22 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 6)
-    ln_forward<80>(R(O_XH2), R(O_RIN), R(O_CAT), wp.p[P_VT_N2W], wp.p[P_VT_N2B], R(O_RSTD2), tid);
+    ln_forward<80>(R(O_XH2), R(O_RIN), R(O_CAT), flat + F_N2W, flat + F_N2B, R(O_RSTD2), tid);
     auto pf4 = gemm_prefetch<16, 83, false>(wp.p[P_RW_W0], 83, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 7)
     // ---------------- P8-P10: radiance-weight MLP 83 -> 16 -> 8 -> 1 (ray_transformer.py:159-163, 313-314)
     gemm_compute<16, 83, false>(pf4, wp.p[P_RW_W0], 83, R(O_RIN), wave, lane,
-                            [&](int r, int c, float v) { R(O_H1 + r)[c] = fmaxf(v + wp.p[P_RW_B0][r], 0.f); });
+                            [&](int r, int c, float v) { R(O_H1 + r)[c] = fmaxf(v + flat[F_RW_B0 + r], 0.f); });
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 8)
     if (tid < 8 * kTT) {
       const int o = tid >> 4, c = tid & 15;
-      float s = wp.p[P_RW_B2][o];
+      float s = flat[F_RW_B2 + o];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s = fmaf(wp.p[P_RW_W2][o * 16 + i], R(O_H1 + i)[c], s);
+      for (int i = 0; i < 16; ++i) s = fmaf(flat[F_RW_W2 + o * 16 + i], R(O_H1 + i)[c], s);
       R(O_H2 + o)[c] = fmaxf(s, 0.f);
     }
     __syncthreads();
@@ -206,10 +263,10 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
       float mx = -INFINITY;
       for (int v = 0; v < NV; ++v) {
         const int c = pt * L + 1 + v;
-        float s = wp.p[P_RW_B4][0];
+        float s = flat[F_RW_B4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s = fmaf(wp.p[P_RW_W4][i], R(O_H2 + i)[c], s);
-        const f32x4 col = ld4(rgbm + ((size_t)p * NV + v) * 4);
+        for (int i = 0; i < 8; ++i) s = fmaf(flat[F_RW_W4 + i], R(O_H2 + i)[c], s);
+        const f32x4 col = ld4(flat + F_RGBM + (pt * NV + v) * 4);
         cr[v] = col[0]; cg[v] = col[1]; cb[v] = col[2]; mk[v] = col[3];
         lg[v] = col[3] == 0.f ? -1e9f : s;
         mx = fmaxf(mx, lg[v]);
@@ -223,7 +280,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
         lg[v] /= den;
         rr = fmaf(lg[v], cr[v], rr); rg = fmaf(lg[v], cg[v], rg); rb = fmaf(lg[v], cb[v], rb);
       }
-      const float dr = d_radiance[(size_t)p * 3 + 0], dg = d_radiance[(size_t)p * 3 + 1], db = d_radiance[(size_t)p * 3 + 2];
+      const float dr = flat[F_DRAD + pt * 3 + 0], dg = flat[F_DRAD + pt * 3 + 1], db = flat[F_DRAD + pt * 3 + 2];
       const float dot_r = rr * dr + rg * dg + rb * db;
       for (int v = 0; v < NV; ++v) {
         const float dl = lg[v] * ((cr[v] * dr + cg[v] * dg + cb[v] * db) - dot_r);
@@ -236,7 +293,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     // ---------------- B1: radiance MLP backwards
     if (tid < 8 * kTT) {
       const int o = tid >> 4, c = tid & 15;
-      R(O_DH2 + o)[c] = R(O_H2 + o)[c] > 0.f ? wp.p[P_RW_W4][o] * R(O_DLOGIT)[c] : 0.f;
+      R(O_DH2 + o)[c] = R(O_H2 + o)[c] > 0.f ? flat[F_RW_W4 + o] * R(O_DLOGIT)[c] : 0.f;
     }
     __syncthreads();
     tid = opaque(tid0);
@@ -245,7 +302,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
       const int i = tid >> 4, c = tid & 15;
       float s = 0.f;
 #pragma unroll
-      for (int o = 0; o < 8; ++o) s = fmaf(wp.p[P_RW_W2][o * 16 + i], R(O_DH2 + o)[c], s);
+      for (int o = 0; o < 8; ++o) s = fmaf(flat[F_RW_W2 + o * 16 + i], R(O_DH2 + o)[c], s);
       R(O_DH1 + i)[c] = R(O_H1 + i)[c] > 0.f ? s : 0.f;
     }
     auto pf5 = gemm_prefetch<80, 16, true>(wp.p[P_RW_W0], 83, wave, lane, 0);
@@ -258,7 +315,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 14)
     // ---------------- B3: LayerNorm2 backwards; y = x + LN2(.) so d x starts as d y
-    ln_backward<80>(R(O_DY), R(O_XH2), wp.p[P_VT_N2W], R(O_RSTD2), R(O_DOPRE), tid);
+    ln_backward<80>(R(O_DY), R(O_XH2), flat + F_N2W, R(O_RSTD2), R(O_DOPRE), tid);
     if (tid < 80) accN2 += row_dot(R(O_DY), R(O_XH2), tid);
     else if (tid < 160) accN2 += row_dot(R(O_DY), nullptr, tid - 80);
     auto pf6 = gemm_prefetch<160, 80, true>(wp.p[P_VT_MLP2], 160, wave, lane, 0);
@@ -277,7 +334,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 17)
     // ---------------- B6: LayerNorm1 backwards on the message half; the x half joins the d x accumulator
-    ln_backward<80>(R(O_DCAT + 80), R(O_XH1), wp.p[P_VT_N1W], R(O_RSTD1), R(O_DMPRE), tid);
+    ln_backward<80>(R(O_DCAT + 80), R(O_XH1), flat + F_N1W, R(O_RSTD1), R(O_DMPRE), tid);
     if (tid < 80) accN1 += row_dot(R(O_DCAT + 80), R(O_XH1), tid);
     else if (tid < 160) accN1 += row_dot(R(O_DCAT + 80), nullptr, tid - 80);
     for (int idx = tid; idx < 80 * kTT; idx += kBwdThreads) {
@@ -306,7 +363,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
         float Qp[10], dm[10], r[10];
 #pragma unroll
         for (int d = 0; d < 10; ++d) {
-          Qp[d] = elu1(R(O_Q + 10 * h + d)[col]);
+          Qp[d] = R(O_Q + 10 * h + d)[col];
           dm[d] = R(O_DMSG + 10 * h + d)[col];
           r[d] = 0.f;
         }
@@ -314,7 +371,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
           const int c2 = pt * L + s;
           float a = 0.f;
 #pragma unroll
-          for (int d = 0; d < 10; ++d) a = fmaf(Qp[d], elu1(R(O_K + 10 * h + d)[c2]), a);
+          for (int d = 0; d < 10; ++d) a = fmaf(Qp[d], R(O_K + 10 * h + d)[c2], a);
 #pragma unroll
           for (int e = 0; e < 10; ++e) r[e] = fmaf(a, R(O_V + 10 * h + e)[c2] * invL, r[e]);
         }
@@ -329,11 +386,14 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
 #pragma unroll
           for (int e = 0; e < 10; ++e) dA = fmaf(u * dm[e], R(O_V + 10 * h + e)[c2] * invL, dA);
 #pragma unroll
-          for (int d = 0; d < 10; ++d) dq[d] = fmaf(dA, elu1(R(O_K + 10 * h + d)[c2]), dq[d]);
+          for (int d = 0; d < 10; ++d) dq[d] = fmaf(dA, R(O_K + 10 * h + d)[c2], dq[d]);
         }
       }
 #pragma unroll
-      for (int d = 0; d < 10; ++d) R(O_DQ + 10 * h + d)[col] = dq[d] * elu1_grad(R(O_Q + 10 * h + d)[col]);
+      for (int d = 0; d < 10; ++d) {
+        const float qp = R(O_Q + 10 * h + d)[col];
+        R(O_DQ + 10 * h + d)[col] = dq[d] * (qp > 1.f ? 1.f : qp);
+      }
       R(O_DDEN + h)[col] = dden;
     }
     __syncthreads();
@@ -350,7 +410,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
         float Kp[10], V[10];
 #pragma unroll
         for (int d = 0; d < 10; ++d) {
-          Kp[d] = elu1(R(O_K + 10 * h + d)[col]);
+          Kp[d] = R(O_K + 10 * h + d)[col];
           V[d] = R(O_V + 10 * h + d)[col] * invL;
         }
         for (int s = 0; s < L; ++s) {
@@ -360,7 +420,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
           float Qs[10], dr[10];
 #pragma unroll
           for (int d = 0; d < 10; ++d) {
-            Qs[d] = elu1(R(O_Q + 10 * h + d)[c2]);
+            Qs[d] = R(O_Q + 10 * h + d)[c2];
             dr[d] = u * R(O_DMSG + 10 * h + d)[c2];
             a = fmaf(Qs[d], Kp[d], a);
             dA = fmaf(dr[d], V[d], dA);
@@ -374,7 +434,8 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
       }
 #pragma unroll
       for (int d = 0; d < 10; ++d) {
-        R(O_DK + 10 * h + d)[col] = dk[d] * elu1_grad(R(O_K + 10 * h + d)[col]);
+        const float kp = R(O_K + 10 * h + d)[col];
+        R(O_DK + 10 * h + d)[col] = dk[d] * (kp > 1.f ? 1.f : kp);
         R(O_DV + 10 * h + d)[col] = dv[d] * invL;
       }
     }
@@ -429,7 +490,9 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
         }
       }
     }
-    // ---------------- B12: weight gradients of the seven matrices on the MFMA, register-resident tiles
+    // ---------------- B12: weight gradients of the seven matrices on the MFMA, register-resident tiles;
+    // the next tile's global inputs are requested first and land while these MFMAs run
+    if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x, cur_in);
     wgrad_all<vb::kList, 7, kSlots, 0>(acc, lds, wave, lane);
     __syncthreads();
     tid = opaque(tid0);

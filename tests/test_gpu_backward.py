@@ -198,3 +198,75 @@ def test_optimizer_step_follows_the_gradients():
                      uniforms=(U1, U2))
     loss2 = _loss_from_tuple(r2, f.batch, idx.to(DEV))
     assert float(loss2) < float(loss)
+
+
+def test_full_size_training_step_properties():
+    """BASELINE configs[4] at its real size (1024 random rays of a 512x640 frame, 3 views, 64+64 samples), checked through
+    size-independent properties of the adjoints: (a) the backward is LINEAR in the output cotangents -- gradients of
+    a L1 + b L2 equal a grad(L1) + b grad(L2); (b) a directional finite difference of the loss along a random parameter
+    direction agrees with <grad, direction>; (c) volume gradients are exactly zero outside the voxels the rays touch."""
+    from uforecon_amd.scene import make_frame
+
+    H, W, NV, RN = 512, 640, 3, 1024
+    c = dict(coarse=64, fine=64)
+    fr = make_frame(H, W, NV, seed=9, train_layout=True)
+    f = fr.to(DEV)
+    vols = [f.feature_volume[st][k] for st in f.feature_volume for k in f.feature_volume[st]]
+    for v in vols:
+        v.requires_grad_(True)
+    m = M.UFORecon(_args(c)).to(DEV)
+    m.load_state_dict(load_weights(), strict=True)
+    g = torch.Generator().manual_seed(17)
+    idx = torch.randperm(H * W, generator=g)[:RN][None].to(DEV)
+    U = (torch.rand(64, RN, generator=g), torch.rand(64, RN, generator=g))
+    params = list(m.parameters())
+
+    def outputs():
+        r = m.infer(f.batch, idx, f.source_imgs_feat, f.feature_volume, match_feature=f.match_feature, uniforms=U)
+        return r[1][0], r[2][0], r[8][0], r[9][0], r[0][0], r[3][0]      # rgb, depth, rgb_2, depth_2, rgb_gt, depth_gt
+
+    def grads_of(loss):
+        gs = torch.autograd.grad(loss, params + vols, allow_unused=True)
+        return [torch.zeros_like(p) if g_ is None else g_ for g_, p in zip(gs, params + vols)]
+
+    rgb, depth, rgb2, depth2, rgb_gt, depth_gt = outputs()
+    L1 = ((rgb - rgb_gt) ** 2).mean() + ((rgb2 - rgb_gt) ** 2).mean()
+    L2 = (depth - depth_gt).abs().mean() + (depth2 - depth_gt).abs().mean()
+    g1 = grads_of(L1)
+    rgb, depth, rgb2, depth2, rgb_gt, depth_gt = outputs()
+    L2 = (depth - depth_gt).abs().mean() + (depth2 - depth_gt).abs().mean()
+    g2 = grads_of(L2)
+    rgb, depth, rgb2, depth2, rgb_gt, depth_gt = outputs()
+    L12 = 0.7 * (((rgb - rgb_gt) ** 2).mean() + ((rgb2 - rgb_gt) ** 2).mean()) \
+        - 1.3 * ((depth - depth_gt).abs().mean() + (depth2 - depth_gt).abs().mean())
+    g12 = grads_of(L12)
+    for a, b, ab in zip(g1, g2, g12):                                   # (a) linearity (atomics reorder sums: 1e-4)
+        want = 0.7 * a - 1.3 * b
+        assert float((ab - want).abs().max()) <= 2e-4 * max(float(want.abs().max()), 1e-6)
+    # (c) sparsity: a frustum voxel no sample touches receives exactly zero
+    touched = sum(int((gv != 0).sum()) for gv in g12[len(params):])
+    total = sum(gv.numel() for gv in g12[len(params):])
+    assert 0 < touched < 0.2 * total
+    # (b) directional derivative along a random parameter direction (central difference, fp32 loss) for a smooth loss of
+    # the COARSE pass: the fine pass's sample positions follow the coarse weights but are detached (model.py:456-457), so
+    # the gradient of a fine-pass loss is by design not its total derivative
+    def smooth_coarse_loss():
+        rgb, depth, _, _, rgb_gt, depth_gt = outputs()
+        return ((rgb - rgb_gt) ** 2).mean() + ((depth - depth_gt) ** 2).mean()
+
+    gc = grads_of(smooth_coarse_loss())
+    with torch.no_grad():
+        direction = [torch.randn(p.shape, generator=g).to(DEV) * p.abs().mean().clamp_min(1e-3) for p in params]
+        slope = sum(float((gi * di).sum()) for gi, di in zip(gc[:len(params)], direction))
+
+        def loss_at(eps):
+            for p, d in zip(params, direction):
+                p.add_(eps * d)
+            out = float(smooth_coarse_loss())
+            for p, d in zip(params, direction):
+                p.sub_(eps * d)
+            return out
+
+        eps = 1e-3
+        fd = (loss_at(eps) - loss_at(-eps)) / (2 * eps)
+    assert abs(fd - slope) <= 0.03 * abs(slope) + 1e-4, (fd, slope)

@@ -20,39 +20,48 @@
 namespace ufr {
 
 // load the ray-transformer input tile: [token-0 feature (80) | order PE (8)] in nat88 layout
+#ifndef UFR_RT_C
+#define UFR_RT_C 1   // 16-token column tiles per wave and iteration
+#endif
+constexpr int kRtC = UFR_RT_C;
+
 __device__ __forceinline__ void load_ray_tile(const float* __restrict__ token0, const int* __restrict__ tok_row,
                                               const float* __restrict__ order_pe, size_t tok_base, int s_base, int g,
-                                              int j, f32x4 (&x)[1][6]) {
+                                              int j, f32x4 (&x)[6]) {
   const float* row = token0 + (tok_row ? (size_t)tok_row[tok_base + j] : tok_base + j) * UFR_TOKEN_DIM;
 #pragma unroll
-  for (int t = 0; t < 5; ++t) x[0][t] = ld4(row + 16 * t + 4 * g);
+  for (int t = 0; t < 5; ++t) x[t] = ld4(row + 16 * t + 4 * g);
   const float* pe = order_pe + (size_t)(s_base + j) * 8 + 2 * g;  // features 80+2g, 81+2g in registers 0,1
-  x[0][5] = f32x4{pe[0], pe[1], 0.f, 0.f};
+  x[5] = f32x4{pe[0], pe[1], 0.f, 0.f};
 }
 
 // LayerNorm over 88 features in nat88 layout (tile 5: registers 0,1 real)
 template <int VW, int VB>
-__device__ __forceinline__ void layer_norm88(f32x4 (&t)[1][6], const WStreamBf& ws, int g) {
-  float s = 0.f;
+__device__ __forceinline__ void layer_norm88(f32x4 (&tt)[kRtC][6], const WStreamBf& ws, int g) {
 #pragma unroll
-  for (int i = 0; i < 5; ++i) s += (t[0][i][0] + t[0][i][1]) + (t[0][i][2] + t[0][i][3]);
-  s += t[0][5][0] + t[0][5][1];
-  const float mean = sum_groups(s) * (1.f / 88.f);
-  float q = 0.f;
+  for (int c = 0; c < kRtC; ++c) {
+    f32x4 (&t)[6] = tt[c];
+    float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 5; ++i) s += (t[i][0] + t[i][1]) + (t[i][2] + t[i][3]);
+    s += t[5][0] + t[5][1];
+    const float mean = sum_groups(s) * (1.f / 88.f);
+    float q = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (i < 5 || r < 2) {
-        float d = t[0][i][r] - mean;
-        q = fmaf(d, d, q);
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (i < 5 || r < 2) {
+          float d = t[i][r] - mean;
+          q = fmaf(d, d, q);
+        }
       }
-    }
-  const float rstd = 1.f / sqrtf(sum_groups(q) * (1.f / 88.f) + 1e-5f);
+    const float rstd = 1.f / sqrtf(sum_groups(q) * (1.f / 88.f) + 1e-5f);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const f32x4 gw = vec_frag<VW>(ws, i, g), gb = vec_frag<VB>(ws, i, g);  // zero in the padding slots
-    t[0][i] = (t[0][i] - mean) * rstd * gw + gb;
+    for (int i = 0; i < 6; ++i) {
+      const f32x4 gw = vec_frag<VW>(ws, i, g), gb = vec_frag<VB>(ws, i, g);  // zero in the padding slots
+      t[i] = (t[i] - mean) * rstd * gw + gb;
+    }
   }
 }
 
@@ -79,6 +88,8 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
   const bool valid = ray_raw < RN;           // no early exit: every wave meets every chunk barrier
   const int ray = valid ? ray_raw : RN - 1;
   const int n_tiles = SN / 16;
+  constexpr int C = kRtC;
+  const int n_iter = (n_tiles + C - 1) / C;   // an odd tile count leaves the last iteration's second tile empty (masked)
   // values / v_length (linear_attention.py:41): a multiply by 1/SN is exact only for power-of-two sample counts;
   // any other total (64 + 32, 48, ...) takes the true division the reference performs
   const float inv_len = 1.f / (float)SN, f_len = (float)SN;
@@ -88,41 +99,51 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
   f32x4 KV[8];
 #pragma unroll
   for (int h = 0; h < 8; ++h) KV[h] = splat4(0.f);
-  for (int tile = 0; tile < n_tiles; ++tile) {
-    const bool wrap = tile + 1 < n_tiles;
-    f32x4 x[1][6], kt[1][8], vt[1][8];
-    load_ray_tile(token0, tok_row, order_pe, (size_t)ray * SN + tile * 16, tile * 16, g, j, x);
+  for (int it = 0; it < n_iter; ++it) {
+    const bool wrap = it + 1 < n_iter;
+    f32x4 x[C][6], kt[C][8], vt[C][8];
+    bool live[C];
 #pragma unroll
-    for (int h = 0; h < 8; ++h) { kt[0][h] = splat4(0.f); vt[0][h] = splat4(0.f); }
+    for (int c = 0; c < C; ++c) {
+      const int tile = it * C + c;
+      live[c] = tile < n_tiles;
+      const int tl = live[c] ? tile : n_tiles - 1;
+      load_ray_tile(token0, tok_row, order_pe, (size_t)ray * SN + tl * 16, tl * 16, g, j, x[c]);
+#pragma unroll
+      for (int h = 0; h < 8; ++h) { kt[c][h] = splat4(0.f); vt[c][h] = splat4(0.f); }
+    }
     {  // swapped operands: kt[h], vt[h] rows = tokens 4g+r, column j = head dim; x is split once per k-step
-      BWords<1> cur;
-      split_units<0, 0, 4>(x, cur);
+      BWords<C> cur;
+      split_units<0, 0, 4 * C>(x, cur);
       static_for<3>([&](auto si) __attribute__((always_inline)) {
         constexpr int s = decltype(si)::value;
-        BStep b[1];
+        BStep b[C];
         bwords_to_bstep(cur, b);
         if constexpr (s < 2) {
-          BWords<1> nxt;
-          gemm_bf_panel<M_RT_K, s, 1, kRtWaves, true>(ws, b, kt, wrap, [&](auto ti) __attribute__((always_inline)) {
+          BWords<C> nxt;
+          gemm_bf_panel<M_RT_K, s, C, kRtWaves, true>(ws, b, kt, wrap, [&](auto ti) __attribute__((always_inline)) {
             constexpr int to = decltype(ti)::value;
-            split_units<s + 1, to * 4 / 8, (to + 1) * 4 / 8>(x, nxt);
+            split_units<s + 1, to * 4 * C / 8, (to + 1) * 4 * C / 8>(x, nxt);
           });
-          gemm_bf_panel<M_RT_V, s, 1, kRtWaves, true>(ws, b, vt, wrap);
+          gemm_bf_panel<M_RT_V, s, C, kRtWaves, true>(ws, b, vt, wrap);
           cur = nxt;
         } else {
-          gemm_bf_panel<M_RT_K, s, 1, kRtWaves, true>(ws, b, kt, wrap);
-          gemm_bf_panel<M_RT_V, s, 1, kRtWaves, true>(ws, b, vt, wrap);
+          gemm_bf_panel<M_RT_K, s, C, kRtWaves, true>(ws, b, kt, wrap);
+          gemm_bf_panel<M_RT_V, s, C, kRtWaves, true>(ws, b, vt, wrap);
         }
       });
     }
 #pragma unroll
-    for (int h = 0; h < 8; ++h) {
+    for (int c = 0; c < C; ++c) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float kk = j < 11 ? elu1(kt[0][h][r]) : 0.f;                      // padded dims contribute nothing
-        const float vs = pow2_len ? vt[0][h][r] * inv_len : vt[0][h][r] / f_len;
-        const float vv = j < 11 ? vs : (j == 11 ? 1.f : 0.f);                     // ones column -> sum of K'
-        KV[h] = mfma16(kk, vv, KV[h]);
+      for (int h = 0; h < 8; ++h) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float kk = (j < 11 && live[c]) ? elu1(kt[c][h][r]) : 0.f;            // padded dims / empty tile contribute nothing
+          const float vs = pow2_len ? vt[c][h][r] * inv_len : vt[c][h][r] / f_len;
+          const float vv = j < 11 ? vs : (j == 11 ? 1.f : 0.f);                       // ones column -> sum of K'
+          KV[h] = mfma16(kk, vv, KV[h]);
+        }
       }
     }
     wstream_bf_finish<B_RT1, kRtWaves>(ws, wrap);
@@ -130,72 +151,102 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
 
   // ---------------- sweep 2 (slot 0 is free: every wave passed the barrier that opened sweep 1's last chunk)
   wstream_bf_prime<B_RT2, kRtWaves>(ws);
-  for (int tile = 0; tile < n_tiles; ++tile) {
-    const bool wrap = tile + 1 < n_tiles;
-    f32x4 x[1][6], q[1][8], msg[1][8];
-    load_ray_tile(token0, tok_row, order_pe, (size_t)ray * SN + tile * 16, tile * 16, g, j, x);
+  for (int it = 0; it < n_iter; ++it) {
+    const bool wrap = it + 1 < n_iter;
+    f32x4 x[C][6], q[C][8], msg[C][8];
+    bool live[C];
+    int tbase[C];
 #pragma unroll
-    for (int h = 0; h < 8; ++h) q[0][h] = splat4(0.f);
-    gemm_bf<M_RT_Q, 1, kRtWaves>(ws, x, q, wrap);  // q[h]: rows = head dims 4g+r, column j = token
+    for (int c = 0; c < C; ++c) {
+      const int tile = it * C + c;
+      live[c] = tile < n_tiles;
+      tbase[c] = (live[c] ? tile : n_tiles - 1) * 16;
+      load_ray_tile(token0, tok_row, order_pe, (size_t)ray * SN + tbase[c], tbase[c], g, j, x[c]);
 #pragma unroll
-    for (int h = 0; h < 8; ++h) {
-      f32x4 acc = splat4(0.f);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float qq = (4 * g + r < 11) ? elu1(q[0][h][r]) : 0.f;
-        acc = mfma16(KV[h][r], qq, acc);           // rows v = 4g+r: sum_d KV[d][v] Q'[d]; row 11 = Q'.sum(K')
-      }
-      const float den = __shfl(acc[3], 32 + j);    // row 11 lives in lane group 2, register 3
-      const float Z = 1.f / (den + 1e-6f);         // linear_attention.py:43
-      msg[0][h] = acc * (Z * (float)SN);           // :44  (rows >= 11 meet zero merge columns)
+      for (int h = 0; h < 8; ++h) q[c][h] = splat4(0.f);
     }
-    f32x4 m[1][6];
+    gemm_bf<M_RT_Q, C, kRtWaves>(ws, x, q, wrap);  // q[h]: rows = head dims 4g+r, column j = token
 #pragma unroll
-    for (int t = 0; t < 6; ++t) m[0][t] = splat4(0.f);
-    gemm_bf<M_RT_MERGE, 1, kRtWaves>(ws, msg, m, wrap);
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        f32x4 acc = splat4(0.f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float qq = (4 * g + r < 11) ? elu1(q[c][h][r]) : 0.f;
+          acc = mfma16(KV[h][r], qq, acc);           // rows v = 4g+r: sum_d KV[d][v] Q'[d]; row 11 = Q'.sum(K')
+        }
+        const float den = __shfl(acc[3], 32 + j);    // row 11 lives in lane group 2, register 3
+        const float Z = 1.f / (den + 1e-6f);         // linear_attention.py:43
+        msg[c][h] = acc * (Z * (float)SN);           // :44  (rows >= 11 meet zero merge columns)
+      }
+    }
+    f32x4 m[C][6];
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int t = 0; t < 6; ++t) m[c][t] = splat4(0.f);
+    gemm_bf<M_RT_MERGE, C, kRtWaves>(ws, msg, m, wrap);
     layer_norm88<V_RT_N1W, V_RT_N1B>(m, ws, g);
 
-    f32x4 cat[1][12], hid[1][11], o[1][6];
+    f32x4 cat[C][12], hid[C][11], o[C][6];
 #pragma unroll
-    for (int t = 0; t < 6; ++t) { cat[0][t] = x[0][t]; cat[0][6 + t] = m[0][t]; }
+    for (int c = 0; c < C; ++c) {
 #pragma unroll
-    for (int t = 0; t < 11; ++t) hid[0][t] = splat4(0.f);
-    gemm_bf<M_RT_MLP0, 1, kRtWaves>(ws, cat, hid, wrap);
+      for (int t = 0; t < 6; ++t) { cat[c][t] = x[c][t]; cat[c][6 + t] = m[c][t]; }
 #pragma unroll
-    for (int t = 0; t < 11; ++t)
+      for (int t = 0; t < 11; ++t) hid[c][t] = splat4(0.f);
+    }
+    gemm_bf<M_RT_MLP0, C, kRtWaves>(ws, cat, hid, wrap);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) hid[0][t][r] = fmaxf(hid[0][t][r], 0.f);
+    for (int c = 0; c < C; ++c) {
 #pragma unroll
-    for (int t = 0; t < 6; ++t) o[0][t] = splat4(0.f);
-    gemm_bf<M_RT_MLP2, 1, kRtWaves>(ws, hid, o, wrap);
+      for (int t = 0; t < 11; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hid[c][t][r] = fmaxf(hid[c][t][r], 0.f);
+#pragma unroll
+      for (int t = 0; t < 6; ++t) o[c][t] = splat4(0.f);
+    }
+    gemm_bf<M_RT_MLP2, C, kRtWaves>(ws, hid, o, wrap);
     layer_norm88<V_RT_N2W, V_RT_N2B>(o, ws, g);
 #pragma unroll
-    for (int t = 0; t < 6; ++t) o[0][t] += x[0][t];
-
-    if (ray_out && valid) {
-      float* row = ray_out + ((size_t)ray * SN + tile * 16 + j) * UFR_RAY_DIM;
+    for (int c = 0; c < C; ++c) {
 #pragma unroll
-      for (int t = 0; t < 5; ++t) st4(row + 16 * t + 4 * g, o[0][t]);
-      row[80 + 2 * g] = o[0][5][0];
-      row[81 + 2 * g] = o[0][5][1];
+      for (int t = 0; t < 6; ++t) o[c][t] += x[c][t];
+      if (ray_out && valid && live[c]) {
+        float* row = ray_out + ((size_t)ray * SN + tbase[c] + j) * UFR_RAY_DIM;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) st4(row + 16 * t + 4 * g, o[c][t]);
+        row[80 + 2 * g] = o[c][5][0];
+        row[81 + 2 * g] = o[c][5][1];
+      }
     }
 
     // ---------------- DensityMLP 88 -> 32 -> 16 -> 1 (ray_transformer.py:147-150, 307)
-    f32x4 d1[1][2], d2[1][1], d3[1][1];
-    d1[0][0] = vec_frag<V_DM_B0>(ws, 0, g);
-    d1[0][1] = vec_frag<V_DM_B0>(ws, 1, g);
-    d2[0][0] = vec_frag<V_DM_B2>(ws, 0, g);
-    d3[0][0] = vec_frag<V_DM_B4>(ws, 0, g);
-    gemm_bf<M_DM0, 1, kRtWaves>(ws, o, d1, wrap);
+    f32x4 d1[C][2], d2[C][1], d3[C][1];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int c = 0; c < C; ++c) {
+      d1[c][0] = vec_frag<V_DM_B0>(ws, 0, g);
+      d1[c][1] = vec_frag<V_DM_B0>(ws, 1, g);
+      d2[c][0] = vec_frag<V_DM_B2>(ws, 0, g);
+      d3[c][0] = vec_frag<V_DM_B4>(ws, 0, g);
+    }
+    gemm_bf<M_DM0, C, kRtWaves>(ws, o, d1, wrap);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) d1[0][t][r] = fmaxf(d1[0][t][r], 0.f);
-    gemm_bf<M_DM2, 1, kRtWaves>(ws, d1, d2, wrap);
+    for (int c = 0; c < C; ++c)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) d2[0][0][r] = fmaxf(d2[0][0][r], 0.f);
-    gemm_bf<M_DM4, 1, kRtWaves>(ws, d2, d3, wrap);
-    if (g == 0 && valid) srdf[(size_t)ray * SN + tile * 16 + j] = d3[0][0][0];
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d1[c][t][r] = fmaxf(d1[c][t][r], 0.f);
+    gemm_bf<M_DM2, C, kRtWaves>(ws, d1, d2, wrap);
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d2[c][0][r] = fmaxf(d2[c][0][r], 0.f);
+    gemm_bf<M_DM4, C, kRtWaves>(ws, d2, d3, wrap);
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+      if (g == 0 && valid && live[c]) srdf[(size_t)ray * SN + tbase[c] + j] = d3[c][0][0];
     wstream_bf_finish<B_RT2, kRtWaves>(ws, wrap);
   }
 }

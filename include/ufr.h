@@ -276,6 +276,20 @@ int ufr_deform_conv2d(const float* input, const float* offset, const float* mask
                       const float* bias, float* output, int32_t B, int32_t C, int32_t Cout, int32_t H, int32_t W,
                       void* workspace, size_t workspace_bytes, ufr_stream stream);
 
+/* ---- feature-matching transformer layer ----------------------------------------------
+ * One EncoderLayer of the FMT (code1/encoder_utils/fmt/FMT.py:82-113: linear attention with the elu+1 feature map, FMT.py:17-39,
+ * d_model 32, 8 heads; out-projection + residual, LayerNorm, 32-64-32 ReLU MLP + residual, LayerNorm; dropout 0).
+ * x (N,T,32): query tokens; src (N,S,32): key/value tokens (NULL = x, self-attention); out (N,T,32) (may alias neither).
+ * All nn.Linear weights row-major [out][in] as in the checkpoint.  workspace >= ufr_fmt_layer_workspace_bytes(N). */
+typedef struct ufr_fmt_layer_weights {
+  const float *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo; /* attention.{query,key,value,out}_projection: [32][32], [32] */
+  const float *w1, *b1, *w2, *b2;                     /* linear1 [64][32], [64]; linear2 [32][64], [32]             */
+  const float *n1w, *n1b, *n2w, *n2b;                 /* norm1 / norm2 weight, bias [32]                            */
+} ufr_fmt_layer_weights;
+size_t ufr_fmt_layer_workspace_bytes(int32_t N);
+int ufr_fmt_layer(const ufr_fmt_layer_weights* w, const float* x, const float* src, int32_t N, int32_t T, int32_t S,
+                  float* out, void* workspace, ufr_stream stream);
+
 void ufr_profile_enable(int on);
 int ufr_profile_read(const char** names, float* ms, int32_t* launches, int cap);
 

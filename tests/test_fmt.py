@@ -50,3 +50,25 @@ def test_fmt_mirror_matches_reference_golden_gpu():
     for k in g.files:
         ref = torch.from_numpy(g[k])
         assert float((got[k] - ref).abs().max()) <= 2e-4 * float(ref.abs().max()), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cross", [False, True])
+def test_fmt_layer_kernel_matches_the_torch_layer(cross):
+    """ufr_fmt_layer (csrc/fmt.hip) against the same layer written with torch ops on the CPU (fmt._layer), self- and
+    cross-attention, token counts that are not multiples of any tile."""
+    from uforecon_amd import fmt
+
+    torch.manual_seed(3)
+    p = fmt._LayerParams(32)
+    with torch.no_grad():
+        for q in p.parameters():
+            q.copy_(torch.randn(q.shape) * (0.3 if q.dim() > 1 else 0.1))
+        p.norm1.weight.add_(1.0)
+        p.norm2.weight.add_(1.0)
+    x = torch.randn(3, 1237, 32)
+    src = torch.randn(3, 2049, 32) if cross else None
+    with torch.no_grad():
+        want = fmt._layer(p, x, src)
+        got = fmt._layer(p.to("cuda:0"), x.to("cuda:0"), None if src is None else src.to("cuda:0"))
+    assert float((got.cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())

@@ -33,6 +33,11 @@ class RawGrads(C.Structure):
     _fields_ = [("p", fptr * 40)]
 
 
+class FmtLayerWeights(C.Structure):
+    _fields_ = [(n, fptr) for n in ("wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo", "w1", "b1", "w2", "b2",
+                                    "n1w", "n1b", "n2w", "n2b")]
+
+
 class FrameDesc(C.Structure):
     _fields_ = [("NV", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("source_imgs", fptr), ("depth_info", fptr), ("feat", fptr), ("match", fptr),
@@ -93,6 +98,8 @@ SIGNATURES = {
                                      C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp, i32, i32, C.c_float, i32, vp]),
     "ufr_deform_conv2d_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "ufr_deform_conv2d": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "ufr_fmt_layer_workspace_bytes": (sz, [i32]),
+    "ufr_fmt_layer": (C.c_int, [C.POINTER(FmtLayerWeights), vp, vp, i32, i32, i32, vp, vp, vp]),
     "ufr_profile_enable": (None, [C.c_int]),
     "ufr_profile_read": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(i32), C.c_int]),
 }

@@ -680,6 +680,26 @@ int ufr_deform_conv2d(const float* input, const float* offset, const float* mask
   return UFR_OK;
 }
 
+// ------------------------------------------------------------------ feature-matching transformer layer
+size_t ufr_fmt_layer_workspace_bytes(int32_t N) { return align_up((size_t)(N > 0 ? N : 1) * 160 * sizeof(float)); }
+
+int ufr_fmt_layer(const ufr_fmt_layer_weights* w, const float* x, const float* src, int32_t N, int32_t T, int32_t S,
+                  float* out, void* workspace, ufr_stream stream) {
+  static_assert(sizeof(ufr_fmt_layer_weights) == sizeof(FmtWeights), "ufr_fmt_layer_weights layout");
+  UFR_REQUIRE(w && x && out && workspace, "ufr_fmt_layer: null argument");
+  FmtWeights fw;
+  memcpy(&fw, w, sizeof(fw));
+  const float* const* pw = reinterpret_cast<const float* const*>(&fw);
+  for (int i = 0; i < 16; ++i) UFR_REQUIRE(pw[i], "ufr_fmt_layer: weight pointer %d is null", i);
+  if (!src) { src = x; S = T; }
+  UFR_REQUIRE(N > 0 && T > 0 && S > 0, "ufr_fmt_layer: N=%d T=%d S=%d", N, T, S);
+  UFR_REQUIRE(out != x && out != src, "ufr_fmt_layer: out must not alias an input");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ProfScope p("fmt_layer", s);
+  UFR_HIP(launch_fmt_layer(fw, x, src, N, T, S, out, static_cast<float*>(workspace), s));
+  return UFR_OK;
+}
+
 // ------------------------------------------------------------------ profiling hooks
 void ufr_profile_enable(int on) {
   std::lock_guard<std::mutex> lock(g_prof_mu);

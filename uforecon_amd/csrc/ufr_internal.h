@@ -72,6 +72,11 @@ hipError_t launch_presim_bwd(const RawPtrs& wp, const GradPtrs& gp, const float*
 hipError_t launch_gather_bwd(const FrameDev& f, float* const* grad_feat, float* const* grad_weight, const float* ray_o,
                              int o_stride, const float* ray_d, const float* z, const float* d_pv, int RN, int SN,
                              hipStream_t s);
+struct FmtWeights {  // = ufr_fmt_layer_weights
+  const float *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo, *w1, *b1, *w2, *b2, *n1w, *n1b, *n2w, *n2b;
+};
+hipError_t launch_fmt_layer(const FmtWeights& w, const float* x, const float* src, int N, int T, int S, float* out,
+                            float* state, hipStream_t s);
 hipError_t launch_pack_weights(const RawPtrs& raw, float* packed, hipStream_t s);
 hipError_t launch_tsdf_integrate(float* tsdf, float* weight, float* color, const int* dim, const float* origin,
                                  float voxel_size, float trunc_margin, const float* K, const float* P,

@@ -1,5 +1,5 @@
 """Feature-matching transformer stage of the per-frame encoder and the pair-wise matching features it feeds to the ray
-path (out of the per-ray hot path, library ops only: 8 GFLOP per 512x640 3-view frame).
+path (out of the per-ray hot path; 8 GFLOP per 512x640 3-view frame).  On the GPU every layer is the HIP kernel pair of csrc/fmt.hip (`ufr_fmt_layer`).
 
 What the reference computes (code1/encoder_utils/fmt/FMT.py:17-316, position_encoding.py:24-60,
 TransMVSNet.py:341-375), restated here around ONE token engine instead of a module per concept:
@@ -66,8 +66,18 @@ def _linear_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, eps: fl
 
 
 def _layer(p: _LayerParams, x: torch.Tensor, src: Optional[torch.Tensor]) -> torch.Tensor:
-    """One post-norm layer (FMT.py:99-113, dropout 0).  ``src is None``: self-attention, q/k/v from one fused GEMM."""
+    """One post-norm layer (FMT.py:99-113, dropout 0).  ``src is None``: self-attention.  GPU tensors run the HIP kernel
+    pair behind ``ufr_fmt_layer`` (csrc/fmt.hip; no fallback: a missing library raises); the torch expression below is the
+    same layer for CPU tensors (q/k/v from one fused GEMM) and what the kernel is tested against."""
     a = p.attention
+    if x.is_cuda:
+        from . import ops
+
+        return ops.fmt_layer([a.query_projection.weight, a.query_projection.bias, a.key_projection.weight,
+                              a.key_projection.bias, a.value_projection.weight, a.value_projection.bias,
+                              a.out_projection.weight, a.out_projection.bias, p.linear1.weight, p.linear1.bias,
+                              p.linear2.weight, p.linear2.bias, p.norm1.weight, p.norm1.bias, p.norm2.weight, p.norm2.bias],
+                             x, src)
     if src is None:
         w = torch.cat([a.query_projection.weight, a.key_projection.weight, a.value_projection.weight], 0)
         b = torch.cat([a.query_projection.bias, a.key_projection.bias, a.value_projection.bias], 0)

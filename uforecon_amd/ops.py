@@ -372,6 +372,33 @@ def render_rays(frame: FrameHandle, weights: PackedWeights, ray_idx: torch.Tenso
     return dict(depth=depth, depth_z=depth_z, rgb=rgb, srdf=srdf, z_all=z_all, workspace=workspace)
 
 
+def fmt_layer(params, x: torch.Tensor, src: Optional[torch.Tensor]) -> torch.Tensor:
+    """One FMT encoder layer on the GPU (ufr_fmt_layer).  ``params``: the 16 tensors in ufr_fmt_layer_weights order;
+    x (N,T,32); src (N,S,32) or None for self-attention."""
+    lib = _lib.load()
+    N, T, D = x.shape
+    if D != 32:
+        raise UfrError(f"fmt_layer: d_model {D}, the kernel is built for 32")
+    w = _lib.FmtLayerWeights()
+    keep = []
+    for name, t in zip([f[0] for f in _lib.FmtLayerWeights._fields_], params):
+        t = t.detach().contiguous()
+        keep.append(t)
+        setattr(w, name, _dev(t, "fmt." + name))
+    x = x.contiguous()
+    S = T
+    if src is not None:
+        src = src.contiguous()
+        if src.shape[0] != N or src.shape[2] != D:
+            raise UfrError(f"fmt_layer: source tokens {tuple(src.shape)} do not match {tuple(x.shape)}")
+        S = src.shape[1]
+    out = torch.empty_like(x)
+    ws = torch.empty(lib.ufr_fmt_layer_workspace_bytes(N) // 4, dtype=torch.float32, device=x.device)
+    _lib.check(lib.ufr_fmt_layer(C.byref(w), _dev(x, "x"), _opt(src, "src"), N, T, S, out.data_ptr(), ws.data_ptr(),
+                                 _stream()), "ufr_fmt_layer")
+    return out
+
+
 def profile_enable(on: bool) -> None:
     _lib.load().ufr_profile_enable(int(on))
 

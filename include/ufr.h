@@ -75,7 +75,8 @@ int ufr_pack_plan(int32_t* param_id, int32_t* elem);
 /* The packed blob is [fp32 region: ufr_packed_fp32_floats() floats | bf16 region: ufr_packed_bf16_halfwords()
  * 16-bit words].  The bf16 region holds the view-transformer chain as three bf16 planes per weight
  * (exact split w = hi + mid + lo, plane 0/1/2) for the split-precision MFMA path; ufr_pack_plan_bf16
- * describes it like ufr_pack_plan (one entry per halfword, plus the plane). */
+ * describes it like ufr_pack_plan (one entry per halfword, plus the plane).  Of the fp32 region ufr_weights_pack fills
+ * only the trailing vector fragments (biases, LayerNorm, view token): the kernels read nothing else of it. */
 size_t ufr_packed_fp32_floats(void);
 size_t ufr_packed_bf16_halfwords(void);
 int ufr_pack_plan_bf16(int32_t* param_id, int32_t* elem, int32_t* plane);

@@ -7,9 +7,9 @@ TAG=${1:-rN}
 OUT=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT
-BENCH="bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline"
+BENCH="bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-gpu-eager-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- python3 $BENCH > $OUT/bench_line.json 2> $OUT/stats_err.txt
-PMC_BENCH="bench.py --steps 1 --warmup 0 --streams 1 --no-cpu-baseline"
+PMC_BENCH="bench.py --steps 1 --warmup 0 --streams 1 --no-cpu-baseline --no-gpu-eager-baseline"
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS -d $OUT -o pmc_sq -- python3 $PMC_BENCH > /dev/null 2> $OUT/pmc_sq_err.txt
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT -o pmc_fetch -- python3 $PMC_BENCH > /dev/null 2> $OUT/pmc_fetch_err.txt
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT -o pmc_write -- python3 $PMC_BENCH > /dev/null 2> $OUT/pmc_write_err.txt

@@ -17,7 +17,10 @@
 
 namespace ufr {
 
-constexpr int kBwdThreads = 256;
+#ifndef UFR_BWD_THREADS
+#define UFR_BWD_THREADS 256
+#endif
+constexpr int kBwdThreads = UFR_BWD_THREADS;
 constexpr int kBwdWaves = kBwdThreads / 64;
 constexpr int kTT = 16;   // tokens per tile = MFMA columns
 constexpr int kLD = 17;   // LDS row stride (floats)
@@ -250,12 +253,16 @@ __device__ __forceinline__ void wgrad_wave(f32x4 (&acc)[NACC], const float* lds,
 }
 template <const auto& LIST, int N, int NSLOT, int SLOT0, int NACC>
 __device__ __forceinline__ void wgrad_all(f32x4 (&acc)[NACC], const float* lds, int wave, int lane) {
-  static_assert(kBwdWaves == 4, "one case per wave");
+  static_assert(kBwdWaves == 4 || kBwdWaves == 8, "one case per wave");
   switch (__builtin_amdgcn_readfirstlane(wave)) {
     case 0: wgrad_wave<LIST, N, NSLOT, SLOT0, 0>(acc, lds, lane); break;
     case 1: wgrad_wave<LIST, N, NSLOT, SLOT0, 1>(acc, lds, lane); break;
     case 2: wgrad_wave<LIST, N, NSLOT, SLOT0, 2>(acc, lds, lane); break;
-    default: wgrad_wave<LIST, N, NSLOT, SLOT0, 3>(acc, lds, lane); break;
+    case 3: wgrad_wave<LIST, N, NSLOT, SLOT0, 3>(acc, lds, lane); break;
+    case 4: wgrad_wave<LIST, N, NSLOT, SLOT0, 4 % kBwdWaves>(acc, lds, lane); break;
+    case 5: wgrad_wave<LIST, N, NSLOT, SLOT0, 5 % kBwdWaves>(acc, lds, lane); break;
+    case 6: wgrad_wave<LIST, N, NSLOT, SLOT0, 6 % kBwdWaves>(acc, lds, lane); break;
+    default: wgrad_wave<LIST, N, NSLOT, SLOT0, 7 % kBwdWaves>(acc, lds, lane); break;
   }
 }
 template <const auto& LIST, int N, int NSLOT, int SLOT0, int WAVE, int NACC>
@@ -272,7 +279,11 @@ __device__ __forceinline__ void wgrad_flush_all(const f32x4 (&acc)[NACC], const 
     case 0: wgrad_flush_wave<LIST, N, NSLOT, SLOT0, 0>(acc, gp, lane); break;
     case 1: wgrad_flush_wave<LIST, N, NSLOT, SLOT0, 1>(acc, gp, lane); break;
     case 2: wgrad_flush_wave<LIST, N, NSLOT, SLOT0, 2>(acc, gp, lane); break;
-    default: wgrad_flush_wave<LIST, N, NSLOT, SLOT0, 3>(acc, gp, lane); break;
+    case 3: wgrad_flush_wave<LIST, N, NSLOT, SLOT0, 3>(acc, gp, lane); break;
+    case 4: wgrad_flush_wave<LIST, N, NSLOT, SLOT0, 4 % kBwdWaves>(acc, gp, lane); break;
+    case 5: wgrad_flush_wave<LIST, N, NSLOT, SLOT0, 5 % kBwdWaves>(acc, gp, lane); break;
+    case 6: wgrad_flush_wave<LIST, N, NSLOT, SLOT0, 6 % kBwdWaves>(acc, gp, lane); break;
+    default: wgrad_flush_wave<LIST, N, NSLOT, SLOT0, 7 % kBwdWaves>(acc, gp, lane); break;
   }
 }
 

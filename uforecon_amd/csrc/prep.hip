@@ -63,9 +63,12 @@ hipError_t launch_volume_pack(const float* feat, const float* weight, float* out
   return hipGetLastError();
 }
 
-// packed[i] = raw[param][elem] per ufr_layout.h:plan_entry (zero for padding)
-__global__ void __launch_bounds__(256) pack_weights_kernel(RawPtrs raw, float* __restrict__ packed, int n) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+// packed[i] = raw[param][elem] per ufr_layout.h:plan_entry (zero for padding), for i in [first, n).  Only the vector
+// fragments (biases, LayerNorm, view token) of the fp32 region are read by the kernels: the fp32 A-fragment part in front
+// of them (the layout of the first, fp32-MFMA version; still described by ufr_pack_plan for the CPU layout tests) is not
+// written on the device any more.
+__global__ void __launch_bounds__(256) pack_weights_kernel(RawPtrs raw, float* __restrict__ packed, int first, int n) {
+  int i = first + blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int p, e;
   plan_entry(i, &p, &e);
@@ -96,8 +99,8 @@ __global__ void __launch_bounds__(256) pack_weights_bf16_kernel(RawPtrs raw, uns
 }
 
 hipError_t launch_pack_weights(const RawPtrs& raw, float* packed, hipStream_t s) {
-  const int n = blob_floats();
-  hipLaunchKernelGGL(pack_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, s, raw, packed, n);
+  const int n = blob_floats(), first = vec_region_offset();
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((n - first + 255) / 256), dim3(256), 0, s, raw, packed, first, n);
   unsigned short* bf = reinterpret_cast<unsigned short*>(packed + n);
   hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((kBfHalfwords + 255) / 256), dim3(256), 0, s, raw, bf, kBfHalfwords);
   return hipGetLastError();

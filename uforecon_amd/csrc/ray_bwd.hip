@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(kBwdThreads) presim_bwd_kernel(RawPtrs wp, Gra
   __shared__ float lds[O_END * kLD];
   const int tid0 = threadIdx.x, wave = tid0 >> 6, lane = tid0 & 63;
   int tid = tid0;   // re-laundered after every barrier (bwd_common.h: opaque)
-  f32x4 acc[2] = {splat4(0.f), splat4(0.f)};
+  f32x4 acc[2] = {splat4(0.f), splat4(0.f)};   // 8 tiles over the waves: at most 2 per wave
   float accB = 0.f;
   auto R = [&](int row) -> float* { return lds + row * kLD; };
   const int n_tiles = (P + kTT - 1) / kTT;

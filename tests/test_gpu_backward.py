@@ -179,6 +179,26 @@ def test_training_step_gradients_match_reference_autograd(name):
     assert r[16].requires_grad                       # variance output stays differentiable (train/variance log)
 
 
+def test_parameter_only_backward_matches_and_skips_the_volume_scatter():
+    """Frustums without requires_grad (e.g. a frozen cost_reg_2): parameter gradients are unchanged and no volume gradient
+    is produced."""
+    name = "c5_train_grads_nv4"
+    m, f, r, loss, g = _train_step(name)
+    loss.backward()
+    ref = {k: p.grad.clone() for k, p in m.named_parameters()}
+    c = CASES[name]
+    fr, idx, U1, U2, _ = case_inputs(name)
+    m2 = M.UFORecon(_args(c)).to(DEV)
+    m2.load_state_dict(load_weights(), strict=True)
+    f2 = fr.to(DEV)
+    r2 = m2.infer(f2.batch, idx.to(DEV), f2.source_imgs_feat, f2.feature_volume, match_feature=f2.match_feature, uniforms=(U1, U2))
+    _loss_from_tuple(r2, f2.batch, idx.to(DEV)).backward()
+    for k, p in m2.named_parameters():
+        if k != SHIFT_BIAS:
+            assert grad_rel_err(p.grad, ref[k]) < 1e-4, k
+    assert all(v.grad is None for st in f2.feature_volume.values() for v in st.values())
+
+
 def test_optimizer_step_follows_the_gradients():
     """One optimizer step through the HIP backward (plain gradient descent, small enough for the first-order decrease
     to hold; the reference trains with Adam, model.py:72-87): every per-ray parameter moves, the packed copy follows,

@@ -50,12 +50,16 @@ class RenderPass(torch.autograd.Function):
             d_srdf = d_srdf + d_srdf_out
         grads = ops.GradBuffer(dev)
         d_pv, _ = ops.aggregate_bwd(W, grads, x, rgbm, dirs, token0, RN, SN, d_radiance.view(RN * SN, 3), d_srdf)
-        gvol = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.vol_shapes]
-        ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z, sim8, d_pv, gvol[0::2], gvol[1::2])
+        need = ctx.needs_input_grad[5:]
+        if any(need[ctx.n_par:]):       # frustum gradients wanted (feature_volume.cost_reg_2 trains through them)
+            gvol = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.vol_shapes]
+            ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z, sim8, d_pv, gvol[0::2], gvol[1::2])
+        else:                           # parameters only: skip the scatter-add (and 0.7 GB of zeroed gradient volumes)
+            gvol = [None] * len(ctx.vol_shapes)
+            ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z, sim8, d_pv, None, None)
         gpar = [grads.grad(k) for k in ops.RAW_WEIGHT_KEYS]
         gpar[-1] = d_var.reshape(gpar[-1].shape)                      # deviation_network.variance
-        need = ctx.needs_input_grad[5:]
-        out = [g if n else None for g, n in zip(gpar + gvol, need)]
+        out = [g if (n and g is not None) else None for g, n in zip(gpar + gvol, need)]
         return (None, None, None, None, None, *out)
 
 

@@ -117,6 +117,46 @@ def test_aggregate_bwd_matches_oracle_autograd(name):
     assert torch.equal(d_pv2, d_pv)
 
 
+@pytest.mark.parametrize("NV,SN", [(2, 48), (5, 96), (7, 32)])
+def test_aggregate_bwd_other_view_counts_and_lengths(NV, SN):
+    """The backward tiles hold 16 // (NV+1) points per 16 token columns and the ray kernel walks SN / 16 tiles per sweep:
+    view counts with idle columns and sample totals that are not a power of two, against autograd through the oracle."""
+    from uforecon_amd.scene import make_frame
+
+    P = load_weights()
+    W = ops.PackedWeights({k: v.to(DEV) for k, v in P.items()})
+    fr = make_frame(48, 64, NV, seed=40 + NV, train_layout=True)
+    f = fr.to(DEV)
+    fh = ops.FrameHandle(f.batch, f.source_imgs_feat, f.feature_volume, f.match_feature)
+    RN = 6
+    idx = torch.arange(RN) * 397 + 411
+    gen = torch.Generator().manual_seed(NV)
+    ray_d = fr.batch["ray_d"][0][:, idx].t().contiguous().to(DEV)
+    ray_o = fr.batch["ray_o"][0].contiguous().to(DEV)
+    near = fr.batch["near_fars"][0, 0, 0].expand(RN).contiguous().to(DEV)
+    far = fr.batch["near_fars"][0, 0, 1].expand(RN).contiguous().to(DEV)
+    z = ops.sample_fixed(near, far, torch.rand(SN, RN, generator=gen).to(DEV))
+    x, rgbm, dirs, _ = ops.project_gather(fh, W, ray_o, ray_d, z)
+    radiance, srdf, agg = ops.aggregate(W, x, rgbm, dirs, RN, SN, keep_workspace=True)
+    co_rad, co_srdf = torch.rand(RN * SN, 3, generator=gen) - 0.5, torch.rand(RN, SN, generator=gen) - 0.5
+    Pg = {k: v.clone().requires_grad_("depthcode" not in k) for k, v in P.items()}
+    xr = x.cpu().clone().requires_grad_(True)
+    rad_o, srdf_o = O.aggregate_tokens(Pg, xr, rgbm.cpu()[..., :3], rgbm.cpu()[..., 3], dirs.cpu()[..., :3], RN, SN)
+    ((rad_o * co_rad).sum() + (srdf_o * co_srdf).sum()).backward()
+    grads = ops.GradBuffer(DEV)
+    d_pv, _ = ops.aggregate_bwd(W, grads, x, rgbm, dirs, agg["token0"], RN, SN, co_rad.to(DEV), co_srdf.to(DEV))
+    torch.cuda.synchronize()
+    worst = {}
+    for k in ops.RAW_WEIGHT_KEYS:
+        if "pre_sim_mlp" in k or k in ("deviation_network.variance", SHIFT_BIAS):
+            continue
+        worst[k] = grad_rel_err(grads.grad(k), Pg[k].grad)
+    worst["d_pv"] = grad_rel_err(d_pv, xr.grad[:, :, 32:72].sum(1))
+    # a ReLU unit within rounding of zero may flip between two fp32 evaluations (DESIGN 3.6): allow it on a few tensors
+    assert sorted(worst.values())[len(worst) // 2] < 2e-5, worst
+    assert max(worst.values()) < 2e-2, worst
+
+
 def test_project_gather_bwd_matches_oracle_autograd():
     name = "c5_train_grads"
     fr, P, W, fh, ray_o, ray_d, z, x, rgbm, dirs, dbg = _token_inputs(name)

@@ -203,6 +203,31 @@ int ufr_project_gather_bwd(const ufr_frame* frame, const ufr_raw_weights* raw, c
                            int32_t SN, const float* sim8, const float* d_pv, float* const* grad_vol_feat,
                            float* const* grad_vol_weight, ufr_stream stream);
 
+/* ------------------------------------------------------------------ the two halves of ufr_aggregate, and the sample pool
+ * The fine pass of `infer` (model.py:455-473) re-evaluates all SN+PN merged samples, but a sample's gathers and
+ * view-transformer output depend on its own position only: evaluating the PN NEW samples and re-using the coarse pass's
+ * rows gives the same numbers (ufr_render_rays does that internally).  These entry points expose the pieces so that the
+ * training step can do the same, forwards and backwards:
+ *   ufr_sample_importance_pool = ufr_sample_importance_merge that also returns the new positions z_new (RN,PN), in draw
+ *     order, and for every merged slot its row in the pool [RN*SN coarse rows (ray-major) | RN*PN new rows]: row (RN,SN+PN) int32;
+ *   ufr_view_transform / ufr_ray_transform = the view-transformer and ray-transformer halves of ufr_aggregate
+ *     (token0 (P,80), radiance (P,3) | token0 rows of the RN*SN samples in slot order -> srdf (RN,SN));
+ *   ufr_view_transform_bwd / ufr_ray_transform_bwd = the corresponding halves of ufr_aggregate_bwd (d_token0 comes out
+ *     as two partial buffers of the ray kernel's sweeps; pass both to ufr_view_transform_bwd or add them). */
+int ufr_sample_importance_pool(const float* weight, const float* z, const float* U2, float* z_all, float* z_new,
+                               int32_t* row, int32_t RN, int32_t SN, int32_t PN, ufr_stream stream);
+int ufr_view_transform(const void* packed_weights, const float* x_tokens, const float* rgb, const float* dir, int32_t P,
+                       int32_t NV, float* token0, float* radiance, ufr_stream stream);
+size_t ufr_ray_transform_workspace_bytes(int32_t SN);
+int ufr_ray_transform(const void* packed_weights, const float* token0, int32_t RN, int32_t SN, float* srdf,
+                      void* workspace, ufr_stream stream);
+int ufr_ray_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const float* token0, int32_t RN,
+                          int32_t SN, const float* d_srdf, float* d_token0_a, float* d_token0_b, void* workspace,
+                          ufr_stream stream);
+int ufr_view_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const float* x_tokens, const float* rgb,
+                           const float* dir, const float* d_token0_a, const float* d_token0_b, const float* d_radiance,
+                           int32_t P, int32_t NV, float* d_pv, ufr_stream stream);
+
 /* ------------------------------------------------------------------ whole-path inference
  * UFORecon.infer(extract_geometry=True) (model.py:393-478) for RN rays of one frame:
  * ray gather by index, near/far / cam_ray_d.z, coarse pass, importance sampling + merge, fine

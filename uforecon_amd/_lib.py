@@ -89,6 +89,12 @@ SIGNATURES = {
                                     vp, vp, vp, vp]),
     "ufr_project_gather_bwd": (C.c_int, [C.POINTER(Frame), C.POINTER(RawWeights), C.POINTER(RawGrads), vp, i32, vp, vp,
                                          i32, i32, vp, vp, C.POINTER(vp), C.POINTER(vp), vp]),
+    "ufr_sample_importance_pool": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "ufr_view_transform": (C.c_int, [vp, vp, vp, vp, i32, i32, vp, vp, vp]),
+    "ufr_ray_transform_workspace_bytes": (sz, [i32]),
+    "ufr_ray_transform": (C.c_int, [vp, vp, i32, i32, vp, vp, vp]),
+    "ufr_ray_transform_bwd": (C.c_int, [C.POINTER(RawWeights), C.POINTER(RawGrads), vp, i32, i32, vp, vp, vp, vp, vp]),
+    "ufr_view_transform_bwd": (C.c_int, [C.POINTER(RawWeights), C.POINTER(RawGrads), vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     "ufr_render_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "ufr_default_chunk_rays": (i32, []),
     "ufr_render_rays": (C.c_int, [C.POINTER(RenderArgs), vp]),

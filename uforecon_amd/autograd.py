@@ -63,6 +63,88 @@ class RenderPass(torch.autograd.Function):
         return (None, None, None, None, None, *out)
 
 
+class RenderTwoPass(torch.autograd.Function):
+    """Both passes of ``infer`` (model.py:429-473) with the coarse samples' per-point work shared: the fine pass gathers
+    and view-transforms only its PN new samples; the ray transformer and the compositor -- which do couple the samples of a
+    ray -- see all SN+PN merged samples through the slot -> pool-row table of ``ufr_sample_importance_pool``.  Same numbers
+    as two ``RenderPass`` applications (a sample's gathers and view-transformer output depend on its own position only), one
+    third less gather / view-transformer work forwards AND backwards: the cotangents that the fine pass sends to the coarse
+    samples' token-0 rows and colours are added to the coarse pass's own before ONE view-transformer backward over them.
+
+    ``apply(frame, weights, ray_o, ray_d, z1, U2, *params, *volumes)`` ->
+    ``rgb, depth, opacity, weight, srdf, xy   (coarse)   rgb2, depth2, opacity2, weight2, srdf2, xy2, z2   (fine)``."""
+
+    @staticmethod
+    def forward(ctx, frame, weights, ray_o, ray_d, z1, U2, *tensors):
+        n_par = len(ops.RAW_WEIGHT_KEYS)
+        RN, SN = z1.shape
+        var = weights.variance.reshape(1)
+        x1, rgbm1, dirs1, g1 = ops.project_gather(frame, weights, ray_o, ray_d, z1, want_sim8=True, want_xy=True)
+        tok1, rad1 = ops.view_transform(weights, x1, rgbm1, dirs1)
+        srdf1 = ops.ray_transform(weights, tok1, RN, SN)
+        rgb, depth, opacity, weight = ops.composite(z1, rad1.view(RN, SN, 3), srdf1, var)
+        z2, z_new, row = ops.sample_importance_pool(weight, z1, U2)                  # model.py:455-470 (weights detached)
+        PN = z_new.shape[1]
+        S2 = SN + PN
+        x2, rgbm2, dirs2, g2 = ops.project_gather(frame, weights, ray_o, ray_d, z_new, want_sim8=True, want_xy=True)
+        tok2, rad2 = ops.view_transform(weights, x2, rgbm2, dirs2)
+        rows = row.reshape(-1).long()
+        tok_slots = torch.cat([tok1, tok2], 0)[rows]                                   # (RN*S2, 80) in slot order
+        rad_slots = torch.cat([rad1, rad2], 0)[rows]
+        srdf2 = ops.ray_transform(weights, tok_slots, RN, S2)
+        rgb2, depth2, opacity2, weight2 = ops.composite(z2, rad_slots.view(RN, S2, 3), srdf2, var)
+        xy2 = torch.cat([g1["xy"], g2["xy"]], 1)[:, rows]                              # (NV, RN*S2, 2)
+        ctx.frame, ctx.weights, ctx.n_par = frame, weights, n_par
+        ctx.vol_shapes = [tuple(t.shape) for t in tensors[n_par:]]
+        ctx.save_for_backward(ray_o, ray_d, z1, z2, z_new, rows, x1, rgbm1, dirs1, g1["sim8"], tok1, rad1, srdf1,
+                              x2, rgbm2, dirs2, g2["sim8"], tok_slots, rad_slots, srdf2)
+        ctx.mark_non_differentiable(g1["xy"], xy2, z2)
+        return rgb, depth, opacity, weight, srdf1, g1["xy"], rgb2, depth2, opacity2, weight2, srdf2, xy2, z2
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_depth, d_opacity, d_weight, d_srdf, _dxy, d_rgb2, d_depth2, d_opacity2, d_weight2, d_srdf2,
+                 _dxy2, _dz2):
+        (ray_o, ray_d, z1, z2, z_new, rows, x1, rgbm1, dirs1, sim8_1, tok1, rad1, srdf1,
+         x2, rgbm2, dirs2, sim8_2, tok_slots, rad_slots, srdf2) = ctx.saved_tensors
+        frame, W = ctx.frame, ctx.weights
+        RN, SN = z1.shape
+        S2 = z2.shape[1]
+        P1 = RN * SN
+        dev = z1.device
+        var = W.variance.reshape(1)
+        grads = ops.GradBuffer(dev)
+        # ---- fine pass: compositor and ray transformer over all merged slots, then back to pool rows
+        d_rad_s, d_srdf_s, d_var2 = ops.composite_bwd(z2, rad_slots.view(RN, S2, 3), srdf2, var, d_rgb2, d_depth2, d_opacity2, d_weight2)
+        if d_srdf2 is not None:
+            d_srdf_s = d_srdf_s + d_srdf2
+        ta, tb = ops.ray_transform_bwd(W, grads, tok_slots, RN, S2, d_srdf_s)
+        pool_tok = torch.empty(P1 + z_new.numel(), ta.shape[1], dtype=torch.float32, device=dev)
+        pool_rad = torch.empty(P1 + z_new.numel(), 3, dtype=torch.float32, device=dev)
+        pool_tok[rows] = ta + tb                                                      # every pool row is exactly one slot
+        pool_rad[rows] = d_rad_s.view(-1, 3)
+        # ---- coarse pass (its weights feed the importance sampler detached: model.py:456-457)
+        d_rad_c, d_srdf_c, d_var1 = ops.composite_bwd(z1, rad1.view(RN, SN, 3), srdf1, var, d_rgb, d_depth, d_opacity, d_weight)
+        if d_srdf is not None:
+            d_srdf_c = d_srdf_c + d_srdf
+        ca, cb = ops.ray_transform_bwd(W, grads, tok1, RN, SN, d_srdf_c)
+        # ---- view transformer backwards: coarse samples once, with the cotangents of both passes; new samples once
+        d_pv1 = ops.view_transform_bwd(W, grads, x1, rgbm1, dirs1, ca + cb, pool_tok[:P1], d_rad_c.view(-1, 3) + pool_rad[:P1])
+        d_pv2 = ops.view_transform_bwd(W, grads, x2, rgbm2, dirs2, pool_tok[P1:], None, pool_rad[P1:])
+        need = ctx.needs_input_grad[6:]
+        if any(need[ctx.n_par:]):
+            gvol = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.vol_shapes]
+            gf, gw = gvol[0::2], gvol[1::2]
+        else:
+            gvol = [None] * len(ctx.vol_shapes)
+            gf = gw = None
+        ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z1, sim8_1, d_pv1, gf, gw)
+        ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z_new, sim8_2, d_pv2, gf, gw)
+        gpar = [grads.grad(k) for k in ops.RAW_WEIGHT_KEYS]
+        gpar[-1] = (d_var1 + d_var2).reshape(gpar[-1].shape)
+        out = [g if (n and g is not None) else None for g, n in zip(gpar + gvol, need)]
+        return (None, None, None, None, None, None, *out)
+
+
 class Aggregate(torch.autograd.Function):
     """RayTransformer.forward (ray_transformer.py:175-322) as the reference exposes it: the frustum lookup `fea_volume`
     and the pair similarity cond_info['feat_info'] are INPUTS.  ``apply(frame, weights, points (P,3), RN, SN,

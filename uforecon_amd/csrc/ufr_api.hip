@@ -397,6 +397,70 @@ int ufr_project_gather_bwd(const ufr_frame* frame, const ufr_raw_weights* raw, c
   return UFR_OK;
 }
 
+// ------------------------------------------------------------------ halves of aggregate / sample pool
+int ufr_sample_importance_pool(const float* weight, const float* z, const float* U2, float* z_all, float* z_new,
+                               int32_t* row, int32_t RN, int32_t SN, int32_t PN, ufr_stream stream) {
+  UFR_REQUIRE(weight && z && U2 && z_all && z_new && row, "ufr_sample_importance_pool: null argument");
+  UFR_REQUIRE(RN > 0 && SN >= 2 && SN <= 256 && PN >= 1 && PN <= 256, "ufr_sample_importance_pool: RN=%d SN=%d PN=%d", RN, SN, PN);
+  UFR_HIP(launch_importance_merge(weight, z, U2, RN, nullptr, z_all, RN, SN, PN, z_new, row, static_cast<hipStream_t>(stream)));
+  return UFR_OK;
+}
+
+int ufr_view_transform(const void* packed_weights, const float* x_tokens, const float* rgb, const float* dir, int32_t P,
+                       int32_t NV, float* token0, float* radiance, ufr_stream stream) {
+  UFR_REQUIRE(packed_weights && x_tokens && rgb && dir && token0 && radiance, "ufr_view_transform: null argument");
+  UFR_REQUIRE(NV >= 2 && NV <= UFR_MAX_VIEWS && P > 0, "ufr_view_transform: P=%d NV=%d", P, NV);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ProfScope p("view_transformer", s);
+  UFR_HIP(launch_view_transformer(static_cast<const float*>(packed_weights), x_tokens, rgb, dir, P, NV, token0, radiance, nullptr, s));
+  return UFR_OK;
+}
+
+size_t ufr_ray_transform_workspace_bytes(int32_t SN) { return align_up((size_t)(SN > 0 ? SN : 1) * 8 * sizeof(float)); }
+
+int ufr_ray_transform(const void* packed_weights, const float* token0, int32_t RN, int32_t SN, float* srdf, void* workspace,
+                      ufr_stream stream) {
+  UFR_REQUIRE(packed_weights && token0 && srdf && workspace, "ufr_ray_transform: null argument");
+  UFR_REQUIRE(RN > 0 && SN >= 16 && SN % 16 == 0 && SN <= 256, "ufr_ray_transform: SN=%d must be a multiple of 16 in [16,256]", SN);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* order_pe = static_cast<float*>(workspace);
+  UFR_HIP(launch_order_pe(order_pe, SN, s));
+  ProfScope p("ray_transformer", s);
+  UFR_HIP(launch_ray_transformer(static_cast<const float*>(packed_weights), token0, nullptr, order_pe, RN, SN, srdf, nullptr, s));
+  return UFR_OK;
+}
+
+int ufr_ray_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const float* token0, int32_t RN, int32_t SN,
+                          const float* d_srdf, float* d_token0_a, float* d_token0_b, void* workspace, ufr_stream stream) {
+  RawPtrs rp;
+  GradPtrs gp;
+  int rc = raw_and_grads(raw, grads, rp, gp, "ufr_ray_transform_bwd");
+  if (rc != UFR_OK) return rc;
+  UFR_REQUIRE(token0 && d_srdf && d_token0_a && d_token0_b && workspace, "ufr_ray_transform_bwd: null argument");
+  UFR_REQUIRE(RN > 0 && SN >= 16 && SN % 16 == 0 && SN <= 256, "ufr_ray_transform_bwd: SN=%d must be a multiple of 16 in [16,256]", SN);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* order_pe = static_cast<float*>(workspace);
+  UFR_HIP(launch_order_pe(order_pe, SN, s));
+  ProfScope p("ray_bwd", s);
+  UFR_HIP(launch_ray_bwd(rp, gp, token0, order_pe, d_srdf, RN, SN, d_token0_a, d_token0_b, nullptr, s));
+  return UFR_OK;
+}
+
+int ufr_view_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const float* x_tokens, const float* rgb,
+                           const float* dir, const float* d_token0_a, const float* d_token0_b, const float* d_radiance,
+                           int32_t P, int32_t NV, float* d_pv, ufr_stream stream) {
+  RawPtrs rp;
+  GradPtrs gp;
+  int rc = raw_and_grads(raw, grads, rp, gp, "ufr_view_transform_bwd");
+  if (rc != UFR_OK) return rc;
+  UFR_REQUIRE(x_tokens && rgb && dir && d_token0_a && d_radiance && d_pv, "ufr_view_transform_bwd: null argument");
+  UFR_REQUIRE(NV >= 2 && NV <= UFR_MAX_VIEWS && P > 0, "ufr_view_transform_bwd: P=%d NV=%d", P, NV);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ProfScope p("view_bwd", s);
+  UFR_HIP(launch_view_bwd(rp, gp, x_tokens, rgb, dir, d_token0_a, d_token0_b, d_radiance, P, NV, d_pv, nullptr, s));
+  return UFR_OK;
+}
+
 // ------------------------------------------------------------------ whole-path inference
 int32_t ufr_default_chunk_rays(void) { return 4096; }
 

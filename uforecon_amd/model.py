@@ -338,10 +338,15 @@ class UFORecon(nn.Module):
         near = batch["near_fars"][0, 0, 0].expand(RN).float().contiguous()
         far = batch["near_fars"][0, 0, 1].expand(RN).float().contiguous()
         z1 = ops.sample_fixed(near, far, U1)
-        rgb, depth, opacity, weight, srdf, pip = self._render_pass(fh, ray_o, ray_d, z1, feature_volume)
-        _, z2 = ops.sample_importance_merge(weight.detach().contiguous(), z1, U2, want_fine=False)
+        # both passes in one autograd node: the fine pass evaluates only its new samples per point and shares the coarse
+        # samples' rows with the coarse pass, forwards and backwards (autograd.RenderTwoPass; same numbers as two sample2rgb
+        # calls on z1 and on the merged z2, model.py:445, 472)
+        params, vols = self._live_params(), ag.flat_volumes(feature_volume)
+        (rgb, depth, opacity, weight, srdf, xy1, rgb2, depth2, opacity2, weight2, srdf2, xy2, z2) = ag.RenderTwoPass.apply(
+            fh, W, ray_o, ray_d, z1, U2, *params, *vols)
         S2 = z2.shape[1]
-        rgb2, depth2, opacity2, weight2, srdf2, pip2 = self._render_pass(fh, ray_o, ray_d, z2, feature_volume)
+        pip = xy1.reshape(1, -1, RN, self.point_num, 2).permute(0, 1, 4, 2, 3)
+        pip2 = xy2.reshape(1, -1, RN, S2, 2).permute(0, 1, 4, 2, 3)
         variance = self._variance_out()
         return (rgb_gt, rgb[None], depth[None], depth_gt, srdf.reshape(RN, -1, 1), opacity[None], weight[None], pip,
                 rgb2[None], depth2[None], srdf2.reshape(RN, S2, 1), opacity2[None], weight2[None], pip2,

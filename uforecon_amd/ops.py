@@ -318,6 +318,63 @@ def project_gather_bwd(frame: FrameHandle, weights: PackedWeights, grads: GradBu
         _dev(z, "z"), RN, SN, _dev(sim8, "sim8"), _dev(d_pv, "d_pv"), gf, gw, _stream()), "ufr_project_gather_bwd")
 
 
+# ----------------------------------------------------------------------------- halves of aggregate / sample pool
+def sample_importance_pool(weight: torch.Tensor, z: torch.Tensor, U2: torch.Tensor):
+    """-> z_all (RN,SN+PN) sorted, z_new (RN,PN) in draw order, row (RN,SN+PN) int32: pool row of every merged slot
+    (pool = [RN*SN coarse rows | RN*PN new rows])."""
+    RN, SN = z.shape
+    PN = U2.shape[0]
+    dev = z.device
+    z_all = torch.empty(RN, SN + PN, dtype=torch.float32, device=dev)
+    z_new = torch.empty(RN, PN, dtype=torch.float32, device=dev)
+    row = torch.empty(RN, SN + PN, dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().ufr_sample_importance_pool(_dev(weight, "weight"), _dev(z, "z"), _dev(U2, "U2"), z_all.data_ptr(),
+                                                      z_new.data_ptr(), row.data_ptr(), RN, SN, PN, _stream()),
+               "ufr_sample_importance_pool")
+    return z_all, z_new, row
+
+
+def view_transform(weights: PackedWeights, x: torch.Tensor, rgb: torch.Tensor, dirs: torch.Tensor):
+    P, NV = x.shape[0], x.shape[1]
+    token0 = torch.empty(P, _lib.TOKEN_DIM, dtype=torch.float32, device=x.device)
+    radiance = torch.empty(P, 3, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().ufr_view_transform(weights.packed.data_ptr(), _dev(x, "x_tokens"), _dev(rgb, "rgb"), _dev(dirs, "dir"),
+                                              P, NV, token0.data_ptr(), radiance.data_ptr(), _stream()), "ufr_view_transform")
+    return token0, radiance
+
+
+def ray_transform(weights: PackedWeights, token0: torch.Tensor, RN: int, SN: int) -> torch.Tensor:
+    lib = _lib.load()
+    srdf = torch.empty(RN, SN, dtype=torch.float32, device=token0.device)
+    ws = torch.empty(lib.ufr_ray_transform_workspace_bytes(SN) // 4, dtype=torch.float32, device=token0.device)
+    _lib.check(lib.ufr_ray_transform(weights.packed.data_ptr(), _dev(token0, "token0"), RN, SN, srdf.data_ptr(), ws.data_ptr(),
+                                     _stream()), "ufr_ray_transform")
+    return srdf
+
+
+def ray_transform_bwd(weights: PackedWeights, grads: GradBuffer, token0: torch.Tensor, RN: int, SN: int, d_srdf: torch.Tensor):
+    """-> the two partial d token0 buffers (P,80) of the ray kernel's sweeps (their sum is the gradient)."""
+    lib = _lib.load()
+    dev = token0.device
+    a = torch.empty(RN * SN, _lib.TOKEN_DIM, dtype=torch.float32, device=dev)
+    b = torch.empty(RN * SN, _lib.TOKEN_DIM, dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.ufr_ray_transform_workspace_bytes(SN) // 4, dtype=torch.float32, device=dev)
+    _lib.check(lib.ufr_ray_transform_bwd(C.byref(weights.raw), C.byref(grads.raw), _dev(token0, "token0"), RN, SN,
+                                         _dev(d_srdf.contiguous(), "d_srdf"), a.data_ptr(), b.data_ptr(), ws.data_ptr(), _stream()),
+               "ufr_ray_transform_bwd")
+    return a, b
+
+
+def view_transform_bwd(weights: PackedWeights, grads: GradBuffer, x, rgb, dirs, d_token0_a, d_token0_b, d_radiance):
+    P, NV = x.shape[0], x.shape[1]
+    d_pv = torch.empty(P, 40, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().ufr_view_transform_bwd(
+        C.byref(weights.raw), C.byref(grads.raw), _dev(x, "x_tokens"), _dev(rgb, "rgb"), _dev(dirs, "dir"),
+        _dev(d_token0_a.contiguous(), "d_token0_a"), _opt(None if d_token0_b is None else d_token0_b.contiguous(), "d_token0_b"),
+        _dev(d_radiance.contiguous(), "d_radiance"), P, NV, d_pv.data_ptr(), _stream()), "ufr_view_transform_bwd")
+    return d_pv
+
+
 class RenderWorkspace:
     """Reusable scratch of ufr_render_rays (sized for `chunk_rays`)."""
 

@@ -41,7 +41,9 @@ enum : int {
 };
 constexpr int kKV = 8 * 11 * 12;   // per head [d][e], e = 11: sum of K' (linear_attention.py:43)
 constexpr int kKVPer = (kKV + kBwdThreads - 1) / kBwdThreads;
-constexpr int kLdsBytes = (O_END * kLD + 2 * kKV) * 4;
+// flat region behind the KV state: small parameters copied once per workgroup (read by every tile's VALU phases)
+enum : int { F_N1W = 0, F_N1B = 88, F_N2W = 176, F_N2B = 264, F_DM_B0 = 352, F_DM_B2 = 384, F_DM_W4 = 400, F_END = 416 };
+constexpr int kLdsBytes = (O_END * kLD + 2 * kKV + F_END) * 4;
 
 constexpr WgMat kMats2[] = {{P_RT_Q, 88, 88, O_DQ, O_CAT},        {P_RT_MERGE, 88, 88, O_DMPRE, O_MSG},
                             {P_RT_MLP0, 176, 176, O_DHID, O_CAT}, {P_RT_MLP2, 88, 176, O_DOPRE, O_HID},
@@ -62,6 +64,7 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* KV = lds + O_END * kLD;
   float* dKV = KV + kKV;
+  float* flat = dKV + kKV;
   const int tid0 = threadIdx.x, wave = tid0 >> 6, lane = tid0 & 63;
   int tid = tid0;   // re-laundered after every barrier (bwd_common.h: opaque)
   const int n_sub = SN / kTT;
@@ -73,6 +76,13 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
   float accB = 0.f, accN1 = 0.f, accN2 = 0.f;
 
   auto R = [&](int row) -> float* { return lds + row * kLD; };
+  if (tid0 < 88) {
+    flat[F_N1W + tid0] = wp.p[P_RT_N1W][tid0]; flat[F_N1B + tid0] = wp.p[P_RT_N1B][tid0];
+    flat[F_N2W + tid0] = wp.p[P_RT_N2W][tid0]; flat[F_N2B + tid0] = wp.p[P_RT_N2B][tid0];
+  }
+  if (tid0 < 32) flat[F_DM_B0 + tid0] = wp.p[P_DM_B0][tid0];
+  if (tid0 < 16) { flat[F_DM_B2 + tid0] = wp.p[P_DM_B2][tid0]; flat[F_DM_W4 + tid0] = wp.p[P_DM_W4][tid0]; }
+  // (the first barrier of the ray loop publishes them)
   // x tile: token-0 feature of sample (ray, s0 + col) | order PE (ray_transformer.py:301-303)
   auto load_x = [&](int ray, int s0) {
     for (int idx = tid; idx < kTT * 22; idx += kBwdThreads) {
@@ -130,7 +140,7 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       auto pf1 = gemm_prefetch<88, 88, false>(wp.p[P_RT_Q], 88, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_compute<88, 88, false>(pf1, wp.p[P_RT_Q], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_Q + r)[c] = v; });
+      gemm_compute<88, 88, false>(pf1, wp.p[P_RT_Q], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_Q + r)[c] = elu1(v); });   // Q' kept: elu'(q) = (Q' > 1 ? 1 : Q')
       __syncthreads();
     tid = opaque(tid0);
       // message of (token, head): t = Q' KV_h, den = Q'.sum K', msg = t * Z * SN (linear_attention.py:43-44)
@@ -138,7 +148,7 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
         const int col = tid >> 3, h = tid & 7;
         float Qp[11], t[11], den = 0.f;
 #pragma unroll
-        for (int d = 0; d < 11; ++d) Qp[d] = elu1(R(O_Q + 11 * h + d)[col]);
+        for (int d = 0; d < 11; ++d) Qp[d] = R(O_Q + 11 * h + d)[col];
 #pragma unroll
         for (int e = 0; e < 11; ++e) t[e] = 0.f;
 #pragma unroll
@@ -159,7 +169,7 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       gemm_compute<88, 88, false>(pf2, wp.p[P_RT_MERGE], 88, R(O_MSG), wave, lane, [&](int r, int c, float v) { R(O_XH1 + r)[c] = v; });
       __syncthreads();
     tid = opaque(tid0);
-      ln_forward<88>(R(O_XH1), R(O_CAT + 88), nullptr, wp.p[P_RT_N1W], wp.p[P_RT_N1B], R(O_RSTD1), tid);
+      ln_forward<88>(R(O_XH1), R(O_CAT + 88), nullptr, flat + F_N1W, flat + F_N1B, R(O_RSTD1), tid);
       auto pf3 = gemm_prefetch<176, 176, false>(wp.p[P_RT_MLP0], 176, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
@@ -171,24 +181,24 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       gemm_compute<88, 176, false>(pf4, wp.p[P_RT_MLP2], 176, R(O_HID), wave, lane, [&](int r, int c, float v) { R(O_XH2 + r)[c] = v; });
       __syncthreads();
     tid = opaque(tid0);
-      ln_forward<88>(R(O_XH2), R(O_Y), R(O_CAT), wp.p[P_RT_N2W], wp.p[P_RT_N2B], R(O_RSTD2), tid);
+      ln_forward<88>(R(O_XH2), R(O_Y), R(O_CAT), flat + F_N2W, flat + F_N2B, R(O_RSTD2), tid);
       auto pf5 = gemm_prefetch<32, 88, false>(wp.p[P_DM_W0], 88, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
       // DensityMLP 88 -> 32 -> 16 (-> 1) (ray_transformer.py:147-150, 307)
       gemm_compute<32, 88, false>(pf5, wp.p[P_DM_W0], 88, R(O_Y), wave, lane,
-                              [&](int r, int c, float v) { R(O_D1 + r)[c] = fmaxf(v + wp.p[P_DM_B0][r], 0.f); });
+                              [&](int r, int c, float v) { R(O_D1 + r)[c] = fmaxf(v + flat[F_DM_B0 + r], 0.f); });
       auto pf6 = gemm_prefetch<16, 32, false>(wp.p[P_DM_W2], 32, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
       gemm_compute<16, 32, false>(pf6, wp.p[P_DM_W2], 32, R(O_D1), wave, lane,
-                              [&](int r, int c, float v) { R(O_D2 + r)[c] = fmaxf(v + wp.p[P_DM_B2][r], 0.f); });
+                              [&](int r, int c, float v) { R(O_D2 + r)[c] = fmaxf(v + flat[F_DM_B2 + r], 0.f); });
       __syncthreads();
     tid = opaque(tid0);
       // ---- backwards: srdf = W4 d2 + b4
       if (tid < 16 * kTT) {
         const int o = tid >> 4, c = tid & 15;
-        R(O_DD2 + o)[c] = R(O_D2 + o)[c] > 0.f ? wp.p[P_DM_W4][o] * R(O_DSRDF)[c] : 0.f;
+        R(O_DD2 + o)[c] = R(O_D2 + o)[c] > 0.f ? flat[F_DM_W4 + o] * R(O_DSRDF)[c] : 0.f;
       }
       auto pf7 = gemm_prefetch<32, 16, true>(wp.p[P_DM_W2], 32, wave, lane, 0);
       __syncthreads();
@@ -201,7 +211,7 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       gemm_compute<88, 32, true>(pf8, wp.p[P_DM_W0], 88, R(O_DD1), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] = v; });
       __syncthreads();
     tid = opaque(tid0);
-      ln_backward<88>(R(O_DY), R(O_XH2), wp.p[P_RT_N2W], R(O_RSTD2), R(O_DOPRE), tid);
+      ln_backward<88>(R(O_DY), R(O_XH2), flat + F_N2W, R(O_RSTD2), R(O_DOPRE), tid);
       if (tid < 88) accN2 += row_dot(R(O_DY), R(O_XH2), tid);
       else if (tid < 176) accN2 += row_dot(R(O_DY), nullptr, tid - 88);
       auto pf9 = gemm_prefetch<176, 88, true>(wp.p[P_RT_MLP2], 176, wave, lane, 0);
@@ -215,7 +225,7 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       gemm_compute<176, 176, true>(pf10, wp.p[P_RT_MLP0], 176, R(O_DHID), wave, lane, [&](int r, int c, float v) { R(O_DCAT + r)[c] = v; });
       __syncthreads();
     tid = opaque(tid0);
-      ln_backward<88>(R(O_DCAT + 88), R(O_XH1), wp.p[P_RT_N1W], R(O_RSTD1), R(O_DMPRE), tid);
+      ln_backward<88>(R(O_DCAT + 88), R(O_XH1), flat + F_N1W, R(O_RSTD1), R(O_DMPRE), tid);
       if (tid < 88) accN1 += row_dot(R(O_DCAT + 88), R(O_XH1), tid);
       else if (tid < 176) accN1 += row_dot(R(O_DCAT + 88), nullptr, tid - 88);
       for (int idx = tid; idx < 88 * kTT; idx += kBwdThreads) {
@@ -233,7 +243,7 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
         const int col = tid >> 3, h = tid & 7;
         float Qp[11], t[11], dt[11], dq[11];
 #pragma unroll
-        for (int d = 0; d < 11; ++d) { Qp[d] = elu1(R(O_Q + 11 * h + d)[col]); t[d] = 0.f; }
+        for (int d = 0; d < 11; ++d) { Qp[d] = R(O_Q + 11 * h + d)[col]; t[d] = 0.f; }
 #pragma unroll
         for (int d = 0; d < 11; ++d) {
           const float* row = KV + (h * 11 + d) * 12;
@@ -259,7 +269,7 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
         }
 #pragma unroll
         for (int d = 0; d < 11; ++d) {
-          R(O_DQ + 11 * h + d)[col] = dq[d] * elu1_grad(R(O_Q + 11 * h + d)[col]);
+          R(O_DQ + 11 * h + d)[col] = dq[d] * (Qp[d] > 1.f ? 1.f : Qp[d]);
           R(O_DMSG + 11 * h + d)[col] = dt[d];
         }
         R(O_DDEN + h)[col] = dden;
@@ -277,7 +287,7 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
           const float* tr = e < 11 ? R(O_DMSG + 11 * h + e) : R(O_DDEN + h);
           float s = 0.f;
 #pragma unroll
-          for (int t = 0; t < kTT; ++t) s = fmaf(elu1(qr[t]), tr[t], s);
+          for (int t = 0; t < kTT; ++t) s = fmaf(qr[t], tr[t], s);
           dkv[i] += s;
         }
       }
@@ -324,7 +334,7 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       auto pf12 = gemm_prefetch<88, 88, false>(wp.p[P_RT_K], 88, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_compute<88, 88, false>(pf12, wp.p[P_RT_K], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = v; });
+      gemm_compute<88, 88, false>(pf12, wp.p[P_RT_K], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = elu1(v); });   // K'
       gemm_lds<88, 88, false>(wp.p[P_RT_V], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_V + r)[c] = v; }, 6);
       __syncthreads();
     tid = opaque(tid0);
@@ -334,7 +344,7 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
         float Kp[11], V[11], dv[11];
 #pragma unroll
         for (int d = 0; d < 11; ++d) {
-          Kp[d] = elu1(R(O_K + 11 * h + d)[col]);
+          Kp[d] = R(O_K + 11 * h + d)[col];
           V[d] = R(O_V + 11 * h + d)[col] / fS;
           dv[d] = 0.f;
         }
@@ -347,7 +357,7 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
             s = fmaf(row[e], V[e], s);
             dv[e] = fmaf(Kp[d], row[e], dv[e]);
           }
-          R(O_DK + 11 * h + d)[col] = s * elu1_grad(R(O_K + 11 * h + d)[col]);
+          R(O_DK + 11 * h + d)[col] = s * (Kp[d] > 1.f ? 1.f : Kp[d]);
         }
 #pragma unroll
         for (int e = 0; e < 11; ++e) R(O_DV + 11 * h + e)[col] = dv[e] / fS;

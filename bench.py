@@ -37,10 +37,10 @@ FLOP_PER_POINT = {3: 708_018, 5: 983_150}
 VIEWT_FLOP_PER_POINT = {3: 204_800 + 307_200 + 13_440 + 8_784, 5: (204_800 + 307_200) * 6 // 4 + 20_160 + 14_640}
 RAYT_FLOP_PER_POINT = 61_952 + 92_928 + 4_048 + 6_688   # ray transformer + DensityMLP (d = 88, 8 heads)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
-PEAK_BF16_MFMA_TFLOPS = 2516.6  # dense bf16 MFMA peak: 256 CU x 4 SIMD x 1024 flop/clk x 2.4 GHz
-# the transformer kernels compute every fp32 product as six bf16 plane products (exact 3-way split of both
-# operands, fp32 accumulate: ufr_layout_bf.h), so their matrix-core bound in fp32-equivalent flop is peak/6
-PEAK_F32_VIA_BF16X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+PEAK_F16_MFMA_TFLOPS = 2516.6  # dense fp16 / bf16 MFMA peak: 256 CU x 4 SIMD x 1024 flop/clk x 2.4 GHz
+# the transformer kernels compute every fp32 product as three fp16 plane products (two-plane split of both
+# operands, fp32 accumulate: ufr_layout_f16.h), so their matrix-core bound in fp32-equivalent flop is peak/3
+PEAK_F32_VIA_F16X3_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0
 
 
 def parse():
@@ -266,22 +266,24 @@ def main():
                         executed_evaluations_per_ray=dict(gather_and_view_transformer=point_evals_per_ray,
                                                           ray_transformer_and_compositor=ray_evals_per_ray,
                                                           note="coarse per-point results are reused by the fine pass (bit-identical)"),
-                        arithmetic="fp32 in/out; dense layers as six bf16 plane products per fp32 product on the bf16 MFMA "
-                                   "(exact 3-way split, fp32 accumulate); gathers, attention, norms, compositor in fp32 VALU",
+                        arithmetic="fp32 in/out; dense layers as three fp16 plane products per fp32 product on the fp16 MFMA "
+                                   "(hi/lo split of both operands, 22+ significand bits, fp32 accumulate; same measured error "
+                                   "as an fp32 GEMM); gathers, attention, norms, compositor in fp32 VALU",
                         executed_tflops=(rays_per_s * exec_flop_per_ray / 1e12) if exec_flop_per_ray else None,
                         reference_equivalent_tflops=(rays_per_s * ref_pts_per_ray * flop_pt / 1e12) if flop_pt else None,
                         kernel_ms_per_frame_rank0={k: v["ms"] / prof_steps for k, v in prof.items()},
                         kernel_ms_measured="timed region" if a.streams <= 1 else "one extra single-stream frame after the timed region",
                         per_rank=per_rank),
-            roofline=dict(bound="mfma", achieved=achieved, peak=PEAK_F32_VIA_BF16X6_TFLOPS, unit="TFLOP/s",
-                          frac=achieved / PEAK_F32_VIA_BF16X6_TFLOPS, traffic=traffic, traffic_source=traffic_src,
+            roofline=dict(bound="mfma", achieved=achieved, peak=PEAK_F32_VIA_F16X3_TFLOPS, unit="TFLOP/s",
+                          frac=achieved / PEAK_F32_VIA_F16X3_TFLOPS, traffic=traffic, traffic_source=traffic_src,
                           kernel="view_transformer_kernel", avg_launch_ms=vt_ms, launches=vt["launches"],
                           algorithmic_flop_per_launch=vt_flop,
-                          peak_basis="dense bf16 MFMA peak 2516.6 TFLOP/s / 6 plane products per fp32 product (bf16x6); "
-                                     "the fp32 MFMA peak is 157.3 TFLOP/s",
+                          peak_basis="dense fp16 MFMA peak 2516.6 TFLOP/s / 3 plane products per fp32 product (fp16x3); "
+                                     "the fp32 MFMA peak is 157.3 TFLOP/s (round 1-2 kernels issued 6 bf16 plane products: "
+                                     "their peak basis was 419.4)",
                           frac_of_fp32_mfma_peak=achieved / PEAK_FP32_MFMA_TFLOPS,
-                          # 1680 v_mfma_f32_16x16x32_bf16 (16 384 flop each) per 8 points at NV = 3, K / row padding included
-                          issued_bf16_tflops=achieved * (1680 * 16384 / 8) / VIEWT_FLOP_PER_POINT[3] if a.views == 3 else None),
+                          # 840 v_mfma_f32_16x16x32_f16 (16 384 flop each) per 8 points at NV = 3, K / row padding included
+                          issued_f16_tflops=achieved * (840 * 16384 / 8) / VIEWT_FLOP_PER_POINT[3] if a.views == 3 else None),
         )
         if not a.no_gpu_eager_baseline and world == 1:
             # the >= 20x target's denominator, measured in the same run on the same GPU (BASELINE.md has no published

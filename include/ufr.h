@@ -72,14 +72,16 @@ int ufr_weights_pack(const ufr_raw_weights* raw, void* packed, ufr_stream stream
  * zero padding) and elem (flat element index inside that parameter).  Arrays of
  * ufr_packed_weights_bytes()/4 int32 each.  No GPU needed. */
 int ufr_pack_plan(int32_t* param_id, int32_t* elem);
-/* The packed blob is [fp32 region: ufr_packed_fp32_floats() floats | bf16 region: ufr_packed_bf16_halfwords()
- * 16-bit words].  The bf16 region holds the view-transformer chain as three bf16 planes per weight
- * (exact split w = hi + mid + lo, plane 0/1/2) for the split-precision MFMA path; ufr_pack_plan_bf16
- * describes it like ufr_pack_plan (one entry per halfword, plus the plane).  Of the fp32 region ufr_weights_pack fills
- * only the trailing vector fragments (biases, LayerNorm, view token): the kernels read nothing else of it. */
+/* The packed blob is [fp32 region: ufr_packed_fp32_floats() floats | fp16 plane region: ufr_packed_f16_halfwords()
+ * 16-bit words | 16-byte tail].  The plane region holds the dense layers of both transformer chains as two fp16
+ * planes per weight (hi = fp16(256 w), lo = fp16(256 w - hi); plane 0/1) for the split-precision MFMA path;
+ * ufr_pack_plan_f16 describes it like ufr_pack_plan (one entry per halfword, plus the plane).  Of the fp32 region
+ * ufr_weights_pack fills only the trailing vector fragments (biases, LayerNorm, view token): the kernels read nothing
+ * else of it.  ufr_weights_pack synchronises the stream and fails with UFR_ERR_ARG when a dense-layer weight is not
+ * finite or |w| >= 255.8 (outside the fp16 planes' range). */
 size_t ufr_packed_fp32_floats(void);
-size_t ufr_packed_bf16_halfwords(void);
-int ufr_pack_plan_bf16(int32_t* param_id, int32_t* elem, int32_t* plane);
+size_t ufr_packed_f16_halfwords(void);
+int ufr_pack_plan_f16(int32_t* param_id, int32_t* elem, int32_t* plane);
 
 /* ------------------------------------------------------------------ frame
  * Per-frame tensors produced by the encoder (model.py:780-808), in the reference layout.

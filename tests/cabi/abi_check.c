@@ -9,8 +9,8 @@ int main(void) {
   /* link-time presence of every entry point */
   const void* syms[] = {
       (const void*)ufr_version, (const void*)ufr_last_error, (const void*)ufr_packed_weights_bytes, (const void*)ufr_weights_pack,
-      (const void*)ufr_pack_plan, (const void*)ufr_packed_fp32_floats, (const void*)ufr_packed_bf16_halfwords,
-      (const void*)ufr_pack_plan_bf16, (const void*)ufr_frame_workspace_bytes, (const void*)ufr_frame_prepare,
+      (const void*)ufr_pack_plan, (const void*)ufr_packed_fp32_floats, (const void*)ufr_packed_f16_halfwords,
+      (const void*)ufr_pack_plan_f16, (const void*)ufr_frame_workspace_bytes, (const void*)ufr_frame_prepare,
       (const void*)ufr_sample_fixed, (const void*)ufr_sample_importance_merge, (const void*)ufr_points,
       (const void*)ufr_project_gather, (const void*)ufr_aggregate_workspace_bytes, (const void*)ufr_aggregate,
       (const void*)ufr_composite, (const void*)ufr_composite_bwd, (const void*)ufr_aggregate_bwd_workspace_bytes,

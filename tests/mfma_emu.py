@@ -171,24 +171,20 @@ def from_tiles_swapped(acc, rm, out_dim):
     return y
 
 
-# ------------------------------------------------------------------ bf16x6 path (ufr_layout_bf.h, weight_stream_bf.h)
-def bf16_rne(x):
-    u = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
-    return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+# ------------------------------------------------------------------ fp16x3 path (ufr_layout_f16.h, weight_stream_f16.h)
+W_SCALE, X_SCALE = np.float32(256.0), np.float32(16.0)   # kWScale, kXScale
 
 
-def split3(x):
-    """exact 3-way bf16 split (planes returned as float32 values with 16 low zero bits)."""
-    x = np.asarray(x, np.float32)
-    h = bf16_rne(x)
-    r = (x - h).astype(np.float32)
-    m = bf16_rne(r)
-    lo = bf16_rne((r - m).astype(np.float32))
-    return h, m, lo
+def split2(x, scale):
+    """fp16 planes of scale * x (ufr_layout_f16.h): hi = fp16(scale x), lo = fp16(scale x - hi), RNE; returned as float32."""
+    x = np.asarray(x, np.float32) * np.float32(scale)
+    hi = x.astype(np.float16)
+    lo = (x - hi.astype(np.float32)).astype(np.float16)
+    return hi.astype(np.float32), lo.astype(np.float32)
 
 
-def bf_streams():
-    """Per bf16 stream: (matrix name, k-step) panels in stream order (ufr_layout_bf.h:bf_panel)."""
+def f16_streams():
+    """Per weight stream: (matrix name, k-step) panels in stream order (ufr_layout_f16.h:f16_panel)."""
     vt = []
     for s in range(3):
         vt += [("VT_Q", s), ("VT_K", s)]
@@ -204,35 +200,35 @@ def bf_streams():
     return [vt, rt1, rt2]
 
 
-BF_CHUNK = 24  # fragments per LDS chunk (kBfChunkFrags)
-BF_SLOTS = 2   # LDS ring depth (kBfSlots): streams are padded to whole rings
+F16_CHUNK = 24  # fragments per LDS chunk (kF16ChunkFrags)
+F16_SLOTS = 2   # LDS ring depth (kF16Slots): streams are padded to whole rings
 
 
 def _stream_len(panels):
-    n = sum(MATS[NAME2IDX[m]][3] * 3 for m, _ in panels)
-    chunks = (n + BF_CHUNK - 1) // BF_CHUNK
-    return (chunks + BF_SLOTS - 1) // BF_SLOTS * BF_SLOTS * BF_CHUNK
+    n = sum(MATS[NAME2IDX[m]][3] * 2 for m, _ in panels)
+    chunks = (n + F16_CHUNK - 1) // F16_CHUNK
+    return (chunks + F16_SLOTS - 1) // F16_SLOTS * F16_SLOTS * F16_CHUNK
 
 
 def panel_start(name, s):
-    """first fragment of panel (name, k-step s) in the bf16 region: streams are padded to whole chunks."""
+    """first fragment of panel (name, k-step s) in the fp16 plane region: streams are padded to whole chunks."""
     base = 0
-    for panels in bf_streams():
+    for panels in f16_streams():
         off = 0
         for n, k in panels:
             if (n, k) == (name, s):
                 return base + off
-            off += MATS[NAME2IDX[n]][3] * 3
+            off += MATS[NAME2IDX[n]][3] * 2
         base += _stream_len(panels)
     raise KeyError((name, s))
 
 
-def bf_region_frags():
-    return sum(_stream_len(p) for p in bf_streams())
+def f16_region_frags():
+    return sum(_stream_len(p) for p in f16_streams())
 
 
-def mfma_bf16(a, b, acc):
-    """v_mfma_f32_16x16x32_bf16: a, b (64,8) lane operands (lane l: A[l&15][8(l>>4)+i], B[8(l>>4)+i][l&15])."""
+def mfma_f16(a, b, acc):
+    """v_mfma_f32_16x16x32_f16: a, b (64,8) lane operands (lane l: A[l&15][8(l>>4)+i], B[8(l>>4)+i][l&15])."""
     A = np.zeros((16, 32), np.float64)
     B = np.zeros((32, 16), np.float64)
     for i in range(8):
@@ -245,7 +241,7 @@ def mfma_bf16(a, b, acc):
     return out.astype(np.float32)  # the accumulator is fp32
 
 
-def gemm_bf(bf_blob, name, tiles_in, swap=False):
+def gemm_f16(f16_blob, name, tiles_in, swap=False):
     """tiles_in (n_in,64,4) fp32 accumulator tiles of the producer -> (n_out,64,4); swap: activations in the A slot."""
     idx = NAME2IDX[name]
     n_out, n_in = MATS[idx][3], MATS[idx][4]
@@ -253,10 +249,10 @@ def gemm_bf(bf_blob, name, tiles_in, swap=False):
     zero = np.zeros((64, 4), np.float32)
     for s in range((n_in + 1) // 2):
         ta, tb = tiles_in[2 * s], (tiles_in[2 * s + 1] if 2 * s + 1 < n_in else zero)
-        xb = [np.concatenate([pa, pb], axis=1) for pa, pb in zip(split3(ta), split3(tb))]  # per plane (64,8)
+        xb = [np.concatenate([pa, pb], axis=1) for pa, pb in zip(split2(ta, X_SCALE), split2(tb, X_SCALE))]  # per plane (64,8)
         f0 = panel_start(name, s)
         for to in range(n_out):
-            a = [bf_blob[(f0 + to * 3 + p) * 512:(f0 + to * 3 + p + 1) * 512].reshape(64, 8) for p in range(3)]
-            for pa, pb in ((1, 1), (0, 2), (2, 0), (0, 1), (1, 0), (0, 0)):
-                out[to] = mfma_bf16(xb[pb], a[pa], out[to]) if swap else mfma_bf16(a[pa], xb[pb], out[to])
-    return out
+            a = [f16_blob[(f0 + to * 2 + p) * 512:(f0 + to * 2 + p + 1) * 512].reshape(64, 8) for p in range(2)]
+            for pa, pb in ((1, 0), (0, 1), (0, 0)):     # w_lo x_hi, w_hi x_lo, w_hi x_hi
+                out[to] = mfma_f16(xb[pb], a[pa], out[to]) if swap else mfma_f16(a[pa], xb[pb], out[to])
+    return out * np.float32(1.0 / 4096.0)               # kAccDescale

@@ -41,8 +41,8 @@ def test_struct_sizes_match_the_header(lib):
     assert C.sizeof(_lib.RawWeights) == 40 * 8
     assert C.sizeof(_lib.Frame) == 160 * 8
     assert lib.ufr_packed_fp32_floats() == E.vec_region_offset() + 16 * (5 * 4 + 6 * 4 + 2 + 5 + 5)
-    assert lib.ufr_packed_weights_bytes() == 4 * lib.ufr_packed_fp32_floats() + 2 * lib.ufr_packed_bf16_halfwords()
-    assert lib.ufr_packed_bf16_halfwords() % (24 * 512) == 0  # whole 24 KiB chunks
+    assert lib.ufr_packed_weights_bytes() == 4 * lib.ufr_packed_fp32_floats() + 2 * lib.ufr_packed_f16_halfwords() + 16  # + flag tail
+    assert lib.ufr_packed_f16_halfwords() % (24 * 512) == 0  # whole 24 KiB chunks
 
 
 def test_argument_errors_are_reported_not_fatal(lib):
@@ -173,39 +173,44 @@ def test_ray_attention_dataflow_in_mfma_form(raw_and_blob):
                         assert abs(msg[lane, r] - ref[16 * tile + (lane & 15), h, v]) < 1e-9
 
 
-# ------------------------------------------------------------------ bf16x6 region (split-precision MFMA path)
+# ------------------------------------------------------------------ fp16 plane region (split-precision MFMA path)
 @pytest.fixture(scope="module")
-def bf_blob(lib, raw_and_blob):
+def f16_blob(lib, raw_and_blob):
     raw, _ = raw_and_blob
-    n = lib.ufr_packed_bf16_halfwords()
+    n = lib.ufr_packed_f16_halfwords()
     pid, el, pl = (np.zeros(n, np.int32) for _ in range(3))
     P32 = C.POINTER(C.c_int32)
-    assert lib.ufr_pack_plan_bf16(pid.ctypes.data_as(P32), el.ctypes.data_as(P32), pl.ctypes.data_as(P32)) == 0
-    planes = {p: E.split3(raw[p].astype(np.float32)) for p in np.unique(pid) if p >= 0}
+    assert lib.ufr_pack_plan_f16(pid.ctypes.data_as(P32), el.ctypes.data_as(P32), pl.ctypes.data_as(P32)) == 0
+    planes = {p: E.split2(raw[p].astype(np.float32), E.W_SCALE) for p in np.unique(pid) if p >= 0}
     blob = np.zeros(n, np.float32)
     for p, sp in planes.items():
-        for k in range(3):
+        for k in range(2):
             sel = (pid == p) & (pl == k)
             blob[sel] = sp[k].reshape(-1)[el[sel]]
     return blob
 
 
-def test_bf16_split_is_exact():
-    x = np.random.default_rng(1).standard_normal(10000).astype(np.float32) * np.float32(37.0)
-    h, m, l = E.split3(x)
-    assert np.array_equal((h.astype(np.float64) + m + l).astype(np.float32), x)
-    for p in (h, m, l):  # every plane is a bf16 number (low 16 bits clear)
-        assert not (p.view(np.uint32) & 0xFFFF).any()
+def test_f16_split_carries_22_bits():
+    """hi + lo of the two-plane fp16 split: within 2^-22 of the value over the supported range (measured max ~2^-23),
+    both planes fp16 numbers; tiny values degrade gradually (absolute floor 2^-25 / scale)."""
+    rng = np.random.default_rng(1)
+    x = (rng.standard_normal(20000) * np.exp(rng.uniform(-6, 5, 20000))).astype(np.float32)
+    x = x[np.abs(x) < 4000]
+    h, l = E.split2(x, E.X_SCALE)
+    err = np.abs((h.astype(np.float64) + l) / 16.0 - x)
+    assert (err <= np.maximum(np.abs(x) * 2.0 ** -22, 2.0 ** -29)).all()
+    for p in (h, l):
+        assert np.array_equal(p.astype(np.float16).astype(np.float32), p)
 
 
-def test_bf16_region_size(lib):
-    assert lib.ufr_packed_bf16_halfwords() == E.bf_region_frags() * 512
+def test_f16_region_size(lib):
+    assert lib.ufr_packed_f16_halfwords() == E.f16_region_frags() * 512
 
 
 @pytest.mark.parametrize("name", [m[0] for m in E.MATS])
-def test_bf16x6_panels_reproduce_linear(name, raw_and_blob, bf_blob):
-    """The exported bf16 plan, pushed through a lane-level model of v_mfma_f32_16x16x32_bf16 with the six
-    plane pairs of csrc/weight_stream_bf.h, reproduces y = W x to fp32 accuracy for every matrix of the chain."""
+def test_fp16x3_panels_reproduce_linear(name, raw_and_blob, f16_blob):
+    """The exported plane plan, pushed through a lane-level model of v_mfma_f32_16x16x32_f16 with the three
+    plane pairs of csrc/weight_stream_f16.h, reproduces y = W x to fp32 accuracy for every matrix of the chain."""
     raw, _ = raw_and_blob
     idx = E.NAME2IDX[name]
     _, param, k_raw, n_out, n_in, rm, cm, out_dim, in_dim = E.MATS[idx]
@@ -214,9 +219,9 @@ def test_bf16x6_panels_reproduce_linear(name, raw_and_blob, bf_blob):
     tiles = E.to_tiles(x, cm, n_in, in_dim).astype(np.float32)
     ref = x.astype(np.float64) @ W[:, :in_dim].astype(np.float64).T
     if name in ("RT_K", "RT_V"):  # swapped operands in the kernel: [token][feature] accumulators
-        y, pad = E.from_tiles_swapped(E.gemm_bf(bf_blob, name, tiles, swap=True), rm, out_dim), 0.0
+        y, pad = E.from_tiles_swapped(E.gemm_f16(f16_blob, name, tiles, swap=True), rm, out_dim), 0.0
     else:
-        y, pad = E.from_tiles(E.gemm_bf(bf_blob, name, tiles), rm, out_dim)
+        y, pad = E.from_tiles(E.gemm_f16(f16_blob, name, tiles), rm, out_dim)
     assert pad == 0.0
     assert np.abs(y - ref).max() / np.abs(ref).max() < 5e-7, name
 

@@ -146,7 +146,10 @@ def test_render_rays_matches_reference_golden(name, weights):
 def test_render_rays_interior_rays_full_coverage(name, weights):
     """Rays strictly inside the image (no sample projects onto an image border of a source view, where the
     reference's inclusive mask is a step function of the last ulp): depth AND RGB within 1e-4 on 100 % of the rays,
-    srdf within 1e-4 of its scale, sample positions (coarse + importance samples, merged) against the golden."""
+    sample positions (coarse + importance samples, merged) against the golden, srdf within 1e-4 of its scale at the
+    golden's own sample positions.  (End to end the srdf rows are compared at positions that differ by the CDF rounding
+    of the importance sampler -- 1e-6 relative -- which the steep signed-distance head amplifies: the oracle on this
+    host is already 6e-5 away from the golden there, so that comparison only gets a 2e-4 sanity bound.)"""
     fr, idx, U1, U2, g, want = _oracle_rows(name)
     assert not bool(border_degenerate_rays(want["fine"]).any())
     out = ops.render_rays(_frame_handle(fr), weights, idx.to(DEV), U1.to(DEV), U2.to(DEV))
@@ -155,7 +158,12 @@ def test_render_rays_interior_rays_full_coverage(name, weights):
     assert max_rel_elem(out["rgb"], g["rgb"], floor=0.05) < REL_TOL
     z_ref = (torch.from_numpy(g["points"]) - fr.batch["ray_o"][0]).norm(dim=-1)
     assert rel_err(out["z_all"], z_ref) < 1e-5                    # importance sampler + merge vs the reference's own
-    assert rel_err(out["srdf"], g["srdf"]) < 1e-4
+    assert rel_err(out["srdf"], g["srdf"]) < 2e-4
+    ray_o, ray_d, _, _ = _ray_setup(fr, idx)
+    RN, SN = z_ref.shape
+    x, rgbm, dirs = ops.project_gather(_frame_handle(fr), weights, ray_o.to(DEV), ray_d.to(DEV), z_ref.to(DEV).contiguous())[:3]
+    srdf = ops.aggregate(weights, x, rgbm, dirs, RN, SN)[1]
+    assert rel_err(srdf.reshape(RN, SN), g["srdf"]) < 1e-4
 
 
 @pytest.mark.parametrize("NV", [2, 4, 6, 7])
@@ -271,3 +279,18 @@ def test_edge_cases(weights):
         ops.render_rays(fh, weights, idx.to(DEV), U1[:60].to(DEV).contiguous(), U2.to(DEV))
     with pytest.raises(ops.UfrError, match="GPU"):
         ops.sample_fixed(torch.zeros(4), torch.ones(4), torch.rand(64, 4))
+
+
+def test_weights_outside_the_plane_range_are_refused():
+    """The dense layers are packed as fp16 planes of 256 w (ufr_layout_f16.h): a weight the planes cannot hold must fail
+    ufr_weights_pack loudly -- it must never render."""
+    from uforecon_amd._lib import UfrError
+
+    for bad in (300.0, float("nan"), float("inf")):
+        P = {k: v.clone().to(DEV) for k, v in load_weights().items()}
+        P["ray_transformer.density_view_transformer.layers.0.mlp.0.weight"][3, 5] = bad
+        with pytest.raises(UfrError, match="supported magnitude"):
+            ops.PackedWeights(P)
+    P = {k: v.clone().to(DEV) for k, v in load_weights().items()}
+    P["ray_transformer.density_view_transformer.layers.0.mlp.0.weight"][3, 5] = 250.0   # inside the range: packs
+    ops.PackedWeights(P)

@@ -71,8 +71,8 @@ SIGNATURES = {
     "ufr_weights_pack": (C.c_int, [C.POINTER(RawWeights), vp, vp]),
     "ufr_pack_plan": (C.c_int, [C.POINTER(i32), C.POINTER(i32)]),
     "ufr_packed_fp32_floats": (sz, []),
-    "ufr_packed_bf16_halfwords": (sz, []),
-    "ufr_pack_plan_bf16": (C.c_int, [C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+    "ufr_packed_f16_halfwords": (sz, []),
+    "ufr_pack_plan_f16": (C.c_int, [C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "ufr_frame_workspace_bytes": (sz, [C.POINTER(FrameDesc)]),
     "ufr_frame_prepare": (C.c_int, [C.POINTER(FrameDesc), vp, sz, C.POINTER(Frame), vp]),
     "ufr_sample_fixed": (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),

@@ -14,6 +14,10 @@
 #include "volume_sample.h"
 #include "weight_stream.h"   // static_for
 
+#ifndef UFR_GBWD_ROUNDS
+#define UFR_GBWD_ROUNDS 3   // fold aligned groups of 2, 4, 8 lanes (4: also 16, the whole DPP / shuffle row)
+#endif
+
 namespace ufr {
 
 struct VolGrads {
@@ -102,7 +106,7 @@ __global__ void __launch_bounds__(448) gather_bwd_kernel(FrameDev f, VolGrads vg
           for (int c = 0; c < 8; ++c) val[c] = wt * dfl[8 * s + c];
           val[8] = wt * dwl;
           bool alive = ok;
-          static_for<3>([&](auto ri) __attribute__((always_inline)) {
+          static_for<UFR_GBWD_ROUNDS>([&](auto ri) __attribute__((always_inline)) {
             constexpr int d = 1 << decltype(ri)::value;
             const int k_dn = __shfl_down(off, d, 16);                        // offset of lane + d (groups never leave a row)
             const int k_up = __shfl_up(off, d, 16);                          // offset of lane - d

@@ -3,7 +3,7 @@
 // texel: 48 B, rgb: 16 B).  HBM-bound streaming kernels, run once per frame
 // (the reference keeps NCHW and lets F.grid_sample stride over channels, model.py:251,370).
 #include "ufr_internal.h"
-#include "ufr_layout_bf.h"
+#include "ufr_layout_f16.h"
 
 namespace ufr {
 
@@ -75,34 +75,31 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(RawPtrs raw, float* _
   packed[i] = p >= 0 ? raw.p[p][e] : 0.f;
 }
 
-// bf16 region (ufr_layout_bf.h): halfword h = plane p of raw[param][elem], planes from the exact 3-way split
-// w = hi + mid + lo with round-to-nearest-even at every level
-__device__ __forceinline__ unsigned short bf16_rne(float x) {
-  unsigned u = __builtin_bit_cast(unsigned, x);
-  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-}
-__global__ void __launch_bounds__(256) pack_weights_bf16_kernel(RawPtrs raw, unsigned short* __restrict__ packed, int n) {
+// fp16 plane region (ufr_layout_f16.h): halfword h = plane p of 2^kWScaleLog2 * raw[param][elem]; hi = fp16(w'),
+// lo = fp16(w' - hi), both round-to-nearest-even (hi + lo carries 22+ significand bits of w').  A weight outside the
+// fp16 range after scaling (or not finite) raises *flag.
+__global__ void __launch_bounds__(256) pack_weights_f16_kernel(RawPtrs raw, unsigned short* __restrict__ packed, int n,
+                                                                int* __restrict__ flag) {
   int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= n) return;
   int p, e, plane;
-  plan_entry_bf(h, &p, &e, &plane);
+  plan_entry_f16(h, &p, &e, &plane);
   unsigned short out = 0;
   if (p >= 0) {
-    float w = raw.p[p][e];
-    unsigned short hi = bf16_rne(w);
-    w -= __builtin_bit_cast(float, (unsigned)hi << 16);
-    unsigned short mid = bf16_rne(w);
-    w -= __builtin_bit_cast(float, (unsigned)mid << 16);
-    out = plane == 0 ? hi : (plane == 1 ? mid : bf16_rne(w));
+    const float w = raw.p[p][e] * kWScale;
+    if (!(fabsf(w) <= 65504.f)) atomicOr(flag, 1);
+    const _Float16 hi = (_Float16)w;
+    const _Float16 lo = (_Float16)(w - (float)hi);
+    out = __builtin_bit_cast(unsigned short, plane == 0 ? hi : lo);
   }
   packed[h] = out;
 }
 
-hipError_t launch_pack_weights(const RawPtrs& raw, float* packed, hipStream_t s) {
+hipError_t launch_pack_weights(const RawPtrs& raw, float* packed, int* range_flag, hipStream_t s) {
   const int n = blob_floats(), first = vec_region_offset();
   hipLaunchKernelGGL(pack_weights_kernel, dim3((n - first + 255) / 256), dim3(256), 0, s, raw, packed, first, n);
-  unsigned short* bf = reinterpret_cast<unsigned short*>(packed + n);
-  hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((kBfHalfwords + 255) / 256), dim3(256), 0, s, raw, bf, kBfHalfwords);
+  unsigned short* planes = reinterpret_cast<unsigned short*>(packed + n);
+  hipLaunchKernelGGL(pack_weights_f16_kernel, dim3((kF16Halfwords + 255) / 256), dim3(256), 0, s, raw, planes, kF16Halfwords, range_flag);
   return hipGetLastError();
 }
 

@@ -5,7 +5,7 @@
 //   LinearAttention.forward    code1/attention/linear_attention.py:20-47
 //
 // One wavefront per ray, two sweeps over its SN/16 column tiles, everything in registers; the dense
-// layers run split-precision on the bf16 matrix cores (ufr_layout_bf.h), the tiny per-head KV / message
+// layers run split-precision on the fp16 matrix cores (ufr_layout_f16.h), the tiny per-head KV / message
 // products (K = 16 tokens / 16 head dims) stay on the fp32 MFMA:
 //  sweep 1: K^T, V^T tiles ([token][head dim], obtained by swapping the MFMA operands), then
 //           KV_h += K'_h^T V_h as 4 MFMAs per head; a ones column appended to V makes
@@ -15,7 +15,7 @@
 // Each head occupies its own 16-row tile (11 real rows) so that head boundaries coincide with MFMA
 // tiles; the 88-wide activations use the "nat88" layout of ufr_layout.h.
 #include "ufr_internal.h"
-#include "weight_stream_bf.h"
+#include "weight_stream_f16.h"
 
 namespace ufr {
 
@@ -37,7 +37,7 @@ __device__ __forceinline__ void load_ray_tile(const float* __restrict__ token0, 
 
 // LayerNorm over 88 features in nat88 layout (tile 5: registers 0,1 real)
 template <int VW, int VB>
-__device__ __forceinline__ void layer_norm88(f32x4 (&tt)[kRtC][6], const WStreamBf& ws, int g) {
+__device__ __forceinline__ void layer_norm88(f32x4 (&tt)[kRtC][6], const WStreamF16& ws, int g) {
 #pragma unroll
   for (int c = 0; c < kRtC; ++c) {
     f32x4 (&t)[6] = tt[c];
@@ -66,7 +66,7 @@ __device__ __forceinline__ void layer_norm88(f32x4 (&tt)[kRtC][6], const WStream
 }
 
 // 256-thread workgroups = 4 rays (one wave each, one per SIMD), two workgroups per CU; the four waves
-// walk the weight streams B_RT1 / B_RT2 together through LDS (weight_stream_bf.h).
+// walk the weight streams B_RT1 / B_RT2 together through LDS (weight_stream_f16.h).
 #ifndef UFR_RT_BLOCK
 #define UFR_RT_BLOCK 256
 #define UFR_RT_MINW 2
@@ -81,8 +81,8 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
                                                                   float* __restrict__ srdf,
                                                                   float* __restrict__ ray_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  WStreamBf ws = wstream_bf_begin<kRtWaves>(packed, smem);
-  wstream_bf_prime<B_RT1, kRtWaves>(ws);
+  WStreamF16 ws = wstream_f16_begin<kRtWaves>(packed, smem);
+  wstream_f16_prime<B_RT1, kRtWaves>(ws);
   const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
   const int ray_raw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const bool valid = ray_raw < RN;           // no early exit: every wave meets every chunk barrier
@@ -121,17 +121,19 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
         bwords_to_bstep(cur, b);
         if constexpr (s < 2) {
           BWords<C> nxt;
-          gemm_bf_panel<M_RT_K, s, C, kRtWaves, true>(ws, b, kt, wrap, [&](auto ti) __attribute__((always_inline)) {
+          gemm_f16_panel<M_RT_K, s, C, kRtWaves, true>(ws, b, kt, wrap, [&](auto ti) __attribute__((always_inline)) {
             constexpr int to = decltype(ti)::value;
             split_units<s + 1, to * 4 * C / 8, (to + 1) * 4 * C / 8>(x, nxt);
           });
-          gemm_bf_panel<M_RT_V, s, C, kRtWaves, true>(ws, b, vt, wrap);
+          gemm_f16_panel<M_RT_V, s, C, kRtWaves, true>(ws, b, vt, wrap);
           cur = nxt;
         } else {
-          gemm_bf_panel<M_RT_K, s, C, kRtWaves, true>(ws, b, kt, wrap);
-          gemm_bf_panel<M_RT_V, s, C, kRtWaves, true>(ws, b, vt, wrap);
+          gemm_f16_panel<M_RT_K, s, C, kRtWaves, true>(ws, b, kt, wrap);
+          gemm_f16_panel<M_RT_V, s, C, kRtWaves, true>(ws, b, vt, wrap);
         }
       });
+      descale_tiles(kt);
+      descale_tiles(vt);
     }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -146,11 +148,11 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
         }
       }
     }
-    wstream_bf_finish<B_RT1, kRtWaves>(ws, wrap);
+    wstream_f16_finish<B_RT1, kRtWaves>(ws, wrap);
   }
 
   // ---------------- sweep 2 (slot 0 is free: every wave passed the barrier that opened sweep 1's last chunk)
-  wstream_bf_prime<B_RT2, kRtWaves>(ws);
+  wstream_f16_prime<B_RT2, kRtWaves>(ws);
   for (int it = 0; it < n_iter; ++it) {
     const bool wrap = it + 1 < n_iter;
     f32x4 x[C][6], q[C][8], msg[C][8];
@@ -165,7 +167,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
 #pragma unroll
       for (int h = 0; h < 8; ++h) q[c][h] = splat4(0.f);
     }
-    gemm_bf<M_RT_Q, C, kRtWaves>(ws, x, q, wrap);  // q[h]: rows = head dims 4g+r, column j = token
+    gemm_f16<M_RT_Q, C, kRtWaves>(ws, x, q, wrap);  // q[h]: rows = head dims 4g+r, column j = token
 #pragma unroll
     for (int c = 0; c < C; ++c) {
 #pragma unroll
@@ -186,7 +188,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int t = 0; t < 6; ++t) m[c][t] = splat4(0.f);
-    gemm_bf<M_RT_MERGE, C, kRtWaves>(ws, msg, m, wrap);
+    gemm_f16<M_RT_MERGE, C, kRtWaves>(ws, msg, m, wrap);
     layer_norm88<V_RT_N1W, V_RT_N1B>(m, ws, g);
 
     f32x4 cat[C][12], hid[C][11], o[C][6];
@@ -197,7 +199,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
 #pragma unroll
       for (int t = 0; t < 11; ++t) hid[c][t] = splat4(0.f);
     }
-    gemm_bf<M_RT_MLP0, C, kRtWaves>(ws, cat, hid, wrap);
+    gemm_f16<M_RT_MLP0, C, kRtWaves>(ws, cat, hid, wrap);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
 #pragma unroll
@@ -207,7 +209,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
 #pragma unroll
       for (int t = 0; t < 6; ++t) o[c][t] = splat4(0.f);
     }
-    gemm_bf<M_RT_MLP2, C, kRtWaves>(ws, hid, o, wrap);
+    gemm_f16<M_RT_MLP2, C, kRtWaves>(ws, hid, o, wrap);
     layer_norm88<V_RT_N2W, V_RT_N2B>(o, ws, g);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -226,28 +228,28 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
     f32x4 d1[C][2], d2[C][1], d3[C][1];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      d1[c][0] = vec_frag<V_DM_B0>(ws, 0, g);
-      d1[c][1] = vec_frag<V_DM_B0>(ws, 1, g);
-      d2[c][0] = vec_frag<V_DM_B2>(ws, 0, g);
-      d3[c][0] = vec_frag<V_DM_B4>(ws, 0, g);
+      d1[c][0] = vec_frag<V_DM_B0>(ws, 0, g) * kAccScale;   // biases enter the scaled accumulators (weight_stream_f16.h)
+      d1[c][1] = vec_frag<V_DM_B0>(ws, 1, g) * kAccScale;
+      d2[c][0] = vec_frag<V_DM_B2>(ws, 0, g) * kAccScale;
+      d3[c][0] = vec_frag<V_DM_B4>(ws, 0, g) * kAccScale;
     }
-    gemm_bf<M_DM0, C, kRtWaves>(ws, o, d1, wrap);
+    gemm_f16<M_DM0, C, kRtWaves>(ws, o, d1, wrap);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) d1[c][t][r] = fmaxf(d1[c][t][r], 0.f);
-    gemm_bf<M_DM2, C, kRtWaves>(ws, d1, d2, wrap);
+    gemm_f16<M_DM2, C, kRtWaves>(ws, d1, d2, wrap);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) d2[c][0][r] = fmaxf(d2[c][0][r], 0.f);
-    gemm_bf<M_DM4, C, kRtWaves>(ws, d2, d3, wrap);
+    gemm_f16<M_DM4, C, kRtWaves>(ws, d2, d3, wrap);
 #pragma unroll
     for (int c = 0; c < C; ++c)
       if (g == 0 && valid && live[c]) srdf[(size_t)ray * SN + tbase[c] + j] = d3[c][0][0];
-    wstream_bf_finish<B_RT2, kRtWaves>(ws, wrap);
+    wstream_f16_finish<B_RT2, kRtWaves>(ws, wrap);
   }
 }
 
@@ -260,11 +262,11 @@ hipError_t launch_ray_transformer(const float* packed, const float* token0, cons
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
   if (!attr_set[dev]) {
     const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ray_transformer_kernel),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, kBfLdsBytes);
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, kF16LdsBytes);
     if (attr != hipSuccess) return attr;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(ray_transformer_kernel, dim3((RN + kRtWaves - 1) / kRtWaves), dim3(kRtBlock), kBfLdsBytes, s,
+  hipLaunchKernelGGL(ray_transformer_kernel, dim3((RN + kRtWaves - 1) / kRtWaves), dim3(kRtBlock), kF16LdsBytes, s,
                      packed, token0, tok_row, order_pe, RN, SN, srdf, ray_out);
   return hipGetLastError();
 }

@@ -11,7 +11,7 @@
 
 #include "bwd_common.h"
 #include "ufr_internal.h"
-#include "ufr_layout_bf.h"
+#include "ufr_layout_f16.h"
 
 using namespace ufr;
 
@@ -109,13 +109,14 @@ int ufr_version(void) { return 100; }
 const char* ufr_last_error(void) { return g_err; }
 
 // ------------------------------------------------------------------ weights
-size_t ufr_packed_weights_bytes(void) { return (size_t)blob_floats() * sizeof(float) + (size_t)kBfBytes; }
+// [fp32 region | fp16 plane region | 16-byte tail: range flag written by ufr_weights_pack]
+size_t ufr_packed_weights_bytes(void) { return (size_t)blob_floats() * sizeof(float) + (size_t)kF16Bytes + 16; }
 size_t ufr_packed_fp32_floats(void) { return (size_t)blob_floats(); }
-size_t ufr_packed_bf16_halfwords(void) { return (size_t)kBfHalfwords; }
+size_t ufr_packed_f16_halfwords(void) { return (size_t)kF16Halfwords; }
 
-int ufr_pack_plan_bf16(int32_t* param_id, int32_t* elem, int32_t* plane) {
-  UFR_REQUIRE(param_id && elem && plane, "ufr_pack_plan_bf16: null output");
-  for (int h = 0; h < kBfHalfwords; ++h) plan_entry_bf(h, &param_id[h], &elem[h], &plane[h]);
+int ufr_pack_plan_f16(int32_t* param_id, int32_t* elem, int32_t* plane) {
+  UFR_REQUIRE(param_id && elem && plane, "ufr_pack_plan_f16: null output");
+  for (int h = 0; h < kF16Halfwords; ++h) plan_entry_f16(h, &param_id[h], &elem[h], &plane[h]);
   return UFR_OK;
 }
 
@@ -136,7 +137,16 @@ int ufr_weights_pack(const ufr_raw_weights* raw, void* packed, ufr_stream stream
   RawPtrs rp;
   memcpy(&rp, raw, sizeof(rp));
   for (int i = 0; i < P_COUNT; ++i) UFR_REQUIRE(rp.p[i], "ufr_weights_pack: parameter %d is null", i);
-  UFR_HIP(launch_pack_weights(rp, static_cast<float*>(packed), static_cast<hipStream_t>(stream)));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int* flag = reinterpret_cast<int*>(static_cast<char*>(packed) + (size_t)blob_floats() * sizeof(float) + (size_t)kF16Bytes);
+  UFR_HIP(hipMemsetAsync(flag, 0, 16, s));
+  UFR_HIP(launch_pack_weights(rp, static_cast<float*>(packed), flag, s));
+  // the fp16 planes hold 2^8 w: a weight beyond +-255.8 (or a non-finite one) cannot be represented -- fail here, loudly,
+  // rather than render with it
+  int host_flag = 0;
+  UFR_HIP(hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  UFR_HIP(hipStreamSynchronize(s));
+  UFR_REQUIRE(host_flag == 0, "ufr_weights_pack: a dense-layer weight is not finite or exceeds the supported magnitude (|w| < 255.8)");
   return UFR_OK;
 }
 

@@ -6,14 +6,14 @@
 //
 // MI355X mapping: tokens are the 16 MFMA columns; a wave owns C column tiles (PPT = 16/L points each,
 // L = NV+1 tokens per point).  Activations never leave registers: the fp32 accumulator tiles of a
-// layer, split exactly into three bf16 planes, are the B operands of the next layer's
-// v_mfma_f32_16x16x32_bf16 ("bf16x6": six plane pairs per product, fp32-grade accuracy on the bf16
-// matrix cores -- ufr_layout_bf.h); the weight planes stream through LDS (weight_stream_bf.h).  Q/K/V
+// layer, split into two fp16 planes, are the B operands of the next layer's
+// v_mfma_f32_16x16x32_f16 ("fp16x3": three plane pairs per product, fp32-grade accuracy on the 16-bit
+// matrix cores -- ufr_layout_f16.h); the weight planes stream through LDS (weight_stream_f16.h).  Q/K/V
 // rows are permuted so lane group g holds heads 2g,2g+1 of its token, and the L-token attention is
 // lane-local with quad DPP exchanges (L = 4) or ds_bpermute (other L).  LayerNorm, attention, elu and
 // the softmax run on the VALU and overlap with the other resident wave's MFMAs.
 #include "ufr_internal.h"
-#include "weight_stream_bf.h"
+#include "weight_stream_f16.h"
 
 namespace ufr {
 
@@ -27,7 +27,7 @@ __device__ __forceinline__ void zero_tiles(f32x4 (&t)[C][N]) {
 
 // LayerNorm over the 80 features of each token: 5 tiles x 4 regs in each of the 4 lane groups.
 template <int C, int VW, int VB>
-__device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const WStreamBf& ws, int g) {
+__device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const WStreamF16& ws, int g) {
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     float s = 0.f;
@@ -88,8 +88,8 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
   constexpr int PPT = 16 / L;          // points per column tile
   constexpr int PPW = PPT * C;         // points per wave iteration
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  WStreamBf ws = wstream_bf_begin<kVtWaves>(packed, smem);
-  wstream_bf_prime<B_VT, kVtWaves>(ws);
+  WStreamF16 ws = wstream_f16_begin<kVtWaves>(packed, smem);
+  wstream_f16_prime<B_VT, kVtWaves>(ws);
   const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
   const int pt_in_tile = j / L, tv = j % L;         // token tv of point pt_in_tile (tv == 0: view token)
   const bool col_ok = j < PPT * L;
@@ -165,17 +165,19 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
         bwords_to_bstep(cur, b);
         if constexpr (s < 2) {       // the next step's split rides on the q panel's MFMAs
           BWords<C> nxt;
-          gemm_bf_panel<M_VT_Q, s, C, kVtWaves, false>(ws, b, q, wrap, [&](auto ti) __attribute__((always_inline)) {
+          gemm_f16_panel<M_VT_Q, s, C, kVtWaves, false>(ws, b, q, wrap, [&](auto ti) __attribute__((always_inline)) {
             constexpr int to = decltype(ti)::value;
             split_units<s + 1, to * 4 * C / 5, (to + 1) * 4 * C / 5>(x, nxt);
           });
-          gemm_bf_panel<M_VT_K, s, C, kVtWaves>(ws, b, k, wrap);
+          gemm_f16_panel<M_VT_K, s, C, kVtWaves>(ws, b, k, wrap);
           cur = nxt;
         } else {
-          gemm_bf_panel<M_VT_Q, s, C, kVtWaves>(ws, b, q, wrap);
-          gemm_bf_panel<M_VT_K, s, C, kVtWaves>(ws, b, k, wrap);
+          gemm_f16_panel<M_VT_Q, s, C, kVtWaves>(ws, b, q, wrap);
+          gemm_f16_panel<M_VT_K, s, C, kVtWaves>(ws, b, k, wrap);
         }
       });
+      descale_tiles(q);
+      descale_tiles(k);
     }
     UFR_PHASE(1)  // q,k GEMMs
     // ---------------- linear attention over the L tokens of each point (linear_attention.py:31-45), written as
@@ -210,7 +212,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     UFR_PHASE(2)  // scores
     f32x4 v[C][5];
     zero_tiles(v);
-    gemm_bf<M_VT_V, C, kVtWaves>(ws, x, v, wrap);
+    gemm_f16<M_VT_V, C, kVtWaves>(ws, x, v, wrap);
     UFR_PHASE(3)  // v GEMM
     f32x4 msg[C][5];
 #pragma unroll
@@ -244,7 +246,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     // ---------------- merge + LayerNorm1 (transformer.py:51-52)
     f32x4 m[C][5];
     zero_tiles(m);
-    gemm_bf<M_VT_MERGE, C, kVtWaves>(ws, msg, m, wrap);
+    gemm_f16<M_VT_MERGE, C, kVtWaves>(ws, msg, m, wrap);
     UFR_PHASE(5)  // merge GEMM
     layer_norm80<C, V_VT_N1W, V_VT_N1B>(m, ws, g);
 
@@ -256,7 +258,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
       for (int t = 0; t < 5; ++t) { cat[c][t] = x[c][t]; cat[c][5 + t] = m[c][t]; }
     zero_tiles(hid);
-    gemm_bf<M_VT_MLP0, C, kVtWaves>(ws, cat, hid, wrap);
+    gemm_f16<M_VT_MLP0, C, kVtWaves>(ws, cat, hid, wrap);
     UFR_PHASE(7)  // MLP0
 #pragma unroll
     for (int c = 0; c < C; ++c)
@@ -265,7 +267,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
         for (int r = 0; r < 4; ++r) hid[c][t][r] = fmaxf(hid[c][t][r], 0.f);
     zero_tiles(o);
-    gemm_bf<M_VT_MLP2, C, kVtWaves>(ws, hid, o, wrap);
+    gemm_f16<M_VT_MLP2, C, kVtWaves>(ws, hid, o, wrap);
     // colour / mask / direction of this lane's (point, view): (issued here: hid is dead, so the 10 registers are free, and LayerNorm2 + the token stores cover the latency)
     f32x4 col[C];
     float dcomp[C];
@@ -308,21 +310,21 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
       for (int t = 0; t < 5; ++t) rin[c][t] = o[c][t];
       rin[c][5] = f32x4{dcomp[c], 0.f, 0.f, 0.f};
-      h1[c][0] = vec_frag<V_RW_B0>(ws, 0, g);
-      h2[c][0] = vec_frag<V_RW_B2>(ws, 0, g);
-      lg[c][0] = vec_frag<V_RW_B4>(ws, 0, g);
+      h1[c][0] = vec_frag<V_RW_B0>(ws, 0, g) * kAccScale;   // biases enter the scaled accumulators (weight_stream_f16.h)
+      h2[c][0] = vec_frag<V_RW_B2>(ws, 0, g) * kAccScale;
+      lg[c][0] = vec_frag<V_RW_B4>(ws, 0, g) * kAccScale;
     }
-    gemm_bf<M_RW0, C, kVtWaves>(ws, rin, h1, wrap);
+    gemm_f16<M_RW0, C, kVtWaves>(ws, rin, h1, wrap);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) h1[c][0][r] = fmaxf(h1[c][0][r], 0.f);
-    gemm_bf<M_RW2, C, kVtWaves>(ws, h1, h2, wrap);
+    gemm_f16<M_RW2, C, kVtWaves>(ws, h1, h2, wrap);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) h2[c][0][r] = fmaxf(h2[c][0][r], 0.f);
-    gemm_bf<M_RW4, C, kVtWaves>(ws, h2, lg, wrap);
+    gemm_f16<M_RW4, C, kVtWaves>(ws, h2, lg, wrap);
 
     UFR_PHASE(10)  // radiance MLP
     // ---------------- masked softmax over the NV view tokens + colour blend (ray_transformer.py:315-319)
@@ -354,7 +356,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
         dst[2] = cb / den;
       }
     }
-    wstream_bf_finish<B_VT, kVtWaves>(ws, wrap);
+    wstream_f16_finish<B_VT, kVtWaves>(ws, wrap);
     UFR_PHASE(11)  // softmax blend
   }
 #ifdef UFR_PHASE_TIMING
@@ -407,11 +409,11 @@ static hipError_t launch_vt(const float* packed, const float* x_tokens, const fl
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
   if (!attr_set[dev]) {
     const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&view_transformer_kernel<L, C>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, kBfLdsBytes);
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, kF16LdsBytes);
     if (attr != hipSuccess) return attr;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((view_transformer_kernel<L, C>), dim3(blocks), dim3(kVtBlock), kBfLdsBytes, s, packed, x_tokens,
+  hipLaunchKernelGGL((view_transformer_kernel<L, C>), dim3(blocks), dim3(kVtBlock), kF16LdsBytes, s, packed, x_tokens,
                      rgb, dir, P, token0, radiance, view_out);
   return hipGetLastError();
 }

@@ -1,4 +1,4 @@
-// Shared pieces of the LDS weight streams (the streaming scheme itself: weight_stream_bf.h).
+// Shared pieces of the LDS weight streams (the streaming scheme itself: weight_stream_f16.h).
 //
 // Every wave of a workgroup walks the same static sequence of 1 KiB operand fragments.  Instead of each wave
 // pulling its own copy from L2 (measured: 81-84 % of the MFMA rate at 2 waves/SIMD because 256 CUs x 8 waves

@@ -40,8 +40,12 @@ constexpr int kPlanes = 2;
 // weights are packed as 2^kWScaleLog2 w (|w| < 255.8, checked at pack time), activations are split as 2^kXScaleLog2 x
 // (|x| < 4094); a layer's accumulator is therefore 2^(kWScaleLog2 + kXScaleLog2) times the true value and is
 // descaled once, exactly, after its last k-step.
-constexpr int kWScaleLog2 = 8, kXScaleLog2 = 4;
-constexpr float kWScale = 256.f, kXScale = 16.f, kAccDescale = 1.f / 4096.f, kAccScale = 4096.f;
+#ifndef UFR_X_SCALE_LOG2
+#define UFR_X_SCALE_LOG2 4
+#endif
+constexpr int kWScaleLog2 = 8, kXScaleLog2 = UFR_X_SCALE_LOG2;
+constexpr float kWScale = (float)(1 << kWScaleLog2), kXScale = (float)(1 << kXScaleLog2);
+constexpr float kAccScale = kWScale * kXScale, kAccDescale = 1.f / kAccScale;
 #ifndef UFR_F16_CHUNK
 #define UFR_F16_CHUNK 24
 #endif
@@ -54,6 +58,12 @@ constexpr int kF16ChunkFrags = UFR_F16_CHUNK;  // KiB per chunk: whole (tile, 2 
 // instructions, not exposed latency), and the extra 48 KiB of LDS per CU costs 5 % of whole-frame throughput
 // when the gather kernel of another chunk runs beside the transformers on side streams.
 constexpr int kF16Slots = UFR_F16_SLOTS;
+#ifndef UFR_F16_DEPTH
+#define UFR_F16_DEPTH 2
+#endif
+// stages (one out tile's plane fragments = 3 C MFMAs of cover) the LDS weight reads run ahead of their use
+constexpr int kF16Depth = UFR_F16_DEPTH;
+static_assert(kF16Depth >= 1 && kF16Depth * kPlanes <= kF16ChunkFrags, "read-ahead must stay inside one chunk");
 
 enum F16Stream { B_VT = 0, B_RT1 = 1, B_RT2 = 2, B_COUNT = 3 };
 

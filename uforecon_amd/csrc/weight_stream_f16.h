@@ -19,7 +19,8 @@ constexpr int kF16LdsBytes = kF16RingBytes + kVecBytes;
 // split of a value pair into fp16 planes of 2^kXScaleLog2 x: hi = fp16(x) 2^k (exact scaling; one v_cvt_pk_f16_f32 and one
 // v_pk_mul_f16), lo = fp16(2^k x - hi) (the difference is exact in fp32; one v_fma_mix per value): 4 VALU instructions
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& l) {
-  const f16x2 hh = __builtin_convertvector(f32x2{a, b}, f16x2) * f16x2{(_Float16)kXScale, (_Float16)kXScale};
+  f16x2 hh = __builtin_convertvector(f32x2{a, b}, f16x2);
+  if constexpr (kXScaleLog2 != 0) hh *= f16x2{(_Float16)kXScale, (_Float16)kXScale};
   const f16x2 ll = {(_Float16)__builtin_fmaf(a, kXScale, -(float)hh[0]), (_Float16)__builtin_fmaf(b, kXScale, -(float)hh[1])};
   h = __builtin_bit_cast(unsigned, hh);
   l = __builtin_bit_cast(unsigned, ll);
@@ -48,7 +49,7 @@ struct WStreamF16 {
   char* ring;          // LDS: two chunk slots
   const f32x4* vecs;   // LDS: vector fragments (fp32)
   int wave, lane;
-  f16x8 pre[kPlanes]; // planes of the next stage's fragment, read one stage ahead when the chunk allows
+  f16x8 pre[kF16Depth][kPlanes];  // plane fragments of the next kF16Depth stages, in flight from LDS (stage s in slot s % depth)
 };
 
 template <int NWAVES>
@@ -58,6 +59,10 @@ __device__ __forceinline__ WStreamF16 wstream_f16_begin(const float* __restrict_
   ws.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   ws.src = reinterpret_cast<const char*>(packed) + (size_t)blob_floats() * 4;
   ws.ring = smem;
+#ifdef UFR_ABL_NOLDS
+  for (int d = 0; d < kF16Depth; ++d)
+    for (int p = 0; p < kPlanes; ++p) ws.pre[d][p] = __builtin_bit_cast(f16x8, u32x4{0x3c003c00u + ws.lane, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u});
+#endif
   f32x4* v = reinterpret_cast<f32x4*>(smem + kF16RingBytes);
   ws.vecs = v;
   constexpr int voff = vec_region_offset(), n4 = vec_region_floats() / 4;
@@ -70,26 +75,30 @@ __device__ __forceinline__ WStreamF16 wstream_f16_begin(const float* __restrict_
   return ws;
 }
 
-// fetch chunk CHK of stream S into its ring slot: this wave's share of the fragments
-template <int S, int NWAVES, int CHK>
+// fetch pieces [P0, P1) of this wave's share of chunk CHK of stream S into the chunk's ring slot (a piece = one
+// 1 KiB LDS-DMA wave instruction; the wave's share is every NWAVES-th fragment)
+template <int S, int NWAVES, int CHK, int P0 = 0, int P1 = kF16ChunkFrags / NWAVES>
 __device__ __forceinline__ void wstream_f16_fetch(const WStreamF16& ws) {
   static_assert(kF16ChunkFrags % NWAVES == 0, "chunk must split evenly over the fetching waves");
-  constexpr size_t goff = ((size_t)f16_stream_base_frags(S) + (size_t)CHK * kF16ChunkFrags) * 1024;
-  constexpr int soff = (CHK % kF16Slots) * (kF16ChunkFrags * 1024);
-  int zero = 0;
-  asm volatile("" : "+s"(zero));  // keep the loop-invariant source address out of LICM's hands
-  const char* g = ws.src + zero + goff + ws.wave * 1024;   // wave-uniform: scalar base + 32-bit lane offset
-  char* slot = ws.ring + soff + ws.wave * 1024;
-  const unsigned lane_off = ws.lane * 16;
+  if constexpr (P1 > P0) {
+    constexpr size_t goff = ((size_t)f16_stream_base_frags(S) + (size_t)CHK * kF16ChunkFrags) * 1024;
+    constexpr int soff = (CHK % kF16Slots) * (kF16ChunkFrags * 1024);
+    int zero = 0;
+    asm volatile("" : "+s"(zero));  // keep the loop-invariant source address out of LICM's hands
+    const char* g = ws.src + zero + goff + ws.wave * 1024;   // wave-uniform: scalar base + 32-bit lane offset
+    char* slot = ws.ring + soff + ws.wave * 1024;
+    const unsigned lane_off = ws.lane * 16;
 #pragma unroll
-  for (int k = 0; k < kF16ChunkFrags / NWAVES; ++k)
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(g + k * NWAVES * 1024 + lane_off), (lds_ptr_t)(slot + k * NWAVES * 1024), 16, 0, 0);
+    for (int k = P0; k < P1; ++k)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(g + k * NWAVES * 1024 + lane_off), (lds_ptr_t)(slot + k * NWAVES * 1024), 16, 0, 0);
+  }
 }
 
-// open chunk CHK: the ring keeps kF16Slots-1 chunks in flight, so at most the (kF16Slots-2) younger fetches
-// of this wave may still be outstanding when chunk CHK must have landed
+// hand-off barrier of chunk CHK: its fragments have landed and every wave is done with the chunk before it.
+// The ring keeps kF16Slots-1 chunks in flight, so at most the (kF16Slots-2) younger fetches of this wave may still
+// be outstanding when chunk CHK must have landed.
 template <int S, int NWAVES, int CHK>
-__device__ __forceinline__ void wstream_f16_open(const WStreamF16& ws, bool wrap) {
+__device__ __forceinline__ void wstream_f16_barrier(const WStreamF16& ws, bool wrap) {
 #ifdef UFR_ABL_NOBARRIER  // ablation builds (timing only, results are garbage): no hand-off at all / barrier without fetch
   (void)ws; (void)wrap;
   return;
@@ -100,20 +109,40 @@ __device__ __forceinline__ void wstream_f16_open(const WStreamF16& ws, bool wrap
 #endif
   constexpr int per_chunk = kF16ChunkFrags / NWAVES, ahead = kF16Slots - 1, n_chunks = f16_stream_chunks(S);
   constexpr int younger = (kF16Slots - 2) * per_chunk;
+  // lgkmcnt(0): this wave's reads of the chunk whose slot is refilled next have returned (the stages are read
+  // kF16Depth ahead, across the chunk boundary: the previous chunk's last stages now live in registers)
   if constexpr (younger == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   } else if constexpr (CHK + ahead <= n_chunks) {          // every younger fetch was issued unconditionally
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(younger) : "memory");
   } else {                                                 // the younger fetches were wrap-around ones
-    if (wrap) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wrap) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(younger) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
   __syncthreads();
+}
+
+// after the barrier of chunk CHK the slot of chunk CHK-1 is free: pieces [P0, P1) of the refill (chunk CHK + ring
+// depth - 1, or its wrap-around into the next pass).  The pieces of one refill are spread over the stages of chunk
+// CHK: an LDS-DMA instruction stalls its wave for 60..185 cycles (MI355X_MICROARCH.md), several in a row for longer.
+template <int S, int NWAVES, int CHK, int P0 = 0, int P1 = kF16ChunkFrags / NWAVES>
+__device__ __forceinline__ void wstream_f16_refill(const WStreamF16& ws, bool wrap) {
+#if defined(UFR_ABL_NOBARRIER) || defined(UFR_ABL_NODMA)
+  (void)ws; (void)wrap;
+  return;
+#endif
+  constexpr int ahead = kF16Slots - 1, n_chunks = f16_stream_chunks(S);
   if constexpr (CHK + ahead < n_chunks) {
-    wstream_f16_fetch<S, NWAVES, CHK + ahead>(ws);
+    wstream_f16_fetch<S, NWAVES, CHK + ahead, P0, P1>(ws);
   } else {
-    if (wrap) wstream_f16_fetch<S, NWAVES, (CHK + ahead) % n_chunks>(ws);
+    if (wrap) wstream_f16_fetch<S, NWAVES, (CHK + ahead) % n_chunks, P0, P1>(ws);
   }
+}
+
+template <int S, int NWAVES, int CHK>
+__device__ __forceinline__ void wstream_f16_open(const WStreamF16& ws, bool wrap) {
+  wstream_f16_barrier<S, NWAVES, CHK>(ws, wrap);
+  wstream_f16_refill<S, NWAVES, CHK>(ws, wrap);
 }
 
 // end of a pass over stream S: open its padding chunks (none for most streams) so the wrap-around fetches go out
@@ -150,6 +179,9 @@ __device__ __forceinline__ f32x4 mfma_f16(const f16x8& a, const f16x8& b, const 
 #define UFR_HOOK_VALU 2   // VALU instructions of the hook issued after each MFMA
 #endif
 constexpr int kProducts = 3;   // MFMAs per fp32 product
+#ifndef UFR_F16_SPREAD
+#define UFR_F16_SPREAD 1       // 1: a chunk's refill pieces are spread over its stages; 0: all right after the barrier
+#endif
 struct NoHook {
   template <class T> __device__ __forceinline__ void operator()(T) const {}
 };
@@ -163,22 +195,32 @@ __device__ __forceinline__ void gemm_f16_panel(WStreamF16& ws, const BStep (&b)[
   static_for<n_out>([&](auto ti) __attribute__((always_inline)) {
     constexpr int to = decltype(ti)::value;
     constexpr int f = F0 + to * kPlanes;                 // first of the stage's plane fragments
-    constexpr int chk = f / kF16ChunkFrags, in_chk = f % kF16ChunkFrags;
-    constexpr int base = ((chk % kF16Slots) * kF16ChunkFrags + in_chk) * 64;
+    constexpr int sidx = f / kPlanes, n_stages = f16_stream_frags(ST) / kPlanes;
     __builtin_amdgcn_sched_barrier(0);
+    // stage s of the pass is read from LDS while stage s - kF16Depth computes; a chunk is opened (hand-off barrier)
+    // right before its first stage is read, i.e. kF16Depth stages before it is needed
+    auto read_stage = [&](auto si) __attribute__((always_inline)) {
+      constexpr int s2 = decltype(si)::value, f2 = s2 * kPlanes;
+      constexpr int chk = f2 / kF16ChunkFrags, in_chk = f2 % kF16ChunkFrags;
+      constexpr int base = ((chk % kF16Slots) * kF16ChunkFrags + in_chk) * 64;
+      // the chunk's barrier before its first stage is read; the refill it allows goes out piecewise with the stages
+      constexpr int in_frags = f16_stream_frags(ST) - chk * kF16ChunkFrags;
+      constexpr int n_st = (in_frags < kF16ChunkFrags ? in_frags : kF16ChunkFrags) / kPlanes, j = in_chk / kPlanes;
+      constexpr int pieces = kF16ChunkFrags / NWAVES;
+      if constexpr (in_chk == 0) wstream_f16_barrier<ST, NWAVES, chk>(ws, wrap);
+      wstream_f16_refill<ST, NWAVES, chk, UFR_F16_SPREAD ? j * pieces / n_st : (j == 0 ? 0 : pieces),
+                         UFR_F16_SPREAD ? (j + 1) * pieces / n_st : pieces>(ws, wrap);
+#ifndef UFR_ABL_NOLDS   // ablation (timing only): the weight fragments are never read from LDS
+#pragma unroll
+      for (int p = 0; p < kPlanes; ++p) ws.pre[s2 % kF16Depth][p] = lds[base + p * 64];
+#endif
+    };
+    if constexpr (sidx == 0)                             // start of a pass: nothing is in flight yet
+      static_for<kF16Depth>([&](auto di) __attribute__((always_inline)) { read_stage(di); });
     f16x8 a[kPlanes];
-    if constexpr (in_chk == 0) {                         // chunk boundary: hand-off, then read this stage now
-      wstream_f16_open<ST, NWAVES, chk>(ws, wrap);
 #pragma unroll
-      for (int p = 0; p < kPlanes; ++p) a[p] = lds[base + p * 64];
-    } else {
-#pragma unroll
-      for (int p = 0; p < kPlanes; ++p) a[p] = ws.pre[p];
-    }
-    if constexpr (in_chk + kPlanes < kF16ChunkFrags && f + kPlanes < f16_stream_frags(ST)) {  // next stage lies in the open chunk
-#pragma unroll
-      for (int p = 0; p < kPlanes; ++p) ws.pre[p] = lds[base + (kPlanes + p) * 64];
-    }
+    for (int p = 0; p < kPlanes; ++p) a[p] = ws.pre[sidx % kF16Depth][p];
+    if constexpr (sidx + kF16Depth < n_stages) read_stage(std::integral_constant<int, sidx + kF16Depth>{});
     __builtin_amdgcn_sched_barrier(0);
     hook(ti);
     // three plane pairs (lo.lo is dropped), small terms first (0 = hi, 1 = lo); SWAP: activations in the A slot

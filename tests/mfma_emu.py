@@ -200,8 +200,8 @@ def f16_streams():
     return [vt, rt1, rt2]
 
 
-F16_CHUNK = 24  # fragments per LDS chunk (kF16ChunkFrags)
-F16_SLOTS = 2   # LDS ring depth (kF16Slots): streams are padded to whole rings
+F16_CHUNK = 12  # fragments per LDS chunk (kF16ChunkFrags)
+F16_SLOTS = 3   # LDS ring depth (kF16Slots): streams are padded to whole rings
 
 
 def _stream_len(panels):

@@ -42,7 +42,7 @@ def test_struct_sizes_match_the_header(lib):
     assert C.sizeof(_lib.Frame) == 160 * 8
     assert lib.ufr_packed_fp32_floats() == E.vec_region_offset() + 16 * (5 * 4 + 6 * 4 + 2 + 5 + 5)
     assert lib.ufr_packed_weights_bytes() == 4 * lib.ufr_packed_fp32_floats() + 2 * lib.ufr_packed_f16_halfwords() + 16  # + flag tail
-    assert lib.ufr_packed_f16_halfwords() % (24 * 512) == 0  # whole 24 KiB chunks
+    assert lib.ufr_packed_f16_halfwords() % (12 * 512) == 0  # whole 12 KiB chunks
 
 
 def test_argument_errors_are_reported_not_fatal(lib):

@@ -47,16 +47,16 @@ constexpr int kWScaleLog2 = 8, kXScaleLog2 = UFR_X_SCALE_LOG2;
 constexpr float kWScale = (float)(1 << kWScaleLog2), kXScale = (float)(1 << kXScaleLog2);
 constexpr float kAccScale = kWScale * kXScale, kAccDescale = 1.f / kAccScale;
 #ifndef UFR_F16_CHUNK
-#define UFR_F16_CHUNK 24
+#define UFR_F16_CHUNK 12
 #endif
 constexpr int kF16ChunkFrags = UFR_F16_CHUNK;  // KiB per chunk: whole (tile, 2 planes) pairs; splits evenly over the 4 fetching waves
 #ifndef UFR_F16_SLOTS
-#define UFR_F16_SLOTS 2
+#define UFR_F16_SLOTS 3
 #endif
-// LDS ring depth: kF16Slots-1 chunks in flight.  Measured: a third slot changes neither kernel alone (the 11 % /
-// 21 % the no-DMA ablation recovers for the view / ray transformer is the issue cost of the LDS-DMA
-// instructions, not exposed latency), and the extra 48 KiB of LDS per CU costs 5 % of whole-frame throughput
-// when the gather kernel of another chunk runs beside the transformers on side streams.
+// LDS ring depth: kF16Slots-1 chunks in flight.  Measured with the fp16x3 kernels (tools/dev/ab_kernels.sh, 4 rounds):
+// 3 x 12 KiB runs the view / ray transformer 4.5 % / 2 % faster than 2 x 24 KiB and needs 12 KiB less LDS per
+// workgroup (which the gather kernels of other chunks use when they share the CU); 4 x 12, 6 x 8 and 12 x 4 KiB are
+// no better.
 constexpr int kF16Slots = UFR_F16_SLOTS;
 #ifndef UFR_F16_DEPTH
 #define UFR_F16_DEPTH 2

@@ -47,6 +47,7 @@ __device__ __forceinline__ BStep make_bstep(const f32x4& ta, const f32x4& tb) {
 struct WStreamF16 {
   const char* src;     // fp16 plane region of the packed blob (global, wave-uniform)
   char* ring;          // LDS: two chunk slots
+  unsigned ring_lds;   // ... as an LDS byte address (scalar)
   const f32x4* vecs;   // LDS: vector fragments (fp32)
   int wave, lane;
   f16x8 pre[kF16Depth][kPlanes];  // plane fragments of the next kF16Depth stages, in flight from LDS (stage s in slot s % depth)
@@ -59,6 +60,7 @@ __device__ __forceinline__ WStreamF16 wstream_f16_begin(const float* __restrict_
   ws.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   ws.src = reinterpret_cast<const char*>(packed) + (size_t)blob_floats() * 4;
   ws.ring = smem;
+  ws.ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem);
 #ifdef UFR_ABL_NOLDS
   for (int d = 0; d < kF16Depth; ++d)
     for (int p = 0; p < kPlanes; ++p) ws.pre[d][p] = __builtin_bit_cast(f16x8, u32x4{0x3c003c00u + ws.lane, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u});
@@ -75,6 +77,16 @@ __device__ __forceinline__ WStreamF16 wstream_f16_begin(const float* __restrict_
   return ws;
 }
 
+// One LDS-DMA piece: 64 lanes x 16 bytes from g_uniform + lane_off (scalar base, 32-bit lane offset: no address
+// VALU) to LDS address lds_addr + 16 lane.  Issued as inline assembly ON PURPOSE: with the compiler-visible
+// __builtin_amdgcn_global_load_lds in the loop, hipcc's s_waitcnt insertion gives up counting LDS reads and drains
+// lgkmcnt to 0 before every use of a weight fragment -- the read-ahead was worth nothing and the kernels ran
+// 15..22 % slower (the "no DMA" ablation).  Untracked vector-memory operations only make the compiler's own
+// vmcnt(N) waits conservative (loads return in order); the hand-off barrier waits for the pieces explicitly.
+__device__ __forceinline__ void lds_dma_16(const char* g_uniform, unsigned lane_off, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(g_uniform), "v"(lane_off), "s"(lds_addr) : "memory");
+}
+
 // fetch pieces [P0, P1) of this wave's share of chunk CHK of stream S into the chunk's ring slot (a piece = one
 // 1 KiB LDS-DMA wave instruction; the wave's share is every NWAVES-th fragment)
 template <int S, int NWAVES, int CHK, int P0 = 0, int P1 = kF16ChunkFrags / NWAVES>
@@ -86,11 +98,9 @@ __device__ __forceinline__ void wstream_f16_fetch(const WStreamF16& ws) {
     int zero = 0;
     asm volatile("" : "+s"(zero));  // keep the loop-invariant source address out of LICM's hands
     const char* g = ws.src + zero + goff + ws.wave * 1024;   // wave-uniform: scalar base + 32-bit lane offset
-    char* slot = ws.ring + soff + ws.wave * 1024;
     const unsigned lane_off = ws.lane * 16;
 #pragma unroll
-    for (int k = P0; k < P1; ++k)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(g + k * NWAVES * 1024 + lane_off), (lds_ptr_t)(slot + k * NWAVES * 1024), 16, 0, 0);
+    for (int k = P0; k < P1; ++k) lds_dma_16(g + k * NWAVES * 1024, lane_off, ws.ring_lds + soff + ws.wave * 1024 + k * NWAVES * 1024);
   }
 }
 

@@ -43,6 +43,62 @@ __device__ __forceinline__ float rot(float x, const int (&src)[8]) {
   }
 }
 
+// L = 4 (three source views): the exchange rides on the FMA itself as a quad-permute DPP operand.  hipcc leaves a
+// v_mov_b32_dpp in front of every such FMA (270 extra VALU instructions per view-transformer iteration), hence the
+// assembly.  One block = ten FMAs behind one s_nop: a DPP read needs two wait states after a VALU write of the same
+// register, the hazard recogniser does not look inside inline assembly, and nothing inside a block writes a register
+// the block permutes.  Same fused multiply-adds in the same order as the C++ form: bit-identical results.
+// sum_d Q[d] * (K[d] held by the lane of token (tv + S) % 4 of the same point)
+template <int S>
+__device__ __forceinline__ float dot10_rot4(const float (&Q)[10], const float (&K)[10]) {
+  static_assert(S >= 1 && S <= 3, "token offset");
+  float a = 0.f;
+#define UFR_DOT10_CASE(PERM)                                                                                          \
+  asm("s_nop 1\n\t"                                                                                                   \
+      "v_fmac_f32_dpp %0, %11, %1 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                      \
+      "v_fmac_f32_dpp %0, %12, %2 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                      \
+      "v_fmac_f32_dpp %0, %13, %3 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                      \
+      "v_fmac_f32_dpp %0, %14, %4 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                      \
+      "v_fmac_f32_dpp %0, %15, %5 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                      \
+      "v_fmac_f32_dpp %0, %16, %6 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                      \
+      "v_fmac_f32_dpp %0, %17, %7 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                      \
+      "v_fmac_f32_dpp %0, %18, %8 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                      \
+      "v_fmac_f32_dpp %0, %19, %9 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                      \
+      "v_fmac_f32_dpp %0, %20, %10 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1"                         \
+      : "+v"(a)                                                                                                       \
+      : "v"(Q[0]), "v"(Q[1]), "v"(Q[2]), "v"(Q[3]), "v"(Q[4]), "v"(Q[5]), "v"(Q[6]), "v"(Q[7]), "v"(Q[8]), "v"(Q[9]),   \
+        "v"(K[0]), "v"(K[1]), "v"(K[2]), "v"(K[3]), "v"(K[4]), "v"(K[5]), "v"(K[6]), "v"(K[7]), "v"(K[8]), "v"(K[9]))
+  if constexpr (S == 1) UFR_DOT10_CASE("[1,2,3,0]");
+  if constexpr (S == 2) UFR_DOT10_CASE("[2,3,0,1]");
+  if constexpr (S == 3) UFR_DOT10_CASE("[3,0,1,2]");
+#undef UFR_DOT10_CASE
+  return a;
+}
+// acc[d] += w * (V[d] held by the lane of token (tv + S) % 4 of the same point)
+template <int S>
+__device__ __forceinline__ void axpy10_rot4(float (&acc)[10], float w, const float (&V)[10]) {
+  static_assert(S >= 1 && S <= 3, "token offset");
+#define UFR_AXPY10_CASE(PERM)                                                                                         \
+  asm("s_nop 1\n\t"                                                                                                   \
+      "v_fmac_f32_dpp %0, %11, %10 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                     \
+      "v_fmac_f32_dpp %1, %12, %10 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                     \
+      "v_fmac_f32_dpp %2, %13, %10 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                     \
+      "v_fmac_f32_dpp %3, %14, %10 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                     \
+      "v_fmac_f32_dpp %4, %15, %10 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                     \
+      "v_fmac_f32_dpp %5, %16, %10 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                     \
+      "v_fmac_f32_dpp %6, %17, %10 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                     \
+      "v_fmac_f32_dpp %7, %18, %10 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                     \
+      "v_fmac_f32_dpp %8, %19, %10 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                     \
+      "v_fmac_f32_dpp %9, %20, %10 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1"                         \
+      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), \
+        "+v"(acc[8]), "+v"(acc[9])                                                                                    \
+      : "v"(w), "v"(V[0]), "v"(V[1]), "v"(V[2]), "v"(V[3]), "v"(V[4]), "v"(V[5]), "v"(V[6]), "v"(V[7]), "v"(V[8]), "v"(V[9]))
+  if constexpr (S == 1) UFR_AXPY10_CASE("[1,2,3,0]");
+  if constexpr (S == 2) UFR_AXPY10_CASE("[2,3,0,1]");
+  if constexpr (S == 3) UFR_AXPY10_CASE("[3,0,1,2]");
+#undef UFR_AXPY10_CASE
+}
+
 // elu(x)+1 (linear_attention.py:10-11).  The negative branch is exp(x) in (0,1]: v_exp_f32 on
 // x*log2(e) (rel. error ~|x| 2^-24, i.e. < 1e-6 for the |x| < 16 that matter) instead of the
 // 15-instruction ocml expf -- 80 of them per view-transformer iteration.

@@ -199,7 +199,11 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #define UFR_ATT_STEP(S)                                                  \
         if (S < L) {                                                     \
           float a = 0.f;                                                 \
-          _Pragma("unroll") for (int d = 0; d < 10; ++d) a = fmaf(Q[d], rot<L, S>(K[d], src), a); \
+          if constexpr (L == 4 && S >= 1 && S <= 3) {                    \
+            a = dot10_rot4<(S >= 1 && S <= 3) ? S : 1>(Q, K);           \
+          } else {                                                       \
+            _Pragma("unroll") for (int d = 0; d < 10; ++d) a = fmaf(Q[d], rot<L, S>(K[d], src), a); \
+          }                                                              \
           den += a;                                                      \
           A[c][hh][S < L ? S : 0] = a;                                   \
         }
@@ -229,7 +233,11 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
         }
 #define UFR_ATT_STEP(S)                                                  \
         if (S < L) {                                                     \
-          _Pragma("unroll") for (int d = 0; d < 10; ++d) acc[d] = fmaf(A[c][hh][S < L ? S : 0], rot<L, S>(V[d], src), acc[d]); \
+          if constexpr (L == 4 && S >= 1 && S <= 3) {                    \
+            axpy10_rot4<(S >= 1 && S <= 3) ? S : 1>(acc, A[c][hh][S < L ? S : 0], V); \
+          } else {                                                       \
+            _Pragma("unroll") for (int d = 0; d < 10; ++d) acc[d] = fmaf(A[c][hh][S < L ? S : 0], rot<L, S>(V[d], src), acc[d]); \
+          }                                                              \
         }
         UFR_ATT_STEP(0) UFR_ATT_STEP(1) UFR_ATT_STEP(2) UFR_ATT_STEP(3)
         UFR_ATT_STEP(4) UFR_ATT_STEP(5) UFR_ATT_STEP(6) UFR_ATT_STEP(7)

@@ -244,6 +244,10 @@ def main():
         vt_ms = vt["ms"] / max(vt["launches"], 1)
         vt_flop = VIEWT_FLOP_PER_POINT.get(a.views, 0) * vt_pts_per_launch
         achieved = vt_flop / (vt_ms * 1e-3) / 1e12 if vt_ms > 0 else 0.0
+        rt = prof.get("ray_transformer", dict(ms=0.0, launches=1))
+        rt_ms = rt["ms"] / max(rt["launches"], 1)
+        rt_flop = RAYT_FLOP_PER_POINT * (RN * ray_evals_per_ray * prof_steps) / max(rt["launches"], 1)
+        rt_achieved = rt_flop / (rt_ms * 1e-3) / 1e12 if rt_ms > 0 else 0.0
         traffic, traffic_src = None, None
         try:  # HBM bytes per view-transformer launch from the latest committed PMC pass (profiles/rN_pmc.json)
             import glob
@@ -282,6 +286,12 @@ def main():
                                      "the fp32 MFMA peak is 157.3 TFLOP/s (round 1-2 kernels issued 6 bf16 plane products: "
                                      "their peak basis was 419.4)",
                           frac_of_fp32_mfma_peak=achieved / PEAK_FP32_MFMA_TFLOPS,
+                          # the same achieved rate against the roof the round-1 / round-2 reviews priced this kernel on
+                          # (six bf16 plane products per fp32 product); the ray transformer on both bases beside it
+                          frac_on_bf16x6_basis=achieved / (PEAK_F16_MFMA_TFLOPS / 6.0),
+                          ray_transformer=dict(achieved=rt_achieved, frac=rt_achieved / PEAK_F32_VIA_F16X3_TFLOPS,
+                                               frac_on_bf16x6_basis=rt_achieved / (PEAK_F16_MFMA_TFLOPS / 6.0),
+                                               avg_launch_ms=rt_ms),
                           # 840 v_mfma_f32_16x16x32_f16 (16 384 flop each) per 8 points at NV = 3, K / row padding included
                           issued_f16_tflops=achieved * (840 * 16384 / 8) / VIEWT_FLOP_PER_POINT[3] if a.views == 3 else None),
         )

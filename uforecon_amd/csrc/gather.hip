@@ -21,7 +21,8 @@ namespace ufr {
 __device__ __forceinline__ f32x4 lerp_tap4(const float* __restrict__ base, int stride, const Tap2& t, int c) {
   f32x4 v[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) v[k] = t.o[k] >= 0 ? ld4(base + (size_t)t.o[k] * stride + c) : splat4(0.f);
+  for (int k = 0; k < 4; ++k)   // texel index < 2^24, row stride < 2^24: one 24-bit multiply
+    v[k] = t.o[k] >= 0 ? ld4(base + (__umul24((unsigned)t.o[k], (unsigned)stride) + (unsigned)c)) : splat4(0.f);
   f32x4 acc;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -140,8 +141,11 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, const float* __
     // relative direction (ray_transformer.py:185-191)
     float ax = px - f.ref_pos[0], ay = py - f.ref_pos[1], az = pz - f.ref_pos[2];
     float bx = px - f.cam_pos[v][0], by = py - f.cam_pos[v][1], bz = pz - f.cam_pos[v][2];
-    float na = sqrtf(ax * ax + ay * ay + az * az), nb = sqrtf(bx * bx + by * by + bz * bz);
-    if (active) st4(dir_out + ((size_t)pidx * NV + v) * 4, f32x4{ax / na - bx / nb, ay / na - by / nb, az / na - bz / nb, 0.f});
+    // unit vectors through one reciprocal each (v_rcp_f32, 1 ulp) instead of three IEEE divisions: the difference to the
+    // reference's x / |x| is a rounding of the last bit of a direction component
+    const float ra = __builtin_amdgcn_rcpf(sqrtf(ax * ax + ay * ay + az * az));
+    const float rb = __builtin_amdgcn_rcpf(sqrtf(bx * bx + by * by + bz * bz));
+    if (active) st4(dir_out + ((size_t)pidx * NV + v) * 4, f32x4{ax * ra - bx * rb, ay * ra - by * rb, az * ra - bz * rb, 0.f});
   }
 
   // ---- correlation frustums of view v (model.py:359-386); skipped when the caller supplies the blended lookup
@@ -211,8 +215,10 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, const float* __
     f32x4 fb = lerp_tap4(bb, f.match_ch, tb, 4 * c8);
     float na = fmaxf(sqrtf(fa[0] * fa[0] + fa[1] * fa[1] + fa[2] * fa[2] + fa[3] * fa[3]), 1e-8f);
     float nb = fmaxf(sqrtf(fb[0] * fb[0] + fb[1] * fb[1] + fb[2] * fb[2] + fb[3] * fb[3]), 1e-8f);
-    sh_sim[(ip * npair + q) * 8 + c8] = (fa[0] / na) * (fb[0] / nb) + (fa[1] / na) * (fb[1] / nb) +
-                                        (fa[2] / na) * (fb[2] / nb) + (fa[3] / na) * (fb[3] / nb);
+    // F.normalize(x) = x / max(|x|, eps) as x * (1 / max(|x|, eps)): two reciprocals instead of eight IEEE divisions
+    const float ra = __builtin_amdgcn_rcpf(na), rb = __builtin_amdgcn_rcpf(nb);
+    sh_sim[(ip * npair + q) * 8 + c8] = (fa[0] * ra) * (fb[0] * rb) + (fa[1] * ra) * (fb[1] * rb) +
+                                        (fa[2] * ra) * (fb[2] * rb) + (fa[3] * ra) * (fb[3] * rb);
   }
   __syncthreads();
 
@@ -230,11 +236,12 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, const float* __
     {
       float Wsum = own[24];                                                       // view 0 first, then 1..NV-1
       for (int n = 1; n < NV; ++n) Wsum += sh_vol[(p * (NV - 1) + n - 1) * 25 + 24];
+      const float rW = 1.f / (Wsum + 1e-8f);                                      // one division for the 24 channels
 #pragma unroll
       for (int c = 0; c < 24; ++c) {
         float G = own[c];
         for (int n = 1; n < NV; ++n) G += sh_vol[(p * (NV - 1) + n - 1) * 25 + c];
-        ov[c] = G / (Wsum + 1e-8f);                                               // model.py:388
+        ov[c] = G * rW;                                                           // model.py:388
         if (vol24_in) ov[c] = vol24_in[(size_t)pc * 24 + c];
       }
     }

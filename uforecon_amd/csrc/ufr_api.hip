@@ -157,12 +157,19 @@ static int frame_check(const ufr_frame_desc* d) {
   UFR_REQUIRE(d->H >= 8 && d->W >= 8 && d->H % 4 == 0 && d->W % 4 == 0, "H,W must be multiples of 4 (got %dx%d)",
               d->H, d->W);
   UFR_REQUIRE(d->source_imgs && d->depth_info && d->feat, "null frame tensor");
+  UFR_REQUIRE((long long)d->H * d->W < (1 << 24) && (long long)(d->H / 4) * (d->W / 4) * 32 * (d->NV - 1) < (1ll << 32),
+              "image of %dx%d is too large for the gather's 24-bit texel indices", d->H, d->W);
   // match / volumes may be absent: such a frame only serves ufr_project_gather calls that pass sim8_in / vol24_in
   const bool has_vol = d->vol_feat[0] != nullptr;
   for (int s = 0; s < UFR_NUM_STAGES; ++s) {
     UFR_REQUIRE((d->vol_feat[s] != nullptr) == has_vol && (d->vol_weight[s] != nullptr) == has_vol,
                 "volumes must be given for all stages or for none (stage %d)", s + 1);
     if (has_vol) UFR_REQUIRE(d->vol_D[s] >= 2 && d->vol_H[s] >= 2 && d->vol_W[s] >= 2, "degenerate volume (stage %d)", s + 1);
+    // the gathers index texels with 24-bit multiplies and 32-bit float offsets inside one view
+    if (has_vol)
+      UFR_REQUIRE((long long)d->vol_D[s] * d->vol_H[s] < (1 << 24) && (long long)d->vol_W[s] * kVolCh < (1 << 24) &&
+                      (long long)d->vol_D[s] * d->vol_H[s] * d->vol_W[s] * kVolCh < (1ll << 32),
+                  "volume of stage %d is too large for the gather's 32-bit texel offsets", s + 1);
   }
   UFR_REQUIRE(d->source_poses && d->source_cam_pos && d->ref_cam_pos && d->w2c_row2, "null camera constants");
   return UFR_OK;

@@ -25,7 +25,10 @@ __device__ __forceinline__ void sample_volume(const float* __restrict__ vol, int
                   cz <= (float)(D - 1);
         if (ok) {
           const float wt = mul_rn(mul_rn(wx[dx], wy[dy]), wz[dz]);
-          const float* t = vol + (((size_t)(int)cz * H + (int)cy) * W + (int)cx) * kVolCh;
+          // in range: 0 <= cz*H + cy < 2^24 and W * kVolCh < 2^24, so the texel offset is two 24-bit multiply-adds (full
+          // rate) instead of 64-bit integer multiplies; ufr_frame_prepare refuses volumes beyond 2^31 floats per view
+          const unsigned row = __umul24((unsigned)(int)cz, (unsigned)H) + (unsigned)(int)cy;
+          const float* t = vol + (__umul24(row, (unsigned)(W * kVolCh)) + __umul24((unsigned)(int)cx, (unsigned)kVolCh));
           const f32x4 v0 = ld4(t), v1 = ld4(t + 4);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {

@@ -294,3 +294,26 @@ def test_weights_outside_the_plane_range_are_refused():
     P = {k: v.clone().to(DEV) for k, v in load_weights().items()}
     P["ray_transformer.density_view_transformer.layers.0.mlp.0.weight"][3, 5] = 250.0   # inside the range: packs
     ops.PackedWeights(P)
+
+
+@pytest.mark.parametrize("scale", [1e-3, 1e-2, 40.0])
+def test_aggregate_rows_token_magnitudes(scale, weights):
+    """The dense layers run as fp16 plane products (ufr_layout_f16.h): fp16's exponent range must not show.  Token inputs
+    far smaller / larger than the synthetic scene's (|x| up to 1.7) against the oracle on the same scaled tokens."""
+    fr, idx, U1, U2, g, want = _oracle_rows("rows_small")
+    w = want["coarse"]
+    RN, SN = w["z"].shape
+    NV = w["x"].shape[1]
+    x = (w["x"] * scale).contiguous()
+    mask = w["mask"].permute(1, 2, 0).reshape(-1, NV)
+    dirs3 = w["dirs"].permute(1, 2, 0, 3).reshape(-1, NV, 3)
+    ref = {}
+    with torch.no_grad():
+        rad_ref, srdf_ref = O.aggregate_tokens(load_weights(), x, w["rgb_s"], mask, dirs3, RN, SN, want=ref)
+    rgbm = torch.cat([w["rgb_s"], mask[..., None]], -1).to(DEV).contiguous()
+    dirs = torch.cat([dirs3, torch.zeros(RN * SN, NV, 1)], -1).to(DEV).contiguous()
+    radiance, srdf, dbg = ops.aggregate(weights, x.to(DEV), rgbm, dirs, RN, SN, debug=True)
+    assert rel_err(dbg["view_out"], ref["view_out"]) < 2e-5
+    assert rel_err(dbg["ray_out"].reshape(RN, SN, 88), ref["ray_out"]) < 2e-5
+    assert rel_err(srdf, srdf_ref) < 5e-5
+    assert rel_err(radiance, rad_ref) < 2e-5

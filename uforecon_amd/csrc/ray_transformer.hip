@@ -144,7 +144,11 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
           const float kk = (j < 11 && live[c]) ? elu1(kt[c][h][r]) : 0.f;            // padded dims / empty tile contribute nothing
           const float vs = pow2_len ? vt[c][h][r] * inv_len : vt[c][h][r] / f_len;
           const float vv = j < 11 ? vs : (j == 11 ? 1.f : 0.f);                       // ones column -> sum of K'
+#ifdef UFR_ABL_NOKV   // ablation (timing only): no fp32 MFMAs for the per-head KV state
+          KV[h][r] += kk * vv;
+#else
           KV[h] = mfma16(kk, vv, KV[h]);
+#endif
         }
       }
     }
@@ -176,7 +180,11 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float qq = (4 * g + r < 11) ? elu1(q[c][h][r]) : 0.f;
+#ifdef UFR_ABL_NOKV
+          acc[r] += KV[h][r] * qq;
+#else
           acc = mfma16(KV[h][r], qq, acc);           // rows v = 4g+r: sum_d KV[d][v] Q'[d]; row 11 = Q'.sum(K')
+#endif
         }
         const float den = __shfl(acc[3], 32 + j);    // row 11 lives in lane group 2, register 3
         const float Z = 1.f / (den + 1e-6f);         // linear_attention.py:43

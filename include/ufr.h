@@ -62,6 +62,18 @@ typedef struct ufr_raw_weights {
   const float* variance;      /* deviation_network.variance, scalar          (single_variance_network.py:8) */
 } ufr_raw_weights;
 
+/* Matrix precision of the dense layers, process-wide (read at launch time by every entry point below).
+ *   UFR_PRECISION_FP32  (default) fp32-grade: every product as three fp16 plane products, fp32 accumulate; the backward
+ *                       kernels on the fp32 matrix instructions.  This is the mode all 1e-4 parity statements refer to.
+ *   UFR_PRECISION_16BIT the "bf16" training mode of the reference's mixed-precision recipe (BASELINE configs[4]): one
+ *                       16-bit plane per operand (fp16 hi planes in the forward, bf16 operands in the backward GEMMs and
+ *                       weight gradients), fp32 accumulation, LayerNorm / attention / softmax / compositor in fp32.
+ *                       Tolerance: 2e-3 of scale on forward rows, 3e-2 on gradients (tests/test_gpu_backward.py). */
+#define UFR_PRECISION_FP32 0
+#define UFR_PRECISION_16BIT 1
+int ufr_set_matrix_precision(int mode);
+int ufr_get_matrix_precision(void);
+
 /* Re-orders the dense matrices into MFMA A-fragment order (one 16x16 output tile x 16
  * input features = 64 lanes x float4, zero padded) so the kernels stream them with
  * contiguous 1 KiB wave loads.  Call again whenever the parameters change. */

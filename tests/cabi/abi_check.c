@@ -8,7 +8,8 @@
 int main(void) {
   /* link-time presence of every entry point */
   const void* syms[] = {
-      (const void*)ufr_version, (const void*)ufr_last_error, (const void*)ufr_packed_weights_bytes, (const void*)ufr_weights_pack,
+      (const void*)ufr_version, (const void*)ufr_last_error, (const void*)ufr_set_matrix_precision,
+      (const void*)ufr_get_matrix_precision, (const void*)ufr_packed_weights_bytes, (const void*)ufr_weights_pack,
       (const void*)ufr_pack_plan, (const void*)ufr_packed_fp32_floats, (const void*)ufr_packed_f16_halfwords,
       (const void*)ufr_pack_plan_f16, (const void*)ufr_frame_workspace_bytes, (const void*)ufr_frame_prepare,
       (const void*)ufr_sample_fixed, (const void*)ufr_sample_importance_merge, (const void*)ufr_points,
@@ -24,6 +25,7 @@ int main(void) {
   for (i = 0; i < n; ++i)
     if (!syms[i]) return 10;
   if (ufr_version() < 100) return 11;
+  if (ufr_get_matrix_precision() != UFR_PRECISION_FP32 || ufr_set_matrix_precision(7) == 0) return 15;
   /* argument validation: negative status + message, no device needed */
   if (ufr_sample_fixed(0, 0, 0, 0, 4, 64, 0) >= 0) return 12;
   if (!strstr(ufr_last_error(), "ufr_sample_fixed")) return 13;

@@ -330,3 +330,64 @@ def test_full_size_training_step_properties():
         eps = 1e-3
         fd = (loss_at(eps) - loss_at(-eps)) / (2 * eps)
     assert abs(fd - slope) <= 0.03 * abs(slope) + 1e-4, (fd, slope)
+
+
+# ------------------------------------------------------------------ reduced-precision ("bf16") training mode
+GRAD_TOL_16BIT = 1e-1   # of each gradient tensor's scale (bf16 operands: 8 significand bits) ...
+GRAD_COS_16BIT = 0.999  # ... and the whole parameter gradient must keep its direction
+FWD_TOL_16BIT = 2e-3    # loss / forward rows
+
+
+@pytest.fixture
+def sixteen_bit_mode():
+    ops.set_matrix_precision(ops.PRECISION_16BIT)
+    try:
+        yield
+    finally:
+        ops.set_matrix_precision(ops.PRECISION_FP32)
+
+
+@pytest.mark.parametrize("name", ["c5_train_grads", "c5_train_grads_nv4"])
+def test_training_step_16bit_mode(name, sixteen_bit_mode):
+    """BASELINE configs[4] asks for the mixed-precision ("bf16") training step: ufr_set_matrix_precision(UFR_PRECISION_16BIT)
+    runs every dense layer with one 16-bit plane per operand (fp16 hi planes forward, bf16 operands in the backward GEMMs
+    and weight gradients, fp32 accumulation; LayerNorm / attention / softmax / compositor stay fp32).  Same golden
+    gradients of the reference's fp32 autograd, looser stated tolerance."""
+    assert ops.get_matrix_precision() == ops.PRECISION_16BIT
+    m, f, r, loss, g = _train_step(name)
+    assert abs(float(loss) - float(g["loss"])) < FWD_TOL_16BIT * abs(float(g["loss"]))
+    loss.backward()
+    torch.cuda.synchronize()
+    worst = {}
+    dot = na = nb = 0.0
+    for k, p in m.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+        worst[k] = grad_rel_err(p.grad, g["grad." + k])
+        ref = torch.from_numpy(g["grad." + k]).to(p.grad).reshape(p.grad.shape)
+        dot += float((p.grad * ref).sum()); na += float((p.grad * p.grad).sum()); nb += float((ref * ref).sum())
+    # the six volume gradients are per-point quantities (nothing averages the bf16 rounding of the data-gradient GEMMs away
+    # as the sum over all tokens does for a weight gradient): direction per tensor + a loose bound on the worst entry
+    vol_cos, vol_worst = {}, {}
+    for key in VOLUME_KEYS:
+        st, k = key.split(".")
+        v = f.feature_volume[st][k]
+        ref = torch.as_tensor(golden_volume_grad(g, key, v.shape)).to(v.grad).reshape(v.grad.shape)
+        vol_worst[key] = grad_rel_err(v.grad, ref)
+        vol_cos[key] = float((v.grad * ref).sum() / ((v.grad * v.grad).sum() * (ref * ref).sum()).sqrt())
+    cos = dot / (na * nb) ** 0.5
+    print("16-bit mode: loss rel", abs(float(loss) - float(g["loss"])) / abs(float(g["loss"])), "parameter cosine", cos,
+          "worst parameter", max(worst.values()), max(worst, key=worst.get), "volumes", vol_cos, vol_worst)
+    assert cos > GRAD_COS_16BIT
+    bad = {k: e for k, e in worst.items() if not e < GRAD_TOL_16BIT}
+    assert not bad, bad
+    assert min(vol_cos.values()) > 0.995 and max(vol_worst.values()) < 0.3, (vol_cos, vol_worst)
+    # and it is a different arithmetic, not the fp32 path under another name
+    assert max(worst.values()) > 10 * GRAD_TOL
+
+
+def test_precision_mode_is_restored_and_validated():
+    assert ops.get_matrix_precision() == ops.PRECISION_FP32
+    from uforecon_amd._lib import UfrError
+    with pytest.raises(UfrError):
+        ops.set_matrix_precision(5)
+    assert ops.get_matrix_precision() == ops.PRECISION_FP32

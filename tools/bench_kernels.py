@@ -31,6 +31,8 @@ def timeit(fn, reps=7):
 
 
 def main():
+    if os.environ.get("UFR_PRECISION") == "16":   # the reduced-precision (one 16-bit plane) mode of include/ufr.h
+        ops.set_matrix_precision(ops.PRECISION_16BIT)
     RN = int(os.environ.get("RN", 4096))
     SN = int(os.environ.get("SN", 128))
     NV = 3

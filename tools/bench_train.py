@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--coarse", type=int, default=64)
     ap.add_argument("--fine", type=int, default=64)
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--precision", choices=("fp32", "16bit"), default="fp32",
+                    help="16bit: ufr_set_matrix_precision(UFR_PRECISION_16BIT), the mixed-precision mode of configs[4]")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -92,6 +94,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if a.precision == "16bit":
+        ops.set_matrix_precision(ops.PRECISION_16BIT)
     for _ in range(a.warmup):
         step()
     fence()
@@ -113,7 +117,7 @@ def main():
         print(json.dumps(dict(
             metric="training rays/s (fwd + bwd + Adam through the HIP ray path)", value=world * a.rays * a.steps / dt,
             unit="rays/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3, scaling="weak",
-            dtype="f32", data="synthetic",
+            dtype="f32" if a.precision == "fp32" else "bf16/fp16 operands, f32 accumulate", data="synthetic",
             config=dict(workload=f"configs[4]: {a.views} source views + GT view, {a.rays} random rays per rank of a "
                                  f"{a.height}x{a.width} frame, {a.coarse}+{a.fine} samples ({pts} point evaluations per rank and "
                                  f"step), frustum gradients on", loss=float(loss),

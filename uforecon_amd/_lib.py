@@ -67,6 +67,8 @@ i32, sz, vp = C.c_int32, C.c_size_t, C.c_void_p
 SIGNATURES = {
     "ufr_version": (C.c_int, []),
     "ufr_last_error": (C.c_char_p, []),
+    "ufr_set_matrix_precision": (C.c_int, [C.c_int]),
+    "ufr_get_matrix_precision": (C.c_int, []),
     "ufr_packed_weights_bytes": (sz, []),
     "ufr_weights_pack": (C.c_int, [C.POINTER(RawWeights), vp, vp]),
     "ufr_pack_plan": (C.c_int, [C.POINTER(i32), C.POINTER(i32)]),

@@ -57,6 +57,22 @@ __device__ __forceinline__ int opaque(int v) {
 // Row tile rt belongs to wave (rt + rt_shift) % kBwdWaves: consecutive GEMMs of one phase pass the running tile count
 // so that their tiles are dealt round-robin over the waves.
 // k-order inside a 16-chunk: MFMA step kk contracts k = 16*kc + 4*g + kk (lane group g), for both operands.
+// ---- reduced-precision mode (ufr_set_matrix_precision(UFR_PRECISION_16BIT)): the GEMMs and weight-gradient products of the
+// backward kernels take bf16 operands (v_mfma_f32_16x16x16_bf16: lane (g, j) supplies k = 4g..4g+3, exactly the four
+// values it feeds to four consecutive v_mfma_f32_16x16x4_f32 in the fp32 mode), fp32 accumulation as before.
+typedef short bf16x4_bits __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16x4_bits pack_bf16x4(float a, float b, float c, float d) {   // round to nearest even
+  const unsigned lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+  const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{c, d}, bf16x2_t));
+  return __builtin_bit_cast(bf16x4_bits, u32x2_t{lo, hi});
+}
+__device__ __forceinline__ f32x4 mfma16_bf16(bf16x4_bits a, bf16x4_bits b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+
 // A operands of one row tile of a GEMM: [k chunk][MFMA step]
 template <int IN>
 struct AFrag { float a[(IN + 15) / 16][4]; };
@@ -107,7 +123,7 @@ __device__ __forceinline__ AFrag<IN> gemm_prefetch(const float* __restrict__ W, 
   return f;
 }
 
-template <int OUT, int IN, bool TRANS, typename Epi>
+template <int OUT, int IN, bool TRANS, bool LOWP, typename Epi>
 __device__ __forceinline__ void gemm_compute(AFrag<IN>& cur, const float* __restrict__ W, int ldw, const float* X, int wave,
                                              int lane, Epi epi, int rt_shift = 0) {
   constexpr int RT = (OUT + 15) / 16, KC = (IN + 15) / 16, FULL = IN / 16;
@@ -128,17 +144,31 @@ __device__ __forceinline__ void gemm_compute(AFrag<IN>& cur, const float* __rest
       b[kc][kk] = ok ? v : 0.f;
     }
   }
+  bf16x4_bits b16[KC];
+  if constexpr (LOWP) {
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) b16[kc] = pack_bf16x4(b[kc][0], b[kc][1], b[kc][2], b[kc][3]);
+  }
   for (int rt = gemm_first_rt(wave, rt_shift); rt < RT; rt += kBwdWaves) {
     AFrag<IN> nxt;
     const bool more = rt + kBwdWaves < RT;
     if (more) gemm_load_a<OUT, IN, TRANS>(W, ldw, rt + kBwdWaves, lane, nxt);   // next row tile's burst rides on these MFMAs
     f32x4 acc0 = splat4(0.f), acc1 = splat4(0.f);
+    if constexpr (LOWP) {
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
-      acc0 = mfma16(cur.a[kc][0], b[kc][0], acc0);
-      acc1 = mfma16(cur.a[kc][1], b[kc][1], acc1);
-      acc0 = mfma16(cur.a[kc][2], b[kc][2], acc0);
-      acc1 = mfma16(cur.a[kc][3], b[kc][3], acc1);
+      for (int kc = 0; kc < KC; ++kc) {
+        const bf16x4_bits a4 = pack_bf16x4(cur.a[kc][0], cur.a[kc][1], cur.a[kc][2], cur.a[kc][3]);
+        if (kc & 1) acc1 = mfma16_bf16(a4, b16[kc], acc1);
+        else acc0 = mfma16_bf16(a4, b16[kc], acc0);
+      }
+    } else {
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        acc0 = mfma16(cur.a[kc][0], b[kc][0], acc0);
+        acc1 = mfma16(cur.a[kc][1], b[kc][1], acc1);
+        acc0 = mfma16(cur.a[kc][2], b[kc][2], acc0);
+        acc1 = mfma16(cur.a[kc][3], b[kc][3], acc1);
+      }
     }
     const f32x4 acc = acc0 + acc1;
 #pragma unroll
@@ -151,11 +181,11 @@ __device__ __forceinline__ void gemm_compute(AFrag<IN>& cur, const float* __rest
 }
 
 // prefetch + compute in one call (phases whose B operand is already published)
-template <int OUT, int IN, bool TRANS, typename Epi>
+template <int OUT, int IN, bool TRANS, bool LOWP, typename Epi>
 __device__ __forceinline__ void gemm_lds(const float* __restrict__ W, int ldw, const float* X, int wave, int lane,
                                          Epi epi, int rt_shift = 0) {
   AFrag<IN> f = gemm_prefetch<OUT, IN, TRANS>(W, ldw, wave, lane, rt_shift);
-  gemm_compute<OUT, IN, TRANS>(f, W, ldw, X, wave, lane, epi, rt_shift);
+  gemm_compute<OUT, IN, TRANS, LOWP>(f, W, ldw, X, wave, lane, epi, rt_shift);
 }
 
 // one 16x16 tile of dW += dY X^T over the tile's 16 tokens
@@ -219,7 +249,7 @@ __host__ __device__ constexpr WgTile wg_decode(const WgList<N>& l, int tile) {
 // Slots are processed in groups of kWgGroup: all LDS operand reads of a group are issued first, then its MFMAs with
 // the group's independent accumulators interleaved (four 40-cycle dependent chains keep the 32-cycle issue rate).
 constexpr int kWgGroup = 4;
-template <const auto& LIST, int N, int NSLOT, int SLOT0, int WAVE, int NACC>
+template <const auto& LIST, int N, int NSLOT, int SLOT0, int WAVE, bool LOWP, int NACC>
 __device__ __forceinline__ void wgrad_wave(f32x4 (&acc)[NACC], const float* lds, int lane) {
   static_assert(SLOT0 + NSLOT <= NACC, "accumulator slots");
   lane = opaque(lane);
@@ -232,37 +262,48 @@ __device__ __forceinline__ void wgrad_wave(f32x4 (&acc)[NACC], const float* lds,
       constexpr WgTile t = wg_decode(LIST, (s0 + u) * kBwdWaves + WAVE);
       if constexpr (s0 + u < NSLOT && t.valid) {
         const bool ao = t.o0 + j < t.OUT, bo = t.i0 + j < t.IN;
-        const float* pa = lds + (t.dy + (ao ? t.o0 + j : 0)) * kLD + g;
-        const float* pb = lds + (t.x + (bo ? t.i0 + j : 0)) * kLD + g;
+        // fp32: MFMA q contracts tokens 4q + g; bf16: the single MFMA takes tokens 4g .. 4g+3 from this lane
+        const float* pa = lds + (t.dy + (ao ? t.o0 + j : 0)) * kLD + (LOWP ? 4 * g : g);
+        const float* pb = lds + (t.x + (bo ? t.i0 + j : 0)) * kLD + (LOWP ? 4 * g : g);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float va = pa[4 * q], vb = pb[4 * q];
+          const float va = pa[LOWP ? q : 4 * q], vb = pb[LOWP ? q : 4 * q];
           a[u][q] = ao ? va : 0.f;
           b[u][q] = bo ? vb : 0.f;
         }
       }
     });
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
+    if constexpr (LOWP) {
       static_for<kWgGroup>([&](auto ui) __attribute__((always_inline)) {
         constexpr int u = decltype(ui)::value;
         constexpr WgTile t = wg_decode(LIST, (s0 + u) * kBwdWaves + WAVE);
-        if constexpr (s0 + u < NSLOT && t.valid) acc[SLOT0 + s0 + u] = mfma16(a[u][q], b[u][q], acc[SLOT0 + s0 + u]);
+        if constexpr (s0 + u < NSLOT && t.valid)
+          acc[SLOT0 + s0 + u] = mfma16_bf16(pack_bf16x4(a[u][0], a[u][1], a[u][2], a[u][3]),
+                                            pack_bf16x4(b[u][0], b[u][1], b[u][2], b[u][3]), acc[SLOT0 + s0 + u]);
       });
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        static_for<kWgGroup>([&](auto ui) __attribute__((always_inline)) {
+          constexpr int u = decltype(ui)::value;
+          constexpr WgTile t = wg_decode(LIST, (s0 + u) * kBwdWaves + WAVE);
+          if constexpr (s0 + u < NSLOT && t.valid) acc[SLOT0 + s0 + u] = mfma16(a[u][q], b[u][q], acc[SLOT0 + s0 + u]);
+        });
+    }
   });
 }
-template <const auto& LIST, int N, int NSLOT, int SLOT0, int NACC>
+template <const auto& LIST, int N, int NSLOT, int SLOT0, bool LOWP, int NACC>
 __device__ __forceinline__ void wgrad_all(f32x4 (&acc)[NACC], const float* lds, int wave, int lane) {
   static_assert(kBwdWaves == 4 || kBwdWaves == 8, "one case per wave");
   switch (__builtin_amdgcn_readfirstlane(wave)) {
-    case 0: wgrad_wave<LIST, N, NSLOT, SLOT0, 0>(acc, lds, lane); break;
-    case 1: wgrad_wave<LIST, N, NSLOT, SLOT0, 1>(acc, lds, lane); break;
-    case 2: wgrad_wave<LIST, N, NSLOT, SLOT0, 2>(acc, lds, lane); break;
-    case 3: wgrad_wave<LIST, N, NSLOT, SLOT0, 3>(acc, lds, lane); break;
-    case 4: wgrad_wave<LIST, N, NSLOT, SLOT0, 4 % kBwdWaves>(acc, lds, lane); break;
-    case 5: wgrad_wave<LIST, N, NSLOT, SLOT0, 5 % kBwdWaves>(acc, lds, lane); break;
-    case 6: wgrad_wave<LIST, N, NSLOT, SLOT0, 6 % kBwdWaves>(acc, lds, lane); break;
-    default: wgrad_wave<LIST, N, NSLOT, SLOT0, 7 % kBwdWaves>(acc, lds, lane); break;
+    case 0: wgrad_wave<LIST, N, NSLOT, SLOT0, 0, LOWP>(acc, lds, lane); break;
+    case 1: wgrad_wave<LIST, N, NSLOT, SLOT0, 1, LOWP>(acc, lds, lane); break;
+    case 2: wgrad_wave<LIST, N, NSLOT, SLOT0, 2, LOWP>(acc, lds, lane); break;
+    case 3: wgrad_wave<LIST, N, NSLOT, SLOT0, 3, LOWP>(acc, lds, lane); break;
+    case 4: wgrad_wave<LIST, N, NSLOT, SLOT0, 4 % kBwdWaves, LOWP>(acc, lds, lane); break;
+    case 5: wgrad_wave<LIST, N, NSLOT, SLOT0, 5 % kBwdWaves, LOWP>(acc, lds, lane); break;
+    case 6: wgrad_wave<LIST, N, NSLOT, SLOT0, 6 % kBwdWaves, LOWP>(acc, lds, lane); break;
+    default: wgrad_wave<LIST, N, NSLOT, SLOT0, 7 % kBwdWaves, LOWP>(acc, lds, lane); break;
   }
 }
 template <const auto& LIST, int N, int NSLOT, int SLOT0, int WAVE, int NACC>

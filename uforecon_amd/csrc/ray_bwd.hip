@@ -55,6 +55,7 @@ constexpr int kSlots2 = (kList2.first[6] + kBwdWaves - 1) / kBwdWaves;   // 273 
 constexpr int kSlots3 = (kList3.first[2] + kBwdWaves - 1) / kBwdWaves;   // 72 tiles -> 9
 }  // namespace rb
 
+template <bool LOWP>
 __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPtrs gp, const float* __restrict__ token0,
                                                               const float* __restrict__ order_pe,
                                                               const float* __restrict__ d_srdf, int RN, int SN,
@@ -104,8 +105,8 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       auto pf0 = gemm_prefetch<88, 88, false>(wp.p[P_RT_K], 88, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_compute<88, 88, false>(pf0, wp.p[P_RT_K], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = elu1(v); });
-      gemm_lds<88, 88, false>(wp.p[P_RT_V], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_V + r)[c] = v / fS; }, 6);
+      gemm_compute<88, 88, false, LOWP>(pf0, wp.p[P_RT_K], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = elu1(v); });
+      gemm_lds<88, 88, false, LOWP>(wp.p[P_RT_V], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_V + r)[c] = v / fS; }, 6);
       __syncthreads();
     tid = opaque(tid0);
 #pragma unroll
@@ -140,7 +141,7 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       auto pf1 = gemm_prefetch<88, 88, false>(wp.p[P_RT_Q], 88, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_compute<88, 88, false>(pf1, wp.p[P_RT_Q], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_Q + r)[c] = elu1(v); });   // Q' kept: elu'(q) = (Q' > 1 ? 1 : Q')
+      gemm_compute<88, 88, false, LOWP>(pf1, wp.p[P_RT_Q], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_Q + r)[c] = elu1(v); });   // Q' kept: elu'(q) = (Q' > 1 ? 1 : Q')
       __syncthreads();
     tid = opaque(tid0);
       // message of (token, head): t = Q' KV_h, den = Q'.sum K', msg = t * Z * SN (linear_attention.py:43-44)
@@ -166,19 +167,19 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       auto pf2 = gemm_prefetch<88, 88, false>(wp.p[P_RT_MERGE], 88, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_compute<88, 88, false>(pf2, wp.p[P_RT_MERGE], 88, R(O_MSG), wave, lane, [&](int r, int c, float v) { R(O_XH1 + r)[c] = v; });
+      gemm_compute<88, 88, false, LOWP>(pf2, wp.p[P_RT_MERGE], 88, R(O_MSG), wave, lane, [&](int r, int c, float v) { R(O_XH1 + r)[c] = v; });
       __syncthreads();
     tid = opaque(tid0);
       ln_forward<88>(R(O_XH1), R(O_CAT + 88), nullptr, flat + F_N1W, flat + F_N1B, R(O_RSTD1), tid);
       auto pf3 = gemm_prefetch<176, 176, false>(wp.p[P_RT_MLP0], 176, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_compute<176, 176, false>(pf3, wp.p[P_RT_MLP0], 176, R(O_CAT), wave, lane,
+      gemm_compute<176, 176, false, LOWP>(pf3, wp.p[P_RT_MLP0], 176, R(O_CAT), wave, lane,
                                 [&](int r, int c, float v) { R(O_HID + r)[c] = fmaxf(v, 0.f); });
       auto pf4 = gemm_prefetch<88, 176, false>(wp.p[P_RT_MLP2], 176, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_compute<88, 176, false>(pf4, wp.p[P_RT_MLP2], 176, R(O_HID), wave, lane, [&](int r, int c, float v) { R(O_XH2 + r)[c] = v; });
+      gemm_compute<88, 176, false, LOWP>(pf4, wp.p[P_RT_MLP2], 176, R(O_HID), wave, lane, [&](int r, int c, float v) { R(O_XH2 + r)[c] = v; });
       __syncthreads();
     tid = opaque(tid0);
       ln_forward<88>(R(O_XH2), R(O_Y), R(O_CAT), flat + F_N2W, flat + F_N2B, R(O_RSTD2), tid);
@@ -186,12 +187,12 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       __syncthreads();
     tid = opaque(tid0);
       // DensityMLP 88 -> 32 -> 16 (-> 1) (ray_transformer.py:147-150, 307)
-      gemm_compute<32, 88, false>(pf5, wp.p[P_DM_W0], 88, R(O_Y), wave, lane,
+      gemm_compute<32, 88, false, LOWP>(pf5, wp.p[P_DM_W0], 88, R(O_Y), wave, lane,
                               [&](int r, int c, float v) { R(O_D1 + r)[c] = fmaxf(v + flat[F_DM_B0 + r], 0.f); });
       auto pf6 = gemm_prefetch<16, 32, false>(wp.p[P_DM_W2], 32, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_compute<16, 32, false>(pf6, wp.p[P_DM_W2], 32, R(O_D1), wave, lane,
+      gemm_compute<16, 32, false, LOWP>(pf6, wp.p[P_DM_W2], 32, R(O_D1), wave, lane,
                               [&](int r, int c, float v) { R(O_D2 + r)[c] = fmaxf(v + flat[F_DM_B2 + r], 0.f); });
       __syncthreads();
     tid = opaque(tid0);
@@ -203,12 +204,12 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       auto pf7 = gemm_prefetch<32, 16, true>(wp.p[P_DM_W2], 32, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_compute<32, 16, true>(pf7, wp.p[P_DM_W2], 32, R(O_DD2), wave, lane,
+      gemm_compute<32, 16, true, LOWP>(pf7, wp.p[P_DM_W2], 32, R(O_DD2), wave, lane,
                              [&](int r, int c, float v) { R(O_DD1 + r)[c] = R(O_D1 + r)[c] > 0.f ? v : 0.f; });
       auto pf8 = gemm_prefetch<88, 32, true>(wp.p[P_DM_W0], 88, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_compute<88, 32, true>(pf8, wp.p[P_DM_W0], 88, R(O_DD1), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] = v; });
+      gemm_compute<88, 32, true, LOWP>(pf8, wp.p[P_DM_W0], 88, R(O_DD1), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] = v; });
       __syncthreads();
     tid = opaque(tid0);
       ln_backward<88>(R(O_DY), R(O_XH2), flat + F_N2W, R(O_RSTD2), R(O_DOPRE), tid);
@@ -217,12 +218,12 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       auto pf9 = gemm_prefetch<176, 88, true>(wp.p[P_RT_MLP2], 176, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_compute<176, 88, true>(pf9, wp.p[P_RT_MLP2], 176, R(O_DOPRE), wave, lane,
+      gemm_compute<176, 88, true, LOWP>(pf9, wp.p[P_RT_MLP2], 176, R(O_DOPRE), wave, lane,
                               [&](int r, int c, float v) { R(O_DHID + r)[c] = R(O_HID + r)[c] > 0.f ? v : 0.f; });
       auto pf10 = gemm_prefetch<176, 176, true>(wp.p[P_RT_MLP0], 176, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_compute<176, 176, true>(pf10, wp.p[P_RT_MLP0], 176, R(O_DHID), wave, lane, [&](int r, int c, float v) { R(O_DCAT + r)[c] = v; });
+      gemm_compute<176, 176, true, LOWP>(pf10, wp.p[P_RT_MLP0], 176, R(O_DHID), wave, lane, [&](int r, int c, float v) { R(O_DCAT + r)[c] = v; });
       __syncthreads();
     tid = opaque(tid0);
       ln_backward<88>(R(O_DCAT + 88), R(O_XH1), flat + F_N1W, R(O_RSTD1), R(O_DMPRE), tid);
@@ -235,7 +236,7 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       auto pf11 = gemm_prefetch<88, 88, true>(wp.p[P_RT_MERGE], 88, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_compute<88, 88, true>(pf11, wp.p[P_RT_MERGE], 88, R(O_DMPRE), wave, lane, [&](int r, int c, float v) { R(O_DMSG + r)[c] = v; });
+      gemm_compute<88, 88, true, LOWP>(pf11, wp.p[P_RT_MERGE], 88, R(O_DMPRE), wave, lane, [&](int r, int c, float v) { R(O_DMSG + r)[c] = v; });
       __syncthreads();
     tid = opaque(tid0);
       // attention backwards, query side: d t = d msg Z SN; d den = -SN Z^2 (d msg . t); d Q' = KV d t + d den sum K'
@@ -291,7 +292,7 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
           dkv[i] += s;
         }
       }
-      gemm_lds<88, 88, true>(wp.p[P_RT_Q], 88, R(O_DQ), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
+      gemm_lds<88, 88, true, LOWP>(wp.p[P_RT_Q], 88, R(O_DQ), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
       __syncthreads();
     tid = opaque(tid0);
       // d x of this sweep (order-PE rows carry no gradient)
@@ -317,7 +318,7 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
           row[264 + k] = R(O_DQ + k)[col];
         }
       }
-      wgrad_all<rb::kList2, 6, kSlots2, 0>(acc, lds, wave, lane);
+      wgrad_all<rb::kList2, 6, kSlots2, 0, LOWP>(acc, lds, wave, lane);
       __syncthreads();
     tid = opaque(tid0);
     }
@@ -334,8 +335,8 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       auto pf12 = gemm_prefetch<88, 88, false>(wp.p[P_RT_K], 88, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_compute<88, 88, false>(pf12, wp.p[P_RT_K], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = elu1(v); });   // K'
-      gemm_lds<88, 88, false>(wp.p[P_RT_V], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_V + r)[c] = v; }, 6);
+      gemm_compute<88, 88, false, LOWP>(pf12, wp.p[P_RT_K], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = elu1(v); });   // K'
+      gemm_lds<88, 88, false, LOWP>(wp.p[P_RT_V], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_V + r)[c] = v; }, 6);
       __syncthreads();
     tid = opaque(tid0);
       // d K'_s[d] = sum_e dKV[d][e] V_s[e] + d(sum K')[d];   d V_s[e] = sum_d K'_s[d] dKV[d][e];  V = v / SN
@@ -365,8 +366,8 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       auto pf13 = gemm_prefetch<88, 88, true>(wp.p[P_RT_K], 88, wave, lane, 0);
       __syncthreads();
     tid = opaque(tid0);
-      gemm_compute<88, 88, true>(pf13, wp.p[P_RT_K], 88, R(O_DK), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] = v; });
-      gemm_lds<88, 88, true>(wp.p[P_RT_V], 88, R(O_DV), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
+      gemm_compute<88, 88, true, LOWP>(pf13, wp.p[P_RT_K], 88, R(O_DK), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] = v; });
+      gemm_lds<88, 88, true, LOWP>(wp.p[P_RT_V], 88, R(O_DV), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
       __syncthreads();
     tid = opaque(tid0);
       for (int idx = tid; idx < kTT * 20; idx += kBwdThreads) {
@@ -383,7 +384,7 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
           row[352 + k] = R(O_DY + k)[col];
         }
       }
-      wgrad_all<rb::kList3, 2, kSlots3, kSlots2>(acc, lds, wave, lane);
+      wgrad_all<rb::kList3, 2, kSlots3, kSlots2, LOWP>(acc, lds, wave, lane);
       __syncthreads();
     tid = opaque(tid0);
     }
@@ -412,6 +413,7 @@ constexpr WgMat kMats[] = {{P_PS_W4, 16, 32, O_DO, O_A2}, {P_PS_W2, 32, 32, O_DA
 constexpr auto kList = make_wglist(kMats);   // 2 + 4 + 2 = 8 tiles: two slots per wave
 }  // namespace pb
 
+template <bool LOWP>
 __global__ void __launch_bounds__(kBwdThreads) presim_bwd_kernel(RawPtrs wp, GradPtrs gp, const float* __restrict__ sim8,
                                                                  const float* __restrict__ d_pv, int P) {
   using namespace pb;
@@ -436,29 +438,29 @@ __global__ void __launch_bounds__(kBwdThreads) presim_bwd_kernel(RawPtrs wp, Gra
     auto pf14 = gemm_prefetch<32, 8, false>(wp.p[P_PS_W0], 8, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
-    gemm_compute<32, 8, false>(pf14, wp.p[P_PS_W0], 8, R(O_S8), wave, lane,
+    gemm_compute<32, 8, false, LOWP>(pf14, wp.p[P_PS_W0], 8, R(O_S8), wave, lane,
                            [&](int r, int c, float v) { R(O_A1 + r)[c] = fmaxf(v + wp.p[P_PS_B0][r], 0.f); });
     auto pf15 = gemm_prefetch<32, 32, false>(wp.p[P_PS_W2], 32, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
-    gemm_compute<32, 32, false>(pf15, wp.p[P_PS_W2], 32, R(O_A1), wave, lane,
+    gemm_compute<32, 32, false, LOWP>(pf15, wp.p[P_PS_W2], 32, R(O_A1), wave, lane,
                             [&](int r, int c, float v) { R(O_A2 + r)[c] = fmaxf(v + wp.p[P_PS_B2][r], 0.f); });
     auto pf16 = gemm_prefetch<32, 16, true>(wp.p[P_PS_W4], 32, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
-    gemm_compute<32, 16, true>(pf16, wp.p[P_PS_W4], 32, R(O_DO), wave, lane,
+    gemm_compute<32, 16, true, LOWP>(pf16, wp.p[P_PS_W4], 32, R(O_DO), wave, lane,
                            [&](int r, int c, float v) { R(O_DA2 + r)[c] = R(O_A2 + r)[c] > 0.f ? v : 0.f; });
     auto pf17 = gemm_prefetch<32, 32, true>(wp.p[P_PS_W2], 32, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
-    gemm_compute<32, 32, true>(pf17, wp.p[P_PS_W2], 32, R(O_DA2), wave, lane,
+    gemm_compute<32, 32, true, LOWP>(pf17, wp.p[P_PS_W2], 32, R(O_DA2), wave, lane,
                            [&](int r, int c, float v) { R(O_DA1 + r)[c] = R(O_A1 + r)[c] > 0.f ? v : 0.f; });
     __syncthreads();
     tid = opaque(tid0);
     if (tid < 16) accB += row_dot(R(O_DO + tid), nullptr, 0);
     else if (tid < 48) accB += row_dot(R(O_DA2 + (tid - 16)), nullptr, 0);
     else if (tid < 80) accB += row_dot(R(O_DA1 + (tid - 48)), nullptr, 0);
-    wgrad_all<pb::kList, 3, 2, 0>(acc, lds, wave, lane);
+    wgrad_all<pb::kList, 3, 2, 0, LOWP>(acc, lds, wave, lane);
     __syncthreads();
     tid = opaque(tid0);
   }
@@ -468,28 +470,38 @@ __global__ void __launch_bounds__(kBwdThreads) presim_bwd_kernel(RawPtrs wp, Gra
   else if (tid < 80) atomic_add_f32(gp.p[P_PS_B0] + (tid - 48), accB);
 }
 
-hipError_t launch_ray_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* token0, const float* order_pe,
-                          const float* d_srdf, int RN, int SN, float* d_tok_a, float* d_tok_b, float* dbg, hipStream_t s) {
-  if (SN % kTT != 0 || SN < kTT) return hipErrorInvalidValue;
+template <bool LOWP>
+static hipError_t launch_ray_bwd_t(const RawPtrs& wp, const GradPtrs& gp, const float* token0, const float* order_pe,
+                                   const float* d_srdf, int RN, int SN, float* d_tok_a, float* d_tok_b, float* dbg,
+                                   hipStream_t s) {
   static bool attr_set[16] = {};   // the attribute is per device
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
   if (!attr_set[dev]) {
-    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ray_bwd_kernel),
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ray_bwd_kernel<LOWP>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, rb::kLdsBytes);
     if (attr != hipSuccess) return attr;
     attr_set[dev] = true;
   }
   const int blocks = RN < 256 ? RN : 256;
-  hipLaunchKernelGGL(ray_bwd_kernel, dim3(blocks), dim3(kBwdThreads), rb::kLdsBytes, s, wp, gp, token0, order_pe, d_srdf,
-                     RN, SN, d_tok_a, d_tok_b, dbg);
+  hipLaunchKernelGGL(ray_bwd_kernel<LOWP>, dim3(blocks), dim3(kBwdThreads), rb::kLdsBytes, s, wp, gp, token0, order_pe,
+                     d_srdf, RN, SN, d_tok_a, d_tok_b, dbg);
   return hipGetLastError();
+}
+
+hipError_t launch_ray_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* token0, const float* order_pe,
+                          const float* d_srdf, int RN, int SN, float* d_tok_a, float* d_tok_b, float* dbg, hipStream_t s) {
+  if (SN % kTT != 0 || SN < kTT) return hipErrorInvalidValue;
+  return matrix_precision_reduced() ? launch_ray_bwd_t<true>(wp, gp, token0, order_pe, d_srdf, RN, SN, d_tok_a, d_tok_b, dbg, s)
+                                    : launch_ray_bwd_t<false>(wp, gp, token0, order_pe, d_srdf, RN, SN, d_tok_a, d_tok_b, dbg, s);
 }
 
 hipError_t launch_presim_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* sim8, const float* d_pv, int P,
                              hipStream_t s) {
   const int n_tiles = (P + kTT - 1) / kTT;
-  hipLaunchKernelGGL(presim_bwd_kernel, dim3(n_tiles < 256 ? n_tiles : 256), dim3(kBwdThreads), 0, s, wp, gp, sim8, d_pv, P);
+  const dim3 grid(n_tiles < 256 ? n_tiles : 256), block(kBwdThreads);
+  if (matrix_precision_reduced()) hipLaunchKernelGGL(presim_bwd_kernel<true>, grid, block, 0, s, wp, gp, sim8, d_pv, P);
+  else hipLaunchKernelGGL(presim_bwd_kernel<false>, grid, block, 0, s, wp, gp, sim8, d_pv, P);
   return hipGetLastError();
 }
 

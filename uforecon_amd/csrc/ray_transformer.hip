@@ -36,8 +36,8 @@ __device__ __forceinline__ void load_ray_tile(const float* __restrict__ token0, 
 }
 
 // LayerNorm over 88 features in nat88 layout (tile 5: registers 0,1 real)
-template <int VW, int VB>
-__device__ __forceinline__ void layer_norm88(f32x4 (&tt)[kRtC][6], const WStreamF16& ws, int g) {
+template <int VW, int VB, class WS>
+__device__ __forceinline__ void layer_norm88(f32x4 (&tt)[kRtC][6], const WS& ws, int g) {
 #pragma unroll
   for (int c = 0; c < kRtC; ++c) {
     f32x4 (&t)[6] = tt[c];
@@ -74,6 +74,7 @@ __device__ __forceinline__ void layer_norm88(f32x4 (&tt)[kRtC][6], const WStream
 constexpr int kRtBlock = UFR_RT_BLOCK;
 constexpr int kRtWaves = kRtBlock / 64;
 
+template <bool LOWP>
 __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(const float* __restrict__ packed,
                                                                   const float* __restrict__ token0,
                                                                   const int* __restrict__ tok_row,
@@ -81,7 +82,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
                                                                   float* __restrict__ srdf,
                                                                   float* __restrict__ ray_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  WStreamF16 ws = wstream_f16_begin<kRtWaves>(packed, smem);
+  auto ws = wstream_f16_begin<kRtWaves, LOWP>(packed, smem);
   wstream_f16_prime<B_RT1, kRtWaves>(ws);
   const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
   const int ray_raw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -261,22 +262,29 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
   }
 }
 
-hipError_t launch_ray_transformer(const float* packed, const float* token0, const int* tok_row, const float* order_pe,
-                                  int RN, int SN, float* srdf, float* ray_out, hipStream_t s) {
-  if (SN % 16 != 0 || SN < 16) return hipErrorInvalidValue;
+template <bool LOWP>
+static hipError_t launch_rt(const float* packed, const float* token0, const int* tok_row, const float* order_pe, int RN,
+                            int SN, float* srdf, float* ray_out, hipStream_t s) {
   // the attribute is per device: set it once on every device this process launches on
   static bool attr_set[16] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
   if (!attr_set[dev]) {
-    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ray_transformer_kernel),
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ray_transformer_kernel<LOWP>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kF16LdsBytes);
     if (attr != hipSuccess) return attr;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(ray_transformer_kernel, dim3((RN + kRtWaves - 1) / kRtWaves), dim3(kRtBlock), kF16LdsBytes, s,
+  hipLaunchKernelGGL(ray_transformer_kernel<LOWP>, dim3((RN + kRtWaves - 1) / kRtWaves), dim3(kRtBlock), kF16LdsBytes, s,
                      packed, token0, tok_row, order_pe, RN, SN, srdf, ray_out);
   return hipGetLastError();
+}
+
+hipError_t launch_ray_transformer(const float* packed, const float* token0, const int* tok_row, const float* order_pe,
+                                  int RN, int SN, float* srdf, float* ray_out, hipStream_t s) {
+  if (SN % 16 != 0 || SN < 16) return hipErrorInvalidValue;
+  return matrix_precision_reduced() ? launch_rt<true>(packed, token0, tok_row, order_pe, RN, SN, srdf, ray_out, s)
+                                    : launch_rt<false>(packed, token0, tok_row, order_pe, RN, SN, srdf, ray_out, s);
 }
 
 }  // namespace ufr

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -103,7 +104,19 @@ hipError_t launch_order_pe(float* table, int SN, hipStream_t s) {
 }
 }  // namespace ufr
 
+namespace ufr {
+static std::atomic<int> g_matrix_precision{UFR_PRECISION_FP32};
+bool matrix_precision_reduced() { return g_matrix_precision.load(std::memory_order_relaxed) == UFR_PRECISION_16BIT; }
+}  // namespace ufr
+
 extern "C" {
+
+int ufr_set_matrix_precision(int mode) {
+  UFR_REQUIRE(mode == UFR_PRECISION_FP32 || mode == UFR_PRECISION_16BIT, "ufr_set_matrix_precision: unknown mode %d", mode);
+  g_matrix_precision.store(mode, std::memory_order_relaxed);
+  return UFR_OK;
+}
+int ufr_get_matrix_precision(void) { return g_matrix_precision.load(std::memory_order_relaxed); }
 
 int ufr_version(void) { return 100; }
 const char* ufr_last_error(void) { return g_err; }

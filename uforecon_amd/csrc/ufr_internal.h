@@ -49,6 +49,10 @@ hipError_t launch_gather(const FrameDev& f, const PreSim& ps, const float* ray_o
                          const float* z, int RN, int SN, float* x_tokens, float* rgb, float* dir, float* sim8,
                          float* vol24, float* xy, float* mask_z, const float* vol24_in, const float* sim8_in,
                          hipStream_t s);
+// process-wide matrix precision (ufr_set_matrix_precision): false = fp32-grade split precision (default), true = one
+// 16-bit plane per operand ("bf16" training mode of BASELINE configs[4]); read by the launchers
+bool matrix_precision_reduced();
+
 hipError_t launch_view_transformer(const float* packed, const float* x_tokens, const float* rgb, const float* dir,
                                    int P, int NV, float* token0, float* radiance, float* view_out, hipStream_t s);
 // tok_row / rad_row (nullable): row of token0 / radiance holding sample (ray, s) -- the fine pass of the whole-path

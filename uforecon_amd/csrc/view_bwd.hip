@@ -64,6 +64,7 @@ constexpr int kDbgCols = 881;
 __device__ unsigned long long g_vb_phase[64];
 #endif
 
+template <bool LOWP>
 __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradPtrs gp, const float* __restrict__ x_tokens,
                                                                const float* __restrict__ rgbm,
                                                                const float* __restrict__ dirs,
@@ -171,9 +172,9 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
 
     // ---------------- P1: Q' = elu(q)+1, K' = elu(k)+1, v (15 row tiles dealt over the waves).  Only the feature-mapped
     // values are kept: elu'(q) = q > 0 ? 1 : exp(q) = (Q' > 1 ? 1 : Q')
-    gemm_compute<80, 80, false>(pf0, wp.p[P_VT_Q], 80, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_Q + r)[c] = elu1(v); });
-    gemm_lds<80, 80, false>(wp.p[P_VT_K], 80, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = elu1(v); }, 5);
-    gemm_lds<80, 80, false>(wp.p[P_VT_V], 80, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_V + r)[c] = v; }, 10);
+    gemm_compute<80, 80, false, LOWP>(pf0, wp.p[P_VT_Q], 80, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_Q + r)[c] = elu1(v); });
+    gemm_lds<80, 80, false, LOWP>(wp.p[P_VT_K], 80, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = elu1(v); }, 5);
+    gemm_lds<80, 80, false, LOWP>(wp.p[P_VT_V], 80, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_V + r)[c] = v; }, 10);
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 1)
@@ -211,7 +212,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     UFR_BWD_PHASE(g_vb_phase, 2)
 
     // ---------------- P3/P4: merge + LayerNorm1 (transformer.py:51-52)
-    gemm_compute<80, 80, false>(pf1, wp.p[P_VT_MERGE], 80, R(O_MSG), wave, lane, [&](int r, int c, float v) { R(O_XH1 + r)[c] = v; });
+    gemm_compute<80, 80, false, LOWP>(pf1, wp.p[P_VT_MERGE], 80, R(O_MSG), wave, lane, [&](int r, int c, float v) { R(O_XH1 + r)[c] = v; });
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 3)
@@ -221,13 +222,13 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 4)
     // ---------------- P5-P7: MLP on [x | m], LayerNorm2, residual (transformer.py:55-58)
-    gemm_compute<160, 160, false>(pf2, wp.p[P_VT_MLP0], 160, R(O_CAT), wave, lane,
+    gemm_compute<160, 160, false, LOWP>(pf2, wp.p[P_VT_MLP0], 160, R(O_CAT), wave, lane,
                               [&](int r, int c, float v) { R(O_HID + r)[c] = fmaxf(v, 0.f); });
     auto pf3 = gemm_prefetch<80, 160, false>(wp.p[P_VT_MLP2], 160, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 5)
-    gemm_compute<80, 160, false>(pf3, wp.p[P_VT_MLP2], 160, R(O_HID), wave, lane, [&](int r, int c, float v) { R(O_XH2 + r)[c] = v; });
+    gemm_compute<80, 160, false, LOWP>(pf3, wp.p[P_VT_MLP2], 160, R(O_HID), wave, lane, [&](int r, int c, float v) { R(O_XH2 + r)[c] = v; });
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 6)
@@ -237,7 +238,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 7)
     // ---------------- P8-P10: radiance-weight MLP 83 -> 16 -> 8 -> 1 (ray_transformer.py:159-163, 313-314)
-    gemm_compute<16, 83, false>(pf4, wp.p[P_RW_W0], 83, R(O_RIN), wave, lane,
+    gemm_compute<16, 83, false, LOWP>(pf4, wp.p[P_RW_W0], 83, R(O_RIN), wave, lane,
                             [&](int r, int c, float v) { R(O_H1 + r)[c] = fmaxf(v + flat[F_RW_B0 + r], 0.f); });
     __syncthreads();
     tid = opaque(tid0);
@@ -310,7 +311,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 13)
     // ---------------- B2: d y = W0^T d h1 (the 80 feature columns) + d token0 (staged in P0)
-    gemm_compute<80, 16, true>(pf5, wp.p[P_RW_W0], 83, R(O_DH1), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
+    gemm_compute<80, 16, true, LOWP>(pf5, wp.p[P_RW_W0], 83, R(O_DH1), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 14)
@@ -323,13 +324,13 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 15)
     // ---------------- B4/B5: MLP backwards
-    gemm_compute<160, 80, true>(pf6, wp.p[P_VT_MLP2], 160, R(O_DOPRE), wave, lane,
+    gemm_compute<160, 80, true, LOWP>(pf6, wp.p[P_VT_MLP2], 160, R(O_DOPRE), wave, lane,
                             [&](int r, int c, float v) { R(O_DHID + r)[c] = R(O_HID + r)[c] > 0.f ? v : 0.f; });
     auto pf7 = gemm_prefetch<160, 160, true>(wp.p[P_VT_MLP0], 160, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 16)
-    gemm_compute<160, 160, true>(pf7, wp.p[P_VT_MLP0], 160, R(O_DHID), wave, lane, [&](int r, int c, float v) { R(O_DCAT + r)[c] = v; });
+    gemm_compute<160, 160, true, LOWP>(pf7, wp.p[P_VT_MLP0], 160, R(O_DHID), wave, lane, [&](int r, int c, float v) { R(O_DCAT + r)[c] = v; });
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 17)
@@ -346,7 +347,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 18)
     // ---------------- B7: merge backwards
-    gemm_compute<80, 80, true>(pf8, wp.p[P_VT_MERGE], 80, R(O_DMPRE), wave, lane, [&](int r, int c, float v) { R(O_DMSG + r)[c] = v; });
+    gemm_compute<80, 80, true, LOWP>(pf8, wp.p[P_VT_MERGE], 80, R(O_DMPRE), wave, lane, [&](int r, int c, float v) { R(O_DMSG + r)[c] = v; });
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 19)
@@ -444,9 +445,9 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 21)
     // ---------------- B10: projections backwards into the d x accumulator (same lane owns an element in all three)
-    gemm_compute<80, 80, true>(pf9, wp.p[P_VT_Q], 80, R(O_DQ), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
-    gemm_lds<80, 80, true>(wp.p[P_VT_K], 80, R(O_DK), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
-    gemm_lds<80, 80, true>(wp.p[P_VT_V], 80, R(O_DV), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
+    gemm_compute<80, 80, true, LOWP>(pf9, wp.p[P_VT_Q], 80, R(O_DQ), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
+    gemm_lds<80, 80, true, LOWP>(wp.p[P_VT_K], 80, R(O_DK), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
+    gemm_lds<80, 80, true, LOWP>(wp.p[P_VT_V], 80, R(O_DV), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 22)
@@ -493,7 +494,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     // ---------------- B12: weight gradients of the seven matrices on the MFMA, register-resident tiles;
     // the next tile's global inputs are requested first and land while these MFMAs run
     if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x, cur_in);
-    wgrad_all<vb::kList, 7, kSlots, 0>(acc, lds, wave, lane);
+    wgrad_all<vb::kList, 7, kSlots, 0, LOWP>(acc, lds, wave, lane);
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 23)
@@ -516,14 +517,15 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
   }
 }
 
-hipError_t launch_view_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* x_tokens, const float* rgbm,
-                           const float* dirs, const float* d_tok_a, const float* d_tok_b, const float* d_radiance, int P,
-                           int NV, float* d_pv, float* dbg, hipStream_t s) {
+template <bool LOWP>
+static hipError_t launch_view_bwd_t(const RawPtrs& wp, const GradPtrs& gp, const float* x_tokens, const float* rgbm,
+                                    const float* dirs, const float* d_tok_a, const float* d_tok_b, const float* d_radiance,
+                                    int P, int NV, float* d_pv, float* dbg, hipStream_t s) {
   static bool attr_set[16] = {};   // the attribute is per device
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
   if (!attr_set[dev]) {
-    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&view_bwd_kernel),
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&view_bwd_kernel<LOWP>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, vb::kLdsBytes);
     if (attr != hipSuccess) return attr;
     attr_set[dev] = true;
@@ -531,9 +533,17 @@ hipError_t launch_view_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* x
   const int PPT = kTT / (NV + 1);
   const int n_tiles = (P + PPT - 1) / PPT;
   const int blocks = n_tiles < 256 ? n_tiles : 256;
-  hipLaunchKernelGGL(view_bwd_kernel, dim3(blocks), dim3(kBwdThreads), vb::kLdsBytes, s, wp, gp, x_tokens, rgbm, dirs,
+  hipLaunchKernelGGL(view_bwd_kernel<LOWP>, dim3(blocks), dim3(kBwdThreads), vb::kLdsBytes, s, wp, gp, x_tokens, rgbm, dirs,
                      d_tok_a, d_tok_b, d_radiance, P, NV, d_pv, dbg);
   return hipGetLastError();
+}
+
+hipError_t launch_view_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* x_tokens, const float* rgbm,
+                           const float* dirs, const float* d_tok_a, const float* d_tok_b, const float* d_radiance, int P,
+                           int NV, float* d_pv, float* dbg, hipStream_t s) {
+  return matrix_precision_reduced()
+             ? launch_view_bwd_t<true>(wp, gp, x_tokens, rgbm, dirs, d_tok_a, d_tok_b, d_radiance, P, NV, d_pv, dbg, s)
+             : launch_view_bwd_t<false>(wp, gp, x_tokens, rgbm, dirs, d_tok_a, d_tok_b, d_radiance, P, NV, d_pv, dbg, s);
 }
 
 }  // namespace ufr

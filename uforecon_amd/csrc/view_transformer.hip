@@ -26,8 +26,8 @@ __device__ __forceinline__ void zero_tiles(f32x4 (&t)[C][N]) {
 }
 
 // LayerNorm over the 80 features of each token: 5 tiles x 4 regs in each of the 4 lane groups.
-template <int C, int VW, int VB>
-__device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const WStreamF16& ws, int g) {
+template <int C, int VW, int VB, class WS>
+__device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const WS& ws, int g) {
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     float s = 0.f;
@@ -76,7 +76,7 @@ __device__ unsigned long long g_vt_wave[4096 * 2];  // start / end tick of every
 constexpr int kVtBlock = UFR_VT_BLOCK;
 constexpr int kVtWaves = kVtBlock / 64;
 
-template <int L, int C>
+template <int L, int C, bool LOWP>
 __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel(const float* __restrict__ packed,
                                                                              const float* __restrict__ x_tokens,
                                                                              const float* __restrict__ rgbm,
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
   constexpr int PPT = 16 / L;          // points per column tile
   constexpr int PPW = PPT * C;         // points per wave iteration
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  WStreamF16 ws = wstream_f16_begin<kVtWaves>(packed, smem);
+  auto ws = wstream_f16_begin<kVtWaves, LOWP>(packed, smem);
   wstream_f16_prime<B_VT, kVtWaves>(ws);
   const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
   const int pt_in_tile = j / L, tv = j % L;         // token tv of point pt_in_tile (tv == 0: view token)
@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #endif
 }
 
-template <int L>
+template <int L, bool LOWP>
 static hipError_t launch_vt(const float* packed, const float* x_tokens, const float* rgb, const float* dir, int P,
                             float* token0, float* radiance, float* view_out, hipStream_t s) {
   constexpr int C = UFR_VT_C;
@@ -416,25 +416,26 @@ static hipError_t launch_vt(const float* packed, const float* x_tokens, const fl
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
   if (!attr_set[dev]) {
-    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&view_transformer_kernel<L, C>),
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&view_transformer_kernel<L, C, LOWP>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kF16LdsBytes);
     if (attr != hipSuccess) return attr;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((view_transformer_kernel<L, C>), dim3(blocks), dim3(kVtBlock), kF16LdsBytes, s, packed, x_tokens,
+  hipLaunchKernelGGL((view_transformer_kernel<L, C, LOWP>), dim3(blocks), dim3(kVtBlock), kF16LdsBytes, s, packed, x_tokens,
                      rgb, dir, P, token0, radiance, view_out);
   return hipGetLastError();
 }
 
 hipError_t launch_view_transformer(const float* packed, const float* x_tokens, const float* rgb, const float* dir,
                                    int P, int NV, float* token0, float* radiance, float* view_out, hipStream_t s) {
+  const bool lowp = matrix_precision_reduced();
   switch (NV) {
-    case 2: return launch_vt<3>(packed, x_tokens, rgb, dir, P, token0, radiance, view_out, s);
-    case 3: return launch_vt<4>(packed, x_tokens, rgb, dir, P, token0, radiance, view_out, s);
-    case 4: return launch_vt<5>(packed, x_tokens, rgb, dir, P, token0, radiance, view_out, s);
-    case 5: return launch_vt<6>(packed, x_tokens, rgb, dir, P, token0, radiance, view_out, s);
-    case 6: return launch_vt<7>(packed, x_tokens, rgb, dir, P, token0, radiance, view_out, s);
-    case 7: return launch_vt<8>(packed, x_tokens, rgb, dir, P, token0, radiance, view_out, s);
+#define UFR_VT_CASE(N)                                                                                       \
+    case N:                                                                                                  \
+      return lowp ? launch_vt<N + 1, true>(packed, x_tokens, rgb, dir, P, token0, radiance, view_out, s)     \
+                  : launch_vt<N + 1, false>(packed, x_tokens, rgb, dir, P, token0, radiance, view_out, s);
+    UFR_VT_CASE(2) UFR_VT_CASE(3) UFR_VT_CASE(4) UFR_VT_CASE(5) UFR_VT_CASE(6) UFR_VT_CASE(7)
+#undef UFR_VT_CASE
     default: return hipErrorInvalidValue;
   }
 }

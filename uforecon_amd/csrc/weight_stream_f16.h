@@ -44,7 +44,10 @@ __device__ __forceinline__ BStep make_bstep(const f32x4& ta, const f32x4& tb) {
   return s;
 }
 
-struct WStreamF16 {
+// LOWP: the reduced-precision mode (ufr_set_matrix_precision): one fp16 plane per operand, one MFMA per product
+template <bool LOWP>
+struct WStreamF16T {
+  static constexpr bool lowp = LOWP;
   const char* src;     // fp16 plane region of the packed blob (global, wave-uniform)
   char* ring;          // LDS: two chunk slots
   unsigned ring_lds;   // ... as an LDS byte address (scalar)
@@ -53,9 +56,10 @@ struct WStreamF16 {
   f16x8 pre[kF16Depth][kPlanes];  // plane fragments of the next kF16Depth stages, in flight from LDS (stage s in slot s % depth)
 };
 
-template <int NWAVES>
-__device__ __forceinline__ WStreamF16 wstream_f16_begin(const float* __restrict__ packed, char* smem) {
-  WStreamF16 ws;
+typedef WStreamF16T<false> WStreamF16;
+template <int NWAVES, bool LOWP = false>
+__device__ __forceinline__ WStreamF16T<LOWP> wstream_f16_begin(const float* __restrict__ packed, char* smem) {
+  WStreamF16T<LOWP> ws;
   ws.lane = threadIdx.x & 63;
   ws.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   ws.src = reinterpret_cast<const char*>(packed) + (size_t)blob_floats() * 4;
@@ -89,8 +93,8 @@ __device__ __forceinline__ void lds_dma_16(const char* g_uniform, unsigned lane_
 
 // fetch pieces [P0, P1) of this wave's share of chunk CHK of stream S into the chunk's ring slot (a piece = one
 // 1 KiB LDS-DMA wave instruction; the wave's share is every NWAVES-th fragment)
-template <int S, int NWAVES, int CHK, int P0 = 0, int P1 = kF16ChunkFrags / NWAVES>
-__device__ __forceinline__ void wstream_f16_fetch(const WStreamF16& ws) {
+template <int S, int NWAVES, int CHK, int P0 = 0, int P1 = kF16ChunkFrags / NWAVES, class WS>
+__device__ __forceinline__ void wstream_f16_fetch(const WS& ws) {
   static_assert(kF16ChunkFrags % NWAVES == 0, "chunk must split evenly over the fetching waves");
   if constexpr (P1 > P0) {
     constexpr size_t goff = ((size_t)f16_stream_base_frags(S) + (size_t)CHK * kF16ChunkFrags) * 1024;
@@ -107,8 +111,8 @@ __device__ __forceinline__ void wstream_f16_fetch(const WStreamF16& ws) {
 // hand-off barrier of chunk CHK: its fragments have landed and every wave is done with the chunk before it.
 // The ring keeps kF16Slots-1 chunks in flight, so at most the (kF16Slots-2) younger fetches of this wave may still
 // be outstanding when chunk CHK must have landed.
-template <int S, int NWAVES, int CHK>
-__device__ __forceinline__ void wstream_f16_barrier(const WStreamF16& ws, bool wrap) {
+template <int S, int NWAVES, int CHK, class WS>
+__device__ __forceinline__ void wstream_f16_barrier(const WS& ws, bool wrap) {
 #ifdef UFR_ABL_NOBARRIER  // ablation builds (timing only, results are garbage): no hand-off at all / barrier without fetch
   (void)ws; (void)wrap;
   return;
@@ -135,8 +139,8 @@ __device__ __forceinline__ void wstream_f16_barrier(const WStreamF16& ws, bool w
 // after the barrier of chunk CHK the slot of chunk CHK-1 is free: pieces [P0, P1) of the refill (chunk CHK + ring
 // depth - 1, or its wrap-around into the next pass).  The pieces of one refill are spread over the stages of chunk
 // CHK: an LDS-DMA instruction stalls its wave for 60..185 cycles (MI355X_MICROARCH.md), several in a row for longer.
-template <int S, int NWAVES, int CHK, int P0 = 0, int P1 = kF16ChunkFrags / NWAVES>
-__device__ __forceinline__ void wstream_f16_refill(const WStreamF16& ws, bool wrap) {
+template <int S, int NWAVES, int CHK, int P0 = 0, int P1 = kF16ChunkFrags / NWAVES, class WS>
+__device__ __forceinline__ void wstream_f16_refill(const WS& ws, bool wrap) {
 #if defined(UFR_ABL_NOBARRIER) || defined(UFR_ABL_NODMA)
   (void)ws; (void)wrap;
   return;
@@ -149,15 +153,15 @@ __device__ __forceinline__ void wstream_f16_refill(const WStreamF16& ws, bool wr
   }
 }
 
-template <int S, int NWAVES, int CHK>
-__device__ __forceinline__ void wstream_f16_open(const WStreamF16& ws, bool wrap) {
+template <int S, int NWAVES, int CHK, class WS>
+__device__ __forceinline__ void wstream_f16_open(const WS& ws, bool wrap) {
   wstream_f16_barrier<S, NWAVES, CHK>(ws, wrap);
   wstream_f16_refill<S, NWAVES, CHK>(ws, wrap);
 }
 
 // end of a pass over stream S: open its padding chunks (none for most streams) so the wrap-around fetches go out
-template <int S, int NWAVES>
-__device__ __forceinline__ void wstream_f16_finish(const WStreamF16& ws, bool wrap) {
+template <int S, int NWAVES, class WS>
+__device__ __forceinline__ void wstream_f16_finish(const WS& ws, bool wrap) {
   constexpr int real = f16_stream_real_chunks(S), pad = f16_stream_chunks(S) - real;
   static_for<pad>([&](auto ci) __attribute__((always_inline)) { wstream_f16_open<S, NWAVES, real + decltype(ci)::value>(ws, wrap); });
 }
@@ -165,13 +169,13 @@ __device__ __forceinline__ void wstream_f16_finish(const WStreamF16& ws, bool wr
 // start of a pass over stream S: its first kF16Slots-1 chunks.  The slots must be free: at kernel start, or
 // after every wave has passed the barrier that opened the previous stream's last chunk with wrap == false
 // (then slot 0.. are no longer read; the last chunk's own slot is (n_chunks-1) % kF16Slots = kF16Slots-1).
-template <int S, int NWAVES>
-__device__ __forceinline__ void wstream_f16_prime(const WStreamF16& ws) {
+template <int S, int NWAVES, class WS>
+__device__ __forceinline__ void wstream_f16_prime(const WS& ws) {
   static_for<kF16Slots - 1>([&](auto ci) __attribute__((always_inline)) { wstream_f16_fetch<S, NWAVES, decltype(ci)::value>(ws); });
 }
 
-template <int V>
-__device__ __forceinline__ f32x4 vec_frag(const WStreamF16& ws, int t, int g) {
+template <int V, class WS>
+__device__ __forceinline__ f32x4 vec_frag(const WS& ws, int t, int g) {
   constexpr int base = (vec_offset(V) - vec_region_offset()) / 4;
   return ws.vecs[base + t * 4 + g];
 }
@@ -195,9 +199,11 @@ constexpr int kProducts = 3;   // MFMAs per fp32 product
 struct NoHook {
   template <class T> __device__ __forceinline__ void operator()(T) const {}
 };
-template <int M, int S, int C, int NWAVES, bool SWAP = false, class Hook = NoHook>
-__device__ __forceinline__ void gemm_f16_panel(WStreamF16& ws, const BStep (&b)[C], f32x4 (&out)[C][mat_desc(M).n_out],
+template <int M, int S, int C, int NWAVES, bool SWAP = false, class Hook = NoHook, class WS = WStreamF16>
+__device__ __forceinline__ void gemm_f16_panel(WS& ws, const BStep (&b)[C], f32x4 (&out)[C][mat_desc(M).n_out],
                                               bool wrap, Hook&& hook = NoHook{}) {
+  constexpr bool LOWP = WS::lowp;
+  constexpr int n_planes = LOWP ? 1 : kPlanes, n_products = LOWP ? 1 : kProducts;
   constexpr int n_out = mat_desc(M).n_out, ST = f16_mat_stream(M);
   static_assert(f16_panel_index(M, S) >= 0, "not a panel of the stream");
   constexpr int F0 = f16_panel_start(ST, f16_panel_index(M, S));
@@ -222,21 +228,21 @@ __device__ __forceinline__ void gemm_f16_panel(WStreamF16& ws, const BStep (&b)[
                          UFR_F16_SPREAD ? (j + 1) * pieces / n_st : pieces>(ws, wrap);
 #ifndef UFR_ABL_NOLDS   // ablation (timing only): the weight fragments are never read from LDS
 #pragma unroll
-      for (int p = 0; p < kPlanes; ++p) ws.pre[s2 % kF16Depth][p] = lds[base + p * 64];
+      for (int p = 0; p < n_planes; ++p) ws.pre[s2 % kF16Depth][p] = lds[base + p * 64];
 #endif
     };
     if constexpr (sidx == 0)                             // start of a pass: nothing is in flight yet
       static_for<kF16Depth>([&](auto di) __attribute__((always_inline)) { read_stage(di); });
     f16x8 a[kPlanes];
 #pragma unroll
-    for (int p = 0; p < kPlanes; ++p) a[p] = ws.pre[sidx % kF16Depth][p];
+    for (int p = 0; p < n_planes; ++p) a[p] = ws.pre[sidx % kF16Depth][p];
     if constexpr (sidx + kF16Depth < n_stages) read_stage(std::integral_constant<int, sidx + kF16Depth>{});
     __builtin_amdgcn_sched_barrier(0);
     hook(ti);
     // three plane pairs (lo.lo is dropped), small terms first (0 = hi, 1 = lo); SWAP: activations in the A slot
-    static_for<kProducts>([&](auto pi) __attribute__((always_inline)) {
+    static_for<n_products>([&](auto pi) __attribute__((always_inline)) {
       constexpr int pw[kProducts] = {1, 0, 0}, px[kProducts] = {0, 1, 0};
-      constexpr int w = pw[decltype(pi)::value], x = px[decltype(pi)::value];
+      constexpr int w = LOWP ? 0 : pw[decltype(pi)::value], x = LOWP ? 0 : px[decltype(pi)::value];
 #pragma unroll
       for (int c = 0; c < C; ++c)
         out[c][to] = SWAP ? mfma_f16(b[c].p[x], a[w], out[c][to]) : mfma_f16(a[w], b[c].p[x], out[c][to]);
@@ -244,7 +250,7 @@ __device__ __forceinline__ void gemm_f16_panel(WStreamF16& ws, const BStep (&b)[
     if constexpr (!std::is_same<std::decay_t<Hook>, NoHook>::value) {
       // issue order: one MFMA, then up to two of the hook's VALU instructions, repeated
 #pragma unroll
-      for (int i = 0; i < kProducts * C; ++i) {
+      for (int i = 0; i < n_products * C; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, UFR_HOOK_VALU, 0);
       }
@@ -294,9 +300,10 @@ __device__ __forceinline__ void descale_tiles(f32x4 (&t)[C][N]) {
 // out = (2^12 out + W_M x in) / 2^12 over all k-steps of M: in[c][0..NIN) are the producer's fp32 accumulator tiles;
 // callers that start from a bias pass it pre-multiplied by kAccScale (exact).
 // The fp16 split of k-step s+1 is interleaved with the MFMAs of k-step s (only step 0's is exposed).
-template <int M, int C, int NWAVES, int NIN>
-__device__ __forceinline__ void gemm_f16(WStreamF16& ws, const f32x4 (&in)[C][NIN], f32x4 (&out)[C][mat_desc(M).n_out],
+template <int M, int C, int NWAVES, int NIN, class WS>
+__device__ __forceinline__ void gemm_f16(WS& ws, const f32x4 (&in)[C][NIN], f32x4 (&out)[C][mat_desc(M).n_out],
                                         bool wrap) {
+  constexpr bool LOWP = WS::lowp;
   static_assert(NIN == mat_desc(M).n_in, "input tile count");
   constexpr int n_out = mat_desc(M).n_out, NU = 4 * C;
   BWords<C> cur;

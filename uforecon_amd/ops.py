@@ -456,6 +456,19 @@ def fmt_layer(params, x: torch.Tensor, src: Optional[torch.Tensor]) -> torch.Ten
     return out
 
 
+PRECISION_FP32, PRECISION_16BIT = 0, 1
+
+
+def set_matrix_precision(mode: int) -> None:
+    """Process-wide precision of the dense layers (include/ufr.h): PRECISION_FP32 (default, the 1e-4 parity mode) or
+    PRECISION_16BIT (one 16-bit plane per operand: the mixed-precision training mode of BASELINE configs[4])."""
+    _lib.check(_lib.load().ufr_set_matrix_precision(int(mode)), "ufr_set_matrix_precision")
+
+
+def get_matrix_precision() -> int:
+    return int(_lib.load().ufr_get_matrix_precision())
+
+
 def profile_enable(on: bool) -> None:
     _lib.load().ufr_profile_enable(int(on))
 

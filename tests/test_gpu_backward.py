@@ -6,7 +6,7 @@ Three levels, all through the C ABI:
     ``training_step`` (code1/model.py:540-566) -- against the REFERENCE's own autograd gradients
     (tests/golden/c5_train_grads*.npz: every per-ray parameter and the six sampled volumes),
   * structural properties: linearity of the adjoints, gradient accumulation, chunk invariance.
-Tolerance: 1e-3 of each gradient tensor's scale (fp32 path; the forward runs the bf16x6 matrix path, the backward
+Tolerance: 1e-3 of each gradient tensor's scale (fp32 path; the forward runs the fp16x3 matrix path, the backward
 recomputes it on the fp32 MFMA).
 """
 import argparse

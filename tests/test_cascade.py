@@ -72,5 +72,6 @@ def test_gpu_cascade_matches_reference_golden(name):
     feats = [{k: v.to(dev) for k, v in f.items()} for f in c["features"]]
     frustums, info = m(feats, c["proj_matrices"], c["depth_values"].to(dev), c["img_hw"])
     assert frustums["stage3"]["feature_volume"].shape == (3, 8, 8, 32, 64)
-    # MIOpen convolutions vs the reference's CPU ones: looser element bound, same outlier budget for WTA ties
-    _compare(frustums, info, _golden(name), tol=2e-3, max_outlier_frac=0.02)
+    # MIOpen's fp32 3-D convolutions vs the reference's CPU ones: measured <= 1e-5 on every tensor of every stage (the
+    # outlier budget is for winner-take-all ties that move a pixel's depth hypotheses, none observed)
+    _compare(frustums, info, _golden(name), tol=1e-4, max_outlier_frac=0.002)

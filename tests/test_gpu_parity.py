@@ -139,7 +139,10 @@ def test_render_rays_matches_reference_golden(name, weights):
     ok = ~degenerate
     assert max_rel_elem(out["rgb"][ok.to(DEV)], rgb_ref[ok], floor=0.05) < REL_TOL
     assert rel_err(out["z_all"], (torch.from_numpy(g["points"]) - fr.batch["ray_o"][0]).norm(dim=-1)) < 1e-5
-    assert rel_err(out["srdf"], g["srdf"]) < 2e-3
+    # measured 2e-5 .. 9e-5: the fine pass's rows are compared at sample positions that differ by the importance sampler's
+    # CDF rounding, which the signed-distance head amplifies (the oracle on this host is 6e-5 from the golden itself);
+    # test_render_rays_interior_rays_full_coverage pins srdf at the golden's own positions to 1e-4
+    assert rel_err(out["srdf"], g["srdf"]) < 3e-4
 
 
 @pytest.mark.parametrize("name", ["c2_hier_interior", "c4_nv5_interior"])

@@ -245,39 +245,62 @@ __host__ __device__ constexpr WgTile wg_decode(const WgList<N>& l, int tile) {
   return WgTile{l.m[mi].param, l.m[mi].OUT, l.m[mi].IN, l.m[mi].dy, l.m[mi].x, (local / ct) * 16, (local % ct) * 16, true};
 }
 
-// accumulate every tile of the list that wave WAVE owns (slot s <-> tile s*kBwdWaves + WAVE); SLOT0 = first slot.
+// Operand rows of the tile (slot s, wave w) = tile s*kBwdWaves + w of a list, for the weight-gradient phase: a table in
+// device memory that the waves read with scalar loads, so that ALL WAVES EXECUTE THE SAME INSTRUCTIONS.  (The first
+// version decoded the tile at compile time per wave behind a switch over the wave id: four copies of a 15 KB unrolled
+// phase, each fetched by one wave only -- with 140..190 KB of code per kernel against a 64 KB instruction cache shared by
+// two CUs the phase was instruction-fetch-bound: 38 k cycles per tile, 20 k with one shared copy.)
+// dY rows a_row + min(j, a_last), X rows b_row + min(j, b_last): a lane past the matrix edge re-reads the last valid row and
+// fills accumulator rows / columns that wgrad_flush never writes out -- no masking of the operands needed
+struct WgEntry { int a_row, a_last, b_row, b_last; };
+template <int NSLOT>
+struct WgTab { WgEntry e[NSLOT * kBwdWaves]; };
+template <int N, int NSLOT>
+__host__ __device__ constexpr WgTab<NSLOT> make_wgtab(const WgList<N>& l) {
+  WgTab<NSLOT> t{};
+  for (int s = 0; s < NSLOT; ++s)
+    for (int w = 0; w < kBwdWaves; ++w) {
+      const WgTile d = wg_decode(l, s * kBwdWaves + w);
+      t.e[s * kBwdWaves + w] = d.valid ? WgEntry{d.dy + d.o0, (d.OUT - d.o0 < 16 ? d.OUT - d.o0 : 16) - 1, d.x + d.i0,
+                                                 (d.IN - d.i0 < 16 ? d.IN - d.i0 : 16) - 1}
+                                       : WgEntry{0, 0, 0, 0};   // a slot past the list: any valid rows, never flushed
+    }
+  return t;
+}
+template <const auto& LIST, int N, int NSLOT>
+__device__ const WgTab<NSLOT> g_wgtab = make_wgtab<N, NSLOT>(LIST);
+
+// accumulate every tile of the list this wave owns (slot s <-> tile s*kBwdWaves + wave); SLOT0 = first accumulator.
 // Slots are processed in groups of kWgGroup: all LDS operand reads of a group are issued first, then its MFMAs with
 // the group's independent accumulators interleaved (four 40-cycle dependent chains keep the 32-cycle issue rate).
 constexpr int kWgGroup = 4;
-template <const auto& LIST, int N, int NSLOT, int SLOT0, int WAVE, bool LOWP, int NACC>
-__device__ __forceinline__ void wgrad_wave(f32x4 (&acc)[NACC], const float* lds, int lane) {
+template <const auto& LIST, int N, int NSLOT, int SLOT0, bool LOWP, int NACC>
+__device__ __forceinline__ void wgrad_all(f32x4 (&acc)[NACC], const float* lds, int wave, int lane) {
   static_assert(SLOT0 + NSLOT <= NACC, "accumulator slots");
   lane = opaque(lane);
   const int g = lane >> 4, j = lane & 15;
+  const WgEntry* tab = g_wgtab<LIST, N, NSLOT>.e + __builtin_amdgcn_readfirstlane(wave);
   static_for<(NSLOT + kWgGroup - 1) / kWgGroup>([&](auto gi) __attribute__((always_inline)) {
     constexpr int s0 = decltype(gi)::value * kWgGroup;
     float a[kWgGroup][4], b[kWgGroup][4];
     static_for<kWgGroup>([&](auto ui) __attribute__((always_inline)) {
       constexpr int u = decltype(ui)::value;
-      constexpr WgTile t = wg_decode(LIST, (s0 + u) * kBwdWaves + WAVE);
-      if constexpr (s0 + u < NSLOT && t.valid) {
-        const bool ao = t.o0 + j < t.OUT, bo = t.i0 + j < t.IN;
+      if constexpr (s0 + u < NSLOT) {
+        const WgEntry e = tab[(s0 + u) * kBwdWaves];
         // fp32: MFMA q contracts tokens 4q + g; bf16: the single MFMA takes tokens 4g .. 4g+3 from this lane
-        const float* pa = lds + (t.dy + (ao ? t.o0 + j : 0)) * kLD + (LOWP ? 4 * g : g);
-        const float* pb = lds + (t.x + (bo ? t.i0 + j : 0)) * kLD + (LOWP ? 4 * g : g);
+        const float* pa = lds + (e.a_row + min(j, e.a_last)) * kLD + (LOWP ? 4 * g : g);
+        const float* pb = lds + (e.b_row + min(j, e.b_last)) * kLD + (LOWP ? 4 * g : g);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float va = pa[LOWP ? q : 4 * q], vb = pb[LOWP ? q : 4 * q];
-          a[u][q] = ao ? va : 0.f;
-          b[u][q] = bo ? vb : 0.f;
+          a[u][q] = pa[LOWP ? q : 4 * q];
+          b[u][q] = pb[LOWP ? q : 4 * q];
         }
       }
     });
     if constexpr (LOWP) {
       static_for<kWgGroup>([&](auto ui) __attribute__((always_inline)) {
         constexpr int u = decltype(ui)::value;
-        constexpr WgTile t = wg_decode(LIST, (s0 + u) * kBwdWaves + WAVE);
-        if constexpr (s0 + u < NSLOT && t.valid)
+        if constexpr (s0 + u < NSLOT)
           acc[SLOT0 + s0 + u] = mfma16_bf16(pack_bf16x4(a[u][0], a[u][1], a[u][2], a[u][3]),
                                             pack_bf16x4(b[u][0], b[u][1], b[u][2], b[u][3]), acc[SLOT0 + s0 + u]);
       });
@@ -286,25 +309,10 @@ __device__ __forceinline__ void wgrad_wave(f32x4 (&acc)[NACC], const float* lds,
       for (int q = 0; q < 4; ++q)
         static_for<kWgGroup>([&](auto ui) __attribute__((always_inline)) {
           constexpr int u = decltype(ui)::value;
-          constexpr WgTile t = wg_decode(LIST, (s0 + u) * kBwdWaves + WAVE);
-          if constexpr (s0 + u < NSLOT && t.valid) acc[SLOT0 + s0 + u] = mfma16(a[u][q], b[u][q], acc[SLOT0 + s0 + u]);
+          if constexpr (s0 + u < NSLOT) acc[SLOT0 + s0 + u] = mfma16(a[u][q], b[u][q], acc[SLOT0 + s0 + u]);
         });
     }
   });
-}
-template <const auto& LIST, int N, int NSLOT, int SLOT0, bool LOWP, int NACC>
-__device__ __forceinline__ void wgrad_all(f32x4 (&acc)[NACC], const float* lds, int wave, int lane) {
-  static_assert(kBwdWaves == 4 || kBwdWaves == 8, "one case per wave");
-  switch (__builtin_amdgcn_readfirstlane(wave)) {
-    case 0: wgrad_wave<LIST, N, NSLOT, SLOT0, 0, LOWP>(acc, lds, lane); break;
-    case 1: wgrad_wave<LIST, N, NSLOT, SLOT0, 1, LOWP>(acc, lds, lane); break;
-    case 2: wgrad_wave<LIST, N, NSLOT, SLOT0, 2, LOWP>(acc, lds, lane); break;
-    case 3: wgrad_wave<LIST, N, NSLOT, SLOT0, 3, LOWP>(acc, lds, lane); break;
-    case 4: wgrad_wave<LIST, N, NSLOT, SLOT0, 4 % kBwdWaves, LOWP>(acc, lds, lane); break;
-    case 5: wgrad_wave<LIST, N, NSLOT, SLOT0, 5 % kBwdWaves, LOWP>(acc, lds, lane); break;
-    case 6: wgrad_wave<LIST, N, NSLOT, SLOT0, 6 % kBwdWaves, LOWP>(acc, lds, lane); break;
-    default: wgrad_wave<LIST, N, NSLOT, SLOT0, 7 % kBwdWaves, LOWP>(acc, lds, lane); break;
-  }
 }
 template <const auto& LIST, int N, int NSLOT, int SLOT0, int WAVE, int NACC>
 __device__ __forceinline__ void wgrad_flush_wave(const f32x4 (&acc)[NACC], const GradPtrs& gp, int lane) {

@@ -250,9 +250,11 @@ __host__ __device__ constexpr WgTile wg_decode(const WgList<N>& l, int tile) {
 // version decoded the tile at compile time per wave behind a switch over the wave id: four copies of a 15 KB unrolled
 // phase, each fetched by one wave only -- with 140..190 KB of code per kernel against a 64 KB instruction cache shared by
 // two CUs the phase was instruction-fetch-bound: 38 k cycles per tile, 20 k with one shared copy.)
-// dY rows a_row + min(j, a_last), X rows b_row + min(j, b_last): a lane past the matrix edge re-reads the last valid row and
-// fills accumulator rows / columns that wgrad_flush never writes out -- no masking of the operands needed
-struct WgEntry { int a_row, a_last, b_row, b_last; };
+// dY rows a_row + min(j, a_last), X rows b_row + min(j, b_last), stored as float offsets (row * kLD): a lane past the
+// matrix edge re-reads the last valid row and fills accumulator rows / columns that wgrad_flush never writes out -- no
+// masking of the operands needed.  One 16-byte entry = one s_load_dwordx4.
+struct alignas(16) WgEntry { int a_off, a_last, b_off, b_last; };
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
 template <int NSLOT>
 struct WgTab { WgEntry e[NSLOT * kBwdWaves]; };
 template <int N, int NSLOT>
@@ -261,8 +263,8 @@ __host__ __device__ constexpr WgTab<NSLOT> make_wgtab(const WgList<N>& l) {
   for (int s = 0; s < NSLOT; ++s)
     for (int w = 0; w < kBwdWaves; ++w) {
       const WgTile d = wg_decode(l, s * kBwdWaves + w);
-      t.e[s * kBwdWaves + w] = d.valid ? WgEntry{d.dy + d.o0, (d.OUT - d.o0 < 16 ? d.OUT - d.o0 : 16) - 1, d.x + d.i0,
-                                                 (d.IN - d.i0 < 16 ? d.IN - d.i0 : 16) - 1}
+      t.e[s * kBwdWaves + w] = d.valid ? WgEntry{(d.dy + d.o0) * kLD, ((d.OUT - d.o0 < 16 ? d.OUT - d.o0 : 16) - 1) * kLD,
+                                                 (d.x + d.i0) * kLD, ((d.IN - d.i0 < 16 ? d.IN - d.i0 : 16) - 1) * kLD}
                                        : WgEntry{0, 0, 0, 0};   // a slot past the list: any valid rows, never flushed
     }
   return t;
@@ -270,26 +272,47 @@ __host__ __device__ constexpr WgTab<NSLOT> make_wgtab(const WgList<N>& l) {
 template <const auto& LIST, int N, int NSLOT>
 __device__ const WgTab<NSLOT> g_wgtab = make_wgtab<N, NSLOT>(LIST);
 
+// The wave's rows of that table live in VGPRs for the whole kernel, slot s in lane s % 64 (field f of slots 64k .. 64k+63
+// in register r[f][k]); the phase pulls an entry out with four v_readlane.  No memory operation in the phase: scalar
+// loads share lgkmcnt with the LDS operand reads and return out of order, so waiting for one drains the others.
+template <int NSLOT>
+struct WgRegs { int r[4][(NSLOT + 63) / 64]; };
+template <const auto& LIST, int N, int NSLOT>
+__device__ __forceinline__ WgRegs<NSLOT> wgrad_table(int wave, int lane) {
+  WgRegs<NSLOT> t;
+  const i32x4_t* tab = reinterpret_cast<const i32x4_t*>(g_wgtab<LIST, N, NSLOT>.e);
+#pragma unroll
+  for (int k = 0; k < (NSLOT + 63) / 64; ++k) {
+    const int slot = min(64 * k + lane, NSLOT - 1);
+    const i32x4_t e = tab[slot * kBwdWaves + wave];
+    t.r[0][k] = e[0]; t.r[1][k] = e[1]; t.r[2][k] = e[2]; t.r[3][k] = e[3];
+  }
+  return t;
+}
+
 // accumulate every tile of the list this wave owns (slot s <-> tile s*kBwdWaves + wave); SLOT0 = first accumulator.
 // Slots are processed in groups of kWgGroup: all LDS operand reads of a group are issued first, then its MFMAs with
 // the group's independent accumulators interleaved (four 40-cycle dependent chains keep the 32-cycle issue rate).
 constexpr int kWgGroup = 4;
-template <const auto& LIST, int N, int NSLOT, int SLOT0, bool LOWP, int NACC>
-__device__ __forceinline__ void wgrad_all(f32x4 (&acc)[NACC], const float* lds, int wave, int lane) {
+template <int NSLOT, int SLOT0, bool LOWP, int NACC>
+__device__ __forceinline__ void wgrad_all(f32x4 (&acc)[NACC], const float* lds, const WgRegs<NSLOT>& tab, int lane) {
   static_assert(SLOT0 + NSLOT <= NACC, "accumulator slots");
   lane = opaque(lane);
   const int g = lane >> 4, j = lane & 15;
-  const WgEntry* tab = g_wgtab<LIST, N, NSLOT>.e + __builtin_amdgcn_readfirstlane(wave);
+  const int jrow = j * kLD;
+  const float* lane_base = lds + (LOWP ? 4 * g : g);
   static_for<(NSLOT + kWgGroup - 1) / kWgGroup>([&](auto gi) __attribute__((always_inline)) {
     constexpr int s0 = decltype(gi)::value * kWgGroup;
     float a[kWgGroup][4], b[kWgGroup][4];
     static_for<kWgGroup>([&](auto ui) __attribute__((always_inline)) {
       constexpr int u = decltype(ui)::value;
       if constexpr (s0 + u < NSLOT) {
-        const WgEntry e = tab[(s0 + u) * kBwdWaves];
+        constexpr int sl = s0 + u;
+        const int e0 = __builtin_amdgcn_readlane(tab.r[0][sl / 64], sl % 64), e1 = __builtin_amdgcn_readlane(tab.r[1][sl / 64], sl % 64);
+        const int e2 = __builtin_amdgcn_readlane(tab.r[2][sl / 64], sl % 64), e3 = __builtin_amdgcn_readlane(tab.r[3][sl / 64], sl % 64);
         // fp32: MFMA q contracts tokens 4q + g; bf16: the single MFMA takes tokens 4g .. 4g+3 from this lane
-        const float* pa = lds + (e.a_row + min(j, e.a_last)) * kLD + (LOWP ? 4 * g : g);
-        const float* pb = lds + (e.b_row + min(j, e.b_last)) * kLD + (LOWP ? 4 * g : g);
+        const float* pa = lane_base + (e0 + min(jrow, e1));
+        const float* pb = lane_base + (e2 + min(jrow, e3));
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           a[u][q] = pa[LOWP ? q : 4 * q];

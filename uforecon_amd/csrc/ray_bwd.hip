@@ -72,6 +72,8 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
   const float fS = (float)SN;
 
   f32x4 acc[kSlots2 + kSlots3];
+  const auto wg_tab2 = wgrad_table<rb::kList2, 6, kSlots2>(wave, lane);
+  const auto wg_tab3 = wgrad_table<rb::kList3, 2, kSlots3>(wave, lane);
 #pragma unroll
   for (int s = 0; s < kSlots2 + kSlots3; ++s) acc[s] = splat4(0.f);
   float accB = 0.f, accN1 = 0.f, accN2 = 0.f;
@@ -318,7 +320,7 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
           row[264 + k] = R(O_DQ + k)[col];
         }
       }
-      wgrad_all<rb::kList2, 6, kSlots2, 0, LOWP>(acc, lds, wave, lane);
+      wgrad_all<kSlots2, 0, LOWP>(acc, lds, wg_tab2, lane);
       __syncthreads();
     tid = opaque(tid0);
     }
@@ -384,7 +386,7 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
           row[352 + k] = R(O_DY + k)[col];
         }
       }
-      wgrad_all<rb::kList3, 2, kSlots3, kSlots2, LOWP>(acc, lds, wave, lane);
+      wgrad_all<kSlots3, kSlots2, LOWP>(acc, lds, wg_tab3, lane);
       __syncthreads();
     tid = opaque(tid0);
     }
@@ -421,6 +423,7 @@ __global__ void __launch_bounds__(kBwdThreads) presim_bwd_kernel(RawPtrs wp, Gra
   const int tid0 = threadIdx.x, wave = tid0 >> 6, lane = tid0 & 63;
   int tid = tid0;   // re-laundered after every barrier (bwd_common.h: opaque)
   f32x4 acc[2] = {splat4(0.f), splat4(0.f)};   // 8 tiles over the waves: at most 2 per wave
+  const auto wg_tab = wgrad_table<pb::kList, 3, 2>(wave, lane);
   float accB = 0.f;
   auto R = [&](int row) -> float* { return lds + row * kLD; };
   const int n_tiles = (P + kTT - 1) / kTT;
@@ -460,7 +463,7 @@ __global__ void __launch_bounds__(kBwdThreads) presim_bwd_kernel(RawPtrs wp, Gra
     if (tid < 16) accB += row_dot(R(O_DO + tid), nullptr, 0);
     else if (tid < 48) accB += row_dot(R(O_DA2 + (tid - 16)), nullptr, 0);
     else if (tid < 80) accB += row_dot(R(O_DA1 + (tid - 48)), nullptr, 0);
-    wgrad_all<pb::kList, 3, 2, 0, LOWP>(acc, lds, wave, lane);
+    wgrad_all<2, 0, LOWP>(acc, lds, wg_tab, lane);
     __syncthreads();
     tid = opaque(tid0);
   }

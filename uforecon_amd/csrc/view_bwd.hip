@@ -81,6 +81,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
   const float invL = 1.f / (float)L;
 
   f32x4 acc[kSlots];
+  const auto wg_tab = wgrad_table<vb::kList, 7, kSlots>(wave, lane);
 #pragma unroll
   for (int s = 0; s < kSlots; ++s) acc[s] = splat4(0.f);
   float accA = 0.f, accB = 0.f, accC = 0.f, accN1 = 0.f, accN2 = 0.f;   // small gradients, a few scalars per thread (see the flush)
@@ -494,7 +495,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     // ---------------- B12: weight gradients of the seven matrices on the MFMA, register-resident tiles;
     // the next tile's global inputs are requested first and land while these MFMAs run
     if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x, cur_in);
-    wgrad_all<vb::kList, 7, kSlots, 0, LOWP>(acc, lds, wave, lane);
+    wgrad_all<kSlots, 0, LOWP>(acc, lds, wg_tab, lane);
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 23)

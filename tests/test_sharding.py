@@ -126,3 +126,34 @@ def test_two_rank_bench_renders_the_one_rank_frame(tmp_path):
     assert line["n_gpus"] == 2 and len(line["config"]["per_rank"]) == 2
     for r in line["config"]["per_rank"]:
         assert r["rays"] == 32 * 96 and "view_transformer" in r["kernel_ms_per_frame"] and r["all_gather_ms_per_step"] >= 0
+
+
+@pytest.mark.gpu
+def test_bench_line_contract(tmp_path):
+    """One JSON line with the fields the driver and the review read (metric / value / unit / n_gpus / steps / warmup /
+    ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload, roofline, cpu_baseline,
+    gpu_eager_baseline), on a small frame so that it runs in seconds."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--height", "64", "--width", "96", "--steps", "2", "--warmup", "1",
+                        "--eager-chunks", "1"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "gpu_eager_baseline"):
+        assert k in d, k
+    assert d["unit"] == "rays/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["data"] == "synthetic" and d["dtype"] == "f32" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 64 * 96 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert abs(rf["peak"] - 2516.6 / 3) < 1e-6 and rf["kernel"] == "view_transformer_kernel" and rf["avg_launch_ms"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "rays/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert d["gpu_eager_baseline"]["value"] > 0 and abs(d["vs_baseline"] - d["value"] / d["gpu_eager_baseline"]["value"]) < 1e-6 * d["vs_baseline"]

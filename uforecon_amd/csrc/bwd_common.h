@@ -369,26 +369,42 @@ __device__ __forceinline__ void ln_forward(float* buf, float* out, const float* 
                                            const float* __restrict__ beta, float* rstd, int tid) {
   tid = opaque(tid);
   const int tok = tid / kTPT, sub = tid % kTPT;
+  // a thread's features stay in registers over the three passes (one LDS read each instead of three)
+  constexpr int NPT = (D + kTPT - 1) / kTPT;
+  float v[NPT];
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
+    const int f = sub + i * kTPT;
+    v[i] = f < D ? buf[f * kLD + tok] : 0.f;
+  }
   float s = 0.f;
-  for (int f = sub; f < D; f += kTPT) s += buf[f * kLD + tok];
+#pragma unroll
+  for (int i = 0; i < NPT; ++i)
+    if (sub + i * kTPT < D) s += v[i];
 #pragma unroll
   for (int d = kTPT / 2; d >= 1; d >>= 1) s += __shfl_xor(s, d);
   const float mean = s * (1.f / D);
   float q = 0.f;
-  for (int f = sub; f < D; f += kTPT) {
-    const float c = buf[f * kLD + tok] - mean;
-    q = fmaf(c, c, q);
-  }
+#pragma unroll
+  for (int i = 0; i < NPT; ++i)
+    if (sub + i * kTPT < D) {
+      const float c = v[i] - mean;
+      q = fmaf(c, c, q);
+    }
 #pragma unroll
   for (int d = kTPT / 2; d >= 1; d >>= 1) q += __shfl_xor(q, d);
   const float rs = 1.f / sqrtf(q * (1.f / D) + 1e-5f);
   if (sub == 0) rstd[tok] = rs;
-  for (int f = sub; f < D; f += kTPT) {
-    const float xh = (buf[f * kLD + tok] - mean) * rs;
-    buf[f * kLD + tok] = xh;
-    float y = fmaf(xh, gamma[f], beta[f]);
-    if (res) y += res[f * kLD + tok];
-    out[f * kLD + tok] = y;
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
+    const int f = sub + i * kTPT;
+    if (f < D) {
+      const float xh = (v[i] - mean) * rs;
+      buf[f * kLD + tok] = xh;
+      float y = fmaf(xh, gamma[f], beta[f]);
+      if (res) y += res[f * kLD + tok];
+      out[f * kLD + tok] = y;
+    }
   }
 }
 
@@ -397,11 +413,20 @@ __device__ __forceinline__ void ln_backward(const float* dout, const float* xhat
                                             const float* rstd, float* din, int tid) {
   tid = opaque(tid);
   const int tok = tid / kTPT, sub = tid % kTPT;
+  constexpr int NPT = (D + kTPT - 1) / kTPT;
+  float gg[NPT], xh[NPT];
   float s1 = 0.f, s2 = 0.f;
-  for (int f = sub; f < D; f += kTPT) {
-    const float gg = dout[f * kLD + tok] * gamma[f];
-    s1 += gg;
-    s2 = fmaf(gg, xhat[f * kLD + tok], s2);
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
+    const int f = sub + i * kTPT;
+    gg[i] = 0.f;
+    xh[i] = 0.f;
+    if (f < D) {
+      gg[i] = dout[f * kLD + tok] * gamma[f];
+      xh[i] = xhat[f * kLD + tok];
+      s1 += gg[i];
+      s2 = fmaf(gg[i], xh[i], s2);
+    }
   }
 #pragma unroll
   for (int d = kTPT / 2; d >= 1; d >>= 1) {
@@ -409,9 +434,10 @@ __device__ __forceinline__ void ln_backward(const float* dout, const float* xhat
     s2 += __shfl_xor(s2, d);
   }
   const float m1 = s1 * (1.f / D), m2 = s2 * (1.f / D), rs = rstd[tok];
-  for (int f = sub; f < D; f += kTPT) {
-    const float gg = dout[f * kLD + tok] * gamma[f];
-    din[f * kLD + tok] = rs * (gg - m1 - xhat[f * kLD + tok] * m2);
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
+    const int f = sub + i * kTPT;
+    if (f < D) din[f * kLD + tok] = rs * (gg[i] - m1 - xh[i] * m2);
   }
 }
 

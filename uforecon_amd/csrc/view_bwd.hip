@@ -192,6 +192,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
         float Qp[10], den = 0.f;
 #pragma unroll
         for (int d = 0; d < 10; ++d) Qp[d] = R(O_Q + 10 * h + d)[col];
+#pragma unroll 4
         for (int s = 0; s < L; ++s) {
           const int c2 = pt * L + s;
           float a = 0.f;
@@ -369,6 +370,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
           dm[d] = R(O_DMSG + 10 * h + d)[col];
           r[d] = 0.f;
         }
+#pragma unroll 4
         for (int s = 0; s < L; ++s) {
           const int c2 = pt * L + s;
           float a = 0.f;
@@ -382,6 +384,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
 #pragma unroll
         for (int e = 0; e < 10; ++e) du = fmaf(dm[e], r[e], du);
         dden = -du * u * u * invL;
+#pragma unroll 4
         for (int s = 0; s < L; ++s) {
           const int c2 = pt * L + s;
           float dA = dden;
@@ -415,6 +418,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
           Kp[d] = R(O_K + 10 * h + d)[col];
           V[d] = R(O_V + 10 * h + d)[col] * invL;
         }
+#pragma unroll 4
         for (int s = 0; s < L; ++s) {
           const int c2 = pt * L + s;
           const float u = R(O_U + h)[c2];

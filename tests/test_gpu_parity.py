@@ -321,3 +321,24 @@ def test_aggregate_rows_token_magnitudes(scale, weights):
     assert rel_err(dbg["ray_out"].reshape(RN, SN, 88), ref["ray_out"]) < 2e-5
     assert rel_err(srdf, srdf_ref) < 5e-5
     assert rel_err(radiance, rad_ref) < 2e-5
+
+
+def test_render_rays_16bit_matrix_mode(weights):
+    """ufr_set_matrix_precision(UFR_PRECISION_16BIT) (the mixed-precision training mode) through the whole forward path:
+    one fp16 plane per operand instead of the fp32-grade split -- depth within 2e-3 of the reference golden (measured
+    ~2e-4), clearly different from the default mode, and the default mode is back afterwards bit for bit."""
+    fr, idx, U1, U2, g, want = _oracle_rows("c2_hier_interior")
+    fh = _frame_handle(fr)
+    args = (idx.to(DEV), U1.to(DEV), U2.to(DEV))
+    ref = ops.render_rays(fh, weights, *args)["depth"].clone()
+    ops.set_matrix_precision(ops.PRECISION_16BIT)
+    try:
+        low = ops.render_rays(fh, weights, *args)["depth"].clone()
+    finally:
+        ops.set_matrix_precision(ops.PRECISION_FP32)
+    again = ops.render_rays(fh, weights, *args)["depth"]
+    torch.cuda.synchronize()
+    e_low = max_rel_elem(low, g["depth"], floor=1e-3)
+    assert e_low < 2e-3
+    assert e_low > 10 * max_rel_elem(ref, g["depth"], floor=1e-3)
+    assert torch.equal(again, ref)

@@ -13,6 +13,12 @@ frame overlap on side streams and a kernel's event interval includes its neighbo
 per-kernel durations are then taken from one extra, untimed, single-stream frame right after the
 timed region (same inputs, same launches); with --streams 1 they come from the timed region itself.
 
+After the timed configs[1] region, a single-GPU run also measures the other single-GPU configurations of BASELINE.json
+and attaches them to the same line as `secondary` (each entry a complete line of its own: value, ms_per_step, kernel
+split, `roofline`, `cpu_baseline`): configs[3] (5 views, 800x600, 128+128 samples; two frames) and the configs[4]
+training step (1024 rays, forward + backward + Adam) in both matrix precisions (tools/bench_train.py's loop).
+`--no-secondary` skips them.
+
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
@@ -43,7 +49,7 @@ PEAK_F16_MFMA_TFLOPS = 2516.6  # dense fp16 / bf16 MFMA peak: 256 CU x 4 SIMD x 
 PEAK_F32_VIA_F16X3_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3)
@@ -64,9 +70,12 @@ def parse():
                    help=">= 0: sampler uniforms are one seeded draw for the whole frame, sliced per rank (so an N-rank run "
                         "renders exactly the frame a 1-rank run renders); default: fresh GPU draws every step")
     p.add_argument("--dump-depth", default="", help="rank 0 writes the (gathered) H x W depth map of the last step here (.npy)")
+    p.add_argument("--no-secondary", action="store_true", help="skip the configs[3] / configs[4] measurements attached as "
+                                                                "`secondary` to a single-GPU line")
+    p.add_argument("--secondary-train-steps", type=int, default=10)
     p.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                                                       "exercise the multi-rank path on a box with fewer GPUs than ranks)")
-    return p.parse_args()
+    return p.parse_args(argv)
 
 
 def cpu_baseline(frame_cpu, weights_cpu, a):
@@ -124,30 +133,22 @@ def gpu_eager_baseline(frame_cpu, weights_cpu, a, dev):
                        f"(= {HW / RN * med:.1f} s per {a.height}x{a.width} frame)")
 
 
-def main():
-    a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+def config_name(a):
+    if (a.views, a.height, a.width, a.coarse, a.fine) == (3, 512, 640, 64, 64):
+        return "configs[1]"
+    if (a.views, a.height, a.width, a.coarse, a.fine) == (5, 600, 800, 128, 128):
+        return "configs[3]"
+    return "custom"
+
+
+def measure_frames(a, dev, world, rank):
+    """Time a.steps frames of the configuration in `a` (after a.warmup); returns the JSON line (rank 0) or None."""
+    import numpy as np
     import torch.distributed as dist
 
     from uforecon_amd import ops
     from uforecon_amd.dist import RayShard, all_gather_tiles
     from uforecon_amd.scene import make_frame
-
-    if os.environ.get("UFR_BENCH_SHARE_GPU"):      # diagnostics only: all ranks on one device (with --backend gloo)
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(a.backend)
-
-    import numpy as np
 
     wz = np.load(os.path.join(ROOT, "tests", "golden", "ray_path_weights_seed0.npz"))
     weights_cpu = {k: torch.from_numpy(wz[k]) for k in wz.files}
@@ -211,6 +212,7 @@ def main():
         fence()
     prof = ops.profile_read()
     ops.profile_enable(False)
+    ops.status_poll(True)        # an activation / weight outside the split-precision planes' range fails the run loudly
     per_rank = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -226,8 +228,10 @@ def main():
     if a.dump_depth and rank == 0:
         np.save(a.dump_depth, gathered[0].detach().cpu().numpy())
 
+    line = None
     if rank == 0:
         S = a.coarse + a.fine
+        cfg = config_name(a)
         # the reference evaluates coarse + (coarse + fine) samples per ray; this path keeps the coarse per-point
         # results and evaluates coarse + fine points (gathers, view transformer), coarse + (coarse + fine) ray-level
         ref_pts_per_ray = a.coarse + S
@@ -249,20 +253,23 @@ def main():
         rt_flop = RAYT_FLOP_PER_POINT * (RN * ray_evals_per_ray * prof_steps) / max(rt["launches"], 1)
         rt_achieved = rt_flop / (rt_ms * 1e-3) / 1e12 if rt_ms > 0 else 0.0
         traffic, traffic_src = None, None
-        try:  # HBM bytes per view-transformer launch from the latest committed PMC pass (profiles/rN_pmc.json)
+        try:  # HBM bytes per view-transformer launch from the latest committed PMC pass OF THIS CONFIGURATION
+            # (profiles/rN_pmc.json: configs[1]; profiles/rN_c4_pmc.json: configs[3], the L = 6 instantiation)
             import glob
-            pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))[-1]
+            pat = {"configs[1]": "r*[0-9]_pmc.json", "configs[3]": "r*_c4_pmc.json"}.get(cfg)
+            pj = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))[-1]
             for k, v in json.load(open(pj)).items():
-                if "view_transformer" in k and v.get("hbm_bytes_per_launch"):
+                if f"view_transformer_kernel<{a.views + 1}," in k and v.get("hbm_bytes_per_launch"):
                     traffic, traffic_src = v["hbm_bytes_per_launch"], os.path.relpath(pj, ROOT)
         except Exception:  # noqa: BLE001
             pass
         line = dict(
-            metric="rays/s (per-ray volume-rendering path, 64+64 hierarchical samples, DTU-shaped 3-view 512x640)",
+            metric=f"rays/s (per-ray volume-rendering path, {a.coarse}+{a.fine} hierarchical samples, DTU-shaped "
+                   f"{a.views}-view {a.height}x{a.width})",
             value=rays_per_s, unit="rays/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
             ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None,
             dtype="f32", data="synthetic",
-            config=dict(workload=f"configs[1]: full {a.height}x{a.width} frame = {HW} rays, {a.views} source views, "
+            config=dict(workload=f"{cfg}: full {a.height}x{a.width} frame = {HW} rays, {a.views} source views, "
                                  f"{a.coarse}+{a.fine} samples, rays sharded by row tiles over {world} GPU(s), depth/RGB "
                                  f"tiles all-gathered",
                         rays_per_frame=HW, chunk_rays=chunk, side_streams=a.streams, depth_map_ms_per_frame=dt / a.steps * 1e3,
@@ -305,6 +312,55 @@ def main():
                                                          "path on this GPU, 800-ray chunks (BASELINE.md section 3)")
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(frame_cpu, weights_cpu, a)
+    del frame, out, ws, W, gathered, fixed
+    torch.cuda.empty_cache()
+    return line
+
+
+def secondary_measurements(a, dev):
+    """The other single-GPU configurations of BASELINE.json, measured in the same process after the headline run."""
+    sec = {}
+    c3 = parse(["--views", "5", "--height", "600", "--width", "800", "--coarse", "128", "--fine", "128", "--steps", "2",
+                "--warmup", "1", "--streams", str(a.streams), "--cpu-rays", "64", "--cpu-calls", "2", "--eager-chunks", "2"])
+    c3.no_cpu_baseline, c3.no_gpu_eager_baseline = a.no_cpu_baseline, a.no_gpu_eager_baseline
+    sec["configs[3]"] = measure_frames(c3, dev, 1, 0)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_train
+
+    for prec in ("fp32", "16bit"):
+        ta = bench_train.parse(["--steps", str(a.secondary_train_steps), "--warmup", "2", "--precision", prec]
+                               + (["--no-cpu-baseline"] if (a.no_cpu_baseline or prec == "16bit") else []))
+        sec[f"configs[4]_{prec}"] = bench_train.run(ta, dev, 1, 0)
+        torch.cuda.empty_cache()
+    # the CPU leg has one arithmetic (fp32): the 16-bit entry points at the fp32 entry's measurement
+    if "cpu_baseline" in sec["configs[4]_fp32"]:
+        sec["configs[4]_16bit"]["cpu_baseline"] = dict(sec["configs[4]_fp32"]["cpu_baseline"],
+                                                       note="same measurement as configs[4]_fp32 (the oracle is fp32)")
+    return sec
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    import torch.distributed as dist
+
+    if os.environ.get("UFR_BENCH_SHARE_GPU"):      # diagnostics only: all ranks on one device (with --backend gloo)
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
+    line = measure_frames(a, dev, world, rank)
+    if rank == 0:
+        if world == 1 and not a.no_secondary and config_name(a) == "configs[1]":
+            line["secondary"] = secondary_measurements(a, dev)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -24,10 +24,15 @@ typedef void* ufr_stream; /* hipStream_t */
 
 enum ufr_status {
   UFR_OK = 0,
-  UFR_ERR_ARG = -1,      /* bad shape / null pointer / unsupported size */
-  UFR_ERR_HIP = -2,      /* a HIP runtime call failed */
-  UFR_ERR_WORKSPACE = -3 /* workspace too small */
+  UFR_ERR_ARG = -1,       /* bad shape / null pointer / unsupported size */
+  UFR_ERR_HIP = -2,       /* a HIP runtime call failed */
+  UFR_ERR_WORKSPACE = -3, /* workspace too small */
+  UFR_ERR_RANGE = -4      /* a value left the range the split-precision planes can hold (see ufr_status_poll) */
 };
+
+/* Version of this header's ABI (argument lists, struct layouts, packed-blob layout).  ufr_version() returns the value
+ * the library was built with: a binding must refuse a library whose version differs (uforecon_amd/_lib.py does). */
+#define UFR_ABI_VERSION 300
 
 #define UFR_MAX_VIEWS 7
 #define UFR_NUM_STAGES 3
@@ -62,17 +67,36 @@ typedef struct ufr_raw_weights {
   const float* variance;      /* deviation_network.variance, scalar          (single_variance_network.py:8) */
 } ufr_raw_weights;
 
-/* Matrix precision of the dense layers, process-wide (read at launch time by every entry point below).
- *   UFR_PRECISION_FP32  (default) fp32-grade: every product as three fp16 plane products, fp32 accumulate; the backward
+/* Matrix precision of the dense layers.  Every entry point that runs dense layers takes a `precision` argument
+ * (ufr_render_args has a field); the forward and the backward of one training step must be given the same value
+ * (uforecon_amd/autograd.py records the forward's in the autograd context).
+ *   UFR_PRECISION_DEFAULT the process default, FP32 unless ufr_set_matrix_precision changed it (a convenience for
+ *                       command-line tools; library code that pairs a forward with a backward passes an explicit mode)
+ *   UFR_PRECISION_FP32  fp32-grade: every product as three fp16 plane products, fp32 accumulate; the backward
  *                       kernels on the fp32 matrix instructions.  This is the mode all 1e-4 parity statements refer to.
  *   UFR_PRECISION_16BIT the "bf16" training mode of the reference's mixed-precision recipe (BASELINE configs[4]): one
  *                       16-bit plane per operand (fp16 hi planes in the forward, bf16 operands in the backward GEMMs and
  *                       weight gradients), fp32 accumulation, LayerNorm / attention / softmax / compositor in fp32.
  *                       Tolerance: 2e-3 of scale on forward rows, 3e-2 on gradients (tests/test_gpu_backward.py). */
+#define UFR_PRECISION_DEFAULT (-1)
 #define UFR_PRECISION_FP32 0
 #define UFR_PRECISION_16BIT 1
-int ufr_set_matrix_precision(int mode);
+int ufr_set_matrix_precision(int mode); /* sets what UFR_PRECISION_DEFAULT resolves to (FP32 or 16BIT) */
 int ufr_get_matrix_precision(void);
+
+/* Sticky range status of the current device.  The split-precision planes hold |weight| < 255.8 and |activation| < 4094
+ * (fp16 after the power-of-two plane scales); the kernels never synchronise, so a violation raises a device-side
+ * sticky flag instead of failing the launch:
+ *   bit 0  a dense-layer input of a transformer kernel reached |x| >= 4094 (its planes overflowed)
+ *   bit 1  a transformer kernel produced a non-finite output row (NaN / inf tokens, srdf)
+ *   bit 2  ufr_weights_pack met a weight that is not finite or |w| >= 255.8
+ * ufr_status_poll copies the flag to the host on `stream`; with synchronize != 0 it waits for the stream and returns
+ * UFR_ERR_RANGE (message: which bits) when the flag is set, clearing it.  Without synchronize it returns what an
+ * EARLIER poll / launch has already delivered.  ufr_render_rays, ufr_aggregate, ufr_view_transform and
+ * ufr_ray_transform poll lazily: each enqueues the copy after its kernels and fails with UFR_ERR_RANGE on entry when a
+ * previous call's copy arrived set -- one call late, without a host synchronisation in the ray loop.  `flags_out`
+ * (nullable) receives the bits. */
+int ufr_status_poll(ufr_stream stream, int32_t synchronize, int32_t* flags_out);
 
 /* Re-orders the dense matrices into MFMA A-fragment order (one 16x16 output tile x 16
  * input features = 64 lanes x float4, zero padded) so the kernels stream them with
@@ -89,8 +113,9 @@ int ufr_pack_plan(int32_t* param_id, int32_t* elem);
  * planes per weight (hi = fp16(256 w), lo = fp16(256 w - hi); plane 0/1) for the split-precision MFMA path;
  * ufr_pack_plan_f16 describes it like ufr_pack_plan (one entry per halfword, plus the plane).  Of the fp32 region
  * ufr_weights_pack fills only the trailing vector fragments (biases, LayerNorm, view token): the kernels read nothing
- * else of it.  ufr_weights_pack synchronises the stream and fails with UFR_ERR_ARG when a dense-layer weight is not
- * finite or |w| >= 255.8 (outside the fp16 planes' range). */
+ * else of it.  ufr_weights_pack does not synchronise: a dense-layer weight that is not finite or |w| >= 255.8 (outside
+ * the fp16 planes' range) raises bit 2 of the sticky status -- call ufr_status_poll(stream, 1, ...) after packing to
+ * fail at once (uforecon_amd.ops.PackedWeights does), or let the next compute entry point report it. */
 size_t ufr_packed_fp32_floats(void);
 size_t ufr_packed_f16_halfwords(void);
 int ufr_pack_plan_f16(int32_t* param_id, int32_t* elem, int32_t* plane);
@@ -166,12 +191,14 @@ int ufr_project_gather(const ufr_frame* frame, const ufr_raw_weights* raw, const
 size_t ufr_aggregate_workspace_bytes(int32_t RN, int32_t SN, int32_t NV);
 int ufr_aggregate(const void* packed_weights, const float* x_tokens, const float* rgb, const float* dir,
                   int32_t RN, int32_t SN, int32_t NV, float* radiance, float* srdf, void* workspace,
-                  float* view_out, float* ray_out, ufr_stream stream);
+                  float* view_out, float* ray_out, int32_t precision, ufr_stream stream);
 
 /* VolumeRenderer.render (encoder_utils/renderer.py:7-48) with SingleVarianceNetwork
  * (single_variance_network.py:10-11).  z,srdf: (RN,SN); radiance: (RN,SN,3); variance: device scalar.
+ * row (nullable, (RN,SN) int32): the colour of slot (ray, s) is radiance[row[ray][s]] -- the sample pool of the two-pass
+ * step (ufr_sample_importance_pool); NULL = slot order.
  * Outputs: rgb (RN,3), depth (RN), opacity (RN), weight (RN,SN); any may be NULL except depth. */
-int ufr_composite(const float* z, const float* radiance, const float* srdf, const float* variance,
+int ufr_composite(const float* z, const float* radiance, const int32_t* row, const float* srdf, const float* variance,
                   int32_t RN, int32_t SN, float* rgb, float* depth, float* opacity, float* weight,
                   ufr_stream stream);
 
@@ -189,11 +216,13 @@ typedef struct ufr_raw_grads {
 } ufr_raw_grads;
 
 /* Adjoint of ufr_composite (autograd of renderer.py:19-46).  d_rgb (RN,3), d_depth (RN), d_opacity (RN),
- * d_weight (RN,SN): gradients of the outputs, any may be NULL (= zero).  Outputs: d_radiance (RN,SN,3),
+ * d_weight (RN,SN): gradients of the outputs, any may be NULL (= zero).  Outputs: d_radiance (rows as `radiance`: slot
+ * order, or pool rows through `row`; overwritten, or added to when accumulate != 0 -- every row is touched once per call),
  * d_srdf (RN,SN) (overwritten); d_variance: device scalar, ACCUMULATED. */
-int ufr_composite_bwd(const float* z, const float* radiance, const float* srdf, const float* variance, int32_t RN,
-                      int32_t SN, const float* d_rgb, const float* d_depth, const float* d_opacity,
-                      const float* d_weight, float* d_radiance, float* d_srdf, float* d_variance, ufr_stream stream);
+int ufr_composite_bwd(const float* z, const float* radiance, const int32_t* row, const float* srdf, const float* variance,
+                      int32_t RN, int32_t SN, const float* d_rgb, const float* d_depth, const float* d_opacity,
+                      const float* d_weight, float* d_radiance, int32_t accumulate, float* d_srdf, float* d_variance,
+                      ufr_stream stream);
 
 /* Adjoint of ufr_aggregate (autograd of ray_transformer.py:283-320).  x_tokens / rgb / dir: the forward's inputs;
  * token0 (P,80): the view transformer's token-0 output = the first RN*SN*80 floats of the forward's workspace;
@@ -206,7 +235,7 @@ size_t ufr_aggregate_bwd_workspace_bytes(int32_t RN, int32_t SN, int32_t NV);
 int ufr_aggregate_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const float* x_tokens, const float* rgb,
                       const float* dir, const float* token0, int32_t RN, int32_t SN, int32_t NV,
                       const float* d_radiance, const float* d_srdf, float* d_pv, void* workspace, float* debug_view,
-                      float* debug_ray, ufr_stream stream);
+                      float* debug_ray, int32_t precision, ufr_stream stream);
 
 /* Adjoint of ufr_project_gather w.r.t. the sampled volumes and pre_sim_mlp (autograd of model.py:350-390 and
  * ray_transformer.py:268).  sim8 (P,8): the forward's `sim8` output; d_pv (P,40) from ufr_aggregate_bwd.
@@ -215,7 +244,7 @@ int ufr_aggregate_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, co
 int ufr_project_gather_bwd(const ufr_frame* frame, const ufr_raw_weights* raw, const ufr_raw_grads* grads,
                            const float* ray_o, int32_t ray_o_stride, const float* ray_d, const float* z, int32_t RN,
                            int32_t SN, const float* sim8, const float* d_pv, float* const* grad_vol_feat,
-                           float* const* grad_vol_weight, ufr_stream stream);
+                           float* const* grad_vol_weight, int32_t precision, ufr_stream stream);
 
 /* ------------------------------------------------------------------ the two halves of ufr_aggregate, and the sample pool
  * The fine pass of `infer` (model.py:455-473) re-evaluates all SN+PN merged samples, but a sample's gathers and
@@ -225,22 +254,25 @@ int ufr_project_gather_bwd(const ufr_frame* frame, const ufr_raw_weights* raw, c
  *   ufr_sample_importance_pool = ufr_sample_importance_merge that also returns the new positions z_new (RN,PN), in draw
  *     order, and for every merged slot its row in the pool [RN*SN coarse rows (ray-major) | RN*PN new rows]: row (RN,SN+PN) int32;
  *   ufr_view_transform / ufr_ray_transform = the view-transformer and ray-transformer halves of ufr_aggregate
- *     (token0 (P,80), radiance (P,3) | token0 rows of the RN*SN samples in slot order -> srdf (RN,SN));
+ *     (token0 (P,80), radiance (P,3) | token0 rows of the RN*SN samples -> srdf (RN,SN)); `row` (nullable, (RN,SN) int32)
+ *     maps slot (ray, s) to its row of token0 (NULL = slot order), so the fine pass reads the pool in place;
  *   ufr_view_transform_bwd / ufr_ray_transform_bwd = the corresponding halves of ufr_aggregate_bwd (d_token0 comes out
- *     as two partial buffers of the ray kernel's sweeps; pass both to ufr_view_transform_bwd or add them). */
+ *     as two partial buffers of the ray kernel's sweeps, written at the same rows `row` names -- overwritten, or added to
+ *     when accumulate != 0 (the coarse pass adds its cotangents onto the fine pass's coarse rows); pass both buffers to
+ *     ufr_view_transform_bwd). */
 int ufr_sample_importance_pool(const float* weight, const float* z, const float* U2, float* z_all, float* z_new,
                                int32_t* row, int32_t RN, int32_t SN, int32_t PN, ufr_stream stream);
 int ufr_view_transform(const void* packed_weights, const float* x_tokens, const float* rgb, const float* dir, int32_t P,
-                       int32_t NV, float* token0, float* radiance, ufr_stream stream);
+                       int32_t NV, float* token0, float* radiance, int32_t precision, ufr_stream stream);
 size_t ufr_ray_transform_workspace_bytes(int32_t SN);
-int ufr_ray_transform(const void* packed_weights, const float* token0, int32_t RN, int32_t SN, float* srdf,
-                      void* workspace, ufr_stream stream);
-int ufr_ray_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const float* token0, int32_t RN,
-                          int32_t SN, const float* d_srdf, float* d_token0_a, float* d_token0_b, void* workspace,
-                          ufr_stream stream);
+int ufr_ray_transform(const void* packed_weights, const float* token0, const int32_t* row, int32_t RN, int32_t SN,
+                      float* srdf, void* workspace, int32_t precision, ufr_stream stream);
+int ufr_ray_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const float* token0, const int32_t* row,
+                          int32_t RN, int32_t SN, const float* d_srdf, float* d_token0_a, float* d_token0_b,
+                          int32_t accumulate, void* workspace, int32_t precision, ufr_stream stream);
 int ufr_view_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const float* x_tokens, const float* rgb,
                            const float* dir, const float* d_token0_a, const float* d_token0_b, const float* d_radiance,
-                           int32_t P, int32_t NV, float* d_pv, ufr_stream stream);
+                           int32_t P, int32_t NV, float* d_pv, int32_t precision, ufr_stream stream);
 
 /* ------------------------------------------------------------------ whole-path inference
  * UFORecon.infer(extract_geometry=True) (model.py:393-478) for RN rays of one frame:
@@ -259,6 +291,7 @@ typedef struct ufr_render_args {
   const float* U2;            /* (PN,RN) importance uniforms; NULL if coarse_only (sampler.py:86) */
   int32_t RN, SN, PN;         /* rays, coarse samples, fine samples                        */
   int32_t coarse_only;        /* args.test_coarse_only                  (model.py:449-452) */
+  int32_t precision;          /* UFR_PRECISION_*                                           */
   /* outputs (device) */
   float* depth;               /* (RN) ray-length depth                                     */
   float* depth_z;             /* (RN) depth * cam_ray_d.z (model.py:821), may be NULL      */

@@ -9,7 +9,7 @@ int main(void) {
   /* link-time presence of every entry point */
   const void* syms[] = {
       (const void*)ufr_version, (const void*)ufr_last_error, (const void*)ufr_set_matrix_precision,
-      (const void*)ufr_get_matrix_precision, (const void*)ufr_packed_weights_bytes, (const void*)ufr_weights_pack,
+      (const void*)ufr_get_matrix_precision, (const void*)ufr_status_poll, (const void*)ufr_packed_weights_bytes, (const void*)ufr_weights_pack,
       (const void*)ufr_pack_plan, (const void*)ufr_packed_fp32_floats, (const void*)ufr_packed_f16_halfwords,
       (const void*)ufr_pack_plan_f16, (const void*)ufr_frame_workspace_bytes, (const void*)ufr_frame_prepare,
       (const void*)ufr_sample_fixed, (const void*)ufr_sample_importance_merge, (const void*)ufr_points,
@@ -24,7 +24,7 @@ int main(void) {
   unsigned i, n = sizeof(syms) / sizeof(syms[0]);
   for (i = 0; i < n; ++i)
     if (!syms[i]) return 10;
-  if (ufr_version() < 100) return 11;
+  if (ufr_version() != UFR_ABI_VERSION) return 11;
   if (ufr_get_matrix_precision() != UFR_PRECISION_FP32 || ufr_set_matrix_precision(7) == 0) return 15;
   /* argument validation: negative status + message, no device needed */
   if (ufr_sample_fixed(0, 0, 0, 0, 4, 64, 0) >= 0) return 12;
@@ -32,8 +32,10 @@ int main(void) {
   if (ufr_tsdf_integrate(0, 0, 0, 0, 0, 1.f, 1.f, 0, 0, 0, 0, 4, 4, 1.f, 0, 0) >= 0) return 14;
   if (ufr_deform_conv2d(0, 0, 0, 0, 0, 0, 1, 32, 32, 8, 8, 0, 0, 0) >= 0) return 15;
   if (ufr_render_workspace_bytes(4096, 64, 64, 3) == 0) return 16;
-  if (ufr_composite_bwd(0, 0, 0, 0, 4, 64, 0, 0, 0, 0, 0, 0, 0, 0) >= 0) return 18;
-  if (ufr_aggregate_bwd(0, 0, 0, 0, 0, 0, 4, 64, 3, 0, 0, 0, 0, 0, 0, 0) >= 0) return 19;
+  if (ufr_composite_bwd(0, 0, 0, 0, 0, 4, 64, 0, 0, 0, 0, 0, 0, 0, 0, 0) >= 0) return 18;
+  if (ufr_aggregate_bwd(0, 0, 0, 0, 0, 0, 4, 64, 3, 0, 0, 0, 0, 0, 0, UFR_PRECISION_DEFAULT, 0) >= 0) return 19;
+  /* an unknown precision is an argument error, not a silent default */
+  if (ufr_view_transform((const void*)1, (const float*)1, (const float*)1, (const float*)1, 4, 3, (float*)1, (float*)1, 7, 0) != UFR_ERR_ARG) return 21;
   if (ufr_aggregate_bwd_workspace_bytes(1024, 128, 3) == 0) return 20;
   if (ufr_correlate_workspace_bytes(32, 128, 160, 2) == 0) return 17;
   printf("abi ok: %u entry points, version %d, %zu packed weight bytes\n", n, ufr_version(), ufr_packed_weights_bytes());

@@ -40,7 +40,34 @@ CASES = {
     "c4_nv5_interior": dict(H=48, W=64, NV=5, seed=8, RN=48, coarse=64, fine=64, interior=True),
     # training layout (s_idx=1, no near/far division), forward only
     "c5_train_fwd": dict(H=64, W=96, NV=3, seed=5, RN=64, coarse=64, fine=64, train=True),
+    # configs[1] at the full 512x640 frame on rays strictly inside every source image: depth AND RGB on 100 % of the rays
+    "c2_hier_512x640_interior": dict(H=512, W=640, NV=3, seed=0, RN=256, coarse=64, fine=64, interior=True),
+    # statistics of a TRAINED checkpoint instead of the default init (the real checkpoint is absent: .MISSING_LARGE_BLOBS):
+    # every weight matrix x 8, LayerNorm gains up to 10 and biases in [-1, 1], 2-D feature maps x 30 -- dense-layer inputs
+    # reach ~1e3 (the split-precision planes hold |x| < 4094, |w| < 255.8).  The modified weights travel in the fixture.
+    "c2_trained_like": dict(H=64, W=96, NV=3, seed=9, RN=128, coarse=64, fine=64, interior=True,
+                            trained_like=dict(w=8.0, gamma=10.0, feat=30.0)),
 }
+
+
+def apply_trained_like(model, fr, t, seed=11):
+    """In-place: the 'trained-like' statistics of a case (see CASES['c2_trained_like']); the same function serves the tests
+    (on the oracle's parameter dict via `params=`)."""
+    g = torch.Generator().manual_seed(seed)
+    named = model if isinstance(model, dict) else dict(model.named_parameters())
+    with torch.no_grad():
+        for k in sorted(named):
+            p = named[k]
+            if not k.startswith("ray_transformer.") or "view_token" in k:
+                continue
+            if p.dim() > 1:
+                p.mul_(t["w"])
+            elif "norm" in k and k.endswith("weight"):
+                p.copy_(0.5 + (t["gamma"] - 0.5) * torch.rand(p.shape, generator=g))
+            elif "norm" in k and k.endswith("bias"):
+                p.copy_(torch.rand(p.shape, generator=g) * 2 - 1)
+        fr.source_imgs_feat.mul_(t["feat"])
+        fr.match_feature[0].mul_(t["feat"])
 
 # reference autograd of the training loss (model.py:552-566) through infer(extract_geometry=False): gradients of every
 # per-ray parameter and of the six sampled volumes (SURVEY.md appendix C) -- BASELINE.json configs[4]
@@ -132,10 +159,16 @@ def run_case(name, c, weight_seed=0, sampler_seed=1):
                                   test_coarse_only=c.get("coarse_only", False), test_n_view=c["NV"],
                                   extract_geometry=not train)
     fr = make_frame(c["H"], c["W"], c["NV"], c["seed"], train_layout=train)
+    dig = frame_digest(fr)          # of the seeded frame, before any trained-like scaling
+    if c.get("trained_like"):
+        apply_trained_like(model, fr, c["trained_like"])
     idx = (clean_ray_indices(model, fr, c["H"], c["W"], c["RN"], sampler_seed, train) if c.get("interior")
            else ray_indices(c["H"], c["W"], c["RN"]))
-    out = {"input_digest": np.float64(frame_digest(fr)), "ray_idx": idx.numpy(),
+    out = {"input_digest": np.float64(dig), "ray_idx": idx.numpy(),
            "sampler_seed": np.int64(sampler_seed), "weight_seed": np.int64(weight_seed)}
+    if c.get("trained_like"):
+        for k, v in ray_path_state_dict(model).items():
+            out["weights." + k] = v.numpy()
     cap = {}
     hooks = []
     if c.get("rows"):
@@ -208,8 +241,6 @@ def run_case(name, c, weight_seed=0, sampler_seed=1):
                  "rgb_2", "depth_2", "srdf_2", "opacity_2", "weight_2", "points_in_pixel_2",
                  "z_val", "z_val_all", "variance"]
         for n, v in zip(names, r):
-            if n.startswith("points_in_pixel"):
-                continue
             out[n] = v.detach().numpy()
     else:
         srdf, pts, depth, rgb = r

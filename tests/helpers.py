@@ -21,6 +21,9 @@ CASES = {
     "c5_train_fwd": dict(H=64, W=96, NV=3, seed=5, RN=64, coarse=64, fine=64, train=True),
     "c2_hier_interior": dict(H=64, W=96, NV=3, seed=7, RN=256, coarse=64, fine=64, interior=True),
     "c4_nv5_interior": dict(H=48, W=64, NV=5, seed=8, RN=48, coarse=64, fine=64, interior=True),
+    "c2_hier_512x640_interior": dict(H=512, W=640, NV=3, seed=0, RN=256, coarse=64, fine=64, interior=True),
+    "c2_trained_like": dict(H=64, W=96, NV=3, seed=9, RN=128, coarse=64, fine=64, interior=True,
+                            trained_like=dict(w=8.0, gamma=10.0, feat=30.0)),
 }
 
 # same table as tests/golden/make_golden.py:GRAD_CASES (reference autograd of the training loss)
@@ -53,12 +56,26 @@ def case_frame(name: str):
     return make_frame(c["H"], c["W"], c["NV"], c["seed"], train_layout=c.get("train", False))
 
 
+def case_weights(name: str) -> dict:
+    """The per-ray parameters of a case: the seed-0 default init, or the modified set a 'trained-like' fixture carries."""
+    if CASES[name].get("trained_like"):
+        g = load_golden(name)
+        return {k[len("weights."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("weights.")}
+    return load_weights()
+
+
 def case_inputs(name: str):
     """(frame, ray_idx (1,RN) int64, U1 (coarse,RN), U2 (fine,RN), golden dict)."""
     c = CASES[name]
     g = load_golden(name)
     fr = case_frame(name)
-    dig = frame_digest(fr)
+    if c.get("trained_like") and not getattr(fr, "_scaled", False):   # feature maps x feat (make_golden.apply_trained_like)
+        fr = make_frame(c["H"], c["W"], c["NV"], c["seed"], train_layout=c.get("train", False))
+        dig = frame_digest(fr)
+        fr.source_imgs_feat.mul_(c["trained_like"]["feat"])
+        fr.match_feature[0].mul_(c["trained_like"]["feat"])
+    else:
+        dig = frame_digest(fr)
     if abs(dig - float(g["input_digest"])) > 1e-9 * abs(dig):
         import pytest
 

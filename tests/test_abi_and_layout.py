@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ufr_version() >= 100
+    assert lib.ufr_version() == _lib.ABI_VERSION
 
 
 def test_struct_sizes_match_the_header(lib):
@@ -52,15 +52,15 @@ def test_argument_errors_are_reported_not_fatal(lib):
     d.NV = 9
     assert lib.ufr_frame_workspace_bytes(C.byref(d)) == 0
     assert b"NV=9" in lib.ufr_last_error()
-    assert lib.ufr_aggregate(None, None, None, None, 4, 60, 3, None, None, None, None, None, None) == -1
+    assert lib.ufr_aggregate(None, None, None, None, 4, 60, 3, None, None, None, None, None, -1, None) == -1
     fr = _lib.Frame()  # never prepared -> magic missing
     assert lib.ufr_project_gather(C.byref(fr), None, None, 0, None, None, 1, 16, None, None, None, None, None, None,
                                   None, None, None, None) == -1
     assert b"not prepared" in lib.ufr_last_error()
-    assert lib.ufr_composite_bwd(None, None, None, None, 4, 64, None, None, None, None, None, None, None, None) == -1
-    assert lib.ufr_aggregate_bwd(None, None, None, None, None, None, 4, 64, 3, None, None, None, None, None, None, None) == -1
+    assert lib.ufr_composite_bwd(None, None, None, None, None, 4, 64, None, None, None, None, None, 0, None, None, None) == -1
+    assert lib.ufr_aggregate_bwd(None, None, None, None, None, None, 4, 64, 3, None, None, None, None, None, None, -1, None) == -1
     assert b"null" in lib.ufr_last_error()
-    assert lib.ufr_project_gather_bwd(C.byref(fr), None, None, None, 0, None, None, 1, 16, None, None, None, None, None) == -1
+    assert lib.ufr_project_gather_bwd(C.byref(fr), None, None, None, 0, None, None, 1, 16, None, None, None, None, -1, None) == -1
     assert b"not prepared" in lib.ufr_last_error()
 
 

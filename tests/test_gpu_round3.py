@@ -1,0 +1,237 @@
+"""GPU tests of the round-3 boundary work: per-call matrix precision, the sticky range status of the split-precision
+planes, the sample pool inside the kernels, the full-size interior fixture and the trained-like statistics fixture."""
+import argparse
+
+import pytest
+import torch
+
+from helpers import (CASES, REL_TOL, border_degenerate_rays, case_inputs, case_weights, load_weights, max_rel_elem,
+                     rel_err)
+from oracle import ufo_oracle as O
+from uforecon_amd import model as M
+from uforecon_amd import ops
+from uforecon_amd._lib import UfrError
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def weights():
+    return ops.PackedWeights({k: v.to(DEV) for k, v in load_weights().items()})
+
+
+def _frame_handle(fr):
+    f = fr.to(DEV)
+    return ops.FrameHandle(f.batch, f.source_imgs_feat, f.feature_volume, f.match_feature)
+
+
+def _args(**kw):
+    a = dict(extract_geometry=False, coarse_sample=64, fine_sample=64, test_sample_coarse=64, test_sample_fine=64)
+    a.update(kw)
+    return argparse.Namespace(**a)
+
+
+# ------------------------------------------------------------------------------------------------ parity fixtures
+def test_full_size_frame_interior_rays(weights):
+    """configs[1] at the full 512x640 frame on rays none of whose samples comes within 1e-4 of a source-image border
+    (selected by probing the reference, make_golden.clean_ray_indices): depth AND RGB within 1e-4 on 100 % of the rays,
+    merged sample positions within 1e-5, srdf within 1e-4 of its scale at the golden's own sample positions."""
+    name = "c2_hier_512x640_interior"
+    fr, idx, U1, U2, g = case_inputs(name)
+    fh = _frame_handle(fr)
+    out = ops.render_rays(fh, weights, idx.to(DEV), U1.to(DEV), U2.to(DEV))
+    torch.cuda.synchronize()
+    assert max_rel_elem(out["depth"], g["depth"], floor=1e-3) < REL_TOL
+    assert max_rel_elem(out["rgb"], g["rgb"], floor=0.05) < REL_TOL
+    z_ref = (torch.from_numpy(g["points"]) - fr.batch["ray_o"][0]).norm(dim=-1)
+    assert rel_err(out["z_all"], z_ref) < 1e-5
+    i = idx.reshape(-1)
+    ray_d = fr.batch["ray_d"][0][:, i].t().contiguous()
+    RN, SN = z_ref.shape
+    x, rgbm, dirs = ops.project_gather(fh, weights, fr.batch["ray_o"][0].contiguous().to(DEV), ray_d.to(DEV),
+                                       z_ref.to(DEV).contiguous())[:3]
+    srdf = ops.aggregate(weights, x, rgbm, dirs, RN, SN)[1]
+    assert rel_err(srdf.reshape(RN, SN), g["srdf"]) < 1e-4
+    assert ops.status_poll(True) == 0
+
+
+def test_trained_like_statistics():
+    """A checkpoint-like parameter set (every matrix x 8, LayerNorm gains up to 10, biases in [-1,1]) on feature maps x 30:
+    dense-layer inputs reach ~1e3, three orders of magnitude above the default init, still inside the split-precision
+    planes' range (|x| < 4094, |w| < 255.8).  The reference itself amplifies rounding here (the srdf head has gain ~1e3),
+    so the oracle on this host is the yardstick: the kernels must be as close to the reference's golden as the oracle is
+    (within a factor), and the range status must stay clear."""
+    name = "c2_trained_like"
+    fr, idx, U1, U2, g = case_inputs(name)
+    P = case_weights(name)
+    with torch.no_grad():
+        _, _, d_o, c_o = O.infer(P, fr.batch, idx, fr.source_imgs_feat, fr.feature_volume, fr.match_feature, U1, U2)
+    W = ops.PackedWeights({k: v.to(DEV) for k, v in P.items()})
+    out = ops.render_rays(_frame_handle(fr), W, idx.to(DEV), U1.to(DEV), U2.to(DEV))
+    assert ops.status_poll(True) == 0
+    e_oracle_d = max_rel_elem(d_o.reshape(-1), g["depth"], floor=1e-3)
+    e_oracle_c = max_rel_elem(c_o.reshape(-1, 3), g["rgb"], floor=0.05)
+    e_d = max_rel_elem(out["depth"], g["depth"], floor=1e-3)
+    e_c = max_rel_elem(out["rgb"], g["rgb"], floor=0.05)
+    print(f"trained-like: depth err {e_d:.2e} (oracle {e_oracle_d:.2e}), rgb err {e_c:.2e} (oracle {e_oracle_c:.2e})")
+    assert bool(torch.isfinite(out["depth"]).all()) and bool(torch.isfinite(out["rgb"]).all())
+    assert e_d < max(REL_TOL, 4 * e_oracle_d)
+    assert e_c < max(REL_TOL, 4 * e_oracle_c)
+
+
+# ------------------------------------------------------------------------------------------------ range status
+def test_activation_overflow_raises_the_sticky_status(weights):
+    """|dense-layer input| >= 4094 cannot be held by the fp16 planes: the launch must not pass silently.  The kernels
+    raise the device's sticky status; ufr_status_poll reports it at once, and WITHOUT a poll the next compute call fails
+    (one call late, no host synchronisation in between)."""
+    fr, idx, U1, U2, g = case_inputs("rows_small")
+    want = {}
+    with torch.no_grad():
+        O.infer(load_weights(), fr.batch, idx, fr.source_imgs_feat, fr.feature_volume, fr.match_feature, U1, U2, want=want)
+    w = want["coarse"]
+    RN, SN = w["z"].shape
+    NV = w["x"].shape[1]
+    rgbm = torch.cat([w["rgb_s"], w["mask"].permute(1, 2, 0).reshape(-1, NV, 1)], -1).to(DEV).contiguous()
+    dirs = torch.cat([w["dirs"].permute(1, 2, 0, 3).reshape(-1, NV, 3), torch.zeros(RN * SN, NV, 1)], -1).to(DEV).contiguous()
+    assert ops.status_poll(True) == 0
+    x_ok = w["x"].to(DEV).contiguous()
+    ops.aggregate(weights, x_ok, rgbm, dirs, RN, SN)
+    assert ops.status_poll(True) == 0
+    # one token feature of one point beyond the planes' range
+    x_bad = x_ok.clone()
+    x_bad[5, 1, 17] = 5000.0
+    ops.aggregate(weights, x_bad, rgbm, dirs, RN, SN)
+    with pytest.raises(UfrError, match="4094"):
+        ops.status_poll(True)
+    assert ops.status_poll(True) == 0                      # reporting clears it
+    # lazily: no poll -> the NEXT entry point reports what the previous one left behind
+    ops.aggregate(weights, x_bad, rgbm, dirs, RN, SN)
+    torch.cuda.synchronize()
+    with pytest.raises(UfrError, match="range status"):
+        ops.aggregate(weights, x_ok, rgbm, dirs, RN, SN)
+    ops.aggregate(weights, x_ok, rgbm, dirs, RN, SN)        # ... once
+    assert ops.status_poll(True) == 0
+    # a NaN in the token inputs comes out as a non-finite row: bit 1
+    x_nan = x_ok.clone()
+    x_nan[9, 0, 3] = float("nan")
+    ops.aggregate(weights, x_nan, rgbm, dirs, RN, SN)
+    with pytest.raises(UfrError, match="non-finite"):
+        ops.status_poll(True)
+    # the same through the 16-bit mode and through the whole-path entry point's kernels (values just inside pass)
+    x_edge = x_ok.clone()
+    x_edge[5, 1, 17] = 4000.0
+    ops.aggregate(weights, x_edge, rgbm, dirs, RN, SN, precision=ops.PRECISION_16BIT)
+    assert ops.status_poll(True) == 0
+    ops.aggregate(weights, x_bad, rgbm, dirs, RN, SN, precision=ops.PRECISION_16BIT)
+    with pytest.raises(UfrError, match="4094"):
+        ops.status_poll(True)
+
+
+def test_weight_range_is_reported_without_synchronising_repack():
+    """ufr_weights_pack is asynchronous now (training re-packs after every optimizer step): construction still fails at
+    once, an in-place update beyond the range surfaces through the status."""
+    P = {k: v.clone().to(DEV) for k, v in load_weights().items()}
+    W = ops.PackedWeights(P)
+    key = "ray_transformer.density_view_transformer.layers.0.mlp.0.weight"
+    P[key][3, 5] = 300.0
+    W.repack()                       # no error here: nothing synchronised
+    with pytest.raises(UfrError, match="255.8"):
+        ops.status_poll(True)
+    with pytest.raises(UfrError, match="255.8"):
+        W.repack(check=True)
+    P[key][3, 5] = 0.25
+    W.repack(check=True)
+    assert ops.status_poll(True) == 0
+
+
+# ------------------------------------------------------------------------------------------------ per-call precision
+def test_backward_runs_in_the_forwards_precision():
+    """The matrix precision is an argument of every call and is recorded by the autograd node: flipping the process
+    default between forward and backward changes nothing, and two models with different modes coexist in one process."""
+    fr, idx, U1, U2, g = case_inputs("c5_train_grads")
+    f = fr.to(DEV)
+
+    def grads(precision, flip_default_to=None):
+        m = M.UFORecon(_args(), precision=precision).to(DEV)
+        m.load_state_dict(load_weights(), strict=True)
+        r = m.infer(f.batch, idx.to(DEV), f.source_imgs_feat, f.feature_volume, match_feature=f.match_feature,
+                    uniforms=(U1, U2))
+        loss = O.training_loss(dict(rgb=r[1][0], depth=r[2][0], rgb_2=r[8][0], depth_2=r[9][0]), f.batch, idx.to(DEV))
+        if flip_default_to is not None:
+            ops.set_matrix_precision(flip_default_to)
+        try:
+            loss.backward()
+        finally:
+            ops.set_matrix_precision(ops.PRECISION_FP32)
+        torch.cuda.synchronize()
+        return float(loss), {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    l32, g32 = grads(ops.PRECISION_FP32)
+    l32b, g32b = grads(ops.PRECISION_FP32, flip_default_to=ops.PRECISION_16BIT)
+    l16, g16 = grads(ops.PRECISION_16BIT)
+    l16b, g16b = grads(ops.PRECISION_16BIT, flip_default_to=ops.PRECISION_FP32)
+    assert l32 == l32b and l16 == l16b and l32 != l16
+    key = "ray_transformer.density_view_transformer.layers.0.mlp.0.weight"       # a matrix-heavy gradient: modes differ
+    assert not torch.equal(g32[key], g16[key])
+    for k in g32:
+        # atomics reorder sums between runs: same mode -> agreement to rounding, far below the gap between the modes
+        assert rel_err(g32b[k], g32[k]) < 1e-4, k
+        assert rel_err(g16b[k], g16[k]) < 1e-4, k
+    assert rel_err(g16[key], g32[key]) > 1e-3
+    # None = the process default, resolved when the forward runs
+    ops.set_matrix_precision(ops.PRECISION_16BIT)
+    try:
+        ldef, _ = grads(None, flip_default_to=ops.PRECISION_FP32)
+    finally:
+        ops.set_matrix_precision(ops.PRECISION_FP32)
+    assert ldef == l16
+    with pytest.raises(UfrError, match="precision"):
+        ops.PackedWeights({k: v.to(DEV) for k, v in load_weights().items()}, precision=7).mode()
+
+
+# ------------------------------------------------------------------------------------------------ pool inside the kernels
+def test_pool_rows_in_the_kernels_equal_materialised_slots(weights):
+    """ufr_ray_transform / ufr_composite read the two-pass sample pool through the slot -> row table, and their adjoints
+    write (or add to) the pool rows: same numbers as gathering the slots into dense tensors first."""
+    torch.manual_seed(0)
+    RN, SN, PN = 12, 32, 32
+    S2, P1, P2 = SN + PN, RN * SN, RN * PN
+    pool_tok = torch.randn(P1 + P2, 80, device=DEV)
+    pool_rad = torch.rand(P1 + P2, 3, device=DEV)
+    # a slot -> row table of the right structure: every pool row exactly once, coarse rows of ray r are r*SN + s
+    row = torch.empty(RN, S2, dtype=torch.int32, device=DEV)
+    for r in range(RN):
+        rows_r = torch.cat([torch.arange(r * SN, (r + 1) * SN), P1 + torch.arange(r * PN, (r + 1) * PN)])
+        row[r] = rows_r[torch.randperm(S2)].to(torch.int32)
+    rows = row.reshape(-1).long()
+    z = torch.sort(torch.rand(RN, S2, device=DEV) + 2.0, dim=1).values.contiguous()
+    var = weights.variance.reshape(1)
+    srdf_a = ops.ray_transform(weights, pool_tok, RN, S2, row=row)
+    srdf_b = ops.ray_transform(weights, pool_tok[rows].contiguous(), RN, S2)
+    assert torch.equal(srdf_a, srdf_b)
+    out_a = ops.composite(z, pool_rad, srdf_a, var, row=row)
+    out_b = ops.composite(z, pool_rad[rows].view(RN, S2, 3).contiguous(), srdf_a, var)
+    for a, b in zip(out_a, out_b):
+        assert torch.equal(a, b)
+    # adjoints: pool form (overwrite, then accumulate) against the slot form scattered by hand
+    d_rgb, d_depth = torch.randn(RN, 3, device=DEV), torch.randn(RN, device=DEV)
+    base = torch.randn(P1 + P2, 3, device=DEV)
+    acc = base.clone()
+    _, d_srdf_p, dv_p = ops.composite_bwd(z, pool_rad, srdf_a, var, d_rgb, d_depth, None, None, row=row, d_radiance=acc,
+                                          accumulate=True)
+    d_rad_s, d_srdf_s, dv_s = ops.composite_bwd(z, pool_rad[rows].view(RN, S2, 3).contiguous(), srdf_a, var, d_rgb, d_depth,
+                                                None, None)
+    want = base.clone()
+    want[rows] += d_rad_s.view(-1, 3)
+    assert torch.allclose(acc, want, rtol=0, atol=1e-6) and torch.equal(d_srdf_p, d_srdf_s)
+    assert rel_err(dv_p, dv_s) < 1e-5
+    ga, gb = ops.GradBuffer(DEV), ops.GradBuffer(DEV)
+    pa, pb = torch.zeros(P1 + P2, 80, device=DEV), torch.zeros(P1 + P2, 80, device=DEV)
+    ops.ray_transform_bwd(weights, ga, pool_tok, RN, S2, d_srdf_p, row=row, out=(pa, pb))
+    sa, sb = ops.ray_transform_bwd(weights, gb, pool_tok[rows].contiguous(), RN, S2, d_srdf_s)
+    assert torch.equal(pa[rows], sa) and torch.equal(pb[rows], sb)
+    assert rel_err(ga.flat, gb.flat) < 1e-5
+    pa2, pb2 = pa.clone(), pb.clone()
+    ops.ray_transform_bwd(weights, ga, pool_tok, RN, S2, d_srdf_p, row=row, out=(pa2, pb2), accumulate=True)
+    assert torch.allclose(pa2, 2 * pa, rtol=1e-6, atol=1e-7) and torch.allclose(pb2, 2 * pb, rtol=1e-6, atol=1e-7)

@@ -216,6 +216,28 @@ def test_infer_training_signature_forward_matches_golden():
     for k in ("weight", "srdf"):
         assert rel_err(got[k], g[k]) < 1e-4, k
     assert rel_err(got["z_val_all"], g["z_val_all"]) < 1e-5
+    # the fine pass's rows sit at sample positions that differ from the reference's by the importance sampler's CDF
+    # rounding (1e-6 relative), which the steep signed-distance head amplifies: 2e-4 sanity bounds there
+    for k in ("srdf_2", "weight_2"):
+        assert rel_err(got[k], g[k]) < 2e-4, k
+    # colours: white-noise source images turn a 1-ulp coordinate difference into 1e-5 of colour; rays of this fixture are
+    # not selected away from image borders, where the reference's inclusive mask is a step function of the last ulp
+    from helpers import border_degenerate_rays
+    from oracle import ufo_oracle as O
+
+    want = {}
+    with torch.no_grad():
+        O.infer(load_weights(), fr.batch, idx, fr.source_imgs_feat, fr.feature_volume, fr.match_feature, U1, U2,
+                extract_geometry=False, want=want)
+    ok = ~border_degenerate_rays(want["fine"])
+    assert float(ok.float().mean()) > 0.85
+    for k in ("rgb", "rgb_2"):
+        assert rel_err(got[k][0][ok.to(dev)], torch.from_numpy(g[k])[0][ok]) < REL_TOL, k
+    # points_in_pixel (B,NV,2,RN,SN): the projected sample positions, bit-level arithmetic of torch.bmm
+    assert got["points_in_pixel"].shape == g["points_in_pixel"].shape
+    assert rel_err(got["points_in_pixel"], g["points_in_pixel"]) < 1e-6
+    assert got["points_in_pixel_2"].shape == g["points_in_pixel_2"].shape
+    assert rel_err(got["points_in_pixel_2"], g["points_in_pixel_2"]) < 1e-5     # at the merged positions (1e-6 apart)
     # with gradients enabled the same call is differentiable (tests/test_gpu_backward.py checks the gradients)
     out = m.infer(f.batch, idx.to(dev), f.source_imgs_feat, f.feature_volume, match_feature=f.match_feature, uniforms=(U1, U2))
     assert out[1].requires_grad and out[9].requires_grad and not out[14].requires_grad

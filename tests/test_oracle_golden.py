@@ -8,18 +8,18 @@ import os
 import pytest
 import torch
 
-from helpers import CASES, REL_TOL, case_inputs, load_weights, rel_err
+from helpers import CASES, REL_TOL, case_inputs, case_weights, load_weights, rel_err
 from oracle import ufo_oracle as O
 
 EXACT = 2e-6  # oracle vs reference differ only by op-order rounding
 
 
 @pytest.mark.parametrize("name", ["c1_coarse_only", "c2_hier_small", "c4_nv5_128", "c2_hier_512x640", "c2_hier_interior",
-                                  "c4_nv5_interior"])
+                                  "c4_nv5_interior", "c2_hier_512x640_interior"])
 def test_infer_matches_reference_golden(name):
     c = CASES[name]
     fr, idx, U1, U2, g = case_inputs(name)
-    P = load_weights()
+    P = case_weights(name)
     with torch.no_grad():
         srdf, pts, depth, rgb = O.infer(P, fr.batch, idx, fr.source_imgs_feat, fr.feature_volume,
                                         fr.match_feature, U1, U2, coarse_only=c.get("coarse_only", False))
@@ -27,6 +27,22 @@ def test_infer_matches_reference_golden(name):
     assert rel_err(depth, g["depth"]) < EXACT < REL_TOL
     assert rel_err(rgb, g["rgb"]) < EXACT
     assert rel_err(srdf, g["srdf"]) < 1e-5
+
+
+def test_trained_like_statistics_match_reference_golden():
+    """Checkpoint-like statistics (matrices x 8, LayerNorm gains up to 10, feature maps x 30; the modified weights travel
+    in the fixture): dense-layer inputs ~1e3 and an srdf head of gain ~1e3 amplify op-order rounding, so the bounds are
+    those of an fp32 evaluation of THIS network, not of the default init."""
+    name = "c2_trained_like"
+    fr, idx, U1, U2, g = case_inputs(name)
+    P = case_weights(name)
+    assert float(P["ray_transformer.density_view_transformer.layers.0.norm1.weight"].max()) > 5.0
+    with torch.no_grad():
+        srdf, pts, depth, rgb = O.infer(P, fr.batch, idx, fr.source_imgs_feat, fr.feature_volume, fr.match_feature, U1, U2)
+    e = dict(pts=rel_err(pts, g["points"]), depth=rel_err(depth, g["depth"]), rgb=rel_err(rgb, g["rgb"]),
+             srdf=rel_err(srdf, g["srdf"]))
+    print("trained-like oracle vs reference:", {k: f"{v:.2e}" for k, v in e.items()})
+    assert e["pts"] < EXACT and e["depth"] < EXACT and e["rgb"] < EXACT and e["srdf"] < 1e-5
 
 
 def test_rows_match_reference_golden():
@@ -66,6 +82,7 @@ def test_train_layout_forward_matches_reference_golden():
     assert rel_err(r["srdf"], g["srdf"][..., 0]) < 1e-5
     assert rel_err(r["srdf_2"], g["srdf_2"][..., 0]) < 1e-5
     assert rel_err(r["variance"], g["variance"]) < 1e-6
+    assert rel_err(r["points_in_pixel"], g["points_in_pixel"][0]) < 1e-6 if "points_in_pixel" in r else True
 
 
 @pytest.mark.parametrize("name", ["c5_train_grads", "c5_train_grads_nv4"])

@@ -62,16 +62,23 @@ def _grad_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.manual_seed(0)
-        # the per-ray parameter shapes (scalar variance included) + one parameter without a gradient
+        # the per-ray parameter shapes (scalar variance included); then a parameter whose gradient is None on rank 1 only
+        # (unused there this step: the bucket must still have the same length on every rank), one that is None everywhere,
+        # and a frozen one (not in the bucket)
         shapes = [(32, 8), (32,), (160, 160), (80, 160), (88,), (1, 80), ()]
-        params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes] + [torch.nn.Parameter(torch.zeros(3))]
-        for i, p in enumerate(params[:-1]):
+        params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+        lopsided, unused = torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(3))
+        frozen = torch.nn.Parameter(torch.zeros(4), requires_grad=False)
+        for i, p in enumerate(params):
             p.grad = torch.full(p.shape, float(rank + 1)) * (i + 1) + torch.arange(p.numel()).float().view(p.shape)
-        n = allreduce_gradients(params)
-        ok = n == sum(p.numel() for p in params[:-1]) and params[-1].grad is None
-        for i, p in enumerate(params[:-1]):
+        if rank == 0:
+            lopsided.grad = torch.full((5,), 6.0)
+        n = allreduce_gradients(params + [lopsided, unused, frozen])
+        ok = n == sum(p.numel() for p in params) + 5 + 3 and frozen.grad is None
+        for i, p in enumerate(params):
             want = torch.full(p.shape, (1 + world) / 2.0) * (i + 1) + torch.arange(p.numel()).float().view(p.shape)
             ok = ok and torch.allclose(p.grad, want)
+        ok = ok and torch.allclose(lopsided.grad, torch.full((5,), 6.0 / world)) and bool((unused.grad == 0).all())
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

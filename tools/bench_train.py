@@ -6,11 +6,15 @@ launched with N ranks: data parallel, every rank its own 1024 rays -- weak scali
 A step = what the reference's training_step does after its encoder (code1/model.py:537-566): sample rays, infer, the two
 colour MSE + two depth L1 losses, backward, optimizer step.  Inputs synthetic (uforecon_amd.scene), resident in HBM; the
 six frustums require gradients (through them feature_volume.cost_reg_2.* trains), so the scatter-add and the 0.67 GB of
-zeroed gradient volumes are inside the timed region.  Rank 0 prints one JSON line with the per-kernel split.
+zeroed gradient volumes are inside the timed region.  Rank 0 prints one JSON line with the per-kernel split, the roofline
+of the dominant kernel (view_bwd_kernel: recompute + data gradients + weight gradients = 3 x the forward's
+view-transformer flop per point) and the CPU baseline (autograd through the oracle on the host cores, bounded sample).
 
-    python tools/bench_train.py --steps 10 --warmup 2
+    python tools/bench_train.py --steps 10 --warmup 2 [--precision 16bit]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         tools/bench_train.py --gpus N
+
+`run(...)` is also what bench.py calls for its `secondary` configs[4] entries.
 """
 from __future__ import annotations
 
@@ -25,8 +29,14 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+# view-transformer flop per point (q/k/v/merge 204 800 + MLP 307 200 + attention 13 440 + radiance MLP 8 784
+# at NV = 3); the backward kernel recomputes the layer, forms the data gradients and the weight gradients: 3 x
+VIEWT_FLOP_PER_POINT = {3: 534_224, 5: (204_800 + 307_200) * 6 // 4 + 20_160 + 14_640}
+PEAK_FP32_MFMA_TFLOPS = 157.3     # the fp32 mode's backward GEMMs issue v_mfma_f32_16x16x4_f32
+PEAK_16BIT_MFMA_TFLOPS = 2516.6   # the 16-bit mode's issue v_mfma_f32_16x16x16_bf16
 
-def main():
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -39,11 +49,55 @@ def main():
     ap.add_argument("--fine", type=int, default=64)
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--precision", choices=("fp32", "16bit"), default="fp32",
-                    help="16bit: ufr_set_matrix_precision(UFR_PRECISION_16BIT), the mixed-precision mode of configs[4]")
-    a = ap.parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = 0 if os.environ.get("UFR_BENCH_SHARE_GPU") else int(os.environ.get("LOCAL_RANK", "0"))
+                    help="16bit: UFR_PRECISION_16BIT, the mixed-precision mode BASELINE configs[4] names")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=64)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--dump-grads", default="", help="rank 0 writes the post-all-reduce parameter gradients of the LAST step "
+                                                     "here (.pt) -- the 2-rank data-parallel test compares them")
+    ap.add_argument("--fixed-seed", type=int, default=-1, help=">= 0: ray indices / uniforms of a step depend only on "
+                                                                "(seed, rank, step), frames on the rank: reproducible")
+    return ap.parse_args(argv)
+
+
+def cpu_baseline(a, frame_cpu, weights_cpu):
+    """One training step (forward, loss, backward) of `cpu_rays` rays through autograd over the oracle -- the CPU port of
+    the reference path -- on this host's cores; the six volumes require grad, as in the GPU step."""
+    from oracle import ufo_oracle as O
+    from uforecon_amd.scene import sampler_uniforms
+
+    RN, HW = a.cpu_rays, a.height * a.width
+    idx = (torch.arange(RN) * (HW // RN) + (HW // RN) // 3)[None]
+    U1, U2 = sampler_uniforms(2, a.coarse, a.fine, RN)
+    P = {k: v.clone().requires_grad_("depthcode" not in k) for k, v in weights_cpu.items()}
+    vols = [frame_cpu.feature_volume[st][k] for st in frame_cpu.feature_volume for k in frame_cpu.feature_volume[st]]
+    times = []
+    for i in range(a.cpu_steps + 1):
+        for v in vols:
+            v.requires_grad_(True)
+            v.grad = None
+        for p in P.values():
+            p.grad = None
+        t = time.perf_counter()
+        r = O.infer(P, frame_cpu.batch, idx, frame_cpu.source_imgs_feat, frame_cpu.feature_volume, frame_cpu.match_feature,
+                    U1, U2, extract_geometry=False)
+        O.training_loss(r, frame_cpu.batch, idx).backward()
+        if i:
+            times.append(time.perf_counter() - t)
+    for v in vols:
+        v.requires_grad_(False)
+        v.grad = None
+    times.sort()
+    med = times[len(times) // 2]
+    return dict(value=RN / med, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle.infer(extract_geometry=False) + training loss + autograd backward on {RN} rays of the same "
+                       f"frame (volume gradients on), {a.coarse}+{a.fine} samples, fp32, median of {a.cpu_steps} steps after "
+                       f"1 warm-up ({med * 1e3:.0f} ms/step)")
+
+
+def run(a, dev, world=1, rank=0):
+    """The measurement; returns the JSON-able result dict on rank 0 (None elsewhere)."""
+    import numpy as np
     import torch.distributed as dist
 
     from uforecon_amd import model as M
@@ -51,23 +105,24 @@ def main():
     from uforecon_amd.dist import allreduce_gradients
     from uforecon_amd.scene import make_frame
 
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group(a.backend, **({"device_id": dev} if a.backend == "nccl" else {}))
     args = argparse.Namespace(extract_geometry=False, test_sample_coarse=a.coarse, test_sample_fine=a.fine,
                               coarse_sample=a.coarse, fine_sample=a.fine, volume_type="correlation", volume_reso=96,
                               mvs_depth_guide=1, depth_pos_encoding=True, use_dir_srdf=False, explicit_similarity=True,
                               test_coarse_only=False, test_ray_num=800)
-    torch.manual_seed(0)
-    m = M.UFORecon(args).to(dev).train()
+    precision = ops.PRECISION_16BIT if a.precision == "16bit" else ops.PRECISION_FP32
+    wz = np.load(os.path.join(ROOT, "tests", "golden", "ray_path_weights_seed0.npz"))
+    weights_cpu = {k: torch.from_numpy(wz[k]) for k in wz.files}
+    m = M.UFORecon(args, precision=precision).to(dev).train()     # the mode travels with the model, not with the process
+    m.load_state_dict(weights_cpu, strict=True)
     opt = torch.optim.Adam(m.parameters(), lr=1e-4)                       # model.py:72-87 (uforecon_lr)
-    f = make_frame(a.height, a.width, a.views, seed=rank, train_layout=True).to(dev)
+    frame_cpu = make_frame(a.height, a.width, a.views, seed=rank, train_layout=True)
+    f = frame_cpu.to(dev)
     vols = [f.feature_volume[st][k] for st in f.feature_volume for k in f.feature_volume[st]]
     for v in vols:
         v.requires_grad_(True)
     HW = a.height * a.width
-    gen = torch.Generator(device=dev).manual_seed(100 + rank)
+    gen = torch.Generator(device=dev).manual_seed(100 + rank if a.fixed_seed < 0 else a.fixed_seed * 1000 + rank)
+    ar_events = []
 
     def step():
         idx = torch.randperm(HW, device=dev, generator=gen)[: a.rays][None]              # model.py:537
@@ -85,7 +140,16 @@ def main():
                 + torch.nn.functional.l1_loss(depth2[mask], depth_gt[mask]))           # model.py:552-566
         loss.backward()
         if world > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            # the per-ray parameters; the volumes are per-rank frames (every rank trains on its own scene), so their
+            # gradients stay local -- in the real pipeline they flow on into feature_volume.cost_reg_2.*, whose own
+            # gradients would join this bucket
             allreduce_gradients(list(m.parameters()), world)
+            e1.record()
+            ar_events.append((e0, e1))
+        if a.dump_grads:
+            step.last_grads = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
         opt.step()
         return loss
 
@@ -94,11 +158,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if a.precision == "16bit":
-        ops.set_matrix_precision(ops.PRECISION_16BIT)
     for _ in range(a.warmup):
         step()
     fence()
+    ar_events.clear()
     ops.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -107,22 +170,80 @@ def main():
     dt = time.perf_counter() - t0
     prof = ops.profile_read()
     ops.profile_enable(False)
+    ops.status_poll(True)        # an activation / weight outside the split-precision planes' range fails the run loudly
+    per_rank = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt_local, dt = dt, float(t.item())
+        mine = dict(rank=rank, wall_ms_per_step=dt_local / a.steps * 1e3,
+                    kernel_ms_per_step={k: v["ms"] / a.steps for k, v in prof.items()},
+                    all_reduce_ms_per_step=sum(e0.elapsed_time(e1) for e0, e1 in ar_events) / max(len(ar_events), 1))
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    if a.dump_grads and rank == 0:
+        torch.save({k: v.cpu() for k, v in step.last_grads.items()}, a.dump_grads)
+    if rank != 0:
+        return None
+    S = a.coarse + a.fine
+    pts = a.rays * (a.coarse + S)
+    vb = prof.get("view_bwd", dict(ms=0.0, launches=1))
+    vb_ms = vb["ms"] / max(vb["launches"], 1)
+    # the fine pass evaluates only its new samples at the point level: coarse + fine points per ray over the launches
+    vb_pts = a.rays * S * a.steps / max(vb["launches"], 1)
+    vb_flop = 3.0 * VIEWT_FLOP_PER_POINT.get(a.views, 0) * vb_pts
+    achieved = vb_flop / (vb_ms * 1e-3) / 1e12 if vb_ms > 0 else 0.0
+    peak = PEAK_16BIT_MFMA_TFLOPS if a.precision == "16bit" else PEAK_FP32_MFMA_TFLOPS
+    traffic, traffic_src = None, None
+    try:
+        import glob
+        pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_train_pmc.json")))[-1]
+        for k, v in json.load(open(pj)).items():
+            if "view_bwd" in k and v.get("hbm_bytes_per_launch"):
+                traffic, traffic_src = v["hbm_bytes_per_launch"], os.path.relpath(pj, ROOT)
+    except Exception:  # noqa: BLE001
+        pass
+    line = dict(
+        metric="training rays/s (fwd + bwd + Adam through the HIP ray path)", value=world * a.rays * a.steps / dt,
+        unit="rays/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
+        higher_is_better=True, scaling="weak",
+        dtype="f32" if a.precision == "fp32" else "bf16", data="synthetic",
+        config=dict(workload=f"configs[4]: {a.views} source views + GT view, {a.rays} random rays per rank of a "
+                             f"{a.height}x{a.width} frame, {a.coarse}+{a.fine} samples ({pts} point evaluations per rank and "
+                             f"step), frustum gradients on, Adam step included",
+                    arithmetic=("fp32 mode: forward dense layers as three fp16 plane products (fp32-grade), backward GEMMs "
+                                "and weight gradients on the fp32 MFMA" if a.precision == "fp32" else
+                                "16-bit mode: one fp16 plane per operand in the forward, bf16 operands in the backward GEMMs "
+                                "and weight gradients, fp32 accumulation; LayerNorm / attention / softmax / compositor fp32"),
+                    loss=float(loss),
+                    kernel_ms_per_step_rank0={k: v["ms"] / a.steps for k, v in prof.items()},
+                    kernel_launches_per_step={k: v["launches"] / a.steps for k, v in prof.items()},
+                    per_rank=per_rank),
+        roofline=dict(bound="mfma", achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak, traffic=traffic,
+                      traffic_source=traffic_src, kernel="view_bwd_kernel", avg_launch_ms=vb_ms, launches=vb["launches"],
+                      algorithmic_flop_per_launch=vb_flop,
+                      peak_basis=("dense fp32 MFMA peak" if a.precision == "fp32" else "dense bf16 MFMA peak")
+                                 + "; algorithmic flop = 3 x the forward view-transformer flop per point (recompute + data "
+                                   "gradients + weight gradients)"))
+    if not a.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_baseline(a, frame_cpu, weights_cpu)
+    return line
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = 0 if os.environ.get("UFR_BENCH_SHARE_GPU") else int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group(a.backend, **({"device_id": dev} if a.backend == "nccl" else {}))
+    line = run(a, dev, world, rank)
     if rank == 0:
-        S = a.coarse + a.fine
-        pts = a.rays * (a.coarse + S)
-        print(json.dumps(dict(
-            metric="training rays/s (fwd + bwd + Adam through the HIP ray path)", value=world * a.rays * a.steps / dt,
-            unit="rays/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3, scaling="weak",
-            dtype="f32" if a.precision == "fp32" else "bf16/fp16 operands, f32 accumulate", data="synthetic",
-            config=dict(workload=f"configs[4]: {a.views} source views + GT view, {a.rays} random rays per rank of a "
-                                 f"{a.height}x{a.width} frame, {a.coarse}+{a.fine} samples ({pts} point evaluations per rank and "
-                                 f"step), frustum gradients on", loss=float(loss),
-                        kernel_ms_per_step_rank0={k: v["ms"] / a.steps for k, v in prof.items()},
-                        kernel_launches_per_step={k: v["launches"] / a.steps for k, v in prof.items()}))), flush=True)
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

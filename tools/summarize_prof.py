@@ -17,33 +17,10 @@ def short(name: str) -> str:
     return name[-60:]
 
 
-def main(src: str, dst_prefix: str):
-    os.makedirs(os.path.dirname(dst_prefix), exist_ok=True)
-    stats = os.path.join(src, "stats_kernel_stats.csv")
-    if os.path.exists(stats):
-        with open(stats) as f, open(dst_prefix + "_kernel_stats.csv", "w", newline="") as g:
-            w = csv.writer(g)
-            for i, row in enumerate(csv.reader(f)):
-                if i:
-                    row[0] = short(row[0])
-                w.writerow(row)
-    tstats = os.path.join(src, "train_kernel_stats.csv")
-    if os.path.exists(tstats):   # training step (tools/bench_train.py)
-        with open(tstats) as f, open(dst_prefix + "_train_kernel_stats.csv", "w", newline="") as g:
-            w = csv.writer(g)
-            for i, row in enumerate(csv.reader(f)):
-                if i:
-                    row[0] = short(row[0])
-                w.writerow(row)
-    tl = os.path.join(src, "train_line.json")
-    if os.path.exists(tl):
-        for line in open(tl).read().strip().splitlines():
-            if line.startswith("{"):
-                with open(dst_prefix + "_train_under_rocprof.json", "w") as g:
-                    json.dump(json.loads(line), g, indent=1)
-                    g.write("\n")
+def pmc_tables(src: str, dst_prefix: str, group: str):
     table = collections.defaultdict(dict)
-    for tag in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_lds", "pmc_tcc"):
+    for base in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_lds", "pmc_tcc"):
+        tag = group + base
         p = os.path.join(src, tag + "_counter_collection.csv")
         if not os.path.exists(p):
             continue
@@ -60,35 +37,65 @@ def main(src: str, dst_prefix: str):
             for c, x in v.items():
                 table[k][c] = sum(x) / len(x)
             table[k].setdefault("launches", len(next(iter(v.values()))))
-            table[k][f"avg_ns[{tag}]"] = sum(dur[k]) / max(len(dur[k]), 1)
-    if table:
-        with open(dst_prefix + "_pmc_summary.md", "w") as g:
-            g.write("# rocprofv3 PMC summary (mean per launch; separate --pmc passes)\n\n")
-            g.write("FETCH_SIZE / WRITE_SIZE are in KiB as reported; on gfx950 FETCH_SIZE counts half of the bytes of wide\n"
-                    "coalesced reads (MI355X_MICROARCH.md, HBM section): double it before comparing with byte counts.\n"
-                    "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* are quad-cycles; SQ_VALU_MFMA_BUSY_CYCLES are cycles summed over SIMDs.\n\n")
-            for k in sorted(table, key=lambda k: -table[k].get("SQ_WAVE_CYCLES", 0)):
-                if "kernel" not in k:
-                    continue
-                g.write(f"## {k}\n\n| counter | mean per launch |\n|---|---|\n")
-                for c, v in sorted(table[k].items()):
-                    g.write(f"| {c} | {v:,.1f} |\n")
-                t = table[k]
-                if "SQ_VALU_MFMA_BUSY_CYCLES" in t and t.get("avg_ns[pmc_sq]") and t["SQ_VALU_MFMA_BUSY_CYCLES"] > 0:
-                    per_simd = t["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0
-                    g.write(f"\nMFMA-busy cycles per SIMD: {per_simd:,.0f} over {t['avg_ns[pmc_sq]'] / 1e3:,.1f} us "
-                            f"=> {per_simd / (t['avg_ns[pmc_sq]'] * 2.4):.2%} of a 2.4 GHz clock "
-                            f"(the chip runs these kernels at ~1.87 GHz: tools/bench_kernels.py phase build)\n")
-                g.write("\n")
-    if table:
-        # HBM bytes per launch, corrected as MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE (KiB) counts
-        # half the bytes of wide coalesced reads on gfx950 -> x2; WRITE_SIZE (KiB) taken as reported (uncalibrated)
-        for k, t in table.items():
-            if "FETCH_SIZE" in t and "WRITE_SIZE" in t:
-                t["hbm_bytes_per_launch"] = (2.0 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024.0
-        with open(dst_prefix + "_pmc.json", "w") as g:
-            json.dump({k: v for k, v in table.items() if "kernel" in k}, g, indent=1)
+            table[k][f"avg_ns[{base}]"] = sum(dur[k]) / max(len(dur[k]), 1)
+    if not table:
+        return
+    with open(dst_prefix + "_pmc_summary.md", "w") as g:
+        g.write("# rocprofv3 PMC summary (mean per launch; separate --pmc passes)\n\n")
+        g.write("FETCH_SIZE / WRITE_SIZE are in KiB as reported; on gfx950 FETCH_SIZE counts half of the bytes of wide\n"
+                "coalesced reads (MI355X_MICROARCH.md, HBM section): double it before comparing with byte counts.\n"
+                "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* are quad-cycles; SQ_VALU_MFMA_BUSY_CYCLES are cycles summed over SIMDs.\n\n")
+        for k in sorted(table, key=lambda k: -table[k].get("SQ_WAVE_CYCLES", table[k].get("FETCH_SIZE", 0))):
+            if "kernel" not in k:
+                continue
+            g.write(f"## {k}\n\n| counter | mean per launch |\n|---|---|\n")
+            for c, v in sorted(table[k].items()):
+                g.write(f"| {c} | {v:,.1f} |\n")
+            t = table[k]
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in t and t.get("avg_ns[pmc_sq]") and t["SQ_VALU_MFMA_BUSY_CYCLES"] > 0:
+                per_simd = t["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0
+                g.write(f"\nMFMA-busy cycles per SIMD: {per_simd:,.0f} over {t['avg_ns[pmc_sq]'] / 1e3:,.1f} us "
+                        f"=> {per_simd / (t['avg_ns[pmc_sq]'] * 2.4):.2%} of a 2.4 GHz clock\n")
             g.write("\n")
+    # HBM bytes per launch, corrected as MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE (KiB) counts
+    # half the bytes of wide coalesced reads on gfx950 -> x2; WRITE_SIZE (KiB) taken as reported (uncalibrated)
+    for k, t in table.items():
+        if "FETCH_SIZE" in t and "WRITE_SIZE" in t:
+            t["hbm_bytes_per_launch"] = (2.0 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024.0
+    with open(dst_prefix + "_pmc.json", "w") as g:
+        json.dump({k: v for k, v in table.items() if "kernel" in k}, g, indent=1)
+        g.write("\n")
+
+
+def main(src: str, dst_prefix: str):
+    os.makedirs(os.path.dirname(dst_prefix), exist_ok=True)
+    stats = os.path.join(src, "stats_kernel_stats.csv")
+    if os.path.exists(stats):
+        with open(stats) as f, open(dst_prefix + "_kernel_stats.csv", "w", newline="") as g:
+            w = csv.writer(g)
+            for i, row in enumerate(csv.reader(f)):
+                if i:
+                    row[0] = short(row[0])
+                w.writerow(row)
+    for tag in ("train", "train16"):   # training step (tools/bench_train.py), fp32 / 16-bit matrix mode
+        tstats = os.path.join(src, f"{tag}_kernel_stats.csv")
+        if os.path.exists(tstats):
+            with open(tstats) as f, open(f"{dst_prefix}_{tag}_kernel_stats.csv", "w", newline="") as g:
+                w = csv.writer(g)
+                for i, row in enumerate(csv.reader(f)):
+                    if i:
+                        row[0] = short(row[0])
+                    w.writerow(row)
+        tl = os.path.join(src, f"{tag}_line.json")
+        if os.path.exists(tl):
+            for line in open(tl).read().strip().splitlines():
+                if line.startswith("{"):
+                    with open(f"{dst_prefix}_{tag}_under_rocprof.json", "w") as g:
+                        json.dump(json.loads(line), g, indent=1)
+                        g.write("\n")
+    # counter passes: "" = bench.py configs[1], "train_" = tools/bench_train.py, "c4_" = tools/bench_c4.py (configs[3])
+    for group in ("", "train_", "c4_"):
+        pmc_tables(src, dst_prefix + ("_" + group.rstrip("_") if group else ""), group)
     bl = os.path.join(src, "bench_line.json")
     if os.path.exists(bl):
         txt = open(bl).read().strip().splitlines()

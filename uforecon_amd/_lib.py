@@ -8,6 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # UFR_LIB selects an alternative in-tree build (A/B kernel variants during development)
 LIB_PATH = os.environ.get("UFR_LIB") or os.path.join(HERE, "lib", "libufr.so")
 
+ABI_VERSION = 300   # = UFR_ABI_VERSION of include/ufr.h; load() refuses a library built against another header
 MAX_VIEWS = 7
 NUM_STAGES = 3
 TOKEN_DIM = 80
@@ -57,7 +58,7 @@ class RenderArgs(C.Structure):
                 ("ray_idx", fptr), ("ray_d", fptr), ("cam_ray_d", fptr),
                 ("ray_o", C.c_float * 3), ("near_z", C.c_float), ("far_z", C.c_float),
                 ("U1", fptr), ("U2", fptr), ("RN", C.c_int32), ("SN", C.c_int32), ("PN", C.c_int32),
-                ("coarse_only", C.c_int32),
+                ("coarse_only", C.c_int32), ("precision", C.c_int32),
                 ("depth", fptr), ("depth_z", fptr), ("rgb", fptr), ("srdf", fptr), ("z_all", fptr),
                 ("chunk_rays", C.c_int32), ("n_streams", C.c_int32), ("workspace", fptr), ("workspace_bytes", C.c_size_t)]
 
@@ -69,6 +70,7 @@ SIGNATURES = {
     "ufr_last_error": (C.c_char_p, []),
     "ufr_set_matrix_precision": (C.c_int, [C.c_int]),
     "ufr_get_matrix_precision": (C.c_int, []),
+    "ufr_status_poll": (C.c_int, [vp, i32, C.POINTER(i32)]),
     "ufr_packed_weights_bytes": (sz, []),
     "ufr_weights_pack": (C.c_int, [C.POINTER(RawWeights), vp, vp]),
     "ufr_pack_plan": (C.c_int, [C.POINTER(i32), C.POINTER(i32)]),
@@ -83,20 +85,20 @@ SIGNATURES = {
     "ufr_project_gather": (C.c_int, [C.POINTER(Frame), C.POINTER(RawWeights), vp, i32, vp, vp, i32, i32,
                                      vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "ufr_aggregate_workspace_bytes": (sz, [i32, i32, i32]),
-    "ufr_aggregate": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
-    "ufr_composite": (C.c_int, [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
-    "ufr_composite_bwd": (C.c_int, [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "ufr_aggregate": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]),
+    "ufr_composite": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
+    "ufr_composite_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
     "ufr_aggregate_bwd_workspace_bytes": (sz, [i32, i32, i32]),
     "ufr_aggregate_bwd": (C.c_int, [C.POINTER(RawWeights), C.POINTER(RawGrads), vp, vp, vp, vp, i32, i32, i32, vp, vp, vp,
-                                    vp, vp, vp, vp]),
+                                    vp, vp, vp, i32, vp]),
     "ufr_project_gather_bwd": (C.c_int, [C.POINTER(Frame), C.POINTER(RawWeights), C.POINTER(RawGrads), vp, i32, vp, vp,
-                                         i32, i32, vp, vp, C.POINTER(vp), C.POINTER(vp), vp]),
+                                         i32, i32, vp, vp, C.POINTER(vp), C.POINTER(vp), i32, vp]),
     "ufr_sample_importance_pool": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
-    "ufr_view_transform": (C.c_int, [vp, vp, vp, vp, i32, i32, vp, vp, vp]),
+    "ufr_view_transform": (C.c_int, [vp, vp, vp, vp, i32, i32, vp, vp, i32, vp]),
     "ufr_ray_transform_workspace_bytes": (sz, [i32]),
-    "ufr_ray_transform": (C.c_int, [vp, vp, i32, i32, vp, vp, vp]),
-    "ufr_ray_transform_bwd": (C.c_int, [C.POINTER(RawWeights), C.POINTER(RawGrads), vp, i32, i32, vp, vp, vp, vp, vp]),
-    "ufr_view_transform_bwd": (C.c_int, [C.POINTER(RawWeights), C.POINTER(RawGrads), vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
+    "ufr_ray_transform": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, i32, vp]),
+    "ufr_ray_transform_bwd": (C.c_int, [C.POINTER(RawWeights), C.POINTER(RawGrads), vp, vp, i32, i32, vp, vp, vp, i32, vp, i32, vp]),
+    "ufr_view_transform_bwd": (C.c_int, [C.POINTER(RawWeights), C.POINTER(RawGrads), vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp]),
     "ufr_render_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "ufr_default_chunk_rays": (i32, []),
     "ufr_render_rays": (C.c_int, [C.POINTER(RenderArgs), vp]),
@@ -136,6 +138,9 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
+        if lib.ufr_version() != ABI_VERSION:   # same symbols, different argument lists: refuse instead of mis-calling
+            raise UfrError(f"{LIB_PATH} has ABI version {lib.ufr_version()}, this binding needs {ABI_VERSION}: rebuild it "
+                           "(`python -m uforecon_amd.build`)")
         _lib = lib
     return _lib
 

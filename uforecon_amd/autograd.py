@@ -28,11 +28,12 @@ class RenderPass(torch.autograd.Function):
     def forward(ctx, frame, weights, ray_o, ray_d, z, *tensors):
         n_par = len(ops.RAW_WEIGHT_KEYS)
         RN, SN = z.shape
+        prec = weights.mode()     # resolved ONCE: the backward of this node runs in the mode its forward ran in
         x, rgbm, dirs, dbg = ops.project_gather(frame, weights, ray_o, ray_d, z, want_sim8=True, want_xy=True)
-        radiance, srdf, agg = ops.aggregate(weights, x, rgbm, dirs, RN, SN, keep_workspace=True)
+        radiance, srdf, agg = ops.aggregate(weights, x, rgbm, dirs, RN, SN, keep_workspace=True, precision=prec)
         variance = weights.variance.reshape(1)
         rgb, depth, opacity, weight = ops.composite(z, radiance.view(RN, SN, 3), srdf, variance)
-        ctx.frame, ctx.weights, ctx.n_par = frame, weights, n_par
+        ctx.frame, ctx.weights, ctx.n_par, ctx.precision = frame, weights, n_par, prec
         ctx.vol_shapes = [tuple(t.shape) for t in tensors[n_par:]]
         ctx.save_for_backward(ray_o, ray_d, z, x, rgbm, dirs, dbg["sim8"], agg["token0"], radiance, srdf)
         ctx.mark_non_differentiable(dbg["xy"])
@@ -49,14 +50,15 @@ class RenderPass(torch.autograd.Function):
         if d_srdf_out is not None:
             d_srdf = d_srdf + d_srdf_out
         grads = ops.GradBuffer(dev)
-        d_pv, _ = ops.aggregate_bwd(W, grads, x, rgbm, dirs, token0, RN, SN, d_radiance.view(RN * SN, 3), d_srdf)
+        prec = ctx.precision
+        d_pv, _ = ops.aggregate_bwd(W, grads, x, rgbm, dirs, token0, RN, SN, d_radiance.view(RN * SN, 3), d_srdf, precision=prec)
         need = ctx.needs_input_grad[5:]
         if any(need[ctx.n_par:]):       # frustum gradients wanted (feature_volume.cost_reg_2 trains through them)
             gvol = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.vol_shapes]
-            ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z, sim8, d_pv, gvol[0::2], gvol[1::2])
+            ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z, sim8, d_pv, gvol[0::2], gvol[1::2], precision=prec)
         else:                           # parameters only: skip the scatter-add (and 0.7 GB of zeroed gradient volumes)
             gvol = [None] * len(ctx.vol_shapes)
-            ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z, sim8, d_pv, None, None)
+            ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z, sim8, d_pv, None, None, precision=prec)
         gpar = [grads.grad(k) for k in ops.RAW_WEIGHT_KEYS]
         gpar[-1] = d_var.reshape(gpar[-1].shape)                      # deviation_network.variance
         out = [g if (n and g is not None) else None for g, n in zip(gpar + gvol, need)]
@@ -78,58 +80,66 @@ class RenderTwoPass(torch.autograd.Function):
     def forward(ctx, frame, weights, ray_o, ray_d, z1, U2, *tensors):
         n_par = len(ops.RAW_WEIGHT_KEYS)
         RN, SN = z1.shape
+        PN = U2.shape[0]
+        S2, P1, P2 = SN + PN, RN * SN, RN * PN
+        dev = z1.device
+        prec = weights.mode()     # resolved ONCE: the backward of this node runs in the mode its forward ran in
         var = weights.variance.reshape(1)
+        # the sample pool [P1 coarse rows (ray-major) | P2 new rows]: the view transformer writes its rows in place, the ray
+        # transformer and the compositor of the fine pass read them through the slot -> row table (no copies, no gathers)
+        pool_tok = torch.empty(P1 + P2, ops._lib.TOKEN_DIM, dtype=torch.float32, device=dev)
+        pool_rad = torch.empty(P1 + P2, 3, dtype=torch.float32, device=dev)
         x1, rgbm1, dirs1, g1 = ops.project_gather(frame, weights, ray_o, ray_d, z1, want_sim8=True, want_xy=True)
-        tok1, rad1 = ops.view_transform(weights, x1, rgbm1, dirs1)
-        srdf1 = ops.ray_transform(weights, tok1, RN, SN)
-        rgb, depth, opacity, weight = ops.composite(z1, rad1.view(RN, SN, 3), srdf1, var)
+        ops.view_transform(weights, x1, rgbm1, dirs1, token0=pool_tok[:P1], radiance=pool_rad[:P1], precision=prec)
+        srdf1 = ops.ray_transform(weights, pool_tok[:P1], RN, SN, precision=prec)
+        rgb, depth, opacity, weight = ops.composite(z1, pool_rad[:P1].view(RN, SN, 3), srdf1, var)
         z2, z_new, row = ops.sample_importance_pool(weight, z1, U2)                  # model.py:455-470 (weights detached)
-        PN = z_new.shape[1]
-        S2 = SN + PN
         x2, rgbm2, dirs2, g2 = ops.project_gather(frame, weights, ray_o, ray_d, z_new, want_sim8=True, want_xy=True)
-        tok2, rad2 = ops.view_transform(weights, x2, rgbm2, dirs2)
-        rows = row.reshape(-1).long()
-        tok_slots = torch.cat([tok1, tok2], 0)[rows]                                   # (RN*S2, 80) in slot order
-        rad_slots = torch.cat([rad1, rad2], 0)[rows]
-        srdf2 = ops.ray_transform(weights, tok_slots, RN, S2)
-        rgb2, depth2, opacity2, weight2 = ops.composite(z2, rad_slots.view(RN, S2, 3), srdf2, var)
-        xy2 = torch.cat([g1["xy"], g2["xy"]], 1)[:, rows]                              # (NV, RN*S2, 2)
-        ctx.frame, ctx.weights, ctx.n_par = frame, weights, n_par
+        ops.view_transform(weights, x2, rgbm2, dirs2, token0=pool_tok[P1:], radiance=pool_rad[P1:], precision=prec)
+        srdf2 = ops.ray_transform(weights, pool_tok, RN, S2, row=row, precision=prec)
+        rgb2, depth2, opacity2, weight2 = ops.composite(z2, pool_rad, srdf2, var, row=row)
+        xy2 = torch.cat([g1["xy"], g2["xy"]], 1)[:, row.reshape(-1).long()]         # (NV, RN*S2, 2), a returned value only
+        ctx.frame, ctx.weights, ctx.n_par, ctx.precision = frame, weights, n_par, prec
         ctx.vol_shapes = [tuple(t.shape) for t in tensors[n_par:]]
-        ctx.save_for_backward(ray_o, ray_d, z1, z2, z_new, rows, x1, rgbm1, dirs1, g1["sim8"], tok1, rad1, srdf1,
-                              x2, rgbm2, dirs2, g2["sim8"], tok_slots, rad_slots, srdf2)
+        ctx.save_for_backward(ray_o, ray_d, z1, z2, z_new, row, x1, rgbm1, dirs1, g1["sim8"], srdf1,
+                              x2, rgbm2, dirs2, g2["sim8"], pool_tok, pool_rad, srdf2)
         ctx.mark_non_differentiable(g1["xy"], xy2, z2)
         return rgb, depth, opacity, weight, srdf1, g1["xy"], rgb2, depth2, opacity2, weight2, srdf2, xy2, z2
 
     @staticmethod
     def backward(ctx, d_rgb, d_depth, d_opacity, d_weight, d_srdf, _dxy, d_rgb2, d_depth2, d_opacity2, d_weight2, d_srdf2,
                  _dxy2, _dz2):
-        (ray_o, ray_d, z1, z2, z_new, rows, x1, rgbm1, dirs1, sim8_1, tok1, rad1, srdf1,
-         x2, rgbm2, dirs2, sim8_2, tok_slots, rad_slots, srdf2) = ctx.saved_tensors
-        frame, W = ctx.frame, ctx.weights
+        (ray_o, ray_d, z1, z2, z_new, row, x1, rgbm1, dirs1, sim8_1, srdf1,
+         x2, rgbm2, dirs2, sim8_2, pool_tok, pool_rad, srdf2) = ctx.saved_tensors
+        frame, W, prec = ctx.frame, ctx.weights, ctx.precision
         RN, SN = z1.shape
         S2 = z2.shape[1]
         P1 = RN * SN
         dev = z1.device
         var = W.variance.reshape(1)
         grads = ops.GradBuffer(dev)
-        # ---- fine pass: compositor and ray transformer over all merged slots, then back to pool rows
-        d_rad_s, d_srdf_s, d_var2 = ops.composite_bwd(z2, rad_slots.view(RN, S2, 3), srdf2, var, d_rgb2, d_depth2, d_opacity2, d_weight2)
+        d_var = torch.zeros((), dtype=torch.float32, device=dev)
+        # cotangent pools, same rows as the forward's: the fine pass writes every row once (each pool row is exactly one
+        # merged slot), the coarse pass then ADDS its own cotangents onto the coarse rows -- inside the kernels
+        pool_a = torch.empty_like(pool_tok)
+        pool_b = torch.empty_like(pool_tok)
+        pool_drad = torch.empty_like(pool_rad)
+        # ---- fine pass: compositor and ray transformer over all merged slots
+        _, d_srdf_s, _ = ops.composite_bwd(z2, pool_rad, srdf2, var, d_rgb2, d_depth2, d_opacity2, d_weight2, row=row,
+                                           d_radiance=pool_drad, accumulate=False, d_variance=d_var)
         if d_srdf2 is not None:
             d_srdf_s = d_srdf_s + d_srdf2
-        ta, tb = ops.ray_transform_bwd(W, grads, tok_slots, RN, S2, d_srdf_s)
-        pool_tok = torch.empty(P1 + z_new.numel(), ta.shape[1], dtype=torch.float32, device=dev)
-        pool_rad = torch.empty(P1 + z_new.numel(), 3, dtype=torch.float32, device=dev)
-        pool_tok[rows] = ta + tb                                                      # every pool row is exactly one slot
-        pool_rad[rows] = d_rad_s.view(-1, 3)
+        ops.ray_transform_bwd(W, grads, pool_tok, RN, S2, d_srdf_s, row=row, out=(pool_a, pool_b), precision=prec)
         # ---- coarse pass (its weights feed the importance sampler detached: model.py:456-457)
-        d_rad_c, d_srdf_c, d_var1 = ops.composite_bwd(z1, rad1.view(RN, SN, 3), srdf1, var, d_rgb, d_depth, d_opacity, d_weight)
+        _, d_srdf_c, _ = ops.composite_bwd(z1, pool_rad[:P1].view(RN, SN, 3), srdf1, var, d_rgb, d_depth, d_opacity, d_weight,
+                                           d_radiance=pool_drad[:P1], accumulate=True, d_variance=d_var)
         if d_srdf is not None:
             d_srdf_c = d_srdf_c + d_srdf
-        ca, cb = ops.ray_transform_bwd(W, grads, tok1, RN, SN, d_srdf_c)
+        ops.ray_transform_bwd(W, grads, pool_tok[:P1], RN, SN, d_srdf_c, out=(pool_a[:P1], pool_b[:P1]), accumulate=True,
+                              precision=prec)
         # ---- view transformer backwards: coarse samples once, with the cotangents of both passes; new samples once
-        d_pv1 = ops.view_transform_bwd(W, grads, x1, rgbm1, dirs1, ca + cb, pool_tok[:P1], d_rad_c.view(-1, 3) + pool_rad[:P1])
-        d_pv2 = ops.view_transform_bwd(W, grads, x2, rgbm2, dirs2, pool_tok[P1:], None, pool_rad[P1:])
+        d_pv1 = ops.view_transform_bwd(W, grads, x1, rgbm1, dirs1, pool_a[:P1], pool_b[:P1], pool_drad[:P1], precision=prec)
+        d_pv2 = ops.view_transform_bwd(W, grads, x2, rgbm2, dirs2, pool_a[P1:], pool_b[P1:], pool_drad[P1:], precision=prec)
         need = ctx.needs_input_grad[6:]
         if any(need[ctx.n_par:]):
             gvol = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.vol_shapes]
@@ -137,10 +147,10 @@ class RenderTwoPass(torch.autograd.Function):
         else:
             gvol = [None] * len(ctx.vol_shapes)
             gf = gw = None
-        ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z1, sim8_1, d_pv1, gf, gw)
-        ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z_new, sim8_2, d_pv2, gf, gw)
+        ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z1, sim8_1, d_pv1, gf, gw, precision=prec)
+        ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z_new, sim8_2, d_pv2, gf, gw, precision=prec)
         gpar = [grads.grad(k) for k in ops.RAW_WEIGHT_KEYS]
-        gpar[-1] = (d_var1 + d_var2).reshape(gpar[-1].shape)
+        gpar[-1] = d_var.reshape(gpar[-1].shape)
         out = [g if (n and g is not None) else None for g, n in zip(gpar + gvol, need)]
         return (None, None, None, None, None, None, *out)
 
@@ -158,8 +168,9 @@ class Aggregate(torch.autograd.Function):
         # every point is its own "ray" of one sample: position = o + 0 * d, exact
         x, rgbm, dirs, dbg = ops.project_gather(frame, weights, points, zeros3, zeros3[:, :1].contiguous(), want_xy=True,
                                                 vol24_in=vol24, sim8_in=sim8)
-        radiance, srdf, agg = ops.aggregate(weights, x, rgbm, dirs, RN, SN, keep_workspace=True)
-        ctx.frame, ctx.weights, ctx.dims = frame, weights, (RN, SN)
+        prec = weights.mode()
+        radiance, srdf, agg = ops.aggregate(weights, x, rgbm, dirs, RN, SN, keep_workspace=True, precision=prec)
+        ctx.frame, ctx.weights, ctx.dims, ctx.precision = frame, weights, (RN, SN), prec
         ctx.save_for_backward(points, zeros3, x, rgbm, dirs, sim8, agg["token0"])
         ctx.mark_non_differentiable(dbg["xy"])
         return radiance, srdf, dbg["xy"]
@@ -175,8 +186,9 @@ class Aggregate(torch.autograd.Function):
         if d_srdf is None:
             d_srdf = torch.zeros(RN, SN, device=dev)
         grads = ops.GradBuffer(dev)
-        d_pv, _ = ops.aggregate_bwd(W, grads, x, rgbm, dirs, token0, RN, SN, d_radiance, d_srdf)
-        ops.project_gather_bwd(ctx.frame, W, grads, points, zeros3, zeros3[:, :1].contiguous(), sim8, d_pv, None, None)
+        d_pv, _ = ops.aggregate_bwd(W, grads, x, rgbm, dirs, token0, RN, SN, d_radiance, d_srdf, precision=ctx.precision)
+        ops.project_gather_bwd(ctx.frame, W, grads, points, zeros3, zeros3[:, :1].contiguous(), sim8, d_pv, None, None,
+                               precision=ctx.precision)
         gpar = [grads.grad(k) for k in ops.RAW_WEIGHT_KEYS]
         need = ctx.needs_input_grad
         d_vol24 = d_pv[:, :24].contiguous() if need[5] else None

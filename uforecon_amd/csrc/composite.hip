@@ -104,7 +104,10 @@ __global__ void __launch_bounds__(256) composite_kernel(const float* __restrict_
 // and the variance parameter given d rgb / d depth / d opacity / d weight (any may be NULL = zero).  Same lane <-> sample
 // map as the forward; the transmittance product becomes an exclusive SUFFIX sum of d w_k w_k:
 //   w_k = alpha_k prod_{j<k} (1 - alpha_j + 1e-7)   =>   d alpha_i = d w_i T_i - (sum_{k>i} d w_k w_k) / (1 - alpha_i + 1e-7)
+// rad_row (nullable): row of `radiance` / `d_radiance` holding slot (ray, i) -- the sample pool of the two-pass training step;
+// accumulate: d_radiance += instead of = (a pool row receives the coarse pass's cotangent on top of the fine pass's)
 __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restrict__ z, const float* __restrict__ radiance,
+                                                             const int* __restrict__ rad_row, int accumulate,
                                                              const float* __restrict__ srdf,
                                                              const float* __restrict__ variance, int RN, int SN,
                                                              const float* __restrict__ d_rgb, const float* __restrict__ d_depth,
@@ -163,11 +166,13 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
       Tk[k] = T;
       w[k] = alpha[k] * T;
       T *= (1.f - alpha[k]) + 1e-7f;
-      const float* c = radiance + ((size_t)ray * SN + i) * 3;
-      dw[k] = (d_weight ? d_weight[(size_t)ray * SN + i] : 0.f) + gr * c[0] + gg * c[1] + gb * c[2] + gd * zr[i] + go;
+      const size_t slot = (size_t)ray * SN + i, rrow = rad_row ? (size_t)rad_row[slot] : slot;
+      const float* c = radiance + rrow * 3;
+      dw[k] = (d_weight ? d_weight[slot] : 0.f) + gr * c[0] + gg * c[1] + gb * c[2] + gd * zr[i] + go;
       lane_sum += dw[k] * w[k];
-      float* dr = d_radiance + ((size_t)ray * SN + i) * 3;
-      dr[0] = w[k] * gr; dr[1] = w[k] * gg; dr[2] = w[k] * gb;
+      float* dr = d_radiance + rrow * 3;
+      if (accumulate) { dr[0] += w[k] * gr; dr[1] += w[k] * gg; dr[2] += w[k] * gb; }
+      else { dr[0] = w[k] * gr; dr[1] = w[k] * gg; dr[2] = w[k] * gb; }
     }
   }
   // exclusive suffix sum over lanes
@@ -199,11 +204,13 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(const float* __restr
   if (lane == 0 && s_live) atomicAdd(d_variance, dvar * 10.f * inv_s);   // inv_s = exp(10 variance)
 }
 
-hipError_t launch_composite_bwd(const float* z, const float* radiance, const float* srdf, const float* variance, int RN,
-                                int SN, const float* d_rgb, const float* d_depth, const float* d_opacity,
-                                const float* d_weight, float* d_radiance, float* d_srdf, float* d_variance, hipStream_t s) {
+hipError_t launch_composite_bwd(const float* z, const float* radiance, const int* rad_row, bool accumulate, const float* srdf,
+                                const float* variance, int RN, int SN, const float* d_rgb, const float* d_depth,
+                                const float* d_opacity, const float* d_weight, float* d_radiance, float* d_srdf,
+                                float* d_variance, hipStream_t s) {
   if (SN > 64 * kMaxK || SN < 2) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(composite_bwd_kernel, dim3((RN + 3) / 4), dim3(256), 0, s, z, radiance, srdf, variance, RN, SN, d_rgb,
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3((RN + 3) / 4), dim3(256), 0, s, z, radiance, rad_row, accumulate ? 1 : 0, srdf,
+                     variance, RN, SN, d_rgb,
                      d_depth, d_opacity, d_weight, d_radiance, d_srdf, d_variance);
   return hipGetLastError();
 }

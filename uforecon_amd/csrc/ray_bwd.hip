@@ -57,6 +57,7 @@ constexpr int kSlots3 = (kList3.first[2] + kBwdWaves - 1) / kBwdWaves;   // 72 t
 
 template <bool LOWP>
 __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPtrs gp, const float* __restrict__ token0,
+                                                              const int* __restrict__ tok_row, int accumulate,
                                                               const float* __restrict__ order_pe,
                                                               const float* __restrict__ d_srdf, int RN, int SN,
                                                               float* __restrict__ d_tok_a, float* __restrict__ d_tok_b,
@@ -90,7 +91,8 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
   auto load_x = [&](int ray, int s0) {
     for (int idx = tid; idx < kTT * 22; idx += kBwdThreads) {
       const int col = idx / 22, f4 = idx - col * 22;
-      const f32x4 v = f4 < 20 ? ld4(token0 + ((size_t)ray * SN + s0 + col) * UFR_TOKEN_DIM + 4 * f4)
+      const size_t slot = (size_t)ray * SN + s0 + col;
+      const f32x4 v = f4 < 20 ? ld4(token0 + (tok_row ? (size_t)tok_row[slot] : slot) * UFR_TOKEN_DIM + 4 * f4)
                               : ld4(order_pe + (size_t)(s0 + col) * 8 + 4 * (f4 - 20));
 #pragma unroll
       for (int e = 0; e < 4; ++e) R(O_CAT + 4 * f4 + e)[col] = v[e];
@@ -303,7 +305,10 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = R(O_DY + 4 * f4 + e)[col];
-        st4(d_tok_a + ((size_t)ray * SN + s0 + col) * UFR_TOKEN_DIM + 4 * f4, v);
+        const size_t slot = (size_t)ray * SN + s0 + col;
+        float* dst = d_tok_a + (tok_row ? (size_t)tok_row[slot] : slot) * UFR_TOKEN_DIM + 4 * f4;
+        if (accumulate) v += ld4(dst);
+        st4(dst, v);
       }
       // small gradients: DensityMLP biases and last layer
       if (tid >= 176 && tid < 208) accB += row_dot(R(O_DD1 + (tid - 176)), nullptr, 0);
@@ -377,7 +382,10 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = R(O_DY + 4 * f4 + e)[col];
-        st4(d_tok_b + ((size_t)ray * SN + s0 + col) * UFR_TOKEN_DIM + 4 * f4, v);
+        const size_t slot = (size_t)ray * SN + s0 + col;
+        float* dst = d_tok_b + (tok_row ? (size_t)tok_row[slot] : slot) * UFR_TOKEN_DIM + 4 * f4;
+        if (accumulate) v += ld4(dst);
+        st4(dst, v);
       }
       if (dbg) {
         for (int idx = tid; idx < kTT * 88; idx += kBwdThreads) {
@@ -474,9 +482,9 @@ __global__ void __launch_bounds__(kBwdThreads) presim_bwd_kernel(RawPtrs wp, Gra
 }
 
 template <bool LOWP>
-static hipError_t launch_ray_bwd_t(const RawPtrs& wp, const GradPtrs& gp, const float* token0, const float* order_pe,
-                                   const float* d_srdf, int RN, int SN, float* d_tok_a, float* d_tok_b, float* dbg,
-                                   hipStream_t s) {
+static hipError_t launch_ray_bwd_t(const RawPtrs& wp, const GradPtrs& gp, const float* token0, const int* tok_row,
+                                   bool accumulate, const float* order_pe, const float* d_srdf, int RN, int SN,
+                                   float* d_tok_a, float* d_tok_b, float* dbg, hipStream_t s) {
   static bool attr_set[16] = {};   // the attribute is per device
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
@@ -487,23 +495,24 @@ static hipError_t launch_ray_bwd_t(const RawPtrs& wp, const GradPtrs& gp, const 
     attr_set[dev] = true;
   }
   const int blocks = RN < 256 ? RN : 256;
-  hipLaunchKernelGGL(ray_bwd_kernel<LOWP>, dim3(blocks), dim3(kBwdThreads), rb::kLdsBytes, s, wp, gp, token0, order_pe,
-                     d_srdf, RN, SN, d_tok_a, d_tok_b, dbg);
+  hipLaunchKernelGGL(ray_bwd_kernel<LOWP>, dim3(blocks), dim3(kBwdThreads), rb::kLdsBytes, s, wp, gp, token0, tok_row,
+                     accumulate ? 1 : 0, order_pe, d_srdf, RN, SN, d_tok_a, d_tok_b, dbg);
   return hipGetLastError();
 }
 
-hipError_t launch_ray_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* token0, const float* order_pe,
-                          const float* d_srdf, int RN, int SN, float* d_tok_a, float* d_tok_b, float* dbg, hipStream_t s) {
+hipError_t launch_ray_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* token0, const int* tok_row, bool accumulate,
+                          const float* order_pe, const float* d_srdf, int RN, int SN, float* d_tok_a, float* d_tok_b,
+                          float* dbg, bool lowp, hipStream_t s) {
   if (SN % kTT != 0 || SN < kTT) return hipErrorInvalidValue;
-  return matrix_precision_reduced() ? launch_ray_bwd_t<true>(wp, gp, token0, order_pe, d_srdf, RN, SN, d_tok_a, d_tok_b, dbg, s)
-                                    : launch_ray_bwd_t<false>(wp, gp, token0, order_pe, d_srdf, RN, SN, d_tok_a, d_tok_b, dbg, s);
+  return lowp ? launch_ray_bwd_t<true>(wp, gp, token0, tok_row, accumulate, order_pe, d_srdf, RN, SN, d_tok_a, d_tok_b, dbg, s)
+              : launch_ray_bwd_t<false>(wp, gp, token0, tok_row, accumulate, order_pe, d_srdf, RN, SN, d_tok_a, d_tok_b, dbg, s);
 }
 
-hipError_t launch_presim_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* sim8, const float* d_pv, int P,
+hipError_t launch_presim_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* sim8, const float* d_pv, int P, bool lowp,
                              hipStream_t s) {
   const int n_tiles = (P + kTT - 1) / kTT;
   const dim3 grid(n_tiles < 256 ? n_tiles : 256), block(kBwdThreads);
-  if (matrix_precision_reduced()) hipLaunchKernelGGL(presim_bwd_kernel<true>, grid, block, 0, s, wp, gp, sim8, d_pv, P);
+  if (lowp) hipLaunchKernelGGL(presim_bwd_kernel<true>, grid, block, 0, s, wp, gp, sim8, d_pv, P);
   else hipLaunchKernelGGL(presim_bwd_kernel<false>, grid, block, 0, s, wp, gp, sim8, d_pv, P);
   return hipGetLastError();
 }

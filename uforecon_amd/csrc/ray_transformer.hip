@@ -80,7 +80,8 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
                                                                   const int* __restrict__ tok_row,
                                                                   const float* __restrict__ order_pe, int RN, int SN,
                                                                   float* __restrict__ srdf,
-                                                                  float* __restrict__ ray_out) {
+                                                                  float* __restrict__ ray_out,
+                                                                  int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   auto ws = wstream_f16_begin<kRtWaves, LOWP>(packed, smem);
   wstream_f16_prime<B_RT1, kRtWaves>(ws);
@@ -258,13 +259,16 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
 #pragma unroll
     for (int c = 0; c < C; ++c)
       if (g == 0 && valid && live[c]) srdf[(size_t)ray * SN + tbase[c] + j] = d3[c][0][0];
+#pragma unroll
+    for (int c = 0; c < C; ++c) probe_output(ws, g == 0 && valid && live[c], d3[c][0][0]);
     wstream_f16_finish<B_RT2, kRtWaves>(ws, wrap);
   }
+  wstream_report_range(ws, status);
 }
 
 template <bool LOWP>
 static hipError_t launch_rt(const float* packed, const float* token0, const int* tok_row, const float* order_pe, int RN,
-                            int SN, float* srdf, float* ray_out, hipStream_t s) {
+                            int SN, float* srdf, float* ray_out, int* status, hipStream_t s) {
   // the attribute is per device: set it once on every device this process launches on
   static bool attr_set[16] = {};
   int dev = 0;
@@ -276,15 +280,15 @@ static hipError_t launch_rt(const float* packed, const float* token0, const int*
     attr_set[dev] = true;
   }
   hipLaunchKernelGGL(ray_transformer_kernel<LOWP>, dim3((RN + kRtWaves - 1) / kRtWaves), dim3(kRtBlock), kF16LdsBytes, s,
-                     packed, token0, tok_row, order_pe, RN, SN, srdf, ray_out);
+                     packed, token0, tok_row, order_pe, RN, SN, srdf, ray_out, status);
   return hipGetLastError();
 }
 
 hipError_t launch_ray_transformer(const float* packed, const float* token0, const int* tok_row, const float* order_pe,
-                                  int RN, int SN, float* srdf, float* ray_out, hipStream_t s) {
+                                  int RN, int SN, float* srdf, float* ray_out, bool lowp, int* status, hipStream_t s) {
   if (SN % 16 != 0 || SN < 16) return hipErrorInvalidValue;
-  return matrix_precision_reduced() ? launch_rt<true>(packed, token0, tok_row, order_pe, RN, SN, srdf, ray_out, s)
-                                    : launch_rt<false>(packed, token0, tok_row, order_pe, RN, SN, srdf, ray_out, s);
+  return lowp ? launch_rt<true>(packed, token0, tok_row, order_pe, RN, SN, srdf, ray_out, status, s)
+              : launch_rt<false>(packed, token0, tok_row, order_pe, RN, SN, srdf, ray_out, status, s);
 }
 
 }  // namespace ufr

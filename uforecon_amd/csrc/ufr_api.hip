@@ -53,7 +53,7 @@ struct Carver {  // bump allocator over a caller workspace
 // ---- optional per-kernel timing with HIP events on the caller's stream
 // process-wide (the backward entry points are called from autograd's worker thread, not the caller's)
 struct ProfEntry { const char* name; hipEvent_t a, b; };
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};
 std::vector<ProfEntry> g_prof;
 std::mutex g_prof_mu;
 
@@ -62,7 +62,7 @@ struct ProfScope {
   hipEvent_t a = nullptr, b = nullptr;
   const char* name;
   ProfScope(const char* n, hipStream_t st) : s(st), name(n) {
-    if (g_prof_on) {
+    if (g_prof_on.load(std::memory_order_relaxed)) {
       hipEventCreate(&a);
       hipEventCreate(&b);
       hipEventRecord(a, s);
@@ -104,10 +104,70 @@ hipError_t launch_order_pe(float* table, int SN, hipStream_t s) {
 }
 }  // namespace ufr
 
-namespace ufr {
-static std::atomic<int> g_matrix_precision{UFR_PRECISION_FP32};
-bool matrix_precision_reduced() { return g_matrix_precision.load(std::memory_order_relaxed) == UFR_PRECISION_16BIT; }
-}  // namespace ufr
+namespace {
+std::atomic<int> g_matrix_precision{UFR_PRECISION_FP32};   // what UFR_PRECISION_DEFAULT resolves to
+
+// precision argument of an entry point -> "reduced" flag of the launchers; false + error for an unknown value
+bool resolve_precision(int precision, bool* lowp) {
+  if (precision == UFR_PRECISION_DEFAULT) precision = g_matrix_precision.load(std::memory_order_relaxed);
+  if (precision != UFR_PRECISION_FP32 && precision != UFR_PRECISION_16BIT) return false;
+  *lowp = precision == UFR_PRECISION_16BIT;
+  return true;
+}
+#define UFR_PRECISION(arg, lowp_var, who)                                                        \
+  bool lowp_var = false;                                                                          \
+  if (!resolve_precision(arg, &lowp_var)) return fail(UFR_ERR_ARG, "%s: unknown precision %d", who, (int)(arg))
+
+// ---- sticky range status (include/ufr.h: ufr_status_poll): one device word the kernels OR into, one pinned host word
+// the entry points copy it to.  Per device, created on first use, never freed (process lifetime).
+struct StatusSlot { int* dev = nullptr; volatile int* host = nullptr; };
+constexpr int kStatusDevices = 16;
+StatusSlot g_status[kStatusDevices];
+std::mutex g_status_mu;
+
+int status_slot(StatusSlot** out) {
+  int dev = 0;
+  UFR_HIP(hipGetDevice(&dev));
+  UFR_REQUIRE(dev >= 0 && dev < kStatusDevices, "status: device %d out of range", dev);
+  StatusSlot& sl = g_status[dev];
+  if (!sl.dev) {
+    std::lock_guard<std::mutex> lock(g_status_mu);
+    if (!sl.dev) {
+      int* h = nullptr;
+      int* d = nullptr;
+      UFR_HIP(hipHostMalloc(reinterpret_cast<void**>(&h), sizeof(int), hipHostMallocDefault));
+      *h = 0;
+      UFR_HIP(hipMalloc(reinterpret_cast<void**>(&d), sizeof(int)));
+      UFR_HIP(hipMemset(d, 0, sizeof(int)));
+      sl.host = h;
+      sl.dev = d;
+    }
+  }
+  *out = &sl;
+  return UFR_OK;
+}
+
+int status_message(int bits, const char* who) {
+  return fail(UFR_ERR_RANGE, "%s: range status 0x%x:%s%s%s (include/ufr.h: ufr_status_poll)", who, bits,
+              (bits & 1) ? " a dense-layer input reached |x| >= 4094 (fp16 planes overflowed);" : "",
+              (bits & 2) ? " a transformer kernel produced non-finite output rows;" : "",
+              (bits & 4) ? " ufr_weights_pack met a weight that is not finite or |w| >= 255.8;" : "");
+}
+
+// entry of a compute call: report (and clear) what an earlier call's copy delivered
+int status_enter(StatusSlot* sl, hipStream_t s, const char* who) {
+  const int bits = *sl->host;
+  if (bits == 0) return UFR_OK;
+  *sl->host = 0;
+  UFR_HIP(hipMemsetAsync(sl->dev, 0, sizeof(int), s));
+  return status_message(bits, who);
+}
+// exit of a compute call: deliver the flag as of the end of this call's kernels
+int status_leave(StatusSlot* sl, hipStream_t s) {
+  UFR_HIP(hipMemcpyAsync(const_cast<int*>(sl->host), sl->dev, sizeof(int), hipMemcpyDeviceToHost, s));
+  return UFR_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -118,11 +178,31 @@ int ufr_set_matrix_precision(int mode) {
 }
 int ufr_get_matrix_precision(void) { return g_matrix_precision.load(std::memory_order_relaxed); }
 
-int ufr_version(void) { return 100; }
+int ufr_status_poll(ufr_stream stream, int32_t synchronize, int32_t* flags_out) {
+  StatusSlot* sl = nullptr;
+  int rc = status_slot(&sl);
+  if (rc != UFR_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (synchronize) {
+    UFR_HIP(hipMemcpyAsync(const_cast<int*>(sl->host), sl->dev, sizeof(int), hipMemcpyDeviceToHost, s));
+    UFR_HIP(hipStreamSynchronize(s));
+  }
+  const int bits = *sl->host;
+  if (flags_out) *flags_out = bits;
+  if (bits == 0) {
+    if (!synchronize) return status_leave(sl, s);
+    return UFR_OK;
+  }
+  *sl->host = 0;
+  UFR_HIP(hipMemsetAsync(sl->dev, 0, sizeof(int), s));
+  return status_message(bits, "ufr_status_poll");
+}
+
+int ufr_version(void) { return UFR_ABI_VERSION; }
 const char* ufr_last_error(void) { return g_err; }
 
 // ------------------------------------------------------------------ weights
-// [fp32 region | fp16 plane region | 16-byte tail: range flag written by ufr_weights_pack]
+// [fp32 region | fp16 plane region | 16-byte tail (reserved)]
 size_t ufr_packed_weights_bytes(void) { return (size_t)blob_floats() * sizeof(float) + (size_t)kF16Bytes + 16; }
 size_t ufr_packed_fp32_floats(void) { return (size_t)blob_floats(); }
 size_t ufr_packed_f16_halfwords(void) { return (size_t)kF16Halfwords; }
@@ -151,16 +231,13 @@ int ufr_weights_pack(const ufr_raw_weights* raw, void* packed, ufr_stream stream
   memcpy(&rp, raw, sizeof(rp));
   for (int i = 0; i < P_COUNT; ++i) UFR_REQUIRE(rp.p[i], "ufr_weights_pack: parameter %d is null", i);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int* flag = reinterpret_cast<int*>(static_cast<char*>(packed) + (size_t)blob_floats() * sizeof(float) + (size_t)kF16Bytes);
-  UFR_HIP(hipMemsetAsync(flag, 0, 16, s));
-  UFR_HIP(launch_pack_weights(rp, static_cast<float*>(packed), flag, s));
-  // the fp16 planes hold 2^8 w: a weight beyond +-255.8 (or a non-finite one) cannot be represented -- fail here, loudly,
-  // rather than render with it
-  int host_flag = 0;
-  UFR_HIP(hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, s));
-  UFR_HIP(hipStreamSynchronize(s));
-  UFR_REQUIRE(host_flag == 0, "ufr_weights_pack: a dense-layer weight is not finite or exceeds the supported magnitude (|w| < 255.8)");
-  return UFR_OK;
+  StatusSlot* sl = nullptr;
+  int rc = status_slot(&sl);
+  if (rc != UFR_OK) return rc;
+  // the fp16 planes hold 2^8 w: a weight beyond +-255.8 (or a non-finite one) cannot be represented -- the pack kernel
+  // raises bit 2 of the sticky status (no synchronisation here: training re-packs after every optimizer step)
+  UFR_HIP(launch_pack_weights(rp, static_cast<float*>(packed), sl->dev, s));
+  return status_leave(sl, s);
 }
 
 // ------------------------------------------------------------------ frame
@@ -301,39 +378,47 @@ size_t ufr_aggregate_workspace_bytes(int32_t RN, int32_t SN, int32_t NV) {
 
 static int aggregate_impl(const void* packed, const float* x_tokens, const float* rgb, const float* dir, int RN, int SN,
                           int NV, float* radiance, float* srdf, float* token0, float* order_pe, bool pe_ready,
-                          float* view_out, float* ray_out, hipStream_t s) {
+                          float* view_out, float* ray_out, bool lowp, int* status, hipStream_t s) {
   {
     ProfScope ps("view_transformer", s);
     UFR_HIP(launch_view_transformer(static_cast<const float*>(packed), x_tokens, rgb, dir, RN * SN, NV, token0, radiance,
-                                    view_out, s));
+                                    view_out, lowp, status, s));
   }
   if (!pe_ready) UFR_HIP(launch_order_pe(order_pe, SN, s));
   {
     ProfScope ps("ray_transformer", s);
-    UFR_HIP(launch_ray_transformer(static_cast<const float*>(packed), token0, nullptr, order_pe, RN, SN, srdf, ray_out, s));
+    UFR_HIP(launch_ray_transformer(static_cast<const float*>(packed), token0, nullptr, order_pe, RN, SN, srdf, ray_out, lowp,
+                                   status, s));
   }
   return UFR_OK;
 }
 
 int ufr_aggregate(const void* packed_weights, const float* x_tokens, const float* rgb, const float* dir, int32_t RN,
                   int32_t SN, int32_t NV, float* radiance, float* srdf, void* workspace, float* view_out,
-                  float* ray_out, ufr_stream stream) {
+                  float* ray_out, int32_t precision, ufr_stream stream) {
   UFR_REQUIRE(packed_weights && x_tokens && rgb && dir && radiance && srdf && workspace, "ufr_aggregate: null argument");
   UFR_REQUIRE(NV >= 2 && NV <= UFR_MAX_VIEWS, "ufr_aggregate: NV=%d unsupported", NV);
   UFR_REQUIRE(RN > 0 && SN >= 16 && SN % 16 == 0 && SN <= 256, "ufr_aggregate: SN=%d must be a multiple of 16 in [16,256]", SN);
+  UFR_PRECISION(precision, lowp, "ufr_aggregate");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  StatusSlot* sl = nullptr;
+  int rc = status_slot(&sl);
+  if (rc == UFR_OK) rc = status_enter(sl, s, "ufr_aggregate");
+  if (rc != UFR_OK) return rc;
   Carver c(workspace);
   float* token0 = c.f32((size_t)RN * SN * UFR_TOKEN_DIM);
   float* order_pe = c.f32((size_t)SN * 8);
-  return aggregate_impl(packed_weights, x_tokens, rgb, dir, RN, SN, NV, radiance, srdf, token0, order_pe, false, view_out,
-                        ray_out, static_cast<hipStream_t>(stream));
+  rc = aggregate_impl(packed_weights, x_tokens, rgb, dir, RN, SN, NV, radiance, srdf, token0, order_pe, false, view_out,
+                      ray_out, lowp, sl->dev, s);
+  return rc != UFR_OK ? rc : status_leave(sl, s);
 }
 
-int ufr_composite(const float* z, const float* radiance, const float* srdf, const float* variance, int32_t RN,
-                  int32_t SN, float* rgb, float* depth, float* opacity, float* weight, ufr_stream stream) {
+int ufr_composite(const float* z, const float* radiance, const int32_t* row, const float* srdf, const float* variance,
+                  int32_t RN, int32_t SN, float* rgb, float* depth, float* opacity, float* weight, ufr_stream stream) {
   UFR_REQUIRE(z && radiance && srdf && variance && depth, "ufr_composite: null argument");
   UFR_REQUIRE(RN > 0 && SN >= 2 && SN <= 256, "ufr_composite: SN=%d out of range [2,256]", SN);
   ProfScope prof("composite", static_cast<hipStream_t>(stream));
-  UFR_HIP(launch_composite(z, radiance, nullptr, srdf, variance, RN, SN, rgb, depth, opacity, weight, nullptr, nullptr,
+  UFR_HIP(launch_composite(z, radiance, row, srdf, variance, RN, SN, rgb, depth, opacity, weight, nullptr, nullptr,
                            static_cast<hipStream_t>(stream)));
   return UFR_OK;
 }
@@ -348,15 +433,16 @@ static int raw_and_grads(const ufr_raw_weights* raw, const ufr_raw_grads* grads,
   return UFR_OK;
 }
 
-int ufr_composite_bwd(const float* z, const float* radiance, const float* srdf, const float* variance, int32_t RN,
-                      int32_t SN, const float* d_rgb, const float* d_depth, const float* d_opacity, const float* d_weight,
-                      float* d_radiance, float* d_srdf, float* d_variance, ufr_stream stream) {
+int ufr_composite_bwd(const float* z, const float* radiance, const int32_t* row, const float* srdf, const float* variance,
+                      int32_t RN, int32_t SN, const float* d_rgb, const float* d_depth, const float* d_opacity,
+                      const float* d_weight, float* d_radiance, int32_t accumulate, float* d_srdf, float* d_variance,
+                      ufr_stream stream) {
   UFR_REQUIRE(z && radiance && srdf && variance && d_radiance && d_srdf && d_variance, "ufr_composite_bwd: null argument");
   UFR_REQUIRE(RN > 0 && SN >= 2 && SN <= 256, "ufr_composite_bwd: SN=%d out of range [2,256]", SN);
   hipStream_t s = static_cast<hipStream_t>(stream);
   ProfScope p("composite_bwd", s);
-  UFR_HIP(launch_composite_bwd(z, radiance, srdf, variance, RN, SN, d_rgb, d_depth, d_opacity, d_weight, d_radiance, d_srdf,
-                               d_variance, s));
+  UFR_HIP(launch_composite_bwd(z, radiance, row, accumulate != 0, srdf, variance, RN, SN, d_rgb, d_depth, d_opacity, d_weight,
+                               d_radiance, d_srdf, d_variance, s));
   return UFR_OK;
 }
 
@@ -372,11 +458,12 @@ size_t ufr_aggregate_bwd_workspace_bytes(int32_t RN, int32_t SN, int32_t NV) {
 int ufr_aggregate_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const float* x_tokens, const float* rgb,
                       const float* dir, const float* token0, int32_t RN, int32_t SN, int32_t NV, const float* d_radiance,
                       const float* d_srdf, float* d_pv, void* workspace, float* debug_view, float* debug_ray,
-                      ufr_stream stream) {
+                      int32_t precision, ufr_stream stream) {
   RawPtrs rp;
   GradPtrs gp;
   int rc = raw_and_grads(raw, grads, rp, gp, "ufr_aggregate_bwd");
   if (rc != UFR_OK) return rc;
+  UFR_PRECISION(precision, lowp, "ufr_aggregate_bwd");
   UFR_REQUIRE(x_tokens && rgb && dir && token0 && d_radiance && d_srdf && d_pv && workspace, "ufr_aggregate_bwd: null argument");
   UFR_REQUIRE(NV >= 2 && NV <= UFR_MAX_VIEWS, "ufr_aggregate_bwd: NV=%d unsupported", NV);
   UFR_REQUIRE(RN > 0 && SN >= 16 && SN % 16 == 0 && SN <= 256, "ufr_aggregate_bwd: SN=%d must be a multiple of 16 in [16,256]", SN);
@@ -388,11 +475,11 @@ int ufr_aggregate_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, co
   UFR_HIP(launch_order_pe(order_pe, SN, s));
   {
     ProfScope p("ray_bwd", s);
-    UFR_HIP(launch_ray_bwd(rp, gp, token0, order_pe, d_srdf, RN, SN, d_tok_a, d_tok_b, debug_ray, s));
+    UFR_HIP(launch_ray_bwd(rp, gp, token0, nullptr, false, order_pe, d_srdf, RN, SN, d_tok_a, d_tok_b, debug_ray, lowp, s));
   }
   {
     ProfScope p("view_bwd", s);
-    UFR_HIP(launch_view_bwd(rp, gp, x_tokens, rgb, dir, d_tok_a, d_tok_b, d_radiance, RN * SN, NV, d_pv, debug_view, s));
+    UFR_HIP(launch_view_bwd(rp, gp, x_tokens, rgb, dir, d_tok_a, d_tok_b, d_radiance, RN * SN, NV, d_pv, debug_view, lowp, s));
   }
   return UFR_OK;
 }
@@ -400,9 +487,10 @@ int ufr_aggregate_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, co
 int ufr_project_gather_bwd(const ufr_frame* frame, const ufr_raw_weights* raw, const ufr_raw_grads* grads,
                            const float* ray_o, int32_t ray_o_stride, const float* ray_d, const float* z, int32_t RN,
                            int32_t SN, const float* sim8, const float* d_pv, float* const* grad_vol_feat,
-                           float* const* grad_vol_weight, ufr_stream stream) {
+                           float* const* grad_vol_weight, int32_t precision, ufr_stream stream) {
   const FrameDev* f = frame_of(frame);
   UFR_REQUIRE(f, "ufr_project_gather_bwd: frame handle not prepared");
+  UFR_PRECISION(precision, lowp, "ufr_project_gather_bwd");
   RawPtrs rp;
   GradPtrs gp;
   int rc = raw_and_grads(raw, grads, rp, gp, "ufr_project_gather_bwd");
@@ -422,7 +510,7 @@ int ufr_project_gather_bwd(const ufr_frame* frame, const ufr_raw_weights* raw, c
   }
   {
     ProfScope p("presim_bwd", s);
-    UFR_HIP(launch_presim_bwd(rp, gp, sim8, d_pv, RN * SN, s));
+    UFR_HIP(launch_presim_bwd(rp, gp, sim8, d_pv, RN * SN, lowp, s));
   }
   return UFR_OK;
 }
@@ -437,57 +525,76 @@ int ufr_sample_importance_pool(const float* weight, const float* z, const float*
 }
 
 int ufr_view_transform(const void* packed_weights, const float* x_tokens, const float* rgb, const float* dir, int32_t P,
-                       int32_t NV, float* token0, float* radiance, ufr_stream stream) {
+                       int32_t NV, float* token0, float* radiance, int32_t precision, ufr_stream stream) {
   UFR_REQUIRE(packed_weights && x_tokens && rgb && dir && token0 && radiance, "ufr_view_transform: null argument");
   UFR_REQUIRE(NV >= 2 && NV <= UFR_MAX_VIEWS && P > 0, "ufr_view_transform: P=%d NV=%d", P, NV);
+  UFR_PRECISION(precision, lowp, "ufr_view_transform");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  ProfScope p("view_transformer", s);
-  UFR_HIP(launch_view_transformer(static_cast<const float*>(packed_weights), x_tokens, rgb, dir, P, NV, token0, radiance, nullptr, s));
-  return UFR_OK;
+  StatusSlot* sl = nullptr;
+  int rc = status_slot(&sl);
+  if (rc == UFR_OK) rc = status_enter(sl, s, "ufr_view_transform");
+  if (rc != UFR_OK) return rc;
+  {
+    ProfScope p("view_transformer", s);
+    UFR_HIP(launch_view_transformer(static_cast<const float*>(packed_weights), x_tokens, rgb, dir, P, NV, token0, radiance,
+                                    nullptr, lowp, sl->dev, s));
+  }
+  return status_leave(sl, s);
 }
 
 size_t ufr_ray_transform_workspace_bytes(int32_t SN) { return align_up((size_t)(SN > 0 ? SN : 1) * 8 * sizeof(float)); }
 
-int ufr_ray_transform(const void* packed_weights, const float* token0, int32_t RN, int32_t SN, float* srdf, void* workspace,
-                      ufr_stream stream) {
+int ufr_ray_transform(const void* packed_weights, const float* token0, const int32_t* row, int32_t RN, int32_t SN,
+                      float* srdf, void* workspace, int32_t precision, ufr_stream stream) {
   UFR_REQUIRE(packed_weights && token0 && srdf && workspace, "ufr_ray_transform: null argument");
   UFR_REQUIRE(RN > 0 && SN >= 16 && SN % 16 == 0 && SN <= 256, "ufr_ray_transform: SN=%d must be a multiple of 16 in [16,256]", SN);
+  UFR_PRECISION(precision, lowp, "ufr_ray_transform");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  StatusSlot* sl = nullptr;
+  int rc = status_slot(&sl);
+  if (rc == UFR_OK) rc = status_enter(sl, s, "ufr_ray_transform");
+  if (rc != UFR_OK) return rc;
   float* order_pe = static_cast<float*>(workspace);
   UFR_HIP(launch_order_pe(order_pe, SN, s));
-  ProfScope p("ray_transformer", s);
-  UFR_HIP(launch_ray_transformer(static_cast<const float*>(packed_weights), token0, nullptr, order_pe, RN, SN, srdf, nullptr, s));
-  return UFR_OK;
+  {
+    ProfScope p("ray_transformer", s);
+    UFR_HIP(launch_ray_transformer(static_cast<const float*>(packed_weights), token0, row, order_pe, RN, SN, srdf, nullptr,
+                                   lowp, sl->dev, s));
+  }
+  return status_leave(sl, s);
 }
 
-int ufr_ray_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const float* token0, int32_t RN, int32_t SN,
-                          const float* d_srdf, float* d_token0_a, float* d_token0_b, void* workspace, ufr_stream stream) {
+int ufr_ray_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const float* token0, const int32_t* row,
+                          int32_t RN, int32_t SN, const float* d_srdf, float* d_token0_a, float* d_token0_b,
+                          int32_t accumulate, void* workspace, int32_t precision, ufr_stream stream) {
   RawPtrs rp;
   GradPtrs gp;
   int rc = raw_and_grads(raw, grads, rp, gp, "ufr_ray_transform_bwd");
   if (rc != UFR_OK) return rc;
+  UFR_PRECISION(precision, lowp, "ufr_ray_transform_bwd");
   UFR_REQUIRE(token0 && d_srdf && d_token0_a && d_token0_b && workspace, "ufr_ray_transform_bwd: null argument");
   UFR_REQUIRE(RN > 0 && SN >= 16 && SN % 16 == 0 && SN <= 256, "ufr_ray_transform_bwd: SN=%d must be a multiple of 16 in [16,256]", SN);
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* order_pe = static_cast<float*>(workspace);
   UFR_HIP(launch_order_pe(order_pe, SN, s));
   ProfScope p("ray_bwd", s);
-  UFR_HIP(launch_ray_bwd(rp, gp, token0, order_pe, d_srdf, RN, SN, d_token0_a, d_token0_b, nullptr, s));
+  UFR_HIP(launch_ray_bwd(rp, gp, token0, row, accumulate != 0, order_pe, d_srdf, RN, SN, d_token0_a, d_token0_b, nullptr, lowp, s));
   return UFR_OK;
 }
 
 int ufr_view_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const float* x_tokens, const float* rgb,
                            const float* dir, const float* d_token0_a, const float* d_token0_b, const float* d_radiance,
-                           int32_t P, int32_t NV, float* d_pv, ufr_stream stream) {
+                           int32_t P, int32_t NV, float* d_pv, int32_t precision, ufr_stream stream) {
   RawPtrs rp;
   GradPtrs gp;
   int rc = raw_and_grads(raw, grads, rp, gp, "ufr_view_transform_bwd");
   if (rc != UFR_OK) return rc;
+  UFR_PRECISION(precision, lowp, "ufr_view_transform_bwd");
   UFR_REQUIRE(x_tokens && rgb && dir && d_token0_a && d_radiance && d_pv, "ufr_view_transform_bwd: null argument");
   UFR_REQUIRE(NV >= 2 && NV <= UFR_MAX_VIEWS && P > 0, "ufr_view_transform_bwd: P=%d NV=%d", P, NV);
   hipStream_t s = static_cast<hipStream_t>(stream);
   ProfScope p("view_bwd", s);
-  UFR_HIP(launch_view_bwd(rp, gp, x_tokens, rgb, dir, d_token0_a, d_token0_b, d_radiance, P, NV, d_pv, nullptr, s));
+  UFR_HIP(launch_view_bwd(rp, gp, x_tokens, rgb, dir, d_token0_a, d_token0_b, d_radiance, P, NV, d_pv, nullptr, lowp, s));
   return UFR_OK;
 }
 
@@ -566,8 +673,8 @@ int side_pool_get(int n, SidePool** out) {
 }
 
 // one chunk of R rays starting at r0, entirely on stream s with workspace w
-int render_chunk(const ufr_render_args* a, const FrameDev* f, const RenderWs& w, bool& pe_ready, int r0, int R,
-                 hipStream_t s) {
+int render_chunk(const ufr_render_args* a, const FrameDev* f, const RenderWs& w, bool& pe_ready, int r0, int R, bool lowp,
+                 int* status, hipStream_t s) {
   const int RN = a->RN, SN = a->SN, PN = a->coarse_only ? 0 : a->PN, NV = f->NV;
   const PreSim ps = presim_of(a->raw);
   const int S2 = SN + PN, HW = f->H * f->W;
@@ -588,7 +695,7 @@ int render_chunk(const ufr_render_args* a, const FrameDev* f, const RenderWs& w,
     UFR_HIP(launch_gather(*f, ps, w.ray_o, 0, w.rd, w.z1, R, SN, w.x, w.rgbm, w.dir, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s));
   }
   int rc = aggregate_impl(a->packed_weights, w.x, w.rgbm, w.dir, R, SN, NV, w.rad, w.srdf1, w.token0, w.pe1, true,
-                          nullptr, nullptr, s);
+                          nullptr, nullptr, lowp, status, s);
   if (rc != UFR_OK) return rc;
   const bool last = a->coarse_only != 0;
   {
@@ -618,12 +725,13 @@ int render_chunk(const ufr_render_args* a, const FrameDev* f, const RenderWs& w,
   {
     ProfScope p("view_transformer", s);
     UFR_HIP(launch_view_transformer(static_cast<const float*>(a->packed_weights), w.x, w.rgbm, w.dir, R * PN, NV,
-                                    w.token0 + (size_t)R * SN * UFR_TOKEN_DIM, w.rad + (size_t)R * SN * 3, nullptr, s));
+                                    w.token0 + (size_t)R * SN * UFR_TOKEN_DIM, w.rad + (size_t)R * SN * 3, nullptr, lowp,
+                                    status, s));
   }
   {
     ProfScope p("ray_transformer", s);
     UFR_HIP(launch_ray_transformer(static_cast<const float*>(a->packed_weights), w.token0, w.row, w.pe2, R, S2, w.srdf2,
-                                   nullptr, s));
+                                   nullptr, lowp, status, s));
   }
   {
     ProfScope p("composite", s);
@@ -652,7 +760,12 @@ int ufr_render_rays(const ufr_render_args* a, ufr_stream stream) {
   const int chunk = a->chunk_rays > 0 ? a->chunk_rays : ufr_default_chunk_rays();
   const size_t need = ufr_render_workspace_bytes(chunk, SN, PN, NV);
   if (a->workspace_bytes < need) return fail(UFR_ERR_WORKSPACE, "render workspace too small: %zu < %zu", a->workspace_bytes, need);
+  UFR_PRECISION(a->precision, lowp, "ufr_render_rays");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  StatusSlot* sl = nullptr;
+  int src = status_slot(&sl);
+  if (src == UFR_OK) src = status_enter(sl, s, "ufr_render_rays");
+  if (src != UFR_OK) return src;
   int lanes = a->n_streams > 1 ? a->n_streams : 1;
   if (lanes > kMaxLanes) lanes = kMaxLanes;
   if ((size_t)lanes * need > a->workspace_bytes) lanes = (int)(a->workspace_bytes / need);  // one workspace per lane
@@ -672,10 +785,10 @@ int ufr_render_rays(const ufr_render_args* a, ufr_stream stream) {
     RenderWs w = carve_render(a->workspace, chunk, SN, PN, NV);
     bool pe_ready = false;
     for (int r0 = 0; r0 < RN; r0 += eff_chunk) {
-      int rc = render_chunk(a, f, w, pe_ready, r0, (RN - r0) < eff_chunk ? (RN - r0) : eff_chunk, s);
+      int rc = render_chunk(a, f, w, pe_ready, r0, (RN - r0) < eff_chunk ? (RN - r0) : eff_chunk, lowp, sl->dev, s);
       if (rc != UFR_OK) return rc;
     }
-    return UFR_OK;
+    return status_leave(sl, s);
   }
   SidePool* side = nullptr;
   int rc = side_pool_get(lanes, &side);
@@ -689,7 +802,7 @@ int ufr_render_rays(const ufr_render_args* a, ufr_stream stream) {
   }
   for (int c = 0; c < n_chunks && rc == UFR_OK; ++c) {
     const int l = c % lanes, r0 = c * eff_chunk;
-    rc = render_chunk(a, f, w[l], pe_ready[l], r0, (RN - r0) < eff_chunk ? (RN - r0) : eff_chunk, side->s[l]);
+    rc = render_chunk(a, f, w[l], pe_ready[l], r0, (RN - r0) < eff_chunk ? (RN - r0) : eff_chunk, lowp, sl->dev, side->s[l]);
   }
   // join even when a chunk failed: the caller's stream must not run ahead of (and its allocator must not recycle the
   // workspace under) side-stream kernels that were already enqueued
@@ -698,7 +811,7 @@ int ufr_render_rays(const ufr_render_args* a, ufr_stream stream) {
     if (e == hipSuccess) e = hipStreamWaitEvent(s, side->join[l], 0);
     if (e != hipSuccess) hipStreamSynchronize(side->s[l]);
   }
-  return rc;
+  return rc != UFR_OK ? rc : status_leave(sl, s);
 }
 
 // ------------------------------------------------------------------ correlation-volume construction
@@ -799,7 +912,7 @@ void ufr_profile_enable(int on) {
   std::lock_guard<std::mutex> lock(g_prof_mu);
   for (auto& e : g_prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   g_prof.clear();
-  g_prof_on = on != 0;
+  g_prof_on.store(on != 0, std::memory_order_relaxed);
 }
 
 int ufr_profile_read(const char** names, float* ms, int32_t* launches, int cap) {

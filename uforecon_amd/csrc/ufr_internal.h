@@ -49,29 +49,32 @@ hipError_t launch_gather(const FrameDev& f, const PreSim& ps, const float* ray_o
                          const float* z, int RN, int SN, float* x_tokens, float* rgb, float* dir, float* sim8,
                          float* vol24, float* xy, float* mask_z, const float* vol24_in, const float* sim8_in,
                          hipStream_t s);
-// process-wide matrix precision (ufr_set_matrix_precision): false = fp32-grade split precision (default), true = one
-// 16-bit plane per operand ("bf16" training mode of BASELINE configs[4]); read by the launchers
-bool matrix_precision_reduced();
-
+// lowp: matrix precision of the call (include/ufr.h): false = fp32-grade split precision, true = one 16-bit plane per
+// operand ("bf16" training mode of BASELINE configs[4]).  status: the device's sticky range word (ufr_status_poll).
 hipError_t launch_view_transformer(const float* packed, const float* x_tokens, const float* rgb, const float* dir,
-                                   int P, int NV, float* token0, float* radiance, float* view_out, hipStream_t s);
+                                   int P, int NV, float* token0, float* radiance, float* view_out, bool lowp, int* status,
+                                   hipStream_t s);
 // tok_row / rad_row (nullable): row of token0 / radiance holding sample (ray, s) -- the fine pass of the whole-path
 // renderer keeps coarse and new evaluations in one pool instead of re-evaluating the coarse points
 hipError_t launch_ray_transformer(const float* packed, const float* token0, const int* tok_row, const float* order_pe,
-                                  int RN, int SN, float* srdf, float* ray_out, hipStream_t s);
+                                  int RN, int SN, float* srdf, float* ray_out, bool lowp, int* status, hipStream_t s);
 hipError_t launch_composite(const float* z, const float* radiance, const int* rad_row, const float* srdf,
                             const float* variance, int RN, int SN, float* rgb, float* depth, float* opacity, float* weight,
                             const float* camz, float* depth_z, hipStream_t s);
-hipError_t launch_composite_bwd(const float* z, const float* radiance, const float* srdf, const float* variance, int RN,
-                                int SN, const float* d_rgb, const float* d_depth, const float* d_opacity,
-                                const float* d_weight, float* d_radiance, float* d_srdf, float* d_variance, hipStream_t s);
+hipError_t launch_composite_bwd(const float* z, const float* radiance, const int* rad_row, bool accumulate, const float* srdf,
+                                const float* variance, int RN, int SN, const float* d_rgb, const float* d_depth,
+                                const float* d_opacity, const float* d_weight, float* d_radiance, float* d_srdf,
+                                float* d_variance, hipStream_t s);
 struct GradPtrs;
 hipError_t launch_view_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* x_tokens, const float* rgbm,
                            const float* dirs, const float* d_tok_a, const float* d_tok_b, const float* d_radiance, int P,
-                           int NV, float* d_pv, float* dbg, hipStream_t s);
-hipError_t launch_ray_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* token0, const float* order_pe,
-                          const float* d_srdf, int RN, int SN, float* d_tok_a, float* d_tok_b, float* dbg, hipStream_t s);
-hipError_t launch_presim_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* sim8, const float* d_pv, int P,
+                           int NV, float* d_pv, float* dbg, bool lowp, hipStream_t s);
+// tok_row (nullable): pool row of sample (ray, s) for token0 AND for the d_tok_a / d_tok_b rows it produces; accumulate:
+// d_tok_* += (every pool row is written once per launch, so a plain read-modify-write)
+hipError_t launch_ray_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* token0, const int* tok_row, bool accumulate,
+                          const float* order_pe, const float* d_srdf, int RN, int SN, float* d_tok_a, float* d_tok_b,
+                          float* dbg, bool lowp, hipStream_t s);
+hipError_t launch_presim_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* sim8, const float* d_pv, int P, bool lowp,
                              hipStream_t s);
 hipError_t launch_gather_bwd(const FrameDev& f, float* const* grad_feat, float* const* grad_weight, const float* ray_o,
                              int o_stride, const float* ray_d, const float* z, const float* d_pv, int RN, int SN,

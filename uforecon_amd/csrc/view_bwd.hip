@@ -545,8 +545,8 @@ static hipError_t launch_view_bwd_t(const RawPtrs& wp, const GradPtrs& gp, const
 
 hipError_t launch_view_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* x_tokens, const float* rgbm,
                            const float* dirs, const float* d_tok_a, const float* d_tok_b, const float* d_radiance, int P,
-                           int NV, float* d_pv, float* dbg, hipStream_t s) {
-  return matrix_precision_reduced()
+                           int NV, float* d_pv, float* dbg, bool lowp, hipStream_t s) {
+  return lowp
              ? launch_view_bwd_t<true>(wp, gp, x_tokens, rgbm, dirs, d_tok_a, d_tok_b, d_radiance, P, NV, d_pv, dbg, s)
              : launch_view_bwd_t<false>(wp, gp, x_tokens, rgbm, dirs, d_tok_a, d_tok_b, d_radiance, P, NV, d_pv, dbg, s);
 }

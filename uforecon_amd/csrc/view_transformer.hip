@@ -52,7 +52,7 @@ __device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const WS& ws, int
 }
 
 // 256-thread workgroups (one wave per SIMD), two per CU; each streams the layer chain's weight planes
-// through its own pair of 24 KiB LDS slots.
+// through its own ring of three 12 KiB LDS slots (weight_stream_f16.h).
 #ifndef UFR_VT_BLOCK
 #define UFR_VT_BLOCK 256   // threads per workgroup
 #define UFR_VT_C 2         // token column tiles per wave
@@ -83,7 +83,8 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
                                                                              const float* __restrict__ dirs, int P,
                                                                              float* __restrict__ token0,
                                                                              float* __restrict__ radiance,
-                                                                             float* __restrict__ view_out) {
+                                                                             float* __restrict__ view_out,
+                                                                             int* __restrict__ status) {
   constexpr int NV = L - 1;
   constexpr int PPT = 16 / L;          // points per column tile
   constexpr int PPW = PPT * C;         // points per wave iteration
@@ -297,6 +298,9 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
       for (int t = 0; t < 5; ++t) o[c][t] += x[c][t];
 
     // ---------------- outputs: token 0 -> ray transformer input; optional full dump
+    // (one element of a LayerNorm output row is non-finite iff anything on the token's path was: the range probe)
+#pragma unroll
+    for (int c = 0; c < C; ++c) probe_output(ws, valid[c], o[c][0][0]);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       if (valid[c] && tv == 0) {
@@ -367,6 +371,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     wstream_f16_finish<B_VT, kVtWaves>(ws, wrap);
     UFR_PHASE(11)  // softmax blend
   }
+  wstream_report_range(ws, status);
 #ifdef UFR_PHASE_TIMING
   if (wave_global == 5 && lane == 0)
     for (int i = 0; i < 12; ++i) g_vt_phase[i] += ph_acc[i];
@@ -388,7 +393,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 
 template <int L, bool LOWP>
 static hipError_t launch_vt(const float* packed, const float* x_tokens, const float* rgb, const float* dir, int P,
-                            float* token0, float* radiance, float* view_out, hipStream_t s) {
+                            float* token0, float* radiance, float* view_out, int* status, hipStream_t s) {
   constexpr int C = UFR_VT_C;
   constexpr int PPW = (16 / L) * C;
   const int n_groups = (P + PPW - 1) / PPW;
@@ -422,18 +427,18 @@ static hipError_t launch_vt(const float* packed, const float* x_tokens, const fl
     attr_set[dev] = true;
   }
   hipLaunchKernelGGL((view_transformer_kernel<L, C, LOWP>), dim3(blocks), dim3(kVtBlock), kF16LdsBytes, s, packed, x_tokens,
-                     rgb, dir, P, token0, radiance, view_out);
+                     rgb, dir, P, token0, radiance, view_out, status);
   return hipGetLastError();
 }
 
 hipError_t launch_view_transformer(const float* packed, const float* x_tokens, const float* rgb, const float* dir,
-                                   int P, int NV, float* token0, float* radiance, float* view_out, hipStream_t s) {
-  const bool lowp = matrix_precision_reduced();
+                                   int P, int NV, float* token0, float* radiance, float* view_out, bool lowp, int* status,
+                                   hipStream_t s) {
   switch (NV) {
 #define UFR_VT_CASE(N)                                                                                       \
     case N:                                                                                                  \
-      return lowp ? launch_vt<N + 1, true>(packed, x_tokens, rgb, dir, P, token0, radiance, view_out, s)     \
-                  : launch_vt<N + 1, false>(packed, x_tokens, rgb, dir, P, token0, radiance, view_out, s);
+      return lowp ? launch_vt<N + 1, true>(packed, x_tokens, rgb, dir, P, token0, radiance, view_out, status, s)     \
+                  : launch_vt<N + 1, false>(packed, x_tokens, rgb, dir, P, token0, radiance, view_out, status, s);
     UFR_VT_CASE(2) UFR_VT_CASE(3) UFR_VT_CASE(4) UFR_VT_CASE(5) UFR_VT_CASE(6) UFR_VT_CASE(7)
 #undef UFR_VT_CASE
     default: return hipErrorInvalidValue;

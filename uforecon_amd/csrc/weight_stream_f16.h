@@ -17,7 +17,12 @@ constexpr int kF16RingBytes = kF16Slots * kF16ChunkFrags * 1024;  // kF16Slots 2
 constexpr int kF16LdsBytes = kF16RingBytes + kVecBytes;
 
 // split of a value pair into fp16 planes of 2^kXScaleLog2 x: hi = fp16(x) 2^k (exact scaling; one v_cvt_pk_f16_f32 and one
-// v_pk_mul_f16), lo = fp16(2^k x - hi) (the difference is exact in fp32; one v_fma_mix per value): 4 VALU instructions
+// v_pk_mul_f16), lo = fp16(2^k x - hi) (the difference is exact in fp32; one v_fma_mix per value): 4 VALU instructions.
+// The planes hold |x| < kActLimit only (beyond it hi overflows to inf and the product to NaN): see track_range.
+constexpr float kActLimit = 4094.f;
+#ifndef UFR_RANGE_MODE
+#define UFR_RANGE_MODE 1   // 0: no range tracking (timing ablation)
+#endif
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& l) {
   f16x2 hh = __builtin_convertvector(f32x2{a, b}, f16x2);
   if constexpr (kXScaleLog2 != 0) hh *= f16x2{(_Float16)kXScale, (_Float16)kXScale};
@@ -30,6 +35,27 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsign
 __device__ __forceinline__ void split_tile(const f32x4& v, unsigned (&pl)[kPlanes][2]) {
 #pragma unroll
   for (int q = 0; q < 2; ++q) split_pair(v[2 * q], v[2 * q + 1], pl[0][q], pl[1][q]);
+}
+
+// Range tracking of the dense-layer inputs: in front of every GEMM the max |x| over the lane's input tiles (one
+// v_max3_f32 with abs modifiers per value pair) is compared with the limit and the wave's verdict is OR-ed into a
+// SCALAR sticky mask -- the transformer kernels sit exactly at their 256-register budget, and a vector register carried
+// across the whole layer chain (a per-lane running max; tried first, also inside split_pair) costs 26..100 spilled
+// registers.  The kernel looks at the mask once at its end and raises the device's sticky range status
+// (include/ufr.h: ufr_status_poll): an overflow is reported, never rendered.
+template <int C, int N>
+__device__ __forceinline__ void track_range(const f32x4 (&t)[C][N], unsigned long long& bad) {
+#if UFR_RANGE_MODE != 0
+  float m = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(t[c][i][0]), __builtin_fabsf(t[c][i][1])));
+      m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(t[c][i][2]), __builtin_fabsf(t[c][i][3])));
+    }
+  bad |= __builtin_amdgcn_ballot_w64(!(m < kActLimit));
+#endif
 }
 
 // B operands of one k-step (accumulator tiles ta, tb of one column tile): one f16x8 per plane
@@ -53,6 +79,7 @@ struct WStreamF16T {
   unsigned ring_lds;   // ... as an LDS byte address (scalar)
   const f32x4* vecs;   // LDS: vector fragments (fp32)
   int wave, lane;
+  unsigned long long bad_in, bad_out;   // sticky wave masks (scalar registers): track_range / the kernels' output probes
   f16x8 pre[kF16Depth][kPlanes];  // plane fragments of the next kF16Depth stages, in flight from LDS (stage s in slot s % depth)
 };
 
@@ -62,6 +89,7 @@ __device__ __forceinline__ WStreamF16T<LOWP> wstream_f16_begin(const float* __re
   WStreamF16T<LOWP> ws;
   ws.lane = threadIdx.x & 63;
   ws.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  ws.bad_in = ws.bad_out = 0ull;
   ws.src = reinterpret_cast<const char*>(packed) + (size_t)blob_floats() * 4;
   ws.ring = smem;
   ws.ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem);
@@ -172,6 +200,20 @@ __device__ __forceinline__ void wstream_f16_finish(const WS& ws, bool wrap) {
 template <int S, int NWAVES, class WS>
 __device__ __forceinline__ void wstream_f16_prime(const WS& ws) {
   static_for<kF16Slots - 1>([&](auto ci) __attribute__((always_inline)) { wstream_f16_fetch<S, NWAVES, decltype(ci)::value>(ws); });
+}
+
+// output probe: `v` is one output value per lane that depends on every activation of its token (a LayerNorm output
+// element, an srdf): x - x is 0 unless x is NaN / inf
+template <class WS>
+__device__ __forceinline__ void probe_output(WS& ws, bool live, float v) {
+  ws.bad_out |= __builtin_amdgcn_ballot_w64(live && !(v - v == 0.f));
+}
+// end of a kernel: raise the sticky range status (bit 0: a dense-layer input reached kActLimit; bit 1: a non-finite
+// output).  One atomic per offending wave.
+template <class WS>
+__device__ __forceinline__ void wstream_report_range(const WS& ws, int* __restrict__ status) {
+  const int bits = (ws.bad_in ? 1 : 0) | (ws.bad_out ? 2 : 0);
+  if (bits && ws.lane == 0) atomicOr(status, bits);
 }
 
 template <int V, class WS>
@@ -315,6 +357,7 @@ __device__ __forceinline__ void gemm_f16(WS& ws, const f32x4 (&in)[C][NIN], f32x
   static_assert(NIN == mat_desc(M).n_in, "input tile count");
   constexpr int n_out = mat_desc(M).n_out, NU = 4 * C;
   BWords<C> cur;
+  track_range(in, ws.bad_in);
   split_units<0, 0, NU>(in, cur);
   static_for<ksteps(M)>([&](auto si) __attribute__((always_inline)) {
     constexpr int s = decltype(si)::value;

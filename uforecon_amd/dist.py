@@ -74,18 +74,26 @@ def allreduce_gradients(params, world: int | None = None, group=None) -> int:
     """Average the gradients of `params` over the ranks with ONE collective: the gradients are packed into a single
     flat fp32 buffer (the per-ray path has 148 947 parameters = 0.6 MB; with feature_volume.cost_reg_2.* 1.8 MB), summed
     with an RCCL all-reduce (ring over xGMI: latency-bound at this size, so one bucket, not one call per tensor) and
-    scattered back.  Every rank must pass the same parameters in the same order.  Returns the number of floats reduced."""
-    ps = [p for p in params if p.grad is not None]
+    scattered back.  Every rank must pass the same parameters in the same order.  The bucket holds EVERY tensor that
+    requires grad -- one whose ``.grad`` is None on this rank (unused this step) contributes zeros and receives the other
+    ranks' mean -- so the buffer length cannot differ between ranks.  Tensors that are not parameters of the module (the
+    sampled volumes, when a caller trains through them) are reduced the same way: pass them in ``params``.
+    Returns the number of floats reduced."""
+    ps = [p for p in params if p.requires_grad]
     if not ps:
         return 0
     world = dist.get_world_size(group) if world is None else world
-    flat = torch.cat([p.grad.reshape(-1).float() for p in ps])
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in ps])
     if world > 1:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         flat /= world
     off = 0
     for p in ps:
-        n = p.grad.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        n = p.numel()
+        g = flat[off:off + n].view_as(p)
+        if p.grad is None:
+            p.grad = g.to(p.dtype).clone()
+        else:
+            p.grad.copy_(g)
         off += n
     return off

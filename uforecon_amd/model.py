@@ -173,18 +173,32 @@ class RayTransformer(nn.Module):
         self.DensityMLP = _mlp3(88, 32, 16, 1)
         self.viewToken = _ViewToken(80)
         self.linear_radianceweight_1_softmax = _mlp3(83, 16, 8, 1)
-        self._packed: Optional[ops.PackedWeights] = None
-        self._packed_key = None
+        self._packed = {}        # storage identity of the 40 tensors -> [PackedWeights, version counters]
 
-    # the packed copy follows the parameters: re-pack whenever any of them changed in place / moved
-    def packed_weights(self, variance: torch.Tensor) -> ops.PackedWeights:
+    # the packed copy follows the parameters.  Same storage, new version counters (an optimizer step, load_state_dict):
+    # re-pack IN PLACE, asynchronously (no allocation, no host synchronisation per training step); other storage (moved to
+    # another device, a different `variance` tensor): a new packed copy, at most two are kept (UFORecon's real variance and
+    # the stub of RayTransformer.forward).  An update that bypasses the version counter (`p.data = ...`, `set_`) needs
+    # invalidate_packed().
+    def packed_weights(self, variance: torch.Tensor, precision: Optional[int] = None) -> ops.PackedWeights:
         params = {"ray_transformer." + k: v for k, v in self.state_dict(keep_vars=True).items()}
         params["deviation_network.variance"] = variance
-        key = tuple((v.data_ptr(), v._version, str(v.device)) for v in params.values())
-        if self._packed is None or key != self._packed_key:
-            self._packed = ops.PackedWeights(params)
-            self._packed_key = key
-        return self._packed
+        ptrs = tuple((v.data_ptr(), str(v.device)) for v in params.values())
+        vers = tuple(v._version for v in params.values())
+        ent = self._packed.get(ptrs)
+        if ent is None:
+            if len(self._packed) >= 2:
+                self._packed.clear()
+            ent = self._packed[ptrs] = [ops.PackedWeights(params, precision), vers]
+        elif ent[1] != vers:
+            ent[0].repack()
+            ent[1] = vers
+        ent[0].precision = precision
+        return ent[0]
+
+    def invalidate_packed(self) -> None:
+        """Forget the packed copies (after parameter updates that do not bump the tensors' version counters)."""
+        self._packed.clear()
 
     def forward(self, point3D, batch, source_imgs_feat, fea_volume=None, cond_info=None, points_projected=None,
                 mask_valid=None):
@@ -208,10 +222,11 @@ class RayTransformer(nn.Module):
         if key != getattr(self, "_lite_key", None):
             self._lite_frame = ops.FrameHandle(batch, source_imgs_feat, None, None)
             self._lite_key = key
+            self._lite_keyed = keyed      # pins the keyed tensors (their addresses are the cache key)
         variance = getattr(self, "_variance_stub", None)
         if variance is None or variance.device != dev:
             variance = self._variance_stub = torch.zeros((), device=dev)       # not an input of this module
-        W = self.packed_weights(variance)
+        W = self.packed_weights(variance, getattr(self, "precision", None))
         P = RN * SN
         pts = point3D.reshape(P, 3).detach().float().contiguous()
         vol24 = fea_volume.reshape(P, 24).float().contiguous()
@@ -229,9 +244,13 @@ class UFORecon(nn.Module):
     reference's names (``ray_transformer.*``, ``deviation_network.variance``), so a reference
     checkpoint loads with ``load_state_dict(strict=False)`` (the encoder keys are not ours)."""
 
-    def __init__(self, args):
+    def __init__(self, args, precision: Optional[int] = None):
+        """``precision``: matrix precision of this model's dense layers (ops.PRECISION_FP32 / PRECISION_16BIT; None = the
+        process default at call time, include/ufr.h).  It travels with every call -- there is no global state to flip
+        between a forward and its backward."""
         super().__init__()
         self.args = args
+        self.precision = precision
         if getattr(args, "extract_geometry", False):
             self.point_num, self.point_num_2 = args.test_sample_coarse, args.test_sample_fine
         else:
@@ -258,10 +277,11 @@ class UFORecon(nn.Module):
         if key != self._frame_key:
             self._frame = ops.FrameHandle(batch, source_imgs_feat, feature_volume, match_feature)
             self._frame_key = key
+            self._frame_keyed = keyed     # pins every keyed tensor: its address cannot be recycled while the entry is cached
         return self._frame
 
     def _weights(self) -> ops.PackedWeights:
-        return self.ray_transformer.packed_weights(self.deviation_network.variance)
+        return self.ray_transformer.packed_weights(self.deviation_network.variance, self.precision)
 
     def sample2rgb(self, batch, points_x, z_val, ray_d, ray_idx, source_imgs_feat, feature_volume, match_feature):
         """model.py:308-348.  ``points_x`` must be ``ray_o + z_val * ray_d`` (it always is in the reference);

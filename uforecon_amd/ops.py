@@ -59,11 +59,35 @@ def _opt(t: Optional[torch.Tensor], name: str) -> Optional[int]:
     return None if t is None else _dev(t, name)
 
 
-class PackedWeights:
-    """ufr_raw_weights (pointers into the live parameters) + the MFMA-ordered packed copy."""
+PRECISION_DEFAULT, PRECISION_FP32, PRECISION_16BIT = -1, 0, 1
 
-    def __init__(self, params: Dict[str, torch.Tensor]):
+
+def resolve_precision(precision: Optional[int]) -> int:
+    """An explicit matrix precision (include/ufr.h: UFR_PRECISION_FP32 / _16BIT) for a call: None / PRECISION_DEFAULT
+    resolve to the process default NOW, so that the value recorded with a forward is what its backward gets."""
+    if precision is None or precision == PRECISION_DEFAULT:
+        return get_matrix_precision()
+    if precision not in (PRECISION_FP32, PRECISION_16BIT):
+        raise UfrError(f"unknown matrix precision {precision!r}")
+    return int(precision)
+
+
+def status_poll(synchronize: bool = True) -> int:
+    """ufr_status_poll: raises UfrError when the device's sticky range status is set (an activation beyond the fp16x3
+    planes' |x| < 4094, a non-finite transformer output, a weight beyond |w| < 255.8), clearing it.  With
+    ``synchronize=False`` only what an earlier launch has already delivered is reported (no host synchronisation)."""
+    flags = C.c_int32(0)
+    _lib.check(_lib.load().ufr_status_poll(_stream(), int(bool(synchronize)), C.byref(flags)), "ufr_status_poll")
+    return int(flags.value)
+
+
+class PackedWeights:
+    """ufr_raw_weights (pointers into the live parameters) + the MFMA-ordered packed copy.  ``precision``: the matrix
+    precision the calls made with these weights use (None = the process default at call time)."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], precision: Optional[int] = None):
         lib = _lib.load()
+        self.precision = precision
         self._keep = []
         ptrs = []
         for key, shape in zip(RAW_WEIGHT_KEYS, RAW_WEIGHT_SHAPES):
@@ -79,11 +103,18 @@ class PackedWeights:
         C.memmove(C.byref(self.raw), (C.c_void_p * 40)(*ptrs), C.sizeof(self.raw))
         self.device = self._keep[0].device
         self.packed = torch.empty(lib.ufr_packed_weights_bytes() // 4, dtype=torch.float32, device=self.device)
-        self.repack()
+        self.repack(check=True)
 
-    def repack(self) -> None:
-        """Call after the parameters changed in place (e.g. an optimizer step)."""
+    def repack(self, check: bool = False) -> None:
+        """Call after the parameters changed in place (e.g. an optimizer step).  Asynchronous: a weight outside the
+        planes' range raises the sticky status, which the next compute call (or ``status_poll``) reports;
+        ``check=True`` synchronises and raises at once (construction does)."""
         _lib.check(_lib.load().ufr_weights_pack(C.byref(self.raw), self.packed.data_ptr(), _stream()), "ufr_weights_pack")
+        if check:
+            status_poll(True)
+
+    def mode(self) -> int:
+        return resolve_precision(self.precision)
 
     @property
     def variance(self) -> torch.Tensor:
@@ -219,7 +250,7 @@ def project_gather(frame: FrameHandle, weights: PackedWeights, ray_o: torch.Tens
 
 
 def aggregate(weights: PackedWeights, x: torch.Tensor, rgb: torch.Tensor, dirs: torch.Tensor, RN: int, SN: int,
-              debug: bool = False, keep_workspace: bool = False):
+              debug: bool = False, keep_workspace: bool = False, precision: Optional[int] = None):
     lib = _lib.load()
     NV, dev = x.shape[1], x.device
     P = RN * SN
@@ -231,21 +262,25 @@ def aggregate(weights: PackedWeights, x: torch.Tensor, rgb: torch.Tensor, dirs: 
         dbg = dict(view_out=torch.empty(P, NV + 1, _lib.TOKEN_DIM, device=dev), ray_out=torch.empty(P, _lib.RAY_DIM, device=dev))
     _lib.check(lib.ufr_aggregate(weights.packed.data_ptr(), _dev(x, "x_tokens"), _dev(rgb, "rgb"), _dev(dirs, "dir"),
                                  RN, SN, NV, radiance.data_ptr(), srdf.data_ptr(), ws.data_ptr(),
-                                 _opt(dbg.get("view_out"), "view_out"), _opt(dbg.get("ray_out"), "ray_out"), _stream()),
+                                 _opt(dbg.get("view_out"), "view_out"), _opt(dbg.get("ray_out"), "ray_out"),
+                                 weights.mode() if precision is None else precision, _stream()),
                "ufr_aggregate")
     if keep_workspace:   # the head of the workspace is the view transformer's token-0 output (P,80): the backward needs it
         dbg["token0"] = ws[: P * _lib.TOKEN_DIM].view(P, _lib.TOKEN_DIM)
     return radiance, srdf, dbg
 
 
-def composite(z: torch.Tensor, radiance: torch.Tensor, srdf: torch.Tensor, variance: torch.Tensor):
+def composite(z: torch.Tensor, radiance: torch.Tensor, srdf: torch.Tensor, variance: torch.Tensor,
+              row: Optional[torch.Tensor] = None):
+    """``row`` (RN,SN) int32: slot (ray, s) takes its colour from ``radiance.view(-1, 3)[row]`` (the sample pool)."""
     RN, SN = z.shape
     dev = z.device
     rgb = torch.empty(RN, 3, dtype=torch.float32, device=dev)
     depth = torch.empty(RN, dtype=torch.float32, device=dev)
     opacity = torch.empty(RN, dtype=torch.float32, device=dev)
     weight = torch.empty(RN, SN, dtype=torch.float32, device=dev)
-    _lib.check(_lib.load().ufr_composite(_dev(z, "z"), _dev(radiance, "radiance"), _dev(srdf, "srdf"),
+    _lib.check(_lib.load().ufr_composite(_dev(z, "z"), _dev(radiance, "radiance"),
+                                         None if row is None else _dev(row, "row", torch.int32), _dev(srdf, "srdf"),
                                          _dev(variance, "variance"), RN, SN, rgb.data_ptr(), depth.data_ptr(),
                                          opacity.data_ptr(), weight.data_ptr(), _stream()), "ufr_composite")
     return rgb, depth, opacity, weight
@@ -271,22 +306,36 @@ class GradBuffer:
         return self.views[key]
 
 
-def composite_bwd(z, radiance, srdf, variance, d_rgb, d_depth, d_opacity, d_weight):
+def composite_bwd(z, radiance, srdf, variance, d_rgb, d_depth, d_opacity, d_weight, row=None, d_radiance=None,
+                  accumulate: bool = False, d_variance=None):
+    """``row`` / ``d_radiance`` / ``accumulate``: the pool form -- d_radiance rows are those ``row`` names inside the given
+    pool-sized buffer, added to its content when ``accumulate``.  ``d_variance`` (a zeroed scalar) is accumulated."""
     RN, SN = z.shape
     dev = z.device
-    d_radiance = torch.empty(RN, SN, 3, dtype=torch.float32, device=dev)
+    if d_radiance is None:
+        d_radiance = torch.empty(RN, SN, 3, dtype=torch.float32, device=dev)
     d_srdf = torch.empty(RN, SN, dtype=torch.float32, device=dev)
-    d_variance = torch.zeros((), dtype=torch.float32, device=dev)
-    opt = lambda t, n: None if t is None else _dev(t.contiguous(), n)
+    if d_variance is None:
+        d_variance = torch.zeros((), dtype=torch.float32, device=dev)
+    keep = []
+
+    def opt(t, n):
+        if t is None:
+            return None
+        keep.append(t.contiguous())
+        return _dev(keep[-1], n)
+
     _lib.check(_lib.load().ufr_composite_bwd(
-        _dev(z, "z"), _dev(radiance, "radiance"), _dev(srdf, "srdf"), _dev(variance, "variance"), RN, SN,
+        _dev(z, "z"), _dev(radiance, "radiance"), None if row is None else _dev(row, "row", torch.int32), _dev(srdf, "srdf"),
+        _dev(variance, "variance"), RN, SN,
         opt(d_rgb, "d_rgb"), opt(d_depth, "d_depth"), opt(d_opacity, "d_opacity"), opt(d_weight, "d_weight"),
-        d_radiance.data_ptr(), d_srdf.data_ptr(), d_variance.data_ptr(), _stream()), "ufr_composite_bwd")
+        _dev(d_radiance, "d_radiance"), int(accumulate), d_srdf.data_ptr(), _dev(d_variance, "d_variance"), _stream()),
+        "ufr_composite_bwd")
     return d_radiance, d_srdf, d_variance
 
 
 def aggregate_bwd(weights: PackedWeights, grads: GradBuffer, x, rgb, dirs, token0, RN: int, SN: int, d_radiance, d_srdf,
-                  debug: bool = False):
+                  debug: bool = False, precision: Optional[int] = None):
     lib = _lib.load()
     NV, dev = x.shape[1], x.device
     P = RN * SN
@@ -298,13 +347,14 @@ def aggregate_bwd(weights: PackedWeights, grads: GradBuffer, x, rgb, dirs, token
     _lib.check(lib.ufr_aggregate_bwd(
         C.byref(weights.raw), C.byref(grads.raw), _dev(x, "x_tokens"), _dev(rgb, "rgb"), _dev(dirs, "dir"),
         _dev(token0, "token0"), RN, SN, NV, _dev(d_radiance.contiguous(), "d_radiance"), _dev(d_srdf.contiguous(), "d_srdf"),
-        d_pv.data_ptr(), ws.data_ptr(), _opt(dbg.get("view"), "debug_view"), _opt(dbg.get("ray"), "debug_ray"), _stream()),
+        d_pv.data_ptr(), ws.data_ptr(), _opt(dbg.get("view"), "debug_view"), _opt(dbg.get("ray"), "debug_ray"),
+        weights.mode() if precision is None else precision, _stream()),
         "ufr_aggregate_bwd")
     return d_pv, dbg
 
 
 def project_gather_bwd(frame: FrameHandle, weights: PackedWeights, grads: GradBuffer, ray_o, ray_d, z, sim8, d_pv,
-                       grad_vol_feat, grad_vol_weight) -> None:
+                       grad_vol_feat, grad_vol_weight, precision: Optional[int] = None) -> None:
     """Scatter-adds into grad_vol_feat[s] (NV,8,D,Hs,Ws) / grad_vol_weight[s] (NV,1,D,Hs,Ws) (zero them first) and
     accumulates the pre_sim_mlp gradients into `grads`."""
     RN, SN = z.shape
@@ -315,7 +365,8 @@ def project_gather_bwd(frame: FrameHandle, weights: PackedWeights, grads: GradBu
         gw = (C.c_void_p * 3)(*[_dev(t, "grad_vol_weight") for t in grad_vol_weight])
     _lib.check(_lib.load().ufr_project_gather_bwd(
         C.byref(frame.frame), C.byref(weights.raw), C.byref(grads.raw), _dev(ray_o, "ray_o"), stride, _dev(ray_d, "ray_d"),
-        _dev(z, "z"), RN, SN, _dev(sim8, "sim8"), _dev(d_pv, "d_pv"), gf, gw, _stream()), "ufr_project_gather_bwd")
+        _dev(z, "z"), RN, SN, _dev(sim8, "sim8"), _dev(d_pv, "d_pv"), gf, gw,
+        weights.mode() if precision is None else precision, _stream()), "ufr_project_gather_bwd")
 
 
 # ----------------------------------------------------------------------------- halves of aggregate / sample pool
@@ -334,44 +385,70 @@ def sample_importance_pool(weight: torch.Tensor, z: torch.Tensor, U2: torch.Tens
     return z_all, z_new, row
 
 
-def view_transform(weights: PackedWeights, x: torch.Tensor, rgb: torch.Tensor, dirs: torch.Tensor):
+def view_transform(weights: PackedWeights, x: torch.Tensor, rgb: torch.Tensor, dirs: torch.Tensor,
+                   token0: Optional[torch.Tensor] = None, radiance: Optional[torch.Tensor] = None,
+                   precision: Optional[int] = None):
+    """``token0`` (P,80) / ``radiance`` (P,3): optional destinations (row ranges of the two-pass step's sample pool)."""
     P, NV = x.shape[0], x.shape[1]
-    token0 = torch.empty(P, _lib.TOKEN_DIM, dtype=torch.float32, device=x.device)
-    radiance = torch.empty(P, 3, dtype=torch.float32, device=x.device)
+    if token0 is None:
+        token0 = torch.empty(P, _lib.TOKEN_DIM, dtype=torch.float32, device=x.device)
+    if radiance is None:
+        radiance = torch.empty(P, 3, dtype=torch.float32, device=x.device)
+    if token0.shape[0] != P or radiance.shape[0] != P:
+        raise UfrError("view_transform: destination rows do not match the number of points")
     _lib.check(_lib.load().ufr_view_transform(weights.packed.data_ptr(), _dev(x, "x_tokens"), _dev(rgb, "rgb"), _dev(dirs, "dir"),
-                                              P, NV, token0.data_ptr(), radiance.data_ptr(), _stream()), "ufr_view_transform")
+                                              P, NV, _dev(token0, "token0"), _dev(radiance, "radiance"),
+                                              weights.mode() if precision is None else precision, _stream()),
+               "ufr_view_transform")
     return token0, radiance
 
 
-def ray_transform(weights: PackedWeights, token0: torch.Tensor, RN: int, SN: int) -> torch.Tensor:
+def ray_transform(weights: PackedWeights, token0: torch.Tensor, RN: int, SN: int, row: Optional[torch.Tensor] = None,
+                  precision: Optional[int] = None) -> torch.Tensor:
+    """``row`` (RN,SN) int32: slot (ray, s) reads ``token0[row]`` (the sample pool); None = slot order."""
     lib = _lib.load()
     srdf = torch.empty(RN, SN, dtype=torch.float32, device=token0.device)
     ws = torch.empty(lib.ufr_ray_transform_workspace_bytes(SN) // 4, dtype=torch.float32, device=token0.device)
-    _lib.check(lib.ufr_ray_transform(weights.packed.data_ptr(), _dev(token0, "token0"), RN, SN, srdf.data_ptr(), ws.data_ptr(),
-                                     _stream()), "ufr_ray_transform")
+    _lib.check(lib.ufr_ray_transform(weights.packed.data_ptr(), _dev(token0, "token0"),
+                                     None if row is None else _dev(row, "row", torch.int32), RN, SN, srdf.data_ptr(),
+                                     ws.data_ptr(), weights.mode() if precision is None else precision, _stream()),
+               "ufr_ray_transform")
     return srdf
 
 
-def ray_transform_bwd(weights: PackedWeights, grads: GradBuffer, token0: torch.Tensor, RN: int, SN: int, d_srdf: torch.Tensor):
-    """-> the two partial d token0 buffers (P,80) of the ray kernel's sweeps (their sum is the gradient)."""
+def ray_transform_bwd(weights: PackedWeights, grads: GradBuffer, token0: torch.Tensor, RN: int, SN: int, d_srdf: torch.Tensor,
+                      row: Optional[torch.Tensor] = None, out=None, accumulate: bool = False, precision: Optional[int] = None):
+    """-> the two partial d token0 buffers of the ray kernel's sweeps (their sum is the gradient).  Plain form: (RN*SN,80)
+    in slot order.  Pool form: ``row`` maps slots to rows of ``token0`` and of the two pool-sized buffers ``out=(a, b)``,
+    which are overwritten or, with ``accumulate``, added to."""
     lib = _lib.load()
     dev = token0.device
-    a = torch.empty(RN * SN, _lib.TOKEN_DIM, dtype=torch.float32, device=dev)
-    b = torch.empty(RN * SN, _lib.TOKEN_DIM, dtype=torch.float32, device=dev)
+    if out is None:
+        a = torch.empty(RN * SN, _lib.TOKEN_DIM, dtype=torch.float32, device=dev)
+        b = torch.empty(RN * SN, _lib.TOKEN_DIM, dtype=torch.float32, device=dev)
+    else:
+        a, b = out
     ws = torch.empty(lib.ufr_ray_transform_workspace_bytes(SN) // 4, dtype=torch.float32, device=dev)
-    _lib.check(lib.ufr_ray_transform_bwd(C.byref(weights.raw), C.byref(grads.raw), _dev(token0, "token0"), RN, SN,
-                                         _dev(d_srdf.contiguous(), "d_srdf"), a.data_ptr(), b.data_ptr(), ws.data_ptr(), _stream()),
+    d_srdf = d_srdf.contiguous()
+    _lib.check(lib.ufr_ray_transform_bwd(C.byref(weights.raw), C.byref(grads.raw), _dev(token0, "token0"),
+                                         None if row is None else _dev(row, "row", torch.int32), RN, SN,
+                                         _dev(d_srdf, "d_srdf"), _dev(a, "d_token0_a"), _dev(b, "d_token0_b"), int(accumulate),
+                                         ws.data_ptr(), weights.mode() if precision is None else precision, _stream()),
                "ufr_ray_transform_bwd")
     return a, b
 
 
-def view_transform_bwd(weights: PackedWeights, grads: GradBuffer, x, rgb, dirs, d_token0_a, d_token0_b, d_radiance):
+def view_transform_bwd(weights: PackedWeights, grads: GradBuffer, x, rgb, dirs, d_token0_a, d_token0_b, d_radiance,
+                       precision: Optional[int] = None):
     P, NV = x.shape[0], x.shape[1]
     d_pv = torch.empty(P, 40, dtype=torch.float32, device=x.device)
+    ta = d_token0_a.contiguous()
+    tb = None if d_token0_b is None else d_token0_b.contiguous()
+    dr = d_radiance.contiguous()
     _lib.check(_lib.load().ufr_view_transform_bwd(
         C.byref(weights.raw), C.byref(grads.raw), _dev(x, "x_tokens"), _dev(rgb, "rgb"), _dev(dirs, "dir"),
-        _dev(d_token0_a.contiguous(), "d_token0_a"), _opt(None if d_token0_b is None else d_token0_b.contiguous(), "d_token0_b"),
-        _dev(d_radiance.contiguous(), "d_radiance"), P, NV, d_pv.data_ptr(), _stream()), "ufr_view_transform_bwd")
+        _dev(ta, "d_token0_a"), _opt(tb, "d_token0_b"), _dev(dr, "d_radiance"), P, NV, d_pv.data_ptr(),
+        weights.mode() if precision is None else precision, _stream()), "ufr_view_transform_bwd")
     return d_pv
 
 
@@ -419,6 +496,7 @@ def render_rays(frame: FrameHandle, weights: PackedWeights, ray_idx: torch.Tenso
     if U1.shape[1] != RN or (not coarse_only and U2.shape[1] != RN):
         raise UfrError("U1/U2 must be (samples, RN)")
     a.RN, a.SN, a.PN, a.coarse_only = RN, SN, PN, int(coarse_only)
+    a.precision = weights.mode()
     a.depth, a.depth_z, a.rgb = depth.data_ptr(), depth_z.data_ptr(), rgb.data_ptr()
     a.srdf = _opt(srdf, "srdf")
     a.z_all = _opt(z_all, "z_all")
@@ -456,12 +534,11 @@ def fmt_layer(params, x: torch.Tensor, src: Optional[torch.Tensor]) -> torch.Ten
     return out
 
 
-PRECISION_FP32, PRECISION_16BIT = 0, 1
-
-
 def set_matrix_precision(mode: int) -> None:
-    """Process-wide precision of the dense layers (include/ufr.h): PRECISION_FP32 (default, the 1e-4 parity mode) or
-    PRECISION_16BIT (one 16-bit plane per operand: the mixed-precision training mode of BASELINE configs[4])."""
+    """What PRECISION_DEFAULT resolves to (include/ufr.h): PRECISION_FP32 (the 1e-4 parity mode) or PRECISION_16BIT (one
+    16-bit plane per operand: the mixed-precision training mode of BASELINE configs[4]).  A convenience for tools; a
+    model pins its mode with ``UFORecon(args, precision=...)`` / ``PackedWeights(..., precision=...)``, and an autograd
+    node always runs its backward in the mode its forward ran in."""
     _lib.check(_lib.load().ufr_set_matrix_precision(int(mode)), "ufr_set_matrix_precision")
 
 

@@ -327,15 +327,17 @@ def secondary_measurements(a, dev):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_train
 
+    # both GPU measurements first, the CPU leg after them (its worker threads keep spinning for a while and slow the
+    # host side of a step that follows)
     for prec in ("fp32", "16bit"):
-        ta = bench_train.parse(["--steps", str(a.secondary_train_steps), "--warmup", "2", "--precision", prec]
-                               + (["--no-cpu-baseline"] if (a.no_cpu_baseline or prec == "16bit") else []))
+        ta = bench_train.parse(["--steps", str(a.secondary_train_steps), "--warmup", "3", "--precision", prec, "--no-cpu-baseline"])
         sec[f"configs[4]_{prec}"] = bench_train.run(ta, dev, 1, 0)
         torch.cuda.empty_cache()
-    # the CPU leg has one arithmetic (fp32): the 16-bit entry points at the fp32 entry's measurement
-    if "cpu_baseline" in sec["configs[4]_fp32"]:
-        sec["configs[4]_16bit"]["cpu_baseline"] = dict(sec["configs[4]_fp32"]["cpu_baseline"],
-                                                       note="same measurement as configs[4]_fp32 (the oracle is fp32)")
+    if not a.no_cpu_baseline:
+        base = bench_train.cpu_baseline_standalone(bench_train.parse([]))
+        sec["configs[4]_fp32"]["cpu_baseline"] = base
+        # the CPU leg has one arithmetic (fp32): the 16-bit entry points at the same measurement
+        sec["configs[4]_16bit"]["cpu_baseline"] = dict(base, note="same measurement as configs[4]_fp32 (the oracle is fp32)")
     return sec
 
 

@@ -52,7 +52,19 @@ def test_full_size_frame_interior_rays(weights):
     x, rgbm, dirs = ops.project_gather(fh, weights, fr.batch["ray_o"][0].contiguous().to(DEV), ray_d.to(DEV),
                                        z_ref.to(DEV).contiguous())[:3]
     srdf = ops.aggregate(weights, x, rgbm, dirs, RN, SN)[1]
-    assert rel_err(srdf.reshape(RN, SN), g["srdf"]) < 1e-4
+    e = (srdf.reshape(RN, SN).cpu() - torch.from_numpy(g["srdf"])).abs() / float(abs(g["srdf"]).max())
+    with torch.no_grad():   # the same rows through the oracle on THIS host: how far apart two fp32 evaluations are here
+        from helpers import load_weights as _lw
+        xo, rgbo, masko, dirso = x.cpu(), rgbm[..., :3].cpu(), rgbm[..., 3].cpu(), dirs[..., :3].cpu()
+        _, srdf_o = O.aggregate_tokens(_lw(), xo, rgbo, masko, dirso, RN, SN)
+    eo = (srdf_o.reshape(RN, SN) - torch.from_numpy(g["srdf"])).abs() / float(abs(g["srdf"]).max())
+    print(f"full-size srdf at golden positions: kernels max {float(e.max()):.2e}, 99.9 % {float(e.flatten().kthvalue(int(0.999 * e.numel())).values):.2e};"
+          f" oracle on this host max {float(eo.max()):.2e}")
+    # the yardstick is what fp32 itself allows on this host: against the same-host oracle on the SAME token rows the
+    # kernels sit at 1e-5; against the golden (made on another CPU: libm sin / cumsum vector paths differ in the last
+    # ulp, which 128x160 white-noise maps amplify more than the small fixtures' 16x24) they may be as far as the oracle is
+    assert rel_err(srdf.reshape(RN, SN), srdf_o.reshape(RN, SN)) < 2e-5
+    assert float(e.max()) < max(1e-4, 1.25 * float(eo.max()))
     assert ops.status_poll(True) == 0
 
 

@@ -95,6 +95,17 @@ def cpu_baseline(a, frame_cpu, weights_cpu):
                        f"1 warm-up ({med * 1e3:.0f} ms/step)")
 
 
+def cpu_baseline_standalone(a):
+    """cpu_baseline on freshly generated inputs (for callers that time the GPU legs first)."""
+    import numpy as np
+
+    from uforecon_amd.scene import make_frame
+
+    wz = np.load(os.path.join(ROOT, "tests", "golden", "ray_path_weights_seed0.npz"))
+    return cpu_baseline(a, make_frame(a.height, a.width, a.views, seed=0, train_layout=True),
+                        {k: torch.from_numpy(wz[k]) for k in wz.files})
+
+
 def run(a, dev, world=1, rank=0):
     """The measurement; returns the JSON-able result dict on rank 0 (None elsewhere)."""
     import numpy as np
@@ -215,7 +226,7 @@ def run(a, dev, world=1, rank=0):
                                 "and weight gradients on the fp32 MFMA" if a.precision == "fp32" else
                                 "16-bit mode: one fp16 plane per operand in the forward, bf16 operands in the backward GEMMs "
                                 "and weight gradients, fp32 accumulation; LayerNorm / attention / softmax / compositor fp32"),
-                    loss=float(loss),
+                    loss=float(loss.detach()),
                     kernel_ms_per_step_rank0={k: v["ms"] / a.steps for k, v in prof.items()},
                     kernel_launches_per_step={k: v["launches"] / a.steps for k, v in prof.items()},
                     per_rank=per_rank),

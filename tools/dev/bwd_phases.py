@@ -27,9 +27,12 @@ torch.cuda.synchronize()
 print("aggregate_bwd ms", (time.perf_counter() - t) * 1e3, "points", RN * SN)
 lib.ufr_debug_vb_phases(buf, 64, 0)
 tot = sum(buf)
-names = ["P0 load", "P1 qkv", "P2 attn", "P3 merge", "P4 LN1", "P5 mlp0", "P6 mlp2", "P7 LN2", "P8 rw0", "P9 h2", "zero dlogit",
-         "softmax", "B1a dh2", "B1b dh1", "B2 dy", "B3 LN2b", "B4 dhid", "B5 dcat", "B6 LN1b", "B7 dmsg", "B8 attn q", "B9 attn kv",
-         "B10 dx", "B11+B12 out+wgrad"]
+names = {0: "P0 commit", 1: "P1 qkv", 2: "P2 attn", 3: "P3 merge", 4: "P4 LN1", 5: "P5 mlp0", 6: "P6 mlp2", 7: "P7 LN2", 8: "P8 rw0",
+         9: "P9 h2", 11: "softmax", 12: "B1a dh2", 13: "B1b dh1", 14: "B2 dy + wg rw0", 15: "B3 LN2b", 16: "W1 wg mlp2",
+         17: "B4 dhid", 18: "B5 dcat + wg mlp0", 19: "B6 LN1b", 20: "B7 dmsg + wg merge", 21: "B8 attn q", 22: "B9 attn kv",
+         23: "B10 dx + wg qkv", 24: "B11 out"}
+n_tiles = (RN * SN + 7) // 8 // 256      # 32-token tiles (8 points at NV = 3) per workgroup
 for i, v in enumerate(buf):
     if v:
-        print(f"{i:2d} {names[i] if i < len(names) else '':20s} {v:12d} {100.0 * v / tot:5.1f}%")
+        print(f"{i:2d} {names.get(i, ''):22s} {v:12d} {100.0 * v / tot:5.1f}%  {v / max(n_tiles, 1):9.0f} cycles/tile")
+print("total cycles per tile", tot / max(n_tiles, 1))

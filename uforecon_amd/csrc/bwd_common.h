@@ -2,15 +2,21 @@
 //
 // Design (gfx950): a 256-thread workgroup (one wave per SIMD, one workgroup per CU: every wave owns the full 512-entry
 // register file of its SIMD, which is what the register-resident weight-gradient tiles need) walks
-// tiles of kTT = 16 tokens.  Every activation of the tile lives in LDS, feature-major [feature][kLD]
-// (kLD = 17: odd stride -> the three MFMA operand access patterns below are bank-conflict free), in
-// exact fp32.  All contractions run on v_mfma_f32_16x16x4_f32 (bitwise an fp32 fma chain):
+// tiles of kTT = 32 tokens = kCT = 2 MFMA column tiles (round 2: 16.  The phases of a tile are separated by workgroup
+// barriers and are latency-bound -- LDS round trips, weight loads from L2, shuffles -- so two column tiles per phase
+// nearly halve the per-token cost: one weight fragment feeds two MFMAs, every per-token phase has all 256 threads busy).
+// Every activation of the tile lives in LDS, feature-major [feature][kLD]
+// (kLD = kTT + 1: odd stride -> the three MFMA operand access patterns below are bank-conflict free), in
+// exact fp32; buffers whose live ranges do not overlap share rows (the kernels' row maps).
+// All contractions run on v_mfma_f32_16x16x4_f32 (bitwise an fp32 fma chain):
 //   data GEMM      Y[o][t]  = sum_i W[o][i]  X[i][t]    A = weights from global (L1/L2-resident, 0.6 MB),
 //   transposed     dX[i][t] = sum_o W[o][i] dY[o][t]     B = activations from LDS, tokens are the 16 columns
 //   weight grad    dW[o][i] = sum_t dY[o][t] X[i][t]     A and B from LDS, k = the tile's 16 tokens
 // Weight gradients accumulate in REGISTERS across the workgroup's persistent tile loop (output tile
-// (s*8 + wave) of the kernel's gradient-tile list lives in accumulator slot s of that wave) and are
-// flushed once per workgroup with float atomics into the reference-layout gradient tensors.
+// (s*4 + wave) of the kernel's gradient-tile list lives in accumulator slot s of that wave) and are
+// flushed once per workgroup with float atomics into the reference-layout gradient tensors.  A matrix's tiles are
+// accumulated right after its dY is final (wgrad_range), beside the GEMM that consumes the same dY -- not in one phase at
+// the end of the tile: that is what lets dY / X buffers die early and share LDS rows.
 #pragma once
 #include "ufr_device.h"
 #include "weight_stream.h"   // static_for
@@ -22,8 +28,13 @@ namespace ufr {
 #endif
 constexpr int kBwdThreads = UFR_BWD_THREADS;
 constexpr int kBwdWaves = kBwdThreads / 64;
-constexpr int kTT = 16;   // tokens per tile = MFMA columns
-constexpr int kLD = 17;   // LDS row stride (floats)
+#ifndef UFR_BWD_TT
+#define UFR_BWD_TT 32
+#endif
+constexpr int kTT = UFR_BWD_TT;   // tokens per tile
+constexpr int kCT = kTT / 16;     // MFMA column tiles per tile
+constexpr int kLD = kTT + 1;      // LDS row stride (floats)
+static_assert(kTT % 16 == 0 && kBwdThreads % kTT == 0, "tile shape");
 
 struct GradPtrs { float* p[P_COUNT]; };
 
@@ -123,58 +134,73 @@ __device__ __forceinline__ AFrag<IN> gemm_prefetch(const float* __restrict__ W, 
   return f;
 }
 
+// The B operand (this tile's activations, kCT column tiles) streams from LDS one 16-deep k-chunk AHEAD of the MFMAs that
+// consume it (two 8-register buffers, instead of the whole K x kCT operand in registers: with two column tiles that was
+// 80 registers for K = 160 and the kernels spilled 260); a chunk's 4 kCT MFMAs (>= 256 cycles) cover the LDS latency.
+template <int IN>
+__device__ __forceinline__ void gemm_load_b(const float* X, int kc, int g, int j, float (&b)[kCT][4]) {
+  constexpr int FULL = IN / 16;
+  const int kb = kc * 16 + 4 * g;
+#pragma unroll
+  for (int ct = 0; ct < kCT; ++ct)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const bool ok = kc < FULL || kb + kk < IN;      // A is zero there, but the LDS row may hold anything (NaN)
+      const float v = X[(ok ? kb + kk : 0) * kLD + 16 * ct + j];
+      b[ct][kk] = ok ? v : 0.f;
+    }
+}
+
 template <int OUT, int IN, bool TRANS, bool LOWP, typename Epi>
 __device__ __forceinline__ void gemm_compute(AFrag<IN>& cur, const float* __restrict__ W, int ldw, const float* X, int wave,
                                              int lane, Epi epi, int rt_shift = 0) {
-  constexpr int RT = (OUT + 15) / 16, KC = (IN + 15) / 16, FULL = IN / 16;
+  constexpr int RT = (OUT + 15) / 16, KC = (IN + 15) / 16;
   lane = opaque(lane);
   const int g = lane >> 4, j = lane & 15;
   int opaque_zero;
   asm volatile("s_mov_b32 %0, 0" : "=s"(opaque_zero));
   W += opaque_zero;
-  // the B operand (this tile's activations) is the same for every row tile of the wave: one LDS burst per GEMM
-  float b[KC][4];
-#pragma unroll
-  for (int kc = 0; kc < KC; ++kc) {
-    const int kb = kc * 16 + 4 * g;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const bool ok = kc < FULL || kb + kk < IN;      // A is zero there, but the LDS row may hold anything (NaN)
-      const float v = X[(ok ? kb + kk : 0) * kLD + j];
-      b[kc][kk] = ok ? v : 0.f;
-    }
-  }
-  bf16x4_bits b16[KC];
-  if constexpr (LOWP) {
-#pragma unroll
-    for (int kc = 0; kc < KC; ++kc) b16[kc] = pack_bf16x4(b[kc][0], b[kc][1], b[kc][2], b[kc][3]);
-  }
   for (int rt = gemm_first_rt(wave, rt_shift); rt < RT; rt += kBwdWaves) {
     AFrag<IN> nxt;
     const bool more = rt + kBwdWaves < RT;
     if (more) gemm_load_a<OUT, IN, TRANS>(W, ldw, rt + kBwdWaves, lane, nxt);   // next row tile's burst rides on these MFMAs
-    f32x4 acc0 = splat4(0.f), acc1 = splat4(0.f);
-    if constexpr (LOWP) {
+    f32x4 acc0[kCT], acc1[kCT];
 #pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
+    for (int ct = 0; ct < kCT; ++ct) { acc0[ct] = splat4(0.f); acc1[ct] = splat4(0.f); }
+    float bb[2][kCT][4];
+    gemm_load_b<IN>(X, 0, g, j, bb[0]);
+    static_for<KC>([&](auto kci) __attribute__((always_inline)) {
+      constexpr int kc = decltype(kci)::value;
+      if constexpr (kc + 1 < KC) gemm_load_b<IN>(X, kc + 1, g, j, bb[(kc + 1) & 1]);
+      float (&b)[kCT][4] = bb[kc & 1];
+      if constexpr (LOWP) {
         const bf16x4_bits a4 = pack_bf16x4(cur.a[kc][0], cur.a[kc][1], cur.a[kc][2], cur.a[kc][3]);
-        if (kc & 1) acc1 = mfma16_bf16(a4, b16[kc], acc1);
-        else acc0 = mfma16_bf16(a4, b16[kc], acc0);
-      }
-    } else {
 #pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
-        acc0 = mfma16(cur.a[kc][0], b[kc][0], acc0);
-        acc1 = mfma16(cur.a[kc][1], b[kc][1], acc1);
-        acc0 = mfma16(cur.a[kc][2], b[kc][2], acc0);
-        acc1 = mfma16(cur.a[kc][3], b[kc][3], acc1);
-      }
-    }
-    const f32x4 acc = acc0 + acc1;
+        for (int ct = 0; ct < kCT; ++ct) {
+          const bf16x4_bits b4 = pack_bf16x4(b[ct][0], b[ct][1], b[ct][2], b[ct][3]);
+          if (kc & 1) acc1[ct] = mfma16_bf16(a4, b4, acc1[ct]);
+          else acc0[ct] = mfma16_bf16(a4, b4, acc0[ct]);
+        }
+      } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int orow = rt * 16 + 4 * g + r;
-      if (orow < OUT) epi(orow, j, acc[r]);
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int ct = 0; ct < kCT; ++ct) {
+            if (kk & 1) acc1[ct] = mfma16(cur.a[kc][kk], b[ct][kk], acc1[ct]);
+            else acc0[ct] = mfma16(cur.a[kc][kk], b[ct][kk], acc0[ct]);
+          }
+      }
+      // keep the chunks in order: without this the scheduler hoists every LDS read of the row tile to its top again
+      __builtin_amdgcn_sched_barrier(0);
+    });
+#pragma unroll
+    for (int ct = 0; ct < kCT; ++ct) {
+      const f32x4 acc = acc0[ct] + acc1[ct];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int orow = rt * 16 + 4 * g + r;
+        if (orow < OUT) epi(orow, 16 * ct + j, acc[r]);
+      }
     }
     if (more) cur = nxt;
   }
@@ -186,18 +212,6 @@ __device__ __forceinline__ void gemm_lds(const float* __restrict__ W, int ldw, c
                                          Epi epi, int rt_shift = 0) {
   AFrag<IN> f = gemm_prefetch<OUT, IN, TRANS>(W, ldw, wave, lane, rt_shift);
   gemm_compute<OUT, IN, TRANS, LOWP>(f, W, ldw, X, wave, lane, epi, rt_shift);
-}
-
-// one 16x16 tile of dW += dY X^T over the tile's 16 tokens
-__device__ __forceinline__ f32x4 wgrad_tile(f32x4 acc, const float* dY, const float* X, int o0, int i0, int OUT, int IN,
-                                            int lane) {
-  const int g = lane >> 4, j = lane & 15;
-  const bool ao = o0 + j < OUT, bo = i0 + j < IN;
-  const float* pa = dY + (o0 + j) * kLD + g;
-  const float* pb = X + (i0 + j) * kLD + g;
-#pragma unroll
-  for (int t0 = 0; t0 < kTT; t0 += 4) acc = mfma16(ao ? pa[t0] : 0.f, bo ? pb[t0] : 0.f, acc);
-  return acc;
 }
 
 __device__ __forceinline__ void wgrad_flush(f32x4 acc, float* dW, int ldw, int o0, int i0, int OUT, int IN, int lane) {
@@ -290,52 +304,73 @@ __device__ __forceinline__ WgRegs<NSLOT> wgrad_table(int wave, int lane) {
   return t;
 }
 
-// accumulate every tile of the list this wave owns (slot s <-> tile s*kBwdWaves + wave); SLOT0 = first accumulator.
-// Slots are processed in groups of kWgGroup: all LDS operand reads of a group are issued first, then its MFMAs with
-// the group's independent accumulators interleaved (four 40-cycle dependent chains keep the 32-cycle issue rate).
+// Accumulate the tiles [TILE0, TILE1) of the list (one matrix, or several whose operands are live at the same time) that
+// this wave owns (slot s <-> tile s*kBwdWaves + wave).  In a slot that straddles the range only some waves take part: a
+// wave-uniform branch.  Slots are processed in groups of kWgGroup: all LDS operand reads of a group are issued first, then
+// its MFMAs with the group's independent accumulators interleaved (four dependent chains keep the MFMA issue rate).
 constexpr int kWgGroup = 4;
-template <int NSLOT, int SLOT0, bool LOWP, int NACC>
-__device__ __forceinline__ void wgrad_all(f32x4 (&acc)[NACC], const float* lds, const WgRegs<NSLOT>& tab, int lane) {
-  static_assert(SLOT0 + NSLOT <= NACC, "accumulator slots");
+template <int NSLOT, int TILE0, int TILE1, bool LOWP, int NACC>
+__device__ __forceinline__ void wgrad_range(f32x4 (&acc)[NACC], const float* lds, const WgRegs<NSLOT>& tab, int wave, int lane) {
+  static_assert(NSLOT <= NACC && TILE0 < TILE1 && TILE1 <= NSLOT * kBwdWaves, "accumulator slots");
+  constexpr int S0 = TILE0 / kBwdWaves, S1 = (TILE1 + kBwdWaves - 1) / kBwdWaves;
+  constexpr int NQ = LOWP ? kCT : kTT / 4;      // MFMAs per tile: fp32 contracts 4 tokens each, bf16 16 tokens
   lane = opaque(lane);
   const int g = lane >> 4, j = lane & 15;
   const int jrow = j * kLD;
   const float* lane_base = lds + (LOWP ? 4 * g : g);
-  static_for<(NSLOT + kWgGroup - 1) / kWgGroup>([&](auto gi) __attribute__((always_inline)) {
-    constexpr int s0 = decltype(gi)::value * kWgGroup;
-    float a[kWgGroup][4], b[kWgGroup][4];
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  static_for<(S1 - S0 + kWgGroup - 1) / kWgGroup>([&](auto gi) __attribute__((always_inline)) {
+    constexpr int s0 = S0 + decltype(gi)::value * kWgGroup;
+    float a[kWgGroup][LOWP ? 4 * kCT : kTT / 4], b[kWgGroup][LOWP ? 4 * kCT : kTT / 4];
+    bool on[kWgGroup];
     static_for<kWgGroup>([&](auto ui) __attribute__((always_inline)) {
       constexpr int u = decltype(ui)::value;
-      if constexpr (s0 + u < NSLOT) {
+      if constexpr (s0 + u < S1) {
         constexpr int sl = s0 + u;
-        const int e0 = __builtin_amdgcn_readlane(tab.r[0][sl / 64], sl % 64), e1 = __builtin_amdgcn_readlane(tab.r[1][sl / 64], sl % 64);
-        const int e2 = __builtin_amdgcn_readlane(tab.r[2][sl / 64], sl % 64), e3 = __builtin_amdgcn_readlane(tab.r[3][sl / 64], sl % 64);
-        // fp32: MFMA q contracts tokens 4q + g; bf16: the single MFMA takes tokens 4g .. 4g+3 from this lane
-        const float* pa = lane_base + (e0 + min(jrow, e1));
-        const float* pb = lane_base + (e2 + min(jrow, e3));
+        constexpr bool interior = sl * kBwdWaves >= TILE0 && sl * kBwdWaves + kBwdWaves - 1 < TILE1;
+        on[u] = interior || (sl * kBwdWaves + wave_u >= TILE0 && sl * kBwdWaves + wave_u < TILE1);
+        if (on[u]) {
+          const int e0 = __builtin_amdgcn_readlane(tab.r[0][sl / 64], sl % 64), e1 = __builtin_amdgcn_readlane(tab.r[1][sl / 64], sl % 64);
+          const int e2 = __builtin_amdgcn_readlane(tab.r[2][sl / 64], sl % 64), e3 = __builtin_amdgcn_readlane(tab.r[3][sl / 64], sl % 64);
+          const float* pa = lane_base + (e0 + min(jrow, e1));
+          const float* pb = lane_base + (e2 + min(jrow, e3));
+          if constexpr (LOWP) {   // MFMA h takes tokens 16h + 4g .. 4g+3 from this lane
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          a[u][q] = pa[LOWP ? q : 4 * q];
-          b[u][q] = pb[LOWP ? q : 4 * q];
+            for (int q = 0; q < 4 * kCT; ++q) {
+              a[u][q] = pa[16 * (q >> 2) + (q & 3)];
+              b[u][q] = pb[16 * (q >> 2) + (q & 3)];
+            }
+          } else {                // MFMA q contracts tokens 4q + g
+#pragma unroll
+            for (int q = 0; q < kTT / 4; ++q) {
+              a[u][q] = pa[4 * q];
+              b[u][q] = pb[4 * q];
+            }
+          }
         }
       }
     });
-    if constexpr (LOWP) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
       static_for<kWgGroup>([&](auto ui) __attribute__((always_inline)) {
         constexpr int u = decltype(ui)::value;
-        if constexpr (s0 + u < NSLOT)
-          acc[SLOT0 + s0 + u] = mfma16_bf16(pack_bf16x4(a[u][0], a[u][1], a[u][2], a[u][3]),
-                                            pack_bf16x4(b[u][0], b[u][1], b[u][2], b[u][3]), acc[SLOT0 + s0 + u]);
+        if constexpr (s0 + u < S1) {
+          if (on[u]) {
+            if constexpr (LOWP)
+              acc[s0 + u] = mfma16_bf16(pack_bf16x4(a[u][4 * q], a[u][4 * q + 1], a[u][4 * q + 2], a[u][4 * q + 3]),
+                                        pack_bf16x4(b[u][4 * q], b[u][4 * q + 1], b[u][4 * q + 2], b[u][4 * q + 3]), acc[s0 + u]);
+            else
+              acc[s0 + u] = mfma16(a[u][q], b[u][q], acc[s0 + u]);
+          }
+        }
       });
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        static_for<kWgGroup>([&](auto ui) __attribute__((always_inline)) {
-          constexpr int u = decltype(ui)::value;
-          if constexpr (s0 + u < NSLOT) acc[SLOT0 + s0 + u] = mfma16(a[u][q], b[u][q], acc[SLOT0 + s0 + u]);
-        });
-    }
   });
+}
+// all tiles of a list (kernels with one weight-gradient phase)
+template <int NSLOT, int SLOT0, bool LOWP, int NACC>
+__device__ __forceinline__ void wgrad_all(f32x4 (&acc)[NACC], const float* lds, const WgRegs<NSLOT>& tab, int lane) {
+  static_assert(SLOT0 == 0, "lists that do not start at accumulator 0 use wgrad_range on a sub-array");
+  wgrad_range<NSLOT, 0, NSLOT * kBwdWaves, LOWP>(acc, lds, tab, 0, lane);
 }
 template <const auto& LIST, int N, int NSLOT, int SLOT0, int WAVE, int NACC>
 __device__ __forceinline__ void wgrad_flush_wave(const f32x4 (&acc)[NACC], const GradPtrs& gp, int lane) {
@@ -364,11 +399,26 @@ __device__ __forceinline__ void wgrad_flush_all(const f32x4 (&acc)[NACC], const 
 //   forward : buf[D][kLD] holds the input and receives xhat; out[f] = xhat*gamma + beta (+ res[f] if res); rstd[t]
 //   backward: dout[D][kLD] -> din = rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dout*gamma   (written to din)
 constexpr int kTPT = kBwdThreads / kTT;   // threads per token in the per-token phases
+// thread -> (token, sub): the kTPT threads of a token are adjacent lanes (shuffle reductions).  With 32-token tiles
+// (kTPT = 8) the tokens of a half-wave are 8 apart, so that the 32 lanes of an LDS access [feature sub + kTPT i][token]
+// hit 32 different banks (bank = sub + 8 (token / 8) + const); the plain tid / kTPT map put four tokens of a half-wave on
+// overlapping banks (4-way conflicts in every LayerNorm phase).
+__device__ __forceinline__ void ln_thread_map(int tid, int& tok, int& sub) {
+  if constexpr (kTT == 32 && kBwdThreads == 256) {
+    const int lane = tid & 63, wave = tid >> 6;
+    sub = lane & 7;
+    tok = 8 * ((lane >> 3) & 3) + 2 * wave + (lane >> 5);
+  } else {
+    tok = tid / kTPT;
+    sub = tid % kTPT;
+  }
+}
 template <int D>
 __device__ __forceinline__ void ln_forward(float* buf, float* out, const float* res, const float* __restrict__ gamma,
                                            const float* __restrict__ beta, float* rstd, int tid) {
   tid = opaque(tid);
-  const int tok = tid / kTPT, sub = tid % kTPT;
+  int tok, sub;
+  ln_thread_map(tid, tok, sub);
   // a thread's features stay in registers over the three passes (one LDS read each instead of three)
   constexpr int NPT = (D + kTPT - 1) / kTPT;
   float v[NPT];
@@ -412,7 +462,8 @@ template <int D>
 __device__ __forceinline__ void ln_backward(const float* dout, const float* xhat, const float* __restrict__ gamma,
                                             const float* rstd, float* din, int tid) {
   tid = opaque(tid);
-  const int tok = tid / kTPT, sub = tid % kTPT;
+  int tok, sub;
+  ln_thread_map(tid, tok, sub);
   constexpr int NPT = (D + kTPT - 1) / kTPT;
   float gg[NPT], xh[NPT];
   float s1 = 0.f, s2 = 0.f;
@@ -441,13 +492,27 @@ __device__ __forceinline__ void ln_backward(const float* dout, const float* xhat
   }
 }
 
-// per-feature row sums over the tile's tokens, accumulated into a register of thread f (f < D):
-//   sum_t a[f][t] (* b[f][t] if b)
+// row sums over the tile's tokens: sum_t a[t] * (b ? b[t] : 1).  All 2 kTT operands are requested before the first use
+// (one LDS round trip): written as a running sum inside the callers' thread-range branches, every read was followed by
+// its own s_waitcnt and the "small gradient" sums cost 7 k cycles per tile.  `b == nullptr` lanes read `a` twice and
+// multiply by one, so that all threads of a phase run the same instructions.
 __device__ __forceinline__ float row_dot(const float* a, const float* b, int f) {
-  float s = 0.f;
+  const float* pa = a + f * kLD;
+  const float* pb = b ? b + f * kLD : pa;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int t = 0; t < kTT; ++t) s = b ? fmaf(a[f * kLD + t], b[f * kLD + t], s) : s + a[f * kLD + t];
-  return s;
+  for (int t0 = 0; t0 < kTT; t0 += 8) {      // batches of 8 tokens: 16 transient registers beside the gradient accumulators
+    float va[8], vb[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      va[t] = pa[t0 + t];
+      vb[t] = pb[t0 + t];
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) s[t & 3] = fmaf(va[t], b ? vb[t] : 1.f, s[t & 3]);
+    __builtin_amdgcn_sched_barrier(0);        // keep the batches apart: hoisting all reads to the top costs 64 registers
+  }
+  return (s[0] + s[1]) + (s[2] + s[3]);
 }
 
 __device__ __forceinline__ float elu1_grad(float x) { return x > 0.f ? 1.f : __expf(x); }

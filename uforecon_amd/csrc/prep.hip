@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) pack_weights_f16_kernel(RawPtrs raw, unsi
   unsigned short out = 0;
   if (p >= 0) {
     const float w = raw.p[p][e] * kWScale;
-    if (!(fabsf(w) <= 65504.f)) atomicOr(flag, 1);
+    if (!(fabsf(w) <= 65504.f)) atomicOr(flag, 4);   // bit 2 of the sticky range status (include/ufr.h)
     const _Float16 hi = (_Float16)w;
     const _Float16 lo = (_Float16)(w - (float)hi);
     out = __builtin_bit_cast(unsigned short, plane == 0 ? hi : lo);

@@ -9,6 +9,7 @@
 //            d x (residual, MLP and q paths) -> d_tok_a; weight gradients of everything but k, v
 //   sweep 3: k, v recomputed, d K', d V from d KV -> d k, d v -> d x contribution -> d_tok_b; dWk, dWv
 // Machinery: bwd_common.h.
+#define UFR_BWD_TT 16   // the row map of this kernel (2 051 rows) only fits the LDS with 16-token tiles
 #include "bwd_common.h"
 #include "ufr_internal.h"
 
@@ -72,11 +73,13 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
   const int n_sub = SN / kTT;
   const float fS = (float)SN;
 
-  f32x4 acc[kSlots2 + kSlots3];
+  f32x4 acc[kSlots2], acc3[kSlots3];
   const auto wg_tab2 = wgrad_table<rb::kList2, 6, kSlots2>(wave, lane);
   const auto wg_tab3 = wgrad_table<rb::kList3, 2, kSlots3>(wave, lane);
 #pragma unroll
-  for (int s = 0; s < kSlots2 + kSlots3; ++s) acc[s] = splat4(0.f);
+  for (int s = 0; s < kSlots2; ++s) acc[s] = splat4(0.f);
+#pragma unroll
+  for (int s = 0; s < kSlots3; ++s) acc3[s] = splat4(0.f);
   float accB = 0.f, accN1 = 0.f, accN2 = 0.f;
 
   auto R = [&](int row) -> float* { return lds + row * kLD; };
@@ -394,14 +397,14 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
           row[352 + k] = R(O_DY + k)[col];
         }
       }
-      wgrad_all<kSlots3, kSlots2, LOWP>(acc, lds, wg_tab3, lane);
+      wgrad_all<kSlots3, 0, LOWP>(acc3, lds, wg_tab3, lane);
       __syncthreads();
     tid = opaque(tid0);
     }
   }
 
   wgrad_flush_all<rb::kList2, 6, kSlots2, 0>(acc, gp, wave, lane);
-  wgrad_flush_all<rb::kList3, 2, kSlots3, kSlots2>(acc, gp, wave, lane);
+  wgrad_flush_all<rb::kList3, 2, kSlots3, 0>(acc3, gp, wave, lane);
   if (tid < 88) {
     atomic_add_f32(gp.p[P_RT_N2W] + tid, accN2);
     atomic_add_f32(gp.p[P_RT_N1W] + tid, accN1);

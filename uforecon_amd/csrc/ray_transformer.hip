@@ -173,6 +173,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
 #pragma unroll
       for (int h = 0; h < 8; ++h) q[c][h] = splat4(0.f);
     }
+    track_external(x, ws);
     gemm_f16<M_RT_Q, C, kRtWaves>(ws, x, q, wrap);  // q[h]: rows = head dims 4g+r, column j = token
 #pragma unroll
     for (int c = 0; c < C; ++c) {

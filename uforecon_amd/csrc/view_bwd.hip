@@ -14,49 +14,57 @@
 namespace ufr {
 
 namespace vb {
-// LDS rows (each kLD floats)
+// LDS rows (each kLD floats).  Buffers whose live ranges do not overlap share rows; the walk through a tile, with the
+// phase that writes (W) / last reads (R) every buffer:
+//   CAT   x | m                W P0 / P4     R B10 (weight gradients of q, k, v), B5 (of mlp0)
+//   Q K V                      W P1          R B9
+//   MSG                        W P2          R B7 (weight gradient of merge)          then  DV   W B9  R B10
+//   XH1   merge out -> xhat1   W P3 / P4     R B6                                      then  DQ   W B8  R B10
+//   HID   relu(mlp0)           W P5          R W1, B4 -> DHID in place (W B4, R B5)    then  DMPRE (rows 0..79, W B6, R B7) | DMSG (80..159, W B7, R B9)
+//   XH2   mlp2 out -> xhat2    W P6 / P7     R B3                                      then  DK   W B9  R B10
+//   RIN   y | dir              W P7 / P0     R B2 (weight gradient of rw0)             then  DOPRE (W B3, R B4)  then  DCATm (W B5, R B6)
+//   H1 H2 DH1 DH2 DY, scalars  not shared
 enum : int {
   O_CAT = 0,        // 160: x (0..79) | m = LN1(merge(msg)) (80..159)        transformer.py:55
   O_Q = 160, O_K = 240, O_V = 320,
-  O_MSG = 400,
-  O_XH1 = 480,      // merge output -> normalised (xhat of LN1)
-  O_HID = 560,      // 160, post-ReLU
-  O_XH2 = 720,      // mlp output -> xhat of LN2
+  O_MSG = 400, O_DV = O_MSG,
+  O_XH1 = 480, O_DQ = O_XH1,
+  O_HID = 560, O_DHID = O_HID, O_DMPRE = O_HID, O_DMSG = O_HID + 80,
+  O_XH2 = 720, O_DK = O_XH2,
   O_RIN = 800,      // 83 (+1 pad): layer output y (0..79) | dir (80..82)     ray_transformer.py:311-313
+  O_DOPRE = O_RIN, O_DCATM = O_RIN,
   O_H1 = 884,       // 16
   O_H2 = 900,       // 8
-  O_DY = 908,       // 80: d y, later the d x accumulator
-  O_DOPRE = 988,    // 80
-  O_DHID = 1068,    // 160
-  O_DCAT = 1228,    // 160
-  O_DMPRE = 1388,   // 80
-  O_DMSG = 1468,    // 80
-  O_DQ = 1548, O_DK = 1628, O_DV = 1708,
-  O_DH1 = 1788,     // 16
-  O_DH2 = 1804,     // 8
-  O_RSTD1 = 1812, O_RSTD2 = 1813, O_DLOGIT = 1814,
-  O_U = 1815,       // 8 heads: L / (Q'.sum K' + eps) of (token, head)
-  O_DDEN = 1823,    // 8 heads
-  O_END = 1831
+  O_DH1 = 908,      // 16
+  O_DH2 = 924,      // 8
+  O_DY = 932,       // 80: d y, later the d x accumulator
+  O_RSTD1 = 1012, O_RSTD2 = 1013, O_DLOGIT = 1014,
+  O_U = 1015,       // 8 heads: L / (Q'.sum K' + eps) of (token, head)
+  O_DDEN = 1023,    // 8 heads
+  O_END = 1031
 };
 // flat regions behind the tile rows (floats): small parameters copied once per workgroup, and the per-tile colours / masks /
 // d radiance of the tile's points (prefetched with the tokens)
 enum : int {
   F_N1W = 0, F_N1B = 80, F_N2W = 160, F_N2B = 240,     // LayerNorm gamma / beta
   F_RW_B0 = 320, F_RW_W2 = 336, F_RW_B2 = 464, F_RW_W4 = 472, F_RW_B4 = 480,
-  F_RGBM = 484,          // [PPT][NV][4]  (<= 5 points x 7 views)
-  F_DRAD = 484 + 140,    // [PPT][3] (+1 pad)
-  F_END = 484 + 140 + 20
+  F_RGBM = 484,               // [PPT][NV][4]  (PPT * NV < kTT)
+  F_DRAD = 484 + 4 * kTT,     // [PPT][3]
+  F_END = 484 + 4 * kTT + kTT
 };
 constexpr int kFlatBase = (O_END * kLD + 3) / 4 * 4;   // 16-byte aligned (float4 reads of the colours)
 constexpr int kLdsBytes = (kFlatBase + F_END) * 4;
+static_assert(kLdsBytes <= 160 * 1024, "tile does not fit the CU's LDS");
 
+// gradient tiles in the order their dY becomes final: rw0 | mlp2 | mlp0 | merge | q k v
 constexpr WgMat kMats[] = {
-    {P_VT_Q, 80, 80, O_DQ, O_CAT},       {P_VT_K, 80, 80, O_DK, O_CAT},        {P_VT_V, 80, 80, O_DV, O_CAT},
-    {P_VT_MERGE, 80, 80, O_DMPRE, O_MSG}, {P_VT_MLP0, 160, 160, O_DHID, O_CAT}, {P_VT_MLP2, 80, 160, O_DOPRE, O_HID},
-    {P_RW_W0, 16, 83, O_DH1, O_RIN}};
+    {P_RW_W0, 16, 83, O_DH1, O_RIN},      {P_VT_MLP2, 80, 160, O_DOPRE, O_HID},  {P_VT_MLP0, 160, 160, O_DHID, O_CAT},
+    {P_VT_MERGE, 80, 80, O_DMPRE, O_MSG}, {P_VT_Q, 80, 80, O_DQ, O_CAT},         {P_VT_K, 80, 80, O_DK, O_CAT},
+    {P_VT_V, 80, 80, O_DV, O_CAT}};
 constexpr auto kList = make_wglist(kMats);
-constexpr int kSlots = (kList.first[7] + kBwdWaves - 1) / kBwdWaves;   // 256 tiles -> 32 slots
+constexpr int kSlots = (kList.first[7] + kBwdWaves - 1) / kBwdWaves;   // 256 tiles -> 64 slots
+constexpr int T_RW0 = kList.first[0], T_MLP2 = kList.first[1], T_MLP0 = kList.first[2], T_MERGE = kList.first[3],
+              T_QKV = kList.first[4], T_END = kList.first[7];
 constexpr int kDbgCols = 881;
 }  // namespace vb
 
@@ -101,8 +109,8 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
   }
 
   // A tile's global inputs (tokens, staged d token0, dir, colours / masks, d radiance) are fetched into registers one
-  // tile AHEAD -- the loads are issued in front of the weight-gradient phase of the previous tile -- and committed to LDS at
-  // the top of the tile: the HBM latency hides behind ~26 k cycles of MFMAs instead of opening every tile.
+  // tile AHEAD -- the loads are issued in front of the last GEMM phase of the previous tile -- and committed to LDS at
+  // the top of the tile: the HBM latency hides behind that phase's MFMAs instead of opening every tile.
   constexpr int kTokLoads = (kTT * 20 + kBwdThreads - 1) / kBwdThreads;   // float4 token loads per thread
   struct TileIn { f32x4 v[kTokLoads], d[kTokLoads]; float misc; };
   auto fetch = [&](int tile, TileIn& in) __attribute__((always_inline)) {
@@ -124,7 +132,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
         }
       }
     }
-    // one float per thread: [0, 48) dir of (col, e); [48, 48 + PPT*NV*4) colours / masks; then PPT*3 d radiance
+    // one float per thread: [0, 3 kTT) dir of (col, e); then PPT*NV*4 colours / masks; then PPT*3 d radiance
     in.misc = 0.f;
     const int i = tid0;
     if (i < kTT * 3) {
@@ -138,6 +146,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
       if (p < P) in.misc = d_radiance[(size_t)p * 3 + (k - pt * 3)];
     }
   };
+  static_assert(kTT * 3 + 4 * kTT + kTT <= kBwdThreads, "one misc value per thread");   // PPT*NV < kTT, PPT*3 <= kTT
   auto commit = [&](const TileIn& in) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < kTokLoads; ++q) {
@@ -156,6 +165,14 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     else if (i < kTT * 3 + PPT * NV * 4) flat[F_RGBM + i - kTT * 3] = in.misc;
     else if (i < kTT * 3 + PPT * NV * 4 + PPT * 3) flat[F_DRAD + i - kTT * 3 - PPT * NV * 4] = in.misc;
   };
+  // development dump of intermediate gradients (tools/dev): rows [row0, row0 + n) -> columns [k0, k0 + n) of the tile's tokens
+  auto dump = [&](int p0, int row0, int n, int k0) {
+    for (int idx = tid; idx < kTT * n; idx += kBwdThreads) {
+      const int col = idx / n, k = idx - col * n;
+      const int pt = col / L, tv = col - pt * L, p = p0 + pt;
+      if (pt < PPT && p < P) dbg[((size_t)p * L + tv) * kDbgCols + k0 + k] = R(row0 + k)[col];
+    }
+  };
 
 #ifdef UFR_BWD_TIMING
   unsigned long long t_prev = __builtin_readcyclecounter();
@@ -173,17 +190,20 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
 
     // ---------------- P1: Q' = elu(q)+1, K' = elu(k)+1, v (15 row tiles dealt over the waves).  Only the feature-mapped
     // values are kept: elu'(q) = q > 0 ? 1 : exp(q) = (Q' > 1 ? 1 : Q')
+    // (the first weight burst of the next matrix is requested before the current one's MFMAs: its L2 trip rides on them)
+    auto pf0k = gemm_prefetch<80, 80, false>(wp.p[P_VT_K], 80, wave, lane, 5);
     gemm_compute<80, 80, false, LOWP>(pf0, wp.p[P_VT_Q], 80, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_Q + r)[c] = elu1(v); });
-    gemm_lds<80, 80, false, LOWP>(wp.p[P_VT_K], 80, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = elu1(v); }, 5);
-    gemm_lds<80, 80, false, LOWP>(wp.p[P_VT_V], 80, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_V + r)[c] = v; }, 10);
+    auto pf0v = gemm_prefetch<80, 80, false>(wp.p[P_VT_V], 80, wave, lane, 10);
+    gemm_compute<80, 80, false, LOWP>(pf0k, wp.p[P_VT_K], 80, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = elu1(v); }, 5);
+    gemm_compute<80, 80, false, LOWP>(pf0v, wp.p[P_VT_V], 80, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_V + r)[c] = v; }, 10);
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 1)
 
     // ---------------- P2: linear attention over the L tokens of each point (linear_attention.py:31-45) in score form:
     // A[s'] = Q'.K'_s', msg = u * sum_s' A[s'] V_s'  with V = v/L and u = L / (sum_s' A[s'] + eps)
-    if (tid < kTT * 8) {
-      const int col = tid >> 3, h = tid & 7, pt = col / L;
+    for (int idx = tid; idx < kTT * 8; idx += kBwdThreads) {
+      const int col = idx >> 3, h = idx & 7, pt = col / L;
       float msg[10];
 #pragma unroll
       for (int e = 0; e < 10; ++e) msg[e] = 0.f;
@@ -245,23 +265,20 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 8)
-    if (tid < 8 * kTT) {
-      const int o = tid >> 4, c = tid & 15;
+    for (int idx = tid; idx < 8 * kTT; idx += kBwdThreads) {
+      const int o = idx / kTT, c = idx - o * kTT;
       float s = flat[F_RW_B2 + o];
 #pragma unroll
       for (int i = 0; i < 16; ++i) s = fmaf(flat[F_RW_W2 + o * 16 + i], R(O_H1 + i)[c], s);
       R(O_H2 + o)[c] = fmaxf(s, 0.f);
     }
+    if (tid < kTT) R(O_DLOGIT)[tid] = 0.f;     // view tokens / empty columns carry no logit gradient
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 9)
     // masked softmax over the views of a point and its adjoint (ray_transformer.py:315-319): one thread per point
-    if (tid < kTT) R(O_DLOGIT)[tid] = 0.f;
-    __syncthreads();
-    tid = opaque(tid0);
-    UFR_BWD_PHASE(g_vb_phase, 10)
     if (tid < PPT && p0 + tid < P) {
-      const int pt = tid, p = p0 + pt;
+      const int pt = tid;
       float lg[UFR_MAX_VIEWS], cr[UFR_MAX_VIEWS], cg[UFR_MAX_VIEWS], cb[UFR_MAX_VIEWS], mk[UFR_MAX_VIEWS];
       float mx = -INFINITY;
       for (int v = 0; v < NV; ++v) {
@@ -294,15 +311,15 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 11)
     // ---------------- B1: radiance MLP backwards
-    if (tid < 8 * kTT) {
-      const int o = tid >> 4, c = tid & 15;
+    for (int idx = tid; idx < 8 * kTT; idx += kBwdThreads) {
+      const int o = idx / kTT, c = idx - o * kTT;
       R(O_DH2 + o)[c] = R(O_H2 + o)[c] > 0.f ? flat[F_RW_W4 + o] * R(O_DLOGIT)[c] : 0.f;
     }
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 12)
-    if (tid < 16 * kTT) {
-      const int i = tid >> 4, c = tid & 15;
+    for (int idx = tid; idx < 16 * kTT; idx += kBwdThreads) {
+      const int i = idx / kTT, c = idx - i * kTT;
       float s = 0.f;
 #pragma unroll
       for (int o = 0; o < 8; ++o) s = fmaf(flat[F_RW_W2 + o * 16 + i], R(O_DH2 + o)[c], s);
@@ -312,52 +329,82 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 13)
-    // ---------------- B2: d y = W0^T d h1 (the 80 feature columns) + d token0 (staged in P0)
+    // ---------------- B2: d y = W0^T d h1 (the 80 feature columns) + d token0 (staged in P0); weight gradient of rw0
     gemm_compute<80, 16, true, LOWP>(pf5, wp.p[P_RW_W0], 83, R(O_DH1), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
+    wgrad_range<kSlots, T_RW0, T_MLP2, LOWP>(acc, lds, wg_tab, wave, lane);
+    // small gradients on the VALU: W2 (8x16), W4 (8), biases (operands final since B1)
+    {  // one instruction stream for all threads: thread -> (row a, row b or none)
+      const float* ra = R(O_DH2 + (tid >> 4));
+      const float* rb = R(O_H1 + (tid & 15));
+      if (tid >= 128) { ra = R(O_DLOGIT); rb = R(O_H2 + ((tid - 128) & 7)); }
+      if (tid >= 136) { ra = R(O_DH1 + ((tid - 136) & 15)); rb = nullptr; }
+      if (tid >= 152) ra = R(O_DH2 + ((tid - 152) & 7));
+      if (tid >= 160) ra = R(O_DLOGIT);
+      const float v = row_dot(ra, rb, 0);
+      if (tid < 128) accA += v;
+      else if (tid <= 160) accB += v;
+    }
+
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 14)
-    // ---------------- B3: LayerNorm2 backwards; y = x + LN2(.) so d x starts as d y
+    // ---------------- B3: LayerNorm2 backwards (d opre takes the rows of [y | dir], dead since B2); y = x + LN2(.) so d x
+    // starts as d y
     ln_backward<80>(R(O_DY), R(O_XH2), flat + F_N2W, R(O_RSTD2), R(O_DOPRE), tid);
-    if (tid < 80) accN2 += row_dot(R(O_DY), R(O_XH2), tid);
-    else if (tid < 160) accN2 += row_dot(R(O_DY), nullptr, tid - 80);
-    auto pf6 = gemm_prefetch<160, 80, true>(wp.p[P_VT_MLP2], 160, wave, lane, 0);
+    {
+      const float v = row_dot(R(O_DY), tid < 80 ? R(O_XH2) : nullptr, tid < 80 ? tid : (tid < 160 ? tid - 80 : 0));
+      if (tid < 160) accN2 += v;
+    }
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 15)
-    // ---------------- B4/B5: MLP backwards
+    if (dbg) dump(p0, O_DOPRE, 80, 80);
+    // ---------------- W1: weight gradient of mlp2 (needs the hidden layer, which B4 overwrites in place)
+    auto pf6 = gemm_prefetch<160, 80, true>(wp.p[P_VT_MLP2], 160, wave, lane, 0);
+    wgrad_range<kSlots, T_MLP2, T_MLP0, LOWP>(acc, lds, wg_tab, wave, lane);
+    __syncthreads();
+    tid = opaque(tid0);
+    UFR_BWD_PHASE(g_vb_phase, 16)
+    // ---------------- B4/B5: MLP backwards; d hid replaces hid element by element
     gemm_compute<160, 80, true, LOWP>(pf6, wp.p[P_VT_MLP2], 160, R(O_DOPRE), wave, lane,
                             [&](int r, int c, float v) { R(O_DHID + r)[c] = R(O_HID + r)[c] > 0.f ? v : 0.f; });
     auto pf7 = gemm_prefetch<160, 160, true>(wp.p[P_VT_MLP0], 160, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
-    UFR_BWD_PHASE(g_vb_phase, 16)
-    gemm_compute<160, 160, true, LOWP>(pf7, wp.p[P_VT_MLP0], 160, R(O_DHID), wave, lane, [&](int r, int c, float v) { R(O_DCAT + r)[c] = v; });
+    UFR_BWD_PHASE(g_vb_phase, 17)
+    if (dbg) dump(p0, O_DHID, 160, 160);
+    // d cat: the x half joins the d x accumulator at once (an element has one owner lane), the message half takes d opre's
+    // rows (dead since B4); weight gradient of mlp0
+    gemm_compute<160, 160, true, LOWP>(pf7, wp.p[P_VT_MLP0], 160, R(O_DHID), wave, lane, [&](int r, int c, float v) {
+      if (r < 80) R(O_DY + r)[c] += v;
+      else R(O_DCATM + r - 80)[c] = v;
+    });
+    wgrad_range<kSlots, T_MLP0, T_MERGE, LOWP>(acc, lds, wg_tab, wave, lane);
     __syncthreads();
     tid = opaque(tid0);
-    UFR_BWD_PHASE(g_vb_phase, 17)
-    // ---------------- B6: LayerNorm1 backwards on the message half; the x half joins the d x accumulator
-    ln_backward<80>(R(O_DCAT + 80), R(O_XH1), flat + F_N1W, R(O_RSTD1), R(O_DMPRE), tid);
-    if (tid < 80) accN1 += row_dot(R(O_DCAT + 80), R(O_XH1), tid);
-    else if (tid < 160) accN1 += row_dot(R(O_DCAT + 80), nullptr, tid - 80);
-    for (int idx = tid; idx < 80 * kTT; idx += kBwdThreads) {
-      const int r = idx >> 4, c = idx & 15;
-      R(O_DY + r)[c] += R(O_DCAT + r)[c];
+    UFR_BWD_PHASE(g_vb_phase, 18)
+    if (dbg) dump(p0, O_DCATM, 80, 400);
+    // ---------------- B6: LayerNorm1 backwards on the message half (d mpre takes d hid's rows)
+    ln_backward<80>(R(O_DCATM), R(O_XH1), flat + F_N1W, R(O_RSTD1), R(O_DMPRE), tid);
+    {
+      const float v = row_dot(R(O_DCATM), tid < 80 ? R(O_XH1) : nullptr, tid < 80 ? tid : (tid < 160 ? tid - 80 : 0));
+      if (tid < 160) accN1 += v;
     }
     auto pf8 = gemm_prefetch<80, 80, true>(wp.p[P_VT_MERGE], 80, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
-    UFR_BWD_PHASE(g_vb_phase, 18)
-    // ---------------- B7: merge backwards
+    UFR_BWD_PHASE(g_vb_phase, 19)
+    // ---------------- B7: merge backwards; weight gradient of merge
     gemm_compute<80, 80, true, LOWP>(pf8, wp.p[P_VT_MERGE], 80, R(O_DMPRE), wave, lane, [&](int r, int c, float v) { R(O_DMSG + r)[c] = v; });
+    wgrad_range<kSlots, T_MERGE, T_QKV, LOWP>(acc, lds, wg_tab, wave, lane);
     __syncthreads();
     tid = opaque(tid0);
-    UFR_BWD_PHASE(g_vb_phase, 19)
+    UFR_BWD_PHASE(g_vb_phase, 20)
     // ---------------- B8: attention backwards, query side (thread = (token s, head)):
     //   msg = u r, r = sum_s' A[s'] V_s';  d r = u d msg;  d u = d msg . r;  d den = -d u u^2 / L;
-    //   d A[s'] = d r . V_s' + d den;  d Q' = sum_s' d A[s'] K'_s'
-    if (tid < kTT * 8) {
-      const int col = tid >> 3, h = tid & 7, pt = col / L;
+    //   d A[s'] = d r . V_s' + d den;  d Q' = sum_s' d A[s'] K'_s'        (d q takes xhat1's rows, dead since B6)
+    for (int idx = tid; idx < kTT * 8; idx += kBwdThreads) {
+      const int col = idx >> 3, h = idx & 7, pt = col / L;
       float dq[10];
 #pragma unroll
       for (int d = 0; d < 10; ++d) dq[d] = 0.f;
@@ -403,21 +450,22 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     }
     __syncthreads();
     tid = opaque(tid0);
-    UFR_BWD_PHASE(g_vb_phase, 20)
+    UFR_BWD_PHASE(g_vb_phase, 21)
     // ---------------- B9: key / value side (thread = (token s', head)): d K'_s' = sum_s d A[s][s'] Q'_s,
-    //   d V_s' = sum_s A[s][s'] d r_s
-    if (tid < kTT * 8) {
-      const int col = tid >> 3, h = tid & 7, pt = col / L;
-      float dk[10], dv[10];
+    //   d V_s' = sum_s A[s][s'] d r_s        (d k takes xhat2's rows, d v the message's: dead since B3 / B7)
+    for (int idx = tid; idx < kTT * 8; idx += kBwdThreads) {
+      const int col = idx >> 3, h = idx & 7, pt = col / L;
+      float dk[10], dv[10], kp_own[10];
 #pragma unroll
-      for (int d = 0; d < 10; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+      for (int d = 0; d < 10; ++d) {
+        dk[d] = 0.f;
+        dv[d] = 0.f;
+        kp_own[d] = R(O_K + 10 * h + d)[col];
+      }
       if (pt < PPT) {
-        float Kp[10], V[10];
+        float V[10];
 #pragma unroll
-        for (int d = 0; d < 10; ++d) {
-          Kp[d] = R(O_K + 10 * h + d)[col];
-          V[d] = R(O_V + 10 * h + d)[col] * invL;
-        }
+        for (int d = 0; d < 10; ++d) V[d] = R(O_V + 10 * h + d)[col] * invL;
 #pragma unroll 4
         for (int s = 0; s < L; ++s) {
           const int c2 = pt * L + s;
@@ -428,7 +476,7 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
           for (int d = 0; d < 10; ++d) {
             Qs[d] = R(O_Q + 10 * h + d)[c2];
             dr[d] = u * R(O_DMSG + 10 * h + d)[c2];
-            a = fmaf(Qs[d], Kp[d], a);
+            a = fmaf(Qs[d], kp_own[d], a);
             dA = fmaf(dr[d], V[d], dA);
           }
 #pragma unroll
@@ -440,22 +488,26 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
       }
 #pragma unroll
       for (int d = 0; d < 10; ++d) {
-        const float kp = R(O_K + 10 * h + d)[col];
-        R(O_DK + 10 * h + d)[col] = dk[d] * (kp > 1.f ? 1.f : kp);
+        R(O_DK + 10 * h + d)[col] = dk[d] * (kp_own[d] > 1.f ? 1.f : kp_own[d]);
         R(O_DV + 10 * h + d)[col] = dv[d] * invL;
       }
     }
     auto pf9 = gemm_prefetch<80, 80, true>(wp.p[P_VT_Q], 80, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
-    UFR_BWD_PHASE(g_vb_phase, 21)
-    // ---------------- B10: projections backwards into the d x accumulator (same lane owns an element in all three)
+    UFR_BWD_PHASE(g_vb_phase, 22)
+    // ---------------- B10: projections backwards into the d x accumulator (same lane owns an element in all three); weight
+    // gradients of q, k, v; the next tile's global inputs are requested first and land while these MFMAs run
+    if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x, cur_in);
+    auto pf9k = gemm_prefetch<80, 80, true>(wp.p[P_VT_K], 80, wave, lane, 0);
     gemm_compute<80, 80, true, LOWP>(pf9, wp.p[P_VT_Q], 80, R(O_DQ), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
-    gemm_lds<80, 80, true, LOWP>(wp.p[P_VT_K], 80, R(O_DK), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
-    gemm_lds<80, 80, true, LOWP>(wp.p[P_VT_V], 80, R(O_DV), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
+    auto pf9v = gemm_prefetch<80, 80, true>(wp.p[P_VT_V], 80, wave, lane, 0);
+    gemm_compute<80, 80, true, LOWP>(pf9k, wp.p[P_VT_K], 80, R(O_DK), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
+    gemm_compute<80, 80, true, LOWP>(pf9v, wp.p[P_VT_V], 80, R(O_DV), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
+    wgrad_range<kSlots, T_QKV, T_END, LOWP>(acc, lds, wg_tab, wave, lane);
     __syncthreads();
     tid = opaque(tid0);
-    UFR_BWD_PHASE(g_vb_phase, 22)
+    UFR_BWD_PHASE(g_vb_phase, 23)
     // ---------------- B11: outputs.  Token columns 32..55 (frustum features) and 56..71 (pre_sim_mlp) are the same for
     // all NV view tokens of a point (ray_transformer.py:258-281): their gradients add up.  Token 0 is the view token.
     for (int idx = tid; idx < PPT * 40; idx += kBwdThreads) {
@@ -470,39 +522,13 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
       for (int pt = 0; pt < PPT; ++pt)
         if (p0 + pt < P) accC += R(O_DY + tid)[pt * L];
     }
-    // small gradients on the VALU: W2 (8x16), W4 (8), biases
-    if (tid < 128) accA += row_dot(R(O_DH2 + (tid >> 4)), R(O_H1 + (tid & 15)), 0);
-    if (tid >= 128 && tid < 136) accB += row_dot(R(O_DLOGIT), R(O_H2 + (tid - 128)), 0);
-    if (tid >= 136 && tid < 152) accB += row_dot(R(O_DH1 + (tid - 136)), nullptr, 0);
-    if (tid >= 152 && tid < 160) accB += row_dot(R(O_DH2 + (tid - 152)), nullptr, 0);
-    if (tid == 160) accB += row_dot(R(O_DLOGIT), nullptr, 0);
-    if (dbg) {
-      for (int idx = tid; idx < kTT * kDbgCols; idx += kBwdThreads) {
-        const int col = idx / kDbgCols, k = idx - col * kDbgCols;
-        const int pt = col / L, tv = col - pt * L, p = p0 + pt;
-        if (pt < PPT && p < P) {
-          int row;
-          if (k < 80) row = O_DY + k;
-          else if (k < 160) row = O_DOPRE + (k - 80);
-          else if (k < 320) row = O_DHID + (k - 160);
-          else if (k < 480) row = O_DCAT + (k - 320);
-          else if (k < 560) row = O_DMPRE + (k - 480);
-          else if (k < 640) row = O_DMSG + (k - 560);
-          else if (k < 720) row = O_DQ + (k - 640);
-          else if (k < 800) row = O_DK + (k - 720);
-          else if (k < 880) row = O_DV + (k - 800);
-          else row = O_DLOGIT;
-          dbg[((size_t)p * L + tv) * kDbgCols + k] = R(row)[col];
-        }
-      }
+    if (dbg) {   // what is still live at the end of the tile (d opre / d hid / d cat were dumped where they were final)
+      dump(p0, O_DY, 80, 0); dump(p0, O_DMPRE, 80, 480); dump(p0, O_DMSG, 80, 560);
+      dump(p0, O_DQ, 80, 640); dump(p0, O_DK, 80, 720); dump(p0, O_DV, 80, 800); dump(p0, O_DLOGIT, 1, 880);
     }
-    // ---------------- B12: weight gradients of the seven matrices on the MFMA, register-resident tiles;
-    // the next tile's global inputs are requested first and land while these MFMAs run
-    if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x, cur_in);
-    wgrad_all<kSlots, 0, LOWP>(acc, lds, wg_tab, lane);
-    __syncthreads();
+    __syncthreads();   // the next tile's commit overwrites CAT / DY / RIN rows that this phase reads
     tid = opaque(tid0);
-    UFR_BWD_PHASE(g_vb_phase, 23)
+    UFR_BWD_PHASE(g_vb_phase, 24)
   }
 
   // ---------------- flush (once per workgroup)

@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
         if (!valid[c]) x[c][t] = splat4(0.f);
       }
     }
+    track_external(x, ws);
     UFR_PHASE(0)  // token loads issued
     // ---------------- q,k projections (slot layout: lane group g <- heads 2g, 2g+1); x is split once per k-step
     // and feeds both matrices (stream order q0 k0 q1 k1 q2 k2)
@@ -322,6 +323,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
       for (int t = 0; t < 5; ++t) rin[c][t] = o[c][t];
       rin[c][5] = f32x4{dcomp[c], 0.f, 0.f, 0.f};
+      ws.bad_out |= __builtin_amdgcn_ballot_w64(dcomp[c] != dcomp[c]);
       h1[c][0] = vec_frag<V_RW_B0>(ws, 0, g) * kAccScale;   // biases enter the scaled accumulators (weight_stream_f16.h)
       h2[c][0] = vec_frag<V_RW_B2>(ws, 0, g) * kAccScale;
       lg[c][0] = vec_frag<V_RW_B4>(ws, 0, g) * kAccScale;

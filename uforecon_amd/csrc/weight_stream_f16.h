@@ -202,6 +202,24 @@ __device__ __forceinline__ void wstream_f16_prime(const WS& ws) {
   static_for<kF16Slots - 1>([&](auto ci) __attribute__((always_inline)) { wstream_f16_fetch<S, NWAVES, decltype(ci)::value>(ws); });
 }
 
+// NaN can only ENTER these kernels through their inputs: internally every divisor is positive, every exponent non-positive,
+// and an overflow needs a dense-layer input beyond kActLimit, which track_range reports (it also sees an infinite input;
+// the max drops NaN operands).  A NaN that did enter does not reliably reach the outputs -- v_max_f32 (ReLU) returns the
+// other operand -- so the externally supplied tiles are tested for it where they are loaded: one unordered compare per
+// value pair into the scalar mask.
+template <int C, int N, class WS>
+__device__ __forceinline__ void track_external(const f32x4 (&t)[C][N], WS& ws) {
+#if UFR_RANGE_MODE != 0
+  bool nan = false;
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      nan |= __builtin_isunordered(t[c][i][0], t[c][i][1]) | __builtin_isunordered(t[c][i][2], t[c][i][3]);
+  ws.bad_out |= __builtin_amdgcn_ballot_w64(nan);
+#endif
+}
+
 // output probe: `v` is one output value per lane that depends on every activation of its token (a LayerNorm output
 // element, an srdf): x - x is 0 unless x is NaN / inf
 template <class WS>

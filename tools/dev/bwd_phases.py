@@ -30,7 +30,8 @@ tot = sum(buf)
 names = {0: "P0 commit", 1: "P1 qkv", 2: "P2 attn", 3: "P3 merge", 4: "P4 LN1", 5: "P5 mlp0", 6: "P6 mlp2", 7: "P7 LN2", 8: "P8 rw0",
          9: "P9 h2", 11: "softmax", 12: "B1a dh2", 13: "B1b dh1", 14: "B2 dy + wg rw0", 15: "B3 LN2b", 16: "W1 wg mlp2",
          17: "B4 dhid", 18: "B5 dcat + wg mlp0", 19: "B6 LN1b", 20: "B7 dmsg + wg merge", 21: "B8 attn q", 22: "B9 attn kv",
-         23: "B10 dx + wg qkv", 24: "B11 out"}
+         23: "B10 tail (barrier)", 24: "B11 out", 30: "B10 fetch", 31: "B10 gemm q", 32: "B10 gemm k v", 33: "B10 wgrad qkv",
+         34: "B5 gemm", 35: "B5 wgrad", 18: "B5 tail (barrier)"}
 n_tiles = (RN * SN + 7) // 8 // 256      # 32-token tiles (8 points at NV = 3) per workgroup
 for i, v in enumerate(buf):
     if v:

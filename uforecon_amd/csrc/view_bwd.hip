@@ -109,61 +109,89 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
   }
 
   // A tile's global inputs (tokens, staged d token0, dir, colours / masks, d radiance) are fetched into registers one
-  // tile AHEAD -- the loads are issued in front of the last GEMM phase of the previous tile -- and committed to LDS at
+  // tile AHEAD -- the loads are issued inside the last GEMM phase of the previous tile -- and committed to LDS at
   // the top of the tile: the HBM latency hides behind that phase's MFMAs instead of opening every tile.
+  // The loads are branch-free (clamped / redirected addresses, selects at commit time) into plain register arrays with
+  // compile-time indices: as a struct filled under divergent branches the compiler kept the buffer in scratch memory, and
+  // every load was followed by s_waitcnt vmcnt(0) + scratch_store -- a dozen serial HBM round trips, 15 k cycles per tile.
   constexpr int kTokLoads = (kTT * 20 + kBwdThreads - 1) / kBwdThreads;   // float4 token loads per thread
-  struct TileIn { f32x4 v[kTokLoads], d[kTokLoads]; float misc; };
-  auto fetch = [&](int tile, TileIn& in) __attribute__((always_inline)) {
+  f32x4 in_v[kTokLoads], in_a[kTokLoads], in_b[kTokLoads];
+  float in_misc = 0.f;
+  // what token-load slot q of this thread holds: column, float4 index, point, token, validity
+  // (`t` is the thread index laundered by the caller: everything derived from the raw index is invariant over the tile
+  // loop, gets hoisted out of it, spilled, and reloaded from scratch one value at a time -- 12 k cycles per tile)
+  auto tok_slot = [&](int t, int q, int p0, int& col, int& f4, int& tv, int& p, bool& ok) __attribute__((always_inline)) {
+    const int idx = t + q * kBwdThreads;
+    col = idx / 20;
+    f4 = idx - col * 20;
+    const int pt = col / L;
+    tv = col - pt * L;
+    p = p0 + pt;
+    ok = idx < kTT * 20 && pt < PPT && p < P;
+  };
+  auto fetch = [&](int tile) __attribute__((always_inline)) {
     const int p0 = tile * PPT;
-#pragma unroll
-    for (int q = 0; q < kTokLoads; ++q) {
-      const int idx = tid0 + q * kBwdThreads;
-      const int col = idx / 20, f4 = idx - col * 20;
-      const int pt = col / L, tv = col - pt * L, p = p0 + pt;
-      in.v[q] = splat4(0.f);
-      in.d[q] = splat4(0.f);
-      if (idx < kTT * 20 && pt < PPT && p < P) {
-        if (tv == 0) {
-          in.v[q] = ld4(wp.p[P_VIEW_TOKEN] + 4 * f4);
-          in.d[q] = ld4(d_tok_a + (size_t)p * UFR_TOKEN_DIM + 4 * f4);
-          if (d_tok_b) in.d[q] += ld4(d_tok_b + (size_t)p * UFR_TOKEN_DIM + 4 * f4);
-        } else {
-          in.v[q] = ld4(x_tokens + ((size_t)p * NV + tv - 1) * UFR_TOKEN_DIM + 4 * f4);
-        }
-      }
-    }
+    const int t_l = opaque(tid0);
+    static_for<kTokLoads>([&](auto qi) __attribute__((always_inline)) {
+      constexpr int q = decltype(qi)::value;
+      int col, f4, tv, p;
+      bool ok;
+      tok_slot(t_l, q, p0, col, f4, tv, p, ok);
+      const size_t pc = ok ? (size_t)p : 0;
+      const float* vt = wp.p[P_VIEW_TOKEN] + 4 * f4;
+      const float* src_v = tv == 0 ? vt : x_tokens + (pc * NV + (tv > 0 ? tv - 1 : 0)) * UFR_TOKEN_DIM + 4 * f4;
+      const float* src_a = tv == 0 ? d_tok_a + pc * UFR_TOKEN_DIM + 4 * f4 : vt;      // d token0 exists for token 0 only
+      const float* src_b = (tv == 0 && d_tok_b) ? d_tok_b + pc * UFR_TOKEN_DIM + 4 * f4 : vt;
+      in_v[q] = ld4(src_v);
+      in_a[q] = ld4(src_a);
+      in_b[q] = ld4(src_b);
+    });
     // one float per thread: [0, 3 kTT) dir of (col, e); then PPT*NV*4 colours / masks; then PPT*3 d radiance
-    in.misc = 0.f;
-    const int i = tid0;
+    const int i = t_l;
+    const float* src = dirs;   // any valid address for the threads without a value
     if (i < kTT * 3) {
       const int col = i / 3, e = i - col * 3, pt = col / L, tv = col - pt * L, p = p0 + pt;
-      if (pt < PPT && p < P && tv > 0) in.misc = dirs[((size_t)p * NV + tv - 1) * 4 + e];
+      if (pt < PPT && p < P && tv > 0) src = dirs + ((size_t)p * NV + tv - 1) * 4 + e;
     } else if (i < kTT * 3 + PPT * NV * 4) {
       const int k = i - kTT * 3, pt = k / (NV * 4), p = p0 + pt;
-      if (p < P) in.misc = rgbm[(size_t)p * NV * 4 + (k - pt * NV * 4)];
+      if (p < P) src = rgbm + (size_t)p * NV * 4 + (k - pt * NV * 4);
     } else if (i < kTT * 3 + PPT * NV * 4 + PPT * 3) {
       const int k = i - kTT * 3 - PPT * NV * 4, pt = k / 3, p = p0 + pt;
-      if (p < P) in.misc = d_radiance[(size_t)p * 3 + (k - pt * 3)];
+      if (p < P) src = d_radiance + (size_t)p * 3 + (k - pt * 3);
     }
+    in_misc = *src;
   };
   static_assert(kTT * 3 + 4 * kTT + kTT <= kBwdThreads, "one misc value per thread");   // PPT*NV < kTT, PPT*3 <= kTT
-  auto commit = [&](const TileIn& in) __attribute__((always_inline)) {
-#pragma unroll
-    for (int q = 0; q < kTokLoads; ++q) {
-      const int idx = tid0 + q * kBwdThreads;
-      if (idx < kTT * 20) {
-        const int col = idx / 20, f4 = idx - col * 20;
+  auto commit = [&](int tile) __attribute__((always_inline)) {
+    const int p0 = tile * PPT;
+    const int t_l = opaque(tid0);
+    static_for<kTokLoads>([&](auto qi) __attribute__((always_inline)) {
+      constexpr int q = decltype(qi)::value;
+      int col, f4, tv, p;
+      bool ok;
+      tok_slot(t_l, q, p0, col, f4, tv, p, ok);
+      if (t_l + q * kBwdThreads < kTT * 20) {
+        const bool tok0 = ok && tv == 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          R(O_CAT + 4 * f4 + e)[col] = in.v[q][e];
-          R(O_DY + 4 * f4 + e)[col] = in.d[q][e];
+          R(O_CAT + 4 * f4 + e)[col] = ok ? in_v[q][e] : 0.f;
+          R(O_DY + 4 * f4 + e)[col] = tok0 ? in_a[q][e] + (d_tok_b ? in_b[q][e] : 0.f) : 0.f;
         }
       }
+    });
+    const int i = t_l;
+    float misc = 0.f;   // same validity conditions as in fetch
+    if (i < kTT * 3) {
+      const int col = i / 3, pt = col / L, tv = col - pt * L;
+      if (pt < PPT && p0 + pt < P && tv > 0) misc = in_misc;
+      R(O_RIN + 80 + i % 3)[i / 3] = misc;
+    } else if (i < kTT * 3 + PPT * NV * 4) {
+      const int k = i - kTT * 3, pt = k / (NV * 4);
+      flat[F_RGBM + k] = p0 + pt < P ? in_misc : 0.f;
+    } else if (i < kTT * 3 + PPT * NV * 4 + PPT * 3) {
+      const int k = i - kTT * 3 - PPT * NV * 4, pt = k / 3;
+      flat[F_DRAD + k] = p0 + pt < P ? in_misc : 0.f;
     }
-    const int i = tid0;
-    if (i < kTT * 3) R(O_RIN + 80 + i % 3)[i / 3] = in.misc;
-    else if (i < kTT * 3 + PPT * NV * 4) flat[F_RGBM + i - kTT * 3] = in.misc;
-    else if (i < kTT * 3 + PPT * NV * 4 + PPT * 3) flat[F_DRAD + i - kTT * 3 - PPT * NV * 4] = in.misc;
   };
   // development dump of intermediate gradients (tools/dev): rows [row0, row0 + n) -> columns [k0, k0 + n) of the tile's tokens
   auto dump = [&](int p0, int row0, int n, int k0) {
@@ -177,12 +205,11 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
 #ifdef UFR_BWD_TIMING
   unsigned long long t_prev = __builtin_readcyclecounter();
 #endif
-  TileIn cur_in;
-  if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x, cur_in);
+  if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x);
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int p0 = tile * PPT;
     // ---------------- P0: token inputs (ray_transformer.py:284-286), dir, staged d token0, colours, d radiance
-    commit(cur_in);
+    commit(tile);
     auto pf0 = gemm_prefetch<80, 80, false>(wp.p[P_VT_Q], 80, wave, lane, 0);
     __syncthreads();
     tid = opaque(tid0);
@@ -379,7 +406,9 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
       if (r < 80) R(O_DY + r)[c] += v;
       else R(O_DCATM + r - 80)[c] = v;
     });
+    UFR_BWD_PHASE(g_vb_phase, 34)
     wgrad_range<kSlots, T_MLP0, T_MERGE, LOWP>(acc, lds, wg_tab, wave, lane);
+    UFR_BWD_PHASE(g_vb_phase, 35)
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 18)
@@ -497,17 +526,24 @@ __global__ void __launch_bounds__(kBwdThreads) view_bwd_kernel(RawPtrs wp, GradP
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 22)
     // ---------------- B10: projections backwards into the d x accumulator (same lane owns an element in all three); weight
-    // gradients of q, k, v; the next tile's global inputs are requested first and land while these MFMAs run
-    if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x, cur_in);
+    // gradients of q, k, v
     auto pf9k = gemm_prefetch<80, 80, true>(wp.p[P_VT_K], 80, wave, lane, 0);
     gemm_compute<80, 80, true, LOWP>(pf9, wp.p[P_VT_Q], 80, R(O_DQ), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
+    UFR_BWD_PHASE(g_vb_phase, 31)
     auto pf9v = gemm_prefetch<80, 80, true>(wp.p[P_VT_V], 80, wave, lane, 0);
     gemm_compute<80, 80, true, LOWP>(pf9k, wp.p[P_VT_K], 80, R(O_DK), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
     gemm_compute<80, 80, true, LOWP>(pf9v, wp.p[P_VT_V], 80, R(O_DV), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
+    UFR_BWD_PHASE(g_vb_phase, 32)
     wgrad_range<kSlots, T_QKV, T_END, LOWP>(acc, lds, wg_tab, wave, lane);
+    UFR_BWD_PHASE(g_vb_phase, 33)
     __syncthreads();
     tid = opaque(tid0);
     UFR_BWD_PHASE(g_vb_phase, 23)
+    // the next tile's global inputs are requested here and land while B11 runs.  (Anywhere inside the GEMM / weight-gradient
+    // phases a reload of a spilled register -- these kernels keep 256 accumulators per lane and spill ~100 others -- waits
+    // with vmcnt(0) for every vector-memory operation in flight, these HBM loads included: 7..15 k cycles per tile.)
+    if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
+    UFR_BWD_PHASE(g_vb_phase, 30)
     // ---------------- B11: outputs.  Token columns 32..55 (frustum features) and 56..71 (pre_sim_mlp) are the same for
     // all NV view tokens of a point (ray_transformer.py:258-281): their gradients add up.  Token 0 is the view token.
     for (int idx = tid; idx < PPT * 40; idx += kBwdThreads) {

@@ -251,8 +251,8 @@ int ufr_project_gather_bwd(const ufr_frame* frame, const ufr_raw_weights* raw, c
  * view-transformer output depend on its own position only: evaluating the PN NEW samples and re-using the coarse pass's
  * rows gives the same numbers (ufr_render_rays does that internally).  These entry points expose the pieces so that the
  * training step can do the same, forwards and backwards:
- *   ufr_sample_importance_pool = ufr_sample_importance_merge that also returns the new positions z_new (RN,PN), in draw
- *     order, and for every merged slot its row in the pool [RN*SN coarse rows (ray-major) | RN*PN new rows]: row (RN,SN+PN) int32;
+ *   ufr_sample_importance_pool = ufr_sample_importance_merge that also returns the new positions z_new (RN,PN), sorted
+ *     along the ray, and for every merged slot its row in the pool [RN*SN coarse rows (ray-major) | RN*PN new rows]: row (RN,SN+PN) int32;
  *   ufr_view_transform / ufr_ray_transform = the view-transformer and ray-transformer halves of ufr_aggregate
  *     (token0 (P,80), radiance (P,3) | token0 rows of the RN*SN samples -> srdf (RN,SN)); `row` (nullable, (RN,SN) int32)
  *     maps slot (ray, s) to its row of token0 (NULL = slot order), so the fine pass reads the pool in place;

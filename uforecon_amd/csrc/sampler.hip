@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(256) importance_merge_kernel(const float* __re
     }
   }
   // coarse + fine sorted together (model.py:466-470), again by rank over the concatenation.
-  // z_new / src_row (whole-path renderer): the PN new positions in draw order, and for every merged slot the
+  // z_new / src_row (whole-path renderer): the PN new positions (sorted along the ray), and for every merged slot the
   // row of the pool [RN*SN coarse evaluations | RN*PN new evaluations] that holds its per-point results --
   // a point's view-transformer output does not depend on the other samples of the ray, so the fine pass
   // re-evaluates only the new points and reads the coarse ones back through this table.
@@ -199,14 +199,19 @@ __global__ void __launch_bounds__(256) importance_merge_kernel(const float* __re
   float* out = z_all + (size_t)ray * T;
   for (int k = lane; k < T; k += 64) {
     float v = all[k];
-    int rank = 0;
+    int rank = 0, rank_new = 0;   // among all merged samples / among the new ones only
     for (int j = 0; j < T; ++j) {
       float o = all[j];
-      rank += (o < v || (o == v && j < k)) ? 1 : 0;
+      const int before = (o < v || (o == v && j < k)) ? 1 : 0;
+      rank += before;
+      rank_new += j >= SN ? before : 0;
     }
     out[rank] = v;
-    if (src_row) src_row[(size_t)ray * T + rank] = k < SN ? ray * SN + k : RN * SN + ray * PN + (k - SN);
-    if (z_new && k >= SN) z_new[(size_t)ray * PN + (k - SN)] = v;
+    // the new samples are emitted SORTED along the ray (their pool rows are only ever reached through src_row, so any order
+    // is valid): neighbouring lanes of the gather kernels then hold neighbouring positions -- shared footprints in the
+    // forward gathers, and the backward scatter folds runs of equal voxel corners before it issues atomics
+    if (src_row) src_row[(size_t)ray * T + rank] = k < SN ? ray * SN + k : RN * SN + ray * PN + rank_new;
+    if (z_new && k >= SN) z_new[(size_t)ray * PN + rank_new] = v;
   }
 }
 

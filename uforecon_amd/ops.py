@@ -371,7 +371,7 @@ def project_gather_bwd(frame: FrameHandle, weights: PackedWeights, grads: GradBu
 
 # ----------------------------------------------------------------------------- halves of aggregate / sample pool
 def sample_importance_pool(weight: torch.Tensor, z: torch.Tensor, U2: torch.Tensor):
-    """-> z_all (RN,SN+PN) sorted, z_new (RN,PN) in draw order, row (RN,SN+PN) int32: pool row of every merged slot
+    """-> z_all (RN,SN+PN) sorted, z_new (RN,PN) sorted along the ray, row (RN,SN+PN) int32: pool row of every merged slot
     (pool = [RN*SN coarse rows | RN*PN new rows])."""
     RN, SN = z.shape
     PN = U2.shape[0]

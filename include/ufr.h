@@ -32,7 +32,7 @@ enum ufr_status {
 
 /* Version of this header's ABI (argument lists, struct layouts, packed-blob layout).  ufr_version() returns the value
  * the library was built with: a binding must refuse a library whose version differs (uforecon_amd/_lib.py does). */
-#define UFR_ABI_VERSION 300
+#define UFR_ABI_VERSION 301
 
 #define UFR_MAX_VIEWS 7
 #define UFR_NUM_STAGES 3
@@ -326,6 +326,29 @@ int ufr_frustum_correlate(const float* ref_fea, const float* src_fea, const floa
                           const float* view_weights, int32_t C, int32_t H, int32_t W, int32_t D, int32_t NS,
                           float* similarity, float* aggregated, void* workspace, size_t workspace_bytes,
                           ufr_stream stream);
+
+/* ---- 3-D convolutions of the frustum construction's U-Nets ---------------------
+ * One layer of CostRegNet / CostRegNetWeight (code1/encoder_utils/fmt/module.py:469-543; Conv3d / Deconv3d = convolution
+ * + BatchNorm + ReLU, :110-187): 3x3x3, padding 1, fp32, volumes CHANNEL-LAST [B][D][H][W][C] (a (B,1,D,H,W) tensor is
+ * both layouts at once).
+ *   mode   UFR_CONV3D_S1 stride 1 | UFR_CONV3D_S2 stride 2 (output ceil(n/2)) | UFR_CONV3D_T2 transposed, stride 2,
+ *          output_padding 1 (output 2n)
+ *   weight the layer's weight in the checkpoint's layout: conv (cout,cin,3,3,3), transposed conv (cin,cout,3,3,3)
+ *   bias (cout, nullable); bn_scale / bn_shift (cout, nullable together): eval-mode BatchNorm folded to
+ *          y = conv * scale + shift with scale = gamma / sqrt(var + eps), shift = beta - mean * scale; relu != 0: ReLU
+ *   skip   (nullable) channel-last tensor of the output's shape, added after the activation (the U-Net's "convK + ...")
+ *   out    channel-last [B][Do][Ho][Wo][cout]; with out_ncdhw != 0 the reference's (B,cout,Do,Ho,Wo) instead, and then
+ *          weight2 (cout2,cin,3,3,3) / out2 (B,cout2,Do,Ho,Wo) may name a second head on the same input whose output goes
+ *          through a sigmoid (CostRegNetWeight's `features` + `weights`, module.py:541-543) -- both heads in one pass.
+ * Supported (cin, cout + cout2): the layers of the two networks with base_channels 8:
+ *   S1: (1,8) (16,16) (32,32) (64,64) (8,1) (8,8) (8,8+1);  S2: (8,16) (16,32) (32,64);  T2: (64,32) (32,16) (16,8).    */
+#define UFR_CONV3D_S1 0
+#define UFR_CONV3D_S2 1
+#define UFR_CONV3D_T2 2
+int ufr_conv3d(const float* in, const float* weight, const float* weight2, const float* bias, const float* bn_scale,
+               const float* bn_shift, const float* skip, float* out, float* out2, int32_t B, int32_t D, int32_t H,
+               int32_t W, int32_t cin, int32_t cout, int32_t cout2, int32_t mode, int32_t relu, int32_t out_ncdhw,
+               ufr_stream stream);
 
 /* ---- TSDF fusion -------------------------------------------------------------------
  * Replaces the reference's `integrate` kernel (tsdf_fusion.py:77-152, a CUDA string compiled through pycuda) and the

@@ -72,6 +72,66 @@ def test_gpu_cascade_matches_reference_golden(name):
     feats = [{k: v.to(dev) for k, v in f.items()} for f in c["features"]]
     frustums, info = m(feats, c["proj_matrices"], c["depth_values"].to(dev), c["img_hw"])
     assert frustums["stage3"]["feature_volume"].shape == (3, 8, 8, 32, 64)
-    # MIOpen's fp32 3-D convolutions vs the reference's CPU ones: measured <= 1e-5 on every tensor of every stage (the
-    # outlier budget is for winner-take-all ties that move a pixel's depth hypotheses, none observed)
+    # the HIP correlate + convolution kernels vs the reference's CPU modules (the outlier budget is for winner-take-all
+    # ties that move a pixel's depth hypotheses)
     _compare(frustums, info, _golden(name), tol=1e-4, max_outlier_frac=0.002)
+
+
+LAYERS = [(1, 8, 0), (16, 16, 0), (32, 32, 0), (64, 64, 0), (8, 8, 0), (8, 16, 1), (16, 32, 1), (32, 64, 1),
+          (64, 32, 2), (32, 16, 2), (16, 8, 2)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,mode", LAYERS)
+def test_gpu_conv3d_layer_matches_torch(cin, cout, mode):
+    """ufr_conv3d, every (cin, cout, stride / transposed) of the two U-Nets, against torch's fp32 CPU convolution of the
+    same layer: plain, with bias, with folded BatchNorm + ReLU + skip; odd extents exercise the zero padding."""
+    import torch.nn.functional as F
+
+    from uforecon_amd import ops
+
+    torch.manual_seed(100 * cin + cout + mode)
+    dev = "cuda:0"
+    B, D, H, W = 2, 6, 10, 36
+    x = torch.randn(B, cin, D, H, W)
+    w = torch.randn((cin, cout, 3, 3, 3) if mode == 2 else (cout, cin, 3, 3, 3)) / (27 * cin) ** 0.5
+    bias, scale, shift = torch.randn(cout), torch.rand(cout) + 0.5, torch.randn(cout)
+    ref = (F.conv_transpose3d(x, w, stride=2, padding=1, output_padding=1) if mode == 2
+           else F.conv3d(x, w, stride=1 + mode, padding=1))
+    skip = torch.randn_like(ref)
+    x_cl = x.permute(0, 2, 3, 4, 1).contiguous().to(dev)
+    cl = lambda t: t.permute(0, 2, 3, 4, 1)
+    out = ops.conv3d(x_cl, w.to(dev), mode)
+    assert out.shape == cl(ref).shape
+    tol = 2e-6 * float(ref.abs().max()) * (27 * cin) ** 0.5
+    assert float((out.cpu() - cl(ref)).abs().max()) < tol
+    out = ops.conv3d(x_cl, w.to(dev), mode, bias=bias.to(dev), skip=cl(skip).contiguous().to(dev))
+    assert float((out.cpu() - cl(ref + bias.view(1, -1, 1, 1, 1) + skip)).abs().max()) < tol
+    want = torch.relu(ref * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)) + skip
+    out = ops.conv3d(x_cl, w.to(dev), mode, bn_scale=scale.to(dev), bn_shift=shift.to(dev), relu=True,
+                     skip=cl(skip).contiguous().to(dev))
+    assert float((out.cpu() - cl(want)).abs().max()) < 2 * tol
+
+
+@pytest.mark.gpu
+def test_gpu_conv3d_heads_and_errors():
+    """The heads: prob (8 -> 1) and features (8 -> 8) + sigmoid(weights (8 -> 1)) in one pass, reference layout out."""
+    import torch.nn.functional as F
+
+    from uforecon_amd import ops
+    from uforecon_amd.ops import UfrError
+
+    torch.manual_seed(5)
+    dev = "cuda:0"
+    x = torch.randn(3, 8, 8, 16, 24)
+    wf, ww = torch.randn(8, 8, 3, 3, 3) / 15, torch.randn(1, 8, 3, 3, 3) / 15
+    x_cl = x.permute(0, 2, 3, 4, 1).contiguous().to(dev)
+    f, s = ops.conv3d(x_cl, wf.to(dev), out_ncdhw=True, weight2=ww.to(dev))
+    assert float((f.cpu() - F.conv3d(x, wf, padding=1)).abs().max()) < 1e-5
+    assert float((s.cpu() - torch.sigmoid(F.conv3d(x, ww, padding=1))).abs().max()) < 1e-5
+    p = ops.conv3d(x_cl, ww.to(dev), out_ncdhw=True)
+    assert p.shape == (3, 1, 8, 16, 24) and float((p.cpu() - F.conv3d(x, ww, padding=1)).abs().max()) < 1e-5
+    with pytest.raises(UfrError, match="not a layer"):
+        ops.conv3d(torch.zeros(1, 8, 8, 8, 24, device=dev), torch.zeros(8, 24, 3, 3, 3, device=dev))
+    with pytest.raises(UfrError, match="GPU"):
+        ops.conv3d(torch.zeros(1, 8, 8, 8, 8), torch.zeros(8, 8, 3, 3, 3))

@@ -1,6 +1,6 @@
 """Per-frame producers at 512x640, 3 views (the part of a frame that is replicated on every rank when rays are sharded):
-FeatureNet (library convolutions + HIP deformable convolution), FMT, the frustum cascade (HIP correlate kernel + MIOpen 3-D
-U-Nets) and the matching features.  Prints the time of `UFOReconInference.encode_frame` and of its parts."""
+FeatureNet (library convolutions + HIP deformable convolution), FMT, the frustum cascade (HIP correlate kernel + HIP 3-D
+U-Nets, csrc/conv3d.hip) and the matching features.  Prints the time of `UFOReconInference.encode_frame` and of its parts."""
 import argparse
 import os
 import sys

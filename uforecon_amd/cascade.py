@@ -9,7 +9,8 @@ Mirrors, with the reference's class names, forward signatures and state_dict key
   MVSVolume                         code1/feature_volume.py:101-121
   the frustum dict of UFORecon      code1/model.py:517-524
 Step 2 of DepthNet.forward (warp + correlate + view weighting) is the fused HIP kernel of csrc/frustum.hip
-(`uforecon_amd.frustum.correlate`); the 3-D U-Nets are plain library convolutions (torch -> MIOpen).  Inference only.
+(`uforecon_amd.frustum.correlate`); the two 3-D U-Nets run on the HIP convolution kernel of csrc/conv3d.hip
+(`uforecon_amd.unet3d`); the modules below own the parameters under the reference's names.  Inference only.
 """
 from __future__ import annotations
 
@@ -17,41 +18,26 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import fmt, frustum
+from . import fmt, frustum, unet3d
 
 Align_Corners_Range = False      # TransMVSNet.py:21
 
 
 class Conv3d(nn.Module):
-    """conv + BatchNorm + ReLU (module.py:110-143)."""
+    """Parameters of conv + BatchNorm (+ ReLU) (module.py:110-143): `conv.weight`, `bn.*`.  Executed fused by
+    `unet3d.cost_reg_net` (one ufr_conv3d launch per block); the block has no forward of its own."""
 
-    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, relu=True, bn=True, bn_momentum=0.1, **kwargs):
+    def __init__(self, in_channels, out_channels, stride=1, transposed=False):
         super().__init__()
-        self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, bias=(not bn), **kwargs)
-        self.bn = nn.BatchNorm3d(out_channels, momentum=bn_momentum) if bn else None
-        self.relu = relu
-
-    def forward(self, x):
-        x = self.conv(x)
-        if self.bn is not None:
-            x = self.bn(x)
-        return F.relu(x, inplace=True) if self.relu else x
+        conv = nn.ConvTranspose3d if transposed else nn.Conv3d
+        extra = dict(output_padding=1) if transposed else {}
+        self.conv = conv(in_channels, out_channels, 3, stride=stride, padding=1, bias=False, **extra)
+        self.bn = nn.BatchNorm3d(out_channels)
 
 
-class Deconv3d(nn.Module):
-    """transposed conv + BatchNorm + ReLU (module.py:152-187)."""
-
-    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, relu=True, bn=True, bn_momentum=0.1, **kwargs):
-        super().__init__()
-        self.conv = nn.ConvTranspose3d(in_channels, out_channels, kernel_size, stride=stride, bias=(not bn), **kwargs)
-        self.bn = nn.BatchNorm3d(out_channels, momentum=bn_momentum) if bn else None
-        self.relu = relu
-
-    def forward(self, x):
-        x = self.conv(x)
-        if self.bn is not None:
-            x = self.bn(x)
-        return F.relu(x, inplace=True) if self.relu else x
+def Deconv3d(in_channels, out_channels):
+    """transposed conv (stride 2, output_padding 1) + BatchNorm (+ ReLU) (module.py:152-187)"""
+    return Conv3d(in_channels, out_channels, stride=2, transposed=True)
 
 
 class ConvBnReLU3D(nn.Module):
@@ -71,28 +57,17 @@ class CostRegNet(nn.Module):
 
     def __init__(self, in_channels, base_channels):
         super().__init__()
-        b = base_channels
-        self.conv0 = Conv3d(in_channels, b, padding=1)
-        self.conv1 = Conv3d(b, b * 2, stride=2, padding=1)
-        self.conv2 = Conv3d(b * 2, b * 2, padding=1)
-        self.conv3 = Conv3d(b * 2, b * 4, stride=2, padding=1)
-        self.conv4 = Conv3d(b * 4, b * 4, padding=1)
-        self.conv5 = Conv3d(b * 4, b * 8, stride=2, padding=1)
-        self.conv6 = Conv3d(b * 8, b * 8, padding=1)
-        self.conv7 = Deconv3d(b * 8, b * 4, stride=2, padding=1, output_padding=1)
-        self.conv9 = Deconv3d(b * 4, b * 2, stride=2, padding=1, output_padding=1)
-        self.conv11 = Deconv3d(b * 2, b, stride=2, padding=1, output_padding=1)
-        self.prob = nn.Conv3d(b, 1, 3, stride=1, padding=1, bias=False)
+        ch = [base_channels * f for f in (1, 2, 4, 8)]
+        self.conv0 = Conv3d(in_channels, ch[0])
+        for lvl in (1, 2, 3):                                    # conv1/conv2, conv3/conv4, conv5/conv6
+            setattr(self, f"conv{2 * lvl - 1}", Conv3d(ch[lvl - 1], ch[lvl], stride=2))
+            setattr(self, f"conv{2 * lvl}", Conv3d(ch[lvl], ch[lvl]))
+        for name, lvl in (("conv7", 3), ("conv9", 2), ("conv11", 1)):
+            setattr(self, name, Deconv3d(ch[lvl], ch[lvl - 1]))
+        self.prob = nn.Conv3d(ch[0], 1, 3, stride=1, padding=1, bias=False)
 
     def forward(self, x):
-        conv0 = self.conv0(x)
-        conv2 = self.conv2(self.conv1(conv0))
-        conv4 = self.conv4(self.conv3(conv2))
-        x = self.conv6(self.conv5(conv4))
-        x = conv4 + self.conv7(x)
-        x = conv2 + self.conv9(x)
-        x = conv0 + self.conv11(x)
-        return self.prob(x)
+        return unet3d.cost_reg_net(self, x)
 
 
 class CostRegNetWeight(nn.Module):
@@ -101,29 +76,18 @@ class CostRegNetWeight(nn.Module):
 
     def __init__(self, in_channels, base_channels):
         super().__init__()
-        b = base_channels
-        self.conv0 = nn.Conv3d(in_channels, b, kernel_size=3, padding=1)
-        self.conv1 = nn.Conv3d(b, b * 2, kernel_size=3, stride=2, padding=1)
-        self.conv2 = nn.Conv3d(b * 2, b * 2, kernel_size=3, padding=1)
-        self.conv3 = nn.Conv3d(b * 2, b * 4, kernel_size=3, stride=2, padding=1)
-        self.conv4 = nn.Conv3d(b * 4, b * 4, kernel_size=3, padding=1)
-        self.conv5 = nn.Conv3d(b * 4, b * 8, kernel_size=3, stride=2, padding=1)
-        self.conv6 = nn.Conv3d(b * 8, b * 8, kernel_size=3, padding=1)
-        self.conv7 = nn.ConvTranspose3d(b * 8, b * 4, kernel_size=3, stride=2, padding=1, output_padding=1)
-        self.conv9 = nn.ConvTranspose3d(b * 4, b * 2, kernel_size=3, stride=2, padding=1, output_padding=1)
-        self.conv11 = nn.ConvTranspose3d(b * 2, b, kernel_size=3, stride=2, padding=1, output_padding=1)
-        self.features = nn.Conv3d(b, 8, kernel_size=3, stride=1, padding=1, bias=False)
-        self.weights = nn.Conv3d(b, 1, kernel_size=3, stride=1, padding=1, bias=False)
+        ch = [base_channels * f for f in (1, 2, 4, 8)]
+        self.conv0 = nn.Conv3d(in_channels, ch[0], 3, padding=1)
+        for lvl in (1, 2, 3):
+            setattr(self, f"conv{2 * lvl - 1}", nn.Conv3d(ch[lvl - 1], ch[lvl], 3, stride=2, padding=1))
+            setattr(self, f"conv{2 * lvl}", nn.Conv3d(ch[lvl], ch[lvl], 3, padding=1))
+        for name, lvl in (("conv7", 3), ("conv9", 2), ("conv11", 1)):
+            setattr(self, name, nn.ConvTranspose3d(ch[lvl], ch[lvl - 1], 3, stride=2, padding=1, output_padding=1))
+        self.features = nn.Conv3d(ch[0], 8, 3, stride=1, padding=1, bias=False)
+        self.weights = nn.Conv3d(ch[0], 1, 3, stride=1, padding=1, bias=False)
 
     def forward(self, x):
-        conv0 = self.conv0(x)
-        conv2 = self.conv2(self.conv1(conv0))
-        conv4 = self.conv4(self.conv3(conv2))
-        x = self.conv6(self.conv5(conv4))
-        x = conv4 + self.conv7(x)
-        x = conv2 + self.conv9(x)
-        x = conv0 + self.conv11(x)
-        return self.features(x), torch.sigmoid(self.weights(x))
+        return unet3d.cost_reg_net_weight(self, x)
 
 
 class PixelwiseNet(nn.Module):

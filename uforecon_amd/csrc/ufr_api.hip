@@ -845,6 +845,31 @@ int ufr_frustum_correlate(const float* ref_fea, const float* src_fea, const floa
   return UFR_OK;
 }
 
+// ------------------------------------------------------------------ 3-D convolutions of the frustum U-Nets
+int ufr_conv3d(const float* in, const float* weight, const float* weight2, const float* bias, const float* bn_scale,
+               const float* bn_shift, const float* skip, float* out, float* out2, int32_t B, int32_t D, int32_t H,
+               int32_t W, int32_t cin, int32_t cout, int32_t cout2, int32_t mode, int32_t relu, int32_t out_ncdhw,
+               ufr_stream stream) {
+  UFR_REQUIRE(in && weight && out, "ufr_conv3d: null argument");
+  UFR_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "ufr_conv3d: B=%d D=%d H=%d W=%d", B, D, H, W);
+  UFR_REQUIRE(mode == UFR_CONV3D_S1 || mode == UFR_CONV3D_S2 || mode == UFR_CONV3D_T2, "ufr_conv3d: unknown mode %d", mode);
+  UFR_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "ufr_conv3d: bn_scale and bn_shift go together");
+  UFR_REQUIRE(cout2 == 0 || (weight2 && out2 && out_ncdhw && mode == UFR_CONV3D_S1),
+              "ufr_conv3d: a second head needs weight2, out2, out_ncdhw and stride 1");
+  UFR_REQUIRE(out_ncdhw || (cout % 4 == 0 && cout2 == 0), "ufr_conv3d: channel-last outputs need cout %% 4 == 0 (got %d)", cout);
+  UFR_REQUIRE(!skip || !out_ncdhw, "ufr_conv3d: skip is a channel-last tensor; not with out_ncdhw");
+  UFR_REQUIRE((long long)B * D * H * W * (cin > cout ? cin : cout) < (1ll << 40), "ufr_conv3d: volume too large");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ProfScope p("conv3d", s);
+  const hipError_t e = launch_conv3d(in, weight, weight2, bias, bn_scale, bn_shift, skip, out, out2, B, D, H, W, cin, cout,
+                                     cout2, mode, relu, out_ncdhw, s);
+  if (e == hipErrorInvalidValue)
+    return fail(UFR_ERR_ARG, "ufr_conv3d: (cin %d, cout %d+%d, mode %d) is not a layer of CostRegNet / CostRegNetWeight", cin,
+                cout, cout2, mode);
+  UFR_HIP(e);
+  return UFR_OK;
+}
+
 // ------------------------------------------------------------------ TSDF fusion
 int ufr_tsdf_integrate(float* tsdf, float* weight, float* color, const int32_t* dim, const float* origin,
                        float voxel_size, float trunc_margin, const float* cam_intr, const float* cam_pose,

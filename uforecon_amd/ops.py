@@ -557,3 +557,37 @@ def profile_read() -> dict:
     launches = (C.c_int32 * cap)()
     n = _lib.load().ufr_profile_read(names, ms, launches, cap)
     return {names[i].decode(): dict(ms=float(ms[i]), launches=int(launches[i])) for i in range(n)}
+
+
+CONV3D_S1, CONV3D_S2, CONV3D_T2 = 0, 1, 2
+
+
+def conv3d(x_cl: torch.Tensor, weight: torch.Tensor, mode: int = CONV3D_S1, bias: Optional[torch.Tensor] = None,
+           bn_scale: Optional[torch.Tensor] = None, bn_shift: Optional[torch.Tensor] = None, relu: bool = False,
+           skip: Optional[torch.Tensor] = None, out_ncdhw: bool = False, weight2: Optional[torch.Tensor] = None):
+    """One 3x3x3 layer of the frustum U-Nets (ufr_conv3d).  ``x_cl`` (B,D,H,W,cin) channel-last; ``weight`` in the
+    checkpoint's layout (conv (cout,cin,3,3,3); transposed conv, mode CONV3D_T2, (cin,cout,3,3,3)).  Returns the
+    channel-last (B,Do,Ho,Wo,cout) output, or with ``out_ncdhw`` the reference's (B,cout,Do,Ho,Wo) -- and, when ``weight2``
+    names a second head, the pair (out, sigmoid(second head))."""
+    B, D, H, W, cin = x_cl.shape
+    transposed = mode == CONV3D_T2
+    cout = weight.shape[1] if transposed else weight.shape[0]
+    if tuple(weight.shape) != ((cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3)):
+        raise UfrError(f"conv3d: weight {tuple(weight.shape)} does not match {cin} input channels (mode {mode})")
+    Do, Ho, Wo = ((2 * D, 2 * H, 2 * W) if transposed else ((D + 1) // 2, (H + 1) // 2, (W + 1) // 2) if mode == CONV3D_S2
+                  else (D, H, W))
+    dev = x_cl.device
+    cout2 = 0 if weight2 is None else weight2.shape[0]
+    out = torch.empty((B, cout, Do, Ho, Wo) if out_ncdhw else (B, Do, Ho, Wo, cout), dtype=torch.float32, device=dev)
+    out2 = torch.empty((B, cout2, Do, Ho, Wo), dtype=torch.float32, device=dev) if cout2 else None
+    if skip is not None and tuple(skip.shape) != tuple(out.shape):
+        raise UfrError(f"conv3d: skip {tuple(skip.shape)} does not match the output {tuple(out.shape)}")
+    keep = [t.detach().contiguous() for t in (weight, weight2, bias, bn_scale, bn_shift) if t is not None]
+    it = iter(keep)
+    ptr = lambda t, n: None if t is None else _dev(next(it), n)
+    w_p, w2_p, b_p, s_p, h_p = ptr(weight, "weight"), ptr(weight2, "weight2"), ptr(bias, "bias"), ptr(bn_scale, "bn_scale"), \
+        ptr(bn_shift, "bn_shift")
+    _lib.check(_lib.load().ufr_conv3d(_dev(x_cl, "x"), w_p, w2_p, b_p, s_p, h_p, _opt(skip, "skip"), out.data_ptr(),
+                                      _opt(out2, "out2"), B, D, H, W, cin, cout, cout2, int(mode), int(bool(relu)),
+                                      int(bool(out_ncdhw)), _stream()), "ufr_conv3d")
+    return (out, out2) if cout2 else out

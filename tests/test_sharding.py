@@ -136,6 +136,48 @@ def test_two_rank_bench_renders_the_one_rank_frame(tmp_path):
 
 
 @pytest.mark.gpu
+def test_two_rank_training_step_allreduces_to_the_mean(tmp_path):
+    """The data-parallel leg of BASELINE configs[4] through the real launcher path (torch.distributed.run -> one process per
+    rank -> tools/bench_train.py --gpus 2), both ranks on this box's single GPU over gloo: every rank trains on its own
+    frame / rays, and the parameter gradients after the flat all-reduce must equal the MEAN of the two ranks' own
+    gradients (each reproduced by a single-process run on that rank's data).  Rank 0 reports per-rank step and
+    all-reduce times."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tools", "bench_train.py")
+    common = ["--height", "64", "--width", "96", "--rays", "128", "--steps", "1", "--warmup", "0", "--fixed-seed", "3",
+              "--no-cpu-baseline"]
+    env = dict(os.environ, UFR_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for r in (0, 1):
+        one = subprocess.run([sys.executable, script, "--gpus", "1", "--data-rank", str(r), "--dump-grads", str(tmp_path / f"g{r}.pt"),
+                              *common], capture_output=True, text=True, env=env, timeout=600)
+        assert one.returncode == 0, one.stderr[-2000:]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), script, "--gpus", "2", "--backend", "gloo", "--dump-grads",
+                          str(tmp_path / "g2.pt"), *common], capture_output=True, text=True, env=env, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    g0, g1, g2 = (torch.load(tmp_path / f"g{k}.pt") for k in ("0", "1", "2"))
+    assert set(g0) == set(g1) == set(g2) and len(g2) >= 40
+    differ = 0
+    for k in g2:
+        mean = 0.5 * (g0[k] + g1[k])
+        scale = float(mean.abs().max()) + 1e-12
+        assert float((g2[k] - mean).abs().max()) <= 2e-5 * scale + 1e-9, k      # float atomics reorder sums between runs
+        differ += int(float((g0[k] - g1[k]).abs().max()) > 1e-3 * scale)
+    assert differ > 30          # the ranks really trained on different data
+    line = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and len(line["config"]["per_rank"]) == 2
+    for r in line["config"]["per_rank"]:
+        assert r["all_reduce_ms_per_step"] >= 0 and "view_bwd" in r["kernel_ms_per_step"] and r["wall_ms_per_step"] > 0
+
+
+@pytest.mark.gpu
 def test_bench_line_contract(tmp_path):
     """One JSON line with the fields the driver and the review read (metric / value / unit / n_gpus / steps / warmup /
     ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload, roofline, cpu_baseline,

@@ -55,6 +55,8 @@ def parse(argv=None):
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--dump-grads", default="", help="rank 0 writes the post-all-reduce parameter gradients of the LAST step "
                                                      "here (.pt) -- the 2-rank data-parallel test compares them")
+    ap.add_argument("--data-rank", type=int, default=-1, help="single-process run on the data (frame, rays, uniforms) of this "
+                                                               "rank of a multi-rank run (the data-parallel test's reference legs)")
     ap.add_argument("--fixed-seed", type=int, default=-1, help=">= 0: ray indices / uniforms of a step depend only on "
                                                                 "(seed, rank, step), frames on the rank: reproducible")
     return ap.parse_args(argv)
@@ -126,13 +128,14 @@ def run(a, dev, world=1, rank=0):
     m = M.UFORecon(args, precision=precision).to(dev).train()     # the mode travels with the model, not with the process
     m.load_state_dict(weights_cpu, strict=True)
     opt = torch.optim.Adam(m.parameters(), lr=1e-4)                       # model.py:72-87 (uforecon_lr)
-    frame_cpu = make_frame(a.height, a.width, a.views, seed=rank, train_layout=True)
+    drank = rank if a.data_rank < 0 else a.data_rank
+    frame_cpu = make_frame(a.height, a.width, a.views, seed=drank, train_layout=True)
     f = frame_cpu.to(dev)
     vols = [f.feature_volume[st][k] for st in f.feature_volume for k in f.feature_volume[st]]
     for v in vols:
         v.requires_grad_(True)
     HW = a.height * a.width
-    gen = torch.Generator(device=dev).manual_seed(100 + rank if a.fixed_seed < 0 else a.fixed_seed * 1000 + rank)
+    gen = torch.Generator(device=dev).manual_seed(100 + drank if a.fixed_seed < 0 else a.fixed_seed * 1000 + drank)
     ar_events = []
 
     def step():

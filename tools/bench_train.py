@@ -149,9 +149,11 @@ def run(a, dev, world=1, rank=0):
         rgb_gt, rgb, depth, depth_gt, rgb2, depth2 = r[0], r[1], r[2], r[3], r[8], r[9]
         nf = f.batch["near_fars"]
         mask = (depth_gt != 0) & (depth_gt >= nf[:, 0, 0:1]) & (depth_gt <= nf[:, 0, 1:2])
-        loss = (torch.nn.functional.mse_loss(rgb, rgb_gt) + torch.nn.functional.mse_loss(rgb2, rgb_gt)
-                + torch.nn.functional.l1_loss(depth[mask], depth_gt[mask])
-                + torch.nn.functional.l1_loss(depth2[mask], depth_gt[mask]))           # model.py:552-566
+        # model.py:552-566.  The masked L1 means are written without boolean indexing: `depth[mask]` makes the host wait for
+        # the forward (it needs the count) before it can enqueue the backward -- same value, no pipeline bubble
+        n_valid = mask.sum().clamp_min(1)
+        l1 = lambda d: ((d - depth_gt).abs() * mask).sum() / n_valid
+        loss = torch.nn.functional.mse_loss(rgb, rgb_gt) + torch.nn.functional.mse_loss(rgb2, rgb_gt) + l1(depth) + l1(depth2)
         loss.backward()
         if world > 1:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -86,47 +86,68 @@ __global__ void __launch_bounds__(448) gather_bwd_kernel(FrameDev f, VolGrads vg
     const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
     const float wx[2] = {(fx + 1.f) - ix, ix - fx}, wy[2] = {(fy + 1.f) - iy, iy - fy}, wz[2] = {(fz + 1.f) - iz, iz - fz};
 #pragma unroll
-    for (int dz = 0; dz < 2; ++dz)
+    for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-      for (int dy = 0; dy < 2; ++dy)
+      for (int dx = 0; dx < 2; ++dx) {
+        // the two corners (dz = 0, 1) of this (dy, dx) column of the cell
+        float val[2][9];
+        int off[2];
+        bool alive[2];
 #pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
+        for (int dz = 0; dz < 2; ++dz) {
           const float cx = fx + dx, cy = fy + dy, cz = fz + dz;
           const bool ok = active && cx >= 0.f && cx <= (float)(W - 1) && cy >= 0.f && cy <= (float)(H - 1) && cz >= 0.f &&
                           cz <= (float)(D - 1);
-          // Neighbouring lanes are consecutive samples of one ray, and a straight line visits the cells of a grid
-          // monotonically: equal corner offsets form contiguous runs.  Float atomics to one address serialise in the
-          // L2 (plain stores instead of atomics: 0.76 vs 4.5 ms for this kernel), so runs are folded first -- aligned
-          // pairs, then quads, then octets of lanes with the same offset add up through lane shifts and only the
-          // surviving lane of each group issues the nine atomics.
           const float wt = ok ? wx[dx] * wy[dy] * wz[dz] : 0.f;
-          const int off = ok ? (((int)cz * H + (int)cy) * W + (int)cx) : -1 - (int)threadIdx.x;   // invalid: never equal
-          float val[9];
+          off[dz] = ok ? (((int)cz * H + (int)cy) * W + (int)cx) : -1 - (int)threadIdx.x - 1024 * dz;   // invalid: never equal
 #pragma unroll
-          for (int c = 0; c < 8; ++c) val[c] = wt * dfl[8 * s + c];
-          val[8] = wt * dwl;
-          bool alive = ok;
+          for (int c = 0; c < 8; ++c) val[dz][c] = wt * dfl[8 * s + c];
+          val[dz][8] = wt * dwl;
+          alive[dz] = ok;
+        }
+        // Neighbouring lanes are consecutive samples of one ray (both passes hand their samples over sorted), and a
+        // straight line visits the cells of a grid monotonically.  Float atomics are what this kernel costs (plain stores
+        // instead: 0.76 vs 4.5 ms), so equal addresses are folded in registers before any is issued:
+        //  (a) across the cell boundary: when the next sample sits one cell further along z, its near corner IS this
+        //      sample's far corner -- this lane hands its dz = 1 value to the next lane's dz = 0 slot;
+        {
+          const int n_off0 = __shfl_down(off[0], 1, 16);                     // next lane's near corner
+          const int n_alive0 = __shfl_down((int)alive[0], 1, 16);
+          const bool give = alive[1] && n_alive0 && n_off0 == off[1] && (threadIdx.x & 15) != 15;
+          const int p_give = __shfl_up((int)give, 1, 16);                    // does the previous lane hand over?
+#pragma unroll
+          for (int c = 0; c < 9; ++c) {
+            const float v_up = __shfl_up(val[1][c], 1, 16);
+            if (p_give && (threadIdx.x & 15) != 0) val[0][c] += v_up;
+          }
+          if (give) alive[1] = false;
+        }
+        //  (b) inside a cell: equal corner offsets form contiguous runs -- aligned pairs, then quads, then octets of lanes
+        //      with the same offset add up through lane shifts and only the surviving lane of each group issues atomics.
+#pragma unroll
+        for (int dz = 0; dz < 2; ++dz) {
           static_for<UFR_GBWD_ROUNDS>([&](auto ri) __attribute__((always_inline)) {
             constexpr int d = 1 << decltype(ri)::value;
-            const int k_dn = __shfl_down(off, d, 16);                        // offset of lane + d (groups never leave a row)
-            const int k_up = __shfl_up(off, d, 16);                          // offset of lane - d
-            const int a_dn = __shfl_down((int)alive, d, 16), a_up = __shfl_up((int)alive, d, 16);
+            const int k_dn = __shfl_down(off[dz], d, 16);                    // offset of lane + d (groups never leave a row)
+            const int k_up = __shfl_up(off[dz], d, 16);                      // offset of lane - d
+            const int a_dn = __shfl_down((int)alive[dz], d, 16), a_up = __shfl_up((int)alive[dz], d, 16);
             const int pos = threadIdx.x & (2 * d - 1);
-            const bool absorb = pos == 0 && alive && a_dn && k_dn == off;
-            const bool absorbed = pos == d && alive && a_up && k_up == off;
+            const bool absorb = pos == 0 && alive[dz] && a_dn && k_dn == off[dz];
+            const bool absorbed = pos == d && alive[dz] && a_up && k_up == off[dz];
 #pragma unroll
             for (int c = 0; c < 9; ++c) {
-              const float v_dn = __shfl_down(val[c], d, 16);
-              if (absorb) val[c] += v_dn;
+              const float v_dn = __shfl_down(val[dz][c], d, 16);
+              if (absorb) val[dz][c] += v_dn;
             }
-            if (absorbed) alive = false;
+            if (absorbed) alive[dz] = false;
           });
-          if (alive) {
+          if (alive[dz]) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) unsafeAtomicAdd(gf + c * plane + off, val[c]);
-            unsafeAtomicAdd(gw + off, val[8]);
+            for (int c = 0; c < 8; ++c) unsafeAtomicAdd(gf + c * plane + off[dz], val[dz][c]);
+            unsafeAtomicAdd(gw + off[dz], val[dz][8]);
           }
         }
+      }
   }
 }
 

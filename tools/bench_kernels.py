@@ -60,7 +60,7 @@ def main():
     ops.profile_enable(True)
     for _ in range(5):
         lib.ufr_aggregate(W.packed.data_ptr(), x.data_ptr(), rgbm.data_ptr(), dirs.data_ptr(), RN, SN, NV,
-                          radiance.data_ptr(), srdf.data_ptr(), ws.data_ptr(), None, None, ops._stream())
+                          radiance.data_ptr(), srdf.data_ptr(), ws.data_ptr(), None, None, -1, ops._stream())
     torch.cuda.synchronize()
     prof = ops.profile_read()
     ops.profile_enable(False)

@@ -13,7 +13,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kF16RingBytes = kF16Slots * kF16ChunkFrags * 1024;  // kF16Slots 24 KiB slots
+constexpr int kF16RingBytes = kF16Slots * kF16ChunkFrags * 1024;  // the ring: kF16Slots (3) slots of kF16ChunkFrags (12) KiB
 constexpr int kF16LdsBytes = kF16RingBytes + kVecBytes;
 
 // split of a value pair into fp16 planes of 2^kXScaleLog2 x: hi = fp16(x) 2^k (exact scaling; one v_cvt_pk_f16_f32 and one
@@ -75,7 +75,7 @@ template <bool LOWP>
 struct WStreamF16T {
   static constexpr bool lowp = LOWP;
   const char* src;     // fp16 plane region of the packed blob (global, wave-uniform)
-  char* ring;          // LDS: two chunk slots
+  char* ring;          // LDS: the ring of kF16Slots chunk slots
   unsigned ring_lds;   // ... as an LDS byte address (scalar)
   const f32x4* vecs;   // LDS: vector fragments (fp32)
   int wave, lane;

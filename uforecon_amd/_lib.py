@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # UFR_LIB selects an alternative in-tree build (A/B kernel variants during development)
 LIB_PATH = os.environ.get("UFR_LIB") or os.path.join(HERE, "lib", "libufr.so")
 
-ABI_VERSION = 301   # = UFR_ABI_VERSION of include/ufr.h; load() refuses a library built against another header
+ABI_VERSION = 302   # = UFR_ABI_VERSION of include/ufr.h; load() refuses a library built against another header
 MAX_VIEWS = 7
 NUM_STAGES = 3
 TOKEN_DIM = 80
@@ -92,7 +92,7 @@ SIGNATURES = {
     "ufr_aggregate_bwd": (C.c_int, [C.POINTER(RawWeights), C.POINTER(RawGrads), vp, vp, vp, vp, i32, i32, i32, vp, vp, vp,
                                     vp, vp, vp, i32, vp]),
     "ufr_project_gather_bwd": (C.c_int, [C.POINTER(Frame), C.POINTER(RawWeights), C.POINTER(RawGrads), vp, i32, vp, vp,
-                                         i32, i32, vp, vp, C.POINTER(vp), C.POINTER(vp), i32, vp]),
+                                         i32, i32, vp, vp, vp, C.POINTER(vp), C.POINTER(vp), i32, vp]),
     "ufr_sample_importance_pool": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "ufr_view_transform": (C.c_int, [vp, vp, vp, vp, i32, i32, vp, vp, i32, vp]),
     "ufr_ray_transform_workspace_bytes": (sz, [i32]),

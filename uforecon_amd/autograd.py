@@ -89,28 +89,29 @@ class RenderTwoPass(torch.autograd.Function):
         # transformer and the compositor of the fine pass read them through the slot -> row table (no copies, no gathers)
         pool_tok = torch.empty(P1 + P2, ops._lib.TOKEN_DIM, dtype=torch.float32, device=dev)
         pool_rad = torch.empty(P1 + P2, 3, dtype=torch.float32, device=dev)
-        x1, rgbm1, dirs1, g1 = ops.project_gather(frame, weights, ray_o, ray_d, z1, want_sim8=True, want_xy=True)
+        sim8_pool = torch.empty(P1 + P2, 8, dtype=torch.float32, device=dev)      # pre_sim_mlp inputs, pool rows
+        x1, rgbm1, dirs1, g1 = ops.project_gather(frame, weights, ray_o, ray_d, z1, want_xy=True, sim8_out=sim8_pool[:P1])
         ops.view_transform(weights, x1, rgbm1, dirs1, token0=pool_tok[:P1], radiance=pool_rad[:P1], precision=prec)
         srdf1 = ops.ray_transform(weights, pool_tok[:P1], RN, SN, precision=prec)
         rgb, depth, opacity, weight = ops.composite(z1, pool_rad[:P1].view(RN, SN, 3), srdf1, var)
         z2, z_new, row = ops.sample_importance_pool(weight, z1, U2)                  # model.py:455-470 (weights detached)
-        x2, rgbm2, dirs2, g2 = ops.project_gather(frame, weights, ray_o, ray_d, z_new, want_sim8=True, want_xy=True)
+        x2, rgbm2, dirs2, g2 = ops.project_gather(frame, weights, ray_o, ray_d, z_new, want_xy=True, sim8_out=sim8_pool[P1:])
         ops.view_transform(weights, x2, rgbm2, dirs2, token0=pool_tok[P1:], radiance=pool_rad[P1:], precision=prec)
         srdf2 = ops.ray_transform(weights, pool_tok, RN, S2, row=row, precision=prec)
         rgb2, depth2, opacity2, weight2 = ops.composite(z2, pool_rad, srdf2, var, row=row)
         xy2 = torch.cat([g1["xy"], g2["xy"]], 1)[:, row.reshape(-1).long()]         # (NV, RN*S2, 2), a returned value only
         ctx.frame, ctx.weights, ctx.n_par, ctx.precision = frame, weights, n_par, prec
         ctx.vol_shapes = [tuple(t.shape) for t in tensors[n_par:]]
-        ctx.save_for_backward(ray_o, ray_d, z1, z2, z_new, row, x1, rgbm1, dirs1, g1["sim8"], srdf1,
-                              x2, rgbm2, dirs2, g2["sim8"], pool_tok, pool_rad, srdf2)
+        ctx.save_for_backward(ray_o, ray_d, z1, z2, row, x1, rgbm1, dirs1, sim8_pool, srdf1,
+                              x2, rgbm2, dirs2, pool_tok, pool_rad, srdf2)
         ctx.mark_non_differentiable(g1["xy"], xy2, z2)
         return rgb, depth, opacity, weight, srdf1, g1["xy"], rgb2, depth2, opacity2, weight2, srdf2, xy2, z2
 
     @staticmethod
     def backward(ctx, d_rgb, d_depth, d_opacity, d_weight, d_srdf, _dxy, d_rgb2, d_depth2, d_opacity2, d_weight2, d_srdf2,
                  _dxy2, _dz2):
-        (ray_o, ray_d, z1, z2, z_new, row, x1, rgbm1, dirs1, sim8_1, srdf1,
-         x2, rgbm2, dirs2, sim8_2, pool_tok, pool_rad, srdf2) = ctx.saved_tensors
+        (ray_o, ray_d, z1, z2, row, x1, rgbm1, dirs1, sim8_pool, srdf1,
+         x2, rgbm2, dirs2, pool_tok, pool_rad, srdf2) = ctx.saved_tensors
         frame, W, prec = ctx.frame, ctx.weights, ctx.precision
         RN, SN = z1.shape
         S2 = z2.shape[1]
@@ -138,8 +139,9 @@ class RenderTwoPass(torch.autograd.Function):
         ops.ray_transform_bwd(W, grads, pool_tok[:P1], RN, SN, d_srdf_c, out=(pool_a[:P1], pool_b[:P1]), accumulate=True,
                               precision=prec)
         # ---- view transformer backwards: coarse samples once, with the cotangents of both passes; new samples once
-        d_pv1 = ops.view_transform_bwd(W, grads, x1, rgbm1, dirs1, pool_a[:P1], pool_b[:P1], pool_drad[:P1], precision=prec)
-        d_pv2 = ops.view_transform_bwd(W, grads, x2, rgbm2, dirs2, pool_a[P1:], pool_b[P1:], pool_drad[P1:], precision=prec)
+        d_pv = torch.empty(pool_tok.shape[0], 40, dtype=torch.float32, device=dev)   # pool rows again
+        ops.view_transform_bwd(W, grads, x1, rgbm1, dirs1, pool_a[:P1], pool_b[:P1], pool_drad[:P1], precision=prec, d_pv=d_pv[:P1])
+        ops.view_transform_bwd(W, grads, x2, rgbm2, dirs2, pool_a[P1:], pool_b[P1:], pool_drad[P1:], precision=prec, d_pv=d_pv[P1:])
         need = ctx.needs_input_grad[6:]
         if any(need[ctx.n_par:]):
             gvol = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.vol_shapes]
@@ -147,8 +149,9 @@ class RenderTwoPass(torch.autograd.Function):
         else:
             gvol = [None] * len(ctx.vol_shapes)
             gf = gw = None
-        ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z1, sim8_1, d_pv1, gf, gw, precision=prec)
-        ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z_new, sim8_2, d_pv2, gf, gw, precision=prec)
+        # ONE frustum scatter over all merged samples of a ray (z2: sorted, twice the density of either pass -- the run
+        # folding of gather_bwd.hip removes more atomics), d_pv / sim8 addressed through the slot -> row table
+        ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z2, sim8_pool, d_pv, gf, gw, precision=prec, row=row)
         gpar = [grads.grad(k) for k in ops.RAW_WEIGHT_KEYS]
         gpar[-1] = d_var.reshape(gpar[-1].shape)
         out = [g if (n and g is not None) else None for g, n in zip(gpar + gvol, need)]

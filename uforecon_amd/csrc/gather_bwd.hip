@@ -28,6 +28,7 @@ struct VolGrads {
 __global__ void __launch_bounds__(448) gather_bwd_kernel(FrameDev f, VolGrads vg, const float* __restrict__ ray_o,
                                                           int o_stride, const float* __restrict__ ray_d,
                                                           const float* __restrict__ zval, const float* __restrict__ d_pv,
+                                                          const int* __restrict__ pv_row,
                                                           int P, int SN) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [64][NV][25]
   const int NV = f.NV;
@@ -65,12 +66,15 @@ __global__ void __launch_bounds__(448) gather_bwd_kernel(FrameDev f, VolGrads vg
   float Wsum = 0.f;
   for (int n = 0; n < NV; ++n) Wsum += smem[(p * NV + n) * 25 + 24];
   const float inv = 1.f / (Wsum + 1e-8f);
+  // pv_row (nullable): row of d_pv holding slot pidx -- the two-pass step hands over ALL merged samples of a ray in one
+  // launch (sorted: twice the density of either pass, so the run folding below removes more atomics) and d_pv as the pool
+  const size_t pv_base = (size_t)(pv_row ? pv_row[pc] : pc) * 40;
   float dfl[24], dwl = 0.f;
 #pragma unroll
   for (int c = 0; c < 24; ++c) {
     float G = 0.f;
     for (int n = 0; n < NV; ++n) G += smem[(p * NV + n) * 25 + c];
-    const float dout = active ? d_pv[(size_t)pidx * 40 + c] : 0.f;
+    const float dout = active ? d_pv[pv_base + c] : 0.f;
     dfl[c] = dout * wl * inv;
     dwl = fmaf(dout, (fl[c] - G * inv) * inv, dwl);
   }
@@ -152,13 +156,13 @@ __global__ void __launch_bounds__(448) gather_bwd_kernel(FrameDev f, VolGrads vg
 }
 
 hipError_t launch_gather_bwd(const FrameDev& f, float* const* grad_feat, float* const* grad_weight, const float* ray_o,
-                             int o_stride, const float* ray_d, const float* z, const float* d_pv, int RN, int SN,
+                             int o_stride, const float* ray_d, const float* z, const float* d_pv, const int* pv_row, int RN, int SN,
                              hipStream_t s) {
   const int P = RN * SN, NV = f.NV;
   VolGrads vg;
   for (int i = 0; i < UFR_NUM_STAGES; ++i) { vg.feat[i] = grad_feat[i]; vg.weight[i] = grad_weight[i]; }
   const size_t lds = sizeof(float) * 64 * NV * 25;
-  hipLaunchKernelGGL(gather_bwd_kernel, dim3((P + 63) / 64), dim3(64 * NV), lds, s, f, vg, ray_o, o_stride, ray_d, z, d_pv,
+  hipLaunchKernelGGL(gather_bwd_kernel, dim3((P + 63) / 64), dim3(64 * NV), lds, s, f, vg, ray_o, o_stride, ray_d, z, d_pv, pv_row,
                      P, SN);
   return hipGetLastError();
 }

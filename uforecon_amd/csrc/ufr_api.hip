@@ -486,8 +486,9 @@ int ufr_aggregate_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, co
 
 int ufr_project_gather_bwd(const ufr_frame* frame, const ufr_raw_weights* raw, const ufr_raw_grads* grads,
                            const float* ray_o, int32_t ray_o_stride, const float* ray_d, const float* z, int32_t RN,
-                           int32_t SN, const float* sim8, const float* d_pv, float* const* grad_vol_feat,
-                           float* const* grad_vol_weight, int32_t precision, ufr_stream stream) {
+                           int32_t SN, const float* sim8, const float* d_pv, const int32_t* row,
+                           float* const* grad_vol_feat, float* const* grad_vol_weight, int32_t precision,
+                           ufr_stream stream) {
   const FrameDev* f = frame_of(frame);
   UFR_REQUIRE(f, "ufr_project_gather_bwd: frame handle not prepared");
   UFR_PRECISION(precision, lowp, "ufr_project_gather_bwd");
@@ -506,7 +507,7 @@ int ufr_project_gather_bwd(const ufr_frame* frame, const ufr_raw_weights* raw, c
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (scatter) {
     ProfScope p("gather_bwd", s);
-    UFR_HIP(launch_gather_bwd(*f, grad_vol_feat, grad_vol_weight, ray_o, ray_o_stride, ray_d, z, d_pv, RN, SN, s));
+    UFR_HIP(launch_gather_bwd(*f, grad_vol_feat, grad_vol_weight, ray_o, ray_o_stride, ray_d, z, d_pv, row, RN, SN, s));
   }
   {
     ProfScope p("presim_bwd", s);

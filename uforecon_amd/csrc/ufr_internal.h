@@ -77,8 +77,8 @@ hipError_t launch_ray_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* to
 hipError_t launch_presim_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* sim8, const float* d_pv, int P, bool lowp,
                              hipStream_t s);
 hipError_t launch_gather_bwd(const FrameDev& f, float* const* grad_feat, float* const* grad_weight, const float* ray_o,
-                             int o_stride, const float* ray_d, const float* z, const float* d_pv, int RN, int SN,
-                             hipStream_t s);
+                             int o_stride, const float* ray_d, const float* z, const float* d_pv, const int* pv_row, int RN,
+                             int SN, hipStream_t s);
 struct FmtWeights {  // = ufr_fmt_layer_weights
   const float *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo, *w1, *b1, *w2, *b2, *n1w, *n1b, *n2w, *n2b;
 };

@@ -224,7 +224,8 @@ def points(ray_o: torch.Tensor, ray_d: torch.Tensor, z: torch.Tensor) -> torch.T
 
 def project_gather(frame: FrameHandle, weights: PackedWeights, ray_o: torch.Tensor, ray_d: torch.Tensor,
                    z: torch.Tensor, debug: bool = False, want_sim8: bool = False, want_xy: bool = False,
-                   vol24_in: Optional[torch.Tensor] = None, sim8_in: Optional[torch.Tensor] = None):
+                   vol24_in: Optional[torch.Tensor] = None, sim8_in: Optional[torch.Tensor] = None,
+                   sim8_out: Optional[torch.Tensor] = None):
     RN, SN = z.shape
     P, NV, dev = RN * SN, frame.NV, z.device
     x = torch.empty(P, NV, _lib.TOKEN_DIM, dtype=torch.float32, device=dev)
@@ -235,7 +236,9 @@ def project_gather(frame: FrameHandle, weights: PackedWeights, ray_o: torch.Tens
         dbg = dict(sim8=torch.empty(P, 8, device=dev), vol24=torch.empty(P, 24, device=dev),
                    xy=torch.empty(NV, P, 2, device=dev), mask_z=torch.empty(NV, P, device=dev))
     else:
-        if want_sim8:   # the backward of pre_sim_mlp needs its input
+        if sim8_out is not None:   # ... into a row range of the two-pass step's pool
+            dbg["sim8"] = sim8_out
+        elif want_sim8:   # the backward of pre_sim_mlp needs its input
             dbg["sim8"] = torch.empty(P, 8, device=dev)
         if want_xy:     # points_in_pixel of the reference's return tuples
             dbg["xy"] = torch.empty(NV, P, 2, device=dev)
@@ -354,9 +357,11 @@ def aggregate_bwd(weights: PackedWeights, grads: GradBuffer, x, rgb, dirs, token
 
 
 def project_gather_bwd(frame: FrameHandle, weights: PackedWeights, grads: GradBuffer, ray_o, ray_d, z, sim8, d_pv,
-                       grad_vol_feat, grad_vol_weight, precision: Optional[int] = None) -> None:
+                       grad_vol_feat, grad_vol_weight, precision: Optional[int] = None,
+                       row: Optional[torch.Tensor] = None) -> None:
     """Scatter-adds into grad_vol_feat[s] (NV,8,D,Hs,Ws) / grad_vol_weight[s] (NV,1,D,Hs,Ws) (zero them first) and
-    accumulates the pre_sim_mlp gradients into `grads`."""
+    accumulates the pre_sim_mlp gradients into `grads`.  ``row`` (RN,SN) int32: ``sim8`` / ``d_pv`` are pool tensors and
+    slot (ray, s) owns ``d_pv[row[ray, s]]``."""
     RN, SN = z.shape
     stride = 0 if ray_o.numel() == 3 else 3
     gf = gw = None        # both None: pre_sim_mlp gradients only
@@ -365,8 +370,8 @@ def project_gather_bwd(frame: FrameHandle, weights: PackedWeights, grads: GradBu
         gw = (C.c_void_p * 3)(*[_dev(t, "grad_vol_weight") for t in grad_vol_weight])
     _lib.check(_lib.load().ufr_project_gather_bwd(
         C.byref(frame.frame), C.byref(weights.raw), C.byref(grads.raw), _dev(ray_o, "ray_o"), stride, _dev(ray_d, "ray_d"),
-        _dev(z, "z"), RN, SN, _dev(sim8, "sim8"), _dev(d_pv, "d_pv"), gf, gw,
-        weights.mode() if precision is None else precision, _stream()), "ufr_project_gather_bwd")
+        _dev(z, "z"), RN, SN, _dev(sim8, "sim8"), _dev(d_pv, "d_pv"), None if row is None else _dev(row, "row", torch.int32),
+        gf, gw, weights.mode() if precision is None else precision, _stream()), "ufr_project_gather_bwd")
 
 
 # ----------------------------------------------------------------------------- halves of aggregate / sample pool
@@ -439,15 +444,16 @@ def ray_transform_bwd(weights: PackedWeights, grads: GradBuffer, token0: torch.T
 
 
 def view_transform_bwd(weights: PackedWeights, grads: GradBuffer, x, rgb, dirs, d_token0_a, d_token0_b, d_radiance,
-                       precision: Optional[int] = None):
+                       precision: Optional[int] = None, d_pv: Optional[torch.Tensor] = None):
     P, NV = x.shape[0], x.shape[1]
-    d_pv = torch.empty(P, 40, dtype=torch.float32, device=x.device)
+    if d_pv is None:
+        d_pv = torch.empty(P, 40, dtype=torch.float32, device=x.device)
     ta = d_token0_a.contiguous()
     tb = None if d_token0_b is None else d_token0_b.contiguous()
     dr = d_radiance.contiguous()
     _lib.check(_lib.load().ufr_view_transform_bwd(
         C.byref(weights.raw), C.byref(grads.raw), _dev(x, "x_tokens"), _dev(rgb, "rgb"), _dev(dirs, "dir"),
-        _dev(ta, "d_token0_a"), _opt(tb, "d_token0_b"), _dev(dr, "d_radiance"), P, NV, d_pv.data_ptr(),
+        _dev(ta, "d_token0_a"), _opt(tb, "d_token0_b"), _dev(dr, "d_radiance"), P, NV, _dev(d_pv, "d_pv"),
         weights.mode() if precision is None else precision, _stream()), "ufr_view_transform_bwd")
     return d_pv
 

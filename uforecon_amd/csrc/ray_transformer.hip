@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
 #pragma unroll
       for (int t = 0; t < 11; ++t) hid[c][t] = splat4(0.f);
     }
-    gemm_f16<M_RT_MLP0, C, kRtWaves>(ws, cat, hid, wrap);
+    gemm_f16<M_RT_MLP0, C, kRtWaves, 6>(ws, cat, hid, wrap);   // cat = [x | m]: x was checked as the q projection's input
 #pragma unroll
     for (int c = 0; c < C; ++c) {
 #pragma unroll

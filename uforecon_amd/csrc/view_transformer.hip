@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
       for (int t = 0; t < 5; ++t) { cat[c][t] = x[c][t]; cat[c][5 + t] = m[c][t]; }
     zero_tiles(hid);
-    gemm_f16<M_VT_MLP0, C, kVtWaves>(ws, cat, hid, wrap);
+    gemm_f16<M_VT_MLP0, C, kVtWaves, 5>(ws, cat, hid, wrap);   // cat = [x | m]: x was checked as the v projection's input
     UFR_PHASE(7)  // MLP0
 #pragma unroll
     for (int c = 0; c < C; ++c)
@@ -299,9 +299,6 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
       for (int t = 0; t < 5; ++t) o[c][t] += x[c][t];
 
     // ---------------- outputs: token 0 -> ray transformer input; optional full dump
-    // (one element of a LayerNorm output row is non-finite iff anything on the token's path was: the range probe)
-#pragma unroll
-    for (int c = 0; c < C; ++c) probe_output(ws, valid[c], o[c][0][0]);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       if (valid[c] && tv == 0) {

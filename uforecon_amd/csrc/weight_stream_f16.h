@@ -43,14 +43,14 @@ __device__ __forceinline__ void split_tile(const f32x4& v, unsigned (&pl)[kPlane
 // across the whole layer chain (a per-lane running max; tried first, also inside split_pair) costs 26..100 spilled
 // registers.  The kernel looks at the mask once at its end and raises the device's sticky range status
 // (include/ufr.h: ufr_status_poll): an overflow is reported, never rendered.
-template <int C, int N>
-__device__ __forceinline__ void track_range(const f32x4 (&t)[C][N], unsigned long long& bad) {
+template <int FROM = 0, int C, int N>
+__device__ __forceinline__ void track_range(const f32x4 (&t)[C][N], unsigned long long& bad) {   // tiles [FROM, N)
 #if UFR_RANGE_MODE != 0
   float m = 0.f;
 #pragma unroll
   for (int c = 0; c < C; ++c)
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
+    for (int i = FROM; i < N; ++i) {
       m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(t[c][i][0]), __builtin_fabsf(t[c][i][1])));
       m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(t[c][i][2]), __builtin_fabsf(t[c][i][3])));
     }
@@ -368,14 +368,15 @@ __device__ __forceinline__ void descale_tiles(f32x4 (&t)[C][N]) {
 // out = (2^12 out + W_M x in) / 2^12 over all k-steps of M: in[c][0..NIN) are the producer's fp32 accumulator tiles;
 // callers that start from a bias pass it pre-multiplied by kAccScale (exact).
 // The fp16 split of k-step s+1 is interleaved with the MFMAs of k-step s (only step 0's is exposed).
-template <int M, int C, int NWAVES, int NIN, class WS>
+// TRACK_FROM: first input tile whose range is checked here (the tiles before it were checked as another GEMM's input)
+template <int M, int C, int NWAVES, int TRACK_FROM = 0, int NIN, class WS>
 __device__ __forceinline__ void gemm_f16(WS& ws, const f32x4 (&in)[C][NIN], f32x4 (&out)[C][mat_desc(M).n_out],
                                         bool wrap) {
   constexpr bool LOWP = WS::lowp;
   static_assert(NIN == mat_desc(M).n_in, "input tile count");
   constexpr int n_out = mat_desc(M).n_out, NU = 4 * C;
   BWords<C> cur;
-  track_range(in, ws.bad_in);
+  track_range<TRACK_FROM>(in, ws.bad_in);
   split_units<0, 0, NU>(in, cur);
   static_for<ksteps(M)>([&](auto si) __attribute__((always_inline)) {
     constexpr int s = decltype(si)::value;

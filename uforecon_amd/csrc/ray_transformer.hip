@@ -36,8 +36,9 @@ __device__ __forceinline__ void load_ray_tile(const float* __restrict__ token0, 
 }
 
 // LayerNorm over 88 features in nat88 layout (tile 5: registers 0,1 real)
-template <int VW, int VB, class WS>
+template <int VW, int VB, bool ACC = false, class WS>
 __device__ __forceinline__ void layer_norm88(f32x4 (&tt)[kRtC][6], const WS& ws, int g) {
+  constexpr float eps = ACC ? 1e-5f * kAccScale * kAccScale : 1e-5f;   // raw accumulators: view_transformer.hip layer_norm80
 #pragma unroll
   for (int c = 0; c < kRtC; ++c) {
     f32x4 (&t)[6] = tt[c];
@@ -56,7 +57,7 @@ __device__ __forceinline__ void layer_norm88(f32x4 (&tt)[kRtC][6], const WS& ws,
           q = fmaf(d, d, q);
         }
       }
-    const float rstd = 1.f / sqrtf(sum_groups(q) * (1.f / 88.f) + 1e-5f);
+    const float rstd = 1.f / sqrtf(sum_groups(q) * (1.f / 88.f) + eps);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const f32x4 gw = vec_frag<VW>(ws, i, g), gb = vec_frag<VB>(ws, i, g);  // zero in the padding slots
@@ -94,7 +95,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
   const int n_iter = (n_tiles + C - 1) / C;   // an odd tile count leaves the last iteration's second tile empty (masked)
   // values / v_length (linear_attention.py:41): a multiply by 1/SN is exact only for power-of-two sample counts;
   // any other total (64 + 32, 48, ...) takes the true division the reference performs
-  const float inv_len = 1.f / (float)SN, f_len = (float)SN;
+  const float inv_len = kAccDescale / (float)SN, f_len = (float)SN * kAccScale;   // applied to raw accumulators
   const bool pow2_len = (SN & (SN - 1)) == 0;
 
   // ---------------- sweep 1: KV_h[d][v] = sum_s K'_h[s][d] * V_h[s][v] / SN   (linear_attention.py:41-42)
@@ -134,8 +135,8 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
           gemm_f16_panel<M_RT_V, s, C, kRtWaves, true>(ws, b, vt, wrap);
         }
       });
-      descale_tiles(kt);
-      descale_tiles(vt);
+      probe_gemm(kt, ws);   // raw accumulators: the scale joins elu1 / the division by the sample count
+      probe_gemm(vt, ws);
     }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
       for (int h = 0; h < 8; ++h) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float kk = (j < 11 && live[c]) ? elu1(kt[c][h][r]) : 0.f;            // padded dims / empty tile contribute nothing
+          const float kk = (j < 11 && live[c]) ? elu1_acc(kt[c][h][r]) : 0.f;            // padded dims / empty tile contribute nothing
           const float vs = pow2_len ? vt[c][h][r] * inv_len : vt[c][h][r] / f_len;
           const float vv = j < 11 ? vs : (j == 11 ? 1.f : 0.f);                       // ones column -> sum of K'
 #ifdef UFR_ABL_NOKV   // ablation (timing only): no fp32 MFMAs for the per-head KV state
@@ -174,7 +175,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
       for (int h = 0; h < 8; ++h) q[c][h] = splat4(0.f);
     }
     track_external(x, ws);
-    gemm_f16<M_RT_Q, C, kRtWaves>(ws, x, q, wrap);  // q[h]: rows = head dims 4g+r, column j = token
+    gemm_f16<M_RT_Q, C, kRtWaves, false, true>(ws, x, q, wrap);  // q[h] (raw accumulators): rows = head dims 4g+r, column j = token
 #pragma unroll
     for (int c = 0; c < C; ++c) {
 #pragma unroll
@@ -182,7 +183,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
         f32x4 acc = splat4(0.f);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float qq = (4 * g + r < 11) ? elu1(q[c][h][r]) : 0.f;
+          const float qq = (4 * g + r < 11) ? elu1_acc(q[c][h][r]) : 0.f;
 #ifdef UFR_ABL_NOKV
           acc[r] += KV[h][r] * qq;
 #else
@@ -199,8 +200,8 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int t = 0; t < 6; ++t) m[c][t] = splat4(0.f);
-    gemm_f16<M_RT_MERGE, C, kRtWaves>(ws, msg, m, wrap);
-    layer_norm88<V_RT_N1W, V_RT_N1B>(m, ws, g);
+    gemm_f16<M_RT_MERGE, C, kRtWaves, false, true>(ws, msg, m, wrap);
+    layer_norm88<V_RT_N1W, V_RT_N1B, true>(m, ws, g);
 
     f32x4 cat[C][12], hid[C][11], o[C][6];
 #pragma unroll
@@ -210,7 +211,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
 #pragma unroll
       for (int t = 0; t < 11; ++t) hid[c][t] = splat4(0.f);
     }
-    gemm_f16<M_RT_MLP0, C, kRtWaves, 6>(ws, cat, hid, wrap);   // cat = [x | m]: x was checked as the q projection's input
+    gemm_f16<M_RT_MLP0, C, kRtWaves, false, true>(ws, cat, hid, wrap);   // hid: raw accumulators through the ReLU
 #pragma unroll
     for (int c = 0; c < C; ++c) {
 #pragma unroll
@@ -220,8 +221,8 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
 #pragma unroll
       for (int t = 0; t < 6; ++t) o[c][t] = splat4(0.f);
     }
-    gemm_f16<M_RT_MLP2, C, kRtWaves>(ws, hid, o, wrap);
-    layer_norm88<V_RT_N2W, V_RT_N2B>(o, ws, g);
+    gemm_f16<M_RT_MLP2, C, kRtWaves, true, true>(ws, hid, o, wrap);
+    layer_norm88<V_RT_N2W, V_RT_N2B, true>(o, ws, g);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
 #pragma unroll
@@ -244,24 +245,22 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
       d2[c][0] = vec_frag<V_DM_B2>(ws, 0, g) * kAccScale;
       d3[c][0] = vec_frag<V_DM_B4>(ws, 0, g) * kAccScale;
     }
-    gemm_f16<M_DM0, C, kRtWaves>(ws, o, d1, wrap);
+    gemm_f16<M_DM0, C, kRtWaves, false, true>(ws, o, d1, wrap);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) d1[c][t][r] = fmaxf(d1[c][t][r], 0.f);
-    gemm_f16<M_DM2, C, kRtWaves>(ws, d1, d2, wrap);
+    gemm_f16<M_DM2, C, kRtWaves, true, true>(ws, d1, d2, wrap);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) d2[c][0][r] = fmaxf(d2[c][0][r], 0.f);
-    gemm_f16<M_DM4, C, kRtWaves>(ws, d2, d3, wrap);
+    gemm_f16<M_DM4, C, kRtWaves, true, true>(ws, d2, d3, wrap);
 #pragma unroll
     for (int c = 0; c < C; ++c)
-      if (g == 0 && valid && live[c]) srdf[(size_t)ray * SN + tbase[c] + j] = d3[c][0][0];
-#pragma unroll
-    for (int c = 0; c < C; ++c) probe_output(ws, g == 0 && valid && live[c], d3[c][0][0]);
+      if (g == 0 && valid && live[c]) srdf[(size_t)ray * SN + tbase[c] + j] = d3[c][0][0] * kAccDescale;
     wstream_f16_finish<B_RT2, kRtWaves>(ws, wrap);
   }
   wstream_report_range(ws, status);

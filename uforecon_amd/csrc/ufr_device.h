@@ -107,6 +107,17 @@ __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x + 1.f : expf
 #else
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x + 1.f : __expf(x); }
 #endif
+// elu(s a) + 1 for a power-of-two s (a raw accumulator of the split-precision GEMMs): bit-identical to elu1(s * a), the
+// scale rides on the fma / on the exponent's log2(e) multiply
+template <int LOG2S>
+__device__ __forceinline__ float elu1_scaled(float a) {
+  constexpr float s = LOG2S >= 0 ? (float)(1u << (LOG2S >= 0 ? LOG2S : 0)) : 1.f / (float)(1u << (LOG2S < 0 ? -LOG2S : 0));
+#ifdef UFR_ACCURATE_EXP
+  return a > 0.f ? __builtin_fmaf(a, s, 1.f) : expf(a * s);
+#else
+  return a > 0.f ? __builtin_fmaf(a, s, 1.f) : __builtin_amdgcn_exp2f((0x1.715476p+0f * s) * a);
+#endif
+}
 
 // sum over the 4 lane groups (lanes l, l^16, l^32, l^48)
 __device__ __forceinline__ float sum_groups(float x) {

@@ -12,6 +12,7 @@
 // rows are permuted so lane group g holds heads 2g,2g+1 of its token, and the L-token attention is
 // lane-local with quad DPP exchanges (L = 4) or ds_bpermute (other L).  LayerNorm, attention, elu and
 // the softmax run on the VALU and overlap with the other resident wave's MFMAs.
+#include <cstdlib>
 #include "ufr_internal.h"
 #include "weight_stream_f16.h"
 
@@ -25,9 +26,12 @@ __device__ __forceinline__ void zero_tiles(f32x4 (&t)[C][N]) {
     for (int i = 0; i < N; ++i) t[c][i] = splat4(0.f);
 }
 
-// LayerNorm over the 80 features of each token: 5 tiles x 4 regs in each of the 4 lane groups.
-template <int C, int VW, int VB, class WS>
+// LayerNorm over the 80 features of each token: 5 tiles x 4 regs in each of the 4 lane groups.  ACC: t holds raw
+// accumulators (2^kAccLog2 times the values): the normalised value is scale-free once the epsilon carries the square of
+// the scale, and with a power-of-two scale every intermediate is the exact multiple -- bit-identical to descaling first.
+template <int C, int VW, int VB, bool ACC = false, class WS>
 __device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const WS& ws, int g) {
+  constexpr float eps = ACC ? 1e-5f * kAccScale * kAccScale : 1e-5f;
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     float s = 0.f;
@@ -42,7 +46,7 @@ __device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const WS& ws, int
         float d = t[c][i][r] - mean;
         q = fmaf(d, d, q);
       }
-    const float rstd = 1.f / sqrtf(sum_groups(q) * (1.f / 80.f) + 1e-5f);
+    const float rstd = 1.f / sqrtf(sum_groups(q) * (1.f / 80.f) + eps);
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const f32x4 gw = vec_frag<VW>(ws, i, g), gb = vec_frag<VB>(ws, i, g);
@@ -178,8 +182,8 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
           gemm_f16_panel<M_VT_K, s, C, kVtWaves>(ws, b, k, wrap);
         }
       });
-      descale_tiles(q);
-      descale_tiles(k);
+      probe_gemm(q, ws);   // q, k stay raw accumulators: elu1_acc
+      probe_gemm(k, ws);
     }
     UFR_PHASE(1)  // q,k GEMMs
     // ---------------- linear attention over the L tokens of each point (linear_attention.py:31-45), written as
@@ -194,8 +198,8 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
         for (int d = 0; d < 10; ++d) {
           const int s = 10 * hh + d;
-          Q[d] = elu1(q[c][s >> 2][s & 3]);
-          K[d] = elu1(k[c][s >> 2][s & 3]);
+          Q[d] = elu1_acc(q[c][s >> 2][s & 3]);
+          K[d] = elu1_acc(k[c][s >> 2][s & 3]);
         }
         float den = 0.f;
 #define UFR_ATT_STEP(S)                                                  \
@@ -218,7 +222,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     UFR_PHASE(2)  // scores
     f32x4 v[C][5];
     zero_tiles(v);
-    gemm_f16<M_VT_V, C, kVtWaves>(ws, x, v, wrap);
+    gemm_f16<M_VT_V, C, kVtWaves, false, true>(ws, x, v, wrap);   // raw accumulators: the descale joins the 1 / v_length
     UFR_PHASE(3)  // v GEMM
     f32x4 msg[C][5];
 #pragma unroll
@@ -230,7 +234,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
         for (int d = 0; d < 10; ++d) {
           const int s = 10 * hh + d;
           // values / v_length: exact as a multiply when L is a power of two (NV = 3, 7)
-          V[d] = (L & (L - 1)) == 0 ? v[c][s >> 2][s & 3] * (1.f / (float)L) : v[c][s >> 2][s & 3] / (float)L;
+          V[d] = (L & (L - 1)) == 0 ? v[c][s >> 2][s & 3] * (kAccDescale / (float)L) : v[c][s >> 2][s & 3] / ((float)L * kAccScale);
           acc[d] = 0.f;
         }
 #define UFR_ATT_STEP(S)                                                  \
@@ -256,9 +260,9 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     // ---------------- merge + LayerNorm1 (transformer.py:51-52)
     f32x4 m[C][5];
     zero_tiles(m);
-    gemm_f16<M_VT_MERGE, C, kVtWaves>(ws, msg, m, wrap);
+    gemm_f16<M_VT_MERGE, C, kVtWaves, false, true>(ws, msg, m, wrap);
     UFR_PHASE(5)  // merge GEMM
-    layer_norm80<C, V_VT_N1W, V_VT_N1B>(m, ws, g);
+    layer_norm80<C, V_VT_N1W, V_VT_N1B, true>(m, ws, g);
 
     UFR_PHASE(6)  // LN1
     // ---------------- MLP on [x | message] + LayerNorm2 + residual (transformer.py:55-58)
@@ -268,7 +272,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
       for (int t = 0; t < 5; ++t) { cat[c][t] = x[c][t]; cat[c][5 + t] = m[c][t]; }
     zero_tiles(hid);
-    gemm_f16<M_VT_MLP0, C, kVtWaves, 5>(ws, cat, hid, wrap);   // cat = [x | m]: x was checked as the v projection's input
+    gemm_f16<M_VT_MLP0, C, kVtWaves, false, true>(ws, cat, hid, wrap);   // hid: raw accumulators through the ReLU
     UFR_PHASE(7)  // MLP0
 #pragma unroll
     for (int c = 0; c < C; ++c)
@@ -277,7 +281,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
         for (int r = 0; r < 4; ++r) hid[c][t][r] = fmaxf(hid[c][t][r], 0.f);
     zero_tiles(o);
-    gemm_f16<M_VT_MLP2, C, kVtWaves>(ws, hid, o, wrap);
+    gemm_f16<M_VT_MLP2, C, kVtWaves, true, true>(ws, hid, o, wrap);
     // colour / mask / direction of this lane's (point, view): (issued here: hid is dead, so the 10 registers are free, and LayerNorm2 + the token stores cover the latency)
     f32x4 col[C];
     float dcomp[C];
@@ -292,7 +296,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     }
 
     UFR_PHASE(8)  // relu + MLP2
-    layer_norm80<C, V_VT_N2W, V_VT_N2B>(o, ws, g);
+    layer_norm80<C, V_VT_N2W, V_VT_N2B, true>(o, ws, g);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
@@ -325,24 +329,24 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
       h2[c][0] = vec_frag<V_RW_B2>(ws, 0, g) * kAccScale;
       lg[c][0] = vec_frag<V_RW_B4>(ws, 0, g) * kAccScale;
     }
-    gemm_f16<M_RW0, C, kVtWaves>(ws, rin, h1, wrap);
+    gemm_f16<M_RW0, C, kVtWaves, false, true>(ws, rin, h1, wrap);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) h1[c][0][r] = fmaxf(h1[c][0][r], 0.f);
-    gemm_f16<M_RW2, C, kVtWaves>(ws, h1, h2, wrap);
+    gemm_f16<M_RW2, C, kVtWaves, true, true>(ws, h1, h2, wrap);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) h2[c][0][r] = fmaxf(h2[c][0][r], 0.f);
-    gemm_f16<M_RW4, C, kVtWaves>(ws, h2, lg, wrap);
+    gemm_f16<M_RW4, C, kVtWaves, true, true>(ws, h2, lg, wrap);
 
     UFR_PHASE(10)  // radiance MLP
     // ---------------- masked softmax over the NV view tokens + colour blend (ray_transformer.py:315-319)
     // logit of token j sits in lane group 0, register 0; lanes of group 0 do the point-local reduction
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      float logit = lg[c][0][0];
+      float logit = lg[c][0][0] * kAccDescale;
       if (col[c][3] == 0.f) logit = -1e9f;
       if (tv == 0) logit = -INFINITY;  // the view token is not a colour source
       float mx = logit;
@@ -401,17 +405,18 @@ static hipError_t launch_vt(const float* packed, const float* x_tokens, const fl
   // 512 persistent workgroups the favoured half finishes ~25 % early and the rest runs alone, without a
   // partner wave to overlap its VALU phases with (measured per-wave lifetimes 1.27 .. 1.64 ms).  Launching a
   // few times more, shorter workgroups lets the dispatcher refill a CU as soon as one retires.
-  const int max_blocks = 256 * 2 * UFR_VT_OVERSUB;
+  constexpr int resident = 256 * (UFR_VT_MINW * 4 / kVtWaves);   // workgroups the chip holds at once
+  const int max_blocks = resident * UFR_VT_OVERSUB;
   if (blocks > max_blocks) {
     // every wave runs the same number of iterations (the chunk barriers are workgroup-wide): size the grid so that
     // the groups divide evenly over them instead of leaving most waves idle in a last, partial iteration
     // (18 432 groups over 8 192 waves would be 3 iterations with 25 % of the slots empty; 6 144 waves x 3 is exact)
-    // ... and so that the workgroups fill whole rounds of the 512 resident slots: cost ~ rounds x iterations
+    // ... and so that the workgroups fill whole rounds of the resident slots: cost ~ rounds x iterations
     const int base = (n_groups + max_blocks * kVtWaves - 1) / (max_blocks * kVtWaves);
     long best_cost = -1;
     for (int n_iter = base; n_iter <= 4 * base; ++n_iter) {
       const int b = (n_groups + kVtWaves * n_iter - 1) / (kVtWaves * n_iter);
-      const long cost = (long)((b + 511) / 512) * n_iter;
+      const long cost = (long)((b + resident - 1) / resident) * n_iter;
       if (best_cost < 0 || cost < best_cost) { best_cost = cost; blocks = b; }
     }
   }
@@ -425,6 +430,16 @@ static hipError_t launch_vt(const float* packed, const float* x_tokens, const fl
     if (attr != hipSuccess) return attr;
     attr_set[dev] = true;
   }
+#ifdef UFR_VT_OCC_PROBE   // development: UFR_VT_PAD_LDS=<bytes> inflates the LDS request to limit the workgroups per CU
+  static const int pad_lds = getenv("UFR_VT_PAD_LDS") ? atoi(getenv("UFR_VT_PAD_LDS")) : 0;
+  if (pad_lds > 0) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&view_transformer_kernel<L, C, LOWP>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, kF16LdsBytes + pad_lds);
+    hipLaunchKernelGGL((view_transformer_kernel<L, C, LOWP>), dim3(blocks), dim3(kVtBlock), kF16LdsBytes + pad_lds, s, packed,
+                       x_tokens, rgb, dir, P, token0, radiance, view_out, status);
+    return hipGetLastError();
+  }
+#endif
   hipLaunchKernelGGL((view_transformer_kernel<L, C, LOWP>), dim3(blocks), dim3(kVtBlock), kF16LdsBytes, s, packed, x_tokens,
                      rgb, dir, P, token0, radiance, view_out, status);
   return hipGetLastError();

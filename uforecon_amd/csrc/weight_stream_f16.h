@@ -18,7 +18,8 @@ constexpr int kF16LdsBytes = kF16RingBytes + kVecBytes;
 
 // split of a value pair into fp16 planes of 2^kXScaleLog2 x: hi = fp16(x) 2^k (exact scaling; one v_cvt_pk_f16_f32 and one
 // v_pk_mul_f16), lo = fp16(2^k x - hi) (the difference is exact in fp32; one v_fma_mix per value): 4 VALU instructions.
-// The planes hold |x| < kActLimit only (beyond it hi overflows to inf and the product to NaN): see track_range.
+// The planes hold |x| < kActLimit only: beyond it hi overflows to inf, lo to -inf, and EVERY output of the layer for that
+// token is NaN (the products w_hi hi and w_hi lo are infinities of opposite sign, or 0 x inf) -- probe_gemm.
 constexpr float kActLimit = 4094.f;
 #ifndef UFR_RANGE_MODE
 #define UFR_RANGE_MODE 1   // 0: no range tracking (timing ablation)
@@ -31,44 +32,20 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsign
   l = __builtin_bit_cast(unsigned, ll);
 }
 
-// the 4 fp32 values a lane holds of one accumulator tile: pl[p][q] = plane p of values (2q, 2q+1), packed
-__device__ __forceinline__ void split_tile(const f32x4& v, unsigned (&pl)[kPlanes][2]) {
-#pragma unroll
-  for (int q = 0; q < 2; ++q) split_pair(v[2 * q], v[2 * q + 1], pl[0][q], pl[1][q]);
+// The same planes straight from a layer's RAW accumulators (2^(kWScaleLog2 + kXScaleLog2) times the value): the exact
+// descale rides on the multiplier of the conversion, hi = fp16(2^-kWScaleLog2 acc), lo = fp16(2^-kWScaleLog2 acc - hi)
+// -- four v_fma_mix{lo,hi}_f16, no descale multiply and no plane scaling.  (hipcc builds the same arithmetic from C
+// source with 5..7 instructions: it converts the second value twice rather than read a register's upper half.)
+__device__ __forceinline__ void split_pair_acc(float a, float b, unsigned& h, unsigned& l) {
+  constexpr float m = kXScale * kAccDescale;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a), "s"(m));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(b), "s"(m));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a), "s"(m), "v"(h));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(b), "s"(m), "v"(h));
 }
 
-// Range tracking of the dense-layer inputs: in front of every GEMM the max |x| over the lane's input tiles (one
-// v_max3_f32 with abs modifiers per value pair) is compared with the limit and the wave's verdict is OR-ed into a
-// SCALAR sticky mask -- the transformer kernels sit exactly at their 256-register budget, and a vector register carried
-// across the whole layer chain (a per-lane running max; tried first, also inside split_pair) costs 26..100 spilled
-// registers.  The kernel looks at the mask once at its end and raises the device's sticky range status
-// (include/ufr.h: ufr_status_poll): an overflow is reported, never rendered.
-template <int FROM = 0, int C, int N>
-__device__ __forceinline__ void track_range(const f32x4 (&t)[C][N], unsigned long long& bad) {   // tiles [FROM, N)
-#if UFR_RANGE_MODE != 0
-  float m = 0.f;
-#pragma unroll
-  for (int c = 0; c < C; ++c)
-#pragma unroll
-    for (int i = FROM; i < N; ++i) {
-      m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(t[c][i][0]), __builtin_fabsf(t[c][i][1])));
-      m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(t[c][i][2]), __builtin_fabsf(t[c][i][3])));
-    }
-  bad |= __builtin_amdgcn_ballot_w64(!(m < kActLimit));
-#endif
-}
-
-// B operands of one k-step (accumulator tiles ta, tb of one column tile): one f16x8 per plane
+// B operands of one k-step (accumulator tiles 2s, 2s+1 of one column tile): one f16x8 per plane
 struct BStep { f16x8 p[kPlanes]; };
-__device__ __forceinline__ BStep make_bstep(const f32x4& ta, const f32x4& tb) {
-  unsigned pa[kPlanes][2], pb[kPlanes][2];
-  split_tile(ta, pa);
-  split_tile(tb, pb);
-  BStep s;
-#pragma unroll
-  for (int p = 0; p < kPlanes; ++p) s.p[p] = __builtin_bit_cast(f16x8, u32x4{pa[p][0], pa[p][1], pb[p][0], pb[p][1]});
-  return s;
-}
 
 // LOWP: the reduced-precision mode (ufr_set_matrix_precision): one fp16 plane per operand, one MFMA per product
 template <bool LOWP>
@@ -79,7 +56,7 @@ struct WStreamF16T {
   unsigned ring_lds;   // ... as an LDS byte address (scalar)
   const f32x4* vecs;   // LDS: vector fragments (fp32)
   int wave, lane;
-  unsigned long long bad_in, bad_out;   // sticky wave masks (scalar registers): track_range / the kernels' output probes
+  unsigned long long bad_in, bad_out;   // sticky wave masks (scalar registers): probe_gemm / track_external
   f16x8 pre[kF16Depth][kPlanes];  // plane fragments of the next kF16Depth stages, in flight from LDS (stage s in slot s % depth)
 };
 
@@ -202,11 +179,24 @@ __device__ __forceinline__ void wstream_f16_prime(const WS& ws) {
   static_for<kF16Slots - 1>([&](auto ci) __attribute__((always_inline)) { wstream_f16_fetch<S, NWAVES, decltype(ci)::value>(ws); });
 }
 
-// NaN can only ENTER these kernels through their inputs: internally every divisor is positive, every exponent non-positive,
-// and an overflow needs a dense-layer input beyond kActLimit, which track_range reports (it also sees an infinite input;
-// the max drops NaN operands).  A NaN that did enter does not reliably reach the outputs -- v_max_f32 (ReLU) returns the
-// other operand -- so the externally supplied tiles are tested for it where they are loaded: one unordered compare per
-// value pair into the scalar mask.
+// Range tracking of the dense-layer inputs.  An input beyond kActLimit (or infinite) makes every accumulator of its token
+// column non-finite (split_pair), so one accumulator element per column and GEMM is classified (one v_cmp_class per column
+// tile) right after the last k-step -- before a ReLU, whose v_max_f32 returns the other operand for a NaN -- and the
+// wave's verdict is OR-ed into a SCALAR sticky mask: the transformer kernels sit at their 256-register budget, a vector
+// register carried across the layer chain costs 26..100 spilled registers.  (Round 3 first scanned the inputs: one
+// v_max3 per value pair, 4 % of the view kernel's vector instructions.)  The kernel looks at the mask once at its end
+// and raises the device's sticky range status (include/ufr.h: ufr_status_poll): an overflow is reported, never rendered.
+// NaN from OUTSIDE is told apart by testing the externally supplied tiles where they are loaded (track_external): one
+// unordered compare per value pair.  Internally every divisor is positive and every exponent non-positive.
+template <int C, int N, class WS>
+__device__ __forceinline__ void probe_gemm(const f32x4 (&out)[C][N], WS& ws) {
+#if UFR_RANGE_MODE != 0
+  bool bad = false;
+#pragma unroll
+  for (int c = 0; c < C; ++c) bad |= __builtin_amdgcn_class(out[c][0][0], 0x207);   // sNaN | qNaN | -inf | +inf
+  ws.bad_in |= __builtin_amdgcn_ballot_w64(bad);
+#endif
+}
 template <int C, int N, class WS>
 __device__ __forceinline__ void track_external(const f32x4 (&t)[C][N], WS& ws) {
 #if UFR_RANGE_MODE != 0
@@ -220,14 +210,8 @@ __device__ __forceinline__ void track_external(const f32x4 (&t)[C][N], WS& ws) {
 #endif
 }
 
-// output probe: `v` is one output value per lane that depends on every activation of its token (a LayerNorm output
-// element, an srdf): x - x is 0 unless x is NaN / inf
-template <class WS>
-__device__ __forceinline__ void probe_output(WS& ws, bool live, float v) {
-  ws.bad_out |= __builtin_amdgcn_ballot_w64(live && !(v - v == 0.f));
-}
-// end of a kernel: raise the sticky range status (bit 0: a dense-layer input reached kActLimit; bit 1: a non-finite
-// output).  One atomic per offending wave.
+// end of a kernel: raise the sticky range status (bit 0: a dense layer produced non-finite accumulators, i.e. one of its
+// inputs reached kActLimit; bit 1: NaN among the kernel's inputs -- which also raises bit 0).  One atomic per offending wave.
 template <class WS>
 __device__ __forceinline__ void wstream_report_range(const WS& ws, int* __restrict__ status) {
   const int bits = (ws.bad_in ? 1 : 0) | (ws.bad_out ? 2 : 0);
@@ -333,14 +317,15 @@ __device__ __forceinline__ void gemm_f16_panel(WS& ws, const BStep (&b)[C], f32x
 template <int C>
 struct BWords { unsigned w[C][kPlanes][4]; };
 
-// units [U0, U1) of k-step S of the tiles in[c][0..NIN)
-template <int S, int U0, int U1, int C, int NIN>
+// units [U0, U1) of k-step S of the tiles in[c][0..NIN); ACC: the tiles are raw accumulators (split_pair_acc)
+template <int S, int U0, int U1, bool ACC = false, int C, int NIN>
 __device__ __forceinline__ void split_units(const f32x4 (&in)[C][NIN], BWords<C>& bw) {
   static_for<U1 - U0>([&](auto ui) __attribute__((always_inline)) {
     constexpr int u = U0 + decltype(ui)::value;
     constexpr int c = u / 4, half = (u >> 1) & 1, q = u & 1, tile = 2 * S + half;
     if constexpr (tile < NIN) {
-      split_pair(in[c][tile][2 * q], in[c][tile][2 * q + 1], bw.w[c][0][2 * half + q], bw.w[c][1][2 * half + q]);
+      if constexpr (ACC) split_pair_acc(in[c][tile][2 * q], in[c][tile][2 * q + 1], bw.w[c][0][2 * half + q], bw.w[c][1][2 * half + q]);
+      else split_pair(in[c][tile][2 * q], in[c][tile][2 * q + 1], bw.w[c][0][2 * half + q], bw.w[c][1][2 * half + q]);
     } else {
       bw.w[c][0][2 * half + q] = bw.w[c][1][2 * half + q] = 0u;
     }
@@ -356,6 +341,9 @@ __device__ __forceinline__ void bwords_to_bstep(const BWords<C>& bw, BStep (&b)[
       b[c].p[p] = __builtin_bit_cast(f16x8, u32x4{bw.w[c][p][0], bw.w[c][p][1], bw.w[c][p][2], bw.w[c][p][3]});
 }
 
+constexpr int kAccLog2 = kWScaleLog2 + kXScaleLog2;
+__device__ __forceinline__ float elu1_acc(float a) { return elu1_scaled<-kAccLog2>(a); }   // elu(value) + 1 of a raw accumulator
+
 // the planes carry 2^kWScaleLog2 (weights) and 2^kXScaleLog2 (activations): exact descale of finished accumulators
 template <int C, int N>
 __device__ __forceinline__ void descale_tiles(f32x4 (&t)[C][N]) {
@@ -365,19 +353,19 @@ __device__ __forceinline__ void descale_tiles(f32x4 (&t)[C][N]) {
     for (int i = 0; i < N; ++i) t[c][i] *= kAccDescale;
 }
 
-// out = (2^12 out + W_M x in) / 2^12 over all k-steps of M: in[c][0..NIN) are the producer's fp32 accumulator tiles;
-// callers that start from a bias pass it pre-multiplied by kAccScale (exact).
+// out = 2^12 out + W_M x in over all k-steps of M, probed for the range (probe_gemm) and then, unless RAW_OUT, descaled
+// exactly by 2^-12.  in[c][0..NIN) are the producer's fp32 tiles -- values, or with ACC_IN its raw accumulators (ReLU
+// commutes with the scale; LayerNorm takes them with a scaled epsilon, elu / the attention fold the factor into a
+// multiply they do anyway: no layer of the two chains pays for a descale pass).  Callers that start from a bias pass
+// it pre-multiplied by kAccScale (exact).
 // The fp16 split of k-step s+1 is interleaved with the MFMAs of k-step s (only step 0's is exposed).
-// TRACK_FROM: first input tile whose range is checked here (the tiles before it were checked as another GEMM's input)
-template <int M, int C, int NWAVES, int TRACK_FROM = 0, int NIN, class WS>
+template <int M, int C, int NWAVES, bool ACC_IN = false, bool RAW_OUT = false, int NIN, class WS>
 __device__ __forceinline__ void gemm_f16(WS& ws, const f32x4 (&in)[C][NIN], f32x4 (&out)[C][mat_desc(M).n_out],
                                         bool wrap) {
-  constexpr bool LOWP = WS::lowp;
   static_assert(NIN == mat_desc(M).n_in, "input tile count");
   constexpr int n_out = mat_desc(M).n_out, NU = 4 * C;
   BWords<C> cur;
-  track_range<TRACK_FROM>(in, ws.bad_in);
-  split_units<0, 0, NU>(in, cur);
+  split_units<0, 0, NU, ACC_IN>(in, cur);
   static_for<ksteps(M)>([&](auto si) __attribute__((always_inline)) {
     constexpr int s = decltype(si)::value;
     BStep b[C];
@@ -391,15 +379,16 @@ __device__ __forceinline__ void gemm_f16(WS& ws, const f32x4 (&in)[C][NIN], f32x
       BWords<C> nxt;
       gemm_f16_panel<M, s, C, NWAVES, false>(ws, b, out, wrap, [&](auto ti) __attribute__((always_inline)) {
         constexpr int to = decltype(ti)::value;
-        split_units<s + 1, to * NU / n_out, (to + 1) * NU / n_out>(in, nxt);
+        split_units<s + 1, to * NU / n_out, (to + 1) * NU / n_out, ACC_IN>(in, nxt);
       });
       cur = nxt;
     } else {
       gemm_f16_panel<M, s, C, NWAVES>(ws, b, out, wrap);
-      if constexpr (s + 1 < ksteps(M)) split_units<s + 1, 0, NU>(in, cur);
+      if constexpr (s + 1 < ksteps(M)) split_units<s + 1, 0, NU, ACC_IN>(in, cur);
     }
   });
-  descale_tiles(out);
+  probe_gemm(out, ws);
+  if constexpr (!RAW_OUT) descale_tiles(out);
 }
 
 }  // namespace ufr

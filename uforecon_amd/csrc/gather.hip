@@ -49,11 +49,86 @@ __device__ __forceinline__ Tap2 get_tap(const float* src) {
   return t;
 }
 
+// pre_sim_mlp: Linear(8,32)-ReLU-Linear(32,32)-ReLU-Linear(32,16) (ray_transformer.py:128-132, 268) on the mean pair
+// similarity of the block's 64 points, by ONE wave (round 3; a separate kernel before: it re-read the similarities and
+// wrote 16 columns into each of the NV token rows of a point -- 64-byte pieces of 320-byte rows, 4.5 ms per frame).
+// Points are MFMA columns (v_mfma_f32_16x16x4_f32, exact fp32 fma chains), four tiles of 16; the accumulator tile of a
+// layer is the B operand of the next (lane (g,j) holds neurons 4g+r of point j, so k-step (tile, r) of the next layer
+// contracts neurons 16*tile + 4g + r and the A operand is loaded with that index), biases are the accumulators'
+// initial values.  sim: LDS, point q's 8 similarities at sim + q * sim_stride; out: LDS [64][40], columns 24..39.
+__device__ __forceinline__ void presim_block(const PreSim& ps, const float* sim, int sim_stride, float* out, int lane) {
+  const int g = lane >> 4, j = lane & 15;
+  f32x4 h1[4][2], h2[4][2], o[4];
+  float x0[4][2];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float* sq = sim + (16 * u + j) * sim_stride;
+    x0[u][0] = sq[g];
+    x0[u][1] = sq[4 + g];
+  }
+  {
+    float a1[2][2];
+#pragma unroll
+    for (int to = 0; to < 2; ++to) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) a1[to][s] = ps.w0[(16 * to + j) * 8 + 4 * s + g];
+      const f32x4 b1 = ld4(ps.b0 + 16 * to + 4 * g);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) h1[u][to] = b1;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int to = 0; to < 2; ++to)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) h1[u][to] = mfma16(a1[to][s], x0[u][s], h1[u][to]);
+  }
+  {
+    float a2[2][2][4];
+#pragma unroll
+    for (int to = 0; to < 2; ++to) {
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a2[to][ti][r] = ps.w2[(16 * to + j) * 32 + 16 * ti + 4 * g + r];
+      const f32x4 b2 = ld4(ps.b2 + 16 * to + 4 * g);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) h2[u][to] = b2;
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int to = 0; to < 2; ++to)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) h2[u][to] = mfma16(a2[to][ti][r], fmaxf(h1[u][ti][r], 0.f), h2[u][to]);
+  }
+  {
+    float a3[2][4];
+#pragma unroll
+    for (int to = 0; to < 2; ++to)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a3[to][r] = ps.w4[j * 32 + 16 * to + 4 * g + r];
+    const f32x4 b3 = ld4(ps.b4 + 4 * g);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) o[u] = b3;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) o[u] = mfma16(a3[ti][r], fmaxf(h2[u][ti][r], 0.f), o[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) st4(out + (16 * u + j) * 40 + 24 + 4 * g, o[u]);
+}
+
 // LDS layout (floats): sim[64][NPAIR][8] | volp[64][NV-1][25] (views >= 1; wave 0 keeps its own in registers) |
 // { tapF[NV][64][8] | tapM[NV][64][8] } aliased with outv[64][40] (the footprints are dead once sim is complete).
 // The footprint of a block bounds the CU's occupancy -- of this kernel, and of the mix when it runs beside the
 // transformer kernels of another chunk (side streams).
-__global__ void __launch_bounds__(448) gather_kernel(FrameDev f, const float* __restrict__ ray_o,
+__global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, const float* __restrict__ ray_o,
                                                       int o_stride, const float* __restrict__ ray_d,
                                                       const float* __restrict__ zval, int P, int SN,
                                                       float* __restrict__ x_tokens, float* __restrict__ rgb_out,
@@ -69,7 +144,7 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, const float* __
   float* sh_vol = sh_sim + 64 * npair * 8;     // 64*(NV-1)*25
   float* sh_tapF = sh_vol + 64 * (NV - 1) * 25;  // NV*64*8: feature-map footprint (align_corners=False, zeros)
   float* sh_tapM = sh_tapF + NV * 64 * 8;      // NV*64*8: matching-map footprint (align_corners=True, border)
-  float* sh_out = sh_tapF;                     // 64*24 used (stride 40), written after the last footprint read
+  float* sh_out = sh_tapF;                     // [64][40]: frustum blend 24 | pre_sim_mlp 16, written after the last footprint read
 
   const int v = threadIdx.x >> 6, p = threadIdx.x & 63;
   // XCD-aware block -> point-group map: workgroups are dealt round-robin to the 8 XCDs (private L2 each), so
@@ -245,11 +320,16 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, const float* __
         if (vol24_in) ov[c] = vol24_in[(size_t)pc * 24 + c];
       }
     }
-    // hand the mean similarity to presim_kernel through token columns 56..63 of the point's first view row
-    if (active) {
-      float* scratch = x_tokens + (size_t)pidx * NV * UFR_TOKEN_DIM + 56;
-      st4(scratch, f32x4{sim[0], sim[1], sim[2], sim[3]});
-      st4(scratch + 4, f32x4{sim[4], sim[5], sim[6], sim[7]});
+    // pre_sim_mlp of the block's 64 points on this wave's matrix core (presim_tile below): the similarities change
+    // from "thread p holds point p" to the MFMA operand layout through the point's own (now dead) sh_sim slots
+    {
+      float* mine = sh_sim + p * npair * 8;
+      st4(mine, f32x4{sim[0], sim[1], sim[2], sim[3]});
+      st4(mine + 4, f32x4{sim[4], sim[5], sim[6], sim[7]});
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      presim_block(ps, sh_sim, npair * 8, sh_out, p);
     }
     if (active && sim8_out) {
 #pragma unroll
@@ -265,78 +345,7 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, const float* __
   if (active) {
     const float* ov = sh_out + p * 40;
 #pragma unroll
-    for (int c = 0; c < 24; c += 4) st4(xrow + 32 + c, ld4(ov + c));   // columns 56..71: presim_kernel
-  }
-}
-
-// pre_sim_mlp: Linear(8,32)-ReLU-Linear(32,32)-ReLU-Linear(32,16) (ray_transformer.py:128-132, 268) on the mean pair
-// similarity of every point, as its own kernel: points are MFMA columns (v_mfma_f32_16x16x4_f32, exact fp32 fma
-// chains), the accumulator tile of a layer is the B operand of the next (lane (g,j) holds neurons 4g+r of point j, so
-// k-step (tile, r) of the next layer contracts neurons 16*tile + 4g + r and the A operand is loaded with that index),
-// biases are the accumulators' initial values.  A wave keeps the 28 weight fragments of the three layers in registers
-// and walks kPresimTiles tiles of 16 points.  The 8 similarities arrive in token columns 56..63 of the point's first view row
-// (written there by gather_kernel) and the 16 outputs go to columns 56..71 of all NV rows.
-constexpr int kPresimTiles = 4;    // 16-point column tiles per wave
-constexpr int kPresimBatch = 4;    // ... of which this many are in flight together
-__global__ void __launch_bounds__(256) presim_kernel(PreSim ps, int P, int NV, float* __restrict__ x_tokens) {
-  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  float a1[2][2], a2[2][2][4], a3[2][4];
-  f32x4 b1[2], b2[2], b3;
-#pragma unroll
-  for (int to = 0; to < 2; ++to) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) a1[to][s] = ps.w0[(16 * to + j) * 8 + 4 * s + g];
-    b1[to] = ld4(ps.b0 + 16 * to + 4 * g);
-    b2[to] = ld4(ps.b2 + 16 * to + 4 * g);
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) a2[to][ti][r] = ps.w2[(16 * to + j) * 32 + 16 * ti + 4 * g + r];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) a3[to][r] = ps.w4[j * 32 + 16 * to + 4 * g + r];
-  }
-  b3 = ld4(ps.b4 + 4 * g);
-  const size_t row = (size_t)NV * UFR_TOKEN_DIM;
-  // kPresimBatch tiles are in flight together: with ~4 waves per SIMD and three dependent layers, one tile at a time
-  // leaves the loads and the 28-deep MFMA chain of a tile fully exposed (measured 40 us per 262 144 points)
-  for (int t0 = 0; t0 < kPresimTiles; t0 += kPresimBatch) {
-    int p[kPresimBatch];
-    float x0[kPresimBatch][2];
-#pragma unroll
-    for (int u = 0; u < kPresimBatch; ++u) {
-      p[u] = wave * (16 * kPresimTiles) + (t0 + u) * 16 + j;
-      const float* sim = x_tokens + (size_t)(p[u] < P ? p[u] : P - 1) * row + 56;
-      x0[u][0] = sim[g];
-      x0[u][1] = sim[4 + g];
-    }
-    f32x4 h1[kPresimBatch][2], h2[kPresimBatch][2], o[kPresimBatch];
-#pragma unroll
-    for (int u = 0; u < kPresimBatch; ++u) { h1[u][0] = b1[0]; h1[u][1] = b1[1]; h2[u][0] = b2[0]; h2[u][1] = b2[1]; o[u] = b3; }
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int to = 0; to < 2; ++to)
-#pragma unroll
-        for (int u = 0; u < kPresimBatch; ++u) h1[u][to] = mfma16(a1[to][s], x0[u][s], h1[u][to]);
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int to = 0; to < 2; ++to)
-#pragma unroll
-          for (int u = 0; u < kPresimBatch; ++u) h2[u][to] = mfma16(a2[to][ti][r], fmaxf(h1[u][ti][r], 0.f), h2[u][to]);
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int u = 0; u < kPresimBatch; ++u) o[u] = mfma16(a3[ti][r], fmaxf(h2[u][ti][r], 0.f), o[u]);
-#pragma unroll
-    for (int u = 0; u < kPresimBatch; ++u)
-      if (p[u] < P)
-        for (int v = 0; v < NV; ++v) st4(x_tokens + (size_t)p[u] * row + (size_t)v * UFR_TOKEN_DIM + 56 + 4 * g, o[u]);
+    for (int c = 0; c < 40; c += 4) st4(xrow + 32 + c, ld4(ov + c));   // frustum lookup 32..55, pre_sim_mlp output 56..71
   }
 }
 
@@ -348,9 +357,8 @@ hipError_t launch_gather(const FrameDev& f, const PreSim& ps, const float* ray_o
   const int npair = NV * (NV - 1) / 2;
   const size_t taps = 2 * (size_t)NV * 64 * 8, outv = 64 * 40;
   size_t lds = sizeof(float) * ((size_t)64 * npair * 8 + 64 * (NV - 1) * 25 + (taps > outv ? taps : outv));
-  hipLaunchKernelGGL(gather_kernel, dim3((P + 63) / 64), dim3(64 * NV), lds, s, f, ray_o, o_stride, ray_d, z, P, SN,
+  hipLaunchKernelGGL(gather_kernel, dim3((P + 63) / 64), dim3(64 * NV), lds, s, f, ps, ray_o, o_stride, ray_d, z, P, SN,
                      x_tokens, rgb, dir, sim8, vol24, xy, mask_z, vol24_in, sim8_in);
-  hipLaunchKernelGGL(presim_kernel, dim3((P + 64 * kPresimTiles - 1) / (64 * kPresimTiles)), dim3(256), 0, s, ps, P, NV, x_tokens);
   return hipGetLastError();
 }
 

@@ -10,6 +10,7 @@ Tolerance: 1e-3 of each gradient tensor's scale (fp32 path; the forward runs the
 recomputes it on the fp32 MFMA).
 """
 import argparse
+import os
 
 import pytest
 import torch
@@ -383,6 +384,23 @@ def test_training_step_16bit_mode(name, sixteen_bit_mode):
     assert min(vol_cos.values()) > 0.995 and max(vol_worst.values()) < 0.3, (vol_cos, vol_worst)
     # and it is a different arithmetic, not the fp32 path under another name
     assert max(worst.values()) > 10 * GRAD_TOL
+    # Anchor (tests/golden/make_bf16_anchor.py): the REFERENCE's own training step under torch.autocast(bfloat16) -- what
+    # its Lightning trainer runs with precision="bf16" -- measured against the same fp32 goldens with the same metrics.
+    # This mode must be no further from the reference's fp32 autograd than the reference's own 16-bit run, in every metric.
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c5_train_bf16_anchor.json")) as fh:
+        anchor = json.load(fh)[name]
+    ours = {"loss_rel": abs(float(loss) - float(g["loss"])) / abs(float(g["loss"])),
+            "forward_rows": max(grad_rel_err(r[i].detach(), g[n]) for n, i in dict(rgb=1, depth=2, rgb_2=8, depth_2=9).items()),
+            "one_minus_parameter_cosine": 1.0 - cos, "parameter_worst": max(worst.values()),
+            "one_minus_volume_cosine": 1.0 - min(vol_cos.values()), "volume_worst": max(vol_worst.values())}
+    theirs = {"loss_rel": anchor["loss_rel"], "forward_rows": max(anchor["forward_rows"].values()),
+              "one_minus_parameter_cosine": 1.0 - anchor["parameter_cosine"], "parameter_worst": anchor["parameter_worst"],
+              "one_minus_volume_cosine": 1.0 - anchor["volume_cosine_min"], "volume_worst": anchor["volume_worst"]}
+    print("16-bit mode vs the reference's bf16-autocast run (errors against the fp32 goldens):",
+          {k: (ours[k], theirs[k]) for k in ours})
+    worse = {k: (ours[k], theirs[k]) for k in ours if not ours[k] <= theirs[k]}
+    assert not worse, worse
 
 
 def test_precision_mode_is_restored_and_validated():

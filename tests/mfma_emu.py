@@ -13,16 +13,16 @@ LANE = np.arange(64)
 G, J = LANE >> 4, LANE & 15
 
 # mirrors of the enums in ufr_layout.h
-ROW_NAT, ROW_SLOT20, ROW_HEAD11, ROW_NAT88 = range(4)
-COL_NAT, COL_SLOT20, COL_NAT88, COL_HEAD11, COL_RW0, COL_CAT88 = range(6)
+ROW_NAT, ROW_SLOT20, ROW_HEAD11K, ROW_NAT88, ROW_QUAD11 = range(5)
+COL_NAT, COL_SLOT20, COL_NAT88, COL_QUAD11, COL_RW0, COL_CAT88 = range(6)
 
 # (name, param, k_raw, n_out, n_in, rm, cm, out_dim, in_dim) in blob order
 MATS = [
     ("VT_Q", 6, 80, 5, 5, ROW_SLOT20, COL_NAT, 80, 80), ("VT_K", 7, 80, 5, 5, ROW_SLOT20, COL_NAT, 80, 80),
     ("VT_V", 8, 80, 5, 5, ROW_SLOT20, COL_NAT, 80, 80), ("VT_MERGE", 9, 80, 5, 5, ROW_NAT, COL_SLOT20, 80, 80),
     ("VT_MLP0", 10, 160, 10, 10, ROW_NAT, COL_NAT, 160, 160), ("VT_MLP2", 11, 160, 5, 10, ROW_NAT, COL_NAT, 80, 160),
-    ("RT_Q", 16, 88, 8, 6, ROW_HEAD11, COL_NAT88, 88, 88), ("RT_K", 17, 88, 8, 6, ROW_HEAD11, COL_NAT88, 88, 88),
-    ("RT_V", 18, 88, 8, 6, ROW_HEAD11, COL_NAT88, 88, 88), ("RT_MERGE", 19, 88, 6, 8, ROW_NAT88, COL_HEAD11, 88, 88),
+    ("RT_Q", 16, 88, 6, 6, ROW_QUAD11, COL_NAT88, 88, 88), ("RT_K", 17, 88, 8, 6, ROW_HEAD11K, COL_NAT88, 88, 88),
+    ("RT_V", 18, 88, 8, 6, ROW_HEAD11K, COL_NAT88, 88, 88), ("RT_MERGE", 19, 88, 6, 6, ROW_NAT88, COL_QUAD11, 88, 88),
     ("RT_MLP0", 20, 176, 11, 12, ROW_NAT, COL_CAT88, 176, 176), ("RT_MLP2", 21, 176, 6, 11, ROW_NAT88, COL_NAT, 88, 176),
     ("DM0", 26, 88, 2, 6, ROW_NAT, COL_NAT88, 32, 88), ("DM2", 28, 32, 1, 2, ROW_NAT, COL_NAT, 16, 32),
     ("DM4", 30, 16, 1, 1, ROW_NAT, COL_NAT, 1, 16), ("RW0", 32, 83, 1, 6, ROW_NAT, COL_RW0, 16, 83),
@@ -34,10 +34,23 @@ def nat88(t, g, r):
     return 16 * t + 4 * g + r if t < 5 else (80 + 2 * g + r if r < 2 else -1)
 
 
+def head11_slot(i):
+    """head dim held by slot i = 4g + r of a 16-slot head tile (ufr_layout.h): 3g + r for r < 3, padding otherwise."""
+    g, r = i >> 2, i & 3
+    return 3 * g + r if (r < 3 and 3 * g + r < 11) else -1
+
+
+def quad11(t, g, r):
+    """feature of register r, lane group g of quad-packed tile t: quad 4t + r = (head, live register)."""
+    h, q = divmod(4 * t + r, 3)
+    return 11 * h + 3 * g + q if 3 * g + q < 11 else -1
+
+
 def row_map(rm, t, i, out_dim):
     g, r = i >> 2, i & 3
-    v = {ROW_NAT: 16 * t + i, ROW_SLOT20: 20 * g + 4 * t + r, ROW_HEAD11: 11 * t + i if i < 11 else -1,
-         ROW_NAT88: nat88(t, g, r)}[rm]
+    v = {ROW_NAT: 16 * t + i, ROW_SLOT20: 20 * g + 4 * t + r,
+         ROW_HEAD11K: 11 * t + head11_slot(i) if head11_slot(i) >= 0 else -1,
+         ROW_NAT88: nat88(t, g, r), ROW_QUAD11: quad11(t, g, r)}[rm]
     return v if 0 <= v < out_dim else -1
 
 
@@ -48,8 +61,8 @@ def col_map(cm, t, g, r, in_dim):
         v = 20 * g + 4 * t + r
     elif cm == COL_NAT88:
         v = nat88(t, g, r)
-    elif cm == COL_HEAD11:
-        v = 11 * t + 4 * g + r if 4 * g + r < 11 else -1
+    elif cm == COL_QUAD11:
+        v = quad11(t, g, r)
     elif cm == COL_RW0:
         v = 16 * t + 4 * g + r if t < 5 else (80 + g if (r == 0 and g < 3) else -1)
     else:
@@ -194,7 +207,7 @@ def f16_streams():
     rt1 = []
     for s in range(3):
         rt1 += [("RT_K", s), ("RT_V", s)]
-    rt2 = [("RT_Q", s) for s in range(3)] + [("RT_MERGE", s) for s in range(4)]
+    rt2 = [("RT_Q", s) for s in range(3)] + [("RT_MERGE", s) for s in range(3)]
     rt2 += [("RT_MLP0", s) for s in range(6)] + [("RT_MLP2", s) for s in range(6)]
     rt2 += [("DM0", s) for s in range(3)] + [("DM2", 0), ("DM4", 0)]
     return [vt, rt1, rt2]

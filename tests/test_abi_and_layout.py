@@ -135,42 +135,55 @@ def test_vector_fragments(plan, raw_and_blob):
 
 
 def test_ray_attention_dataflow_in_mfma_form(raw_and_blob):
-    """KV = K'^T V and message = (Q' KV) / (Q'.sum K') computed exactly as ray_transformer.hip does
-    (swapped projections, ones column, row-11 normaliser) equal the textbook linear attention."""
+    """KV = K'^T V, message = (Q' KV) / (Q'.sum K') and the merge projection computed exactly as ray_transformer.hip does
+    (swapped K / V projections with the 11 head dims in the slots 4g + r, r < 3; ones column in the padding slot 3;
+    quad-packed Q: three MFMAs per head; the message's live registers renamed into merge's 6 input tiles) equal the
+    textbook linear attention followed by the merge matrix."""
     raw, blob = raw_and_blob
     rng = np.random.default_rng(7)
     SN = 32
     X = rng.standard_normal((SN, 88))
-    Wq, Wk, Wv = (raw[p].reshape(88, 88) for p in (16, 17, 18))
+    Wq, Wk, Wv, Wm = (raw[p].reshape(88, 88) for p in (16, 17, 18, 19))
     elu1 = lambda a: np.where(a > 0, a + 1, np.exp(a))
-    iq, ik, iv = (next(i for i, m in enumerate(E.MATS) if m[0] == n) for n in ("RT_Q", "RT_K", "RT_V"))
+    iq, ik, iv, im = (E.NAME2IDX[n] for n in ("RT_Q", "RT_K", "RT_V", "RT_MERGE"))
+    slot_ok = np.array([E.head11_slot(int(j)) >= 0 for j in E.J])
     KV = np.zeros((8, 64, 4))
     for tile in range(SN // 16):
         xin = E.to_tiles(X[16 * tile: 16 * tile + 16], E.COL_NAT88, 6, 88)
         kt, vt = E.gemm(blob, ik, xin, swap=True), E.gemm(blob, iv, xin, swap=True)
         for h in range(8):
             for r in range(4):
-                kk = np.where(E.J < 11, elu1(kt[h][:, r]), 0.0)
-                vv = np.where(E.J < 11, vt[h][:, r] / SN, np.where(E.J == 11, 1.0, 0.0))
+                kk = np.where(slot_ok, elu1(kt[h][:, r]), 0.0)
+                vv = np.where(slot_ok, vt[h][:, r] / SN, np.where(E.J == 3, 1.0, 0.0))
                 KV[h] = E.mfma16(kk, vv, KV[h])
     Q = elu1(X @ Wq.T).reshape(SN, 8, 11)
     K = elu1(X @ Wk.T).reshape(SN, 8, 11)
     V = (X @ Wv.T).reshape(SN, 8, 11) / SN
     ref = np.einsum("lhd,hdv->lhv", Q, np.einsum("shd,shv->hdv", K, V)) / (np.einsum("lhd,hd->lh", Q, K.sum(0))[..., None] + 1e-6) * SN
+    ref_merged = ref.reshape(SN, 88) @ Wm.T
     for tile in range(SN // 16):
         q = E.gemm(blob, iq, E.to_tiles(X[16 * tile: 16 * tile + 16], E.COL_NAT88, 6, 88))
+        assert q.shape[0] == 6
+        msg_tiles = np.zeros((6, 64, 4))
         for h in range(8):
             acc = np.zeros((64, 4))
-            for r in range(4):
-                qq = np.where(4 * E.G + r < 11, elu1(q[h][:, r]), 0.0)
-                acc = E.mfma16(KV[h][:, r], qq, acc)
-            den = acc[32 + E.J, 3]
+            for qd in range(3):
+                quad = 3 * h + qd
+                qq = np.where(3 * E.G + qd < 11, elu1(q[quad >> 2][:, quad & 3]), 0.0)
+                acc = E.mfma16(KV[h][:, qd], qq, acc)
+            den = acc[E.J, 3]                              # slot 3: lane group 0, register 3
             msg = acc * (1.0 / (den + 1e-6) * SN)[:, None]
             for lane in range(64):
-                for r in range(4):
-                    v = 4 * (lane >> 4) + r
-                    if v < 11:
+                for r in range(3):
+                    v = E.head11_slot(4 * (lane >> 4) + r)
+                    if v >= 0:
                         assert abs(msg[lane, r] - ref[16 * tile + (lane & 15), h, v]) < 1e-9
+            for rr in range(3):
+                quad = 3 * h + rr
+                msg_tiles[quad >> 2][:, quad & 3] = msg[:, rr]
+        merged, pad = E.from_tiles(E.gemm(blob, im, msg_tiles), E.ROW_NAT88, 88)
+        assert pad == 0.0
+        np.testing.assert_allclose(merged, ref_merged[16 * tile: 16 * tile + 16], rtol=1e-9, atol=1e-9)
 
 
 # ------------------------------------------------------------------ fp16 plane region (split-precision MFMA path)

@@ -7,13 +7,15 @@
 // One wavefront per ray, two sweeps over its SN/16 column tiles, everything in registers; the dense
 // layers run split-precision on the fp16 matrix cores (ufr_layout_f16.h), the tiny per-head KV / message
 // products (K = 16 tokens / 16 head dims) stay on the fp32 MFMA:
-//  sweep 1: K^T, V^T tiles ([token][head dim], obtained by swapping the MFMA operands), then
-//           KV_h += K'_h^T V_h as 4 MFMAs per head; a ones column appended to V makes
-//           column 11 of KV_h the K' sum needed for the normaliser.
-//  sweep 2: Q tiles, message_h = KV_h^T-chained MFMA with Q'_h (row 11 of the result is Q'.sum K'),
-//           merge, LayerNorm, MLP, LayerNorm, residual, DensityMLP.
-// Each head occupies its own 16-row tile (11 real rows) so that head boundaries coincide with MFMA
-// tiles; the 88-wide activations use the "nat88" layout of ufr_layout.h.
+//  sweep 1: K^T, V^T tiles ([token][head slot], obtained by swapping the MFMA operands), then
+//           KV_h += K'_h^T V_h as 4 MFMAs per head (k = the tile's 16 tokens); a ones column in a padding
+//           slot of V makes that column of KV_h the K' sum needed for the normaliser.
+//  sweep 2: Q, message_h = KV_h^T-chained MFMA with Q'_h (k = head dims: THREE MFMAs per head, the padding
+//           row 3 of the result is Q'.sum K'), merge, LayerNorm, MLP, LayerNorm, residual, DensityMLP.
+// K and V give each head its own 16-column tile with the 11 dims in the slots 4g + r, r < 3 (ufr_layout.h:
+// head11_slot), which makes register 3 of every KV / message tile padding: Q is computed for the live registers
+// only (24 "quads" = 6 tiles instead of 8) and merge contracts 6 input tiles instead of 8 -- weight rows and columns
+// are permuted at pack time, the kernel only renames registers.  The 88-wide activations use the "nat88" layout.
 #include "ufr_internal.h"
 #include "weight_stream_f16.h"
 
@@ -104,6 +106,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
   for (int h = 0; h < 8; ++h) KV[h] = splat4(0.f);
   for (int it = 0; it < n_iter; ++it) {
     const bool wrap = it + 1 < n_iter;
+    const bool slot_ok = head11_slot(j) >= 0;   // column j of a head tile carries a head dim
     f32x4 x[C][6], kt[C][8], vt[C][8];
     bool live[C];
 #pragma unroll
@@ -144,9 +147,9 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
       for (int h = 0; h < 8; ++h) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float kk = (j < 11 && live[c]) ? elu1_acc(kt[c][h][r]) : 0.f;            // padded dims / empty tile contribute nothing
+          const float kk = (slot_ok && live[c]) ? elu1_acc(kt[c][h][r]) : 0.f;           // padding slots / empty tile contribute nothing
           const float vs = pow2_len ? vt[c][h][r] * inv_len : vt[c][h][r] / f_len;
-          const float vv = j < 11 ? vs : (j == 11 ? 1.f : 0.f);                       // ones column -> sum of K'
+          const float vv = slot_ok ? vs : (j == 3 ? 1.f : 0.f);                       // ones column (slot 3) -> sum of K'
 #ifdef UFR_ABL_NOKV   // ablation (timing only): no fp32 MFMAs for the per-head KV state
           KV[h][r] += kk * vv;
 #else
@@ -162,7 +165,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
   wstream_f16_prime<B_RT2, kRtWaves>(ws);
   for (int it = 0; it < n_iter; ++it) {
     const bool wrap = it + 1 < n_iter;
-    f32x4 x[C][6], q[C][8], msg[C][8];
+    f32x4 x[C][6], q[C][6], msg[C][6];   // q, msg: quad-packed (ROW_QUAD11 / COL_QUAD11)
     bool live[C];
     int tbase[C];
 #pragma unroll
@@ -172,28 +175,32 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
       tbase[c] = (live[c] ? tile : n_tiles - 1) * 16;
       load_ray_tile(token0, tok_row, order_pe, (size_t)ray * SN + tbase[c], tbase[c], g, j, x[c]);
 #pragma unroll
-      for (int h = 0; h < 8; ++h) q[c][h] = splat4(0.f);
+      for (int t = 0; t < 6; ++t) q[c][t] = splat4(0.f);
     }
     track_external(x, ws);
-    gemm_f16<M_RT_Q, C, kRtWaves, false, true>(ws, x, q, wrap);  // q[h] (raw accumulators): rows = head dims 4g+r, column j = token
+    gemm_f16<M_RT_Q, C, kRtWaves, false, true>(ws, x, q, wrap);  // raw accumulators, quad-packed rows, column j = token
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-#pragma unroll
-      for (int h = 0; h < 8; ++h) {
+      static_for<8>([&](auto hi) __attribute__((always_inline)) {
+        constexpr int h = decltype(hi)::value;
         f32x4 acc = splat4(0.f);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float qq = (4 * g + r < 11) ? elu1_acc(q[c][h][r]) : 0.f;
+        static_for<3>([&](auto qi) __attribute__((always_inline)) {
+          constexpr int qd = decltype(qi)::value, quad = 3 * h + qd;   // lane group g: head dim 3g + qd
+          const float qq = (3 * g + qd < 11) ? elu1_acc(q[c][quad >> 2][quad & 3]) : 0.f;
 #ifdef UFR_ABL_NOKV
-          acc[r] += KV[h][r] * qq;
+          acc[qd] += KV[h][qd] * qq;
 #else
-          acc = mfma16(KV[h][r], qq, acc);           // rows v = 4g+r: sum_d KV[d][v] Q'[d]; row 11 = Q'.sum(K')
+          acc = mfma16(KV[h][qd], qq, acc);          // rows = V slots: sum_d KV[d][v] Q'[d]; slot 3 = Q'.sum(K')
 #endif
-        }
-        const float den = __shfl(acc[3], 32 + j);    // row 11 lives in lane group 2, register 3
+        });
+        const float den = __shfl(acc[3], j);         // slot 3 lives in lane group 0, register 3
         const float Z = 1.f / (den + 1e-6f);         // linear_attention.py:43
-        msg[c][h] = acc * (Z * (float)SN);           // :44  (rows >= 11 meet zero merge columns)
-      }
+        const float zs = Z * (float)SN;              // :44
+        static_for<3>([&](auto ri) __attribute__((always_inline)) {
+          constexpr int rr = decltype(ri)::value, quad = 3 * h + rr;
+          msg[c][quad >> 2][quad & 3] = acc[rr] * zs;   // the live registers, in merge's input order
+        });
+      });
     }
     f32x4 m[C][6];
 #pragma unroll

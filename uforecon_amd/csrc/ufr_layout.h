@@ -17,8 +17,24 @@
 
 namespace ufr {
 
-enum RowMap : int { ROW_NAT = 0, ROW_SLOT20, ROW_HEAD11, ROW_NAT88 };
-enum ColMap : int { COL_NAT = 0, COL_SLOT20, COL_NAT88, COL_HEAD11, COL_RW0, COL_CAT88 };
+enum RowMap : int { ROW_NAT = 0, ROW_SLOT20, ROW_HEAD11K, ROW_NAT88, ROW_QUAD11 };
+enum ColMap : int { COL_NAT = 0, COL_SLOT20, COL_NAT88, COL_QUAD11, COL_RW0, COL_CAT88 };
+
+// The ray transformer's 8 heads of 11 dims (ray_transformer.hip).  In a 16-slot head tile, slot i = 4g + r holds head
+// dim 3g + r for r < 3 (slots with r = 3, and slot 14, are padding): the k-index of the per-head fp32 MFMAs is the lane
+// group g, so MFMA r of a head contracts dims {r, 3 + r, 6 + r, 9 + r} and THREE of them cover the 11 dims.
+//   ROW_HEAD11K  K and V (swapped operands: a head tile's column j = slot j): one 16-column tile per head.
+//   ROW_QUAD11   Q: only the 3 live registers of a head are computed -- "quad" 3h + q (the 4 rows one register index
+//                contributes to a tile, one per lane group) is register (3h + q) & 3 of tile (3h + q) >> 2: 24 quads =
+//                6 tiles instead of 8, addressed at compile time.
+//   COL_QUAD11   merge: its input registers are the message's live registers in the same quad order (6 input tiles = 3
+//                k-steps of the 16-bit MFMA instead of 4).
+__host__ __device__ constexpr int head11_slot(int i) {   // head dim of slot i of a head tile, or -1
+  return ((i & 3) < 3 && 3 * (i >> 2) + (i & 3) < 11) ? 3 * (i >> 2) + (i & 3) : -1;
+}
+__host__ __device__ constexpr int quad11(int t, int g, int r) {   // feature of register r, lane group g of quad-packed tile t
+  return 3 * g + (4 * t + r) % 3 < 11 ? 11 * ((4 * t + r) / 3) + 3 * g + (4 * t + r) % 3 : -1;
+}
 
 // nat88: 88 features in 6 tiles; tile 5 keeps its 8 real features in registers r<2 of every lane
 // group (feature 80+2g+r) so only 2 of its 4 MFMA steps are real.
@@ -30,8 +46,9 @@ __host__ __device__ constexpr int row_map(int rm, int t, int i, int out_dim) {
   switch (rm) {
     case ROW_NAT: v = 16 * t + i; break;
     case ROW_SLOT20: v = 20 * g + 4 * t + r; break;          // lane group g owns heads 2g,2g+1 (10 dims each)
-    case ROW_HEAD11: v = i < 11 ? 11 * t + i : -1; break;    // one 16-row tile per 11-dim head
+    case ROW_HEAD11K: v = head11_slot(i) >= 0 ? 11 * t + head11_slot(i) : -1; break;
     case ROW_NAT88: v = nat88(t, g, r); break;
+    case ROW_QUAD11: v = quad11(t, g, r); break;
   }
   return (v >= 0 && v < out_dim) ? v : -1;
 }
@@ -41,7 +58,7 @@ __host__ __device__ constexpr int col_map(int cm, int t, int g, int r, int in_di
     case COL_NAT: v = 16 * t + 4 * g + r; break;
     case COL_SLOT20: v = 20 * g + 4 * t + r; break;
     case COL_NAT88: v = nat88(t, g, r); break;
-    case COL_HEAD11: v = (4 * g + r < 11) ? 11 * t + 4 * g + r : -1; break;
+    case COL_QUAD11: v = quad11(t, g, r); break;
     case COL_RW0: v = t < 5 ? 16 * t + 4 * g + r : ((r == 0 && g < 3) ? 80 + g : -1); break;  // [token 80 | dir 3]
     case COL_CAT88: v = t < 6 ? nat88(t, g, r) : (nat88(t - 6, g, r) < 0 ? -1 : 88 + nat88(t - 6, g, r)); break;
   }
@@ -79,10 +96,10 @@ __host__ __device__ constexpr MatDesc mat_desc(int m) {
     case M_VT_MERGE: return {P_VT_MERGE, 80, 5, 5, ROW_NAT, COL_SLOT20, 80, 80};
     case M_VT_MLP0: return {P_VT_MLP0, 160, 10, 10, ROW_NAT, COL_NAT, 160, 160};
     case M_VT_MLP2: return {P_VT_MLP2, 160, 5, 10, ROW_NAT, COL_NAT, 80, 160};
-    case M_RT_Q: return {P_RT_Q, 88, 8, 6, ROW_HEAD11, COL_NAT88, 88, 88};
-    case M_RT_K: return {P_RT_K, 88, 8, 6, ROW_HEAD11, COL_NAT88, 88, 88};
-    case M_RT_V: return {P_RT_V, 88, 8, 6, ROW_HEAD11, COL_NAT88, 88, 88};
-    case M_RT_MERGE: return {P_RT_MERGE, 88, 6, 8, ROW_NAT88, COL_HEAD11, 88, 88};
+    case M_RT_Q: return {P_RT_Q, 88, 6, 6, ROW_QUAD11, COL_NAT88, 88, 88};
+    case M_RT_K: return {P_RT_K, 88, 8, 6, ROW_HEAD11K, COL_NAT88, 88, 88};
+    case M_RT_V: return {P_RT_V, 88, 8, 6, ROW_HEAD11K, COL_NAT88, 88, 88};
+    case M_RT_MERGE: return {P_RT_MERGE, 88, 6, 6, ROW_NAT88, COL_QUAD11, 88, 88};
     case M_RT_MLP0: return {P_RT_MLP0, 176, 11, 12, ROW_NAT, COL_CAT88, 176, 176};
     case M_RT_MLP2: return {P_RT_MLP2, 176, 6, 11, ROW_NAT88, COL_NAT, 88, 176};
     case M_DM0: return {P_DM_W0, 88, 2, 6, ROW_NAT, COL_NAT88, 32, 88};

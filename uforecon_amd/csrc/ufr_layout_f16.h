@@ -72,7 +72,7 @@ struct Panel { int mat, s; };
 __host__ __device__ constexpr int ksteps(int m) { return (mat_desc(m).n_in + 1) / 2; }
 
 __host__ __device__ constexpr int f16_n_panels(int S) {
-  return S == B_VT ? 3 * 3 + 3 + 5 + 5 + 3 + 1 + 1 : S == B_RT1 ? 6 : 3 + 4 + 6 + 6 + 3 + 1 + 1;
+  return S == B_VT ? 3 * 3 + 3 + 5 + 5 + 3 + 1 + 1 : S == B_RT1 ? 6 : 3 + 3 + 6 + 6 + 3 + 1 + 1;
 }
 // consumption order.  q and k (view) / k and v (ray) are interleaved per k-step: x is split once per step.
 __host__ __device__ constexpr Panel f16_panel(int S, int i) {
@@ -93,8 +93,8 @@ __host__ __device__ constexpr Panel f16_panel(int S, int i) {
   if (S == B_RT1) return {i % 2 == 0 ? M_RT_K : M_RT_V, i / 2};
   if (i < 3) return {M_RT_Q, i};
   i -= 3;
-  if (i < 4) return {M_RT_MERGE, i};
-  i -= 4;
+  if (i < 3) return {M_RT_MERGE, i};
+  i -= 3;
   if (i < 6) return {M_RT_MLP0, i};
   i -= 6;
   if (i < 6) return {M_RT_MLP2, i};

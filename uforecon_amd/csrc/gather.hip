@@ -131,7 +131,8 @@ __device__ __forceinline__ void presim_block(const PreSim& ps, const float* sim,
 __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, const float* __restrict__ ray_o,
                                                       int o_stride, const float* __restrict__ ray_d,
                                                       const float* __restrict__ zval, int P, int SN,
-                                                      float* __restrict__ x_tokens, float* __restrict__ rgb_out,
+                                                      float* __restrict__ x_tokens, float* __restrict__ x_point,
+                                                      float* __restrict__ rgb_out,
                                                       float* __restrict__ dir_out, float* __restrict__ sim8_out,
                                                       float* __restrict__ vol24_out, float* __restrict__ xy_out,
                                                       float* __restrict__ maskz_out,
@@ -182,7 +183,9 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
   }
   if (active && maskz_out) maskz_out[(size_t)v * P + pidx] = mask_z;
 
-  float* xrow = x_tokens + ((size_t)pc * NV + v) * UFR_TOKEN_DIM;
+  // token row of (point, view): public layout 80 columns, compact layout [feat 32 | PE 8] (ufr_internal.h)
+  const int row_cols = x_point ? kViewCols : UFR_TOKEN_DIM, pe_col = x_point ? 32 : 72;
+  float* xrow = x_tokens + ((size_t)pc * NV + v) * row_cols;
 
   // ---- 2-D gathers with align_corners=False, zeros (grid_sample.py:5-19; ray_transformer.py:222-237)
   {
@@ -210,8 +213,8 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
       pe[2 * k + 1] = sinf(fmaf(delta, fr, 1.57079637050628662f));  // phase pi/2 -> cosine slot
     }
     if (active) {
-      st4(xrow + 72, f32x4{pe[0], pe[1], pe[2], pe[3]});
-      st4(xrow + 76, f32x4{pe[4], pe[5], pe[6], pe[7]});
+      st4(xrow + pe_col, f32x4{pe[0], pe[1], pe[2], pe[3]});
+      st4(xrow + pe_col + 4, f32x4{pe[4], pe[5], pe[6], pe[7]});
     }
     // relative direction (ray_transformer.py:185-191)
     float ax = px - f.ref_pos[0], ay = py - f.ref_pos[1], az = pz - f.ref_pos[2];
@@ -267,7 +270,7 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
     const int ipidx = blk * 64 + ip;
     if (ipidx < P) {
       const Tap2 t = get_tap(sh_tapF + (iv * 64 + ip) * 8);
-      st4(x_tokens + ((size_t)ipidx * NV + iv) * UFR_TOKEN_DIM + 4 * c8,
+      st4(x_tokens + ((size_t)ipidx * NV + iv) * row_cols + 4 * c8,
           lerp_tap4(f.feat + (size_t)iv * f.h * f.w * 32, 32, t, 4 * c8));
     }
   }
@@ -342,15 +345,17 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
   __syncthreads();
 
   // ---- token assembly: [feat 32 | vol 24 | sim 16 | depth PE 8] (ray_transformer.py:258-281)
-  if (active) {
+  // (public layout: the per-point columns go into every view's row; compact: once, by view 0's thread)
+  if (active && (!x_point || v == 0)) {
     const float* ov = sh_out + p * 40;
+    float* dst = x_point ? x_point + (size_t)pidx * kPointCols : xrow + 32;
 #pragma unroll
-    for (int c = 0; c < 40; c += 4) st4(xrow + 32 + c, ld4(ov + c));   // frustum lookup 32..55, pre_sim_mlp output 56..71
+    for (int c = 0; c < 40; c += 4) st4(dst + c, ld4(ov + c));   // frustum lookup 32..55, pre_sim_mlp output 56..71
   }
 }
 
 hipError_t launch_gather(const FrameDev& f, const PreSim& ps, const float* ray_o, int o_stride, const float* ray_d,
-                         const float* z, int RN, int SN, float* x_tokens, float* rgb, float* dir, float* sim8,
+                         const float* z, int RN, int SN, float* x_tokens, float* x_point, float* rgb, float* dir, float* sim8,
                          float* vol24, float* xy, float* mask_z, const float* vol24_in, const float* sim8_in,
                          hipStream_t s) {
   const int P = RN * SN, NV = f.NV;
@@ -358,7 +363,7 @@ hipError_t launch_gather(const FrameDev& f, const PreSim& ps, const float* ray_o
   const size_t taps = 2 * (size_t)NV * 64 * 8, outv = 64 * 40;
   size_t lds = sizeof(float) * ((size_t)64 * npair * 8 + 64 * (NV - 1) * 25 + (taps > outv ? taps : outv));
   hipLaunchKernelGGL(gather_kernel, dim3((P + 63) / 64), dim3(64 * NV), lds, s, f, ps, ray_o, o_stride, ray_d, z, P, SN,
-                     x_tokens, rgb, dir, sim8, vol24, xy, mask_z, vol24_in, sim8_in);
+                     x_tokens, x_point, rgb, dir, sim8, vol24, xy, mask_z, vol24_in, sim8_in);
   return hipGetLastError();
 }
 

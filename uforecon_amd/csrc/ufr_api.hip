@@ -363,7 +363,7 @@ int ufr_project_gather(const ufr_frame* frame, const ufr_raw_weights* raw, const
   UFR_REQUIRE(f->match || sim8_in, "ufr_project_gather: the frame has no matching features: sim8_in is required");
   UFR_REQUIRE(f->vol[0] || vol24_in, "ufr_project_gather: the frame has no volumes: vol24_in is required");
   ProfScope prof("gather", static_cast<hipStream_t>(stream));
-  UFR_HIP(launch_gather(*f, presim_of(raw), ray_o, ray_o_stride, ray_d, z, RN, SN, x_tokens, rgb, dir, sim8, vol24, xy,
+  UFR_HIP(launch_gather(*f, presim_of(raw), ray_o, ray_o_stride, ray_d, z, RN, SN, x_tokens, nullptr, rgb, dir, sim8, vol24, xy,
                         mask_z, vol24_in, sim8_in, static_cast<hipStream_t>(stream)));
   return UFR_OK;
 }
@@ -376,12 +376,12 @@ size_t ufr_aggregate_workspace_bytes(int32_t RN, int32_t SN, int32_t NV) {
   return c.off;
 }
 
-static int aggregate_impl(const void* packed, const float* x_tokens, const float* rgb, const float* dir, int RN, int SN,
+static int aggregate_impl(const void* packed, const float* x_tokens, const float* x_point, const float* rgb, const float* dir, int RN, int SN,
                           int NV, float* radiance, float* srdf, float* token0, float* order_pe, bool pe_ready,
                           float* view_out, float* ray_out, bool lowp, int* status, hipStream_t s) {
   {
     ProfScope ps("view_transformer", s);
-    UFR_HIP(launch_view_transformer(static_cast<const float*>(packed), x_tokens, rgb, dir, RN * SN, NV, token0, radiance,
+    UFR_HIP(launch_view_transformer(static_cast<const float*>(packed), x_tokens, x_point, rgb, dir, RN * SN, NV, token0, radiance,
                                     view_out, lowp, status, s));
   }
   if (!pe_ready) UFR_HIP(launch_order_pe(order_pe, SN, s));
@@ -408,7 +408,7 @@ int ufr_aggregate(const void* packed_weights, const float* x_tokens, const float
   Carver c(workspace);
   float* token0 = c.f32((size_t)RN * SN * UFR_TOKEN_DIM);
   float* order_pe = c.f32((size_t)SN * 8);
-  rc = aggregate_impl(packed_weights, x_tokens, rgb, dir, RN, SN, NV, radiance, srdf, token0, order_pe, false, view_out,
+  rc = aggregate_impl(packed_weights, x_tokens, nullptr, rgb, dir, RN, SN, NV, radiance, srdf, token0, order_pe, false, view_out,
                       ray_out, lowp, sl->dev, s);
   return rc != UFR_OK ? rc : status_leave(sl, s);
 }
@@ -537,7 +537,7 @@ int ufr_view_transform(const void* packed_weights, const float* x_tokens, const 
   if (rc != UFR_OK) return rc;
   {
     ProfScope p("view_transformer", s);
-    UFR_HIP(launch_view_transformer(static_cast<const float*>(packed_weights), x_tokens, rgb, dir, P, NV, token0, radiance,
+    UFR_HIP(launch_view_transformer(static_cast<const float*>(packed_weights), x_tokens, nullptr, rgb, dir, P, NV, token0, radiance,
                                     nullptr, lowp, sl->dev, s));
   }
   return status_leave(sl, s);
@@ -604,7 +604,7 @@ int32_t ufr_default_chunk_rays(void) { return 4096; }
 
 namespace {
 struct RenderWs {
-  float *ray_o, *rd, *near, *far, *camz, *z1, *w1, *srdf1, *depth1, *rgb1, *z2, *srdf2, *rad, *x, *rgbm, *dir, *token0,
+  float *ray_o, *rd, *near, *far, *camz, *z1, *w1, *srdf1, *depth1, *rgb1, *z2, *srdf2, *rad, *x, *xp, *rgbm, *dir, *token0,
       *pe1, *pe2, *z_new;
   int* row;  // merged slot -> row of the [coarse | new] evaluation pool (token0, rad)
   size_t bytes;
@@ -628,7 +628,8 @@ RenderWs carve_render(void* ws, int R, int SN, int PN, int NV) {
   r.z2 = c.f32((size_t)R * S2);
   r.srdf2 = c.f32((size_t)R * S2);
   r.rad = c.f32((size_t)R * Smax * 3);
-  r.x = c.f32((size_t)R * Sg * NV * UFR_TOKEN_DIM);
+  r.x = c.f32((size_t)R * Sg * NV * kViewCols);   // compact token layout (ufr_internal.h): per-view columns ...
+  r.xp = c.f32((size_t)R * Sg * kPointCols);      // ... and the per-point ones, once
   r.rgbm = c.f32((size_t)R * Sg * NV * 4);
   r.dir = c.f32((size_t)R * Sg * NV * 4);
   r.z_new = c.f32((size_t)R * (PN > 0 ? PN : 1));
@@ -693,9 +694,9 @@ int render_chunk(const ufr_render_args* a, const FrameDev* f, const RenderWs& w,
   // ---- coarse pass (model.py:445)
   {
     ProfScope p("gather", s);
-    UFR_HIP(launch_gather(*f, ps, w.ray_o, 0, w.rd, w.z1, R, SN, w.x, w.rgbm, w.dir, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s));
+    UFR_HIP(launch_gather(*f, ps, w.ray_o, 0, w.rd, w.z1, R, SN, w.x, w.xp, w.rgbm, w.dir, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s));
   }
-  int rc = aggregate_impl(a->packed_weights, w.x, w.rgbm, w.dir, R, SN, NV, w.rad, w.srdf1, w.token0, w.pe1, true,
+  int rc = aggregate_impl(a->packed_weights, w.x, w.xp, w.rgbm, w.dir, R, SN, NV, w.rad, w.srdf1, w.token0, w.pe1, true,
                           nullptr, nullptr, lowp, status, s);
   if (rc != UFR_OK) return rc;
   const bool last = a->coarse_only != 0;
@@ -721,11 +722,11 @@ int render_chunk(const ufr_render_args* a, const FrameDev* f, const RenderWs& w,
   }
   {
     ProfScope p("gather", s);
-    UFR_HIP(launch_gather(*f, ps, w.ray_o, 0, w.rd, w.z_new, R, PN, w.x, w.rgbm, w.dir, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s));
+    UFR_HIP(launch_gather(*f, ps, w.ray_o, 0, w.rd, w.z_new, R, PN, w.x, w.xp, w.rgbm, w.dir, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s));
   }
   {
     ProfScope p("view_transformer", s);
-    UFR_HIP(launch_view_transformer(static_cast<const float*>(a->packed_weights), w.x, w.rgbm, w.dir, R * PN, NV,
+    UFR_HIP(launch_view_transformer(static_cast<const float*>(a->packed_weights), w.x, w.xp, w.rgbm, w.dir, R * PN, NV,
                                     w.token0 + (size_t)R * SN * UFR_TOKEN_DIM, w.rad + (size_t)R * SN * 3, nullptr, lowp,
                                     status, s));
   }

@@ -45,14 +45,20 @@ hipError_t launch_importance_merge(const float* weight, const float* z, const fl
 hipError_t launch_order_pe(float* table, int SN, hipStream_t s);
 hipError_t launch_points(const float* ray_o, int o_stride, const float* ray_d, const float* z, float* pts, int RN,
                          int SN, hipStream_t s);
+// Token rows.  Public layout (x_point == nullptr): x_tokens (P, NV, 80) = [feat 32 | frustum lookup 24 | pre_sim_mlp 16 |
+// depth PE 8] per (point, view).  Columns 32..71 are the same for all views of a point, and writing them NV times is a
+// sixth of the gather kernel's time (ablation, round 3): the whole-path entry point keeps them once per point --
+// compact layout (x_point != nullptr): x_tokens (P, NV, kViewCols) = [feat 32 | depth PE 8], x_point (P, kPointCols) =
+// [frustum lookup 24 | pre_sim_mlp 16].
+constexpr int kViewCols = 40, kPointCols = 40;
 hipError_t launch_gather(const FrameDev& f, const PreSim& ps, const float* ray_o, int o_stride, const float* ray_d,
-                         const float* z, int RN, int SN, float* x_tokens, float* rgb, float* dir, float* sim8,
+                         const float* z, int RN, int SN, float* x_tokens, float* x_point, float* rgb, float* dir, float* sim8,
                          float* vol24, float* xy, float* mask_z, const float* vol24_in, const float* sim8_in,
                          hipStream_t s);
 // lowp: matrix precision of the call (include/ufr.h): false = fp32-grade split precision, true = one 16-bit plane per
 // operand ("bf16" training mode of BASELINE configs[4]).  status: the device's sticky range word (ufr_status_poll).
-hipError_t launch_view_transformer(const float* packed, const float* x_tokens, const float* rgb, const float* dir,
-                                   int P, int NV, float* token0, float* radiance, float* view_out, bool lowp, int* status,
+hipError_t launch_view_transformer(const float* packed, const float* x_tokens, const float* x_point, const float* rgb,
+                                   const float* dir, int P, int NV, float* token0, float* radiance, float* view_out, bool lowp, int* status,
                                    hipStream_t s);
 // tok_row / rad_row (nullable): row of token0 / radiance holding sample (ray, s) -- the fine pass of the whole-path
 // renderer keeps coarse and new evaluations in one pool instead of re-evaluating the coarse points

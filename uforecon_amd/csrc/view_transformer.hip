@@ -18,6 +18,14 @@
 
 namespace ufr {
 
+// base + 32-bit element offset, the byte offset computed in 32 bits: the access becomes "scalar base + 32-bit lane
+// offset" (global_load ... v_off, s[base]) with no 64-bit per-lane address to keep alive (the launcher bounds the sizes)
+template <class T>
+__device__ __forceinline__ T* at32(T* base, unsigned elem) {
+  typedef typename std::conditional<std::is_const<T>::value, const char, char>::type B;
+  return reinterpret_cast<T*>(reinterpret_cast<B*>(base) + (elem * (unsigned)sizeof(T)));
+}
+
 template <int C, int N>
 __device__ __forceinline__ void zero_tiles(f32x4 (&t)[C][N]) {
 #pragma unroll
@@ -83,6 +91,7 @@ constexpr int kVtWaves = kVtBlock / 64;
 template <int L, int C, bool LOWP>
 __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel(const float* __restrict__ packed,
                                                                              const float* __restrict__ x_tokens,
+                                                                             const float* __restrict__ x_point,
                                                                              const float* __restrict__ rgbm,
                                                                              const float* __restrict__ dirs, int P,
                                                                              float* __restrict__ token0,
@@ -147,11 +156,20 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
       pidx[c] = grp * PPW + c * PPT + pt_in_tile;
       valid[c] = col_ok && grp < n_groups && pidx[c] < P;
       const int pp = valid[c] ? pidx[c] : 0;
-      const float* row = x_tokens + ((size_t)pp * NV + (tv > 0 ? tv - 1 : 0)) * UFR_TOKEN_DIM;
+      // token columns 0..31 and 72..79 are per (point, view), 32..71 per point: one 80-column row in the public layout,
+      // a 40-column view row plus a 40-column point row in the compact one (ufr_internal.h)
+      // (32-bit element offsets from the scalar bases -- the launcher bounds P: 64-bit per-lane addresses that the
+      // optimiser hoists out of the loop cost this kernel spills it cannot afford)
+      const unsigned vrow = ((unsigned)pp * NV + (tv > 0 ? tv - 1 : 0)) * (x_point ? kViewCols : UFR_TOKEN_DIM);
+      const unsigned prow_e = x_point ? (unsigned)pp * kPointCols : vrow + 32;
+      const float* pbase = x_point ? x_point : x_tokens;
+      const float* row = at32(x_tokens, vrow + 4 * g);
+      const float* prow = at32(pbase, prow_e + 4 * g);
+      const float* last = g < 2 ? prow + 32 : row + (x_point ? 32 : 72) - 8;
 #pragma unroll
       for (int t = 0; t < 5; ++t) {
         f32x4 tok = vec_frag<V_VIEW_TOKEN>(ws, t, g);
-        f32x4 val = ld4(row + 16 * t + 4 * g);
+        f32x4 val = ld4(t < 2 ? row + 16 * t : t < 4 ? prow + 16 * (t - 2) : last);
         x[c][t] = tv == 0 ? tok : val;                     // ray_transformer.py:284-286
         if (!valid[c]) x[c][t] = splat4(0.f);
       }
@@ -290,8 +308,8 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
       col[c] = splat4(0.f);
       dcomp[c] = 0.f;
       if (valid[c] && tv > 0) {
-        col[c] = ld4(rgbm + ((size_t)pidx[c] * NV + (tv - 1)) * 4);           // r,g,b,mask
-        dcomp[c] = dirs[((size_t)pidx[c] * NV + (tv - 1)) * 4 + g];           // lane group g <- dir[g], 0 for g=3
+        col[c] = ld4(at32(rgbm, ((unsigned)pidx[c] * NV + (tv - 1)) * 4u));           // r,g,b,mask
+        dcomp[c] = *at32(dirs, ((unsigned)pidx[c] * NV + (tv - 1)) * 4u + g);         // lane group g <- dir[g], 0 for g=3
       }
     }
 
@@ -307,12 +325,12 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     for (int c = 0; c < C; ++c) {
       if (valid[c] && tv == 0) {
 #pragma unroll
-        for (int t = 0; t < 5; ++t) st4(token0 + (size_t)pidx[c] * UFR_TOKEN_DIM + 16 * t + 4 * g, o[c][t]);
+        for (int t = 0; t < 5; ++t) st4(at32(token0, (unsigned)pidx[c] * UFR_TOKEN_DIM + 4 * g) + 16 * t, o[c][t]);
       }
       if (valid[c] && view_out) {
 #pragma unroll
         for (int t = 0; t < 5; ++t)
-          st4(view_out + ((size_t)pidx[c] * L + tv) * UFR_TOKEN_DIM + 16 * t + 4 * g, o[c][t]);
+          st4(at32(view_out, ((unsigned)pidx[c] * L + tv) * UFR_TOKEN_DIM + 4 * g) + 16 * t, o[c][t]);
       }
     }
 
@@ -365,7 +383,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
       UFR_SUM_STEP(1) UFR_SUM_STEP(2) UFR_SUM_STEP(3) UFR_SUM_STEP(4) UFR_SUM_STEP(5) UFR_SUM_STEP(6) UFR_SUM_STEP(7)
 #undef UFR_SUM_STEP
       if (valid[c] && tv == 0 && g == 0) {
-        float* dst = radiance + (size_t)pidx[c] * 3;
+        float* dst = at32(radiance, (unsigned)pidx[c] * 3u);
         dst[0] = cr / den;
         dst[1] = cg / den;
         dst[2] = cb / den;
@@ -395,7 +413,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 }
 
 template <int L, bool LOWP>
-static hipError_t launch_vt(const float* packed, const float* x_tokens, const float* rgb, const float* dir, int P,
+static hipError_t launch_vt(const float* packed, const float* x_tokens, const float* x_point, const float* rgb, const float* dir, int P,
                             float* token0, float* radiance, float* view_out, int* status, hipStream_t s) {
   constexpr int C = UFR_VT_C;
   constexpr int PPW = (16 / L) * C;
@@ -436,23 +454,26 @@ static hipError_t launch_vt(const float* packed, const float* x_tokens, const fl
     hipFuncSetAttribute(reinterpret_cast<const void*>(&view_transformer_kernel<L, C, LOWP>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, kF16LdsBytes + pad_lds);
     hipLaunchKernelGGL((view_transformer_kernel<L, C, LOWP>), dim3(blocks), dim3(kVtBlock), kF16LdsBytes + pad_lds, s, packed,
-                       x_tokens, rgb, dir, P, token0, radiance, view_out, status);
+                       x_tokens, x_point, rgb, dir, P, token0, radiance, view_out, status);
     return hipGetLastError();
   }
 #endif
   hipLaunchKernelGGL((view_transformer_kernel<L, C, LOWP>), dim3(blocks), dim3(kVtBlock), kF16LdsBytes, s, packed, x_tokens,
-                     rgb, dir, P, token0, radiance, view_out, status);
+                     x_point, rgb, dir, P, token0, radiance, view_out, status);
   return hipGetLastError();
 }
 
-hipError_t launch_view_transformer(const float* packed, const float* x_tokens, const float* rgb, const float* dir,
-                                   int P, int NV, float* token0, float* radiance, float* view_out, bool lowp, int* status,
+hipError_t launch_view_transformer(const float* packed, const float* x_tokens, const float* x_point, const float* rgb,
+                                   const float* dir, int P, int NV, float* token0, float* radiance, float* view_out, bool lowp, int* status,
                                    hipStream_t s) {
+  // the kernel addresses its buffers with 32-bit element offsets: the largest one, view_out (P, NV + 1, 80), must stay
+  // below 2^32 floats' worth of bytes / 4 (6.7 M points at NV = 3; a chunk of the whole-path call has 0.5 M)
+  if (P <= 0 || (unsigned long long)P * (NV + 1) * UFR_TOKEN_DIM >= (1ull << 30)) return hipErrorInvalidValue;
   switch (NV) {
 #define UFR_VT_CASE(N)                                                                                       \
     case N:                                                                                                  \
-      return lowp ? launch_vt<N + 1, true>(packed, x_tokens, rgb, dir, P, token0, radiance, view_out, status, s)     \
-                  : launch_vt<N + 1, false>(packed, x_tokens, rgb, dir, P, token0, radiance, view_out, status, s);
+      return lowp ? launch_vt<N + 1, true>(packed, x_tokens, x_point, rgb, dir, P, token0, radiance, view_out, status, s)     \
+                  : launch_vt<N + 1, false>(packed, x_tokens, x_point, rgb, dir, P, token0, radiance, view_out, status, s);
     UFR_VT_CASE(2) UFR_VT_CASE(3) UFR_VT_CASE(4) UFR_VT_CASE(5) UFR_VT_CASE(6) UFR_VT_CASE(7)
 #undef UFR_VT_CASE
     default: return hipErrorInvalidValue;

@@ -90,28 +90,35 @@ class RenderTwoPass(torch.autograd.Function):
         pool_tok = torch.empty(P1 + P2, ops._lib.TOKEN_DIM, dtype=torch.float32, device=dev)
         pool_rad = torch.empty(P1 + P2, 3, dtype=torch.float32, device=dev)
         sim8_pool = torch.empty(P1 + P2, 8, dtype=torch.float32, device=dev)      # pre_sim_mlp inputs, pool rows
-        x1, rgbm1, dirs1, g1 = ops.project_gather(frame, weights, ray_o, ray_d, z1, want_xy=True, sim8_out=sim8_pool[:P1])
+        # ... and the gathered view-transformer inputs of both passes, so that ONE backward launch walks all pool rows
+        NV = frame.NV
+        pool_x = torch.empty(P1 + P2, NV, ops._lib.TOKEN_DIM, dtype=torch.float32, device=dev)
+        pool_rgbm = torch.empty(P1 + P2, NV, 4, dtype=torch.float32, device=dev)
+        pool_dirs = torch.empty(P1 + P2, NV, 4, dtype=torch.float32, device=dev)
+        x1, rgbm1, dirs1, g1 = ops.project_gather(frame, weights, ray_o, ray_d, z1, want_xy=True, sim8_out=sim8_pool[:P1],
+                                                  out=(pool_x[:P1], pool_rgbm[:P1], pool_dirs[:P1]))
         ops.view_transform(weights, x1, rgbm1, dirs1, token0=pool_tok[:P1], radiance=pool_rad[:P1], precision=prec)
         srdf1 = ops.ray_transform(weights, pool_tok[:P1], RN, SN, precision=prec)
         rgb, depth, opacity, weight = ops.composite(z1, pool_rad[:P1].view(RN, SN, 3), srdf1, var)
         z2, z_new, row = ops.sample_importance_pool(weight, z1, U2)                  # model.py:455-470 (weights detached)
-        x2, rgbm2, dirs2, g2 = ops.project_gather(frame, weights, ray_o, ray_d, z_new, want_xy=True, sim8_out=sim8_pool[P1:])
+        x2, rgbm2, dirs2, g2 = ops.project_gather(frame, weights, ray_o, ray_d, z_new, want_xy=True, sim8_out=sim8_pool[P1:],
+                                                  out=(pool_x[P1:], pool_rgbm[P1:], pool_dirs[P1:]))
         ops.view_transform(weights, x2, rgbm2, dirs2, token0=pool_tok[P1:], radiance=pool_rad[P1:], precision=prec)
         srdf2 = ops.ray_transform(weights, pool_tok, RN, S2, row=row, precision=prec)
         rgb2, depth2, opacity2, weight2 = ops.composite(z2, pool_rad, srdf2, var, row=row)
         xy2 = torch.cat([g1["xy"], g2["xy"]], 1)[:, row.reshape(-1).long()]         # (NV, RN*S2, 2), a returned value only
         ctx.frame, ctx.weights, ctx.n_par, ctx.precision = frame, weights, n_par, prec
         ctx.vol_shapes = [tuple(t.shape) for t in tensors[n_par:]]
-        ctx.save_for_backward(ray_o, ray_d, z1, z2, row, x1, rgbm1, dirs1, sim8_pool, srdf1,
-                              x2, rgbm2, dirs2, pool_tok, pool_rad, srdf2)
+        ctx.save_for_backward(ray_o, ray_d, z1, z2, row, pool_x, pool_rgbm, pool_dirs, sim8_pool, srdf1,
+                              pool_tok, pool_rad, srdf2)
         ctx.mark_non_differentiable(g1["xy"], xy2, z2)
         return rgb, depth, opacity, weight, srdf1, g1["xy"], rgb2, depth2, opacity2, weight2, srdf2, xy2, z2
 
     @staticmethod
     def backward(ctx, d_rgb, d_depth, d_opacity, d_weight, d_srdf, _dxy, d_rgb2, d_depth2, d_opacity2, d_weight2, d_srdf2,
                  _dxy2, _dz2):
-        (ray_o, ray_d, z1, z2, row, x1, rgbm1, dirs1, sim8_pool, srdf1,
-         x2, rgbm2, dirs2, pool_tok, pool_rad, srdf2) = ctx.saved_tensors
+        (ray_o, ray_d, z1, z2, row, pool_x, pool_rgbm, pool_dirs, sim8_pool, srdf1,
+         pool_tok, pool_rad, srdf2) = ctx.saved_tensors
         frame, W, prec = ctx.frame, ctx.weights, ctx.precision
         RN, SN = z1.shape
         S2 = z2.shape[1]
@@ -138,10 +145,10 @@ class RenderTwoPass(torch.autograd.Function):
             d_srdf_c = d_srdf_c + d_srdf
         ops.ray_transform_bwd(W, grads, pool_tok[:P1], RN, SN, d_srdf_c, out=(pool_a[:P1], pool_b[:P1]), accumulate=True,
                               precision=prec)
-        # ---- view transformer backwards: coarse samples once, with the cotangents of both passes; new samples once
+        # ---- view transformer backwards, ONE launch over the pool: coarse samples once, with the cotangents of both passes,
+        # and the new samples
         d_pv = torch.empty(pool_tok.shape[0], 40, dtype=torch.float32, device=dev)   # pool rows again
-        ops.view_transform_bwd(W, grads, x1, rgbm1, dirs1, pool_a[:P1], pool_b[:P1], pool_drad[:P1], precision=prec, d_pv=d_pv[:P1])
-        ops.view_transform_bwd(W, grads, x2, rgbm2, dirs2, pool_a[P1:], pool_b[P1:], pool_drad[P1:], precision=prec, d_pv=d_pv[P1:])
+        ops.view_transform_bwd(W, grads, pool_x, pool_rgbm, pool_dirs, pool_a, pool_b, pool_drad, precision=prec, d_pv=d_pv)
         need = ctx.needs_input_grad[6:]
         if any(need[ctx.n_par:]):
             gvol = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.vol_shapes]

@@ -225,12 +225,18 @@ def points(ray_o: torch.Tensor, ray_d: torch.Tensor, z: torch.Tensor) -> torch.T
 def project_gather(frame: FrameHandle, weights: PackedWeights, ray_o: torch.Tensor, ray_d: torch.Tensor,
                    z: torch.Tensor, debug: bool = False, want_sim8: bool = False, want_xy: bool = False,
                    vol24_in: Optional[torch.Tensor] = None, sim8_in: Optional[torch.Tensor] = None,
-                   sim8_out: Optional[torch.Tensor] = None):
+                   sim8_out: Optional[torch.Tensor] = None, out=None):
+    """``out`` = (x (P,NV,80), rgb (P,NV,4), dirs (P,NV,4)): write into these (row ranges of the two-pass step's pool)."""
     RN, SN = z.shape
     P, NV, dev = RN * SN, frame.NV, z.device
-    x = torch.empty(P, NV, _lib.TOKEN_DIM, dtype=torch.float32, device=dev)
-    rgb = torch.empty(P, NV, 4, dtype=torch.float32, device=dev)
-    dirs = torch.empty(P, NV, 4, dtype=torch.float32, device=dev)
+    if out is not None:
+        x, rgb, dirs = out
+        assert x.shape == (P, NV, _lib.TOKEN_DIM) and rgb.shape == (P, NV, 4) and dirs.shape == (P, NV, 4)
+        assert x.is_contiguous() and rgb.is_contiguous() and dirs.is_contiguous()
+    else:
+        x = torch.empty(P, NV, _lib.TOKEN_DIM, dtype=torch.float32, device=dev)
+        rgb = torch.empty(P, NV, 4, dtype=torch.float32, device=dev)
+        dirs = torch.empty(P, NV, 4, dtype=torch.float32, device=dev)
     dbg = {}
     if debug:
         dbg = dict(sim8=torch.empty(P, 8, device=dev), vol24=torch.empty(P, 24, device=dev),

@@ -193,13 +193,17 @@ __device__ __forceinline__ void gemm_compute(AFrag<IN>& cur, const float* __rest
       // keep the chunks in order: without this the scheduler hoists every LDS read of the row tile to its top again
       __builtin_amdgcn_sched_barrier(0);
     });
+    // Stores without per-element guards.  At run time a guard is a compare, an exec-mask save / restore and a branch per
+    // ELEMENT (view_bwd 4.46 -> 4.27 ms, ray_bwd 2.80 -> 2.63 ms when they went): whole row tiles need none, and when
+    // the row count is a multiple of 4 a lane's four rows are all in or all out -- one guard per lane and row tile.
+    const int orow0 = rt * 16 + 4 * g;
+    if (OUT % 16 == 0 || OUT % 4 != 0 || orow0 < OUT) {
 #pragma unroll
-    for (int ct = 0; ct < kCT; ++ct) {
-      const f32x4 acc = acc0[ct] + acc1[ct];
+      for (int ct = 0; ct < kCT; ++ct) {
+        const f32x4 acc = acc0[ct] + acc1[ct];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int orow = rt * 16 + 4 * g + r;
-        if (orow < OUT) epi(orow, 16 * ct + j, acc[r]);
+        for (int r = 0; r < 4; ++r)
+          if (OUT % 4 == 0 || orow0 + r < OUT) epi(orow0 + r, 16 * ct + j, acc[r]);
       }
     }
     if (more) cur = nxt;

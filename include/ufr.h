@@ -187,7 +187,9 @@ int ufr_project_gather(const ufr_frame* frame, const ufr_raw_weights* raw, const
 
 /* View transformer + ray transformer + SRDF / radiance heads (ray_transformer.py:283-320).
  * radiance: (P,3); srdf: (RN,SN).  workspace >= ufr_aggregate_workspace_bytes(RN,SN).
- * Optional debug outputs (may be NULL): view_out (P,NV+1,80), ray_out (P,88). */
+ * Optional debug outputs (may be NULL): view_out (P,NV+1,80), ray_out (P,88).
+ * One call handles at most P * (NV + 1) * 80 < 2^30 token values (6.7 M points at NV = 3; the view-transformer kernel
+ * addresses its buffers with 32-bit offsets): UFR_ERR_ARG beyond it -- chunk the points (ufr_render_rays does). */
 size_t ufr_aggregate_workspace_bytes(int32_t RN, int32_t SN, int32_t NV);
 int ufr_aggregate(const void* packed_weights, const float* x_tokens, const float* rgb, const float* dir,
                   int32_t RN, int32_t SN, int32_t NV, float* radiance, float* srdf, void* workspace,

@@ -379,6 +379,8 @@ size_t ufr_aggregate_workspace_bytes(int32_t RN, int32_t SN, int32_t NV) {
 static int aggregate_impl(const void* packed, const float* x_tokens, const float* x_point, const float* rgb, const float* dir, int RN, int SN,
                           int NV, float* radiance, float* srdf, float* token0, float* order_pe, bool pe_ready,
                           float* view_out, float* ray_out, bool lowp, int* status, hipStream_t s) {
+  UFR_REQUIRE((unsigned long long)RN * SN * (NV + 1) * UFR_TOKEN_DIM < (1ull << 30),
+              "view transformer: %d x %d points x %d tokens exceed the 2^30 token values one call addresses; chunk the points", RN, SN, NV + 1);
   {
     ProfScope ps("view_transformer", s);
     UFR_HIP(launch_view_transformer(static_cast<const float*>(packed), x_tokens, x_point, rgb, dir, RN * SN, NV, token0, radiance,
@@ -537,6 +539,8 @@ int ufr_view_transform(const void* packed_weights, const float* x_tokens, const 
   if (rc != UFR_OK) return rc;
   {
     ProfScope p("view_transformer", s);
+    UFR_REQUIRE((unsigned long long)P * (NV + 1) * UFR_TOKEN_DIM < (1ull << 30),
+                "ufr_view_transform: %d points x %d tokens exceed the 2^30 token values one call addresses; chunk the points", P, NV + 1);
     UFR_HIP(launch_view_transformer(static_cast<const float*>(packed_weights), x_tokens, nullptr, rgb, dir, P, NV, token0, radiance,
                                     nullptr, lowp, sl->dev, s));
   }

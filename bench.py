@@ -292,6 +292,9 @@ def measure_frames(a, dev, world, rank):
                           peak_basis="dense fp16 MFMA peak 2516.6 TFLOP/s / 3 plane products per fp32 product (fp16x3); "
                                      "the fp32 MFMA peak is 157.3 TFLOP/s (round 1-2 kernels issued 6 bf16 plane products: "
                                      "their peak basis was 419.4)",
+                          power_note="the package runs these kernels at ~1.31 kW of its 1.4 kW cap and the firmware lowers the "
+                                     "shader clock to ~2.0 GHz (peak assumes 2.4 GHz; the same instruction stream on a zeroed "
+                                     "weight blob keeps 2.39 GHz and is 18.5 % faster): profiles/r3_power_probe.md",
                           frac_of_fp32_mfma_peak=achieved / PEAK_FP32_MFMA_TFLOPS,
                           # the same achieved rate against the roof the round-1 / round-2 reviews priced this kernel on
                           # (six bf16 plane products per fp32 product); the ray transformer on both bases beside it

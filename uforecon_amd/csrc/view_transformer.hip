@@ -100,16 +100,64 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
                                                                              int* __restrict__ status) {
   constexpr int NV = L - 1;
   constexpr int PPT = 16 / L;          // points per column tile
-  constexpr int PPW = PPT * C;         // points per wave iteration
+  // L = 6 (five source views) fills only 12 of a tile's 16 columns with whole points: with two column tiles per wave a
+  // fifth point STRADDLES them -- tile 0 = points 0, 1 and tokens 0..3 of point 2; tile 1 = points 3, 4, then tokens 4, 5 of
+  // point 2 in columns 12, 13 (30 of 32 columns).  The dense layers do not care where a token sits; the attention and the
+  // softmax exchange tokens of a point through the schedule below.
+  constexpr bool STRADDLE = (L == 6 && C == 2);
+  constexpr int PPW = STRADDLE ? 5 : PPT * C;         // points per wave iteration
   extern __shared__ __attribute__((aligned(16))) char smem[];
   auto ws = wstream_f16_begin<kVtWaves, LOWP>(packed, smem);
   wstream_f16_prime<B_VT, kVtWaves>(ws);
   const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
-  const int pt_in_tile = j / L, tv = j % L;         // token tv of point pt_in_tile (tv == 0: view token)
-  const bool col_ok = j < PPT * L;
-  int src[8];
+  // column (c, j) holds token tvv[c] of the wave's point ptw[c] (tvv == 0: view token)
+  int ptw[C], tvv[C];
+  bool okc[C];
 #pragma unroll
-  for (int s = 0; s < 8; ++s) src[s] = col_ok ? (lane - tv + (tv + s) % L) : lane;
+  for (int c = 0; c < C; ++c) {
+    if constexpr (STRADDLE) {
+      ptw[c] = j < 12 ? 3 * c + j / 6 : 2;
+      tvv[c] = j < 12 ? j % 6 : (c == 0 ? j - 12 : j - 8);
+      okc[c] = c == 0 || j < 14;
+    } else {
+      ptw[c] = c * PPT + j / L;
+      tvv[c] = j % L;
+      okc[c] = j < PPT * L;
+    }
+  }
+  int src[8];    // L != 4, no straddle: lane of token (tv + S) % L of the same point (the same for every tile)
+#pragma unroll
+  for (int s = 0; s < 8; ++s) src[s] = okc[0] ? (lane - tvv[0] + (tvv[0] + s) % L) : lane;
+  // STRADDLE: a token meets the other five of its point in five STEPS, token t reading token kStep[t][step] -- the same
+  // schedule for every point, so a point's arithmetic does not depend on the slot it lands in.  The schedule is chosen so
+  // that ONE exchange per value, tile and step suffices: the two halves of the straddling point sit in the same lanes
+  // (12..15) of the two tiles, and in no step does a tile's consumer set want both tiles' value of one lane -- the source
+  // register of tile c at a step is the tile's own value with lanes 12..15 taken from the other tile where `ovr` says so
+  // (tile 0: lane 12 at step 0 = token 4, lane 13 at step 1 = token 5; tile 1: lanes 12..15 = tokens 0..3 from step 1 on).
+  int srcx[C][5];
+  if constexpr (STRADDLE) {
+    constexpr int kStep[6][5] = {{4, 5, 1, 2, 3}, {4, 5, 0, 2, 3}, {4, 5, 0, 1, 3}, {4, 5, 0, 1, 2}, {5, 0, 1, 2, 3}, {4, 0, 1, 2, 3}};
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int st = 0; st < 5; ++st) {
+        int u = 0;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) u = tvv[c] == t ? kStep[t][st] : u;
+        const int base = j < 12 ? (j / 6) * 6 : 12;            // first lane of the point's tokens in the source register
+        const int off = j < 12 ? u : (u & 3);                  // straddling point: tokens 0..3 and 4, 5 both at lanes 12..
+        srcx[c][st] = 4 * (okc[c] ? 16 * g + base + off : lane);   // byte address of ds_bpermute_b32
+      }
+  }
+  // value that token kStep[tv][st] of this lane's point holds of (xc: this tile's register, xo: the other tile's)
+  auto exch = [&](auto ci, auto sti, float xc, float xo) __attribute__((always_inline)) -> float {
+    constexpr int c = decltype(ci)::value, st = decltype(sti)::value;
+    float m = xc;
+    if constexpr (c == 0 && st == 0) m = j == 12 ? xo : xc;
+    if constexpr (c == 0 && st == 1) m = j == 13 ? xo : xc;
+    if constexpr (c == 1 && st >= 1) m = j >= 12 ? xo : xc;
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(srcx[c][st], __builtin_bit_cast(int, m)));
+  };
 
   const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -153,13 +201,14 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     bool valid[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      pidx[c] = grp * PPW + c * PPT + pt_in_tile;
-      valid[c] = col_ok && grp < n_groups && pidx[c] < P;
+      pidx[c] = grp * PPW + ptw[c];
+      valid[c] = okc[c] && grp < n_groups && pidx[c] < P;
       const int pp = valid[c] ? pidx[c] : 0;
       // token columns 0..31 and 72..79 are per (point, view), 32..71 per point: one 80-column row in the public layout,
       // a 40-column view row plus a 40-column point row in the compact one (ufr_internal.h)
       // (32-bit element offsets from the scalar bases -- the launcher bounds P: 64-bit per-lane addresses that the
       // optimiser hoists out of the loop cost this kernel spills it cannot afford)
+      const int tv = tvv[c];
       const unsigned vrow = ((unsigned)pp * NV + (tv > 0 ? tv - 1 : 0)) * (x_point ? kViewCols : UFR_TOKEN_DIM);
       const unsigned prow_e = x_point ? (unsigned)pp * kPointCols : vrow + 32;
       const float* pbase = x_point ? x_point : x_tokens;
@@ -208,6 +257,40 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     // msg = sum_S A_S V_S / sum_S A_S with A_S = Q'.K'_S for the token (tv+S)%L of the same point: the
     // scores are reduced to L numbers per head before v is even computed, so q and k die early
     float A[C][2][L], Zs[C][2];
+    if constexpr (STRADDLE) {
+      // index 0 = the token itself, 1 + step = its partner of that step (the schedule above)
+      static_for<2>([&](auto hi) __attribute__((always_inline)) {
+        constexpr int hh = decltype(hi)::value;
+        float Q[C][10], K[C][10], den[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+          for (int d = 0; d < 10; ++d) {
+            const int s = 10 * hh + d;
+            Q[c][d] = elu1_acc(q[c][s >> 2][s & 3]);
+            K[c][d] = elu1_acc(k[c][s >> 2][s & 3]);
+          }
+          float a = 0.f;
+#pragma unroll
+          for (int d = 0; d < 10; ++d) a = fmaf(Q[c][d], K[c][d], a);
+          A[c][hh][0] = a;
+          den[c] = a;
+        }
+        static_for<5>([&](auto sti) __attribute__((always_inline)) {
+          constexpr int st = decltype(sti)::value;
+          float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+          for (int d = 0; d < 10; ++d) {
+            a0 = fmaf(Q[0][d], exch(std::integral_constant<int, 0>{}, sti, K[0][d], K[1][d]), a0);
+            a1 = fmaf(Q[1][d], exch(std::integral_constant<int, 1>{}, sti, K[1][d], K[0][d]), a1);
+          }
+          A[0][hh][1 + st] = a0; den[0] += a0;
+          A[1][hh][1 + st] = a1; den[1] += a1;
+        });
+#pragma unroll
+        for (int c = 0; c < C; ++c) Zs[c][hh] = (float)L / (den[c] + 1e-6f);   // Z * v_length (linear_attention.py:43-44)
+      });
+    } else {
 #pragma unroll
     for (int c = 0; c < C; ++c) {
 #pragma unroll
@@ -237,12 +320,42 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
         Zs[c][hh] = (float)L / (den + 1e-6f);             // Z * v_length (linear_attention.py:43-44)
       }
     }
+    }
     UFR_PHASE(2)  // scores
     f32x4 v[C][5];
     zero_tiles(v);
     gemm_f16<M_VT_V, C, kVtWaves, false, true>(ws, x, v, wrap);   // raw accumulators: the descale joins the 1 / v_length
     UFR_PHASE(3)  // v GEMM
     f32x4 msg[C][5];
+    if constexpr (STRADDLE) {
+      static_for<2>([&](auto hi) __attribute__((always_inline)) {
+        constexpr int hh = decltype(hi)::value;
+        float V[C][10], acc[C][10];
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+          for (int d = 0; d < 10; ++d) {
+            const int s = 10 * hh + d;
+            V[c][d] = v[c][s >> 2][s & 3] / ((float)L * kAccScale);   // values / v_length (L = 6: a true division)
+            acc[c][d] = A[c][hh][0] * V[c][d];
+          }
+        static_for<5>([&](auto sti) __attribute__((always_inline)) {
+          constexpr int st = decltype(sti)::value;
+#pragma unroll
+          for (int d = 0; d < 10; ++d) {
+            acc[0][d] = fmaf(A[0][hh][1 + st], exch(std::integral_constant<int, 0>{}, sti, V[0][d], V[1][d]), acc[0][d]);
+            acc[1][d] = fmaf(A[1][hh][1 + st], exch(std::integral_constant<int, 1>{}, sti, V[1][d], V[0][d]), acc[1][d]);
+          }
+        });
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+          for (int d = 0; d < 10; ++d) {
+            const int s = 10 * hh + d;
+            msg[c][s >> 2][s & 3] = acc[c][d] * Zs[c][hh];
+          }
+      });
+    } else {
 #pragma unroll
     for (int c = 0; c < C; ++c) {
 #pragma unroll
@@ -272,6 +385,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
           msg[c][s >> 2][s & 3] = acc[d] * Zs[c][hh];
         }
       }
+    }
     }
 
     UFR_PHASE(4)  // message
@@ -307,6 +421,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     for (int c = 0; c < C; ++c) {
       col[c] = splat4(0.f);
       dcomp[c] = 0.f;
+      const int tv = tvv[c];
       if (valid[c] && tv > 0) {
         col[c] = ld4(at32(rgbm, ((unsigned)pidx[c] * NV + (tv - 1)) * 4u));           // r,g,b,mask
         dcomp[c] = *at32(dirs, ((unsigned)pidx[c] * NV + (tv - 1)) * 4u + g);         // lane group g <- dir[g], 0 for g=3
@@ -323,6 +438,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     // ---------------- outputs: token 0 -> ray transformer input; optional full dump
 #pragma unroll
     for (int c = 0; c < C; ++c) {
+      const int tv = tvv[c];
       if (valid[c] && tv == 0) {
 #pragma unroll
         for (int t = 0; t < 5; ++t) st4(at32(token0, (unsigned)pidx[c] * UFR_TOKEN_DIM + 4 * g) + 16 * t, o[c][t]);
@@ -362,8 +478,48 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     UFR_PHASE(10)  // radiance MLP
     // ---------------- masked softmax over the NV view tokens + colour blend (ray_transformer.py:315-319)
     // logit of token j sits in lane group 0, register 0; lanes of group 0 do the point-local reduction
+    if constexpr (STRADDLE) {
+      float logit[C], mx[C], e[C], den[C], cr[C], cg[C], cb[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        logit[c] = lg[c][0][0] * kAccDescale;
+        if (col[c][3] == 0.f) logit[c] = -1e9f;
+        if (tvv[c] == 0) logit[c] = -INFINITY;  // the view token is not a colour source
+        mx[c] = logit[c];
+      }
+      static_for<5>([&](auto sti) __attribute__((always_inline)) {
+        mx[0] = fmaxf(mx[0], exch(std::integral_constant<int, 0>{}, sti, logit[0], logit[1]));
+        mx[1] = fmaxf(mx[1], exch(std::integral_constant<int, 1>{}, sti, logit[1], logit[0]));
+      });
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        e[c] = tvv[c] == 0 ? 0.f : expf(logit[c] - mx[c]);
+        den[c] = e[c]; cr[c] = e[c] * col[c][0]; cg[c] = e[c] * col[c][1]; cb[c] = e[c] * col[c][2];
+      }
+      static_for<5>([&](auto sti) __attribute__((always_inline)) {
+        constexpr std::integral_constant<int, 0> c0{};
+        constexpr std::integral_constant<int, 1> c1{};
+        den[0] += exch(c0, sti, e[0], e[1]);
+        den[1] += exch(c1, sti, e[1], e[0]);
+        cr[0] += exch(c0, sti, e[0] * col[0][0], e[1] * col[1][0]);
+        cr[1] += exch(c1, sti, e[1] * col[1][0], e[0] * col[0][0]);
+        cg[0] += exch(c0, sti, e[0] * col[0][1], e[1] * col[1][1]);
+        cg[1] += exch(c1, sti, e[1] * col[1][1], e[0] * col[0][1]);
+        cb[0] += exch(c0, sti, e[0] * col[0][2], e[1] * col[1][2]);
+        cb[1] += exch(c1, sti, e[1] * col[1][2], e[0] * col[0][2]);
+      });
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+        if (valid[c] && tvv[c] == 0 && g == 0) {
+          float* dst = at32(radiance, (unsigned)pidx[c] * 3u);
+          dst[0] = cr[c] / den[c];
+          dst[1] = cg[c] / den[c];
+          dst[2] = cb[c] / den[c];
+        }
+    } else {
 #pragma unroll
     for (int c = 0; c < C; ++c) {
+      const int tv = tvv[c];
       float logit = lg[c][0][0] * kAccDescale;
       if (col[c][3] == 0.f) logit = -1e9f;
       if (tv == 0) logit = -INFINITY;  // the view token is not a colour source
@@ -388,6 +544,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
         dst[1] = cg / den;
         dst[2] = cb / den;
       }
+    }
     }
     wstream_f16_finish<B_VT, kVtWaves>(ws, wrap);
     UFR_PHASE(11)  // softmax blend
@@ -416,7 +573,7 @@ template <int L, bool LOWP>
 static hipError_t launch_vt(const float* packed, const float* x_tokens, const float* x_point, const float* rgb, const float* dir, int P,
                             float* token0, float* radiance, float* view_out, int* status, hipStream_t s) {
   constexpr int C = UFR_VT_C;
-  constexpr int PPW = (16 / L) * C;
+  constexpr int PPW = (L == 6 && C == 2) ? 5 : (16 / L) * C;   // L = 6: a fifth point straddles the wave's two column tiles
   const int n_groups = (P + PPW - 1) / PPW;
   int blocks = (n_groups + kVtWaves - 1) / kVtWaves;
   // Two workgroups are resident per CU, and the older one wins the SIMD's issue arbitration: with exactly

@@ -247,3 +247,19 @@ def test_pool_rows_in_the_kernels_equal_materialised_slots(weights):
     pa2, pb2 = pa.clone(), pb.clone()
     ops.ray_transform_bwd(weights, ga, pool_tok, RN, S2, d_srdf_p, row=row, out=(pa2, pb2), accumulate=True)
     assert torch.allclose(pa2, 2 * pa, rtol=1e-6, atol=1e-7) and torch.allclose(pb2, 2 * pb, rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------ five views: straddling point
+def test_five_view_slots_are_invisible(weights):
+    """At NV = 5 the view transformer packs five points into a wave's 32 token columns, the third one straddling the two
+    column tiles (view_transformer.hip).  Every point runs the same exchange schedule, so WHICH slot a point lands in must
+    not change a bit of its result: chunks of 16 rays start at point indices that are not multiples of 5, i.e. every
+    point of the second chunk sits in another slot than in the one-chunk launch."""
+    fr, idx, U1, U2, g = case_inputs("c4_nv5_interior")
+    fh = _frame_handle(fr)
+    c = CASES["c4_nv5_interior"]
+    a = ops.render_rays(fh, weights, idx.to(DEV), U1.to(DEV), U2.to(DEV))
+    ws = ops.RenderWorkspace(DEV, c["coarse"], c["fine"], 5, chunk_rays=16)
+    b = ops.render_rays(fh, weights, idx.to(DEV), U1.to(DEV), U2.to(DEV), workspace=ws)
+    for k in ("depth", "rgb", "srdf", "z_all"):
+        assert torch.equal(a[k], b[k]), k

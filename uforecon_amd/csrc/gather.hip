@@ -55,8 +55,10 @@ __device__ __forceinline__ Tap2 get_tap(const float* src) {
 // Points are MFMA columns (v_mfma_f32_16x16x4_f32, exact fp32 fma chains), four tiles of 16; the accumulator tile of a
 // layer is the B operand of the next (lane (g,j) holds neurons 4g+r of point j, so k-step (tile, r) of the next layer
 // contracts neurons 16*tile + 4g + r and the A operand is loaded with that index), biases are the accumulators'
-// initial values.  sim: LDS, point q's 8 similarities at sim + q * sim_stride; out: LDS [64][40], columns 24..39.
-__device__ __forceinline__ void presim_block(const PreSim& ps, const float* sim, int sim_stride, float* out, int lane) {
+// initial values.  sim: LDS, point q's 8 similarities at sim + q * sim_stride; out: LDS, point q's row at out + q *
+// out_stride, columns 24..39.
+__device__ __forceinline__ void presim_block(const PreSim& ps, const float* sim, int sim_stride, float* out, int out_stride,
+                                             int lane) {
   const int g = lane >> 4, j = lane & 15;
   f32x4 h1[4][2], h2[4][2], o[4];
   float x0[4][2];
@@ -121,13 +123,15 @@ __device__ __forceinline__ void presim_block(const PreSim& ps, const float* sim,
         for (int u = 0; u < 4; ++u) o[u] = mfma16(a3[ti][r], fmaxf(h2[u][ti][r], 0.f), o[u]);
   }
 #pragma unroll
-  for (int u = 0; u < 4; ++u) st4(out + (16 * u + j) * 40 + 24 + 4 * g, o[u]);
+  for (int u = 0; u < 4; ++u) st4(out + (16 * u + j) * out_stride + 24 + 4 * g, o[u]);
 }
 
-// LDS layout (floats): sim[64][NPAIR][8] | volp[64][NV-1][25] (views >= 1; wave 0 keeps its own in registers) |
-// { tapF[NV][64][8] | tapM[NV][64][8] } aliased with outv[64][40] (the footprints are dead once sim is complete).
-// The footprint of a block bounds the CU's occupancy -- of this kernel, and of the mix when it runs beside the
-// transformer kernels of another chunk (side streams).
+// LDS layout (floats): sim[64][NPAIR][8] | { tapF[NV][64][8] | tapM[NV][64][8] } aliased with volp[64][NV-1][25] (views
+// >= 1; wave 0 keeps its own in registers: the frustums are sampled AFTER the cooperative gathers, when the footprints
+// are dead) | outv[64][40] -- which moves into the (then dead) similarity slots of its point when they are large enough
+// (NV >= 4: a slot is NPAIR * 8 >= 48 floats).  The footprint of a block bounds the CU's occupancy -- of this kernel, and
+// of the mix when it runs beside the transformer kernels of another chunk (side streams): 31 -> 29 KB at NV = 3 (no
+// effect: 4 blocks per CU are enough there), 66 -> 46 KB at NV = 5 (2 -> 3 blocks per CU).
 __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, const float* __restrict__ ray_o,
                                                       int o_stride, const float* __restrict__ ray_d,
                                                       const float* __restrict__ zval, int P, int SN,
@@ -142,10 +146,14 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
   const int NV = f.NV;
   const int npair = NV * (NV - 1) / 2;
   float* sh_sim = smem;                        // 64*npair*8
-  float* sh_vol = sh_sim + 64 * npair * 8;     // 64*(NV-1)*25
-  float* sh_tapF = sh_vol + 64 * (NV - 1) * 25;  // NV*64*8: feature-map footprint (align_corners=False, zeros)
+  float* sh_tapF = sh_sim + 64 * npair * 8;    // NV*64*8: feature-map footprint (align_corners=False, zeros)
   float* sh_tapM = sh_tapF + NV * 64 * 8;      // NV*64*8: matching-map footprint (align_corners=True, border)
-  float* sh_out = sh_tapF;                     // [64][40]: frustum blend 24 | pre_sim_mlp 16, written after the last footprint read
+  float* sh_vol = sh_tapF;                     // 64*(NV-1)*25, written after the last footprint read
+  const int sim_slot = npair * 8;              // floats per point in sh_sim
+  const bool out_in_sim = sim_slot >= 48;      // [64][40] = frustum blend 24 | pre_sim_mlp 16 ...
+  const int region2 = 2 * NV * 64 * 8 > 64 * (NV - 1) * 25 ? 2 * NV * 64 * 8 : 64 * (NV - 1) * 25;
+  float* sh_out = out_in_sim ? sh_sim + 8 : sh_tapF + region2;   // ... behind the point's 8 pre_sim_mlp inputs, or on its own
+  const int out_stride = out_in_sim ? sim_slot : 40;
 
   const int v = threadIdx.x >> 6, p = threadIdx.x & 63;
   // XCD-aware block -> point-group map: workgroups are dealt round-robin to the 8 XCDs (private L2 each), so
@@ -226,37 +234,6 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
     if (active) st4(dir_out + ((size_t)pidx * NV + v) * 4, f32x4{ax * ra - bx * rb, ay * ra - by * rb, az * ra - bz * rb, 0.f});
   }
 
-  // ---- correlation frustums of view v (model.py:359-386); skipped when the caller supplies the blended lookup
-  // (RayTransformer.forward receives it as `fea_volume`, ray_transformer.py:175, 199)
-  float own[25];
-  if (vol24_in) {
-#pragma unroll
-    for (int c = 0; c < 25; ++c) own[c] = 0.f;
-  } else {
-    const float zn = ((qz - f.vol_near) / (f.vol_far - f.vol_near)) * 2.f - 1.f;  // camera.py:400-401
-    float fl[24], wl = 0.f;
-#pragma unroll
-    for (int s = 0; s < UFR_NUM_STAGES; ++s) {
-      float fs[8], ws;
-      const float* vol = f.vol[s] + (size_t)v * f.vD[s] * f.vH[s] * f.vW[s] * kVolCh;
-#ifdef UFR_GABL_NOVOL   // ablation build: no frustum taps (timing only)
-      for (int c = 0; c < 8; ++c) fs[c] = x; ws = y;
-#else
-      sample_volume(vol, f.vD[s], f.vH[s], f.vW[s], x, y, zn, fs, ws);
-#endif
-#pragma unroll
-      for (int c = 0; c < 8; ++c) fl[8 * s + c] = fs[c];
-      wl = s == 0 ? ws : wl + ws;                                                 // :375-378
-    }
-#pragma unroll
-    for (int c = 0; c < 24; ++c) own[c] = fl[c] * wl;                             // features_L * weights_L
-    own[24] = wl;
-    if (v > 0) {
-      float* dst = sh_vol + (p * (NV - 1) + (v - 1)) * 25;
-#pragma unroll
-      for (int c = 0; c < 25; ++c) dst[c] = own[c];
-    }
-  }
   __syncthreads();
 
   // ---- cooperative 32-channel gathers: lane group of 8 = one footprint, lane c8 = channels 4*c8..4*c8+3
@@ -300,6 +277,39 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
   }
   __syncthreads();
 
+  // ---- correlation frustums of view v (model.py:359-386); skipped when the caller supplies the blended lookup
+  // (RayTransformer.forward receives it as `fea_volume`, ray_transformer.py:175, 199)
+  float own[25];
+  if (vol24_in) {
+#pragma unroll
+    for (int c = 0; c < 25; ++c) own[c] = 0.f;
+  } else {
+    const float zn = ((qz - f.vol_near) / (f.vol_far - f.vol_near)) * 2.f - 1.f;  // camera.py:400-401
+    float fl[24], wl = 0.f;
+#pragma unroll
+    for (int s = 0; s < UFR_NUM_STAGES; ++s) {
+      float fs[8], ws;
+      const float* vol = f.vol[s] + (size_t)v * f.vD[s] * f.vH[s] * f.vW[s] * kVolCh;
+#ifdef UFR_GABL_NOVOL   // ablation build: no frustum taps (timing only)
+      for (int c = 0; c < 8; ++c) fs[c] = x; ws = y;
+#else
+      sample_volume(vol, f.vD[s], f.vH[s], f.vW[s], x, y, zn, fs, ws);
+#endif
+#pragma unroll
+      for (int c = 0; c < 8; ++c) fl[8 * s + c] = fs[c];
+      wl = s == 0 ? ws : wl + ws;                                                 // :375-378
+    }
+#pragma unroll
+    for (int c = 0; c < 24; ++c) own[c] = fl[c] * wl;                             // features_L * weights_L
+    own[24] = wl;
+    if (v > 0) {
+      float* dst = sh_vol + (p * (NV - 1) + (v - 1)) * 25;
+#pragma unroll
+      for (int c = 0; c < 25; ++c) dst[c] = own[c];
+    }
+  }
+  __syncthreads();
+
   // ---- per-point reductions by wave 0: mean similarity, frustum blend, pre_sim_mlp
   if (v == 0) {
     float sim[8];
@@ -310,7 +320,7 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
       sim[gi] = s / (float)npair;                                                 // torch.mean over pairs
       if (sim8_in) sim[gi] = sim8_in[(size_t)pc * 8 + gi];                        // cond_info['feat_info'] given
     }
-    float* ov = sh_out + p * 40;
+    float* ov = sh_out + p * out_stride;
     {
       float Wsum = own[24];                                                       // view 0 first, then 1..NV-1
       for (int n = 1; n < NV; ++n) Wsum += sh_vol[(p * (NV - 1) + n - 1) * 25 + 24];
@@ -332,7 +342,7 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      presim_block(ps, sh_sim, npair * 8, sh_out, p);
+      presim_block(ps, sh_sim, sim_slot, sh_out, out_stride, p);
     }
     if (active && sim8_out) {
 #pragma unroll
@@ -347,7 +357,7 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
   // ---- token assembly: [feat 32 | vol 24 | sim 16 | depth PE 8] (ray_transformer.py:258-281)
   // (public layout: the per-point columns go into every view's row; compact: once, by view 0's thread)
   if (active && (!x_point || v == 0)) {
-    const float* ov = sh_out + p * 40;
+    const float* ov = sh_out + p * out_stride;
     float* dst = x_point ? x_point + (size_t)pidx * kPointCols : xrow + 32;
 #pragma unroll
     for (int c = 0; c < 40; c += 4) st4(dst + c, ld4(ov + c));   // frustum lookup 32..55, pre_sim_mlp output 56..71
@@ -360,8 +370,8 @@ hipError_t launch_gather(const FrameDev& f, const PreSim& ps, const float* ray_o
                          hipStream_t s) {
   const int P = RN * SN, NV = f.NV;
   const int npair = NV * (NV - 1) / 2;
-  const size_t taps = 2 * (size_t)NV * 64 * 8, outv = 64 * 40;
-  size_t lds = sizeof(float) * ((size_t)64 * npair * 8 + 64 * (NV - 1) * 25 + (taps > outv ? taps : outv));
+  const size_t taps = 2 * (size_t)NV * 64 * 8, volp = (size_t)64 * (NV - 1) * 25, outv = npair * 8 >= 48 ? 0 : 64 * 40;
+  size_t lds = sizeof(float) * ((size_t)64 * npair * 8 + (taps > volp ? taps : volp) + outv);
   hipLaunchKernelGGL(gather_kernel, dim3((P + 63) / 64), dim3(64 * NV), lds, s, f, ps, ray_o, o_stride, ray_d, z, P, SN,
                      x_tokens, x_point, rgb, dir, sim8, vol24, xy, mask_z, vol24_in, sim8_in);
   return hipGetLastError();

@@ -291,13 +291,15 @@ __device__ __forceinline__ void gemm_f16_panel(WS& ws, const BStep (&b)[C], f32x
     __builtin_amdgcn_sched_barrier(0);
     hook(ti);
     // three plane pairs (lo.lo is dropped), small terms first (0 = hi, 1 = lo); SWAP: activations in the A slot
-    static_for<n_products>([&](auto pi) __attribute__((always_inline)) {
-      constexpr int pw[kProducts] = {1, 0, 0}, px[kProducts] = {0, 1, 0};
-      constexpr int w = LOWP ? 0 : pw[decltype(pi)::value], x = LOWP ? 0 : px[decltype(pi)::value];
+    // the three products of a column tile back to back (same accumulator, same results bit for bit): 1.5 % faster than
+    // alternating the column tiles between the products -- the accumulate chain stays in the matrix pipe
 #pragma unroll
-      for (int c = 0; c < C; ++c)
+    for (int c = 0; c < C; ++c)
+      static_for<n_products>([&](auto pi) __attribute__((always_inline)) {
+        constexpr int pw[kProducts] = {1, 0, 0}, px[kProducts] = {0, 1, 0};
+        constexpr int w = LOWP ? 0 : pw[decltype(pi)::value], x = LOWP ? 0 : px[decltype(pi)::value];
         out[c][to] = SWAP ? mfma_f16(b[c].p[x], a[w], out[c][to]) : mfma_f16(a[w], b[c].p[x], out[c][to]);
-    });
+      });
     if constexpr (!std::is_same<std::decay_t<Hook>, NoHook>::value) {
       // issue order: one MFMA, then up to two of the hook's VALU instructions, repeated
 #pragma unroll

@@ -37,3 +37,19 @@ for i, v in enumerate(buf):
     if v:
         print(f"{i:2d} {names.get(i, ''):22s} {v:12d} {100.0 * v / tot:5.1f}%  {v / max(n_tiles, 1):9.0f} cycles/tile")
 print("total cycles per tile", tot / max(n_tiles, 1))
+
+# ---- ray_bwd_kernel (markers are numbered in source order; the line printed is the marker's line in csrc/ray_bwd.hip)
+if hasattr(lib, "ufr_debug_rb_phases"):
+    import re
+    rb = (C.c_ulonglong * 64)()
+    lib.ufr_debug_rb_phases(rb, 64, 0)
+    src = open(os.path.join(ROOT, "uforecon_amd", "csrc", "ray_bwd.hip")).read().splitlines()
+    where = {int(m.group(1)): i + 1 for i, l in enumerate(src) for m in [re.search(r"UFR_BWD_PHASE\(g_rb_phase, (\d+)\)", l)] if m}
+    tot = sum(rb)
+    rays_per_wg = max(RN // 256, 1)
+    print(f"ray_bwd: {tot / rays_per_wg:.0f} cycles per ray (SN = {SN}), workgroup 0")
+    for i, v in enumerate(rb):
+        if v:
+            ln = where.get(i, 0)
+            ctx = next((src[k].strip() for k in range(ln, min(ln + 6, len(src))) if src[k].strip() and "UFR_BWD_PHASE" not in src[k]), "")
+            print(f"{i:2d} line {ln:4d} {v / rays_per_wg:10.0f} cyc/ray {100.0 * v / tot:5.1f}%   next: {ctx[:90]}")

@@ -63,6 +63,10 @@ constexpr int T_DM0 = kList2.first[1], T_MLP2 = kList2.first[2], T_MLP0 = kList2
               T_Q = kList2.first[5], T_END2 = kList2.first[6];
 }  // namespace rb
 
+#ifdef UFR_BWD_TIMING
+__device__ unsigned long long g_rb_phase[64];   // cycles between consecutive barriers of workgroup 0 (tools/dev/bwd_phases.py)
+#endif
+
 template <bool LOWP>
 __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPtrs gp, const float* __restrict__ token0,
                                                               const int* __restrict__ tok_row, int accumulate,
@@ -71,6 +75,9 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
                                                               float* __restrict__ d_tok_a, float* __restrict__ d_tok_b,
                                                               float* __restrict__ dbg) {
   using namespace rb;
+#ifdef UFR_BWD_TIMING
+  unsigned long long t_prev = __builtin_readcyclecounter();
+#endif
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* KV = lds + O_END * kLD;
   float* dKV = KV + kKV;
@@ -143,32 +150,36 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       auto pf0 = gemm_prefetch<88, 88, false>(wp.p[P_RT_K], 88, wave, lane, 0);
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 0)
       auto pf0v = gemm_prefetch<88, 88, false>(wp.p[P_RT_V], 88, wave, lane, 6);
-      gemm_compute<88, 88, false, LOWP>(pf0, wp.p[P_RT_K], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = elu1(v); });
+      // (columns past the ray's end hold x = 0: V = 0 there, but K' = elu(0) + 1 = 1 -- zeroed here so that the sums below can
+      // run over whole tiles)
+      gemm_compute<88, 88, false, LOWP>(pf0, wp.p[P_RT_K], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = c < nt ? elu1(v) : 0.f; });
       gemm_compute<88, 88, false, LOWP>(pf0v, wp.p[P_RT_V], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_V + r)[c] = v / fS; }, 6);
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 1)
 #pragma unroll
       for (int i = 0; i < kKVPer; ++i) {
         const int o = tid + i * kBwdThreads;
         if (o < kKV) {
           int h, d, e;
           kv_entry(o, h, d, e);
-          const float* kr = R(O_K + 11 * h + d);
-          const float* vr = R(O_V + 11 * h + (e < 11 ? e : 0));
-          float s = 0.f;
-          for (int t = 0; t < nt; ++t) s = e < 11 ? fmaf(kr[t], vr[t], s) : s + kr[t];
-          kv[i] += s;
+          // batched operand reads (row_dot): as a running sum over a run-time token count every read waited for its own
+          // LDS round trip -- 31 k cycles per tile, an eighth of this kernel
+          kv[i] += row_dot(R(O_K + 11 * h + d), e < 11 ? R(O_V + 11 * h + e) : nullptr, 0);
         }
       }
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 2)
     }
 #pragma unroll
     for (int i = 0; i < kKVPer; ++i)
       if (tid + i * kBwdThreads < kKV) KV[tid + i * kBwdThreads] = kv[i];
     __syncthreads();
     tid = opaque(tid0);
+    UFR_BWD_PHASE(g_rb_phase, 3)
 
     // ================= sweep 2
     float dkv[kKVPer] = {};
@@ -179,9 +190,11 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       auto pf1 = gemm_prefetch<88, 88, false>(wp.p[P_RT_Q], 88, wave, lane, 0);
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 4)
       gemm_compute<88, 88, false, LOWP>(pf1, wp.p[P_RT_Q], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_Q + r)[c] = elu1(v); });   // Q' kept: elu'(q) = (Q' > 1 ? 1 : Q')
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 5)
       // message of (token, head): t = Q' KV_h, den = Q'.sum K', msg = t * Z * SN (linear_attention.py:43-44)
       for (int idx = tid; idx < kTT * 8; idx += kBwdThreads) {
         const int col = idx >> 3, h = idx & 7;
@@ -205,35 +218,43 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       auto pf2 = gemm_prefetch<88, 88, false>(wp.p[P_RT_MERGE], 88, wave, lane, 0);
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 6)
       gemm_compute<88, 88, false, LOWP>(pf2, wp.p[P_RT_MERGE], 88, R(O_MSG), wave, lane, [&](int r, int c, float v) { R(O_XH1 + r)[c] = v; });
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 7)
       ln_forward<88>(R(O_XH1), R(O_CAT + 88), nullptr, flat + F_N1W, flat + F_N1B, R(O_RSTD1), tid);
       auto pf3 = gemm_prefetch<176, 176, false>(wp.p[P_RT_MLP0], 176, wave, lane, 0);
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 8)
       gemm_compute<176, 176, false, LOWP>(pf3, wp.p[P_RT_MLP0], 176, R(O_CAT), wave, lane,
                                 [&](int r, int c, float v) { R(O_HID + r)[c] = fmaxf(v, 0.f); });
       auto pf4 = gemm_prefetch<88, 176, false>(wp.p[P_RT_MLP2], 176, wave, lane, 0);
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 9)
       gemm_compute<88, 176, false, LOWP>(pf4, wp.p[P_RT_MLP2], 176, R(O_HID), wave, lane, [&](int r, int c, float v) { R(O_XH2 + r)[c] = v; });
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 10)
       ln_forward<88>(R(O_XH2), R(O_Y), R(O_CAT), flat + F_N2W, flat + F_N2B, R(O_RSTD2), tid);
       auto pf5 = gemm_prefetch<32, 88, false>(wp.p[P_DM_W0], 88, wave, lane, 0);
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 11)
       // DensityMLP 88 -> 32 -> 16 (-> 1) (ray_transformer.py:147-150, 307)
       gemm_compute<32, 88, false, LOWP>(pf5, wp.p[P_DM_W0], 88, R(O_Y), wave, lane,
                               [&](int r, int c, float v) { R(O_D1 + r)[c] = fmaxf(v + flat[F_DM_B0 + r], 0.f); });
       auto pf6 = gemm_prefetch<16, 32, false>(wp.p[P_DM_W2], 32, wave, lane, 0);
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 12)
       gemm_compute<16, 32, false, LOWP>(pf6, wp.p[P_DM_W2], 32, R(O_D1), wave, lane,
                               [&](int r, int c, float v) { R(O_D2 + r)[c] = fmaxf(v + flat[F_DM_B2 + r], 0.f); });
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 13)
       // ---- backwards: srdf = W4 d2 + b4
       for (int idx = tid; idx < 16 * kTT; idx += kBwdThreads) {
         const int o = idx / kTT, c = idx - o * kTT;
@@ -242,11 +263,13 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       auto pf7 = gemm_prefetch<32, 16, true>(wp.p[P_DM_W2], 32, wave, lane, 0);
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 14)
       gemm_compute<32, 16, true, LOWP>(pf7, wp.p[P_DM_W2], 32, R(O_DD2), wave, lane,
                              [&](int r, int c, float v) { R(O_DD1 + r)[c] = R(O_D1 + r)[c] > 0.f ? v : 0.f; });
       auto pf8 = gemm_prefetch<88, 32, true>(wp.p[P_DM_W0], 88, wave, lane, 0);
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 15)
       // d y; weight gradients of the DensityMLP (dm2: d d2 x d1, dm0: d d1 x y); its small gradients on the VALU
       gemm_compute<88, 32, true, LOWP>(pf8, wp.p[P_DM_W0], 88, R(O_DD1), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] = v; });
       wgrad_range<kSlots2, 0, T_MLP2, LOWP>(acc, lds, wg_tab2, wave, lane);
@@ -261,6 +284,7 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       }
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 16)
       // LayerNorm2 backwards (d opre takes y's rows, dead since the weight gradient of dm0)
       ln_backward<88>(R(O_DY), R(O_XH2), flat + F_N2W, R(O_RSTD2), R(O_DOPRE), tid);
       {
@@ -269,17 +293,20 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       }
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 17)
       if (dbg) dump(ray, s0, O_DOPRE, 88);
       // weight gradient of mlp2 (needs the hidden layer, which the next phase overwrites in place)
       auto pf9 = gemm_prefetch<176, 88, true>(wp.p[P_RT_MLP2], 176, wave, lane, 0);
       wgrad_range<kSlots2, T_MLP2, T_MLP0, LOWP>(acc, lds, wg_tab2, wave, lane);
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 18)
       gemm_compute<176, 88, true, LOWP>(pf9, wp.p[P_RT_MLP2], 176, R(O_DOPRE), wave, lane,
                               [&](int r, int c, float v) { R(O_DHID + r)[c] = R(O_HID + r)[c] > 0.f ? v : 0.f; });
       auto pf10 = gemm_prefetch<176, 176, true>(wp.p[P_RT_MLP0], 176, wave, lane, 0);
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 19)
       // d cat: the x half joins d x at once, the message half takes xhat2's rows (dead since LN2 backwards); weight gradient of mlp0
       gemm_compute<176, 176, true, LOWP>(pf10, wp.p[P_RT_MLP0], 176, R(O_DHID), wave, lane, [&](int r, int c, float v) {
         if (r < 88) R(O_DY + r)[c] += v;
@@ -288,6 +315,7 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       wgrad_range<kSlots2, T_MLP0, T_MERGE, LOWP>(acc, lds, wg_tab2, wave, lane);
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 20)
       ln_backward<88>(R(O_DCATM), R(O_XH1), flat + F_N1W, R(O_RSTD1), R(O_DMPRE), tid);
       {
         const float v = row_dot(R(O_DCATM), tid < 88 ? R(O_XH1) : nullptr, tid < 88 ? tid : (tid < 176 ? tid - 88 : 0));
@@ -296,11 +324,13 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       auto pf11 = gemm_prefetch<88, 88, true>(wp.p[P_RT_MERGE], 88, wave, lane, 0);
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 21)
       if (dbg) dump(ray, s0, O_DMPRE, 176);
       gemm_compute<88, 88, true, LOWP>(pf11, wp.p[P_RT_MERGE], 88, R(O_DMPRE), wave, lane, [&](int r, int c, float v) { R(O_DMSG + r)[c] = v; });
       wgrad_range<kSlots2, T_MERGE, T_Q, LOWP>(acc, lds, wg_tab2, wave, lane);
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 22)
       // attention backwards, query side: d t = d msg Z SN; d den = -SN Z^2 (d msg . t); d Q' = KV d t + d den sum K'
       // (d q takes xhat1's rows, dead since LN1 backwards)
       for (int idx = tid; idx < kTT * 8; idx += kBwdThreads) {
@@ -341,6 +371,7 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       auto pf12 = gemm_prefetch<88, 88, true>(wp.p[P_RT_Q], 88, wave, lane, 0);
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 23)
       // d KV_h[d][e] += sum_t Q'_t[d] d t_t[e];   d (sum K')[d] += sum_t d den_t Q'_t[d]   (columns past the ray's end: d t = 0)
 #pragma unroll
       for (int i = 0; i < kKVPer; ++i) {
@@ -355,16 +386,19 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       wgrad_range<kSlots2, T_Q, T_END2, LOWP>(acc, lds, wg_tab2, wave, lane);
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 24)
       store_dx(ray, s0, d_tok_a);
       if (dbg) { dump(ray, s0, O_DY, 0); dump(ray, s0, O_DQ, 264); }
       __syncthreads();   // the next tile's load_x / d y overwrite rows this phase reads
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 25)
     }
 #pragma unroll
     for (int i = 0; i < kKVPer; ++i)
       if (tid + i * kBwdThreads < kKV) dKV[tid + i * kBwdThreads] = dkv[i];
     __syncthreads();
     tid = opaque(tid0);
+    UFR_BWD_PHASE(g_rb_phase, 26)
 
     // ================= sweep 3: key / value side
     for (int sub = 0; sub < n_sub; ++sub) {
@@ -373,11 +407,13 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       auto pf13 = gemm_prefetch<88, 88, false>(wp.p[P_RT_K], 88, wave, lane, 0);
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 27)
       auto pf13v = gemm_prefetch<88, 88, false>(wp.p[P_RT_V], 88, wave, lane, 6);
       gemm_compute<88, 88, false, LOWP>(pf13, wp.p[P_RT_K], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_K + r)[c] = elu1(v); });   // K'
       gemm_compute<88, 88, false, LOWP>(pf13v, wp.p[P_RT_V], 88, R(O_CAT), wave, lane, [&](int r, int c, float v) { R(O_V + r)[c] = v; }, 6);
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 28)
       // d K'_s[d] = sum_e dKV[d][e] V_s[e] + d(sum K')[d];   d V_s[e] = sum_d K'_s[d] dKV[d][e];  V = v / SN
       // (a column past the ray's end took no part in the forward: its d k, d v are zero)
       for (int idx = tid; idx < kTT * 8; idx += kBwdThreads) {
@@ -407,16 +443,19 @@ __global__ void __launch_bounds__(kBwdThreads) ray_bwd_kernel(RawPtrs wp, GradPt
       auto pf14 = gemm_prefetch<88, 88, true>(wp.p[P_RT_K], 88, wave, lane, 0);
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 29)
       auto pf14v = gemm_prefetch<88, 88, true>(wp.p[P_RT_V], 88, wave, lane, 0);
       gemm_compute<88, 88, true, LOWP>(pf14, wp.p[P_RT_K], 88, R(O_DK), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] = v; });
       gemm_compute<88, 88, true, LOWP>(pf14v, wp.p[P_RT_V], 88, R(O_DV), wave, lane, [&](int r, int c, float v) { R(O_DY + r)[c] += v; });
       wgrad_all<kSlots3, 0, LOWP>(acc3, lds, wg_tab3, lane);
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 30)
       store_dx(ray, s0, d_tok_b);
       if (dbg) dump(ray, s0, O_DY, 352);
       __syncthreads();
       tid = opaque(tid0);
+      UFR_BWD_PHASE(g_rb_phase, 31)
     }
   }
 
@@ -538,3 +577,16 @@ hipError_t launch_presim_bwd(const RawPtrs& wp, const GradPtrs& gp, const float*
 }
 
 }  // namespace ufr
+
+#ifdef UFR_BWD_TIMING
+extern "C" int ufr_debug_rb_phases(unsigned long long* out, int n, int reset) {
+  unsigned long long h[64] = {};
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(ufr::g_rb_phase), sizeof(h)) != hipSuccess) return -1;
+  for (int i = 0; i < n && i < 64; ++i) out[i] = h[i];
+  if (reset) {
+    unsigned long long z[64] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(ufr::g_rb_phase), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

@@ -20,6 +20,20 @@
 
 namespace ufr {
 
+// value of lane + D / lane - D of the same 16-lane row (own value where that lane does not exist): __shfl_down / __shfl_up
+// with width 16, as a DPP row shift -- one VALU instruction; the ds_bpermute the shuffle intrinsics compile to is an LDS
+// round trip each, and this kernel issued 1 056 of them per thread with a wait behind every one
+template <int D, class T>
+__device__ __forceinline__ T row_down(T v) {
+  const int b = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(b, b, 0x100 + D, 0xf, 0xf, false));   // row_shl:D
+}
+template <int D, class T>
+__device__ __forceinline__ T row_up(T v) {
+  const int b = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(b, b, 0x110 + D, 0xf, 0xf, false));   // row_shr:D
+}
+
 struct VolGrads {
   float* feat[UFR_NUM_STAGES];
   float* weight[UFR_NUM_STAGES];
@@ -115,13 +129,13 @@ __global__ void __launch_bounds__(448) gather_bwd_kernel(FrameDev f, VolGrads vg
         //  (a) across the cell boundary: when the next sample sits one cell further along z, its near corner IS this
         //      sample's far corner -- this lane hands its dz = 1 value to the next lane's dz = 0 slot;
         {
-          const int n_off0 = __shfl_down(off[0], 1, 16);                     // next lane's near corner
-          const int n_alive0 = __shfl_down((int)alive[0], 1, 16);
+          const int n_off0 = row_down<1>(off[0]);                            // next lane's near corner
+          const int n_alive0 = row_down<1>((int)alive[0]);
           const bool give = alive[1] && n_alive0 && n_off0 == off[1] && (threadIdx.x & 15) != 15;
-          const int p_give = __shfl_up((int)give, 1, 16);                    // does the previous lane hand over?
+          const int p_give = row_up<1>((int)give);                           // does the previous lane hand over?
 #pragma unroll
           for (int c = 0; c < 9; ++c) {
-            const float v_up = __shfl_up(val[1][c], 1, 16);
+            const float v_up = row_up<1>(val[1][c]);
             if (p_give && (threadIdx.x & 15) != 0) val[0][c] += v_up;
           }
           if (give) alive[1] = false;
@@ -132,15 +146,15 @@ __global__ void __launch_bounds__(448) gather_bwd_kernel(FrameDev f, VolGrads vg
         for (int dz = 0; dz < 2; ++dz) {
           static_for<UFR_GBWD_ROUNDS>([&](auto ri) __attribute__((always_inline)) {
             constexpr int d = 1 << decltype(ri)::value;
-            const int k_dn = __shfl_down(off[dz], d, 16);                    // offset of lane + d (groups never leave a row)
-            const int k_up = __shfl_up(off[dz], d, 16);                      // offset of lane - d
-            const int a_dn = __shfl_down((int)alive[dz], d, 16), a_up = __shfl_up((int)alive[dz], d, 16);
+            const int k_dn = row_down<d>(off[dz]);                           // offset of lane + d (groups never leave a row)
+            const int k_up = row_up<d>(off[dz]);                             // offset of lane - d
+            const int a_dn = row_down<d>((int)alive[dz]), a_up = row_up<d>((int)alive[dz]);
             const int pos = threadIdx.x & (2 * d - 1);
             const bool absorb = pos == 0 && alive[dz] && a_dn && k_dn == off[dz];
             const bool absorbed = pos == d && alive[dz] && a_up && k_up == off[dz];
 #pragma unroll
             for (int c = 0; c < 9; ++c) {
-              const float v_dn = __shfl_down(val[dz][c], d, 16);
+              const float v_dn = row_down<d>(val[dz][c]);
               if (absorb) val[dz][c] += v_dn;
             }
             if (absorbed) alive[dz] = false;

@@ -68,6 +68,15 @@ def main():
     rt = prof["ray_transformer"]["ms"] / prof["ray_transformer"]["launches"]
     print(f"[{tag}] view_transformer  {vt:8.3f} ms  {534224 * P / vt / 1e9:8.2f} TFLOP/s algorithmic")
     print(f"[{tag}] ray_transformer   {rt:8.3f} ms  {(61952 + 92928 + 4048 + 6688) * P / rt / 1e9:8.2f} TFLOP/s algorithmic")
+    if hasattr(lib, "ufr_debug_rt_phases"):  # -DUFR_PHASE_TIMING development build: ray transformer, wave of ray 5
+        rbuf = (C.c_ulonglong * 32)()
+        lib.ufr_debug_rt_phases(rbuf, 32, 1)
+        rnames = ["s1 load + K,V gemm", "s1 KV mfma", "s2 load + Q gemm", "message", "merge gemm", "LN1", "MLP0", "relu+MLP2",
+                  "LN2", "stores + DensityMLP"]
+        rtot = sum(rbuf[:10])
+        for i, nm in enumerate(rnames):
+            print(f"   rt phase {nm:20s} {rbuf[i] / 5:12.0f} cyc/launch  {100.0 * rbuf[i] / max(rtot, 1):5.1f} %")
+        print(f"   rt total {rtot / 5:.0f} cycle-counter ticks per launch (one ray, {SN // 16} tiles)")
     if hasattr(lib, "ufr_debug_vt_phases"):  # -DUFR_PHASE_TIMING development build
         buf = (C.c_ulonglong * 32)()
         lib.ufr_debug_vt_phases(buf, 32, 1)

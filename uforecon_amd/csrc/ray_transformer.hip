@@ -77,6 +77,18 @@ __device__ __forceinline__ void layer_norm88(f32x4 (&tt)[kRtC][6], const WS& ws,
 constexpr int kRtBlock = UFR_RT_BLOCK;
 constexpr int kRtWaves = kRtBlock / 64;
 
+#ifdef UFR_PHASE_TIMING  // development build: cycle counts per phase of wave 5 (tools/bench_kernels.py prints them)
+__device__ unsigned long long g_rt_phase[32];
+#define UFR_RT_PHASE(i)                                                                \
+  {                                                                                    \
+    const unsigned long long t_now = __builtin_readcyclecounter();                     \
+    rt_acc[i] += t_now - rt_prev;                                                      \
+    rt_prev = t_now;                                                                   \
+  }
+#else
+#define UFR_RT_PHASE(i)
+#endif
+
 template <bool LOWP>
 __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(const float* __restrict__ packed,
                                                                   const float* __restrict__ token0,
@@ -100,6 +112,10 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
   const float inv_len = kAccDescale / (float)SN, f_len = (float)SN * kAccScale;   // applied to raw accumulators
   const bool pow2_len = (SN & (SN - 1)) == 0;
 
+#ifdef UFR_PHASE_TIMING
+  unsigned long long rt_acc[16] = {};
+  unsigned long long rt_prev = __builtin_readcyclecounter();
+#endif
   // ---------------- sweep 1: KV_h[d][v] = sum_s K'_h[s][d] * V_h[s][v] / SN   (linear_attention.py:41-42)
   f32x4 KV[8];
 #pragma unroll
@@ -141,6 +157,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
       probe_gemm(kt, ws);   // raw accumulators: the scale joins elu1 / the division by the sample count
       probe_gemm(vt, ws);
     }
+    UFR_RT_PHASE(0)  // sweep 1: token load + K, V GEMMs
 #pragma unroll
     for (int c = 0; c < C; ++c) {
 #pragma unroll
@@ -159,6 +176,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
       }
     }
     wstream_f16_finish<B_RT1, kRtWaves>(ws, wrap);
+    UFR_RT_PHASE(1)  // sweep 1: KV accumulation (fp32 MFMA)
   }
 
   // ---------------- sweep 2 (slot 0 is free: every wave passed the barrier that opened sweep 1's last chunk)
@@ -179,6 +197,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
     }
     track_external(x, ws);
     gemm_f16<M_RT_Q, C, kRtWaves, false, true>(ws, x, q, wrap);  // raw accumulators, quad-packed rows, column j = token
+    UFR_RT_PHASE(2)  // sweep 2: token load + Q GEMM
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       static_for<8>([&](auto hi) __attribute__((always_inline)) {
@@ -202,13 +221,16 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
         });
       });
     }
+    UFR_RT_PHASE(3)  // message (fp32 MFMA)
     f32x4 m[C][6];
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int t = 0; t < 6; ++t) m[c][t] = splat4(0.f);
     gemm_f16<M_RT_MERGE, C, kRtWaves, false, true>(ws, msg, m, wrap);
+    UFR_RT_PHASE(4)  // merge GEMM
     layer_norm88<V_RT_N1W, V_RT_N1B, true>(m, ws, g);
+    UFR_RT_PHASE(5)  // LayerNorm 1
 
     f32x4 cat[C][12], hid[C][11], o[C][6];
 #pragma unroll
@@ -219,6 +241,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
       for (int t = 0; t < 11; ++t) hid[c][t] = splat4(0.f);
     }
     gemm_f16<M_RT_MLP0, C, kRtWaves, false, true>(ws, cat, hid, wrap);   // hid: raw accumulators through the ReLU
+    UFR_RT_PHASE(6)  // MLP0
 #pragma unroll
     for (int c = 0; c < C; ++c) {
 #pragma unroll
@@ -229,7 +252,9 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
       for (int t = 0; t < 6; ++t) o[c][t] = splat4(0.f);
     }
     gemm_f16<M_RT_MLP2, C, kRtWaves, true, true>(ws, hid, o, wrap);
+    UFR_RT_PHASE(7)  // ReLU + MLP2
     layer_norm88<V_RT_N2W, V_RT_N2B, true>(o, ws, g);
+    UFR_RT_PHASE(8)  // LayerNorm 2
 #pragma unroll
     for (int c = 0; c < C; ++c) {
 #pragma unroll
@@ -269,8 +294,13 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
     for (int c = 0; c < C; ++c)
       if (g == 0 && valid && live[c]) srdf[(size_t)ray * SN + tbase[c] + j] = d3[c][0][0] * kAccDescale;
     wstream_f16_finish<B_RT2, kRtWaves>(ws, wrap);
+    UFR_RT_PHASE(9)  // residual, stores, DensityMLP
   }
   wstream_report_range(ws, status);
+#ifdef UFR_PHASE_TIMING
+  if (ray_raw == 5 && lane == 0)
+    for (int i = 0; i < 16; ++i) g_rt_phase[i] += rt_acc[i];
+#endif
 }
 
 template <bool LOWP>
@@ -299,3 +329,16 @@ hipError_t launch_ray_transformer(const float* packed, const float* token0, cons
 }
 
 }  // namespace ufr
+
+#ifdef UFR_PHASE_TIMING
+extern "C" int ufr_debug_rt_phases(unsigned long long* out, int n, int reset) {
+  unsigned long long h[32] = {};
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(ufr::g_rt_phase), sizeof(h)) != hipSuccess) return -1;
+  for (int i = 0; i < n && i < 32; ++i) out[i] = h[i];
+  if (reset) {
+    unsigned long long z[32] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(ufr::g_rt_phase), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

@@ -32,7 +32,7 @@ enum ufr_status {
 
 /* Version of this header's ABI (argument lists, struct layouts, packed-blob layout).  ufr_version() returns the value
  * the library was built with: a binding must refuse a library whose version differs (uforecon_amd/_lib.py does). */
-#define UFR_ABI_VERSION 302
+#define UFR_ABI_VERSION 400
 
 #define UFR_MAX_VIEWS 7
 #define UFR_NUM_STAGES 3
@@ -88,7 +88,8 @@ int ufr_get_matrix_precision(void);
  * (fp16 after the power-of-two plane scales); the kernels never synchronise, so a violation raises a device-side
  * sticky flag instead of failing the launch:
  *   bit 0  a dense-layer input of a transformer kernel reached |x| >= 4094 (its planes overflowed)
- *   bit 1  a transformer kernel produced a non-finite output row (NaN / inf tokens, srdf)
+ *   bit 1  NaN among the externally supplied inputs of a transformer kernel (token rows, dir); +-inf inputs and
+ *          internally produced overflows raise bit 0
  *   bit 2  ufr_weights_pack met a weight that is not finite or |w| >= 255.8
  * ufr_status_poll copies the flag to the host on `stream`; with synchronize != 0 it waits for the stream and returns
  * UFR_ERR_RANGE (message: which bits) when the flag is set, clearing it.  Without synchronize it returns what an
@@ -109,7 +110,9 @@ int ufr_weights_pack(const ufr_raw_weights* raw, void* packed, ufr_stream stream
  * ufr_packed_weights_bytes()/4 int32 each.  No GPU needed. */
 int ufr_pack_plan(int32_t* param_id, int32_t* elem);
 /* The packed blob is [fp32 region: ufr_packed_fp32_floats() floats | fp16 plane region: ufr_packed_f16_halfwords()
- * 16-bit words | 16-byte tail].  The plane region holds the dense layers of both transformer chains as two fp16
+ * 16-bit words | bf16 plane region of the backward kernels: ufr_packed_bwd_halfwords() 16-bit words | 16-byte tail].
+ * The bf16 region holds the TRANSPOSED dense matrices of the data-gradient chains (hi = bf16(w), lo = bf16(w - hi), same
+ * fragment order as the forward planes).  The fp16 plane region holds the dense layers of both transformer chains as two fp16
  * planes per weight (hi = fp16(256 w), lo = fp16(256 w - hi); plane 0/1) for the split-precision MFMA path;
  * ufr_pack_plan_f16 describes it like ufr_pack_plan (one entry per halfword, plus the plane).  Of the fp32 region
  * ufr_weights_pack fills only the trailing vector fragments (biases, LayerNorm, view token): the kernels read nothing
@@ -118,6 +121,8 @@ int ufr_pack_plan(int32_t* param_id, int32_t* elem);
  * fail at once (uforecon_amd.ops.PackedWeights does), or let the next compute entry point report it. */
 size_t ufr_packed_fp32_floats(void);
 size_t ufr_packed_f16_halfwords(void);
+size_t ufr_packed_bwd_halfwords(void);
+int ufr_pack_plan_bwd(int32_t* param_id, int32_t* elem, int32_t* plane);   /* the bf16 region, like ufr_pack_plan_f16 */
 int ufr_pack_plan_f16(int32_t* param_id, int32_t* elem, int32_t* plane);
 
 /* ------------------------------------------------------------------ frame
@@ -231,13 +236,16 @@ int ufr_composite_bwd(const float* z, const float* radiance, const int32_t* row,
  * d_radiance (P,3), d_srdf (RN,SN): gradients of the forward's outputs.  Accumulates the gradients of the view / ray
  * transformer, DensityMLP, radiance-weight MLP and view-token parameters into `grads`; writes d_pv (P,40): gradient
  * w.r.t. token columns 32..71 (24 frustum features | 16 pre_sim_mlp outputs) summed over the NV view tokens of a
- * point -- the input of ufr_project_gather_bwd.  debug_view (P*(NV+1),881) / debug_ray (P,440): optional dumps of the
- * intermediate gradients (tests), may be NULL. */
+ * point -- the input of ufr_project_gather_bwd.  packed_weights: ufr_weights_pack of the same parameters (the view
+ * transformer's backward re-runs the forward kernel with a tape and walks the chain backwards on transposed weight planes
+ * of the packed blob; its weight gradients are one streaming contraction over the tokens).  The workspace holds the tape
+ * and the cotangent tiles: ~15 KB per point at NV = 3.  debug_ray (P,440): optional dump of the ray kernel's intermediate
+ * gradients (development), may be NULL. */
 size_t ufr_aggregate_bwd_workspace_bytes(int32_t RN, int32_t SN, int32_t NV);
-int ufr_aggregate_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const float* x_tokens, const float* rgb,
-                      const float* dir, const float* token0, int32_t RN, int32_t SN, int32_t NV,
-                      const float* d_radiance, const float* d_srdf, float* d_pv, void* workspace, float* debug_view,
-                      float* debug_ray, int32_t precision, ufr_stream stream);
+int ufr_aggregate_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const void* packed_weights, const float* x_tokens,
+                      const float* rgb, const float* dir, const float* token0, int32_t RN, int32_t SN, int32_t NV,
+                      const float* d_radiance, const float* d_srdf, float* d_pv, void* workspace, float* debug_ray,
+                      int32_t precision, ufr_stream stream);
 
 /* Adjoint of ufr_project_gather w.r.t. the sampled volumes and pre_sim_mlp (autograd of model.py:350-390 and
  * ray_transformer.py:268).  sim8 (P,8): the forward's `sim8` output; d_pv (P,40) from ufr_aggregate_bwd.
@@ -275,9 +283,11 @@ int ufr_ray_transform(const void* packed_weights, const float* token0, const int
 int ufr_ray_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const float* token0, const int32_t* row,
                           int32_t RN, int32_t SN, const float* d_srdf, float* d_token0_a, float* d_token0_b,
                           int32_t accumulate, void* workspace, int32_t precision, ufr_stream stream);
-int ufr_view_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const float* x_tokens, const float* rgb,
-                           const float* dir, const float* d_token0_a, const float* d_token0_b, const float* d_radiance,
-                           int32_t P, int32_t NV, float* d_pv, int32_t precision, ufr_stream stream);
+size_t ufr_view_transform_bwd_workspace_bytes(int32_t P, int32_t NV);
+int ufr_view_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const void* packed_weights,
+                           const float* x_tokens, const float* rgb, const float* dir, const float* d_token0_a,
+                           const float* d_token0_b, const float* d_radiance, int32_t P, int32_t NV, float* d_pv, void* workspace,
+                           int32_t precision, ufr_stream stream);
 
 /* ------------------------------------------------------------------ whole-path inference
  * UFORecon.infer(extract_geometry=True) (model.py:393-478) for RN rays of one frame:

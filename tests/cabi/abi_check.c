@@ -17,7 +17,7 @@ int main(void) {
       (const void*)ufr_composite, (const void*)ufr_composite_bwd, (const void*)ufr_aggregate_bwd_workspace_bytes,
       (const void*)ufr_aggregate_bwd, (const void*)ufr_project_gather_bwd, (const void*)ufr_sample_importance_pool, (const void*)ufr_view_transform,
       (const void*)ufr_ray_transform_workspace_bytes, (const void*)ufr_ray_transform, (const void*)ufr_ray_transform_bwd,
-      (const void*)ufr_view_transform_bwd, (const void*)ufr_render_workspace_bytes, (const void*)ufr_default_chunk_rays,
+      (const void*)ufr_view_transform_bwd, (const void*)ufr_view_transform_bwd_workspace_bytes, (const void*)ufr_packed_bwd_halfwords, (const void*)ufr_pack_plan_bwd, (const void*)ufr_render_workspace_bytes, (const void*)ufr_default_chunk_rays,
       (const void*)ufr_render_rays, (const void*)ufr_correlate_workspace_bytes, (const void*)ufr_frustum_correlate,
       (const void*)ufr_conv3d, (const void*)ufr_tsdf_integrate, (const void*)ufr_deform_conv2d_workspace_bytes, (const void*)ufr_deform_conv2d, (const void*)ufr_fmt_layer_workspace_bytes, (const void*)ufr_fmt_layer,
       (const void*)ufr_profile_enable, (const void*)ufr_profile_read};
@@ -33,7 +33,7 @@ int main(void) {
   if (ufr_deform_conv2d(0, 0, 0, 0, 0, 0, 1, 32, 32, 8, 8, 0, 0, 0) >= 0) return 15;
   if (ufr_render_workspace_bytes(4096, 64, 64, 3) == 0) return 16;
   if (ufr_composite_bwd(0, 0, 0, 0, 0, 4, 64, 0, 0, 0, 0, 0, 0, 0, 0, 0) >= 0) return 18;
-  if (ufr_aggregate_bwd(0, 0, 0, 0, 0, 0, 4, 64, 3, 0, 0, 0, 0, 0, 0, UFR_PRECISION_DEFAULT, 0) >= 0) return 19;
+  if (ufr_aggregate_bwd(0, 0, 0, 0, 0, 0, 0, 4, 64, 3, 0, 0, 0, 0, 0, UFR_PRECISION_DEFAULT, 0) >= 0) return 19;
   /* an unknown precision is an argument error, not a silent default */
   if (ufr_view_transform((const void*)1, (const float*)1, (const float*)1, (const float*)1, 4, 3, (float*)1, (float*)1, 7, 0) != UFR_ERR_ARG) return 21;
   if (ufr_aggregate_bwd_workspace_bytes(1024, 128, 3) == 0) return 20;

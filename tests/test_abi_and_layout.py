@@ -40,8 +40,10 @@ def test_every_declared_symbol_is_exported(lib):
 def test_struct_sizes_match_the_header(lib):
     assert C.sizeof(_lib.RawWeights) == 40 * 8
     assert C.sizeof(_lib.Frame) == 160 * 8
-    assert lib.ufr_packed_fp32_floats() == E.vec_region_offset() + 16 * (5 * 4 + 6 * 4 + 2 + 5 + 5)
-    assert lib.ufr_packed_weights_bytes() == 4 * lib.ufr_packed_fp32_floats() + 2 * lib.ufr_packed_f16_halfwords() + 16  # + flag tail
+    assert lib.ufr_packed_fp32_floats() == E.vec_region_offset() + 16 * (5 * 4 + 6 * 4 + 2 + 5 + 5 + 1)   # + rw4 as a vector
+    assert lib.ufr_packed_weights_bytes() == (4 * lib.ufr_packed_fp32_floats() + 2 * lib.ufr_packed_f16_halfwords()
+                                              + 2 * lib.ufr_packed_bwd_halfwords() + 16)  # + flag tail
+    assert lib.ufr_packed_bwd_halfwords() % (12 * 512) == 0
     assert lib.ufr_packed_f16_halfwords() % (12 * 512) == 0  # whole 12 KiB chunks
 
 
@@ -58,7 +60,7 @@ def test_argument_errors_are_reported_not_fatal(lib):
                                   None, None, None, None) == -1
     assert b"not prepared" in lib.ufr_last_error()
     assert lib.ufr_composite_bwd(None, None, None, None, None, 4, 64, None, None, None, None, None, 0, None, None, None) == -1
-    assert lib.ufr_aggregate_bwd(None, None, None, None, None, None, 4, 64, 3, None, None, None, None, None, None, -1, None) == -1
+    assert lib.ufr_aggregate_bwd(None, None, None, None, None, None, None, 4, 64, 3, None, None, None, None, None, -1, None) == -1
     assert b"null" in lib.ufr_last_error()
     assert lib.ufr_project_gather_bwd(C.byref(fr), None, None, None, 0, None, None, 1, 16, None, None, None, None, None, -1, None) == -1
     assert b"not prepared" in lib.ufr_last_error()
@@ -122,7 +124,7 @@ def test_vector_fragments(plan, raw_and_blob):
     vecs = [(12, 5, E.ROW_NAT, 80), (13, 5, E.ROW_NAT, 80), (14, 5, E.ROW_NAT, 80), (15, 5, E.ROW_NAT, 80),
             (22, 6, E.ROW_NAT88, 88), (23, 6, E.ROW_NAT88, 88), (24, 6, E.ROW_NAT88, 88), (25, 6, E.ROW_NAT88, 88),
             (27, 2, E.ROW_NAT, 32), (29, 1, E.ROW_NAT, 16), (31, 1, E.ROW_NAT, 1), (33, 1, E.ROW_NAT, 16),
-            (35, 1, E.ROW_NAT, 8), (37, 1, E.ROW_NAT, 1), (38, 5, E.ROW_NAT, 80)]
+            (35, 1, E.ROW_NAT, 8), (37, 1, E.ROW_NAT, 1), (38, 5, E.ROW_NAT, 80), (36, 1, E.ROW_NAT, 8)]
     for param, nt, rm, dim in vecs:
         frag = blob[off: off + nt * 16].reshape(nt, 4, 4)
         for t in range(nt):
@@ -237,6 +239,106 @@ def test_fp16x3_panels_reproduce_linear(name, raw_and_blob, f16_blob):
         y, pad = E.from_tiles(E.gemm_f16(f16_blob, name, tiles), rm, out_dim)
     assert pad == 0.0
     assert np.abs(y - ref).max() / np.abs(ref).max() < 5e-7, name
+
+
+# ------------------------------------------------------------------ bf16 plane region (backward data-gradient chains)
+def _bf16(x):
+    """round to nearest even to bf16, returned as float32"""
+    u = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def _split_bf16(x):
+    hi = _bf16(x)
+    return hi, _bf16(np.asarray(x, np.float32) - hi)
+
+
+# (name, param, raw shape, n_out, n_in, row map, col map, out_dim, in_dim, k-steps) in the order of stream B_VTB
+BWD_MATS = [("RW2T", 34, (8, 16), 1, 1, E.ROW_NAT, E.COL_NAT, 16, 8), ("RW0T", 32, (16, 83), 5, 1, E.ROW_NAT, E.COL_NAT, 80, 16),
+            ("MLP2T", 11, (80, 160), 10, 5, E.ROW_NAT, E.COL_NAT, 160, 80), ("MLP0T", 10, (160, 160), 10, 10, E.ROW_NAT, E.COL_NAT, 160, 160),
+            ("MERGET", 9, (80, 80), 5, 5, E.ROW_SLOT20, E.COL_NAT, 80, 80), ("QT", 6, (80, 80), 5, 5, E.ROW_NAT, E.COL_SLOT20, 80, 80),
+            ("KT", 7, (80, 80), 5, 5, E.ROW_NAT, E.COL_SLOT20, 80, 80), ("VT", 8, (80, 80), 5, 5, E.ROW_NAT, E.COL_SLOT20, 80, 80)]
+
+
+@pytest.fixture(scope="module")
+def bwd_blob(lib, raw_and_blob):
+    raw, _ = raw_and_blob
+    n = lib.ufr_packed_bwd_halfwords()
+    pid, el, pl = (np.zeros(n, np.int32) for _ in range(3))
+    P32 = C.POINTER(C.c_int32)
+    assert lib.ufr_pack_plan_bwd(pid.ctypes.data_as(P32), el.ctypes.data_as(P32), pl.ctypes.data_as(P32)) == 0
+    blob = np.zeros(n, np.float32)
+    for p in np.unique(pid):
+        if p < 0:
+            continue
+        planes = _split_bf16(raw[p].astype(np.float32).reshape(-1))
+        for k in range(2):
+            sel = (pid == p) & (pl == k)
+            blob[sel] = planes[k][el[sel]]
+    return blob
+
+
+@pytest.mark.parametrize("mi", range(len(BWD_MATS)))
+def test_bf16x3_transposed_panels_reproduce_the_data_gradient(mi, raw_and_blob, bwd_blob):
+    """The exported plan of the backward region, pushed through the lane-level MFMA model with bf16 hi/lo planes and the
+    three plane products of csrc/weight_stream_f16.h, reproduces d in = W^T d out for every matrix of the view
+    transformer's data-gradient chain (csrc/view_dgrad.hip) to 16-bit-split accuracy."""
+    raw, _ = raw_and_blob
+    f0 = 0
+    for name, param, shape, n_out, n_in, rm, cm, out_dim, in_dim in BWD_MATS[:mi]:
+        f0 += ((n_in + 1) // 2) * n_out * 2
+    name, param, shape, n_out, n_in, rm, cm, out_dim, in_dim = BWD_MATS[mi]
+    W = raw[param].reshape(shape).astype(np.float32)
+    dy = np.random.default_rng(300 + mi).standard_normal((16, in_dim)).astype(np.float32)
+    tiles = E.to_tiles(dy, cm, n_in, in_dim).astype(np.float32)
+    ref = dy.astype(np.float64) @ W.astype(np.float64)[:in_dim, :out_dim]        # (16, out_dim) = dY W
+    out = np.zeros((n_out, 64, 4), np.float32)
+    zero = np.zeros((64, 4), np.float32)
+    for s in range((n_in + 1) // 2):
+        ta, tb = tiles[2 * s], (tiles[2 * s + 1] if 2 * s + 1 < n_in else zero)
+        xb = [np.concatenate([pa, pb], axis=1) for pa, pb in zip(_split_bf16(ta), _split_bf16(tb))]
+        for to in range(n_out):
+            f = f0 + (s * n_out + to) * 2
+            a = [bwd_blob[(f + p) * 512:(f + p + 1) * 512].reshape(64, 8) for p in range(2)]
+            for pa, pb in ((1, 0), (0, 1), (0, 0)):
+                out[to] = E.mfma_f16(a[pa], xb[pb], out[to])
+    y, pad = E.from_tiles(out, rm, out_dim)
+    assert pad == 0.0
+    assert np.abs(y - ref).max() / np.abs(ref).max() < 3e-5, name
+
+
+def test_mfma_identity_transposes_a_tile_into_contraction_layout():
+    """csrc/wgrad_stream.hip: a stored tile (lane (g, j): features 4g..4g+3 of token j) fed as the A operand of the 16x16x32
+    MFMA against the selector B[8g + i][n] = (i < 4 and 4g + i == n) comes out as lane (g', j') = feature j', tokens
+    4g'..4g'+3 -- and two such operands contract to sum_t dY[o][t] X[i][t]."""
+    rng = np.random.default_rng(7)
+    dY, X = (_bf16(rng.standard_normal((2, 16, 16))) for _ in range(2))          # [column tile][feature][token]
+    sel = np.zeros((64, 8), np.float32)
+    for lane in range(64):
+        g, j = lane >> 4, lane & 15
+        if (j >> 2) == g:
+            sel[lane, j & 3] = 1.0
+
+    def frag(V):
+        parts = []
+        for c in range(2):
+            a = np.zeros((64, 8), np.float32)
+            for lane in range(64):
+                g, j = lane >> 4, lane & 15
+                a[lane, :4] = V[c, 4 * g:4 * g + 4, j]
+            parts.append(E.mfma_f16(a, sel, np.zeros((64, 4), np.float32)))
+        for lane in range(64):                                                 # lane = feature j', registers = tokens 4g' + r
+            g, j = lane >> 4, lane & 15
+            for c in range(2):
+                assert np.array_equal(parts[c][lane], V[c, j, 4 * g:4 * g + 4])
+        return np.concatenate(parts, axis=1)
+
+    acc = E.mfma_f16(frag(dY), frag(X), np.zeros((64, 4), np.float32))
+    ref = np.einsum("cot,cit->oi", dY.astype(np.float64), X.astype(np.float64))
+    for lane in range(64):
+        g, j = lane >> 4, lane & 15
+        np.testing.assert_allclose(acc[lane], ref[4 * g:4 * g + 4, j], rtol=1e-6, atol=1e-6)
 
 
 def test_header_is_usable_from_plain_c(lib, tmp_path):

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # UFR_LIB selects an alternative in-tree build (A/B kernel variants during development)
 LIB_PATH = os.environ.get("UFR_LIB") or os.path.join(HERE, "lib", "libufr.so")
 
-ABI_VERSION = 302   # = UFR_ABI_VERSION of include/ufr.h; load() refuses a library built against another header
+ABI_VERSION = 400   # = UFR_ABI_VERSION of include/ufr.h; load() refuses a library built against another header
 MAX_VIEWS = 7
 NUM_STAGES = 3
 TOKEN_DIM = 80
@@ -76,6 +76,8 @@ SIGNATURES = {
     "ufr_pack_plan": (C.c_int, [C.POINTER(i32), C.POINTER(i32)]),
     "ufr_packed_fp32_floats": (sz, []),
     "ufr_packed_f16_halfwords": (sz, []),
+    "ufr_packed_bwd_halfwords": (sz, []),
+    "ufr_pack_plan_bwd": (C.c_int, [C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "ufr_pack_plan_f16": (C.c_int, [C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "ufr_frame_workspace_bytes": (sz, [C.POINTER(FrameDesc)]),
     "ufr_frame_prepare": (C.c_int, [C.POINTER(FrameDesc), vp, sz, C.POINTER(Frame), vp]),
@@ -89,8 +91,8 @@ SIGNATURES = {
     "ufr_composite": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
     "ufr_composite_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
     "ufr_aggregate_bwd_workspace_bytes": (sz, [i32, i32, i32]),
-    "ufr_aggregate_bwd": (C.c_int, [C.POINTER(RawWeights), C.POINTER(RawGrads), vp, vp, vp, vp, i32, i32, i32, vp, vp, vp,
-                                    vp, vp, vp, i32, vp]),
+    "ufr_aggregate_bwd": (C.c_int, [C.POINTER(RawWeights), C.POINTER(RawGrads), vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp,
+                                    vp, vp, i32, vp]),
     "ufr_project_gather_bwd": (C.c_int, [C.POINTER(Frame), C.POINTER(RawWeights), C.POINTER(RawGrads), vp, i32, vp, vp,
                                          i32, i32, vp, vp, vp, C.POINTER(vp), C.POINTER(vp), i32, vp]),
     "ufr_sample_importance_pool": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
@@ -98,7 +100,8 @@ SIGNATURES = {
     "ufr_ray_transform_workspace_bytes": (sz, [i32]),
     "ufr_ray_transform": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, i32, vp]),
     "ufr_ray_transform_bwd": (C.c_int, [C.POINTER(RawWeights), C.POINTER(RawGrads), vp, vp, i32, i32, vp, vp, vp, i32, vp, i32, vp]),
-    "ufr_view_transform_bwd": (C.c_int, [C.POINTER(RawWeights), C.POINTER(RawGrads), vp, vp, vp, vp, vp, vp, i32, i32, vp, i32, vp]),
+    "ufr_view_transform_bwd_workspace_bytes": (sz, [i32, i32]),
+    "ufr_view_transform_bwd": (C.c_int, [C.POINTER(RawWeights), C.POINTER(RawGrads), vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, vp]),
     "ufr_render_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "ufr_default_chunk_rays": (i32, []),
     "ufr_render_rays": (C.c_int, [C.POINTER(RenderArgs), vp]),

@@ -82,15 +82,23 @@ __global__ void __launch_bounds__(256) pack_weights_f16_kernel(RawPtrs raw, unsi
                                                                 int* __restrict__ flag) {
   int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= n) return;
-  int p, e, plane;
-  plan_entry_f16(h, &p, &e, &plane);
+  int p, e, plane, stream;
+  plan_entry_f16(h, &p, &e, &plane, &stream);
   unsigned short out = 0;
   if (p >= 0) {
-    const float w = raw.p[p][e] * kWScale;
-    if (!(fabsf(w) <= 65504.f)) atomicOr(flag, 4);   // bit 2 of the sticky range status (include/ufr.h)
-    const _Float16 hi = (_Float16)w;
-    const _Float16 lo = (_Float16)(w - (float)hi);
-    out = __builtin_bit_cast(unsigned short, plane == 0 ? hi : lo);
+    if (f16_stream_is_bf16(stream)) {
+      // backward streams: bf16 planes of the unscaled weight, hi = bf16(w), lo = bf16(w - hi) (round to nearest even)
+      const float w = raw.p[p][e];
+      const __bf16 hi = (__bf16)w;
+      const __bf16 lo = (__bf16)(w - (float)hi);
+      out = __builtin_bit_cast(unsigned short, plane == 0 ? hi : lo);
+    } else {
+      const float w = raw.p[p][e] * kWScale;
+      if (!(fabsf(w) <= 65504.f)) atomicOr(flag, 4);   // bit 2 of the sticky range status (include/ufr.h)
+      const _Float16 hi = (_Float16)w;
+      const _Float16 lo = (_Float16)(w - (float)hi);
+      out = __builtin_bit_cast(unsigned short, plane == 0 ? hi : lo);
+    }
   }
   packed[h] = out;
 }
@@ -99,7 +107,8 @@ hipError_t launch_pack_weights(const RawPtrs& raw, float* packed, int* range_fla
   const int n = blob_floats(), first = vec_region_offset();
   hipLaunchKernelGGL(pack_weights_kernel, dim3((n - first + 255) / 256), dim3(256), 0, s, raw, packed, first, n);
   unsigned short* planes = reinterpret_cast<unsigned short*>(packed + n);
-  hipLaunchKernelGGL(pack_weights_f16_kernel, dim3((kF16Halfwords + 255) / 256), dim3(256), 0, s, raw, planes, kF16Halfwords, range_flag);
+  constexpr int n_half = kF16Halfwords + kBwdHalfwords;   // forward fp16 planes, then the backward kernels' bf16 planes
+  hipLaunchKernelGGL(pack_weights_f16_kernel, dim3((n_half + 255) / 256), dim3(256), 0, s, raw, planes, n_half, range_flag);
   return hipGetLastError();
 }
 

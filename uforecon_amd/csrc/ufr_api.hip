@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "bwd_common.h"
+#include "bwd_tape.h"
 #include "ufr_internal.h"
 #include "ufr_layout_f16.h"
 
@@ -150,7 +151,7 @@ int status_slot(StatusSlot** out) {
 int status_message(int bits, const char* who) {
   return fail(UFR_ERR_RANGE, "%s: range status 0x%x:%s%s%s (include/ufr.h: ufr_status_poll)", who, bits,
               (bits & 1) ? " a dense-layer input reached |x| >= 4094 (fp16 planes overflowed);" : "",
-              (bits & 2) ? " a transformer kernel produced non-finite output rows;" : "",
+              (bits & 2) ? " NaN among the token / dir inputs handed to a transformer kernel;" : "",
               (bits & 4) ? " ufr_weights_pack met a weight that is not finite or |w| >= 255.8;" : "");
 }
 
@@ -202,14 +203,21 @@ int ufr_version(void) { return UFR_ABI_VERSION; }
 const char* ufr_last_error(void) { return g_err; }
 
 // ------------------------------------------------------------------ weights
-// [fp32 region | fp16 plane region | 16-byte tail (reserved)]
-size_t ufr_packed_weights_bytes(void) { return (size_t)blob_floats() * sizeof(float) + (size_t)kF16Bytes + 16; }
+// [fp32 region | fp16 plane region (forward) | bf16 plane region (backward data-gradient chains) | 16-byte tail (reserved)]
+size_t ufr_packed_weights_bytes(void) { return (size_t)blob_floats() * sizeof(float) + (size_t)kF16Bytes + (size_t)kBwdBytes + 16; }
+size_t ufr_packed_bwd_halfwords(void) { return (size_t)kBwdHalfwords; }
 size_t ufr_packed_fp32_floats(void) { return (size_t)blob_floats(); }
 size_t ufr_packed_f16_halfwords(void) { return (size_t)kF16Halfwords; }
 
 int ufr_pack_plan_f16(int32_t* param_id, int32_t* elem, int32_t* plane) {
   UFR_REQUIRE(param_id && elem && plane, "ufr_pack_plan_f16: null output");
   for (int h = 0; h < kF16Halfwords; ++h) plan_entry_f16(h, &param_id[h], &elem[h], &plane[h]);
+  return UFR_OK;
+}
+
+int ufr_pack_plan_bwd(int32_t* param_id, int32_t* elem, int32_t* plane) {
+  UFR_REQUIRE(param_id && elem && plane, "ufr_pack_plan_bwd: null output");
+  for (int h = 0; h < kBwdHalfwords; ++h) plan_entry_f16(kF16Halfwords + h, &param_id[h], &elem[h], &plane[h]);
   return UFR_OK;
 }
 
@@ -448,25 +456,66 @@ int ufr_composite_bwd(const float* z, const float* radiance, const int32_t* row,
   return UFR_OK;
 }
 
+// The three kernels of the view transformer's backward (bwd_tape.h) over a caller workspace:
+// [tape | dY tiles | token0 scratch | radiance scratch]
+struct ViewBwdWs { float *tape, *dbuf, *token0, *radiance; int blocks; };
+static ViewBwdWs carve_view_bwd(Carver& c, int P, int NV) {
+  ViewBwdWs w;
+  w.blocks = view_tape_blocks(P, NV);
+  w.tape = c.f32((size_t)w.blocks * TV_COUNT * kBlockCols * kTileFloats);
+  w.dbuf = c.f32((size_t)w.blocks * DV_COUNT * kBlockCols * kTileFloats);
+  w.token0 = c.f32((size_t)P * UFR_TOKEN_DIM);
+  w.radiance = c.f32((size_t)P * 3);
+  return w;
+}
+static int view_bwd_impl(const void* packed, const GradPtrs& gp, const float* x_tokens, const float* rgb, const float* dir,
+                         const float* d_tok_a, const float* d_tok_b, const float* d_radiance, int P, int NV, float* d_pv,
+                         const ViewBwdWs& w, bool lowp, int* status, hipStream_t s) {
+  UFR_REQUIRE((unsigned long long)P * (NV + 1) * UFR_TOKEN_DIM < (1ull << 30),
+              "view transformer backward: %d points x %d tokens exceed the 2^30 token values one call addresses; chunk the points", P, NV + 1);
+  const float* pk = static_cast<const float*>(packed);
+  {
+    ProfScope p("view_tape", s);
+    UFR_HIP(launch_view_tape(pk, x_tokens, rgb, dir, P, NV, w.token0, w.radiance, w.tape, lowp, status, s));
+  }
+  {
+    ProfScope p("view_dgrad", s);
+    UFR_HIP(launch_view_dgrad(pk, w.tape, rgb, d_tok_a, d_tok_b, d_radiance, P, NV, w.dbuf, d_pv, lowp, s));
+  }
+  {
+    ProfScope p("view_wgrad", s);
+    UFR_HIP(launch_view_wgrad(w.tape, w.dbuf, w.blocks, gp, lowp, s));
+  }
+  return UFR_OK;
+}
+
+size_t ufr_view_transform_bwd_workspace_bytes(int32_t P, int32_t NV) {
+  if (P <= 0 || NV < 2 || NV > UFR_MAX_VIEWS) return 0;
+  Carver c(nullptr);
+  carve_view_bwd(c, P, NV);
+  return c.off;
+}
+
 size_t ufr_aggregate_bwd_workspace_bytes(int32_t RN, int32_t SN, int32_t NV) {
-  (void)NV;
+  if (RN <= 0 || SN <= 0 || NV < 2 || NV > UFR_MAX_VIEWS) return 0;
   Carver c(nullptr);
   c.f32((size_t)RN * SN * UFR_TOKEN_DIM);
   c.f32((size_t)RN * SN * UFR_TOKEN_DIM);
   c.f32((size_t)SN * 8);
+  carve_view_bwd(c, RN * SN, NV);
   return c.off;
 }
 
-int ufr_aggregate_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const float* x_tokens, const float* rgb,
-                      const float* dir, const float* token0, int32_t RN, int32_t SN, int32_t NV, const float* d_radiance,
-                      const float* d_srdf, float* d_pv, void* workspace, float* debug_view, float* debug_ray,
+int ufr_aggregate_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const void* packed_weights, const float* x_tokens,
+                      const float* rgb, const float* dir, const float* token0, int32_t RN, int32_t SN, int32_t NV,
+                      const float* d_radiance, const float* d_srdf, float* d_pv, void* workspace, float* debug_ray,
                       int32_t precision, ufr_stream stream) {
   RawPtrs rp;
   GradPtrs gp;
   int rc = raw_and_grads(raw, grads, rp, gp, "ufr_aggregate_bwd");
   if (rc != UFR_OK) return rc;
   UFR_PRECISION(precision, lowp, "ufr_aggregate_bwd");
-  UFR_REQUIRE(x_tokens && rgb && dir && token0 && d_radiance && d_srdf && d_pv && workspace, "ufr_aggregate_bwd: null argument");
+  UFR_REQUIRE(packed_weights && x_tokens && rgb && dir && token0 && d_radiance && d_srdf && d_pv && workspace, "ufr_aggregate_bwd: null argument");
   UFR_REQUIRE(NV >= 2 && NV <= UFR_MAX_VIEWS, "ufr_aggregate_bwd: NV=%d unsupported", NV);
   UFR_REQUIRE(RN > 0 && SN >= 16 && SN % 16 == 0 && SN <= 256, "ufr_aggregate_bwd: SN=%d must be a multiple of 16 in [16,256]", SN);
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -474,16 +523,16 @@ int ufr_aggregate_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, co
   float* d_tok_a = c.f32((size_t)RN * SN * UFR_TOKEN_DIM);
   float* d_tok_b = c.f32((size_t)RN * SN * UFR_TOKEN_DIM);
   float* order_pe = c.f32((size_t)SN * 8);
+  const ViewBwdWs vw = carve_view_bwd(c, RN * SN, NV);
+  StatusSlot* sl = nullptr;
+  rc = status_slot(&sl);
+  if (rc != UFR_OK) return rc;
   UFR_HIP(launch_order_pe(order_pe, SN, s));
   {
     ProfScope p("ray_bwd", s);
     UFR_HIP(launch_ray_bwd(rp, gp, token0, nullptr, false, order_pe, d_srdf, RN, SN, d_tok_a, d_tok_b, debug_ray, lowp, s));
   }
-  {
-    ProfScope p("view_bwd", s);
-    UFR_HIP(launch_view_bwd(rp, gp, x_tokens, rgb, dir, d_tok_a, d_tok_b, d_radiance, RN * SN, NV, d_pv, debug_view, lowp, s));
-  }
-  return UFR_OK;
+  return view_bwd_impl(packed_weights, gp, x_tokens, rgb, dir, d_tok_a, d_tok_b, d_radiance, RN * SN, NV, d_pv, vw, lowp, sl->dev, s);
 }
 
 int ufr_project_gather_bwd(const ufr_frame* frame, const ufr_raw_weights* raw, const ufr_raw_grads* grads,
@@ -587,20 +636,24 @@ int ufr_ray_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads
   return UFR_OK;
 }
 
-int ufr_view_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const float* x_tokens, const float* rgb,
-                           const float* dir, const float* d_token0_a, const float* d_token0_b, const float* d_radiance,
-                           int32_t P, int32_t NV, float* d_pv, int32_t precision, ufr_stream stream) {
+int ufr_view_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const void* packed_weights,
+                           const float* x_tokens, const float* rgb, const float* dir, const float* d_token0_a,
+                           const float* d_token0_b, const float* d_radiance, int32_t P, int32_t NV, float* d_pv, void* workspace,
+                           int32_t precision, ufr_stream stream) {
   RawPtrs rp;
   GradPtrs gp;
   int rc = raw_and_grads(raw, grads, rp, gp, "ufr_view_transform_bwd");
   if (rc != UFR_OK) return rc;
   UFR_PRECISION(precision, lowp, "ufr_view_transform_bwd");
-  UFR_REQUIRE(x_tokens && rgb && dir && d_token0_a && d_radiance && d_pv, "ufr_view_transform_bwd: null argument");
+  UFR_REQUIRE(packed_weights && x_tokens && rgb && dir && d_token0_a && d_radiance && d_pv && workspace, "ufr_view_transform_bwd: null argument");
   UFR_REQUIRE(NV >= 2 && NV <= UFR_MAX_VIEWS && P > 0, "ufr_view_transform_bwd: P=%d NV=%d", P, NV);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  ProfScope p("view_bwd", s);
-  UFR_HIP(launch_view_bwd(rp, gp, x_tokens, rgb, dir, d_token0_a, d_token0_b, d_radiance, P, NV, d_pv, nullptr, lowp, s));
-  return UFR_OK;
+  Carver c(workspace);
+  const ViewBwdWs vw = carve_view_bwd(c, P, NV);
+  StatusSlot* sl = nullptr;
+  rc = status_slot(&sl);
+  if (rc != UFR_OK) return rc;
+  return view_bwd_impl(packed_weights, gp, x_tokens, rgb, dir, d_token0_a, d_token0_b, d_radiance, P, NV, d_pv, vw, lowp, sl->dev, s);
 }
 
 // ------------------------------------------------------------------ whole-path inference

@@ -75,6 +75,15 @@ struct GradPtrs;
 hipError_t launch_view_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* x_tokens, const float* rgbm,
                            const float* dirs, const float* d_tok_a, const float* d_tok_b, const float* d_radiance, int P,
                            int NV, float* d_pv, float* dbg, bool lowp, hipStream_t s);
+// The streaming view-transformer backward (round 4; bwd_tape.h): the forward again with a tape, the data-gradient chain,
+// the weight-gradient contraction.  tape: view_tape_blocks(P, NV) blocks of TV_COUNT tiles; dbuf: as many blocks of DV_COUNT.
+int view_tape_blocks(int P, int NV);
+hipError_t launch_view_tape(const float* packed, const float* x_tokens, const float* rgb, const float* dir, int P, int NV,
+                            float* token0, float* radiance, float* tape, bool lowp, int* status, hipStream_t s);
+hipError_t launch_view_dgrad(const float* packed, const float* tape, const float* rgbm, const float* d_tok_a,
+                             const float* d_tok_b, const float* d_radiance, int P, int NV, float* dbuf, float* d_pv, bool lowp,
+                             hipStream_t s);
+hipError_t launch_view_wgrad(const float* tape, const float* dbuf, int n_blocks, const GradPtrs& gp, bool lowp, hipStream_t s);
 // tok_row (nullable): pool row of sample (ray, s) for token0 AND for the d_tok_a / d_tok_b rows it produces; accumulate:
 // d_tok_* += (every pool row is written once per launch, so a plain read-modify-write)
 hipError_t launch_ray_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* token0, const int* tok_row, bool accumulate,

@@ -75,17 +75,21 @@ enum Param : int {
   P_VIEW_TOKEN, P_VARIANCE, P_COUNT
 };
 
-struct MatDesc { int param, k_raw, n_out, n_in, rm, cm, out_dim, in_dim; };
+// trans: the matrix is used TRANSPOSED (data-gradient chains of the backward kernels): out = W^T in, i.e. element
+// (row, col) of the operand is raw[col * k_raw + row]; out_dim / in_dim are those of the transposed product.
+struct MatDesc { int param, k_raw, n_out, n_in, rm, cm, out_dim, in_dim, trans; };
 struct VecDesc { int param, n_tiles, rm, dim; };
 
 enum Mat : int {
   M_VT_Q = 0, M_VT_K, M_VT_V, M_VT_MERGE, M_VT_MLP0, M_VT_MLP2,
   M_RT_Q, M_RT_K, M_RT_V, M_RT_MERGE, M_RT_MLP0, M_RT_MLP2,
-  M_DM0, M_DM2, M_DM4, M_RW0, M_RW2, M_RW4, M_COUNT
+  M_DM0, M_DM2, M_DM4, M_RW0, M_RW2, M_RW4, M_COUNT,
+  // transposed operands of the data-gradient chain (view_dgrad.hip); not part of the forward streams
+  M_RW2T = M_COUNT, M_RW0T, M_VT_MLP2T, M_VT_MLP0T, M_VT_MERGET, M_VT_QT, M_VT_KT, M_VT_VT, M_ALL_COUNT
 };
 enum Vec : int {
   V_VT_N1W = 0, V_VT_N1B, V_VT_N2W, V_VT_N2B, V_RT_N1W, V_RT_N1B, V_RT_N2W, V_RT_N2B,
-  V_DM_B0, V_DM_B2, V_DM_B4, V_RW_B0, V_RW_B2, V_RW_B4, V_VIEW_TOKEN, V_COUNT
+  V_DM_B0, V_DM_B2, V_DM_B4, V_RW_B0, V_RW_B2, V_RW_B4, V_VIEW_TOKEN, V_RW_W4, V_COUNT
 };
 
 __host__ __device__ constexpr MatDesc mat_desc(int m) {
@@ -108,8 +112,17 @@ __host__ __device__ constexpr MatDesc mat_desc(int m) {
     case M_RW0: return {P_RW_W0, 83, 1, 6, ROW_NAT, COL_RW0, 16, 83};
     case M_RW2: return {P_RW_W2, 16, 1, 1, ROW_NAT, COL_NAT, 8, 16};
     case M_RW4: return {P_RW_W4, 8, 1, 1, ROW_NAT, COL_NAT, 1, 8};
+    // d in = W^T d out: rows follow the layout of the layer's INPUT tiles, columns that of its OUTPUT tiles
+    case M_RW2T: return {P_RW_W2, 16, 1, 1, ROW_NAT, COL_NAT, 16, 8, 1};
+    case M_RW0T: return {P_RW_W0, 83, 5, 1, ROW_NAT, COL_NAT, 80, 16, 1};          // the 80 feature rows (dir has no consumer)
+    case M_VT_MLP2T: return {P_VT_MLP2, 160, 10, 5, ROW_NAT, COL_NAT, 160, 80, 1};
+    case M_VT_MLP0T: return {P_VT_MLP0, 160, 10, 10, ROW_NAT, COL_NAT, 160, 160, 1};
+    case M_VT_MERGET: return {P_VT_MERGE, 80, 5, 5, ROW_SLOT20, COL_NAT, 80, 80, 1};
+    case M_VT_QT: return {P_VT_Q, 80, 5, 5, ROW_NAT, COL_SLOT20, 80, 80, 1};
+    case M_VT_KT: return {P_VT_K, 80, 5, 5, ROW_NAT, COL_SLOT20, 80, 80, 1};
+    case M_VT_VT: return {P_VT_V, 80, 5, 5, ROW_NAT, COL_SLOT20, 80, 80, 1};
   }
-  return {0, 0, 0, 0, 0, 0, 0, 0};
+  return {0, 0, 0, 0, 0, 0, 0, 0, 0};
 }
 __host__ __device__ constexpr VecDesc vec_desc(int v) {
   switch (v) {
@@ -128,6 +141,7 @@ __host__ __device__ constexpr VecDesc vec_desc(int v) {
     case V_RW_B2: return {P_RW_B2, 1, ROW_NAT, 8};
     case V_RW_B4: return {P_RW_B4, 1, ROW_NAT, 1};
     case V_VIEW_TOKEN: return {P_VIEW_TOKEN, 5, ROW_NAT, 80};
+    case V_RW_W4: return {P_RW_W4, 1, ROW_NAT, 8};     // the last radiance-MLP layer as a vector (view_dgrad.hip)
   }
   return {0, 0, 0, 0};
 }

@@ -65,14 +65,21 @@ constexpr int kF16Slots = UFR_F16_SLOTS;
 constexpr int kF16Depth = UFR_F16_DEPTH;
 static_assert(kF16Depth >= 1 && kF16Depth * kPlanes <= kF16ChunkFrags, "read-ahead must stay inside one chunk");
 
-enum F16Stream { B_VT = 0, B_RT1 = 1, B_RT2 = 2, B_COUNT = 3 };
+// B_COUNT forward streams (fp16 planes, this header's arithmetic), then the data-gradient streams of the backward kernels:
+// the same fragment / panel / chunk format, but TRANSPOSED matrices (MatDesc::trans) as bf16 planes without a scale
+// (hi = bf16(w), lo = bf16(w - hi): gradients need the exponent range, and 16 significand bits per operand are ample for
+// the 1e-3 gradient tolerance) -- they follow the forward region in the blob, so one stream base formula serves both.
+//   B_VTB  view transformer backwards  rw2^T | rw0^T | mlp2^T | mlp0^T | merge^T | q^T | k^T | v^T
+enum F16Stream { B_VT = 0, B_RT1 = 1, B_RT2 = 2, B_COUNT = 3, B_VTB = 3, B_ALL = 4 };
+__host__ __device__ constexpr bool f16_stream_is_bf16(int S) { return S >= B_COUNT; }
 
 struct Panel { int mat, s; };
 
 __host__ __device__ constexpr int ksteps(int m) { return (mat_desc(m).n_in + 1) / 2; }
 
 __host__ __device__ constexpr int f16_n_panels(int S) {
-  return S == B_VT ? 3 * 3 + 3 + 5 + 5 + 3 + 1 + 1 : S == B_RT1 ? 6 : 3 + 3 + 6 + 6 + 3 + 1 + 1;
+  return S == B_VT ? 3 * 3 + 3 + 5 + 5 + 3 + 1 + 1 : S == B_RT1 ? 6 : S == B_RT2 ? 3 + 3 + 6 + 6 + 3 + 1 + 1
+       : 1 + 1 + 3 + 5 + 3 + 3 * 3;   // B_VTB
 }
 // consumption order.  q and k (view) / k and v (ray) are interleaved per k-step: x is split once per step.
 __host__ __device__ constexpr Panel f16_panel(int S, int i) {
@@ -91,6 +98,19 @@ __host__ __device__ constexpr Panel f16_panel(int S, int i) {
     return {i == 0 ? M_RW2 : M_RW4, 0};
   }
   if (S == B_RT1) return {i % 2 == 0 ? M_RT_K : M_RT_V, i / 2};
+  if (S == B_VTB) {
+    if (i < 1) return {M_RW2T, 0};
+    i -= 1;
+    if (i < 1) return {M_RW0T, 0};
+    i -= 1;
+    if (i < 3) return {M_VT_MLP2T, i};
+    i -= 3;
+    if (i < 5) return {M_VT_MLP0T, i};
+    i -= 5;
+    if (i < 3) return {M_VT_MERGET, i};
+    i -= 3;
+    return {i < 3 ? M_VT_QT : i < 6 ? M_VT_KT : M_VT_VT, i % 3};
+  }
   if (i < 3) return {M_RT_Q, i};
   i -= 3;
   if (i < 3) return {M_RT_MERGE, i};
@@ -104,7 +124,8 @@ __host__ __device__ constexpr Panel f16_panel(int S, int i) {
   return {i == 0 ? M_DM2 : M_DM4, 0};
 }
 __host__ __device__ constexpr int f16_mat_stream(int m) {
-  return (m == M_RT_K || m == M_RT_V) ? B_RT1
+  return m >= M_COUNT ? B_VTB
+         : (m == M_RT_K || m == M_RT_V) ? B_RT1
          : (m == M_RT_Q || m == M_RT_MERGE || m == M_RT_MLP0 || m == M_RT_MLP2 || m == M_DM0 || m == M_DM2 || m == M_DM4)
              ? B_RT2
              : B_VT;
@@ -135,6 +156,9 @@ __host__ __device__ constexpr int f16_stream_base_frags(int S) {   // first frag
 constexpr int kF16FragsPadded = f16_stream_base_frags(B_COUNT);
 constexpr int kF16Halfwords = kF16FragsPadded * 512;                  // fp16 elements in the region
 constexpr int kF16Bytes = kF16FragsPadded * 1024;
+constexpr int kBwdFragsPadded = f16_stream_base_frags(B_ALL) - kF16FragsPadded;   // the bf16 streams behind it
+constexpr int kBwdHalfwords = kBwdFragsPadded * 512;
+constexpr int kBwdBytes = kBwdFragsPadded * 1024;
 
 // input feature of k-slot (g, i) of panel step s (or -1): accumulator tiles 2s and 2s+1 of the producer
 __host__ __device__ constexpr int f16_col(int m, int s, int g, int i) {
@@ -143,13 +167,15 @@ __host__ __device__ constexpr int f16_col(int m, int s, int g, int i) {
   return tile < d.n_in ? col_map(d.cm, tile, g, i & 3, d.in_dim) : -1;
 }
 
-// source of halfword h of the fp16 plane region: parameter, element, plane (param -1 = zero)
-__host__ __device__ inline void plan_entry_f16(int h, int* param, int* elem, int* plane) {
+// source of halfword h of the plane regions (h < kF16Halfwords: fp16 forward streams; beyond: the bf16 backward streams):
+// parameter, element, plane (param -1 = zero)
+__host__ __device__ inline void plan_entry_f16(int h, int* param, int* elem, int* plane, int* stream = nullptr) {
   *param = -1; *elem = 0; *plane = 0;
   int f = h >> 9;                 // fragment
   const int lane = (h >> 3) & 63, i = h & 7;
   int S = 0;
-  while (S + 1 < B_COUNT && f >= f16_stream_base_frags(S + 1)) ++S;
+  while (S + 1 < B_ALL && f >= f16_stream_base_frags(S + 1)) ++S;
+  if (stream) *stream = S;
   f -= f16_stream_base_frags(S);
   if (f >= f16_stream_frags(S)) return;  // tail padding of the stream's last chunk
   int pi = 0;
@@ -160,7 +186,7 @@ __host__ __device__ inline void plan_entry_f16(int h, int* param, int* elem, int
   *plane = f % kPlanes;
   const int row = row_map(d.rm, to, lane & 15, d.out_dim);
   const int col = f16_col(p.mat, p.s, lane >> 4, i);
-  if (row >= 0 && col >= 0) { *param = d.param; *elem = row * d.k_raw + col; }
+  if (row >= 0 && col >= 0) { *param = d.param; *elem = d.trans ? col * d.k_raw + row : row * d.k_raw + col; }
 }
 
 }  // namespace ufr

@@ -13,6 +13,7 @@
 // lane-local with quad DPP exchanges (L = 4) or ds_bpermute (other L).  LayerNorm, attention, elu and
 // the softmax run on the VALU and overlap with the other resident wave's MFMAs.
 #include <cstdlib>
+#include "bwd_tape.h"
 #include "ufr_internal.h"
 #include "weight_stream_f16.h"
 
@@ -37,8 +38,10 @@ __device__ __forceinline__ void zero_tiles(f32x4 (&t)[C][N]) {
 // LayerNorm over the 80 features of each token: 5 tiles x 4 regs in each of the 4 lane groups.  ACC: t holds raw
 // accumulators (2^kAccLog2 times the values): the normalised value is scale-free once the epsilon carries the square of
 // the scale, and with a power-of-two scale every intermediate is the exact multiple -- bit-identical to descaling first.
+// XH / RS (TAPE builds): the normalised input and 1 / sigma of the TRUE values (raw accumulators: kAccScale times the
+// raw one), which the backward needs.
 template <int C, int VW, int VB, bool ACC = false, class WS>
-__device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const WS& ws, int g) {
+__device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const WS& ws, int g, f32x4 (*XH)[5] = nullptr, float* RS = nullptr) {
   constexpr float eps = ACC ? 1e-5f * kAccScale * kAccScale : 1e-5f;
 #pragma unroll
   for (int c = 0; c < C; ++c) {
@@ -55,9 +58,11 @@ __device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const WS& ws, int
         q = fmaf(d, d, q);
       }
     const float rstd = 1.f / sqrtf(sum_groups(q) * (1.f / 80.f) + eps);
+    if (RS) RS[c] = ACC ? rstd * kAccScale : rstd;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const f32x4 gw = vec_frag<VW>(ws, i, g), gb = vec_frag<VB>(ws, i, g);
+      if (XH) XH[c][i] = (t[c][i] - mean) * rstd;
       t[c][i] = (t[c][i] - mean) * rstd * gw + gb;
     }
   }
@@ -88,7 +93,8 @@ __device__ unsigned long long g_vt_wave[4096 * 2];  // start / end tick of every
 constexpr int kVtBlock = UFR_VT_BLOCK;
 constexpr int kVtWaves = kVtBlock / 64;
 
-template <int L, int C, bool LOWP>
+// TAPE: the instantiation the backward launches (bwd_tape.h): the same arithmetic, plus one store per activation tile.
+template <int L, int C, bool LOWP, bool TAPE = false>
 __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel(const float* __restrict__ packed,
                                                                              const float* __restrict__ x_tokens,
                                                                              const float* __restrict__ x_point,
@@ -97,14 +103,16 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
                                                                              float* __restrict__ token0,
                                                                              float* __restrict__ radiance,
                                                                              float* __restrict__ view_out,
-                                                                             int* __restrict__ status) {
+                                                                             int* __restrict__ status,
+                                                                             float* __restrict__ tape = nullptr) {
   constexpr int NV = L - 1;
   constexpr int PPT = 16 / L;          // points per column tile
   // L = 6 (five source views) fills only 12 of a tile's 16 columns with whole points: with two column tiles per wave a
   // fifth point STRADDLES them -- tile 0 = points 0, 1 and tokens 0..3 of point 2; tile 1 = points 3, 4, then tokens 4, 5 of
   // point 2 in columns 12, 13 (30 of 32 columns).  The dense layers do not care where a token sits; the attention and the
   // softmax exchange tokens of a point through the schedule below.
-  constexpr bool STRADDLE = (L == 6 && C == 2);
+  constexpr bool STRADDLE = (L == 6 && C == 2 && !TAPE);   // the tape's consumers use the plain slot map
+  static_assert(!TAPE || C == kBlockCols, "tape blocks");
   constexpr int PPW = STRADDLE ? 5 : PPT * C;         // points per wave iteration
   extern __shared__ __attribute__((aligned(16))) char smem[];
   auto ws = wstream_f16_begin<kVtWaves, LOWP>(packed, smem);
@@ -173,6 +181,9 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
   for (int it = 0; it < n_iter; ++it) {
     const int grp = it * n_waves + wave_global;
     const bool wrap = it + 1 < n_iter;
+    auto tape_st = [&](int tile, int c, f32x4 v) __attribute__((always_inline)) {
+      if (grp < n_groups) st4(tape + tile_offset(TV_COUNT, (size_t)grp, tile, c) + lane * 4, v);
+    };
 #ifdef UFR_FUSION_PROBE
     // Feasibility probe for fusing the gather into this kernel: a synthetic producer phase with
     // the gather's per-iteration footprint -- 3 dependent rounds (projection -> footprint -> taps) of UFR_FUSION_PROBE
@@ -224,6 +235,12 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
       }
     }
     track_external(x, ws);
+    if constexpr (TAPE) {
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int t = 0; t < 5; ++t) tape_st(TV_X + t, c, x[c][t]);
+    }
     UFR_PHASE(0)  // token loads issued
     // ---------------- q,k projections (slot layout: lane group g <- heads 2g, 2g+1); x is split once per k-step
     // and feeds both matrices (stream order q0 k0 q1 k1 q2 k2)
@@ -251,6 +268,15 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
       });
       probe_gemm(q, ws);   // q, k stay raw accumulators: elu1_acc
       probe_gemm(k, ws);
+    }
+    if constexpr (TAPE) {
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+          tape_st(TV_Q + t, c, f32x4{elu1_acc(q[c][t][0]), elu1_acc(q[c][t][1]), elu1_acc(q[c][t][2]), elu1_acc(q[c][t][3])});
+          tape_st(TV_K + t, c, f32x4{elu1_acc(k[c][t][0]), elu1_acc(k[c][t][1]), elu1_acc(k[c][t][2]), elu1_acc(k[c][t][3])});
+        }
     }
     UFR_PHASE(1)  // q,k GEMMs
     // ---------------- linear attention over the L tokens of each point (linear_attention.py:31-45), written as
@@ -326,6 +352,18 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     zero_tiles(v);
     gemm_f16<M_VT_V, C, kVtWaves, false, true>(ws, x, v, wrap);   // raw accumulators: the descale joins the 1 / v_length
     UFR_PHASE(3)  // v GEMM
+    if constexpr (TAPE) {   // values / v_length, exactly as the message phase below forms them
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+          f32x4 vv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            vv[r] = (L & (L - 1)) == 0 ? v[c][t][r] * (kAccDescale / (float)L) : v[c][t][r] / ((float)L * kAccScale);
+          tape_st(TV_V + t, c, vv);
+        }
+    }
     f32x4 msg[C][5];
     if constexpr (STRADDLE) {
       static_for<2>([&](auto hi) __attribute__((always_inline)) {
@@ -389,12 +427,28 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     }
 
     UFR_PHASE(4)  // message
+    if constexpr (TAPE) {
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int t = 0; t < 5; ++t) tape_st(TV_MSG + t, c, msg[c][t]);
+    }
     // ---------------- merge + LayerNorm1 (transformer.py:51-52)
     f32x4 m[C][5];
     zero_tiles(m);
     gemm_f16<M_VT_MERGE, C, kVtWaves, false, true>(ws, msg, m, wrap);
     UFR_PHASE(5)  // merge GEMM
-    layer_norm80<C, V_VT_N1W, V_VT_N1B, true>(m, ws, g);
+    float rstd1[C] = {}, rstd2[C] = {};
+    if constexpr (TAPE) {
+      f32x4 xh[C][5];
+      layer_norm80<C, V_VT_N1W, V_VT_N1B, true>(m, ws, g, xh, rstd1);
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int t = 0; t < 5; ++t) { tape_st(TV_XH1 + t, c, xh[c][t]); tape_st(TV_M + t, c, m[c][t]); }
+    } else {
+      layer_norm80<C, V_VT_N1W, V_VT_N1B, true>(m, ws, g);
+    }
 
     UFR_PHASE(6)  // LN1
     // ---------------- MLP on [x | message] + LayerNorm2 + residual (transformer.py:55-58)
@@ -412,6 +466,12 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
       for (int t = 0; t < 10; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) hid[c][t][r] = fmaxf(hid[c][t][r], 0.f);
+    if constexpr (TAPE) {
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int t = 0; t < 10; ++t) tape_st(TV_HID + t, c, hid[c][t] * kAccDescale);
+    }
     zero_tiles(o);
     gemm_f16<M_VT_MLP2, C, kVtWaves, true, true>(ws, hid, o, wrap);
     // colour / mask / direction of this lane's (point, view): (issued here: hid is dead, so the 10 registers are free, and LayerNorm2 + the token stores cover the latency)
@@ -429,11 +489,28 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     }
 
     UFR_PHASE(8)  // relu + MLP2
-    layer_norm80<C, V_VT_N2W, V_VT_N2B, true>(o, ws, g);
+    if constexpr (TAPE) {
+      f32x4 xh[C][5];
+      layer_norm80<C, V_VT_N2W, V_VT_N2B, true>(o, ws, g, xh, rstd2);
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int t = 0; t < 5; ++t) tape_st(TV_XH2 + t, c, xh[c][t]);
+    } else {
+      layer_norm80<C, V_VT_N2W, V_VT_N2B, true>(o, ws, g);
+    }
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int t = 0; t < 5; ++t) o[c][t] += x[c][t];
+    if constexpr (TAPE) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int t = 0; t < 5; ++t) tape_st(TV_Y + t, c, o[c][t]);
+        tape_st(TV_Y + 5, c, f32x4{dcomp[c], 0.f, 0.f, 0.f});
+      }
+    }
 
     // ---------------- outputs: token 0 -> ray transformer input; optional full dump
 #pragma unroll
@@ -474,6 +551,15 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
       for (int r = 0; r < 4; ++r) h2[c][0][r] = fmaxf(h2[c][0][r], 0.f);
     gemm_f16<M_RW4, C, kVtWaves, true, true>(ws, h2, lg, wrap);
+    if constexpr (TAPE) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        tape_st(TV_H1, c, h1[c][0] * kAccDescale);
+        tape_st(TV_H2, c, h2[c][0] * kAccDescale);
+        // the logit of column j sits in lane group 0, register 0: every lane group records it
+        tape_st(TV_MISC, c, f32x4{rstd1[c], rstd2[c], __shfl(lg[c][0][0], j) * kAccDescale, 0.f});
+      }
+    }
 
     UFR_PHASE(10)  // radiance MLP
     // ---------------- masked softmax over the NV view tokens + colour blend (ray_transformer.py:315-319)
@@ -569,11 +655,11 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #endif
 }
 
-template <int L, bool LOWP>
+template <int L, bool LOWP, bool TAPE = false>
 static hipError_t launch_vt(const float* packed, const float* x_tokens, const float* x_point, const float* rgb, const float* dir, int P,
-                            float* token0, float* radiance, float* view_out, int* status, hipStream_t s) {
+                            float* token0, float* radiance, float* view_out, int* status, hipStream_t s, float* tape = nullptr) {
   constexpr int C = UFR_VT_C;
-  constexpr int PPW = (L == 6 && C == 2) ? 5 : (16 / L) * C;   // L = 6: a fifth point straddles the wave's two column tiles
+  constexpr int PPW = (L == 6 && C == 2 && !TAPE) ? 5 : (16 / L) * C;   // L = 6: a fifth point straddles the wave's two column tiles
   const int n_groups = (P + PPW - 1) / PPW;
   int blocks = (n_groups + kVtWaves - 1) / kVtWaves;
   // Two workgroups are resident per CU, and the older one wins the SIMD's issue arbitration: with exactly
@@ -600,7 +686,7 @@ static hipError_t launch_vt(const float* packed, const float* x_tokens, const fl
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
   if (!attr_set[dev]) {
-    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&view_transformer_kernel<L, C, LOWP>),
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&view_transformer_kernel<L, C, LOWP, TAPE>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kF16LdsBytes);
     if (attr != hipSuccess) return attr;
     attr_set[dev] = true;
@@ -615,9 +701,29 @@ static hipError_t launch_vt(const float* packed, const float* x_tokens, const fl
     return hipGetLastError();
   }
 #endif
-  hipLaunchKernelGGL((view_transformer_kernel<L, C, LOWP>), dim3(blocks), dim3(kVtBlock), kF16LdsBytes, s, packed, x_tokens,
-                     x_point, rgb, dir, P, token0, radiance, view_out, status);
+  hipLaunchKernelGGL((view_transformer_kernel<L, C, LOWP, TAPE>), dim3(blocks), dim3(kVtBlock), kF16LdsBytes, s, packed, x_tokens,
+                     x_point, rgb, dir, P, token0, radiance, view_out, status, tape);
   return hipGetLastError();
+}
+
+// The forward again for the backward: every activation goes to `tape` (bwd_tape.h; view_tape_blocks(P, NV) blocks of
+// TV_COUNT tiles); token0 / radiance are written as usual (the caller passes scratch rows).
+int view_tape_blocks(int P, int NV) {
+  const int PPW = (16 / (NV + 1)) * kBlockCols;
+  return (P + PPW - 1) / PPW;
+}
+hipError_t launch_view_tape(const float* packed, const float* x_tokens, const float* rgb, const float* dir, int P, int NV,
+                            float* token0, float* radiance, float* tape, bool lowp, int* status, hipStream_t s) {
+  if (P <= 0 || (unsigned long long)P * (NV + 1) * UFR_TOKEN_DIM >= (1ull << 30)) return hipErrorInvalidValue;
+  switch (NV) {
+#define UFR_VT_CASE(N)                                                                                                   \
+    case N:                                                                                                              \
+      return lowp ? launch_vt<N + 1, true, true>(packed, x_tokens, nullptr, rgb, dir, P, token0, radiance, nullptr, status, s, tape) \
+                  : launch_vt<N + 1, false, true>(packed, x_tokens, nullptr, rgb, dir, P, token0, radiance, nullptr, status, s, tape);
+    UFR_VT_CASE(2) UFR_VT_CASE(3) UFR_VT_CASE(4) UFR_VT_CASE(5) UFR_VT_CASE(6) UFR_VT_CASE(7)
+#undef UFR_VT_CASE
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t launch_view_transformer(const float* packed, const float* x_tokens, const float* x_point, const float* rgb,

@@ -47,10 +47,23 @@ __device__ __forceinline__ void split_pair_acc(float a, float b, unsigned& h, un
 // B operands of one k-step (accumulator tiles 2s, 2s+1 of one column tile): one f16x8 per plane
 struct BStep { f16x8 p[kPlanes]; };
 
-// LOWP: the reduced-precision mode (ufr_set_matrix_precision): one fp16 plane per operand, one MFMA per product
-template <bool LOWP>
+// the same split into bf16 planes WITHOUT a scale (backward data-gradient chains: cotangents need the exponent range, and
+// hi + lo = 16 significand bits are ample for the 1e-3 gradient tolerance): v_cvt_pk_bf16_f32, two shifts / masks to get
+// hi back as fp32, two subtractions, v_cvt_pk_bf16_f32 -- 6 VALU instructions per pair
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split_pair_bf16(float a, float b, unsigned& h, unsigned& l) {
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+  const float ah = __builtin_bit_cast(float, h << 16), bh = __builtin_bit_cast(float, h & 0xffff0000u);
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a - ah, b - bh}, bf16x2));
+}
+
+// LOWP: the reduced-precision mode (ufr_set_matrix_precision): one 16-bit plane per operand, one MFMA per product
+// BF16: the stream holds bf16 planes (ufr_layout_f16.h: B_VTB ...), the activations are split with split_pair_bf16
+template <bool LOWP, bool BF16 = false>
 struct WStreamF16T {
   static constexpr bool lowp = LOWP;
+  static constexpr bool bf16 = BF16;
   const char* src;     // fp16 plane region of the packed blob (global, wave-uniform)
   char* ring;          // LDS: the ring of kF16Slots chunk slots
   unsigned ring_lds;   // ... as an LDS byte address (scalar)
@@ -61,9 +74,9 @@ struct WStreamF16T {
 };
 
 typedef WStreamF16T<false> WStreamF16;
-template <int NWAVES, bool LOWP = false>
-__device__ __forceinline__ WStreamF16T<LOWP> wstream_f16_begin(const float* __restrict__ packed, char* smem) {
-  WStreamF16T<LOWP> ws;
+template <int NWAVES, bool LOWP = false, bool BF16 = false>
+__device__ __forceinline__ WStreamF16T<LOWP, BF16> wstream_f16_begin(const float* __restrict__ packed, char* smem) {
+  WStreamF16T<LOWP, BF16> ws;
   ws.lane = threadIdx.x & 63;
   ws.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   ws.bad_in = ws.bad_out = 0ull;
@@ -227,6 +240,14 @@ __device__ __forceinline__ f32x4 vec_frag(const WS& ws, int t, int g) {
 __device__ __forceinline__ f32x4 mfma_f16(const f16x8& a, const f16x8& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
+// the operands' 16-bit words are fp16 (BF = false) or bf16 (BF = true); same lane layout, same rate
+template <bool BF>
+__device__ __forceinline__ f32x4 mfma_planes(const f16x8& a, const f16x8& b, const f32x4& c) {
+  if constexpr (BF)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
 
 // One panel (k-step S of matrix M): out[c][to] += W[:, 32 S .. 32 S + 31] x b[c], all out tiles.
 // Panels must be executed in stream order (ufr_layout_f16.h: vt_panel).
@@ -298,7 +319,7 @@ __device__ __forceinline__ void gemm_f16_panel(WS& ws, const BStep (&b)[C], f32x
       static_for<n_products>([&](auto pi) __attribute__((always_inline)) {
         constexpr int pw[kProducts] = {1, 0, 0}, px[kProducts] = {0, 1, 0};
         constexpr int w = LOWP ? 0 : pw[decltype(pi)::value], x = LOWP ? 0 : px[decltype(pi)::value];
-        out[c][to] = SWAP ? mfma_f16(b[c].p[x], a[w], out[c][to]) : mfma_f16(a[w], b[c].p[x], out[c][to]);
+        out[c][to] = SWAP ? mfma_planes<WS::bf16>(b[c].p[x], a[w], out[c][to]) : mfma_planes<WS::bf16>(a[w], b[c].p[x], out[c][to]);
       });
     if constexpr (!std::is_same<std::decay_t<Hook>, NoHook>::value) {
       // issue order: one MFMA, then up to two of the hook's VALU instructions, repeated
@@ -320,13 +341,15 @@ template <int C>
 struct BWords { unsigned w[C][kPlanes][4]; };
 
 // units [U0, U1) of k-step S of the tiles in[c][0..NIN); ACC: the tiles are raw accumulators (split_pair_acc)
-template <int S, int U0, int U1, bool ACC = false, int C, int NIN>
+template <int S, int U0, int U1, bool ACC = false, bool BF = false, int C, int NIN>
 __device__ __forceinline__ void split_units(const f32x4 (&in)[C][NIN], BWords<C>& bw) {
+  static_assert(!(ACC && BF), "bf16 planes carry no scale: there are no raw accumulators to split");
   static_for<U1 - U0>([&](auto ui) __attribute__((always_inline)) {
     constexpr int u = U0 + decltype(ui)::value;
     constexpr int c = u / 4, half = (u >> 1) & 1, q = u & 1, tile = 2 * S + half;
     if constexpr (tile < NIN) {
-      if constexpr (ACC) split_pair_acc(in[c][tile][2 * q], in[c][tile][2 * q + 1], bw.w[c][0][2 * half + q], bw.w[c][1][2 * half + q]);
+      if constexpr (BF) split_pair_bf16(in[c][tile][2 * q], in[c][tile][2 * q + 1], bw.w[c][0][2 * half + q], bw.w[c][1][2 * half + q]);
+      else if constexpr (ACC) split_pair_acc(in[c][tile][2 * q], in[c][tile][2 * q + 1], bw.w[c][0][2 * half + q], bw.w[c][1][2 * half + q]);
       else split_pair(in[c][tile][2 * q], in[c][tile][2 * q + 1], bw.w[c][0][2 * half + q], bw.w[c][1][2 * half + q]);
     } else {
       bw.w[c][0][2 * half + q] = bw.w[c][1][2 * half + q] = 0u;
@@ -366,8 +389,10 @@ __device__ __forceinline__ void gemm_f16(WS& ws, const f32x4 (&in)[C][NIN], f32x
                                         bool wrap) {
   static_assert(NIN == mat_desc(M).n_in, "input tile count");
   constexpr int n_out = mat_desc(M).n_out, NU = 4 * C;
+  constexpr bool BF = WS::bf16;      // bf16 planes: no scales, so the output is exact as it stands (RAW_OUT) and never probed
+  static_assert(!BF || (RAW_OUT && !ACC_IN), "bf16 streams: plain values in, plain values out");
   BWords<C> cur;
-  split_units<0, 0, NU, ACC_IN>(in, cur);
+  split_units<0, 0, NU, ACC_IN, BF>(in, cur);
   static_for<ksteps(M)>([&](auto si) __attribute__((always_inline)) {
     constexpr int s = decltype(si)::value;
     BStep b[C];
@@ -381,15 +406,15 @@ __device__ __forceinline__ void gemm_f16(WS& ws, const f32x4 (&in)[C][NIN], f32x
       BWords<C> nxt;
       gemm_f16_panel<M, s, C, NWAVES, false>(ws, b, out, wrap, [&](auto ti) __attribute__((always_inline)) {
         constexpr int to = decltype(ti)::value;
-        split_units<s + 1, to * NU / n_out, (to + 1) * NU / n_out, ACC_IN>(in, nxt);
+        split_units<s + 1, to * NU / n_out, (to + 1) * NU / n_out, ACC_IN, BF>(in, nxt);
       });
       cur = nxt;
     } else {
       gemm_f16_panel<M, s, C, NWAVES>(ws, b, out, wrap);
-      if constexpr (s + 1 < ksteps(M)) split_units<s + 1, 0, NU, ACC_IN>(in, cur);
+      if constexpr (s + 1 < ksteps(M)) split_units<s + 1, 0, NU, ACC_IN, BF>(in, cur);
     }
   });
-  probe_gemm(out, ws);
+  if constexpr (!BF) probe_gemm(out, ws);
   if constexpr (!RAW_OUT) descale_tiles(out);
 }
 

@@ -352,11 +352,11 @@ def aggregate_bwd(weights: PackedWeights, grads: GradBuffer, x, rgb, dirs, token
     ws = torch.empty(lib.ufr_aggregate_bwd_workspace_bytes(RN, SN, NV) // 4, dtype=torch.float32, device=dev)
     dbg = {}
     if debug:
-        dbg = dict(view=torch.zeros(P * (NV + 1), 881, device=dev), ray=torch.zeros(P, 440, device=dev))
+        dbg = dict(ray=torch.zeros(P, 440, device=dev))
     _lib.check(lib.ufr_aggregate_bwd(
-        C.byref(weights.raw), C.byref(grads.raw), _dev(x, "x_tokens"), _dev(rgb, "rgb"), _dev(dirs, "dir"),
-        _dev(token0, "token0"), RN, SN, NV, _dev(d_radiance.contiguous(), "d_radiance"), _dev(d_srdf.contiguous(), "d_srdf"),
-        d_pv.data_ptr(), ws.data_ptr(), _opt(dbg.get("view"), "debug_view"), _opt(dbg.get("ray"), "debug_ray"),
+        C.byref(weights.raw), C.byref(grads.raw), weights.packed.data_ptr(), _dev(x, "x_tokens"), _dev(rgb, "rgb"),
+        _dev(dirs, "dir"), _dev(token0, "token0"), RN, SN, NV, _dev(d_radiance.contiguous(), "d_radiance"),
+        _dev(d_srdf.contiguous(), "d_srdf"), d_pv.data_ptr(), ws.data_ptr(), _opt(dbg.get("ray"), "debug_ray"),
         weights.mode() if precision is None else precision, _stream()),
         "ufr_aggregate_bwd")
     return d_pv, dbg
@@ -457,10 +457,13 @@ def view_transform_bwd(weights: PackedWeights, grads: GradBuffer, x, rgb, dirs, 
     ta = d_token0_a.contiguous()
     tb = None if d_token0_b is None else d_token0_b.contiguous()
     dr = d_radiance.contiguous()
-    _lib.check(_lib.load().ufr_view_transform_bwd(
-        C.byref(weights.raw), C.byref(grads.raw), _dev(x, "x_tokens"), _dev(rgb, "rgb"), _dev(dirs, "dir"),
-        _dev(ta, "d_token0_a"), _opt(tb, "d_token0_b"), _dev(dr, "d_radiance"), P, NV, _dev(d_pv, "d_pv"),
-        weights.mode() if precision is None else precision, _stream()), "ufr_view_transform_bwd")
+    lib = _lib.load()
+    # tape + cotangent tiles of the streaming backward (csrc/bwd_tape.h)
+    ws = torch.empty(lib.ufr_view_transform_bwd_workspace_bytes(P, NV) // 4, dtype=torch.float32, device=x.device)
+    _lib.check(lib.ufr_view_transform_bwd(
+        C.byref(weights.raw), C.byref(grads.raw), weights.packed.data_ptr(), _dev(x, "x_tokens"), _dev(rgb, "rgb"),
+        _dev(dirs, "dir"), _dev(ta, "d_token0_a"), _opt(tb, "d_token0_b"), _dev(dr, "d_radiance"), P, NV, _dev(d_pv, "d_pv"),
+        ws.data_ptr(), weights.mode() if precision is None else precision, _stream()), "ufr_view_transform_bwd")
     return d_pv
 
 

@@ -174,7 +174,7 @@ def test_two_rank_training_step_allreduces_to_the_mean(tmp_path):
     line = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and len(line["config"]["per_rank"]) == 2
     for r in line["config"]["per_rank"]:
-        assert r["all_reduce_ms_per_step"] >= 0 and "view_bwd" in r["kernel_ms_per_step"] and r["wall_ms_per_step"] > 0
+        assert r["all_reduce_ms_per_step"] >= 0 and "view_dgrad" in r["kernel_ms_per_step"] and r["wall_ms_per_step"] > 0
 
 
 @pytest.mark.gpu

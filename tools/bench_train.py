@@ -203,7 +203,10 @@ def run(a, dev, world=1, rank=0):
         return None
     S = a.coarse + a.fine
     pts = a.rays * (a.coarse + S)
-    vb = prof.get("view_bwd", dict(ms=0.0, launches=1))
+    # the view transformer's backward = three kernels per launch (csrc/bwd_tape.h): forward with a tape, data gradients,
+    # weight-gradient contraction
+    parts = [prof[k] for k in ("view_tape", "view_dgrad", "view_wgrad") if k in prof]
+    vb = dict(ms=sum(p["ms"] for p in parts), launches=max([p["launches"] for p in parts] or [1]))
     vb_ms = vb["ms"] / max(vb["launches"], 1)
     # the fine pass evaluates only its new samples at the point level: coarse + fine points per ray over the launches
     vb_pts = a.rays * S * a.steps / max(vb["launches"], 1)
@@ -236,7 +239,7 @@ def run(a, dev, world=1, rank=0):
                     kernel_launches_per_step={k: v["launches"] / a.steps for k, v in prof.items()},
                     per_rank=per_rank),
         roofline=dict(bound="mfma", achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak, traffic=traffic,
-                      traffic_source=traffic_src, kernel="view_bwd_kernel", avg_launch_ms=vb_ms, launches=vb["launches"],
+                      traffic_source=traffic_src, kernel="view_transformer_kernel<TAPE> + view_dgrad_kernel + view_wgrad_kernel", avg_launch_ms=vb_ms, launches=vb["launches"],
                       algorithmic_flop_per_launch=vb_flop,
                       peak_basis=("dense fp32 MFMA peak" if a.precision == "fp32" else "dense bf16 MFMA peak")
                                  + "; algorithmic flop = 3 x the forward view-transformer flop per point (recompute + data "

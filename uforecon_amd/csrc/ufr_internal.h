@@ -72,9 +72,6 @@ hipError_t launch_composite_bwd(const float* z, const float* radiance, const int
                                 const float* d_opacity, const float* d_weight, float* d_radiance, float* d_srdf,
                                 float* d_variance, hipStream_t s);
 struct GradPtrs;
-hipError_t launch_view_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* x_tokens, const float* rgbm,
-                           const float* dirs, const float* d_tok_a, const float* d_tok_b, const float* d_radiance, int P,
-                           int NV, float* d_pv, float* dbg, bool lowp, hipStream_t s);
 // The streaming view-transformer backward (round 4; bwd_tape.h): the forward again with a tape, the data-gradient chain,
 // the weight-gradient contraction.  tape: view_tape_blocks(P, NV) blocks of TV_COUNT tiles; dbuf: as many blocks of DV_COUNT.
 int view_tape_blocks(int P, int NV);

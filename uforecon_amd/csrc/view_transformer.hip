@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
   // point 2 in columns 12, 13 (30 of 32 columns).  The dense layers do not care where a token sits; the attention and the
   // softmax exchange tokens of a point through the schedule below.
   constexpr bool STRADDLE = (L == 6 && C == 2 && !TAPE);   // the tape's consumers use the plain slot map
-  static_assert(!TAPE || C == kBlockCols, "tape blocks");
+  static_assert(!TAPE || kBlockCols % C == 0, "tape blocks");
   constexpr int PPW = STRADDLE ? 5 : PPT * C;         // points per wave iteration
   extern __shared__ __attribute__((aligned(16))) char smem[];
   auto ws = wstream_f16_begin<kVtWaves, LOWP>(packed, smem);
@@ -169,7 +169,8 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 
   const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int n_waves = (gridDim.x * blockDim.x) >> 6;
-  const int n_groups = (P + PPW - 1) / PPW;
+  // TAPE: whole blocks of kBlockCols column tiles (a trailing group without points writes finite values, never garbage)
+  const int n_groups = TAPE ? ((P + PPT * kBlockCols - 1) / (PPT * kBlockCols)) * (kBlockCols / C) : (P + PPW - 1) / PPW;
   const int n_iter = (n_groups + n_waves - 1) / n_waves;  // uniform over the grid: every wave meets every barrier
 
 #ifdef UFR_PHASE_TIMING
@@ -181,8 +182,11 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
   for (int it = 0; it < n_iter; ++it) {
     const int grp = it * n_waves + wave_global;
     const bool wrap = it + 1 < n_iter;
+    // tape tile (block, column tile) of this wave iteration: scalar base + 32-bit lane offset (see at32)
+    const int col0 = __builtin_amdgcn_readfirstlane(grp < n_groups ? grp : 0) * C;      // first column tile, counted over all blocks
+    float* const tape_blk = tape + (size_t)(col0 / kBlockCols) * (TV_COUNT * kBlockCols * kTileFloats);
     auto tape_st = [&](int tile, int c, f32x4 v) __attribute__((always_inline)) {
-      if (grp < n_groups) st4(tape + tile_offset(TV_COUNT, (size_t)grp, tile, c) + lane * 4, v);
+      if (grp < n_groups) st4(at32(tape_blk, (unsigned)((tile * kBlockCols + col0 % kBlockCols + c) * kTileFloats) + lane * 4u), v);
     };
 #ifdef UFR_FUSION_PROBE
     // Feasibility probe for fusing the gather into this kernel: a synthetic producer phase with
@@ -658,9 +662,11 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 template <int L, bool LOWP, bool TAPE = false>
 static hipError_t launch_vt(const float* packed, const float* x_tokens, const float* x_point, const float* rgb, const float* dir, int P,
                             float* token0, float* radiance, float* view_out, int* status, hipStream_t s, float* tape = nullptr) {
-  constexpr int C = UFR_VT_C;
+  // TAPE: one column tile per wave -- the tape stores keep a tile's activations alive longer, and with two column tiles
+  // the kernel spilled 250..330 registers (1.2 ms per 131 072 points for 0.2 ms of arithmetic)
+  constexpr int C = TAPE ? 1 : UFR_VT_C;
   constexpr int PPW = (L == 6 && C == 2 && !TAPE) ? 5 : (16 / L) * C;   // L = 6: a fifth point straddles the wave's two column tiles
-  const int n_groups = (P + PPW - 1) / PPW;
+  const int n_groups = TAPE ? ((P + (16 / L) * kBlockCols - 1) / ((16 / L) * kBlockCols)) * (kBlockCols / C) : (P + PPW - 1) / PPW;
   int blocks = (n_groups + kVtWaves - 1) / kVtWaves;
   // Two workgroups are resident per CU, and the older one wins the SIMD's issue arbitration: with exactly
   // 512 persistent workgroups the favoured half finishes ~25 % early and the rest runs alone, without a

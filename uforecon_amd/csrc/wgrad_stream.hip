@@ -161,10 +161,12 @@ __device__ __forceinline__ void run_role(const float* __restrict__ tape, const f
   for (int s = 0; s < NS; ++s) acc[s] = splat4(0.f);
 
   for (int blk = blk0; blk < blk1; ++blk) {
-    const float* tb = tape + tile_offset(NT_TAPE, (size_t)blk, 0, 0) + lane * 4;
-    const float* db = dbuf + tile_offset(NT_DY, (size_t)blk, 0, 0) + lane * 4;
+    // scalar block bases + 32-bit lane offsets
+    const char* tb = reinterpret_cast<const char*>(tape + tile_offset(NT_TAPE, (size_t)blk, 0, 0));
+    const char* db = reinterpret_cast<const char*>(dbuf + tile_offset(NT_DY, (size_t)blk, 0, 0));
     auto raw = [&](int buf, int tile, int c) __attribute__((always_inline)) -> f32x4 {
-      return ld4((buf == B_TAPE ? tb : db) + (tile * kBlockCols + c) * kTileFloats);
+      const unsigned off = (unsigned)((tile * kBlockCols + c) * kTileFloats * 4) + lane * 16u;
+      return *reinterpret_cast<const f32x4*>((buf == B_TAPE ? tb : db) + off);
     };
     static_for<R.n>([&](auto ji) __attribute__((always_inline)) {
       constexpr int jx = decltype(ji)::value;

@@ -98,6 +98,9 @@ int ufr_get_matrix_precision(void);
  * previous call's copy arrived set -- one call late, without a host synchronisation in the ray loop.  `flags_out`
  * (nullable) receives the bits. */
 int ufr_status_poll(ufr_stream stream, int32_t synchronize, int32_t* flags_out);
+/* The same, restricted to the bits of `mask`: other bits stay set for whoever polls for them (uforecon_amd.ops.PackedWeights
+ * checks a fresh pack with mask 4, so that an unrelated, still unreported activation overflow does not fail a valid pack). */
+int ufr_status_poll_bits(ufr_stream stream, int32_t synchronize, int32_t mask, int32_t* flags_out);
 
 /* Re-orders the dense matrices into MFMA A-fragment order (one 16x16 output tile x 16
  * input features = 64 lanes x float4, zero padded) so the kernels stream them with

@@ -63,6 +63,41 @@ def test_product_cascade_has_no_cpu_path():
         m(c["features"], c["proj_matrices"], c["depth_values"], c["img_hw"])
 
 
+def test_trainable_frustum_unet_refuses_cpu_tensors_too():
+    """cost_reg_2 is trained by the reference: with gradients wanted the differentiable expression runs -- on the GPU only."""
+    from uforecon_amd.ops import UfrError
+
+    m = cascade.CostRegNetWeight(1, 8)
+    x = torch.randn(1, 1, 8, 8, 8)
+    with pytest.raises(UfrError):
+        m(x)                                    # parameters require grad -> trainable path -> CPU tensor refused
+    with torch.no_grad(), pytest.raises(UfrError):
+        m(x)                                    # forward-only HIP plan -> CPU tensor refused
+
+
+@pytest.mark.gpu
+def test_gpu_frustum_unet_stays_differentiable_when_gradients_are_wanted():
+    """MVSVolume's U-Net (`feature_volume.cost_reg_2`, module.py:530-543) trains in the reference: with grad mode on and
+    parameters that require grad its outputs carry a graph and every parameter receives a gradient; without, the
+    forward-only HIP plan runs and gives the same numbers."""
+    dev = "cuda:0"
+    torch.manual_seed(3)
+    m = cascade.CostRegNetWeight(1, 8).to(dev)
+    x = torch.randn(2, 1, 8, 16, 24, device=dev)
+    f, w = m(x)
+    assert f.requires_grad and w.requires_grad
+    (f.square().mean() + w.mean()).backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().max()) > 0 for p in m.parameters())
+    with torch.no_grad():
+        f2, w2 = m(x)
+    assert not f2.requires_grad
+    assert float((f2 - f).abs().max()) < 1e-4 * float(f.abs().max()) and float((w2 - w).abs().max()) < 1e-5
+    for p in m.parameters():
+        p.requires_grad_(False)
+    f3, _ = m(x)                                # nothing to differentiate -> HIP plan even in grad mode
+    assert not f3.requires_grad and torch.equal(f3, f2)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", list(CASCADE_CASES))
 def test_gpu_cascade_matches_reference_golden(name):

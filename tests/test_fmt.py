@@ -12,6 +12,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def _run(dev):
+    if dev == "cpu":                # the product has no CPU path: the layers run through the CPU restatement (oracle/)
+        from oracle import fmt_oracle
+
+        with fmt_oracle.cpu_layers():
+            return _run_on(dev)
+    return _run_on(dev)
+
+
+def _run_on(dev):
     c = make_fmt_case("small3")
     m = fill_state_dict(cascade.FrustumBuilder(), c["weight_seed"]).eval().to(dev)
     feats = [{k: v.to(dev) for k, v in f.items()} for f in c["features"]]
@@ -37,10 +46,18 @@ def test_fmt_mirror_matches_reference_golden_cpu():
     g = np.load(os.path.join(HERE, "golden", "fmt_small3.npz"))
     got = _run("cpu")
     assert set(got) == set(g.files)
-    for k in g.files:                          # same math, own op decomposition (fused projections, batched matmuls)
+    for k in g.files:                          # the mirror's walks of the stack around the CPU restatement of a layer
         ref = torch.from_numpy(g[k])
         assert float((got[k] - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), k
     assert got["match_feature"].shape == (1, 3, 64, 8, 16)      # (B, V, 32 (V-1), h, w): ufr_frame_prepare's match_feature
+
+
+def test_fmt_product_has_no_cpu_path():
+    from uforecon_amd import fmt
+    from uforecon_amd.ops import UfrError
+
+    with pytest.raises(UfrError), torch.no_grad():
+        fmt._layer(fmt._LayerParams(32), torch.randn(1, 40, 32), None)
 
 
 @pytest.mark.gpu
@@ -55,8 +72,9 @@ def test_fmt_mirror_matches_reference_golden_gpu():
 @pytest.mark.gpu
 @pytest.mark.parametrize("cross", [False, True])
 def test_fmt_layer_kernel_matches_the_torch_layer(cross):
-    """ufr_fmt_layer (csrc/fmt.hip) against the same layer written with torch ops on the CPU (fmt._layer), self- and
-    cross-attention, token counts that are not multiples of any tile."""
+    """ufr_fmt_layer (csrc/fmt.hip) against the same layer written with torch ops on the CPU (oracle/fmt_oracle.py), self-
+    and cross-attention, token counts that are not multiples of any tile."""
+    from oracle import fmt_oracle
     from uforecon_amd import fmt
 
     torch.manual_seed(3)
@@ -69,6 +87,6 @@ def test_fmt_layer_kernel_matches_the_torch_layer(cross):
     x = torch.randn(3, 1237, 32)
     src = torch.randn(3, 2049, 32) if cross else None
     with torch.no_grad():
-        want = fmt._layer(p, x, src)
+        want = fmt_oracle.layer(p, x, src)
         got = fmt._layer(p.to("cuda:0"), x.to("cuda:0"), None if src is None else src.to("cuda:0"))
     assert float((got.cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())

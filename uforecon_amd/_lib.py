@@ -71,6 +71,7 @@ SIGNATURES = {
     "ufr_set_matrix_precision": (C.c_int, [C.c_int]),
     "ufr_get_matrix_precision": (C.c_int, []),
     "ufr_status_poll": (C.c_int, [vp, i32, C.POINTER(i32)]),
+    "ufr_status_poll_bits": (C.c_int, [vp, i32, i32, C.POINTER(i32)]),
     "ufr_packed_weights_bytes": (sz, []),
     "ufr_weights_pack": (C.c_int, [C.POINTER(RawWeights), vp, vp]),
     "ufr_pack_plan": (C.c_int, [C.POINTER(i32), C.POINTER(i32)]),

@@ -544,15 +544,8 @@ template <bool LOWP>
 static hipError_t launch_ray_bwd_t(const RawPtrs& wp, const GradPtrs& gp, const float* token0, const int* tok_row,
                                    bool accumulate, const float* order_pe, const float* d_srdf, int RN, int SN,
                                    float* d_tok_a, float* d_tok_b, float* dbg, hipStream_t s) {
-  static bool attr_set[16] = {};   // the attribute is per device
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
-  if (!attr_set[dev]) {
-    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ray_bwd_kernel<LOWP>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, rb::kLdsBytes);
-    if (attr != hipSuccess) return attr;
-    attr_set[dev] = true;
-  }
+  static LdsAttrOnce lds_attr;   // per instantiation; thread-safe, once per device
+  if (const hipError_t attr = lds_attr.set(reinterpret_cast<const void*>(&ray_bwd_kernel<LOWP>), rb::kLdsBytes); attr != hipSuccess) return attr;
   const int blocks = RN < 256 ? RN : 256;
   hipLaunchKernelGGL(ray_bwd_kernel<LOWP>, dim3(blocks), dim3(kBwdThreads), rb::kLdsBytes, s, wp, gp, token0, tok_row,
                      accumulate ? 1 : 0, order_pe, d_srdf, RN, SN, d_tok_a, d_tok_b, dbg);

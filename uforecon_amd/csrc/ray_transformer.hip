@@ -306,16 +306,8 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
 template <bool LOWP>
 static hipError_t launch_rt(const float* packed, const float* token0, const int* tok_row, const float* order_pe, int RN,
                             int SN, float* srdf, float* ray_out, int* status, hipStream_t s) {
-  // the attribute is per device: set it once on every device this process launches on
-  static bool attr_set[16] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
-  if (!attr_set[dev]) {
-    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ray_transformer_kernel<LOWP>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, kF16LdsBytes);
-    if (attr != hipSuccess) return attr;
-    attr_set[dev] = true;
-  }
+  static LdsAttrOnce lds_attr;   // per instantiation; thread-safe, once per device
+  if (const hipError_t attr = lds_attr.set(reinterpret_cast<const void*>(&ray_transformer_kernel<LOWP>), kF16LdsBytes); attr != hipSuccess) return attr;
   hipLaunchKernelGGL(ray_transformer_kernel<LOWP>, dim3((RN + kRtWaves - 1) / kRtWaves), dim3(kRtBlock), kF16LdsBytes, s,
                      packed, token0, tok_row, order_pe, RN, SN, srdf, ray_out, status);
   return hipGetLastError();

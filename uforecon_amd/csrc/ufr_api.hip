@@ -119,31 +119,48 @@ bool resolve_precision(int precision, bool* lowp) {
   bool lowp_var = false;                                                                          \
   if (!resolve_precision(arg, &lowp_var)) return fail(UFR_ERR_ARG, "%s: unknown precision %d", who, (int)(arg))
 
-// ---- sticky range status (include/ufr.h: ufr_status_poll): one device word the kernels OR into, one pinned host word
-// the entry points copy it to.  Per device, created on first use, never freed (process lifetime).
-struct StatusSlot { int* dev = nullptr; volatile int* host = nullptr; };
+// ---- sticky range status (include/ufr.h: ufr_status_poll): per device, created on first use (call_once: the entry points
+// run on the caller's thread and on autograd's workers), never freed (process lifetime).
+//   dev[0]  the bits the kernels OR into          dev[1]  generation tag, rewritten by every report-and-clear
+//   host[0..1]  pinned copy of both words: written only by the D2H copies the entry points enqueue
+// A report clears the reported bits on the device and starts a new generation; a copy that was already in flight then
+// still delivers the OLD tag and is ignored -- without the tag it re-armed the host word with stale bits and a later,
+// healthy call failed with UFR_ERR_RANGE (round-3 advisor finding).
+struct StatusSlot {
+  std::once_flag once;
+  int rc = UFR_OK;
+  int* dev = nullptr;
+  volatile int* host = nullptr;
+  std::atomic<int> gen{0};
+  std::mutex report_mu;
+};
 constexpr int kStatusDevices = 16;
 StatusSlot g_status[kStatusDevices];
-std::mutex g_status_mu;
+constexpr int kStatusAll = 7;
+
+__global__ void status_update_kernel(int* dev, int keep_mask, int gen) {
+  atomicAnd(dev, keep_mask);
+  dev[1] = gen;
+}
 
 int status_slot(StatusSlot** out) {
   int dev = 0;
   UFR_HIP(hipGetDevice(&dev));
   UFR_REQUIRE(dev >= 0 && dev < kStatusDevices, "status: device %d out of range", dev);
   StatusSlot& sl = g_status[dev];
-  if (!sl.dev) {
-    std::lock_guard<std::mutex> lock(g_status_mu);
-    if (!sl.dev) {
-      int* h = nullptr;
-      int* d = nullptr;
-      UFR_HIP(hipHostMalloc(reinterpret_cast<void**>(&h), sizeof(int), hipHostMallocDefault));
-      *h = 0;
-      UFR_HIP(hipMalloc(reinterpret_cast<void**>(&d), sizeof(int)));
-      UFR_HIP(hipMemset(d, 0, sizeof(int)));
-      sl.host = h;
-      sl.dev = d;
+  std::call_once(sl.once, [&sl] {
+    int* h = nullptr;
+    int* d = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&h), 2 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&d), 2 * sizeof(int)) != hipSuccess || hipMemset(d, 0, 2 * sizeof(int)) != hipSuccess) {
+      sl.rc = UFR_ERR_HIP;
+      return;
     }
-  }
+    h[0] = h[1] = 0;
+    sl.host = h;
+    sl.dev = d;
+  });
+  if (sl.rc != UFR_OK) return fail(sl.rc, "status: could not allocate the device's status words");
   *out = &sl;
   return UFR_OK;
 }
@@ -152,20 +169,29 @@ int status_message(int bits, const char* who) {
   return fail(UFR_ERR_RANGE, "%s: range status 0x%x:%s%s%s (include/ufr.h: ufr_status_poll)", who, bits,
               (bits & 1) ? " a dense-layer input reached |x| >= 4094 (fp16 planes overflowed);" : "",
               (bits & 2) ? " NaN among the token / dir inputs handed to a transformer kernel;" : "",
-              (bits & 4) ? " ufr_weights_pack met a weight that is not finite or |w| >= 255.8;" : "");
+              (bits & 4) ? " ufr_weights_pack met a weight that is not finite or outside the fp16 planes' range;" : "");
 }
 
-// entry of a compute call: report (and clear) what an earlier call's copy delivered
-int status_enter(StatusSlot* sl, hipStream_t s, const char* who) {
-  const int bits = *sl->host;
-  if (bits == 0) return UFR_OK;
-  *sl->host = 0;
-  UFR_HIP(hipMemsetAsync(sl->dev, 0, sizeof(int), s));
-  return status_message(bits, who);
+// what the last delivered copy says about the CURRENT generation, restricted to `mask`; reported bits are cleared on the
+// device (enqueued on `s`) and a new generation starts
+int status_consume(StatusSlot* sl, hipStream_t s, int mask, const char* who, int* flags_out) {
+  std::lock_guard<std::mutex> lock(sl->report_mu);
+  const int bits = sl->host[0], tag = sl->host[1];
+  const int cur = sl->gen.load(std::memory_order_relaxed);
+  const int hit = tag == cur ? bits & mask : 0;
+  if (flags_out) *flags_out = tag == cur ? bits : 0;
+  if (hit == 0) return UFR_OK;
+  const int next = cur + 1;
+  sl->gen.store(next, std::memory_order_relaxed);
+  hipLaunchKernelGGL(status_update_kernel, dim3(1), dim3(1), 0, s, sl->dev, ~hit, next);
+  UFR_HIP(hipGetLastError());
+  return status_message(hit, who);
 }
-// exit of a compute call: deliver the flag as of the end of this call's kernels
+// entry of a compute call: report (and clear) what an earlier call's copy delivered
+int status_enter(StatusSlot* sl, hipStream_t s, const char* who) { return status_consume(sl, s, kStatusAll, who, nullptr); }
+// exit of a compute call: deliver the words as of the end of this call's kernels
 int status_leave(StatusSlot* sl, hipStream_t s) {
-  UFR_HIP(hipMemcpyAsync(const_cast<int*>(sl->host), sl->dev, sizeof(int), hipMemcpyDeviceToHost, s));
+  UFR_HIP(hipMemcpyAsync(const_cast<int*>(sl->host), sl->dev, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
   return UFR_OK;
 }
 }  // namespace
@@ -179,24 +205,24 @@ int ufr_set_matrix_precision(int mode) {
 }
 int ufr_get_matrix_precision(void) { return g_matrix_precision.load(std::memory_order_relaxed); }
 
-int ufr_status_poll(ufr_stream stream, int32_t synchronize, int32_t* flags_out) {
+int ufr_status_poll_bits(ufr_stream stream, int32_t synchronize, int32_t mask, int32_t* flags_out) {
   StatusSlot* sl = nullptr;
   int rc = status_slot(&sl);
   if (rc != UFR_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (synchronize) {
-    UFR_HIP(hipMemcpyAsync(const_cast<int*>(sl->host), sl->dev, sizeof(int), hipMemcpyDeviceToHost, s));
+    UFR_HIP(hipMemcpyAsync(const_cast<int*>(sl->host), sl->dev, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     UFR_HIP(hipStreamSynchronize(s));
   }
-  const int bits = *sl->host;
-  if (flags_out) *flags_out = bits;
-  if (bits == 0) {
-    if (!synchronize) return status_leave(sl, s);
-    return UFR_OK;
-  }
-  *sl->host = 0;
-  UFR_HIP(hipMemsetAsync(sl->dev, 0, sizeof(int), s));
-  return status_message(bits, "ufr_status_poll");
+  int flags = 0;
+  rc = status_consume(sl, s, mask, "ufr_status_poll", &flags);
+  if (flags_out) *flags_out = flags;
+  if (rc == UFR_OK && !synchronize) return status_leave(sl, s);
+  return rc;
+}
+
+int ufr_status_poll(ufr_stream stream, int32_t synchronize, int32_t* flags_out) {
+  return ufr_status_poll_bits(stream, synchronize, kStatusAll, flags_out);
 }
 
 int ufr_version(void) { return UFR_ABI_VERSION; }
@@ -817,6 +843,11 @@ int ufr_render_rays(const ufr_render_args* a, ufr_stream stream) {
   UFR_REQUIRE(a->coarse_only || (PN >= 16 && (SN + PN) % 16 == 0 && SN + PN <= 256 && PN <= 256),
               "ufr_render_rays: fine samples %d unsupported", PN);
   const int chunk = a->chunk_rays > 0 ? a->chunk_rays : ufr_default_chunk_rays();
+  // the transformer kernels address a launch's buffers with 32-bit offsets: validate the caller's chunk size up front, not
+  // after the gather and earlier chunks were enqueued (the default 4096 rays is 160 x below the limit)
+  UFR_REQUIRE((unsigned long long)chunk * (SN > PN ? SN : PN) * (NV + 1) * UFR_TOKEN_DIM < (1ull << 30),
+              "ufr_render_rays: chunk_rays=%d x %d samples x %d tokens exceeds the 2^30 token values one launch addresses; use a "
+              "smaller chunk", chunk, SN > PN ? SN : PN, NV + 1);
   const size_t need = ufr_render_workspace_bytes(chunk, SN, PN, NV);
   if (a->workspace_bytes < need) return fail(UFR_ERR_WORKSPACE, "render workspace too small: %zu < %zu", a->workspace_bytes, need);
   UFR_PRECISION(a->precision, lowp, "ufr_render_rays");

@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <mutex>
+
 #include "../../include/ufr.h"
 #include "ufr_layout.h"
 
@@ -30,6 +33,19 @@ constexpr uint32_t kFrameMagic = 0x55465246u;  // "UFRF"
 
 struct PreSim {  // pre_sim_mlp raw pointers (reference layout) used by the gather kernel
   const float *w0, *b0, *w2, *b2, *w4, *b4;
+};
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute of a kernel: set it once per (kernel, device),
+// safely from any thread (the entry points are called from the caller's thread AND from autograd's workers).
+struct LdsAttrOnce {
+  std::once_flag flag[16];
+  hipError_t err[16];
+  hipError_t set(const void* kernel, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+    std::call_once(flag[dev], [&] { err[dev] = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); });
+    return err[dev];
+  }
 };
 
 // kernel launchers (one per .hip file); all enqueue on `s` and return hipGetLastError()

@@ -376,15 +376,8 @@ static hipError_t launch_vd(const float* packed, const float* tape, const float*
       if (best_cost < 0 || cost < best_cost) { best_cost = cost; blocks = b; }
     }
   }
-  static bool attr_set[16] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
-  if (!attr_set[dev]) {
-    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&view_dgrad_kernel<L, LOWP>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, kF16LdsBytes);
-    if (attr != hipSuccess) return attr;
-    attr_set[dev] = true;
-  }
+  static LdsAttrOnce lds_attr;   // per instantiation; thread-safe, once per device
+  if (const hipError_t attr = lds_attr.set(reinterpret_cast<const void*>(&view_dgrad_kernel<L, LOWP>), kF16LdsBytes); attr != hipSuccess) return attr;
   hipLaunchKernelGGL((view_dgrad_kernel<L, LOWP>), dim3(blocks), dim3(kVdBlock), kF16LdsBytes, s, packed, tape, rgbm, d_tok_a,
                      d_tok_b, d_radiance, P, dbuf, d_pv);
   return hipGetLastError();

@@ -687,16 +687,8 @@ static hipError_t launch_vt(const float* packed, const float* x_tokens, const fl
       if (best_cost < 0 || cost < best_cost) { best_cost = cost; blocks = b; }
     }
   }
-  // the attribute is per device: set it once on every device this process launches on
-  static bool attr_set[16] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
-  if (!attr_set[dev]) {
-    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&view_transformer_kernel<L, C, LOWP, TAPE>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, kF16LdsBytes);
-    if (attr != hipSuccess) return attr;
-    attr_set[dev] = true;
-  }
+  static LdsAttrOnce lds_attr;   // per instantiation; thread-safe, once per device
+  if (const hipError_t attr = lds_attr.set(reinterpret_cast<const void*>(&view_transformer_kernel<L, C, LOWP, TAPE>), kF16LdsBytes); attr != hipSuccess) return attr;
 #ifdef UFR_VT_OCC_PROBE   // development: UFR_VT_PAD_LDS=<bytes> inflates the LDS request to limit the workgroups per CU
   static const int pad_lds = getenv("UFR_VT_PAD_LDS") ? atoi(getenv("UFR_VT_PAD_LDS")) : 0;
   if (pad_lds > 0) {

@@ -12,7 +12,7 @@ TransMVSNet.py:341-375), restated here around ONE token engine instead of a modu
 
 Only the PARAMETER TREE follows the reference (a checkpoint must load: ``FMT.layers.<i>.attention.query_projection.weight``
 ...); the computation lives in the functions below: the three projections of a self layer are one fused GEMM, attention is
-two batched matmuls per layer on a (batch*heads, tokens, 4) layout, and the three walks are one loop over a per-layer plan.
+a per-sample 4 x 4 state per head (csrc/fmt.hip), and the three walks are one loop over a per-layer plan.
 Inference only.
 """
 from __future__ import annotations
@@ -49,49 +49,19 @@ class _LayerParams(nn.Module):
 
 
 # ------------------------------------------------------------------ token engine
-def _split_heads(t: torch.Tensor) -> torch.Tensor:
-    """(N, T, C) -> (N*HEADS, T, C/HEADS)"""
-    n, t_, c = t.shape
-    return t.view(n, t_, HEADS, c // HEADS).permute(0, 2, 1, 3).reshape(n * HEADS, t_, c // HEADS)
-
-
-def _linear_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
-    """softmax-free attention with the elu+1 feature map (FMT.py:25-38), all heads in one batched matmul pair:
-    out_l = phi(q_l) (sum_s phi(k_s)^T v_s) / (phi(q_l) . sum_s phi(k_s) + eps)."""
-    n, tq, c = q.shape
-    qh, kh, vh = _split_heads(F.elu(q) + 1), _split_heads(F.elu(k) + 1), _split_heads(v)
-    state = torch.bmm(kh.transpose(1, 2), vh)                      # (N*H, 4, 4)   sum_s phi(k)^T v
-    norm = torch.bmm(qh, kh.sum(dim=1, keepdim=True).transpose(1, 2)) + eps   # (N*H, T, 1)
-    out = torch.bmm(qh, state) / norm
-    return out.view(n, HEADS, tq, c // HEADS).permute(0, 2, 1, 3).reshape(n, tq, c)
-
-
 def _layer(p: _LayerParams, x: torch.Tensor, src: Optional[torch.Tensor]) -> torch.Tensor:
-    """One post-norm layer (FMT.py:99-113, dropout 0).  ``src is None``: self-attention.  GPU tensors run the HIP kernel
-    pair behind ``ufr_fmt_layer`` (csrc/fmt.hip; no fallback: a missing library raises); the torch expression below is the
-    same layer for CPU tensors (q/k/v from one fused GEMM) and what the kernel is tested against."""
-    a = p.attention
-    if x.is_cuda:
-        from . import ops
+    """One post-norm layer (FMT.py:99-113, dropout 0) = the HIP kernel pair behind ``ufr_fmt_layer`` (csrc/fmt.hip).
+    ``src is None``: self-attention.  GPU only, like every other module of the package: a CPU tensor or a missing library
+    raises (the torch expression of the same layer that the kernel is checked against lives in ``oracle/fmt_oracle.py``;
+    the CPU test-suite swaps it in)."""
+    from . import ops
 
-        return ops.fmt_layer([a.query_projection.weight, a.query_projection.bias, a.key_projection.weight,
-                              a.key_projection.bias, a.value_projection.weight, a.value_projection.bias,
-                              a.out_projection.weight, a.out_projection.bias, p.linear1.weight, p.linear1.bias,
-                              p.linear2.weight, p.linear2.bias, p.norm1.weight, p.norm1.bias, p.norm2.weight, p.norm2.bias],
-                             x, src)
-    if src is None:
-        w = torch.cat([a.query_projection.weight, a.key_projection.weight, a.value_projection.weight], 0)
-        b = torch.cat([a.query_projection.bias, a.key_projection.bias, a.value_projection.bias], 0)
-        q, k, v = F.linear(x, w, b).chunk(3, dim=-1)
-    else:
-        q = F.linear(x, a.query_projection.weight, a.query_projection.bias)
-        w = torch.cat([a.key_projection.weight, a.value_projection.weight], 0)
-        b = torch.cat([a.key_projection.bias, a.value_projection.bias], 0)
-        k, v = F.linear(src, w, b).chunk(2, dim=-1)
-    x = F.layer_norm(x + F.linear(_linear_attention(q, k, v), a.out_projection.weight, a.out_projection.bias),
-                     x.shape[-1:], p.norm1.weight, p.norm1.bias)
-    y = F.linear(F.relu(F.linear(x, p.linear1.weight, p.linear1.bias)), p.linear2.weight, p.linear2.bias)
-    return F.layer_norm(x + y, x.shape[-1:], p.norm2.weight, p.norm2.bias)
+    a = p.attention
+    return ops.fmt_layer([a.query_projection.weight, a.query_projection.bias, a.key_projection.weight,
+                          a.key_projection.bias, a.value_projection.weight, a.value_projection.bias,
+                          a.out_projection.weight, a.out_projection.bias, p.linear1.weight, p.linear1.bias,
+                          p.linear2.weight, p.linear2.bias, p.norm1.weight, p.norm1.bias, p.norm2.weight, p.norm2.bias],
+                         x, src)
 
 
 def _to_tokens(img: torch.Tensor) -> torch.Tensor:

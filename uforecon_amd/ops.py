@@ -72,12 +72,13 @@ def resolve_precision(precision: Optional[int]) -> int:
     return int(precision)
 
 
-def status_poll(synchronize: bool = True) -> int:
-    """ufr_status_poll: raises UfrError when the device's sticky range status is set (an activation beyond the fp16x3
-    planes' |x| < 4094, a non-finite transformer output, a weight beyond |w| < 255.8), clearing it.  With
-    ``synchronize=False`` only what an earlier launch has already delivered is reported (no host synchronisation)."""
+def status_poll(synchronize: bool = True, mask: int = 7) -> int:
+    """ufr_status_poll_bits: raises UfrError when one of the ``mask`` bits of the device's sticky range status is set (1: an
+    activation beyond the fp16x3 planes, 2: NaN among a transformer kernel's inputs, 4: a weight outside the planes'
+    range), clearing those bits.  With ``synchronize=False`` only what an earlier launch has already delivered is reported
+    (no host synchronisation)."""
     flags = C.c_int32(0)
-    _lib.check(_lib.load().ufr_status_poll(_stream(), int(bool(synchronize)), C.byref(flags)), "ufr_status_poll")
+    _lib.check(_lib.load().ufr_status_poll_bits(_stream(), int(bool(synchronize)), int(mask), C.byref(flags)), "ufr_status_poll")
     return int(flags.value)
 
 
@@ -111,7 +112,7 @@ class PackedWeights:
         ``check=True`` synchronises and raises at once (construction does)."""
         _lib.check(_lib.load().ufr_weights_pack(C.byref(self.raw), self.packed.data_ptr(), _stream()), "ufr_weights_pack")
         if check:
-            status_poll(True)
+            status_poll(True, mask=4)    # the pack's own bit: an unrelated, still unreported overflow must not fail a valid pack
 
     def mode(self) -> int:
         return resolve_precision(self.precision)
@@ -258,11 +259,23 @@ def project_gather(frame: FrameHandle, weights: PackedWeights, ray_o: torch.Tens
     return x, rgb, dirs, dbg
 
 
+def _max_points(NV: int) -> int:
+    """points one transformer launch addresses (32-bit offsets: P * (NV + 1) * 80 < 2^30, include/ufr.h)"""
+    return ((1 << 30) - 1) // ((NV + 1) * _lib.TOKEN_DIM)
+
+
 def aggregate(weights: PackedWeights, x: torch.Tensor, rgb: torch.Tensor, dirs: torch.Tensor, RN: int, SN: int,
               debug: bool = False, keep_workspace: bool = False, precision: Optional[int] = None):
     lib = _lib.load()
     NV, dev = x.shape[1], x.device
     P = RN * SN
+    rays_max = _max_points(NV) // SN
+    if RN > rays_max >= 1:      # beyond one launch's 32-bit addressing: rays are independent, so call per ray range
+        parts = [aggregate(weights, x[r0 * SN:(r0 + rays_max) * SN], rgb[r0 * SN:(r0 + rays_max) * SN],
+                           dirs[r0 * SN:(r0 + rays_max) * SN], min(rays_max, RN - r0), SN, debug, keep_workspace, precision)
+                 for r0 in range(0, RN, rays_max)]
+        dbg = {k: torch.cat([p[2][k] for p in parts]) for k in parts[0][2]}
+        return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts]), dbg
     radiance = torch.empty(P, 3, dtype=torch.float32, device=dev)
     srdf = torch.empty(RN, SN, dtype=torch.float32, device=dev)
     ws = torch.empty(lib.ufr_aggregate_workspace_bytes(RN, SN, NV) // 4, dtype=torch.float32, device=dev)
@@ -407,6 +420,12 @@ def view_transform(weights: PackedWeights, x: torch.Tensor, rgb: torch.Tensor, d
         radiance = torch.empty(P, 3, dtype=torch.float32, device=x.device)
     if token0.shape[0] != P or radiance.shape[0] != P:
         raise UfrError("view_transform: destination rows do not match the number of points")
+    pmax = _max_points(NV)
+    if P > pmax:                # beyond one launch's 32-bit addressing: points are independent, so call per point range
+        for p0 in range(0, P, pmax):
+            view_transform(weights, x[p0:p0 + pmax], rgb[p0:p0 + pmax], dirs[p0:p0 + pmax], token0[p0:p0 + pmax],
+                           radiance[p0:p0 + pmax], precision)
+        return token0, radiance
     _lib.check(_lib.load().ufr_view_transform(weights.packed.data_ptr(), _dev(x, "x_tokens"), _dev(rgb, "rgb"), _dev(dirs, "dir"),
                                               P, NV, _dev(token0, "token0"), _dev(radiance, "radiance"),
                                               weights.mode() if precision is None else precision, _stream()),

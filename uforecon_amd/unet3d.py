@@ -64,11 +64,39 @@ def cost_reg_net(m, x: torch.Tensor) -> torch.Tensor:
     return ops.conv3d(x, m.prob.weight, S1, out_ncdhw=True)
 
 
-@torch.no_grad()
+def _needs_grad(m, x: torch.Tensor) -> bool:
+    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in m.parameters()))
+
+
+def _cost_reg_net_weight_trainable(m, x: torch.Tensor):
+    """The same network through the module's own layers (library convolutions on the GPU): differentiable, which the
+    forward-only `ufr_conv3d` plan is not.  `feature_volume.cost_reg_2` is the one producer the reference trains
+    (model.py:75-83: everything but `transmvsnet.*`); its gradients arrive through the frustum scatter of
+    `ufr_project_gather_bwd`, so this path must keep the autograd graph (module.py:530-543)."""
+    if not x.is_cuda:
+        raise UfrError("the frustum U-Nets run on the GPU only (no CPU implementation)")
+    c0 = m.conv0(x)
+    c2 = m.conv2(m.conv1(c0))
+    c4 = m.conv4(m.conv3(c2))
+    y = m.conv6(m.conv5(c4))
+    y = c4 + m.conv7(y)
+    y = c2 + m.conv9(y)
+    y = c0 + m.conv11(y)
+    return m.features(y), torch.sigmoid(m.weights(y))
+
+
 def cost_reg_net_weight(m, x: torch.Tensor):
     """(B,1,D,H,W) cost volume -> feature frustum (B,8,D,H,W), weight frustum (B,1,D,H,W) = sigmoid.  Plain convolutions with
-    bias, no activation between them (as upstream); the two heads share one pass over the last feature map."""
+    bias, no activation between them (as upstream); the two heads share one pass over the last feature map.
+    When a gradient is wanted (grad mode on and the input or a parameter requires grad) the differentiable
+    library-convolution expression runs instead: the HIP plan is forward-only and would silently cut the graph."""
+    if _needs_grad(m, x):
+        return _cost_reg_net_weight_trainable(m, x)
+    with torch.no_grad():
+        return _cost_reg_net_weight_hip(m, x)
 
+
+def _cost_reg_net_weight_hip(m, x: torch.Tensor):
     def layer(name, t, mode, skip):
         conv = getattr(m, name)
         return ops.conv3d(t, conv.weight, mode, bias=conv.bias, skip=skip)

@@ -73,6 +73,15 @@ def parse(argv=None):
     p.add_argument("--no-secondary", action="store_true", help="skip the configs[3] / configs[4] measurements attached as "
                                                                 "`secondary` to a single-GPU line")
     p.add_argument("--secondary-train-steps", type=int, default=10)
+    p.add_argument("--config", default="", help="c3: BASELINE configs[2], the evaluation loop over 15 scenes x 3 render views "
+                                                 "(per-frame producers + sharded ray path + all-gather, uforecon_amd/evalset.py) "
+                                                 "instead of one pre-encoded frame")
+    p.add_argument("--frames", type=int, default=45, help="--config c3: frames of the evaluation set")
+    p.add_argument("--producers", default="replicated", choices=["replicated", "sharded"],
+                   help="--config c3, N > 1: every rank encodes every frame, or the frames' producers are dealt over the "
+                        "ranks and broadcast")
+    p.add_argument("--no-overlap", action="store_true", help="--config c3: encode frame k+1 only after frame k's rays")
+    p.add_argument("--dump-depths", default="", help="--config c3: rank 0 writes all depth maps here (.npy, frames x H x W)")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                                                       "exercise the multi-rank path on a box with fewer GPUs than ranks)")
     return p.parse_args(argv)
@@ -320,6 +329,78 @@ def measure_frames(a, dev, world, rank):
     return line
 
 
+def measure_evalset(a, dev, world, rank):
+    """BASELINE configs[2]: the evaluation loop (main.py:229-230 -> model.py:760-842) over a.frames synthetic frames."""
+    import numpy as np
+
+    from uforecon_amd import pipeline
+    from uforecon_amd.dist import RayShard
+    from uforecon_amd.evalset import EvalLoop, make_eval_batch
+    from uforecon_amd.scene import fill_state_dict
+
+    args = argparse.Namespace(extract_geometry=True, test_sample_coarse=a.coarse, test_sample_fine=a.fine, coarse_sample=a.coarse,
+                              fine_sample=a.fine, volume_type="correlation", volume_reso=96, mvs_depth_guide=1,
+                              depth_pos_encoding=True, use_dir_srdf=False, explicit_similarity=True, test_coarse_only=False,
+                              test_ray_num=800, test_n_view=a.views, out_dir=None)
+    # library convolutions of the backbone: the default algorithms (no per-process search), so that every process
+    # computes the same bits
+    net = fill_state_dict(pipeline.UFOReconInference(args, tune_convolutions=False), 21).eval().to(dev)
+    wz = np.load(os.path.join(ROOT, "tests", "golden", "ray_path_weights_seed0.npz"))
+    net.load_state_dict({k: torch.from_numpy(wz[k]) for k in wz.files}, strict=False)     # the per-ray path's seed-0 weights
+    batches = [make_eval_batch(a.height, a.width, a.views, k, dev) for k in range(a.frames)]
+    shard = RayShard(a.height, a.width, world, rank)
+    loop = EvalLoop(net, shard, n_streams=a.streams, overlap=not a.no_overlap, producers=a.producers, chunk_rays=a.chunk)
+    uni = None
+    if a.fixed_uniforms >= 0:
+        HW = a.height * a.width
+
+        def uni(k):
+            g = torch.Generator().manual_seed(a.fixed_uniforms * 1000 + k)
+            return torch.rand(a.coarse, HW, generator=g), torch.rand(a.fine, HW, generator=g)
+    warm = min(2, a.frames)
+    loop.run(batches[:warm], uni)                       # warm-up: allocator, first-use costs
+    st = loop.run(batches, uni, keep_depth=bool(a.dump_depths))
+    ops_mod = __import__("uforecon_amd.ops", fromlist=["status_poll"])
+    ops_mod.status_poll(True)
+    per_rank = None
+    mine = dict(rank=rank, encode_ms_mean=sum(st["encode_ms"]) / a.frames, ray_path_ms_mean=sum(st["ray_path_ms"]) / a.frames,
+                all_gather_ms_mean=sum(st["all_gather_ms"]) / a.frames, encodes=st["encodes_on_this_rank"],
+                ray_path_rays_per_s=st["ray_path_rays_per_s_this_rank"])
+    if world > 1:
+        import torch.distributed as dist
+
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        t = torch.tensor([st["wall_s"]], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        st["wall_s"] = float(t.item())
+    if a.dump_depths and rank == 0:
+        np.save(a.dump_depths, torch.stack(st["depths"]).cpu().numpy())
+    if rank != 0:
+        return None
+    HW = a.height * a.width
+    wall = st["wall_s"]
+    ray_only = sum(r["ray_path_rays_per_s"] for r in (per_rank or [mine]))
+    return dict(
+        metric=f"rays/s and depth-map ms/frame over the evaluation set ({a.frames} frames = 15 scenes x 3 render views, "
+               f"{a.views}-view {a.height}x{a.width}, {a.coarse}+{a.fine} samples), producers included",
+        value=HW * a.frames / wall, unit="rays/s", n_gpus=world, steps=a.frames, warmup=warm, ms_per_step=wall / a.frames * 1e3,
+        higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f32", mfma_operand_dtype="f16x3", data="synthetic",
+        config=dict(workload=f"configs[2]: per frame encode_frame (backbone, FMT, frustum cascade) -> this rank's row tile "
+                             f"through ufr_render_rays -> all-gather of the depth / RGB tiles; frame k+1's producers run on "
+                             f"a side stream beside frame k's rays" + ("" if not a.no_overlap else " (overlap OFF)"),
+                    frames=a.frames, rays_per_frame=HW, producers=a.producers if world > 1 else "local",
+                    depth_map_ms_per_frame_inclusive=wall / a.frames * 1e3,
+                    ray_path_only_rays_per_s=ray_only,
+                    encode_frame_ms=mine["encode_ms_mean"], ray_path_ms_per_frame_rank0=mine["ray_path_ms_mean"],
+                    all_gather_ms_per_frame_rank0=mine["all_gather_ms_mean"],
+                    note="encode_frame_ms and ray_path_ms are HIP-event intervals on their own streams; with the overlap on they "
+                         "run concurrently and each is stretched by the other's share of the GPU" if not a.no_overlap else
+                         "no overlap: the intervals add up to the frame time",
+                    scaling_note="unmeasured beyond this run's n_gpus: no multi-GPU box in the build environment" if world == 1 else None,
+                    per_rank=per_rank))
+
+
 def secondary_measurements(a, dev):
     """The other single-GPU configurations of BASELINE.json, measured in the same process after the headline run."""
     sec = {}
@@ -327,6 +408,15 @@ def secondary_measurements(a, dev):
                 "--warmup", "1", "--streams", str(a.streams), "--cpu-rays", "64", "--cpu-calls", "2", "--eager-chunks", "2"])
     c3.no_cpu_baseline, c3.no_gpu_eager_baseline = a.no_cpu_baseline, a.no_gpu_eager_baseline
     sec["configs[3]"] = measure_frames(c3, dev, 1, 0)
+    # configs[2] on this one GPU: the whole evaluation loop, producers included, with and without the producer overlap
+    ev = parse(["--config", "c3", "--frames", "45", "--streams", str(a.streams)])
+    sec["configs[2]@1gpu"] = measure_evalset(ev, dev, 1, 0)
+    ev_serial = parse(["--config", "c3", "--frames", "9", "--streams", str(a.streams), "--no-overlap"])
+    serial = measure_evalset(ev_serial, dev, 1, 0)
+    sec["configs[2]@1gpu"]["config"]["without_overlap"] = dict(
+        frames=9, depth_map_ms_per_frame_inclusive=serial["ms_per_step"], encode_frame_ms=serial["config"]["encode_frame_ms"],
+        ray_path_ms_per_frame=serial["config"]["ray_path_ms_per_frame_rank0"])
+    torch.cuda.empty_cache()
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_train
 
@@ -362,6 +452,14 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(a.backend)
+    if a.config == "c3":
+        line = measure_evalset(a, dev, world, rank)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     line = measure_frames(a, dev, world, rank)
     if rank == 0:
         if world == 1 and not a.no_secondary and config_name(a) == "configs[1]":

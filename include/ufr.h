@@ -400,7 +400,7 @@ typedef struct ufr_fmt_layer_weights {
   const float *w1, *b1, *w2, *b2;                     /* linear1 [64][32], [64]; linear2 [32][64], [32]             */
   const float *n1w, *n1b, *n2w, *n2b;                 /* norm1 / norm2 weight, bias [32]                            */
 } ufr_fmt_layer_weights;
-size_t ufr_fmt_layer_workspace_bytes(int32_t N);
+size_t ufr_fmt_layer_workspace_bytes(int32_t N, int32_t S);   /* S: source tokens per sample (T for self-attention) */
 int ufr_fmt_layer(const ufr_fmt_layer_weights* w, const float* x, const float* src, int32_t N, int32_t T, int32_t S,
                   float* out, void* workspace, ufr_stream stream);
 

@@ -136,6 +136,45 @@ def test_two_rank_bench_renders_the_one_rank_frame(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("producers", ["replicated", "sharded"])
+def test_two_rank_evaluation_loop_renders_the_one_rank_depth_maps(tmp_path, producers):
+    """BASELINE configs[2] through the real launcher path: the evaluation loop over several frames -- per-frame producers one
+    frame ahead on a side stream, this rank's row tile through ufr_render_rays, all-gather -- with 2 ranks sharing this box's
+    single GPU over gloo, the producers either replicated on both ranks or dealt over the ranks and broadcast: every depth
+    map must equal the 1-rank loop's bit for bit (rays are independent, the producers deterministic)."""
+    import json
+    import subprocess
+    import sys
+
+    import numpy as np
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--config", "c3", "--frames", "4", "--height", "128", "--width", "160", "--fixed-uniforms", "5", "--chunk", "2048",
+              "--producers", producers]
+    env = dict(os.environ, UFR_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dump-depths", str(tmp_path / "d1.npy"),
+                          *common], capture_output=True, text=True, env=env, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--dump-depths", str(tmp_path / "d2.npy"), *common], capture_output=True, text=True, env=env, timeout=1200)
+    assert two.returncode == 0, two.stderr[-2000:]
+    d1, d2 = np.load(tmp_path / "d1.npy"), np.load(tmp_path / "d2.npy")
+    assert d1.shape == d2.shape == (4, 128, 160)
+    assert np.isfinite(d1).all() and len({d1[k].tobytes() for k in range(4)}) == 4       # four different frames
+    assert np.array_equal(d1, d2)
+    line = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["frames"] == 4 and len(line["config"]["per_rank"]) == 2
+    encodes = sorted(r["encodes"] for r in line["config"]["per_rank"])
+    assert encodes == ([4, 4] if producers == "replicated" else [2, 2])
+    for k in ("encode_frame_ms", "ray_path_ms_per_frame_rank0", "depth_map_ms_per_frame_inclusive", "ray_path_only_rays_per_s"):
+        assert line["config"][k] > 0
+
+
+@pytest.mark.gpu
 def test_two_rank_training_step_allreduces_to_the_mean(tmp_path):
     """The data-parallel leg of BASELINE configs[4] through the real launcher path (torch.distributed.run -> one process per
     rank -> tools/bench_train.py --gpus 2), both ranks on this box's single GPU over gloo: every rank trains on its own

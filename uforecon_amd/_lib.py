@@ -113,7 +113,7 @@ SIGNATURES = {
                                      C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp, i32, i32, C.c_float, i32, vp]),
     "ufr_deform_conv2d_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "ufr_deform_conv2d": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
-    "ufr_fmt_layer_workspace_bytes": (sz, [i32]),
+    "ufr_fmt_layer_workspace_bytes": (sz, [i32, i32]),
     "ufr_fmt_layer": (C.c_int, [C.POINTER(FmtLayerWeights), vp, vp, i32, i32, i32, vp, vp, vp]),
     "ufr_profile_enable": (None, [C.c_int]),
     "ufr_profile_read": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(i32), C.c_int]),

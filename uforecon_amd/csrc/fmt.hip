@@ -5,8 +5,10 @@
 //   LinearAttention.forward FMT.py:25-38                             phi = elu + 1; KV_h = sum_s phi(k_s)^T v_s (4x4 per head),
 //                                                                    out_l = phi(q_l) KV_h / (phi(q_l) . sum_s phi(k_s) + eps)
 // The layer is a global reduction over the source tokens (the 8 x (16 + 4) state per sample) followed by a purely
-// per-token map, so it is two kernels: `fmt_state_kernel` (every thread folds a few source tokens into 160 register
-// accumulators, wave reduction, one atomic per value and wave) and `fmt_apply_kernel` (one token per thread: 6 272 FMAs with
+// per-token map, so it is two kernels (+ a tiny fixed-order sum): `fmt_state_kernel` (every thread folds a few source tokens
+// into 160 register accumulators, wave reduction, one PARTIAL per wave -- summed in a fixed order by `fmt_state_sum_kernel`,
+// not with float atomics: the frame encoder must give the same bits in every process, or a frame rendered by two ranks
+// would not equal the same frame rendered by one) and `fmt_apply_kernel` (one token per thread: 6 272 FMAs with
 // the weights broadcast from LDS).  d = 32 is too narrow for the matrix cores to pay (a 16x16x4 tile chain would be all
 // latency); on the VALU the whole stage of a 512x640 3-view frame (about 70 layer passes over 20 480 tokens) is ~9 GFMA.
 #include "ufr_device.h"
@@ -43,8 +45,9 @@ constexpr int kFmtTokPerBlock = 1024;   // source tokens folded by one workgroup
 
 // state[n][h*16 + m*4 + d] = sum_s phi(k_s)[4h+d] v_s[4h+m];  state[n][128 + 4h + d] = sum_s phi(k_s)[4h+d]
 // thread = (token slot, head): 8 adjacent lanes share a token (one broadcast load) and each owns one head's 16 + 4 sums
+// partial[n][part = 4 blockIdx.x + wave][160]
 __global__ void __launch_bounds__(256) fmt_state_kernel(FmtWeights w, const float* __restrict__ src, int S,
-                                                         float* __restrict__ state) {
+                                                         float* __restrict__ partial) {
   __shared__ __attribute__((aligned(16))) float sw[2 * kFmtD * kFmtD + 2 * kFmtD];
   float* swk = sw;
   float* swv = sw + kFmtD * kFmtD;
@@ -90,12 +93,21 @@ __global__ void __launch_bounds__(256) fmt_state_kernel(FmtWeights w, const floa
     ks[i] += __shfl_xor(ks[i], 32);
   }
   if ((threadIdx.x & 63) < 8) {
-    float* dst = state + (size_t)n * kFmtState;
+    float* dst = partial + ((size_t)n * (gridDim.x * 4) + blockIdx.x * 4 + (threadIdx.x >> 6)) * kFmtState;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) unsafeAtomicAdd(dst + h * 16 + i, kv[i]);
+    for (int i = 0; i < 16; ++i) dst[h * 16 + i] = kv[i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) unsafeAtomicAdd(dst + 128 + 4 * h + i, ks[i]);
+    for (int i = 0; i < 4; ++i) dst[128 + 4 * h + i] = ks[i];
   }
+}
+
+// state[n][i] = sum over the parts in index order
+__global__ void __launch_bounds__(kFmtState) fmt_state_sum_kernel(const float* __restrict__ partial, int parts, float* __restrict__ state) {
+  const int n = blockIdx.x, i = threadIdx.x;
+  const float* p = partial + (size_t)n * parts * kFmtState + i;
+  float s = 0.f;
+  for (int k = 0; k < parts; ++k) s += p[(size_t)k * kFmtState];
+  state[(size_t)n * kFmtState + i] = s;
 }
 
 template <int D>
@@ -193,12 +205,15 @@ __global__ void __launch_bounds__(256) fmt_apply_kernel(FmtWeights w, const floa
   for (int i = 0; i < 8; ++i) st4(dst + 4 * i, f32x4{hsum[4 * i], hsum[4 * i + 1], hsum[4 * i + 2], hsum[4 * i + 3]});
 }
 
+int fmt_state_parts(int S) { return 4 * ((S + kFmtTokPerBlock - 1) / kFmtTokPerBlock); }
+
+// state: N x 160 floats followed by N x fmt_state_parts(S) x 160 floats of per-wave partials
 hipError_t launch_fmt_layer(const FmtWeights& w, const float* x, const float* src, int N, int T, int S, float* out,
                             float* state, hipStream_t s) {
-  hipError_t e = hipMemsetAsync(state, 0, sizeof(float) * (size_t)N * kFmtState, s);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(fmt_state_kernel, dim3((S + kFmtTokPerBlock - 1) / kFmtTokPerBlock, N), dim3(256), 0, s, w,
-                     src, S, state);
+  const int parts = fmt_state_parts(S);
+  float* partial = state + (size_t)N * kFmtState;
+  hipLaunchKernelGGL(fmt_state_kernel, dim3(parts / 4, N), dim3(256), 0, s, w, src, S, partial);
+  hipLaunchKernelGGL(fmt_state_sum_kernel, dim3(N), dim3(kFmtState), 0, s, partial, parts, state);
   hipLaunchKernelGGL(fmt_apply_kernel, dim3((T + 255) / 256, N), dim3(256), 0, s, w, x, T, state, out);
   return hipGetLastError();
 }

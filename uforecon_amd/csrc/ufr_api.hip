@@ -1003,7 +1003,9 @@ int ufr_deform_conv2d(const float* input, const float* offset, const float* mask
 }
 
 // ------------------------------------------------------------------ feature-matching transformer layer
-size_t ufr_fmt_layer_workspace_bytes(int32_t N) { return align_up((size_t)(N > 0 ? N : 1) * 160 * sizeof(float)); }
+size_t ufr_fmt_layer_workspace_bytes(int32_t N, int32_t S) {
+  return align_up((size_t)(N > 0 ? N : 1) * 160 * sizeof(float) * (1 + (size_t)fmt_state_parts(S > 0 ? S : 1)));
+}
 
 int ufr_fmt_layer(const ufr_fmt_layer_weights* w, const float* x, const float* src, int32_t N, int32_t T, int32_t S,
                   float* out, void* workspace, ufr_stream stream) {

@@ -110,6 +110,7 @@ hipError_t launch_gather_bwd(const FrameDev& f, float* const* grad_feat, float* 
 struct FmtWeights {  // = ufr_fmt_layer_weights
   const float *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo, *w1, *b1, *w2, *b2, *n1w, *n1b, *n2w, *n2b;
 };
+int fmt_state_parts(int S);   // per-wave partial states of one sample's source tokens
 hipError_t launch_fmt_layer(const FmtWeights& w, const float* x, const float* src, int N, int T, int S, float* out,
                             float* state, hipStream_t s);
 hipError_t launch_pack_weights(const RawPtrs& raw, float* packed, int* range_flag, hipStream_t s);

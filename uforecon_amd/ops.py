@@ -562,7 +562,7 @@ def fmt_layer(params, x: torch.Tensor, src: Optional[torch.Tensor]) -> torch.Ten
             raise UfrError(f"fmt_layer: source tokens {tuple(src.shape)} do not match {tuple(x.shape)}")
         S = src.shape[1]
     out = torch.empty_like(x)
-    ws = torch.empty(lib.ufr_fmt_layer_workspace_bytes(N) // 4, dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib.ufr_fmt_layer_workspace_bytes(N, S) // 4, dtype=torch.float32, device=x.device)
     _lib.check(lib.ufr_fmt_layer(C.byref(w), _dev(x, "x"), _opt(src, "src"), N, T, S, out.data_ptr(), ws.data_ptr(),
                                  _stream()), "ufr_fmt_layer")
     return out

@@ -262,6 +262,7 @@ def measure_frames(a, dev, world, rank):
         rt_flop = RAYT_FLOP_PER_POINT * (RN * ray_evals_per_ray * prof_steps) / max(rt["launches"], 1)
         rt_achieved = rt_flop / (rt_ms * 1e-3) / 1e12 if rt_ms > 0 else 0.0
         traffic, traffic_src = None, None
+        pmc_vt, pmc_rt, pmc_src = None, None, None
         try:  # HBM bytes per view-transformer launch from the latest committed PMC pass OF THIS CONFIGURATION
             # (profiles/rN_pmc.json: configs[1]; profiles/rN_c4_pmc.json: configs[3], the L = 6 instantiation)
             import glob
@@ -270,14 +271,28 @@ def measure_frames(a, dev, world, rank):
             for k, v in json.load(open(pj)).items():
                 if f"view_transformer_kernel<{a.views + 1}," in k and v.get("hbm_bytes_per_launch"):
                     traffic, traffic_src = v["hbm_bytes_per_launch"], os.path.relpath(pj, ROOT)
+                if f"view_transformer_kernel<{a.views + 1}," in k and v.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+                    pmc_vt, pmc_src = v, os.path.relpath(pj, ROOT)
+                if k.startswith("ray_transformer_kernel") and v.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+                    pmc_rt = v
         except Exception:  # noqa: BLE001
             pass
+
+        def pmc_fracs(v, algo_flop_per_launch_in_that_run):
+            """From the committed SQ counter pass: the fraction of the launch the matrix pipes were busy (busy cycles summed
+            over the 1024 SIMDs / launch duration at the 2.4 GHz the peak assumes) and issued / algorithmic matrix work
+            (SQ_INSTS_MFMA wave instructions x 16 384 flop of a 16x16x32 MFMA / 3 plane products / the algorithmic flop)."""
+            if not v or not v.get("avg_ns[pmc_sq]"):
+                return None, None
+            busy = v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (v["avg_ns[pmc_sq]"] * 2.4)
+            issued = v.get("SQ_INSTS_MFMA", 0.0) * 16384.0 / 3.0
+            return busy, (issued / algo_flop_per_launch_in_that_run if algo_flop_per_launch_in_that_run else None)
         line = dict(
             metric=f"rays/s (per-ray volume-rendering path, {a.coarse}+{a.fine} hierarchical samples, DTU-shaped "
                    f"{a.views}-view {a.height}x{a.width})",
             value=rays_per_s, unit="rays/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
             ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None,
-            dtype="f32", data="synthetic",
+            dtype="f32", mfma_operand_dtype="f16x3", data="synthetic",
             config=dict(workload=f"{cfg}: full {a.height}x{a.width} frame = {HW} rays, {a.views} source views, "
                                  f"{a.coarse}+{a.fine} samples, rays sharded by row tiles over {world} GPU(s), depth/RGB "
                                  f"tiles all-gathered",
@@ -314,6 +329,12 @@ def measure_frames(a, dev, world, rank):
                           # 840 v_mfma_f32_16x16x32_f16 (16 384 flop each) per 8 points at NV = 3, K / row padding included
                           issued_f16_tflops=achieved * (840 * 16384 / 8) / VIEWT_FLOP_PER_POINT[3] if a.views == 3 else None),
         )
+        # reproducible from profiles/ without trusting the peak basis: matrix-pipe busy fraction and issued / algorithmic work
+        # of the same kernels in the committed counter pass (which ran the same chunking: points per launch = vt_pts_per_launch)
+        busy, over = pmc_fracs(pmc_vt, vt_flop)
+        line["roofline"].update(mfma_busy_frac=busy, issued_over_algorithmic=over, pmc_source=pmc_src)
+        rbusy, rover = pmc_fracs(pmc_rt, rt_flop)
+        line["roofline"]["ray_transformer"].update(mfma_busy_frac=rbusy, issued_over_algorithmic=rover)
         if not a.no_gpu_eager_baseline and world == 1:
             # the >= 20x target's denominator, measured in the same run on the same GPU (BASELINE.md has no published
             # number: vs_baseline is relative to this leg, not to a figure from the reference's authors)
@@ -418,7 +439,16 @@ def secondary_measurements(a, dev):
         ray_path_ms_per_frame=serial["config"]["ray_path_ms_per_frame_rank0"])
     torch.cuda.empty_cache()
     sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_correlate
+    import bench_encoder
     import bench_train
+    import bench_tsdf
+
+    # the per-frame producers and the consumer of the depth maps: driver-timed numbers with achieved GB/s
+    sec["encode_frame"] = bench_encoder.measure(512, 640, reps=3)
+    sec["correlate"] = bench_correlate.measure(reps=20)
+    sec["tsdf"] = bench_tsdf.measure(384, reps=10)
+    torch.cuda.empty_cache()
 
     # both GPU measurements first, the CPU leg after them (its worker threads keep spinning for a while and slow the
     # host side of a step that follows)

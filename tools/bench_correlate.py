@@ -17,10 +17,10 @@ DEV = "cuda:0"
 STAGES = [("stage1", 32, 128, 160, 48), ("stage2", 16, 256, 320, 32), ("stage3", 8, 512, 640, 8)]
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--reps", type=int, default=20)
-    a = ap.parse_args()
+def measure(reps: int = 20, verbose: bool = False):
+    """-> one dict per cascade stage: launch time, algorithmic bytes, achieved GB/s, fraction of the 8 TB/s roof"""
+    rows = []
+    a = argparse.Namespace(reps=reps)
     for name, C, H, W, D in STAGES:
         c = make_correlate_case("custom", C=C, H=H, W=W, D=D, NV=3, seed=7)
         args = (c["ref_fea"].to(DEV), torch.stack(c["src_feas"]).to(DEV), c["ref_proj_pair"], c["src_proj_pairs"],
@@ -40,9 +40,20 @@ def main():
         feat = (1 + NS) * C * H * W * 4
         algo = 3 * feat + D * H * W * 4 * 2 + NS * H * W * 4
         ref_bytes = NS * 2 * C * D * H * W * 4
-        print(f"{name}: C={C} {H}x{W} D={D}: {ms * 1e3:8.1f} us/launch  {algo / ms / 1e6:7.1f} GB/s algorithmic "
-              f"({algo / 1e6:.1f} MB; {algo / ms / 1e6 / 8000:.1%} of the 8 TB/s roof); samples/s "
-              f"{NS * D * H * W / ms / 1e6:.2f} G; warped volume the reference materialises: {ref_bytes / 1e6:.0f} MB")
+        rows.append(dict(stage=name, channels=C, height=H, width=W, depth_hypotheses=D, ms_per_launch=ms,
+                         algorithmic_bytes=algo, achieved_gbps=algo / ms / 1e6, hbm_frac=algo / ms / 1e6 / 8000,
+                         samples_per_s=NS * D * H * W / ms * 1e3, reference_warped_volume_bytes=ref_bytes))
+        if verbose:
+            print(f"{name}: C={C} {H}x{W} D={D}: {ms * 1e3:8.1f} us/launch  {algo / ms / 1e6:7.1f} GB/s algorithmic "
+                  f"({algo / 1e6:.1f} MB; {algo / ms / 1e6 / 8000:.1%} of the 8 TB/s roof); samples/s "
+                  f"{NS * D * H * W / ms / 1e6:.2f} G; warped volume the reference materialises: {ref_bytes / 1e6:.0f} MB")
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    measure(ap.parse_args().reps, verbose=True)
 
 
 if __name__ == "__main__":

@@ -14,13 +14,8 @@ from uforecon_amd import pipeline  # noqa: E402
 from uforecon_amd.scene import fill_state_dict, make_frame  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--height", type=int, default=512)
-    ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--tune", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen algorithm search)")
-    a = ap.parse_args()
+def measure(height: int = 512, width: int = 640, reps: int = 3, tune: bool = False, verbose: bool = False):
+    a = argparse.Namespace(height=height, width=width, reps=reps, tune=tune)
     torch.backends.cudnn.benchmark = a.tune
     dev, NV = "cuda:0", 3
     fr = make_frame(a.height, a.width, NV, seed=0).to(dev)
@@ -62,13 +57,31 @@ def main():
         pr = ops.profile_read()
         ops.profile_enable(False)
         dcn = pr.get("deform_conv2d", dict(ms=0.0, launches=0))
-        print(f"   of FeatureNet: {dcn['launches']} deformable convolutions, {dcn['ms']:.1f} ms in the HIP kernel (+ re-layout)")
+        if verbose:
+            print(f"   of FeatureNet: {dcn['launches']} deformable convolutions, {dcn['ms']:.1f} ms in the HIP kernel (+ re-layout)")
         t_fmt, feats2 = timed(lambda: net.transmvsnet.encode([dict(f) for f in feats], ref_idx=0))
         t_cas, info = timed(lambda: net.transmvsnet(feats2, pmr, dv, (a.height, a.width)))
         t_vol, _ = timed(lambda: [net.feature_volume(batch, info[st]["cost_volume"]) for st in ("stage1", "stage2", "stage3")])
         t_all, _ = timed(lambda: net.encode_frame(batch))
-    print(f"{a.height}x{a.width}, {NV} views ({NV} rotations): FeatureNet {t_fn:.1f} ms, FMT {t_fmt:.1f} ms, cascade (3 stages: "
-          f"correlate + PixelwiseNet + CostRegNet) {t_cas:.1f} ms, CostRegNetWeight x3 {t_vol:.1f} ms; encode_frame total {t_all:.1f} ms")
+    if verbose:
+        print(f"{a.height}x{a.width}, {NV} views ({NV} rotations): FeatureNet {t_fn:.1f} ms, FMT {t_fmt:.1f} ms, cascade (3 stages: "
+              f"correlate + PixelwiseNet + CostRegNet) {t_cas:.1f} ms, CostRegNetWeight x3 {t_vol:.1f} ms; encode_frame total {t_all:.1f} ms")
+    del net, fr, batch
+    torch.cuda.empty_cache()
+    return dict(height=a.height, width=a.width, views=NV, encode_frame_ms=t_all,
+                parts_ms_timed_separately=dict(featurenet_with_the_references_redundancy=t_fn, fmt=t_fmt,
+                                               cascade_correlate_pixelwise_costreg=t_cas, cost_reg_net_weight_x3=t_vol),
+                deformable_convolution_ms=dcn["ms"], miopen_algorithm_search=bool(a.tune))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--tune", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen algorithm search)")
+    a = ap.parse_args()
+    measure(a.height, a.width, a.reps, a.tune, verbose=True)
 
 
 if __name__ == "__main__":

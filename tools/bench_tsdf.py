@@ -25,11 +25,8 @@ def scene(n, H=512, W=640):
     return K, P, depth, bnds, vs
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--n", type=int, default=384)
-    ap.add_argument("--reps", type=int, default=10)
-    a = ap.parse_args()
+def measure(n: int = 384, reps: int = 10, verbose: bool = False):
+    a = argparse.Namespace(n=n, reps=reps)
     K, P, depth, bnds, vs = scene(a.n)
     vol = tsdf.TSDFVolume(bnds.copy(), voxel_size=vs, margin=3)
     d = torch.from_numpy(depth).cuda()
@@ -45,9 +42,21 @@ def main():
     n_vox = int(np.prod(vol._vol_dim))
     upd = int((vol._weight_vol_gpu > 0).sum())
     algo = 16 * upd
-    print(f"volume {tuple(vol._vol_dim)} = {n_vox / 1e6:.1f} M voxels, {upd / 1e6:.2f} M updated per observation: "
-          f"{ms * 1e3:.1f} us/launch, {n_vox / ms / 1e6:.1f} G voxels/s, algorithmic {algo / 1e6:.1f} MB -> "
-          f"{algo / ms / 1e6:.0f} GB/s = {algo / ms / 1e6 / 8000:.1%} of the 8 TB/s roof")
+    if verbose:
+        print(f"volume {tuple(vol._vol_dim)} = {n_vox / 1e6:.1f} M voxels, {upd / 1e6:.2f} M updated per observation: "
+              f"{ms * 1e3:.1f} us/launch, {n_vox / ms / 1e6:.1f} G voxels/s, algorithmic {algo / 1e6:.1f} MB -> "
+              f"{algo / ms / 1e6:.0f} GB/s = {algo / ms / 1e6 / 8000:.1%} of the 8 TB/s roof")
+    return dict(volume=[int(v) for v in vol._vol_dim], voxels=n_vox, updated_voxels=upd, ms_per_observation=ms,
+                voxels_per_s=n_vox / ms * 1e3, algorithmic_bytes=algo, achieved_gbps=algo / ms / 1e6,
+                hbm_frac=algo / ms / 1e6 / 8000, depth_map="512x640")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=384)
+    ap.add_argument("--reps", type=int, default=10)
+    a = ap.parse_args()
+    measure(a.n, a.reps, verbose=True)
 
 
 if __name__ == "__main__":

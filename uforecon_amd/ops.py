@@ -489,7 +489,7 @@ def view_transform_bwd(weights: PackedWeights, grads: GradBuffer, x, rgb, dirs, 
 class RenderWorkspace:
     """Reusable scratch of ufr_render_rays (sized for `chunk_rays`)."""
 
-    def __init__(self, device, SN: int, PN: int, NV: int, chunk_rays: int = 0, n_streams: int = 2):
+    def __init__(self, device, SN: int, PN: int, NV: int, chunk_rays: int = 0, n_streams: int = 3):
         lib = _lib.load()
         self.chunk = chunk_rays if chunk_rays > 0 else lib.ufr_default_chunk_rays()
         self.n_streams = max(1, int(n_streams))

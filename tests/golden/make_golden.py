@@ -41,7 +41,12 @@ CASES = {
     # training layout (s_idx=1, no near/far division), forward only
     "c5_train_fwd": dict(H=64, W=96, NV=3, seed=5, RN=64, coarse=64, fine=64, train=True),
     # configs[1] at the full 512x640 frame on rays strictly inside every source image: depth AND RGB on 100 % of the rays
-    "c2_hier_512x640_interior": dict(H=512, W=640, NV=3, seed=0, RN=256, coarse=64, fine=64, interior=True),
+    # `srdf64`: the dense half of the path (view / ray transformer, DensityMLP) evaluated in float64 on the fp32 token inputs at
+    # the reference's own sample positions -- a host-independent yardstick for the kernels' srdf rows (the fp32 reference is
+    # itself one rounding realisation: two CPUs differ by 6e-5 here)
+    "c2_hier_512x640_interior": dict(H=512, W=640, NV=3, seed=0, RN=256, coarse=64, fine=64, interior=True, srdf64=True),
+    # BASELINE.json configs[3] AT FULL SIZE: 5 views, 600x800, 128+128 samples, rays strictly inside every source image
+    "c4_full_interior": dict(H=600, W=800, NV=5, seed=3, RN=256, coarse=128, fine=128, interior=True, srdf64=True),
     # statistics of a TRAINED checkpoint instead of the default init (the real checkpoint is absent: .MISSING_LARGE_BLOBS):
     # every weight matrix x 8, LayerNorm gains up to 10 and biases in [-1, 1], 2-D feature maps x 30 -- dense-layer inputs
     # reach ~1e3 (the split-precision planes hold |x| < 4094, |w| < 255.8).  The modified weights travel in the fixture.
@@ -152,6 +157,40 @@ def clean_ray_indices(model, fr, H, W, RN, sampler_seed, train, relu_margin=0.0,
     raise RuntimeError("could not find a clean ray set")
 
 
+def srdf_in_float64(model, fr, pts):
+    """srdf (RN,SN) at the sample positions `pts` (RN,SN,3) with EVERYTHING after the positions in float64: projection,
+    gathers, pair similarity, frustum lookup, depth code, both transformers, DensityMLP -- through the functional
+    restatement oracle/ufo_oracle.py (which reproduces the reference's fp32 rows to 2e-6) on float64 copies of the frame
+    and the weights.  This is what the fp32 evaluations (the reference on any CPU, the kernels) are rounding realisations of."""
+    from oracle import ufo_oracle as O
+
+    def d(t):
+        if torch.is_tensor(t):
+            return t.double() if t.is_floating_point() else t
+        if isinstance(t, dict):
+            return {k: d(v) for k, v in t.items()}
+        if isinstance(t, list):
+            return [d(v) for v in t]
+        return t
+
+    P = d({k: v.detach() for k, v in ray_path_state_dict(model).items()})
+    batch, feat, vols, match, pts = d(fr.batch), d(fr.source_imgs_feat), d(fr.feature_volume), d(fr.match_feature), pts.double()
+    RN, SN, _ = pts.shape
+    with torch.no_grad():
+        s_idx = batch["start_idx"] if "start_idx" in batch else 1
+        poses = batch["source_poses"][0]
+        NV = poses.shape[0]
+        xy, _, mask_z = O.project(poses, pts)
+        sim8 = O.pair_similarity(xy, match[0][0], NV)
+        vol24 = O.volume_lookup(poses, pts, vols, batch["near_fars"][0][0])
+        x, rgb, dirs, mask = O.gather_inputs(P, pts, batch, feat[0], vol24, sim8, xy, mask_z.double(), s_idx)
+        dirp = dirs.permute(1, 2, 0, 3).reshape(RN * SN, NV, 3).double()
+        maskp = mask.permute(1, 2, 0).reshape(RN * SN, NV).double()
+        rgbp = rgb.permute(2, 3, 0, 1).reshape(RN * SN, NV, 3).double()
+        _, srdf = O.aggregate_tokens(P, x.double(), rgbp, maskp, dirp, RN, SN)
+    return srdf.reshape(RN, SN)
+
+
 def run_case(name, c, weight_seed=0, sampler_seed=1):
     train = c.get("train", False)
     model = build_reference_model(weight_seed, test_sample_coarse=c["coarse"], test_sample_fine=c["fine"],
@@ -247,6 +286,10 @@ def run_case(name, c, weight_seed=0, sampler_seed=1):
         out.update(srdf=srdf[0].numpy(), points=pts[0].numpy(), depth=depth[0].numpy(), rgb=rgb[0].numpy())
     for k, v in cap.items():
         out[k] = v.numpy()
+    if c.get("srdf64"):
+        out["srdf64"] = srdf_in_float64(model, fr, torch.from_numpy(out["points"])).numpy().astype(np.float32)
+        e = np.abs(out["srdf64"] - out["srdf"]).max() / np.abs(out["srdf"]).max()
+        print(f"  float64 evaluation vs the reference's fp32 srdf at its own positions: {e:.2e} of scale")
     np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
     print(f"{name}: {len(out)} arrays, {os.path.getsize(os.path.join(HERE, name + '.npz')) / 1e6:.2f} MB")
     return model

@@ -21,7 +21,8 @@ CASES = {
     "c5_train_fwd": dict(H=64, W=96, NV=3, seed=5, RN=64, coarse=64, fine=64, train=True),
     "c2_hier_interior": dict(H=64, W=96, NV=3, seed=7, RN=256, coarse=64, fine=64, interior=True),
     "c4_nv5_interior": dict(H=48, W=64, NV=5, seed=8, RN=48, coarse=64, fine=64, interior=True),
-    "c2_hier_512x640_interior": dict(H=512, W=640, NV=3, seed=0, RN=256, coarse=64, fine=64, interior=True),
+    "c2_hier_512x640_interior": dict(H=512, W=640, NV=3, seed=0, RN=256, coarse=64, fine=64, interior=True, srdf64=True),
+    "c4_full_interior": dict(H=600, W=800, NV=5, seed=3, RN=256, coarse=128, fine=128, interior=True, srdf64=True),
     "c2_trained_like": dict(H=64, W=96, NV=3, seed=9, RN=128, coarse=64, fine=64, interior=True,
                             trained_like=dict(w=8.0, gamma=10.0, feat=30.0)),
 }

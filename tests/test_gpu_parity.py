@@ -135,7 +135,11 @@ def test_render_rays_matches_reference_golden(name, weights):
     # ulp of the sample position (rows of the render view are aligned with source view 0), so the
     # reference is discontinuous and no implementation can track it; such rays must stay rare.
     degenerate = border_degenerate_rays(want["coarse" if c.get("coarse_only") else "fine"])
-    assert float(degenerate.float().mean()) < 0.15
+    frac = float(degenerate.float().mean())
+    print(f"{name}: {frac:.1%} of the rays have a sample within 2e-5 of a source-image border (RGB not asserted on them)")
+    # the small frames' ray grids include whole first / last pixel rows, which project onto y = -+1 of source view 0 exactly;
+    # at the benchmark's 512x640 the excluded rays must stay below 5 % (and the *_interior fixtures assert RGB on 100 %)
+    assert frac < (0.05 if name == "c2_hier_512x640" else 0.15)
     ok = ~degenerate
     assert max_rel_elem(out["rgb"][ok.to(DEV)], rgb_ref[ok], floor=0.05) < REL_TOL
     assert rel_err(out["z_all"], (torch.from_numpy(g["points"]) - fr.batch["ray_o"][0]).norm(dim=-1)) < 1e-5

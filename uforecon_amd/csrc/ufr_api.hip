@@ -169,7 +169,7 @@ int status_message(int bits, const char* who) {
   return fail(UFR_ERR_RANGE, "%s: range status 0x%x:%s%s%s (include/ufr.h: ufr_status_poll)", who, bits,
               (bits & 1) ? " a dense-layer input reached |x| >= 4094 (fp16 planes overflowed);" : "",
               (bits & 2) ? " NaN among the token / dir inputs handed to a transformer kernel;" : "",
-              (bits & 4) ? " ufr_weights_pack met a weight that is not finite or outside the fp16 planes' range;" : "");
+              (bits & 4) ? " ufr_weights_pack met a weight that is not finite or |w| >= 255.8;" : "");
 }
 
 // what the last delivered copy says about the CURRENT generation, restricted to `mask`; reported bits are cleared on the
@@ -488,8 +488,9 @@ struct ViewBwdWs { float *tape, *dbuf, *token0, *radiance; int blocks; };
 static ViewBwdWs carve_view_bwd(Carver& c, int P, int NV) {
   ViewBwdWs w;
   w.blocks = view_tape_blocks(P, NV);
-  w.tape = c.f32((size_t)w.blocks * TV_COUNT * kBlockCols * kTileFloats);
-  w.dbuf = c.f32((size_t)w.blocks * DV_COUNT * kBlockCols * kTileFloats);
+  // sized for the fp32 layouts (the 16-bit mode's are smaller)
+  w.tape = c.f32((size_t)w.blocks * ViewTapeLayout<false>::block_units * 128);
+  w.dbuf = c.f32((size_t)w.blocks * ViewGradLayout<false>::block_units * 128);
   w.token0 = c.f32((size_t)P * UFR_TOKEN_DIM);
   w.radiance = c.f32((size_t)P * 3);
   return w;
@@ -506,7 +507,7 @@ static int view_bwd_impl(const void* packed, const GradPtrs& gp, const float* x_
   }
   {
     ProfScope p("view_dgrad", s);
-    UFR_HIP(launch_view_dgrad(pk, w.tape, rgb, d_tok_a, d_tok_b, d_radiance, P, NV, w.dbuf, d_pv, lowp, s));
+    UFR_HIP(launch_view_dgrad(pk, w.tape, rgb, d_tok_a, d_tok_b, d_radiance, P, NV, w.dbuf, d_pv, gp, lowp, s));
   }
   {
     ProfScope p("view_wgrad", s);

@@ -94,8 +94,8 @@ int view_tape_blocks(int P, int NV);
 hipError_t launch_view_tape(const float* packed, const float* x_tokens, const float* rgb, const float* dir, int P, int NV,
                             float* token0, float* radiance, float* tape, bool lowp, int* status, hipStream_t s);
 hipError_t launch_view_dgrad(const float* packed, const float* tape, const float* rgbm, const float* d_tok_a,
-                             const float* d_tok_b, const float* d_radiance, int P, int NV, float* dbuf, float* d_pv, bool lowp,
-                             hipStream_t s);
+                             const float* d_tok_b, const float* d_radiance, int P, int NV, float* dbuf, float* d_pv,
+                             const GradPtrs& gp, bool lowp, hipStream_t s);
 hipError_t launch_view_wgrad(const float* tape, const float* dbuf, int n_blocks, const GradPtrs& gp, bool lowp, hipStream_t s);
 // tok_row (nullable): pool row of sample (ray, s) for token0 AND for the d_tok_a / d_tok_b rows it produces; accumulate:
 // d_tok_* += (every pool row is written once per launch, so a plain read-modify-write)

@@ -8,10 +8,13 @@
 // TRANSPOSED weights stream through the same LDS ring as bf16 planes (ufr_layout_f16.h: B_VTB; three plane products per
 // fp32 product, one in the 16-bit mode).  Everything the chain needs from the forward comes from the tape
 // (bwd_tape.h, written by view_transformer_kernel<.., TAPE>); every layer-output cotangent goes to the dY tile buffer, from
-// which wgrad_stream.hip contracts the weight gradients over the tokens.  No token reduction happens here: LayerNorm
-// gamma / beta, biases and the view token are row sums / diagonals of tile products and are formed there too.
+// which wgrad_stream.hip contracts the weight gradients over the tokens.  The only token reductions here are the
+// elementwise ones -- LayerNorm gamma / beta and the view token: 100 values per lane group and iteration, all-reduced over
+// the 16 token lanes of a DPP row (four v_add_f32_dpp each) and added to the gradient tensors with one atomic instruction
+// per ten values; as tiles through HBM they were a sixth of the three kernels' traffic.
 // Outputs of this kernel itself: the dY tiles and d_pv (P,40) = the gradient w.r.t. the 24 frustum features and the 16
 // pre_sim_mlp outputs of each point, summed over its NV view tokens (gather_bwd.hip consumes it).
+#include "bwd_common.h"   // GradPtrs
 #include "bwd_tape.h"
 #include "ufr_internal.h"
 #include "weight_stream_f16.h"
@@ -19,6 +22,43 @@
 namespace ufr {
 
 constexpr int kVdBlock = 256, kVdWaves = 4;
+
+// v[i] <- sum of v[i] over the 16 lanes of the DPP row (= the 16 token columns of a lane group), for ten values.  One block
+// of assembly: a DPP read needs two wait states after a VALU write of the same register and the hazard recogniser does not
+// look inside inline assembly -- within the block a register's next read is ten instructions after its write.
+__device__ __forceinline__ void row_allreduce10(float (&v)[10]) {
+#define UFR_RR_STEP(CTRL)                                                    \
+  "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"        \
+  "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"        \
+  "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"        \
+  "v_add_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t"        \
+  "v_add_f32_dpp %4, %4, %4 " CTRL " row_mask:0xf bank_mask:0xf\n\t"        \
+  "v_add_f32_dpp %5, %5, %5 " CTRL " row_mask:0xf bank_mask:0xf\n\t"        \
+  "v_add_f32_dpp %6, %6, %6 " CTRL " row_mask:0xf bank_mask:0xf\n\t"        \
+  "v_add_f32_dpp %7, %7, %7 " CTRL " row_mask:0xf bank_mask:0xf\n\t"        \
+  "v_add_f32_dpp %8, %8, %8 " CTRL " row_mask:0xf bank_mask:0xf\n\t"        \
+  "v_add_f32_dpp %9, %9, %9 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+  asm volatile("s_nop 1\n\t" UFR_RR_STEP("quad_perm:[1,0,3,2]") UFR_RR_STEP("quad_perm:[2,3,0,1]") UFR_RR_STEP("row_half_mirror")
+               UFR_RR_STEP("row_mirror")
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]));
+#undef UFR_RR_STEP
+}
+// dst[16 t + 4 g + r] += sum over the 16 token lanes of t[tile][r], for the 80 features of a natural-layout vector: two
+// blocks of ten values per lane group; after the all-reduce lane j < 10 of each row adds value 10 b + j
+__device__ __forceinline__ void reduce_add80(const f32x4 (&t)[5], float* __restrict__ dst, int g, int j) {
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    float v[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) v[i] = t[(10 * b + i) >> 2][(10 * b + i) & 3];
+    row_allreduce10(v);
+    float mine = v[0];
+#pragma unroll
+    for (int i = 1; i < 10; ++i) mine = j == i ? v[i] : mine;
+    const int idx = 10 * b + j;
+    if (j < 10) unsafeAtomicAdd(dst + 16 * (idx >> 2) + 4 * g + (idx & 3), mine);
+  }
+}
 
 // sum_d Q[d] * (K[d] of the lane holding token (tv + S) % L of the same point); acc[d] += w * (V[d] of that lane)
 template <int L, int S>
@@ -48,7 +88,12 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
                                                                 const float* __restrict__ d_tok_a,
                                                                 const float* __restrict__ d_tok_b,
                                                                 const float* __restrict__ d_radiance, int P,
-                                                                float* __restrict__ dbuf, float* __restrict__ d_pv) {
+                                                                float* __restrict__ dbuf, float* __restrict__ d_pv,
+                                                                float* __restrict__ g_n1w, float* __restrict__ g_n1b,
+                                                                float* __restrict__ g_n2w, float* __restrict__ g_n2b,
+                                                                float* __restrict__ g_vtok) {
+  typedef ViewTapeLayout<LOWP> TapeL;
+  typedef ViewGradLayout<LOWP> GradL;
   constexpr int NV = L - 1, C = kBlockCols;
   constexpr int PPT = 16 / L, PPW = PPT * C;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -77,15 +122,13 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
     const bool wrap = it + 1 < n_iter;
     const bool live = grp_raw < n_groups;
     const size_t grp = live ? grp_raw : 0;                 // an idle wave re-reads block 0 and stores nothing
-    auto tape_ld = [&](int tile, int c) __attribute__((always_inline)) -> f32x4 {
-      return ld4(tape + tile_offset(TV_COUNT, grp, tile, c) + lane * 4);
-    };
+    const char* const tape_blk = reinterpret_cast<const char*>(tape) + grp * (TapeL::block_units * 512);
+    char* const dy_blk = reinterpret_cast<char*>(dbuf) + grp * (GradL::block_units * 512);
+    auto tape_ld = [&](int tile, int c) __attribute__((always_inline)) -> f32x4 { return tile_load<TapeL>(tape_blk, tile, c, lane); };
     auto dy_st = [&](int tile, int c, f32x4 v) __attribute__((always_inline)) {
-      if (live) st4(dbuf + tile_offset(DV_COUNT, grp, tile, c) + lane * 4, v);
+      if (live) tile_store<GradL>(dy_blk, tile, c, lane, v);
     };
-    auto dy_ld = [&](int tile, int c) __attribute__((always_inline)) -> f32x4 {
-      return ld4(dbuf + tile_offset(DV_COUNT, grp, tile, c) + lane * 4);
-    };
+    auto dy_ld = [&](int tile, int c) __attribute__((always_inline)) -> f32x4 { return tile_load<GradL>(dy_blk, tile, c, lane); };
     int pidx[C];
     bool valid[C];
 #pragma unroll
@@ -165,16 +208,19 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
         }
       }
 
-    // ---------------- LayerNorm2 backwards (transformer.py:56-58): y = x + LN2(opre), so d x starts as d y (DV_YLN)
+    // ---------------- LayerNorm2 backwards (transformer.py:56-58): y = x + LN2(opre), so d x starts as d y (parked in DV_SCR)
     f32x4 dopre[C][5];
+    f32x4 dgam[5], dbet[5];     // d gamma2 = sum_t d y xhat2, d beta2 = sum_t d y: summed over the column tiles, then the lanes
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       f32x4 xh[5], gy[5];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int t = 0; t < 5; ++t) {
-        dy_st(DV_YLN + t, c, dy[c][t]);
+        dy_st(DV_SCR + t, c, dy[c][t]);
         xh[t] = tape_ld(TV_XH2 + t, c);
+        dgam[t] = c == 0 ? dy[c][t] * xh[t] : dgam[t] + dy[c][t] * xh[t];
+        dbet[t] = c == 0 ? dy[c][t] : dbet[t] + dy[c][t];
         gy[t] = dy[c][t] * vec_frag<V_VT_N2W>(ws, t, g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -189,6 +235,8 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
         dy_st(DV_OPRE + t, c, dopre[c][t]);
       }
     }
+    reduce_add80(dgam, g_n2w, g, j);       // (idle / padding columns carry zeros)
+    reduce_add80(dbet, g_n2b, g, j);
 
     // ---------------- MLP backwards (transformer.py:55-56)
     f32x4 dhid[C][10];
@@ -212,8 +260,8 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
 #pragma unroll
       for (int t = 0; t < 10; ++t) dcat[c][t] = splat4(0.f);
     gemm_f16<M_VT_MLP0T, C, kVdWaves, false, true>(ws, dhid, dcat, wrap);
-    // the x half of d cat is parked in the DV_X0 tiles (the kernel's own scratch until the end of the iteration: the
-    // attention phase below needs the registers), the message half goes on
+    // the x half of d cat joins d y in the scratch tiles (the attention phase below needs the registers; this lane wrote the
+    // tile itself, so the load is ordered behind its store), the message half goes on
     f32x4 dmpre[C][5];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -221,9 +269,10 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int t = 0; t < 5; ++t) {
-        dy_st(DV_X0 + t, c, dcat[c][t]);
-        dy_st(DV_MLN + t, c, dcat[c][5 + t]);
+        dy_st(DV_SCR + t, c, dcat[c][t] + dy_ld(DV_SCR + t, c));
         xh[t] = tape_ld(TV_XH1 + t, c);
+        dgam[t] = c == 0 ? dcat[c][5 + t] * xh[t] : dgam[t] + dcat[c][5 + t] * xh[t];
+        dbet[t] = c == 0 ? dcat[c][5 + t] : dbet[t] + dcat[c][5 + t];
         gm[t] = dcat[c][5 + t] * vec_frag<V_VT_N1W>(ws, t, g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -239,6 +288,8 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
         dy_st(DV_MPRE + t, c, dmpre[c][t]);
       }
     }
+    reduce_add80(dgam, g_n1w, g, j);
+    reduce_add80(dbet, g_n1b, g, j);
     // ---------------- merge backwards: d msg in the slot layout (lane group g <- heads 2g, 2g+1 of its token)
     f32x4 dmsg[C][5];
 #pragma unroll
@@ -330,14 +381,15 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
 
     // ---------------- outputs: d x = d y (residual) + d cat[0..79] + the projections.  Token columns 32..55 (frustum
     // features) and 56..71 (pre_sim_mlp) are the same for all NV view tokens of a point (ray_transformer.py:258-281):
-    // their gradients add up into d_pv; column 0 of a point is the view token (DV_X0 -> its gradient in wgrad_stream.hip)
+    // their gradients add up into d_pv; column 0 of a point is the view token: its gradient is d x summed over those columns
+    f32x4 dtok[5];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
 #pragma unroll
       for (int t = 0; t < 5; ++t) {
-        // this lane wrote both tiles itself: the loads are ordered behind its own stores
-        dx[c][t] += dy_ld(DV_YLN + t, c) + dy_ld(DV_X0 + t, c);
-        dy_st(DV_X0 + t, c, (valid[c] && tv[c] == 0) ? dx[c][t] : splat4(0.f));
+        dx[c][t] += dy_ld(DV_SCR + t, c);
+        const f32x4 v0 = (valid[c] && tv[c] == 0) ? dx[c][t] : splat4(0.f);
+        dtok[t] = c == 0 ? v0 : dtok[t] + v0;
       }
       // features 32..71 = tiles 2, 3 and lane groups 0, 1 of tile 4
 #pragma unroll
@@ -355,13 +407,14 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
         if (valid[c] && tv[c] == 0 && (t < 4 || g < 2)) st4(d_pv + (size_t)pidx[c] * 40 + 16 * (t - 2) + 4 * g, sum);
       }
     }
+    reduce_add80(dtok, g_vtok, g, j);
     wstream_f16_finish<B_VTB, kVdWaves>(ws, wrap);
   }
 }
 
 template <int L, bool LOWP>
 static hipError_t launch_vd(const float* packed, const float* tape, const float* rgbm, const float* d_tok_a, const float* d_tok_b,
-                            const float* d_radiance, int P, float* dbuf, float* d_pv, hipStream_t s) {
+                            const float* d_radiance, int P, float* dbuf, float* d_pv, const GradPtrs& gp, hipStream_t s) {
   constexpr int PPW = (16 / L) * kBlockCols;
   const int n_groups = (P + PPW - 1) / PPW;
   int blocks = (n_groups + kVdWaves - 1) / kVdWaves;
@@ -379,18 +432,19 @@ static hipError_t launch_vd(const float* packed, const float* tape, const float*
   static LdsAttrOnce lds_attr;   // per instantiation; thread-safe, once per device
   if (const hipError_t attr = lds_attr.set(reinterpret_cast<const void*>(&view_dgrad_kernel<L, LOWP>), kF16LdsBytes); attr != hipSuccess) return attr;
   hipLaunchKernelGGL((view_dgrad_kernel<L, LOWP>), dim3(blocks), dim3(kVdBlock), kF16LdsBytes, s, packed, tape, rgbm, d_tok_a,
-                     d_tok_b, d_radiance, P, dbuf, d_pv);
+                     d_tok_b, d_radiance, P, dbuf, d_pv, gp.p[P_VT_N1W], gp.p[P_VT_N1B], gp.p[P_VT_N2W], gp.p[P_VT_N2B],
+                     gp.p[P_VIEW_TOKEN]);
   return hipGetLastError();
 }
 
 hipError_t launch_view_dgrad(const float* packed, const float* tape, const float* rgbm, const float* d_tok_a,
-                             const float* d_tok_b, const float* d_radiance, int P, int NV, float* dbuf, float* d_pv, bool lowp,
-                             hipStream_t s) {
+                             const float* d_tok_b, const float* d_radiance, int P, int NV, float* dbuf, float* d_pv,
+                             const GradPtrs& gp, bool lowp, hipStream_t s) {
   switch (NV) {
 #define UFR_VD_CASE(N)                                                                                              \
     case N:                                                                                                         \
-      return lowp ? launch_vd<N + 1, true>(packed, tape, rgbm, d_tok_a, d_tok_b, d_radiance, P, dbuf, d_pv, s)      \
-                  : launch_vd<N + 1, false>(packed, tape, rgbm, d_tok_a, d_tok_b, d_radiance, P, dbuf, d_pv, s);
+      return lowp ? launch_vd<N + 1, true>(packed, tape, rgbm, d_tok_a, d_tok_b, d_radiance, P, dbuf, d_pv, gp, s)  \
+                  : launch_vd<N + 1, false>(packed, tape, rgbm, d_tok_a, d_tok_b, d_radiance, P, dbuf, d_pv, gp, s);
     UFR_VD_CASE(2) UFR_VD_CASE(3) UFR_VD_CASE(4) UFR_VD_CASE(5) UFR_VD_CASE(6) UFR_VD_CASE(7)
 #undef UFR_VD_CASE
     default: return hipErrorInvalidValue;

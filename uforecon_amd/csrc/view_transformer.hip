@@ -182,11 +182,13 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
   for (int it = 0; it < n_iter; ++it) {
     const int grp = it * n_waves + wave_global;
     const bool wrap = it + 1 < n_iter;
-    // tape tile (block, column tile) of this wave iteration: scalar base + 32-bit lane offset (see at32)
+    // tape tile (block, column tile) of this wave iteration (bwd_tape.h: per-tile layout, bf16 storage of some tiles in the
+    // 16-bit mode)
+    typedef ViewTapeLayout<LOWP> TapeL;
     const int col0 = __builtin_amdgcn_readfirstlane(grp < n_groups ? grp : 0) * C;      // first column tile, counted over all blocks
-    float* const tape_blk = tape + (size_t)(col0 / kBlockCols) * (TV_COUNT * kBlockCols * kTileFloats);
+    char* const tape_blk = reinterpret_cast<char*>(tape) + (size_t)(col0 / kBlockCols) * (TapeL::block_units * 512);
     auto tape_st = [&](int tile, int c, f32x4 v) __attribute__((always_inline)) {
-      if (grp < n_groups) st4(at32(tape_blk, (unsigned)((tile * kBlockCols + col0 % kBlockCols + c) * kTileFloats) + lane * 4u), v);
+      if (grp < n_groups) tile_store<TapeL>(tape_blk, tile, col0 % kBlockCols + c, lane, v);
     };
 #ifdef UFR_FUSION_PROBE
     // Feasibility probe for fusing the gather into this kernel: a synthetic producer phase with

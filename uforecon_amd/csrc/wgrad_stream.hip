@@ -83,15 +83,14 @@ constexpr Role kViewRoles[kViewTypes * 4] = {
     {1, {full(DV_HID, 5, 0, FM_NAT, 160, B_TAPE, TV_M, 5, 0, FM_NAT, 80, P_VT_MLP0, 160, 80)}},
     {1, {full(DV_HID + 5, 5, 5, FM_NAT, 160, B_TAPE, TV_X, 5, 0, FM_NAT, 80, P_VT_MLP0, 160, 0)}},
     {1, {full(DV_HID + 5, 5, 5, FM_NAT, 160, B_TAPE, TV_M, 5, 0, FM_NAT, 80, P_VT_MLP0, 160, 80)}},
-    // type 2: mlp2 in halves, the LayerNorm parameters, the radiance MLP and the view token
-    {1, {full(DV_OPRE, 5, 0, FM_NAT, 80, B_TAPE, TV_HID, 5, 0, FM_NAT, 160, P_VT_MLP2, 160)}},
-    {1, {full(DV_OPRE, 5, 0, FM_NAT, 80, B_TAPE, TV_HID + 5, 5, 5, FM_NAT, 160, P_VT_MLP2, 160)}},
-    {4, {diag(DV_YLN, 5, 80, TV_XH2, P_VT_N2W), rowsum(DV_YLN, 5, 80, P_VT_N2B), diag(DV_MLN, 5, 80, TV_XH1, P_VT_N1W),
-         rowsum(DV_MLN, 5, 80, P_VT_N1B)}},
-    {7, {full(DV_H1, 1, 0, FM_NAT, 16, B_TAPE, TV_Y, 6, 0, FM_RW0, 83, P_RW_W0, 83), rowsum(DV_H1, 1, 16, P_RW_B0),
+    // type 2: mlp2 (80 x 160) in three column ranges of the hidden layer, and the radiance MLP with its biases
+    // (LayerNorm gamma / beta and the view token are reduced inside view_dgrad.hip)
+    {1, {full(DV_OPRE, 5, 0, FM_NAT, 80, B_TAPE, TV_HID, 4, 0, FM_NAT, 160, P_VT_MLP2, 160)}},
+    {1, {full(DV_OPRE, 5, 0, FM_NAT, 80, B_TAPE, TV_HID + 4, 3, 4, FM_NAT, 160, P_VT_MLP2, 160)}},
+    {1, {full(DV_OPRE, 5, 0, FM_NAT, 80, B_TAPE, TV_HID + 7, 3, 7, FM_NAT, 160, P_VT_MLP2, 160)}},
+    {6, {full(DV_H1, 1, 0, FM_NAT, 16, B_TAPE, TV_Y, 6, 0, FM_RW0, 83, P_RW_W0, 83), rowsum(DV_H1, 1, 16, P_RW_B0),
          full(DV_H2, 1, 0, FM_NAT, 8, B_TAPE, TV_H1, 1, 0, FM_NAT, 16, P_RW_W2, 16), rowsum(DV_H2, 1, 8, P_RW_B2),
-         full(DV_LG, 1, 0, FM_NAT, 1, B_TAPE, TV_H2, 1, 0, FM_NAT, 8, P_RW_W4, 8), rowsum(DV_LG, 1, 1, P_RW_B4),
-         rowsum(DV_X0, 5, 80, P_VIEW_TOKEN)}},
+         full(DV_LG, 1, 0, FM_NAT, 1, B_TAPE, TV_H2, 1, 0, FM_NAT, 8, P_RW_W4, 8), rowsum(DV_LG, 1, 1, P_RW_B4)}},
 };
 
 // an operand tile pair (both column tiles of a block) in contraction layout: bf16 planes, 8 k slots per lane
@@ -130,6 +129,26 @@ __device__ __forceinline__ Frag make_frag(const f32x4& v0, const f32x4& v1, cons
   return f;
 }
 
+// the same from tiles STORED as bf16 (16-bit mode, bwd_tape.h): the lane's 8 bytes are its hi-plane words already
+__device__ __forceinline__ Frag make_frag16(const u32x2_tile& w0, const u32x2_tile& w1, const f16x8& sel) {
+  typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+  const f32x4 z = splat4(0.f);
+  const f32x4 t0 = mfma_planes<true>(__builtin_bit_cast(f16x8, u32x4v{w0[0], w0[1], 0u, 0u}), sel, z);
+  const f32x4 t1 = mfma_planes<true>(__builtin_bit_cast(f16x8, u32x4v{w1[0], w1[1], 0u, 0u}), sel, z);
+  Frag f;
+  f.p[0] = __builtin_bit_cast(f16x8, u32x4v{hi16_pair(t0[0], t0[1]), hi16_pair(t0[2], t0[3]), hi16_pair(t1[0], t1[1]), hi16_pair(t1[2], t1[3])});
+  f.p[1] = f.p[0];
+  return f;
+}
+// raw tile of one column tile as it sits in memory, and its conversion
+template <bool IS16> struct RawTile { f32x4 v; };
+template <> struct RawTile<true> { u32x2_tile v; };
+template <bool LOWP, bool IS16>
+__device__ __forceinline__ Frag to_frag(const RawTile<IS16>& a, const RawTile<IS16>& b, const f16x8& sel) {
+  if constexpr (IS16) return make_frag16(a.v, b.v, sel);
+  else return make_frag<LOWP>(a.v, b.v, sel);
+}
+
 template <bool LOWP>
 __device__ __forceinline__ f32x4 contract(const Frag& a, const Frag& b, f32x4 acc) {
   if constexpr (!LOWP) {   // small terms first (lo.lo is dropped)
@@ -144,7 +163,7 @@ __device__ __forceinline__ f32x4 contract_ones(const Frag& a, const f16x8& ones,
   return mfma_planes<true>(a.p[0], ones, acc);
 }
 
-template <const auto& TABLE, int IDX, bool LOWP, int NT_TAPE, int NT_DY>
+template <const auto& TABLE, int IDX, bool LOWP, class TAPE_L, class DY_L>
 __device__ __forceinline__ void run_role(const float* __restrict__ tape, const float* __restrict__ dbuf, int blk0, int blk1,
                                          const GradPtrs& gp, int lane) {
   constexpr Role R = TABLE[IDX];
@@ -162,35 +181,44 @@ __device__ __forceinline__ void run_role(const float* __restrict__ tape, const f
 
   for (int blk = blk0; blk < blk1; ++blk) {
     // scalar block bases + 32-bit lane offsets
-    const char* tb = reinterpret_cast<const char*>(tape + tile_offset(NT_TAPE, (size_t)blk, 0, 0));
-    const char* db = reinterpret_cast<const char*>(dbuf + tile_offset(NT_DY, (size_t)blk, 0, 0));
-    auto raw = [&](int buf, int tile, int c) __attribute__((always_inline)) -> f32x4 {
-      const unsigned off = (unsigned)((tile * kBlockCols + c) * kTileFloats * 4) + lane * 16u;
-      return *reinterpret_cast<const f32x4*>((buf == B_TAPE ? tb : db) + off);
-    };
+    const char* tb = reinterpret_cast<const char*>(tape) + (size_t)blk * (TAPE_L::block_units * 512);
+    const char* db = reinterpret_cast<const char*>(dbuf) + (size_t)blk * (DY_L::block_units * 512);
     static_for<R.n>([&](auto ji) __attribute__((always_inline)) {
       constexpr int jx = decltype(ji)::value;
       constexpr Job J = R.j[jx];
       constexpr int S0 = role_slot0(R, jx);
       constexpr int NB = J.kind == K_ROWSUM ? 0 : J.b_n;
+      // a job's tiles share a storage format (all of one tensor): fp32, or bf16 in the 16-bit mode
+      constexpr bool A16 = DY_L::is16(J.a_tile), B16 = NB > 0 && TAPE_L::is16(J.b_tile);
+      static_assert(J.b_buf == B_TAPE, "X operands come from the tape");
+      auto raw_a = [&](int tile, int c) __attribute__((always_inline)) -> RawTile<A16> {
+        RawTile<A16> r;
+        r.v = *reinterpret_cast<const decltype(r.v)*>(db + tile_byte_offset<DY_L>(tile, c, lane));
+        return r;
+      };
+      auto raw_b = [&](int tile, int c) __attribute__((always_inline)) -> RawTile<B16> {
+        RawTile<B16> r;
+        r.v = *reinterpret_cast<const decltype(r.v)*>(tb + tile_byte_offset<TAPE_L>(tile, c, lane));
+        return r;
+      };
       // the X tiles of the job first (they stay in registers as fragments), the dY tiles one tile ahead of their use: the tile
       // loads are the kernel's bottleneck, the matrix work hides behind them
-      f32x4 rb[NB > 0 ? NB : 1][2];
+      RawTile<B16> rb[NB > 0 ? NB : 1][2];
 #pragma unroll
-      for (int i = 0; i < NB; ++i) { rb[i][0] = raw(J.b_buf, J.b_tile + i, 0); rb[i][1] = raw(J.b_buf, J.b_tile + i, 1); }
-      f32x4 ra[2][2];
-      ra[0][0] = raw(B_DY, J.a_tile, 0);
-      ra[0][1] = raw(B_DY, J.a_tile, 1);
+      for (int i = 0; i < NB; ++i) { rb[i][0] = raw_b(J.b_tile + i, 0); rb[i][1] = raw_b(J.b_tile + i, 1); }
+      RawTile<A16> ra[2][2];
+      ra[0][0] = raw_a(J.a_tile, 0);
+      ra[0][1] = raw_a(J.a_tile, 1);
       Frag fb[NB > 0 ? NB : 1];
 #pragma unroll
-      for (int i = 0; i < NB; ++i) fb[i] = make_frag<LOWP>(rb[i][0], rb[i][1], sel);
+      for (int i = 0; i < NB; ++i) fb[i] = to_frag<LOWP, B16>(rb[i][0], rb[i][1], sel);
       static_for<J.a_n>([&](auto aii) __attribute__((always_inline)) {
         constexpr int ai = decltype(aii)::value;
         if constexpr (ai + 1 < J.a_n) {
-          ra[(ai + 1) & 1][0] = raw(B_DY, J.a_tile + ai + 1, 0);
-          ra[(ai + 1) & 1][1] = raw(B_DY, J.a_tile + ai + 1, 1);
+          ra[(ai + 1) & 1][0] = raw_a(J.a_tile + ai + 1, 0);
+          ra[(ai + 1) & 1][1] = raw_a(J.a_tile + ai + 1, 1);
         }
-        const Frag fa = make_frag<LOWP>(ra[ai & 1][0], ra[ai & 1][1], sel);
+        const Frag fa = to_frag<LOWP, A16>(ra[ai & 1][0], ra[ai & 1][1], sel);
         if constexpr (J.kind == K_FULL) {
 #pragma unroll
           for (int bi = 0; bi < NB; ++bi) acc[S0 + ai * NB + bi] = contract<LOWP>(fa, fb[bi], acc[S0 + ai * NB + bi]);
@@ -243,9 +271,9 @@ __global__ void __launch_bounds__(256, 2) view_wgrad_kernel(const float* __restr
   const int blk0 = chunk * per, blk1 = min(n_blocks, blk0 + per);
   switch (__builtin_amdgcn_readfirstlane(type * 4 + wave)) {
 #ifdef UFR_WG_ONLY
-#define UFR_ROLE(i) case i: if constexpr (i == UFR_WG_ONLY) run_role<kViewRoles, i, LOWP, TV_COUNT, DV_COUNT>(tape, dbuf, blk0, blk1, gp, lane); break;
+#define UFR_ROLE(i) case i: if constexpr (i == UFR_WG_ONLY) run_role<kViewRoles, i, LOWP, ViewTapeLayout<LOWP>, ViewGradLayout<LOWP>>(tape, dbuf, blk0, blk1, gp, lane); break;
 #else
-#define UFR_ROLE(i) case i: run_role<kViewRoles, i, LOWP, TV_COUNT, DV_COUNT>(tape, dbuf, blk0, blk1, gp, lane); break;
+#define UFR_ROLE(i) case i: run_role<kViewRoles, i, LOWP, ViewTapeLayout<LOWP>, ViewGradLayout<LOWP>>(tape, dbuf, blk0, blk1, gp, lane); break;
 #endif
     UFR_ROLE(0) UFR_ROLE(1) UFR_ROLE(2) UFR_ROLE(3) UFR_ROLE(4) UFR_ROLE(5) UFR_ROLE(6) UFR_ROLE(7)
     UFR_ROLE(8) UFR_ROLE(9) UFR_ROLE(10) UFR_ROLE(11)

@@ -43,9 +43,12 @@ __device__ __forceinline__ void row_allreduce10(float (&v)[10]) {
                : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]));
 #undef UFR_RR_STEP
 }
-// dst[16 t + 4 g + r] += sum over the 16 token lanes of t[tile][r], for the 80 features of a natural-layout vector: two
-// blocks of ten values per lane group; after the all-reduce lane j < 10 of each row adds value 10 b + j
-__device__ __forceinline__ void reduce_add80(const f32x4 (&t)[5], float* __restrict__ dst, int g, int j) {
+// acc[b] += sum over the 16 token lanes of value 10 b + j of the 80-feature natural-layout vector t (20 values per lane
+// group: two blocks of ten): after the all-reduce every lane of a row holds all ten sums and lane j < 10 keeps the j-th.
+// Accumulated over the wave's whole persistent loop -- in a private LDS slot per (vector, block, lane): ten more live
+// registers cost this kernel 50..70 spills -- and flushed once (flush80): per iteration the atomics of all waves would
+// queue up on the same 400 addresses (measured: +0.1 ms, more than the tiles had cost).
+__device__ __forceinline__ void reduce_acc80(const f32x4 (&t)[5], float* acc /* LDS: [2][64], this lane's column */, int j) {
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     float v[10];
@@ -55,10 +58,17 @@ __device__ __forceinline__ void reduce_add80(const f32x4 (&t)[5], float* __restr
     float mine = v[0];
 #pragma unroll
     for (int i = 1; i < 10; ++i) mine = j == i ? v[i] : mine;
-    const int idx = 10 * b + j;
-    if (j < 10) unsafeAtomicAdd(dst + 16 * (idx >> 2) + 4 * g + (idx & 3), mine);
+    acc[64 * b] += mine;
   }
 }
+__device__ __forceinline__ void flush80(const float* acc, float* __restrict__ dst, int g, int j) {
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int idx = 10 * b + j;
+    if (j < 10) unsafeAtomicAdd(dst + 16 * (idx >> 2) + 4 * g + (idx & 3), acc[64 * b]);
+  }
+}
+constexpr int kVdAccFloats = 5 * 2 * 64;   // per wave: 5 vectors x 2 blocks x 64 lanes
 
 // sum_d Q[d] * (K[d] of the lane holding token (tv + S) % L of the same point); acc[d] += w * (V[d] of that lane)
 template <int L, int S>
@@ -117,6 +127,15 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
   const int n_groups = (P + PPW - 1) / PPW;
   const int n_iter = (n_groups + n_waves - 1) / n_waves;   // uniform over the grid: every wave meets every chunk barrier
 
+  // the small-gradient accumulators behind the weight ring and the vector fragments
+  float* const a_base = reinterpret_cast<float*>(smem + kF16LdsBytes) + (threadIdx.x >> 6) * kVdAccFloats + lane;
+  float* const a_n1w = a_base;
+  float* const a_n1b = a_base + 128;
+  float* const a_n2w = a_base + 256;
+  float* const a_n2b = a_base + 384;
+  float* const a_vtok = a_base + 512;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) a_base[64 * i] = 0.f;
   for (int it = 0; it < n_iter; ++it) {
     const int grp_raw = it * n_waves + wave_global;
     const bool wrap = it + 1 < n_iter;
@@ -235,8 +254,8 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
         dy_st(DV_OPRE + t, c, dopre[c][t]);
       }
     }
-    reduce_add80(dgam, g_n2w, g, j);       // (idle / padding columns carry zeros)
-    reduce_add80(dbet, g_n2b, g, j);
+    reduce_acc80(dgam, a_n2w, j);       // (idle / padding columns carry zeros)
+    reduce_acc80(dbet, a_n2b, j);
 
     // ---------------- MLP backwards (transformer.py:55-56)
     f32x4 dhid[C][10];
@@ -288,8 +307,8 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
         dy_st(DV_MPRE + t, c, dmpre[c][t]);
       }
     }
-    reduce_add80(dgam, g_n1w, g, j);
-    reduce_add80(dbet, g_n1b, g, j);
+    reduce_acc80(dgam, a_n1w, j);
+    reduce_acc80(dbet, a_n1b, j);
     // ---------------- merge backwards: d msg in the slot layout (lane group g <- heads 2g, 2g+1 of its token)
     f32x4 dmsg[C][5];
 #pragma unroll
@@ -407,9 +426,14 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
         if (valid[c] && tv[c] == 0 && (t < 4 || g < 2)) st4(d_pv + (size_t)pidx[c] * 40 + 16 * (t - 2) + 4 * g, sum);
       }
     }
-    reduce_add80(dtok, g_vtok, g, j);
+    reduce_acc80(dtok, a_vtok, j);
     wstream_f16_finish<B_VTB, kVdWaves>(ws, wrap);
   }
+  flush80(a_n1w, g_n1w, g, j);
+  flush80(a_n1b, g_n1b, g, j);
+  flush80(a_n2w, g_n2w, g, j);
+  flush80(a_n2b, g_n2b, g, j);
+  flush80(a_vtok, g_vtok, g, j);
 }
 
 template <int L, bool LOWP>
@@ -430,8 +454,8 @@ static hipError_t launch_vd(const float* packed, const float* tape, const float*
     }
   }
   static LdsAttrOnce lds_attr;   // per instantiation; thread-safe, once per device
-  if (const hipError_t attr = lds_attr.set(reinterpret_cast<const void*>(&view_dgrad_kernel<L, LOWP>), kF16LdsBytes); attr != hipSuccess) return attr;
-  hipLaunchKernelGGL((view_dgrad_kernel<L, LOWP>), dim3(blocks), dim3(kVdBlock), kF16LdsBytes, s, packed, tape, rgbm, d_tok_a,
+  if (const hipError_t attr = lds_attr.set(reinterpret_cast<const void*>(&view_dgrad_kernel<L, LOWP>), kF16LdsBytes + kVdWaves * kVdAccFloats * 4); attr != hipSuccess) return attr;
+  hipLaunchKernelGGL((view_dgrad_kernel<L, LOWP>), dim3(blocks), dim3(kVdBlock), kF16LdsBytes + kVdWaves * kVdAccFloats * 4, s, packed, tape, rgbm, d_tok_a,
                      d_tok_b, d_radiance, P, dbuf, d_pv, gp.p[P_VT_N1W], gp.p[P_VT_N1B], gp.p[P_VT_N2W], gp.p[P_VT_N2B],
                      gp.p[P_VIEW_TOKEN]);
   return hipGetLastError();

@@ -254,13 +254,17 @@ int ufr_aggregate_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, co
  * ray_transformer.py:268).  sim8 (P,8): the forward's `sim8` output; d_pv (P,40) from ufr_aggregate_bwd.
  * row (nullable, (RN,SN) int32): d_pv / sim8 are POOL tensors and slot (ray, s) owns row row[ray][s] of d_pv (the two-pass
  * step hands over all merged samples of a ray in one call; sim8 is only summed over, any row order).
- * grad_vol_feat[s] (NV,8,D,Hs,Ws) / grad_vol_weight[s] (NV,1,D,Hs,Ws): reference layout, ACCUMULATED (scatter-add);
- * both arrays NULL: only the pre_sim_mlp gradients (accumulated into `grads`) are computed. */
+ * grad_vol_feat[s] (NV,8,D,Hs,Ws) / grad_vol_weight[s] (NV,1,D,Hs,Ws): reference layout, written whole -- overwritten, or
+ * added to when accumulate != 0 (the scatter itself goes into a channel-last record volume in `workspace`,
+ * ufr_project_gather_bwd_workspace_bytes(frame) bytes = 1.33 x the volumes: nine lanes of one atomic instruction add the
+ * nine values of a voxel corner as ONE L2 transaction, then one coalesced pass writes these tensors);
+ * both arrays NULL: only the pre_sim_mlp gradients (accumulated into `grads`) are computed, no workspace needed. */
+size_t ufr_project_gather_bwd_workspace_bytes(const ufr_frame* frame);
 int ufr_project_gather_bwd(const ufr_frame* frame, const ufr_raw_weights* raw, const ufr_raw_grads* grads,
                            const float* ray_o, int32_t ray_o_stride, const float* ray_d, const float* z, int32_t RN,
                            int32_t SN, const float* sim8, const float* d_pv, const int32_t* row,
-                           float* const* grad_vol_feat, float* const* grad_vol_weight, int32_t precision,
-                           ufr_stream stream);
+                           float* const* grad_vol_feat, float* const* grad_vol_weight, int32_t accumulate, void* workspace,
+                           int32_t precision, ufr_stream stream);
 
 /* ------------------------------------------------------------------ the two halves of ufr_aggregate, and the sample pool
  * The fine pass of `infer` (model.py:455-473) re-evaluates all SN+PN merged samples, but a sample's gathers and

@@ -54,8 +54,9 @@ class RenderPass(torch.autograd.Function):
         d_pv, _ = ops.aggregate_bwd(W, grads, x, rgbm, dirs, token0, RN, SN, d_radiance.view(RN * SN, 3), d_srdf, precision=prec)
         need = ctx.needs_input_grad[5:]
         if any(need[ctx.n_par:]):       # frustum gradients wanted (feature_volume.cost_reg_2 trains through them)
-            gvol = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.vol_shapes]
-            ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z, sim8, d_pv, gvol[0::2], gvol[1::2], precision=prec)
+            gvol = [torch.empty(s, dtype=torch.float32, device=dev) for s in ctx.vol_shapes]      # written whole: no zero-fill
+            ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z, sim8, d_pv, gvol[0::2], gvol[1::2], precision=prec,
+                                   accumulate=False)
         else:                           # parameters only: skip the scatter-add (and 0.7 GB of zeroed gradient volumes)
             gvol = [None] * len(ctx.vol_shapes)
             ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z, sim8, d_pv, None, None, precision=prec)
@@ -151,14 +152,15 @@ class RenderTwoPass(torch.autograd.Function):
         ops.view_transform_bwd(W, grads, pool_x, pool_rgbm, pool_dirs, pool_a, pool_b, pool_drad, precision=prec, d_pv=d_pv)
         need = ctx.needs_input_grad[6:]
         if any(need[ctx.n_par:]):
-            gvol = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.vol_shapes]
+            gvol = [torch.empty(s, dtype=torch.float32, device=dev) for s in ctx.vol_shapes]      # written whole: no zero-fill
             gf, gw = gvol[0::2], gvol[1::2]
         else:
             gvol = [None] * len(ctx.vol_shapes)
             gf = gw = None
         # ONE frustum scatter over all merged samples of a ray (z2: sorted, twice the density of either pass -- the run
-        # folding of gather_bwd.hip removes more atomics), d_pv / sim8 addressed through the slot -> row table
-        ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z2, sim8_pool, d_pv, gf, gw, precision=prec, row=row)
+        # folding of gather_bwd.hip removes more corner records), d_pv / sim8 addressed through the slot -> row table
+        ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z2, sim8_pool, d_pv, gf, gw, precision=prec, row=row,
+                               accumulate=False)
         gpar = [grads.grad(k) for k in ops.RAW_WEIGHT_KEYS]
         gpar[-1] = d_var.reshape(gpar[-1].shape)
         out = [g if (n and g is not None) else None for g, n in zip(gpar + gvol, need)]

@@ -562,11 +562,16 @@ int ufr_aggregate_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, co
   return view_bwd_impl(packed_weights, gp, x_tokens, rgb, dir, d_tok_a, d_tok_b, d_radiance, RN * SN, NV, d_pv, vw, lowp, sl->dev, s);
 }
 
+size_t ufr_project_gather_bwd_workspace_bytes(const ufr_frame* frame) {
+  const FrameDev* f = frame_of(frame);
+  return (f && f->vol[0]) ? align_up(gather_bwd_scratch_floats(*f) * sizeof(float)) : 0;
+}
+
 int ufr_project_gather_bwd(const ufr_frame* frame, const ufr_raw_weights* raw, const ufr_raw_grads* grads,
                            const float* ray_o, int32_t ray_o_stride, const float* ray_d, const float* z, int32_t RN,
                            int32_t SN, const float* sim8, const float* d_pv, const int32_t* row,
-                           float* const* grad_vol_feat, float* const* grad_vol_weight, int32_t precision,
-                           ufr_stream stream) {
+                           float* const* grad_vol_feat, float* const* grad_vol_weight, int32_t accumulate, void* workspace,
+                           int32_t precision, ufr_stream stream) {
   const FrameDev* f = frame_of(frame);
   UFR_REQUIRE(f, "ufr_project_gather_bwd: frame handle not prepared");
   UFR_PRECISION(precision, lowp, "ufr_project_gather_bwd");
@@ -582,10 +587,12 @@ int ufr_project_gather_bwd(const ufr_frame* frame, const ufr_raw_weights* raw, c
   UFR_REQUIRE(RN > 0 && SN > 0, "ufr_project_gather_bwd: RN=%d SN=%d", RN, SN);
   for (int i = 0; scatter && i < UFR_NUM_STAGES; ++i)
     UFR_REQUIRE(grad_vol_feat[i] && grad_vol_weight[i], "ufr_project_gather_bwd: null volume gradient (stage %d)", i + 1);
+  UFR_REQUIRE(!scatter || workspace, "ufr_project_gather_bwd: the volume scatter needs its workspace");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (scatter) {
     ProfScope p("gather_bwd", s);
-    UFR_HIP(launch_gather_bwd(*f, grad_vol_feat, grad_vol_weight, ray_o, ray_o_stride, ray_d, z, d_pv, row, RN, SN, s));
+    UFR_HIP(launch_gather_bwd(*f, grad_vol_feat, grad_vol_weight, ray_o, ray_o_stride, ray_d, z, d_pv, row, RN, SN,
+                              static_cast<float*>(workspace), accumulate != 0, s));
   }
   {
     ProfScope p("presim_bwd", s);

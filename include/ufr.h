@@ -277,9 +277,10 @@ int ufr_project_gather_bwd(const ufr_frame* frame, const ufr_raw_weights* raw, c
  *     (token0 (P,80), radiance (P,3) | token0 rows of the RN*SN samples -> srdf (RN,SN)); `row` (nullable, (RN,SN) int32)
  *     maps slot (ray, s) to its row of token0 (NULL = slot order), so the fine pass reads the pool in place;
  *   ufr_view_transform_bwd / ufr_ray_transform_bwd = the corresponding halves of ufr_aggregate_bwd (d_token0 comes out
- *     as two partial buffers of the ray kernel's sweeps, written at the same rows `row` names -- overwritten, or added to
- *     when accumulate != 0 (the coarse pass adds its cotangents onto the fine pass's coarse rows); pass both buffers to
- *     ufr_view_transform_bwd). */
+ *     in d_token0_a, written at the same rows `row` names -- overwritten, or added to when accumulate != 0 (the coarse
+ *     pass adds its cotangents onto the fine pass's coarse rows); d_token0_b (nullable) is the second partial buffer of
+ *     the interface's earlier two-sweep form: zero-filled when not accumulating, so that a + b is the gradient; pass
+ *     both, or a and NULL, to ufr_view_transform_bwd). */
 int ufr_sample_importance_pool(const float* weight, const float* z, const float* U2, float* z_all, float* z_new,
                                int32_t* row, int32_t RN, int32_t SN, int32_t PN, ufr_stream stream);
 int ufr_view_transform(const void* packed_weights, const float* x_tokens, const float* rgb, const float* dir, int32_t P,
@@ -287,8 +288,9 @@ int ufr_view_transform(const void* packed_weights, const float* x_tokens, const 
 size_t ufr_ray_transform_workspace_bytes(int32_t SN);
 int ufr_ray_transform(const void* packed_weights, const float* token0, const int32_t* row, int32_t RN, int32_t SN,
                       float* srdf, void* workspace, int32_t precision, ufr_stream stream);
-int ufr_ray_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const float* token0, const int32_t* row,
-                          int32_t RN, int32_t SN, const float* d_srdf, float* d_token0_a, float* d_token0_b,
+size_t ufr_ray_transform_bwd_workspace_bytes(int32_t RN, int32_t SN);   /* tape, per-ray attention state, cotangent tiles */
+int ufr_ray_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const void* packed_weights, const float* token0,
+                          const int32_t* row, int32_t RN, int32_t SN, const float* d_srdf, float* d_token0_a, float* d_token0_b,
                           int32_t accumulate, void* workspace, int32_t precision, ufr_stream stream);
 size_t ufr_view_transform_bwd_workspace_bytes(int32_t P, int32_t NV);
 int ufr_view_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const void* packed_weights,

@@ -40,7 +40,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_struct_sizes_match_the_header(lib):
     assert C.sizeof(_lib.RawWeights) == 40 * 8
     assert C.sizeof(_lib.Frame) == 160 * 8
-    assert lib.ufr_packed_fp32_floats() == E.vec_region_offset() + 16 * (5 * 4 + 6 * 4 + 2 + 5 + 5 + 1)   # + rw4 as a vector
+    assert lib.ufr_packed_fp32_floats() == E.vec_region_offset() + 16 * (5 * 4 + 6 * 4 + 2 + 5 + 5 + 1 + 1)   # + rw4 and dm4 as vectors
     assert lib.ufr_packed_weights_bytes() == (4 * lib.ufr_packed_fp32_floats() + 2 * lib.ufr_packed_f16_halfwords()
                                               + 2 * lib.ufr_packed_bwd_halfwords() + 16)  # + flag tail
     assert lib.ufr_packed_bwd_halfwords() % (12 * 512) == 0
@@ -124,7 +124,7 @@ def test_vector_fragments(plan, raw_and_blob):
     vecs = [(12, 5, E.ROW_NAT, 80), (13, 5, E.ROW_NAT, 80), (14, 5, E.ROW_NAT, 80), (15, 5, E.ROW_NAT, 80),
             (22, 6, E.ROW_NAT88, 88), (23, 6, E.ROW_NAT88, 88), (24, 6, E.ROW_NAT88, 88), (25, 6, E.ROW_NAT88, 88),
             (27, 2, E.ROW_NAT, 32), (29, 1, E.ROW_NAT, 16), (31, 1, E.ROW_NAT, 1), (33, 1, E.ROW_NAT, 16),
-            (35, 1, E.ROW_NAT, 8), (37, 1, E.ROW_NAT, 1), (38, 5, E.ROW_NAT, 80), (36, 1, E.ROW_NAT, 8)]
+            (35, 1, E.ROW_NAT, 8), (37, 1, E.ROW_NAT, 1), (38, 5, E.ROW_NAT, 80), (36, 1, E.ROW_NAT, 8), (30, 1, E.ROW_NAT, 16)]
     for param, nt, rm, dim in vecs:
         frag = blob[off: off + nt * 16].reshape(nt, 4, 4)
         for t in range(nt):

@@ -153,8 +153,10 @@ def test_aggregate_bwd_other_view_counts_and_lengths(NV, SN):
             continue
         worst[k] = grad_rel_err(grads.grad(k), Pg[k].grad)
     worst["d_pv"] = grad_rel_err(d_pv, xr.grad[:, :, 32:72].sum(1))
-    # a ReLU unit within rounding of zero may flip between two fp32 evaluations: allow it on a few tensors
-    assert sorted(worst.values())[len(worst) // 2] < 2e-5, worst
+    # a ReLU unit within rounding of zero may flip between two fp32 evaluations: allow it on a few tensors.
+    # The median sits at the arithmetic's own floor: since round 4 the data-gradient chain and the weight-gradient
+    # contraction run as three bf16 plane products (16 significand bits per operand: ~1e-5 per tensor; GRAD_TOL is 1e-3)
+    assert sorted(worst.values())[len(worst) // 2] < 5e-5, worst
     assert max(worst.values()) < 2e-2, worst
 
 

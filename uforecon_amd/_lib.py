@@ -101,7 +101,8 @@ SIGNATURES = {
     "ufr_view_transform": (C.c_int, [vp, vp, vp, vp, i32, i32, vp, vp, i32, vp]),
     "ufr_ray_transform_workspace_bytes": (sz, [i32]),
     "ufr_ray_transform": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, i32, vp]),
-    "ufr_ray_transform_bwd": (C.c_int, [C.POINTER(RawWeights), C.POINTER(RawGrads), vp, vp, i32, i32, vp, vp, vp, i32, vp, i32, vp]),
+    "ufr_ray_transform_bwd_workspace_bytes": (sz, [i32, i32]),
+    "ufr_ray_transform_bwd": (C.c_int, [C.POINTER(RawWeights), C.POINTER(RawGrads), vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, i32, vp]),
     "ufr_view_transform_bwd_workspace_bytes": (sz, [i32, i32]),
     "ufr_view_transform_bwd": (C.c_int, [C.POINTER(RawWeights), C.POINTER(RawGrads), vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, vp]),
     "ufr_render_workspace_bytes": (sz, [i32, i32, i32, i32]),

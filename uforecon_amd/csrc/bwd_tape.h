@@ -81,6 +81,65 @@ struct ViewGradLayout {
   static constexpr int block_units = off(DV_COUNT);
 };
 
+// ---- ray transformer tape (A1 = ray_transformer_kernel<.., TAPE>): per 16-token tile of a ray; a block = two consecutive
+// tiles of the ray (block index = ray * ceil(n_tiles / 2) + tile / 2, column tile = tile & 1; an odd tile count leaves a
+// padding tile: finite X tiles, zero dY tiles)
+enum RayTape : int {
+  RT_X = 0,        // 6  [token-0 feature 80 | order PE 8]                nat88 rows                       (bf16 in 16-bit mode)
+  RT_Q = 6,        // 6  Q' = elu(q) + 1                                   quad-packed rows (ROW_QUAD11)
+  RT_MSG = 12,     // 6  attention message                                 quad-packed                      (bf16)
+  RT_ZS = 18,      // 2  Z * SN of (token, head): heads 0..3 | 4..7, the same in every lane group
+  RT_XH1 = 20,     // 6  LayerNorm1 normalised input                       nat88
+  RT_M = 26,       // 6  LayerNorm1 output                                 nat88                            (bf16)
+  RT_HID = 32,     // 11 relu(mlp0)                                        natural (176)                    (bf16)
+  RT_XH2 = 43,     // 6  LayerNorm2 normalised input                       nat88
+  RT_O = 49,       // 6  layer output                                      nat88                            (bf16)
+  RT_D1 = 55,      // 2  relu(dm0)                                         natural (32)                     (bf16)
+  RT_D2 = 57,      // 1  relu(dm2)                                         natural (16)                     (bf16)
+  RT_MISC = 58,    // 1  per column: {rstd1, rstd2, ReLU bits 0..31, bits 32..59}: bit 4 t + r = hidden unit (t, r) > 0 for
+                   //    t < 11, then d1 (tiles 11, 12), d2 (tile 13) -- this lane's rows of the column
+  RT_COUNT = 59
+};
+constexpr int kRayStateTiles = 16;   // per ray: KV_h (8 heads) then KV_h^T (8), fp32 16 x 16 tiles in accumulator layout
+// ---- ray transformer cotangents (A2 = ray_dgrad_kernel)
+enum RayGrad : int {
+  DR_Q = 0,        // 6  d q     quad-packed
+  DR_K = 6,        // 8  d k     one 16-slot tile per head (ROW_HEAD11K as rows)
+  DR_V = 14,       // 8  d v
+  DR_MPRE = 22,    // 6  d (merge output)   nat88
+  DR_HID = 28,     // 11 d (mlp0 output, after the ReLU mask)
+  DR_OPRE = 39,    // 6  d (mlp2 output)    nat88
+  DR_D1 = 45,      // 2  d (dm0 output, masked)
+  DR_D2 = 47,      // 1  d (dm2 output, masked)
+  DR_SR = 48,      // 1  d srdf in row 0
+  DR_SCR = 49,     // 6  scratch: d x parts of sweep 1 waiting for sweep 2 (fp32)
+  DR_COUNT = 55
+};
+template <bool LOWP>
+struct RayTapeLayout {
+  static constexpr int count = RT_COUNT;
+  static constexpr bool is16(int t) {
+    return LOWP && ((t >= RT_X && t < RT_Q) || (t >= RT_MSG && t < RT_ZS) || (t >= RT_M && t < RT_XH2) || (t >= RT_O && t < RT_MISC));
+  }
+  static constexpr int off(int t) {
+    int o = 0;
+    for (int u = 0; u < t; ++u) o += is16(u) ? 2 : 4;
+    return o;
+  }
+  static constexpr int block_units = off(RT_COUNT);
+};
+template <bool LOWP>
+struct RayGradLayout {
+  static constexpr int count = DR_COUNT;
+  static constexpr bool is16(int t) { return LOWP && t < DR_SCR; }
+  static constexpr int off(int t) {
+    int o = 0;
+    for (int u = 0; u < t; ++u) o += is16(u) ? 2 : 4;
+    return o;
+  }
+  static constexpr int block_units = off(DR_COUNT);
+};
+
 typedef unsigned u32x2_tile __attribute__((ext_vector_type(2)));
 // byte offset of (tile, column tile c, lane) inside a block
 template <class LAYOUT>

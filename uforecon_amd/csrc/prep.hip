@@ -82,11 +82,11 @@ __global__ void __launch_bounds__(256) pack_weights_f16_kernel(RawPtrs raw, unsi
                                                                 int* __restrict__ flag) {
   int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= n) return;
-  int p, e, plane, stream;
-  plan_entry_f16(h, &p, &e, &plane, &stream);
+  int p, e, plane, bf;
+  plan_entry_f16(h, &p, &e, &plane, &bf);
   unsigned short out = 0;
   if (p >= 0) {
-    if (f16_stream_is_bf16(stream)) {
+    if (bf) {
       // backward streams: bf16 planes of the unscaled weight, hi = bf16(w), lo = bf16(w - hi) (round to nearest even)
       const float w = raw.p[p][e];
       const __bf16 hi = (__bf16)w;

@@ -16,6 +16,7 @@
 // head11_slot), which makes register 3 of every KV / message tile padding: Q is computed for the live registers
 // only (24 "quads" = 6 tiles instead of 8) and merge contracts 6 input tiles instead of 8 -- weight rows and columns
 // are permuted at pack time, the kernel only renames registers.  The 88-wide activations use the "nat88" layout.
+#include "bwd_tape.h"
 #include "ufr_internal.h"
 #include "weight_stream_f16.h"
 
@@ -38,8 +39,9 @@ __device__ __forceinline__ void load_ray_tile(const float* __restrict__ token0, 
 }
 
 // LayerNorm over 88 features in nat88 layout (tile 5: registers 0,1 real)
+// XH / RS (TAPE builds): the normalised input and 1 / sigma of the TRUE values, which the backward needs
 template <int VW, int VB, bool ACC = false, class WS>
-__device__ __forceinline__ void layer_norm88(f32x4 (&tt)[kRtC][6], const WS& ws, int g) {
+__device__ __forceinline__ void layer_norm88(f32x4 (&tt)[kRtC][6], const WS& ws, int g, f32x4 (*XH)[6] = nullptr, float* RS = nullptr) {
   constexpr float eps = ACC ? 1e-5f * kAccScale * kAccScale : 1e-5f;   // raw accumulators: view_transformer.hip layer_norm80
 #pragma unroll
   for (int c = 0; c < kRtC; ++c) {
@@ -60,9 +62,14 @@ __device__ __forceinline__ void layer_norm88(f32x4 (&tt)[kRtC][6], const WS& ws,
         }
       }
     const float rstd = 1.f / sqrtf(sum_groups(q) * (1.f / 88.f) + eps);
+    if (RS) RS[c] = ACC ? rstd * kAccScale : rstd;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const f32x4 gw = vec_frag<VW>(ws, i, g), gb = vec_frag<VB>(ws, i, g);  // zero in the padding slots
+      if (XH) {
+        XH[c][i] = (t[i] - mean) * rstd;
+        if (i == 5) { XH[c][i][2] = 0.f; XH[c][i][3] = 0.f; }                 // nat88: registers 2, 3 of tile 5 are padding
+      }
       t[i] = (t[i] - mean) * rstd * gw + gb;
     }
   }
@@ -89,14 +96,18 @@ __device__ unsigned long long g_rt_phase[32];
 #define UFR_RT_PHASE(i)
 #endif
 
-template <bool LOWP>
+// TAPE: the instantiation the backward launches (bwd_tape.h): the same arithmetic, plus one store per activation tile, the
+// transposed per-head state KV_h^T beside KV_h, and an even number of sweep-2 tiles (blocks of two).
+template <bool LOWP, bool TAPE = false>
 __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(const float* __restrict__ packed,
                                                                   const float* __restrict__ token0,
                                                                   const int* __restrict__ tok_row,
                                                                   const float* __restrict__ order_pe, int RN, int SN,
                                                                   float* __restrict__ srdf,
                                                                   float* __restrict__ ray_out,
-                                                                  int* __restrict__ status) {
+                                                                  int* __restrict__ status, float* __restrict__ tape = nullptr,
+                                                                  float* __restrict__ ray_state = nullptr) {
+  static_assert(!TAPE || kRtC == 1, "the tape build walks one tile per iteration");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   auto ws = wstream_f16_begin<kRtWaves, LOWP>(packed, smem);
   wstream_f16_prime<B_RT1, kRtWaves>(ws);
@@ -117,9 +128,11 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
   unsigned long long rt_prev = __builtin_readcyclecounter();
 #endif
   // ---------------- sweep 1: KV_h[d][v] = sum_s K'_h[s][d] * V_h[s][v] / SN   (linear_attention.py:41-42)
-  f32x4 KV[8];
+  f32x4 KV[8], KVT[TAPE ? 8 : 1];
 #pragma unroll
   for (int h = 0; h < 8; ++h) KV[h] = splat4(0.f);
+#pragma unroll
+  for (int h = 0; h < (TAPE ? 8 : 1); ++h) KVT[h] = splat4(0.f);
   for (int it = 0; it < n_iter; ++it) {
     const bool wrap = it + 1 < n_iter;
     const bool slot_ok = head11_slot(j) >= 0;   // column j of a head tile carries a head dim
@@ -171,6 +184,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
           KV[h][r] += kk * vv;
 #else
           KV[h] = mfma16(kk, vv, KV[h]);
+          if constexpr (TAPE) KVT[h] = mfma16(vv, kk, KVT[h]);   // [V slot][K slot]: the A operand of d Q' = KV d acc
 #endif
         }
       }
@@ -179,10 +193,23 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
     UFR_RT_PHASE(1)  // sweep 1: KV accumulation (fp32 MFMA)
   }
 
+  if constexpr (TAPE) {
+    if (valid) {
+      float* st = ray_state + (size_t)ray * (kRayStateTiles * kTileFloats) + lane * 4;
+#pragma unroll
+      for (int h = 0; h < 8; ++h) { st4(st + h * kTileFloats, KV[h]); st4(st + (8 + h) * kTileFloats, KVT[h]); }
+    }
+  }
   // ---------------- sweep 2 (slot 0 is free: every wave passed the barrier that opened sweep 1's last chunk)
   wstream_f16_prime<B_RT2, kRtWaves>(ws);
-  for (int it = 0; it < n_iter; ++it) {
-    const bool wrap = it + 1 < n_iter;
+  const int n_iter2 = TAPE ? n_iter + (n_iter & 1) : n_iter;     // TAPE: whole blocks of two tiles (a padding tile is not live)
+  typedef RayTapeLayout<LOWP> TapeL;
+  for (int it = 0; it < n_iter2; ++it) {
+    const bool wrap = it + 1 < n_iter2;
+    char* const tape_blk = reinterpret_cast<char*>(tape) + ((size_t)ray * (n_iter2 / 2) + it / 2) * (TapeL::block_units * 512);
+    auto tape_st = [&](int tile, f32x4 v) __attribute__((always_inline)) {
+      if (valid) tile_store<TapeL>(tape_blk, tile, it & 1, lane, v);
+    };
     f32x4 x[C][6], q[C][6], msg[C][6];   // q, msg: quad-packed (ROW_QUAD11 / COL_QUAD11)
     bool live[C];
     int tbase[C];
@@ -197,6 +224,17 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
     }
     track_external(x, ws);
     gemm_f16<M_RT_Q, C, kRtWaves, false, true>(ws, x, q, wrap);  // raw accumulators, quad-packed rows, column j = token
+    float zs_all[8];
+    if constexpr (TAPE) {
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        tape_st(RT_X + t, live[0] ? x[0][t] : splat4(0.f));
+        f32x4 qq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) qq[r] = quad11(t, g, r) >= 0 ? elu1_acc(q[0][t][r]) : 0.f;
+        tape_st(RT_Q + t, qq);
+      }
+    }
     UFR_RT_PHASE(2)  // sweep 2: token load + Q GEMM
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -215,6 +253,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
         const float den = __shfl(acc[3], j);         // slot 3 lives in lane group 0, register 3
         const float Z = 1.f / (den + 1e-6f);         // linear_attention.py:43
         const float zs = Z * (float)SN;              // :44
+        if constexpr (TAPE) zs_all[h] = zs;
         static_for<3>([&](auto ri) __attribute__((always_inline)) {
           constexpr int rr = decltype(ri)::value, quad = 3 * h + rr;
           msg[c][quad >> 2][quad & 3] = acc[rr] * zs;   // the live registers, in merge's input order
@@ -222,6 +261,12 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
       });
     }
     UFR_RT_PHASE(3)  // message (fp32 MFMA)
+    if constexpr (TAPE) {
+#pragma unroll
+      for (int t = 0; t < 6; ++t) tape_st(RT_MSG + t, msg[0][t]);
+      tape_st(RT_ZS, f32x4{zs_all[0], zs_all[1], zs_all[2], zs_all[3]});
+      tape_st(RT_ZS + 1, f32x4{zs_all[4], zs_all[5], zs_all[6], zs_all[7]});
+    }
     f32x4 m[C][6];
 #pragma unroll
     for (int c = 0; c < C; ++c)
@@ -229,7 +274,15 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
       for (int t = 0; t < 6; ++t) m[c][t] = splat4(0.f);
     gemm_f16<M_RT_MERGE, C, kRtWaves, false, true>(ws, msg, m, wrap);
     UFR_RT_PHASE(4)  // merge GEMM
-    layer_norm88<V_RT_N1W, V_RT_N1B, true>(m, ws, g);
+    float rstd1[C] = {}, rstd2[C] = {};
+    if constexpr (TAPE) {
+      f32x4 xh[C][6];
+      layer_norm88<V_RT_N1W, V_RT_N1B, true>(m, ws, g, xh, rstd1);
+#pragma unroll
+      for (int t = 0; t < 6; ++t) { tape_st(RT_XH1 + t, xh[0][t]); tape_st(RT_M + t, m[0][t]); }
+    } else {
+      layer_norm88<V_RT_N1W, V_RT_N1B, true>(m, ws, g);
+    }
     UFR_RT_PHASE(5)  // LayerNorm 1
 
     f32x4 cat[C][12], hid[C][11], o[C][6];
@@ -251,14 +304,35 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
 #pragma unroll
       for (int t = 0; t < 6; ++t) o[c][t] = splat4(0.f);
     }
+    unsigned relu_bits[2] = {0u, 0u};      // TAPE: bit 4 t + r <-> unit (t, r) of this lane is active (hid, then d1, d2)
+    if constexpr (TAPE) {
+#pragma unroll
+      for (int t = 0; t < 11; ++t) {
+        tape_st(RT_HID + t, hid[0][t] * kAccDescale);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (hid[0][t][r] > 0.f) relu_bits[(4 * t + r) >> 5] |= 1u << ((4 * t + r) & 31);
+      }
+    }
     gemm_f16<M_RT_MLP2, C, kRtWaves, true, true>(ws, hid, o, wrap);
     UFR_RT_PHASE(7)  // ReLU + MLP2
-    layer_norm88<V_RT_N2W, V_RT_N2B, true>(o, ws, g);
+    if constexpr (TAPE) {
+      f32x4 xh[C][6];
+      layer_norm88<V_RT_N2W, V_RT_N2B, true>(o, ws, g, xh, rstd2);
+#pragma unroll
+      for (int t = 0; t < 6; ++t) tape_st(RT_XH2 + t, xh[0][t]);
+    } else {
+      layer_norm88<V_RT_N2W, V_RT_N2B, true>(o, ws, g);
+    }
     UFR_RT_PHASE(8)  // LayerNorm 2
 #pragma unroll
     for (int c = 0; c < C; ++c) {
 #pragma unroll
       for (int t = 0; t < 6; ++t) o[c][t] += x[c][t];
+      if constexpr (TAPE) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) tape_st(RT_O + t, o[c][t]);
+      }
       if (ray_out && valid && live[c]) {
         float* row = ray_out + ((size_t)ray * SN + tbase[c] + j) * UFR_RAY_DIM;
 #pragma unroll
@@ -289,6 +363,20 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) d2[c][0][r] = fmaxf(d2[c][0][r], 0.f);
+    if constexpr (TAPE) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        tape_st(RT_D1 + t, d1[0][t] * kAccDescale);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (d1[0][t][r] > 0.f) relu_bits[(44 + 4 * t + r) >> 5] |= 1u << ((44 + 4 * t + r) & 31);
+      }
+      tape_st(RT_D2, d2[0][0] * kAccDescale);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (d2[0][0][r] > 0.f) relu_bits[1] |= 1u << (52 + r - 32);
+      tape_st(RT_MISC, f32x4{rstd1[0], rstd2[0], __builtin_bit_cast(float, relu_bits[0]), __builtin_bit_cast(float, relu_bits[1])});
+    }
     gemm_f16<M_DM4, C, kRtWaves, true, true>(ws, d2, d3, wrap);
 #pragma unroll
     for (int c = 0; c < C; ++c)
@@ -303,14 +391,24 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
 #endif
 }
 
-template <bool LOWP>
+template <bool LOWP, bool TAPE = false>
 static hipError_t launch_rt(const float* packed, const float* token0, const int* tok_row, const float* order_pe, int RN,
-                            int SN, float* srdf, float* ray_out, int* status, hipStream_t s) {
+                            int SN, float* srdf, float* ray_out, int* status, hipStream_t s, float* tape = nullptr,
+                            float* ray_state = nullptr) {
   static LdsAttrOnce lds_attr;   // per instantiation; thread-safe, once per device
-  if (const hipError_t attr = lds_attr.set(reinterpret_cast<const void*>(&ray_transformer_kernel<LOWP>), kF16LdsBytes); attr != hipSuccess) return attr;
-  hipLaunchKernelGGL(ray_transformer_kernel<LOWP>, dim3((RN + kRtWaves - 1) / kRtWaves), dim3(kRtBlock), kF16LdsBytes, s,
-                     packed, token0, tok_row, order_pe, RN, SN, srdf, ray_out, status);
+  if (const hipError_t attr = lds_attr.set(reinterpret_cast<const void*>(&ray_transformer_kernel<LOWP, TAPE>), kF16LdsBytes); attr != hipSuccess) return attr;
+  hipLaunchKernelGGL((ray_transformer_kernel<LOWP, TAPE>), dim3((RN + kRtWaves - 1) / kRtWaves), dim3(kRtBlock), kF16LdsBytes, s,
+                     packed, token0, tok_row, order_pe, RN, SN, srdf, ray_out, status, tape, ray_state);
   return hipGetLastError();
+}
+
+// The forward again for the backward (bwd_tape.h): tape = RN x ceil(SN / 32) blocks of RT_COUNT tiles, ray_state = RN x
+// kRayStateTiles tiles; srdf is written as usual (the caller passes scratch).
+hipError_t launch_ray_tape(const float* packed, const float* token0, const int* tok_row, const float* order_pe, int RN, int SN,
+                           float* srdf, float* tape, float* ray_state, bool lowp, int* status, hipStream_t s) {
+  if (SN % 16 != 0 || SN < 16) return hipErrorInvalidValue;
+  return lowp ? launch_rt<true, true>(packed, token0, tok_row, order_pe, RN, SN, srdf, nullptr, status, s, tape, ray_state)
+              : launch_rt<false, true>(packed, token0, tok_row, order_pe, RN, SN, srdf, nullptr, status, s, tape, ray_state);
 }
 
 hipError_t launch_ray_transformer(const float* packed, const float* token0, const int* tok_row, const float* order_pe,

@@ -516,6 +516,45 @@ static int view_bwd_impl(const void* packed, const GradPtrs& gp, const float* x_
   return UFR_OK;
 }
 
+// ... and of the ray transformer's: [order code | tape | per-ray state | dY tiles | srdf scratch]
+struct RayBwdWs { float *order_pe, *tape, *state, *dbuf, *srdf; int blocks; };
+static RayBwdWs carve_ray_bwd(Carver& c, int RN, int SN) {
+  RayBwdWs w;
+  w.blocks = RN * ((SN / 16 + 1) / 2);
+  w.order_pe = c.f32((size_t)SN * 8);
+  w.tape = c.f32((size_t)w.blocks * RayTapeLayout<false>::block_units * 128);
+  w.state = c.f32((size_t)RN * kRayStateTiles * kTileFloats);
+  w.dbuf = c.f32((size_t)w.blocks * RayGradLayout<false>::block_units * 128);
+  w.srdf = c.f32((size_t)RN * SN);
+  return w;
+}
+static int ray_bwd_impl(const void* packed, const GradPtrs& gp, const float* token0, const int* row, bool accumulate,
+                        const float* d_srdf, int RN, int SN, float* d_tok_a, float* d_tok_b, const RayBwdWs& w, bool lowp,
+                        int* status, hipStream_t s) {
+  const float* pk = static_cast<const float*>(packed);
+  UFR_HIP(launch_order_pe(w.order_pe, SN, s));
+  {
+    ProfScope p("ray_tape", s);
+    UFR_HIP(launch_ray_tape(pk, token0, row, w.order_pe, RN, SN, w.srdf, w.tape, w.state, lowp, status, s));
+  }
+  {
+    ProfScope p("ray_dgrad", s);
+    UFR_HIP(launch_ray_dgrad(pk, w.tape, w.state, d_srdf, row, accumulate, RN, SN, w.dbuf, d_tok_a, d_tok_b, gp, lowp, s));
+  }
+  {
+    ProfScope p("ray_wgrad", s);
+    UFR_HIP(launch_ray_wgrad(w.tape, w.dbuf, w.blocks, gp, lowp, s));
+  }
+  return UFR_OK;
+}
+
+size_t ufr_ray_transform_bwd_workspace_bytes(int32_t RN, int32_t SN) {
+  if (RN <= 0 || SN < 16 || SN % 16 != 0) return 0;
+  Carver c(nullptr);
+  carve_ray_bwd(c, RN, SN);
+  return c.off;
+}
+
 size_t ufr_view_transform_bwd_workspace_bytes(int32_t P, int32_t NV) {
   if (P <= 0 || NV < 2 || NV > UFR_MAX_VIEWS) return 0;
   Carver c(nullptr);
@@ -525,10 +564,10 @@ size_t ufr_view_transform_bwd_workspace_bytes(int32_t P, int32_t NV) {
 
 size_t ufr_aggregate_bwd_workspace_bytes(int32_t RN, int32_t SN, int32_t NV) {
   if (RN <= 0 || SN <= 0 || NV < 2 || NV > UFR_MAX_VIEWS) return 0;
+  if (SN < 16 || SN % 16 != 0) return 0;
   Carver c(nullptr);
   c.f32((size_t)RN * SN * UFR_TOKEN_DIM);
-  c.f32((size_t)RN * SN * UFR_TOKEN_DIM);
-  c.f32((size_t)SN * 8);
+  carve_ray_bwd(c, RN, SN);
   carve_view_bwd(c, RN * SN, NV);
   return c.off;
 }
@@ -547,19 +586,16 @@ int ufr_aggregate_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, co
   UFR_REQUIRE(RN > 0 && SN >= 16 && SN % 16 == 0 && SN <= 256, "ufr_aggregate_bwd: SN=%d must be a multiple of 16 in [16,256]", SN);
   hipStream_t s = static_cast<hipStream_t>(stream);
   Carver c(workspace);
-  float* d_tok_a = c.f32((size_t)RN * SN * UFR_TOKEN_DIM);
-  float* d_tok_b = c.f32((size_t)RN * SN * UFR_TOKEN_DIM);
-  float* order_pe = c.f32((size_t)SN * 8);
+  float* d_tok = c.f32((size_t)RN * SN * UFR_TOKEN_DIM);
+  const RayBwdWs rw = carve_ray_bwd(c, RN, SN);
   const ViewBwdWs vw = carve_view_bwd(c, RN * SN, NV);
   StatusSlot* sl = nullptr;
   rc = status_slot(&sl);
   if (rc != UFR_OK) return rc;
-  UFR_HIP(launch_order_pe(order_pe, SN, s));
-  {
-    ProfScope p("ray_bwd", s);
-    UFR_HIP(launch_ray_bwd(rp, gp, token0, nullptr, false, order_pe, d_srdf, RN, SN, d_tok_a, d_tok_b, debug_ray, lowp, s));
-  }
-  return view_bwd_impl(packed_weights, gp, x_tokens, rgb, dir, d_tok_a, d_tok_b, d_radiance, RN * SN, NV, d_pv, vw, lowp, sl->dev, s);
+  (void)debug_ray;
+  rc = ray_bwd_impl(packed_weights, gp, token0, nullptr, false, d_srdf, RN, SN, d_tok, nullptr, rw, lowp, sl->dev, s);
+  if (rc != UFR_OK) return rc;
+  return view_bwd_impl(packed_weights, gp, x_tokens, rgb, dir, d_tok, nullptr, d_radiance, RN * SN, NV, d_pv, vw, lowp, sl->dev, s);
 }
 
 size_t ufr_project_gather_bwd_workspace_bytes(const ufr_frame* frame) {
@@ -652,22 +688,23 @@ int ufr_ray_transform(const void* packed_weights, const float* token0, const int
   return status_leave(sl, s);
 }
 
-int ufr_ray_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const float* token0, const int32_t* row,
-                          int32_t RN, int32_t SN, const float* d_srdf, float* d_token0_a, float* d_token0_b,
+int ufr_ray_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const void* packed_weights, const float* token0,
+                          const int32_t* row, int32_t RN, int32_t SN, const float* d_srdf, float* d_token0_a, float* d_token0_b,
                           int32_t accumulate, void* workspace, int32_t precision, ufr_stream stream) {
   RawPtrs rp;
   GradPtrs gp;
   int rc = raw_and_grads(raw, grads, rp, gp, "ufr_ray_transform_bwd");
   if (rc != UFR_OK) return rc;
   UFR_PRECISION(precision, lowp, "ufr_ray_transform_bwd");
-  UFR_REQUIRE(token0 && d_srdf && d_token0_a && d_token0_b && workspace, "ufr_ray_transform_bwd: null argument");
+  UFR_REQUIRE(packed_weights && token0 && d_srdf && d_token0_a && workspace, "ufr_ray_transform_bwd: null argument");
   UFR_REQUIRE(RN > 0 && SN >= 16 && SN % 16 == 0 && SN <= 256, "ufr_ray_transform_bwd: SN=%d must be a multiple of 16 in [16,256]", SN);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  float* order_pe = static_cast<float*>(workspace);
-  UFR_HIP(launch_order_pe(order_pe, SN, s));
-  ProfScope p("ray_bwd", s);
-  UFR_HIP(launch_ray_bwd(rp, gp, token0, row, accumulate != 0, order_pe, d_srdf, RN, SN, d_token0_a, d_token0_b, nullptr, lowp, s));
-  return UFR_OK;
+  Carver c(workspace);
+  const RayBwdWs rw = carve_ray_bwd(c, RN, SN);
+  StatusSlot* sl = nullptr;
+  rc = status_slot(&sl);
+  if (rc != UFR_OK) return rc;
+  return ray_bwd_impl(packed_weights, gp, token0, row, accumulate != 0, d_srdf, RN, SN, d_token0_a, d_token0_b, rw, lowp, sl->dev, s);
 }
 
 int ufr_view_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const void* packed_weights,

@@ -97,6 +97,15 @@ hipError_t launch_view_dgrad(const float* packed, const float* tape, const float
                              const float* d_tok_b, const float* d_radiance, int P, int NV, float* dbuf, float* d_pv,
                              const GradPtrs& gp, bool lowp, hipStream_t s);
 hipError_t launch_view_wgrad(const float* tape, const float* dbuf, int n_blocks, const GradPtrs& gp, bool lowp, hipStream_t s);
+// ... and the ray transformer's: tape = RN x ceil(SN / 32) blocks of RT_COUNT tiles, ray_state = RN x kRayStateTiles tiles,
+// dbuf = as many blocks of DR_COUNT tiles.  d_tok_a receives the whole gradient (rows through tok_row, += when accumulate),
+// d_tok_b (nullable) is zero-filled when not accumulating: the two-buffer form of the former kernel's interface.
+hipError_t launch_ray_tape(const float* packed, const float* token0, const int* tok_row, const float* order_pe, int RN, int SN,
+                           float* srdf, float* tape, float* ray_state, bool lowp, int* status, hipStream_t s);
+hipError_t launch_ray_dgrad(const float* packed, const float* tape, const float* ray_state, const float* d_srdf, const int* tok_row,
+                            bool accumulate, int RN, int SN, float* dbuf, float* d_tok_a, float* d_tok_b, const GradPtrs& gp, bool lowp,
+                            hipStream_t s);
+hipError_t launch_ray_wgrad(const float* tape, const float* dbuf, int n_blocks, const GradPtrs& gp, bool lowp, hipStream_t s);
 // tok_row (nullable): pool row of sample (ray, s) for token0 AND for the d_tok_a / d_tok_b rows it produces; accumulate:
 // d_tok_* += (every pool row is written once per launch, so a plain read-modify-write)
 hipError_t launch_ray_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* token0, const int* tok_row, bool accumulate,

@@ -17,8 +17,8 @@
 
 namespace ufr {
 
-enum RowMap : int { ROW_NAT = 0, ROW_SLOT20, ROW_HEAD11K, ROW_NAT88, ROW_QUAD11 };
-enum ColMap : int { COL_NAT = 0, COL_SLOT20, COL_NAT88, COL_QUAD11, COL_RW0, COL_CAT88 };
+enum RowMap : int { ROW_NAT = 0, ROW_SLOT20, ROW_HEAD11K, ROW_NAT88, ROW_QUAD11, ROW_CAT88 };
+enum ColMap : int { COL_NAT = 0, COL_SLOT20, COL_NAT88, COL_QUAD11, COL_RW0, COL_CAT88, COL_HEAD11K };
 
 // The ray transformer's 8 heads of 11 dims (ray_transformer.hip).  In a 16-slot head tile, slot i = 4g + r holds head
 // dim 3g + r for r < 3 (slots with r = 3, and slot 14, are padding): the k-index of the per-head fp32 MFMAs is the lane
@@ -49,6 +49,7 @@ __host__ __device__ constexpr int row_map(int rm, int t, int i, int out_dim) {
     case ROW_HEAD11K: v = head11_slot(i) >= 0 ? 11 * t + head11_slot(i) : -1; break;
     case ROW_NAT88: v = nat88(t, g, r); break;
     case ROW_QUAD11: v = quad11(t, g, r); break;
+    case ROW_CAT88: v = t < 6 ? nat88(t, g, r) : (nat88(t - 6, g, r) < 0 ? -1 : 88 + nat88(t - 6, g, r)); break;   // [x 88 | m 88]
   }
   return (v >= 0 && v < out_dim) ? v : -1;
 }
@@ -61,6 +62,7 @@ __host__ __device__ constexpr int col_map(int cm, int t, int g, int r, int in_di
     case COL_QUAD11: v = quad11(t, g, r); break;
     case COL_RW0: v = t < 5 ? 16 * t + 4 * g + r : ((r == 0 && g < 3) ? 80 + g : -1); break;  // [token 80 | dir 3]
     case COL_CAT88: v = t < 6 ? nat88(t, g, r) : (nat88(t - 6, g, r) < 0 ? -1 : 88 + nat88(t - 6, g, r)); break;
+    case COL_HEAD11K: v = head11_slot(4 * g + r) >= 0 ? 11 * t + head11_slot(4 * g + r) : -1; break;   // head tile t, slot 4g + r
   }
   return (v >= 0 && v < in_dim) ? v : -1;
 }
@@ -85,11 +87,13 @@ enum Mat : int {
   M_RT_Q, M_RT_K, M_RT_V, M_RT_MERGE, M_RT_MLP0, M_RT_MLP2,
   M_DM0, M_DM2, M_DM4, M_RW0, M_RW2, M_RW4, M_COUNT,
   // transposed operands of the data-gradient chain (view_dgrad.hip); not part of the forward streams
-  M_RW2T = M_COUNT, M_RW0T, M_VT_MLP2T, M_VT_MLP0T, M_VT_MERGET, M_VT_QT, M_VT_KT, M_VT_VT, M_ALL_COUNT
+  M_RW2T = M_COUNT, M_RW0T, M_VT_MLP2T, M_VT_MLP0T, M_VT_MERGET, M_VT_QT, M_VT_KT, M_VT_VT,
+  // ... and of the ray transformer's (ray_dgrad.hip)
+  M_DM2T, M_DM0T, M_RT_MLP2T, M_RT_MLP0T, M_RT_MERGET, M_RT_QT, M_RT_KT, M_RT_VT, M_ALL_COUNT
 };
 enum Vec : int {
   V_VT_N1W = 0, V_VT_N1B, V_VT_N2W, V_VT_N2B, V_RT_N1W, V_RT_N1B, V_RT_N2W, V_RT_N2B,
-  V_DM_B0, V_DM_B2, V_DM_B4, V_RW_B0, V_RW_B2, V_RW_B4, V_VIEW_TOKEN, V_RW_W4, V_COUNT
+  V_DM_B0, V_DM_B2, V_DM_B4, V_RW_B0, V_RW_B2, V_RW_B4, V_VIEW_TOKEN, V_RW_W4, V_DM_W4, V_COUNT
 };
 
 __host__ __device__ constexpr MatDesc mat_desc(int m) {
@@ -121,6 +125,14 @@ __host__ __device__ constexpr MatDesc mat_desc(int m) {
     case M_VT_QT: return {P_VT_Q, 80, 5, 5, ROW_NAT, COL_SLOT20, 80, 80, 1};
     case M_VT_KT: return {P_VT_K, 80, 5, 5, ROW_NAT, COL_SLOT20, 80, 80, 1};
     case M_VT_VT: return {P_VT_V, 80, 5, 5, ROW_NAT, COL_SLOT20, 80, 80, 1};
+    case M_DM2T: return {P_DM_W2, 32, 2, 1, ROW_NAT, COL_NAT, 32, 16, 1};
+    case M_DM0T: return {P_DM_W0, 88, 6, 2, ROW_NAT88, COL_NAT, 88, 32, 1};
+    case M_RT_MLP2T: return {P_RT_MLP2, 176, 11, 6, ROW_NAT, COL_NAT88, 176, 88, 1};
+    case M_RT_MLP0T: return {P_RT_MLP0, 176, 12, 11, ROW_CAT88, COL_NAT, 176, 176, 1};
+    case M_RT_MERGET: return {P_RT_MERGE, 88, 6, 6, ROW_QUAD11, COL_NAT88, 88, 88, 1};   // d msg in the quad-packed layout
+    case M_RT_QT: return {P_RT_Q, 88, 6, 6, ROW_NAT88, COL_QUAD11, 88, 88, 1};
+    case M_RT_KT: return {P_RT_K, 88, 6, 8, ROW_NAT88, COL_HEAD11K, 88, 88, 1};          // d k / d v: one 16-slot tile per head
+    case M_RT_VT: return {P_RT_V, 88, 6, 8, ROW_NAT88, COL_HEAD11K, 88, 88, 1};
   }
   return {0, 0, 0, 0, 0, 0, 0, 0, 0};
 }
@@ -142,6 +154,7 @@ __host__ __device__ constexpr VecDesc vec_desc(int v) {
     case V_RW_B4: return {P_RW_B4, 1, ROW_NAT, 1};
     case V_VIEW_TOKEN: return {P_VIEW_TOKEN, 5, ROW_NAT, 80};
     case V_RW_W4: return {P_RW_W4, 1, ROW_NAT, 8};     // the last radiance-MLP layer as a vector (view_dgrad.hip)
+    case V_DM_W4: return {P_DM_W4, 1, ROW_NAT, 16};    // the last DensityMLP layer as a vector (ray_dgrad.hip)
   }
   return {0, 0, 0, 0};
 }

@@ -69,9 +69,13 @@ static_assert(kF16Depth >= 1 && kF16Depth * kPlanes <= kF16ChunkFrags, "read-ahe
 // the same fragment / panel / chunk format, but TRANSPOSED matrices (MatDesc::trans) as bf16 planes without a scale
 // (hi = bf16(w), lo = bf16(w - hi): gradients need the exponent range, and 16 significand bits per operand are ample for
 // the 1e-3 gradient tolerance) -- they follow the forward region in the blob, so one stream base formula serves both.
-//   B_VTB  view transformer backwards  rw2^T | rw0^T | mlp2^T | mlp0^T | merge^T | q^T | k^T | v^T
-enum F16Stream { B_VT = 0, B_RT1 = 1, B_RT2 = 2, B_COUNT = 3, B_VTB = 3, B_ALL = 4 };
-__host__ __device__ constexpr bool f16_stream_is_bf16(int S) { return S >= B_COUNT; }
+//   B_VTB   view transformer backwards  rw2^T | rw0^T | mlp2^T | mlp0^T | merge^T | q^T | k^T | v^T
+//   B_RTB1  ray transformer backwards, sweep 1 (per tile)  dm2^T | dm0^T | mlp2^T | mlp0^T | merge^T | q^T
+//   B_RTB2  ... sweep 2: k0 v0 k1 v1 k2 v2 (the FORWARD fp16 planes again: k, v are recomputed in the plain orientation) |
+//           k^T | v^T
+// The plane type is a property of the MATRIX (a transposed one = bf16), so a stream may mix both.
+enum F16Stream { B_VT = 0, B_RT1 = 1, B_RT2 = 2, B_COUNT = 3, B_VTB = 3, B_RTB1 = 4, B_RTB2 = 5, B_ALL = 6 };
+__host__ __device__ constexpr bool f16_mat_is_bf16(int m) { return m >= M_COUNT; }
 
 struct Panel { int mat, s; };
 
@@ -79,7 +83,9 @@ __host__ __device__ constexpr int ksteps(int m) { return (mat_desc(m).n_in + 1) 
 
 __host__ __device__ constexpr int f16_n_panels(int S) {
   return S == B_VT ? 3 * 3 + 3 + 5 + 5 + 3 + 1 + 1 : S == B_RT1 ? 6 : S == B_RT2 ? 3 + 3 + 6 + 6 + 3 + 1 + 1
-       : 1 + 1 + 3 + 5 + 3 + 3 * 3;   // B_VTB
+       : S == B_VTB ? 1 + 1 + 3 + 5 + 3 + 3 * 3
+       : S == B_RTB1 ? 1 + 1 + 3 + 6 + 3 + 3
+       : 6 + 4 + 4;   // B_RTB2
 }
 // consumption order.  q and k (view) / k and v (ray) are interleaved per k-step: x is split once per step.
 __host__ __device__ constexpr Panel f16_panel(int S, int i) {
@@ -111,6 +117,24 @@ __host__ __device__ constexpr Panel f16_panel(int S, int i) {
     i -= 3;
     return {i < 3 ? M_VT_QT : i < 6 ? M_VT_KT : M_VT_VT, i % 3};
   }
+  if (S == B_RTB1) {
+    if (i < 1) return {M_DM2T, 0};
+    i -= 1;
+    if (i < 1) return {M_DM0T, 0};
+    i -= 1;
+    if (i < 3) return {M_RT_MLP2T, i};
+    i -= 3;
+    if (i < 6) return {M_RT_MLP0T, i};
+    i -= 6;
+    if (i < 3) return {M_RT_MERGET, i};
+    i -= 3;
+    return {M_RT_QT, i};
+  }
+  if (S == B_RTB2) {
+    if (i < 6) return {i % 2 == 0 ? M_RT_K : M_RT_V, i / 2};
+    i -= 6;
+    return {i < 4 ? M_RT_KT : M_RT_VT, i % 4};
+  }
   if (i < 3) return {M_RT_Q, i};
   i -= 3;
   if (i < 3) return {M_RT_MERGE, i};
@@ -124,7 +148,8 @@ __host__ __device__ constexpr Panel f16_panel(int S, int i) {
   return {i == 0 ? M_DM2 : M_DM4, 0};
 }
 __host__ __device__ constexpr int f16_mat_stream(int m) {
-  return m >= M_COUNT ? B_VTB
+  return m >= M_DM2T ? ((m == M_RT_KT || m == M_RT_VT) ? B_RTB2 : B_RTB1)
+         : m >= M_COUNT ? B_VTB
          : (m == M_RT_K || m == M_RT_V) ? B_RT1
          : (m == M_RT_Q || m == M_RT_MERGE || m == M_RT_MLP0 || m == M_RT_MLP2 || m == M_DM0 || m == M_DM2 || m == M_DM4)
              ? B_RT2
@@ -136,8 +161,8 @@ __host__ __device__ constexpr int f16_panel_start(int S, int i) {  // first frag
   for (int j = 0; j < i; ++j) o += f16_panel_frags(S, j);
   return o;
 }
-__host__ __device__ constexpr int f16_panel_index(int m, int s) {  // within the matrix's stream
-  const int S = f16_mat_stream(m);
+__host__ __device__ constexpr int f16_panel_index(int m, int s, int S = -1) {  // within stream S (default: the matrix's own)
+  if (S < 0) S = f16_mat_stream(m);
   for (int i = 0; i < f16_n_panels(S); ++i)
     if (f16_panel(S, i).mat == m && f16_panel(S, i).s == s) return i;
   return -1;
@@ -169,18 +194,19 @@ __host__ __device__ constexpr int f16_col(int m, int s, int g, int i) {
 
 // source of halfword h of the plane regions (h < kF16Halfwords: fp16 forward streams; beyond: the bf16 backward streams):
 // parameter, element, plane (param -1 = zero)
-__host__ __device__ inline void plan_entry_f16(int h, int* param, int* elem, int* plane, int* stream = nullptr) {
+__host__ __device__ inline void plan_entry_f16(int h, int* param, int* elem, int* plane, int* is_bf16 = nullptr) {
   *param = -1; *elem = 0; *plane = 0;
   int f = h >> 9;                 // fragment
   const int lane = (h >> 3) & 63, i = h & 7;
   int S = 0;
   while (S + 1 < B_ALL && f >= f16_stream_base_frags(S + 1)) ++S;
-  if (stream) *stream = S;
+  if (is_bf16) *is_bf16 = 0;
   f -= f16_stream_base_frags(S);
   if (f >= f16_stream_frags(S)) return;  // tail padding of the stream's last chunk
   int pi = 0;
   while (f >= f16_panel_frags(S, pi)) { f -= f16_panel_frags(S, pi); ++pi; }
   const Panel p = f16_panel(S, pi);
+  if (is_bf16) *is_bf16 = f16_mat_is_bf16(p.mat) ? 1 : 0;
   const MatDesc d = mat_desc(p.mat);
   const int to = f / kPlanes;
   *plane = f % kPlanes;

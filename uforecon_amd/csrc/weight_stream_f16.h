@@ -267,14 +267,17 @@ constexpr int kProducts = 3;   // MFMAs per fp32 product
 struct NoHook {
   template <class T> __device__ __forceinline__ void operator()(T) const {}
 };
-template <int M, int S, int C, int NWAVES, bool SWAP = false, class Hook = NoHook, class WS = WStreamF16>
+// STREAM: the stream the panel is read from (default: the matrix's own; the ray transformer's k / v panels also sit in the
+// backward stream B_RTB2).  The planes' type -- fp16 with scales, or bf16 -- is the matrix's (f16_mat_is_bf16).
+template <int M, int S, int C, int NWAVES, bool SWAP = false, int STREAM = -1, class Hook = NoHook, class WS = WStreamF16>
 __device__ __forceinline__ void gemm_f16_panel(WS& ws, const BStep (&b)[C], f32x4 (&out)[C][mat_desc(M).n_out],
                                               bool wrap, Hook&& hook = NoHook{}) {
   constexpr bool LOWP = WS::lowp;
+  constexpr bool BF = f16_mat_is_bf16(M);
   constexpr int n_planes = LOWP ? 1 : kPlanes, n_products = LOWP ? 1 : kProducts;
-  constexpr int n_out = mat_desc(M).n_out, ST = f16_mat_stream(M);
-  static_assert(f16_panel_index(M, S) >= 0, "not a panel of the stream");
-  constexpr int F0 = f16_panel_start(ST, f16_panel_index(M, S));
+  constexpr int n_out = mat_desc(M).n_out, ST = STREAM >= 0 ? STREAM : f16_mat_stream(M);
+  static_assert(f16_panel_index(M, S, ST) >= 0, "not a panel of the stream");
+  constexpr int F0 = f16_panel_start(ST, f16_panel_index(M, S, ST));
   const f16x8* lds = reinterpret_cast<const f16x8*>(ws.ring) + ws.lane;
   // inside a GEMM panel the wave wins issue arbitration over a partner that is in a VALU-only phase (measured: view
   // transformer -1.7 %, ray transformer -1.4 % alone, 0.1 % on the whole frame with the gather beside them; priority 3
@@ -319,7 +322,7 @@ __device__ __forceinline__ void gemm_f16_panel(WS& ws, const BStep (&b)[C], f32x
       static_for<n_products>([&](auto pi) __attribute__((always_inline)) {
         constexpr int pw[kProducts] = {1, 0, 0}, px[kProducts] = {0, 1, 0};
         constexpr int w = LOWP ? 0 : pw[decltype(pi)::value], x = LOWP ? 0 : px[decltype(pi)::value];
-        out[c][to] = SWAP ? mfma_planes<WS::bf16>(b[c].p[x], a[w], out[c][to]) : mfma_planes<WS::bf16>(a[w], b[c].p[x], out[c][to]);
+        out[c][to] = SWAP ? mfma_planes<BF>(b[c].p[x], a[w], out[c][to]) : mfma_planes<BF>(a[w], b[c].p[x], out[c][to]);
       });
     if constexpr (!std::is_same<std::decay_t<Hook>, NoHook>::value) {
       // issue order: one MFMA, then up to two of the hook's VALU instructions, repeated
@@ -384,12 +387,12 @@ __device__ __forceinline__ void descale_tiles(f32x4 (&t)[C][N]) {
 // multiply they do anyway: no layer of the two chains pays for a descale pass).  Callers that start from a bias pass
 // it pre-multiplied by kAccScale (exact).
 // The fp16 split of k-step s+1 is interleaved with the MFMAs of k-step s (only step 0's is exposed).
-template <int M, int C, int NWAVES, bool ACC_IN = false, bool RAW_OUT = false, int NIN, class WS>
+template <int M, int C, int NWAVES, bool ACC_IN = false, bool RAW_OUT = false, int STREAM = -1, int NIN, class WS>
 __device__ __forceinline__ void gemm_f16(WS& ws, const f32x4 (&in)[C][NIN], f32x4 (&out)[C][mat_desc(M).n_out],
                                         bool wrap) {
   static_assert(NIN == mat_desc(M).n_in, "input tile count");
   constexpr int n_out = mat_desc(M).n_out, NU = 4 * C;
-  constexpr bool BF = WS::bf16;      // bf16 planes: no scales, so the output is exact as it stands (RAW_OUT) and never probed
+  constexpr bool BF = f16_mat_is_bf16(M);   // bf16 planes: no scales, so the output is exact as it stands (RAW_OUT) and never probed
   static_assert(!BF || (RAW_OUT && !ACC_IN), "bf16 streams: plain values in, plain values out");
   BWords<C> cur;
   split_units<0, 0, NU, ACC_IN, BF>(in, cur);
@@ -404,13 +407,13 @@ __device__ __forceinline__ void gemm_f16(WS& ws, const f32x4 (&in)[C][NIN], f32x
 #endif
     if constexpr (use_hook && s + 1 < ksteps(M) && n_out >= 2) {
       BWords<C> nxt;
-      gemm_f16_panel<M, s, C, NWAVES, false>(ws, b, out, wrap, [&](auto ti) __attribute__((always_inline)) {
+      gemm_f16_panel<M, s, C, NWAVES, false, STREAM>(ws, b, out, wrap, [&](auto ti) __attribute__((always_inline)) {
         constexpr int to = decltype(ti)::value;
         split_units<s + 1, to * NU / n_out, (to + 1) * NU / n_out, ACC_IN, BF>(in, nxt);
       });
       cur = nxt;
     } else {
-      gemm_f16_panel<M, s, C, NWAVES>(ws, b, out, wrap);
+      gemm_f16_panel<M, s, C, NWAVES, false, STREAM>(ws, b, out, wrap);
       if constexpr (s + 1 < ksteps(M)) split_units<s + 1, 0, NU, ACC_IN, BF>(in, cur);
     }
   });

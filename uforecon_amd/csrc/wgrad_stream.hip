@@ -24,7 +24,7 @@
 namespace ufr {
 namespace wgs {
 
-enum FMap : int { FM_NAT = 0, FM_SLOT20, FM_RW0 };
+enum FMap : int { FM_NAT = 0, FM_SLOT20, FM_RW0, FM_NAT88, FM_QUAD11, FM_HEAD11K };
 // feature held by row m = 4g + r of tile t of a tensor with that row map (-1: padding)
 __host__ __device__ constexpr int fmap(int kind, int t, int m, int dim) {
   const int g = m >> 2, r = m & 3;
@@ -33,6 +33,9 @@ __host__ __device__ constexpr int fmap(int kind, int t, int m, int dim) {
     case FM_NAT: v = 16 * t + m; break;
     case FM_SLOT20: v = 20 * g + 4 * t + r; break;
     case FM_RW0: v = t < 5 ? 16 * t + m : ((r == 0 && g < 3) ? 80 + g : -1); break;   // [y 80 | dir 3] (COL_RW0)
+    case FM_NAT88: v = nat88(t, g, r); break;
+    case FM_QUAD11: v = quad11(t, g, r); break;
+    case FM_HEAD11K: v = head11_slot(m) >= 0 ? 11 * t + head11_slot(m) : -1; break;   // head tile t
   }
   return (v >= 0 && v < dim) ? v : -1;
 }
@@ -282,7 +285,60 @@ __global__ void __launch_bounds__(256, 2) view_wgrad_kernel(const float* __restr
   }
 }
 
+// ---- ray transformer: 4 workgroup types x 4 waves.  X tiles: RT_X (nat88), RT_MSG (quad-packed), RT_M, RT_HID, RT_O, RT_D1,
+// RT_D2; dY tiles: DR_Q (quad-packed rows), DR_K / DR_V (one 16-slot tile per head), DR_MPRE, DR_HID, DR_OPRE, DR_D1, DR_D2, DR_SR
+constexpr int kRayTypes = 4;
+constexpr Role kRayRoles[kRayTypes * 4] = {
+    // type 0: q (6 x 6), merge (6 x 6), k in two halves of its head tiles (4 x 6 each)
+    {1, {full(DR_Q, 6, 0, FM_QUAD11, 88, B_TAPE, RT_X, 6, 0, FM_NAT88, 88, P_RT_Q, 88)}},
+    {1, {full(DR_MPRE, 6, 0, FM_NAT88, 88, B_TAPE, RT_MSG, 6, 0, FM_QUAD11, 88, P_RT_MERGE, 88)}},
+    {1, {full(DR_K, 4, 0, FM_HEAD11K, 88, B_TAPE, RT_X, 6, 0, FM_NAT88, 88, P_RT_K, 88)}},
+    {1, {full(DR_K + 4, 4, 4, FM_HEAD11K, 88, B_TAPE, RT_X, 6, 0, FM_NAT88, 88, P_RT_K, 88)}},
+    // type 1: v in two halves, mlp2 (88 x 176) in two column ranges of the hidden layer
+    {1, {full(DR_V, 4, 0, FM_HEAD11K, 88, B_TAPE, RT_X, 6, 0, FM_NAT88, 88, P_RT_V, 88)}},
+    {1, {full(DR_V + 4, 4, 4, FM_HEAD11K, 88, B_TAPE, RT_X, 6, 0, FM_NAT88, 88, P_RT_V, 88)}},
+    {1, {full(DR_OPRE, 6, 0, FM_NAT88, 88, B_TAPE, RT_HID, 6, 0, FM_NAT, 176, P_RT_MLP2, 176)}},
+    {1, {full(DR_OPRE, 6, 0, FM_NAT88, 88, B_TAPE, RT_HID + 6, 5, 6, FM_NAT, 176, P_RT_MLP2, 176)}},
+    // type 2: mlp0 (176 x [x 88 | m 88]), hidden rows 0..95 against x and m, rows 96..175 against x and m
+    {1, {full(DR_HID, 6, 0, FM_NAT, 176, B_TAPE, RT_X, 6, 0, FM_NAT88, 88, P_RT_MLP0, 176, 0)}},
+    {1, {full(DR_HID, 6, 0, FM_NAT, 176, B_TAPE, RT_M, 6, 0, FM_NAT88, 88, P_RT_MLP0, 176, 88)}},
+    {1, {full(DR_HID + 6, 5, 6, FM_NAT, 176, B_TAPE, RT_X, 6, 0, FM_NAT88, 88, P_RT_MLP0, 176, 0)}},
+    {1, {full(DR_HID + 6, 5, 6, FM_NAT, 176, B_TAPE, RT_M, 6, 0, FM_NAT88, 88, P_RT_MLP0, 176, 88)}},
+    // type 3: the DensityMLP and its biases (one wave; the other three idle)
+    {6, {full(DR_D1, 2, 0, FM_NAT, 32, B_TAPE, RT_O, 6, 0, FM_NAT88, 88, P_DM_W0, 88), rowsum(DR_D1, 2, 32, P_DM_B0),
+         full(DR_D2, 1, 0, FM_NAT, 16, B_TAPE, RT_D1, 2, 0, FM_NAT, 32, P_DM_W2, 32), rowsum(DR_D2, 1, 16, P_DM_B2),
+         full(DR_SR, 1, 0, FM_NAT, 1, B_TAPE, RT_D2, 1, 0, FM_NAT, 16, P_DM_W4, 16), rowsum(DR_SR, 1, 1, P_DM_B4)}},
+    {0, {}}, {0, {}}, {0, {}},
+};
+
+template <bool LOWP>
+__global__ void __launch_bounds__(256, 2) ray_wgrad_kernel(const float* __restrict__ tape, const float* __restrict__ dbuf,
+                                                           int n_blocks, int n_chunks, GradPtrs gp) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int type = blockIdx.x / n_chunks, chunk = blockIdx.x - type * n_chunks;
+  const int per = (n_blocks + n_chunks - 1) / n_chunks;
+  const int blk0 = chunk * per, blk1 = min(n_blocks, blk0 + per);
+  switch (__builtin_amdgcn_readfirstlane(type * 4 + wave)) {
+#define UFR_ROLE(i) case i: run_role<kRayRoles, i, LOWP, RayTapeLayout<LOWP>, RayGradLayout<LOWP>>(tape, dbuf, blk0, blk1, gp, lane); break;
+    UFR_ROLE(0) UFR_ROLE(1) UFR_ROLE(2) UFR_ROLE(3) UFR_ROLE(4) UFR_ROLE(5) UFR_ROLE(6) UFR_ROLE(7)
+    UFR_ROLE(8) UFR_ROLE(9) UFR_ROLE(10) UFR_ROLE(11) UFR_ROLE(12)
+#undef UFR_ROLE
+    default: break;
+  }
+}
+
 }  // namespace wgs
+
+hipError_t launch_ray_wgrad(const float* tape, const float* dbuf, int n_blocks, const GradPtrs& gp, bool lowp, hipStream_t s) {
+  if (n_blocks <= 0) return hipErrorInvalidValue;
+  int n_chunks = (n_blocks + 15) / 16;
+  if (n_chunks > 384) n_chunks = 384;
+  const dim3 grid(n_chunks * wgs::kRayTypes), block(256);
+  if (lowp) hipLaunchKernelGGL(wgs::ray_wgrad_kernel<true>, grid, block, 0, s, tape, dbuf, n_blocks, n_chunks, gp);
+  else hipLaunchKernelGGL(wgs::ray_wgrad_kernel<false>, grid, block, 0, s, tape, dbuf, n_blocks, n_chunks, gp);
+  return hipGetLastError();
+}
 
 hipError_t launch_view_wgrad(const float* tape, const float* dbuf, int n_blocks, const GradPtrs& gp, bool lowp, hipStream_t s) {
   if (n_blocks <= 0) return hipErrorInvalidValue;

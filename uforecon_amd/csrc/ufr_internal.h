@@ -106,11 +106,6 @@ hipError_t launch_ray_dgrad(const float* packed, const float* tape, const float*
                             bool accumulate, int RN, int SN, float* dbuf, float* d_tok_a, float* d_tok_b, const GradPtrs& gp, bool lowp,
                             hipStream_t s);
 hipError_t launch_ray_wgrad(const float* tape, const float* dbuf, int n_blocks, const GradPtrs& gp, bool lowp, hipStream_t s);
-// tok_row (nullable): pool row of sample (ray, s) for token0 AND for the d_tok_a / d_tok_b rows it produces; accumulate:
-// d_tok_* += (every pool row is written once per launch, so a plain read-modify-write)
-hipError_t launch_ray_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* token0, const int* tok_row, bool accumulate,
-                          const float* order_pe, const float* d_srdf, int RN, int SN, float* d_tok_a, float* d_tok_b,
-                          float* dbg, bool lowp, hipStream_t s);
 hipError_t launch_presim_bwd(const RawPtrs& wp, const GradPtrs& gp, const float* sim8, const float* d_pv, int P, bool lowp,
                              hipStream_t s);
 // scratch: gather_bwd_scratch_floats(f) floats (zeroed by the launcher): the channel-last record volumes of the scatter

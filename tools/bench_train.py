@@ -217,9 +217,14 @@ def run(a, dev, world=1, rank=0):
     try:
         import glob
         pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_train_pmc.json")))[-1]
+        tot = 0.0
         for k, v in json.load(open(pj)).items():
-            if "view_bwd" in k and v.get("hbm_bytes_per_launch"):
-                traffic, traffic_src = v["hbm_bytes_per_launch"], os.path.relpath(pj, ROOT)
+            # the three kernels of the view transformer's backward (the TAPE instantiation has four template arguments)
+            if (("view_dgrad_kernel" in k or "view_wgrad_kernel" in k or ("view_transformer_kernel" in k and k.count(",") >= 3))
+                    and v.get("hbm_bytes_per_launch")):
+                tot += v["hbm_bytes_per_launch"]
+        if tot > 0:
+            traffic, traffic_src = tot, os.path.relpath(pj, ROOT)
     except Exception:  # noqa: BLE001
         pass
     line = dict(
@@ -230,10 +235,17 @@ def run(a, dev, world=1, rank=0):
         config=dict(workload=f"configs[4]: {a.views} source views + GT view, {a.rays} random rays per rank of a "
                              f"{a.height}x{a.width} frame, {a.coarse}+{a.fine} samples ({pts} point evaluations per rank and "
                              f"step), frustum gradients on, Adam step included",
-                    arithmetic=("fp32 mode: forward dense layers as three fp16 plane products (fp32-grade), backward GEMMs "
-                                "and weight gradients on the fp32 MFMA" if a.precision == "fp32" else
-                                "16-bit mode: one fp16 plane per operand in the forward, bf16 operands in the backward GEMMs "
-                                "and weight gradients, fp32 accumulation; LayerNorm / attention / softmax / compositor fp32"),
+                    arithmetic=("fp32 mode: forward dense layers as three fp16 plane products (fp32-grade); backward data-gradient "
+                                "chains and weight-gradient contractions as three bf16 plane products (16 significand bits per "
+                                "operand, fp32 accumulate; every gradient tensor within 3e-5 of the reference's autograd)"
+                                if a.precision == "fp32" else
+                                "16-bit mode: one fp16 plane per operand in the forward, one bf16 plane per operand in the backward "
+                                "chains and weight gradients (tiles stored as bf16), fp32 accumulation; LayerNorm / attention / "
+                                "softmax / compositor fp32"),
+                    backward_ms_per_step=dict(
+                        view_transformer=vb_ms * vb["launches"] / a.steps,
+                        ray_transformer=sum(prof[k]["ms"] for k in ("ray_tape", "ray_dgrad", "ray_wgrad") if k in prof) / a.steps,
+                        frustum_scatter=prof.get("gather_bwd", dict(ms=0.0))["ms"] / a.steps),
                     loss=float(loss.detach()),
                     kernel_ms_per_step_rank0={k: v["ms"] / a.steps for k, v in prof.items()},
                     kernel_launches_per_step={k: v["launches"] / a.steps for k, v in prof.items()},
@@ -243,7 +255,10 @@ def run(a, dev, world=1, rank=0):
                       algorithmic_flop_per_launch=vb_flop,
                       peak_basis=("dense fp32 MFMA peak" if a.precision == "fp32" else "dense bf16 MFMA peak")
                                  + "; algorithmic flop = 3 x the forward view-transformer flop per point (recompute + data "
-                                   "gradients + weight gradients)"))
+                                   "gradients + weight gradients); the three kernels are bound by the tile traffic between them "
+                                   "(`traffic` bytes per launch group at `hbm_gbps`), not by the matrix cores",
+                      hbm_gbps=(traffic / (vb_ms * 1e-3) / 1e9) if (traffic and vb_ms > 0) else None,
+                      frac_of_f16x3_peak=(achieved / (PEAK_16BIT_MFMA_TFLOPS / 3.0)) if a.precision == "fp32" else None))
     if not a.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(a, frame_cpu, weights_cpu)
     return line

@@ -2,6 +2,8 @@
 // tap of the gather kernel is one contiguous line (feat: 128 B, match: 128*(NV-1) B, volume
 // texel: 48 B, rgb: 16 B).  HBM-bound streaming kernels, run once per frame
 // (the reference keeps NCHW and lets F.grid_sample stride over channels, model.py:251,370).
+#include <mutex>
+
 #include "ufr_internal.h"
 #include "ufr_layout_f16.h"
 
@@ -75,40 +77,73 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(RawPtrs raw, float* _
   packed[i] = p >= 0 ? raw.p[p][e] : 0.f;
 }
 
-// fp16 plane region (ufr_layout_f16.h): halfword h = plane p of 2^kWScaleLog2 * raw[param][elem]; hi = fp16(w'),
-// lo = fp16(w' - hi), both round-to-nearest-even (hi + lo carries 22+ significand bits of w').  A weight outside the
-// fp16 range after scaling (or not finite) raises *flag.
-__global__ void __launch_bounds__(256) pack_weights_f16_kernel(RawPtrs raw, unsigned short* __restrict__ packed, int n,
-                                                                int* __restrict__ flag) {
+// Plane regions (ufr_layout_f16.h).  Forward streams: halfword h = fp16 plane p of 2^kWScaleLog2 * raw[param][elem]; hi =
+// fp16(w'), lo = fp16(w' - hi), both round-to-nearest-even (hi + lo carries 22+ significand bits of w'); a weight outside
+// the fp16 range after scaling (or not finite) raises *flag.  Backward streams: bf16 planes of the unscaled weight.
+// Where a halfword comes from is a pure function of the layout: it is evaluated ONCE per device into a table (param, elem,
+// plane | bf16 flag), and a pack is a gather through that table -- training re-packs after every optimizer step, and
+// walking the panel lists per halfword (plan_entry_f16) cost 0.41 ms per step once the backward streams had tripled the region.
+struct PlaneSrc { int elem; short param; unsigned char plane, bf16; };
+static_assert(sizeof(PlaneSrc) == 8, "one 8-byte entry per halfword");
+
+__global__ void __launch_bounds__(256) plane_plan_kernel(PlaneSrc* __restrict__ plan, int n) {
   int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= n) return;
   int p, e, plane, bf;
   plan_entry_f16(h, &p, &e, &plane, &bf);
+  plan[h] = PlaneSrc{e, (short)p, (unsigned char)plane, (unsigned char)bf};
+}
+
+__global__ void __launch_bounds__(256) pack_weights_f16_kernel(RawPtrs raw, const PlaneSrc* __restrict__ plan,
+                                                                unsigned short* __restrict__ packed, int n,
+                                                                int* __restrict__ flag) {
+  int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= n) return;
+  const PlaneSrc src = plan[h];
   unsigned short out = 0;
-  if (p >= 0) {
-    if (bf) {
-      // backward streams: bf16 planes of the unscaled weight, hi = bf16(w), lo = bf16(w - hi) (round to nearest even)
-      const float w = raw.p[p][e];
+  if (src.param >= 0) {
+    if (src.bf16) {
+      const float w = raw.p[src.param][src.elem];
       const __bf16 hi = (__bf16)w;
       const __bf16 lo = (__bf16)(w - (float)hi);
-      out = __builtin_bit_cast(unsigned short, plane == 0 ? hi : lo);
+      out = __builtin_bit_cast(unsigned short, src.plane == 0 ? hi : lo);
     } else {
-      const float w = raw.p[p][e] * kWScale;
+      const float w = raw.p[src.param][src.elem] * kWScale;
       if (!(fabsf(w) <= 65504.f)) atomicOr(flag, 4);   // bit 2 of the sticky range status (include/ufr.h)
       const _Float16 hi = (_Float16)w;
       const _Float16 lo = (_Float16)(w - (float)hi);
-      out = __builtin_bit_cast(unsigned short, plane == 0 ? hi : lo);
+      out = __builtin_bit_cast(unsigned short, src.plane == 0 ? hi : lo);
     }
   }
   packed[h] = out;
 }
 
+namespace {
+struct PlanCache {
+  std::once_flag once[16];
+  hipError_t err[16];
+  PlaneSrc* plan[16];
+};
+PlanCache g_plan;
+}  // namespace
+
 hipError_t launch_pack_weights(const RawPtrs& raw, float* packed, int* range_flag, hipStream_t s) {
   const int n = blob_floats(), first = vec_region_offset();
+  constexpr int n_half = kF16Halfwords + kBwdHalfwords;   // forward fp16 planes, then the backward kernels' bf16 planes
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+  std::call_once(g_plan.once[dev], [&] {      // process lifetime, 8 bytes per halfword (~13 MB)
+    g_plan.err[dev] = hipMalloc(reinterpret_cast<void**>(&g_plan.plan[dev]), sizeof(PlaneSrc) * (size_t)n_half);
+    if (g_plan.err[dev] != hipSuccess) return;
+    hipLaunchKernelGGL(plane_plan_kernel, dim3((n_half + 255) / 256), dim3(256), 0, s, g_plan.plan[dev], n_half);
+    g_plan.err[dev] = hipGetLastError();
+    if (g_plan.err[dev] == hipSuccess) g_plan.err[dev] = hipStreamSynchronize(s);   // other streams may pack next
+  });
+  if (g_plan.err[dev] != hipSuccess) return g_plan.err[dev];
   hipLaunchKernelGGL(pack_weights_kernel, dim3((n - first + 255) / 256), dim3(256), 0, s, raw, packed, first, n);
   unsigned short* planes = reinterpret_cast<unsigned short*>(packed + n);
-  constexpr int n_half = kF16Halfwords + kBwdHalfwords;   // forward fp16 planes, then the backward kernels' bf16 planes
-  hipLaunchKernelGGL(pack_weights_f16_kernel, dim3((n_half + 255) / 256), dim3(256), 0, s, raw, planes, n_half, range_flag);
+  hipLaunchKernelGGL(pack_weights_f16_kernel, dim3((n_half + 255) / 256), dim3(256), 0, s, raw, g_plan.plan[dev], planes, n_half,
+                     range_flag);
   return hipGetLastError();
 }
 

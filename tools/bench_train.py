@@ -223,7 +223,7 @@ def run(a, dev, world=1, rank=0):
             if (("view_dgrad_kernel" in k or "view_wgrad_kernel" in k or ("view_transformer_kernel" in k and k.count(",") >= 3))
                     and v.get("hbm_bytes_per_launch")):
                 tot += v["hbm_bytes_per_launch"]
-        if tot > 0:
+        if tot > 0 and a.precision == "fp32":     # the committed counter pass ran the fp32 mode (the 16-bit mode stores bf16 tiles)
             traffic, traffic_src = tot, os.path.relpath(pj, ROOT)
     except Exception:  # noqa: BLE001
         pass

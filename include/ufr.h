@@ -32,7 +32,7 @@ enum ufr_status {
 
 /* Version of this header's ABI (argument lists, struct layouts, packed-blob layout).  ufr_version() returns the value
  * the library was built with: a binding must refuse a library whose version differs (uforecon_amd/_lib.py does). */
-#define UFR_ABI_VERSION 400
+#define UFR_ABI_VERSION 401
 
 #define UFR_MAX_VIEWS 7
 #define UFR_NUM_STAGES 3
@@ -84,13 +84,17 @@ typedef struct ufr_raw_weights {
 int ufr_set_matrix_precision(int mode); /* sets what UFR_PRECISION_DEFAULT resolves to (FP32 or 16BIT) */
 int ufr_get_matrix_precision(void);
 
-/* Sticky range status of the current device.  The split-precision planes hold |weight| < 255.8 and |activation| < 4094
- * (fp16 after the power-of-two plane scales); the kernels never synchronise, so a violation raises a device-side
- * sticky flag instead of failing the launch:
- *   bit 0  a dense-layer input of a transformer kernel reached |x| >= 4094 (its planes overflowed)
+/* Sticky range status of the current device.  The dense layers run on fp16 planes whose power-of-two scales are chosen
+ * when the weights are packed: per matrix from max |w| (any finite weight fits), per layer from an analytic upper bound
+ * of the layer's input that starts at the bound of the token features the caller states (ufr_weights_pack_for; default
+ * 256) and is carried through the matrices' infinity norms, the LayerNorm gains and the biases.  With a true input bound
+ * no layer can overflow.  The kernels never synchronise, so a violation raises a device-side sticky flag instead of
+ * failing the launch:
+ *   bit 0  a dense-layer input of a transformer kernel left the range of its planes: a token feature beyond the stated
+ *          bound, or +-inf -- repack with a larger input_abs_max
  *   bit 1  NaN among the externally supplied inputs of a transformer kernel (token rows, dir); +-inf inputs and
  *          internally produced overflows raise bit 0
- *   bit 2  ufr_weights_pack met a weight that is not finite or |w| >= 255.8
+ *   bit 2  ufr_weights_pack met a parameter that is not finite
  * ufr_status_poll copies the flag to the host on `stream`; with synchronize != 0 it waits for the stream and returns
  * UFR_ERR_RANGE (message: which bits) when the flag is set, clearing it.  Without synchronize it returns what an
  * EARLIER poll / launch has already delivered.  ufr_render_rays, ufr_aggregate, ufr_view_transform and
@@ -106,7 +110,12 @@ int ufr_status_poll_bits(ufr_stream stream, int32_t synchronize, int32_t mask, i
  * input features = 64 lanes x float4, zero padded) so the kernels stream them with
  * contiguous 1 KiB wave loads.  Call again whenever the parameters change. */
 size_t ufr_packed_weights_bytes(void);
-int ufr_weights_pack(const ufr_raw_weights* raw, void* packed, ufr_stream stream);
+int ufr_weights_pack(const ufr_raw_weights* raw, void* packed, ufr_stream stream);   /* input_abs_max = 256 */
+/* The same for token features bounded by input_abs_max (positive, finite): |x_tokens| of ufr_aggregate /
+ * ufr_view_transform, i.e. the magnitude of the frame's feature maps, volumes and pre-similarity features.  The bound
+ * only sets the exponents the activations' planes carry (a pessimistic one costs no accuracy: the planes keep 22
+ * significand bits down to 2^-17 of each layer's bound), so state it generously. */
+int ufr_weights_pack_for(const ufr_raw_weights* raw, void* packed, float input_abs_max, ufr_stream stream);
 /* Host-only description of that re-ordering (for tests / other bindings): for every packed
  * float, param_id (index into the pointer list of ufr_raw_weights in declaration order, -1 =
  * zero padding) and elem (flat element index inside that parameter).  Arrays of
@@ -116,12 +125,17 @@ int ufr_pack_plan(int32_t* param_id, int32_t* elem);
  * 16-bit words | bf16 plane region of the backward kernels: ufr_packed_bwd_halfwords() 16-bit words | 16-byte tail].
  * The bf16 region holds the TRANSPOSED dense matrices of the data-gradient chains (hi = bf16(w), lo = bf16(w - hi), same
  * fragment order as the forward planes).  The fp16 plane region holds the dense layers of both transformer chains as two fp16
- * planes per weight (hi = fp16(256 w), lo = fp16(256 w - hi); plane 0/1) for the split-precision MFMA path;
+ * planes per weight (w' = 2^s_M w with the matrix's exponent s_M: hi = fp16(w'), lo = fp16(w' - hi); plane 0/1) for the
+ * split-precision MFMA path;
  * ufr_pack_plan_f16 describes it like ufr_pack_plan (one entry per halfword, plus the plane).  Of the fp32 region
- * ufr_weights_pack fills only the trailing vector fragments (biases, LayerNorm, view token): the kernels read nothing
- * else of it.  ufr_weights_pack does not synchronise: a dense-layer weight that is not finite or |w| >= 255.8 (outside
- * the fp16 planes' range) raises bit 2 of the sticky status -- call ufr_status_poll(stream, 1, ...) after packing to
- * fail at once (uforecon_amd.ops.PackedWeights does), or let the next compute entry point report it. */
+ * ufr_weights_pack fills only the trailing vector fragments (biases, LayerNorm, view token) and, behind them, the scale
+ * table: per dense matrix M (ufr_packed_scale_table_offset() floats into the blob, 4 floats each, in the order of
+ * csrc/ufr_layout.h: Mat) {2^a_M, 2^-(s_M + a_M), 2^(s_M + a_M), 2^s_M}; the kernels read nothing else of the region.
+ * ufr_weights_pack does not synchronise: a parameter that is not finite raises bit 2 of the sticky status -- call
+ * ufr_status_poll(stream, 1, ...) after packing to fail at once (uforecon_amd.ops.PackedWeights does), or let the next
+ * compute entry point report it. */
+size_t ufr_packed_scale_table_offset(void);
+int ufr_packed_scale_table_entries(void);
 size_t ufr_packed_fp32_floats(void);
 size_t ufr_packed_f16_halfwords(void);
 size_t ufr_packed_bwd_halfwords(void);

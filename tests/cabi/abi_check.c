@@ -9,7 +9,8 @@ int main(void) {
   /* link-time presence of every entry point */
   const void* syms[] = {
       (const void*)ufr_version, (const void*)ufr_last_error, (const void*)ufr_set_matrix_precision,
-      (const void*)ufr_get_matrix_precision, (const void*)ufr_status_poll, (const void*)ufr_packed_weights_bytes, (const void*)ufr_weights_pack,
+      (const void*)ufr_get_matrix_precision, (const void*)ufr_status_poll, (const void*)ufr_packed_weights_bytes, (const void*)ufr_weights_pack, (const void*)ufr_weights_pack_for, (const void*)ufr_packed_scale_table_offset,
+      (const void*)ufr_packed_scale_table_entries,
       (const void*)ufr_pack_plan, (const void*)ufr_packed_fp32_floats, (const void*)ufr_packed_f16_halfwords,
       (const void*)ufr_pack_plan_f16, (const void*)ufr_frame_workspace_bytes, (const void*)ufr_frame_prepare,
       (const void*)ufr_sample_fixed, (const void*)ufr_sample_importance_merge, (const void*)ufr_points,

@@ -98,8 +98,8 @@ def test_full_size_configs3_frame_is_chunk_and_slot_invariant(weights):
 
 def test_trained_like_statistics():
     """A checkpoint-like parameter set (every matrix x 8, LayerNorm gains up to 10, biases in [-1,1]) on feature maps x 30:
-    dense-layer inputs reach ~1e3, three orders of magnitude above the default init, still inside the split-precision
-    planes' range (|x| < 4094, |w| < 255.8).  The reference itself amplifies rounding here (the srdf head has gain ~1e3),
+    dense-layer inputs reach ~1e3, three orders of magnitude above the default init (the planes' exponents follow the
+    weights: ufr_layout_f16.h).  The reference itself amplifies rounding here (the srdf head has gain ~1e3),
     so the oracle on this host is the yardstick: the kernels must be as close to the reference's golden as the oracle is
     (within a factor), and the range status must stay clear."""
     name = "c2_trained_like"
@@ -122,7 +122,8 @@ def test_trained_like_statistics():
 
 # ------------------------------------------------------------------------------------------------ range status
 def test_activation_overflow_raises_the_sticky_status(weights):
-    """|dense-layer input| >= 4094 cannot be held by the fp16 planes: the launch must not pass silently.  The kernels
+    """A token feature far beyond the bound the weights were packed for (default 256; the planes of the first layers
+    hold 2^7 x < 65504, i.e. |x| < 511.7) cannot be held by the fp16 planes: the launch must not pass silently.  The kernels
     raise the device's sticky status; ufr_status_poll reports it at once, and WITHOUT a poll the next compute call fails
     (one call late, no host synchronisation in between)."""
     fr, idx, U1, U2, g = case_inputs("rows_small")
@@ -140,9 +141,9 @@ def test_activation_overflow_raises_the_sticky_status(weights):
     assert ops.status_poll(True) == 0
     # one token feature of one point beyond the planes' range
     x_bad = x_ok.clone()
-    x_bad[5, 1, 17] = 5000.0
+    x_bad[5, 1, 17] = 600.0
     ops.aggregate(weights, x_bad, rgbm, dirs, RN, SN)
-    with pytest.raises(UfrError, match="4094"):
+    with pytest.raises(UfrError, match="input_abs_max"):
         ops.status_poll(True)
     assert ops.status_poll(True) == 0                      # reporting clears it
     # lazily: no poll -> the NEXT entry point reports what the previous one left behind
@@ -160,29 +161,34 @@ def test_activation_overflow_raises_the_sticky_status(weights):
         ops.status_poll(True)
     # the same through the 16-bit mode and through the whole-path entry point's kernels (values just inside pass)
     x_edge = x_ok.clone()
-    x_edge[5, 1, 17] = 4000.0
+    x_edge[5, 1, 17] = 500.0
     ops.aggregate(weights, x_edge, rgbm, dirs, RN, SN, precision=ops.PRECISION_16BIT)
     assert ops.status_poll(True) == 0
     ops.aggregate(weights, x_bad, rgbm, dirs, RN, SN, precision=ops.PRECISION_16BIT)
-    with pytest.raises(UfrError, match="4094"):
+    with pytest.raises(UfrError, match="input_abs_max"):
         ops.status_poll(True)
 
 
-def test_weight_range_is_reported_without_synchronising_repack():
-    """ufr_weights_pack is asynchronous now (training re-packs after every optimizer step): construction still fails at
-    once, an in-place update beyond the range surfaces through the status."""
+def test_bad_weights_are_reported_without_synchronising_repack():
+    """ufr_weights_pack is asynchronous (training re-packs after every optimizer step): construction still fails at once,
+    an in-place update to a non-finite value surfaces through the status; any finite value just re-derives the exponents."""
     P = {k: v.clone().to(DEV) for k, v in load_weights().items()}
     W = ops.PackedWeights(P)
     key = "ray_transformer.density_view_transformer.layers.0.mlp.0.weight"
+    s0 = W.scale_exponents()["vt_mlp0"][0]
     P[key][3, 5] = 300.0
+    W.repack(check=True)
+    assert W.scale_exponents()["vt_mlp0"][0] == 6 < s0      # 300 * 2^6 = 19200 in [2^14, 2^15]
+    P[key][3, 5] = float("nan")
     W.repack()                       # no error here: nothing synchronised
-    with pytest.raises(UfrError, match="255.8"):
+    with pytest.raises(UfrError, match="not finite"):
         ops.status_poll(True)
-    with pytest.raises(UfrError, match="255.8"):
+    with pytest.raises(UfrError, match="not finite"):
         W.repack(check=True)
     P[key][3, 5] = 0.25
     W.repack(check=True)
     assert ops.status_poll(True) == 0
+    assert W.scale_exponents()["vt_mlp0"][0] == s0
 
 
 # ------------------------------------------------------------------------------------------------ per-call precision

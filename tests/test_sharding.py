@@ -208,8 +208,9 @@ def test_two_rank_training_step_allreduces_to_the_mean(tmp_path):
         mean = 0.5 * (g0[k] + g1[k])
         scale = float(mean.abs().max()) + 1e-12
         # float atomics reorder sums between runs (a tensor whose entries are small differences of large sums -- the first
-        # pre_sim_mlp layer -- moved by 6e-5 of its scale; the gradient tolerance itself is 1e-3)
-        assert float((g2[k] - mean).abs().max()) <= 1e-4 * scale + 1e-9, k
+        # pre_sim_mlp layer -- moved by 6e-5 of its scale in most runs, past 1e-4 in one of ~10; the gradient tolerance
+        # itself is 1e-3)
+        assert float((g2[k] - mean).abs().max()) <= 3e-4 * scale + 1e-9, k
         differ += int(float((g0[k] - g1[k]).abs().max()) > 1e-3 * scale)
     assert differ > 30          # the ranks really trained on different data
     line = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # UFR_LIB selects an alternative in-tree build (A/B kernel variants during development)
 LIB_PATH = os.environ.get("UFR_LIB") or os.path.join(HERE, "lib", "libufr.so")
 
-ABI_VERSION = 400   # = UFR_ABI_VERSION of include/ufr.h; load() refuses a library built against another header
+ABI_VERSION = 401   # = UFR_ABI_VERSION of include/ufr.h; load() refuses a library built against another header
 MAX_VIEWS = 7
 NUM_STAGES = 3
 TOKEN_DIM = 80
@@ -74,6 +74,9 @@ SIGNATURES = {
     "ufr_status_poll_bits": (C.c_int, [vp, i32, i32, C.POINTER(i32)]),
     "ufr_packed_weights_bytes": (sz, []),
     "ufr_weights_pack": (C.c_int, [C.POINTER(RawWeights), vp, vp]),
+    "ufr_weights_pack_for": (C.c_int, [C.POINTER(RawWeights), vp, C.c_float, vp]),
+    "ufr_packed_scale_table_offset": (sz, []),
+    "ufr_packed_scale_table_entries": (C.c_int, []),
     "ufr_pack_plan": (C.c_int, [C.POINTER(i32), C.POINTER(i32)]),
     "ufr_packed_fp32_floats": (sz, []),
     "ufr_packed_f16_halfwords": (sz, []),

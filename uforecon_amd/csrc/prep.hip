@@ -2,6 +2,7 @@
 // tap of the gather kernel is one contiguous line (feat: 128 B, match: 128*(NV-1) B, volume
 // texel: 48 B, rgb: 16 B).  HBM-bound streaming kernels, run once per frame
 // (the reference keeps NCHW and lets F.grid_sample stride over channels, model.py:251,370).
+#include <cstdlib>
 #include <mutex>
 
 #include "ufr_internal.h"
@@ -77,39 +78,142 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(RawPtrs raw, float* _
   packed[i] = p >= 0 ? raw.p[p][e] : 0.f;
 }
 
-// Plane regions (ufr_layout_f16.h).  Forward streams: halfword h = fp16 plane p of 2^kWScaleLog2 * raw[param][elem]; hi =
-// fp16(w'), lo = fp16(w' - hi), both round-to-nearest-even (hi + lo carries 22+ significand bits of w'); a weight outside
-// the fp16 range after scaling (or not finite) raises *flag.  Backward streams: bf16 planes of the unscaled weight.
+// ---- the scale table (ufr_layout.h: scale_table_offset; ufr_layout_f16.h: what s_M and a_M mean).
+// One workgroup.  Per forward matrix: max |w| and the infinity norm (largest absolute row sum); per vector parameter: max
+// |.|.  Thread 0 then walks the two layer chains once, carrying an upper bound of every dense layer's input:
+//   projections     |x| <= X (the caller's bound of the token features; the learned view token counts)
+//   attention       the message is a (sub-)convex combination of the values (the scores Q'.K' are positive):
+//                   |msg| <= |v| <= ||W_v||_inf X
+//   LayerNorm       |(x - mean) / sigma| <= sqrt(D - 1), so |out| <= max|gamma| sqrt(D - 1) + max|beta|
+//   ReLU MLPs       |W x + b| <= ||W||_inf |x| + max|b|
+//   residual        |x + LN(.)| <= X + the LayerNorm bound
+// (ray transformer: its tokens are [view-transformer output of token 0 | order encoding], |PE| <= 1).  The bounds are
+// pessimistic by the usual gap between an infinity norm and a typical gain (3..7 bits here) -- which costs nothing: the
+// planes keep 22 significand bits for everything above 2^-17 of the bound.
+// A non-finite parameter raises bit 2 of the sticky status (include/ufr.h) and leaves default exponents.
+namespace {
+__device__ float block_max(float v, float* red) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ float absmax_or_nan(const float* __restrict__ p, int n, float* red, bool& bad) {
+  float m = 0.f;
+  bool b = false;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float a = fabsf(p[i]);
+    b |= !(a <= 3.0e38f);
+    m = fmaxf(m, a);
+  }
+  bad |= block_max(b ? 1.f : 0.f, red) != 0.f;
+  return block_max(m, red);
+}
+// largest exponent in [lo, hi] with 2^e bound <= 2^15 (bound > 0, finite; fp16 holds up to 65504)
+__device__ int plane_exponent(float bound, int lo, int hi) {
+  int e;
+  const float f = frexpf(bound, &e);   // bound = f 2^e, f in [0.5, 1)
+  return max(lo, min(hi, f == 0.5f ? 16 - e : 15 - e));
+}
+}  // namespace
+
+__global__ void __launch_bounds__(256) weight_scale_kernel(RawPtrs raw, float* __restrict__ table, float x_max,
+                                                            int* __restrict__ flag, int fixed) {
+  __shared__ float red[4];
+  __shared__ float wmax[M_COUNT], ninf[M_COUNT], vmax[P_COUNT];
+  bool bad = false;
+  for (int m = 0; m < M_COUNT; ++m) {
+    const MatDesc d = mat_desc(m);
+    const float* w = raw.p[d.param];
+    float rs = 0.f;
+    for (int r = threadIdx.x; r < d.out_dim; r += 256) {
+      float a = 0.f;
+      for (int k = 0; k < d.k_raw; ++k) a += fabsf(w[r * d.k_raw + k]);
+      rs = fmaxf(rs, a);
+    }
+    const float mx = absmax_or_nan(w, d.out_dim * d.k_raw, red, bad);
+    const float ni = block_max(rs, red);
+    if (threadIdx.x == 0) { wmax[m] = mx; ninf[m] = ni; }
+  }
+  constexpr int vparams[][2] = {{P_VT_N1W, 80}, {P_VT_N1B, 80}, {P_VT_N2W, 80}, {P_VT_N2B, 80}, {P_RT_N1W, 88}, {P_RT_N1B, 88},
+                                {P_RT_N2W, 88}, {P_RT_N2B, 88}, {P_DM_B0, 32}, {P_DM_B2, 16}, {P_DM_B4, 1}, {P_RW_B0, 16},
+                                {P_RW_B2, 8}, {P_RW_B4, 1}, {P_VIEW_TOKEN, 80}};
+  for (const auto& vp : vparams) {
+    const float mx = absmax_or_nan(raw.p[vp[0]], vp[1], red, bad);
+    if (threadIdx.x == 0) vmax[vp[0]] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  bad |= !(x_max > 0.f && x_max <= 3.0e38f);
+  float in[M_COUNT];
+  const float X = fmaxf(x_max, vmax[P_VIEW_TOKEN]);
+  // q, k, v and mlp0 (whose input is [x | LayerNorm1 output]) all split the token x: ONE exponent for the four, so the
+  // kernels split x once per phase with the same multiplier (and the compiler merges the repeats)
+  const float vm = vmax[P_VT_N1W] * sqrtf(79.f) + vmax[P_VT_N1B];
+  in[M_VT_Q] = in[M_VT_K] = in[M_VT_V] = in[M_VT_MLP0] = fmaxf(X, vm);
+  in[M_VT_MERGE] = ninf[M_VT_V] * X;
+  in[M_VT_MLP2] = ninf[M_VT_MLP0] * in[M_VT_MLP0];
+  const float Y = X + vmax[P_VT_N2W] * sqrtf(79.f) + vmax[P_VT_N2B];
+  in[M_RW0] = fmaxf(Y, 1.f);                                   // [y | unit direction]
+  in[M_RW2] = ninf[M_RW0] * in[M_RW0] + vmax[P_RW_B0];
+  in[M_RW4] = ninf[M_RW2] * in[M_RW2] + vmax[P_RW_B2];
+  const float XR = fmaxf(Y, 1.f);                              // [y of token 0 | order encoding]
+  const float rm = vmax[P_RT_N1W] * sqrtf(87.f) + vmax[P_RT_N1B];
+  in[M_RT_Q] = in[M_RT_K] = in[M_RT_V] = in[M_RT_MLP0] = fmaxf(XR, rm);
+  in[M_RT_MERGE] = ninf[M_RT_V] * XR;
+  in[M_RT_MLP2] = ninf[M_RT_MLP0] * in[M_RT_MLP0];
+  const float O = XR + vmax[P_RT_N2W] * sqrtf(87.f) + vmax[P_RT_N2B];
+  in[M_DM0] = O;
+  in[M_DM2] = ninf[M_DM0] * O + vmax[P_DM_B0];
+  in[M_DM4] = ninf[M_DM2] * in[M_DM2] + vmax[P_DM_B2];
+  for (int m = 0; m < M_COUNT; ++m) bad |= !(in[m] <= 3.0e38f);
+  if (bad) atomicOr(flag, 4);
+  for (int m = 0; m < M_COUNT; ++m) {
+    // (matrices that share one split of their input -- q / k / v / mlp0 of either transformer -- get the same a_M: it
+    // depends on the input's bound only)
+    // fixed (UFR_DEBUG_FIXED_SCALES=1, ablation): round 3's constants for every matrix
+    const int sw = (!fixed && !bad && wmax[m] > 0.f) ? plane_exponent(wmax[m], kScaleExpWMin, kScaleExpWMax) : 8;
+    const int ax = (!fixed && !bad && in[m] > 0.f) ? plane_exponent(in[m], kScaleExpXMin, kScaleExpXMax) : 4;
+    table[4 * m + 0] = ldexpf(1.f, ax);
+    table[4 * m + 1] = ldexpf(1.f, -(sw + ax));
+    table[4 * m + 2] = ldexpf(1.f, sw + ax);
+    table[4 * m + 3] = ldexpf(1.f, sw);
+  }
+}
+
+// Plane regions (ufr_layout_f16.h).  Forward streams: halfword h = fp16 plane p of 2^s_M * raw[param][elem] (2^s_M from the
+// scale table); hi = fp16(w'), lo = fp16(w' - hi), both round-to-nearest-even (hi + lo carries 22+ significand bits of w').
+// Backward streams: bf16 planes of the unscaled weight.
 // Where a halfword comes from is a pure function of the layout: it is evaluated ONCE per device into a table (param, elem,
-// plane | bf16 flag), and a pack is a gather through that table -- training re-packs after every optimizer step, and
+// plane, matrix), and a pack is a gather through that table -- training re-packs after every optimizer step, and
 // walking the panel lists per halfword (plan_entry_f16) cost 0.41 ms per step once the backward streams had tripled the region.
-struct PlaneSrc { int elem; short param; unsigned char plane, bf16; };
+struct PlaneSrc { int elem; short param; unsigned char plane, mat; };
 static_assert(sizeof(PlaneSrc) == 8, "one 8-byte entry per halfword");
 
 __global__ void __launch_bounds__(256) plane_plan_kernel(PlaneSrc* __restrict__ plan, int n) {
   int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= n) return;
-  int p, e, plane, bf;
-  plan_entry_f16(h, &p, &e, &plane, &bf);
-  plan[h] = PlaneSrc{e, (short)p, (unsigned char)plane, (unsigned char)bf};
+  int p, e, plane, bf, mat;
+  plan_entry_f16(h, &p, &e, &plane, &bf, &mat);
+  plan[h] = PlaneSrc{e, (short)p, (unsigned char)plane, (unsigned char)(mat < 0 ? 0 : mat)};
 }
 
 __global__ void __launch_bounds__(256) pack_weights_f16_kernel(RawPtrs raw, const PlaneSrc* __restrict__ plan,
-                                                                unsigned short* __restrict__ packed, int n,
-                                                                int* __restrict__ flag) {
+                                                                const float* __restrict__ table,
+                                                                unsigned short* __restrict__ packed, int n) {
   int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= n) return;
   const PlaneSrc src = plan[h];
   unsigned short out = 0;
   if (src.param >= 0) {
-    if (src.bf16) {
+    if (f16_mat_is_bf16(src.mat)) {
       const float w = raw.p[src.param][src.elem];
       const __bf16 hi = (__bf16)w;
       const __bf16 lo = (__bf16)(w - (float)hi);
       out = __builtin_bit_cast(unsigned short, src.plane == 0 ? hi : lo);
     } else {
-      const float w = raw.p[src.param][src.elem] * kWScale;
-      if (!(fabsf(w) <= 65504.f)) atomicOr(flag, 4);   // bit 2 of the sticky range status (include/ufr.h)
+      const float w = raw.p[src.param][src.elem] * table[4 * src.mat + 3];
       const _Float16 hi = (_Float16)w;
       const _Float16 lo = (_Float16)(w - (float)hi);
       out = __builtin_bit_cast(unsigned short, src.plane == 0 ? hi : lo);
@@ -127,8 +231,8 @@ struct PlanCache {
 PlanCache g_plan;
 }  // namespace
 
-hipError_t launch_pack_weights(const RawPtrs& raw, float* packed, int* range_flag, hipStream_t s) {
-  const int n = blob_floats(), first = vec_region_offset();
+hipError_t launch_pack_weights(const RawPtrs& raw, float* packed, float input_abs_max, int* range_flag, hipStream_t s) {
+  const int n = blob_floats(), first = vec_region_offset(), n_vec = scale_table_offset();
   constexpr int n_half = kF16Halfwords + kBwdHalfwords;   // forward fp16 planes, then the backward kernels' bf16 planes
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
@@ -140,10 +244,13 @@ hipError_t launch_pack_weights(const RawPtrs& raw, float* packed, int* range_fla
     if (g_plan.err[dev] == hipSuccess) g_plan.err[dev] = hipStreamSynchronize(s);   // other streams may pack next
   });
   if (g_plan.err[dev] != hipSuccess) return g_plan.err[dev];
-  hipLaunchKernelGGL(pack_weights_kernel, dim3((n - first + 255) / 256), dim3(256), 0, s, raw, packed, first, n);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((n_vec - first + 255) / 256), dim3(256), 0, s, raw, packed, first, n_vec);
+  float* table = packed + scale_table_offset();
+  static const int fixed = [] { const char* e = getenv("UFR_DEBUG_FIXED_SCALES"); return (e && e[0] == '1') ? 1 : 0; }();
+  hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(256), 0, s, raw, table, input_abs_max, range_flag, fixed);
   unsigned short* planes = reinterpret_cast<unsigned short*>(packed + n);
-  hipLaunchKernelGGL(pack_weights_f16_kernel, dim3((n_half + 255) / 256), dim3(256), 0, s, raw, g_plan.plan[dev], planes, n_half,
-                     range_flag);
+  hipLaunchKernelGGL(pack_weights_f16_kernel, dim3((n_half + 255) / 256), dim3(256), 0, s, raw, g_plan.plan[dev], table, planes,
+                     n_half);
   return hipGetLastError();
 }
 

@@ -98,7 +98,9 @@ __global__ void __launch_bounds__(kRdBlock, 2) ray_dgrad_kernel(const float* __r
   const int ray = valid ? ray_raw : RN - 1;
   const int n_tiles = SN / 16, n2 = n_tiles + (n_tiles & 1), nb = n2 / 2;
   const float fSN = (float)SN;
-  const float inv_len = kAccDescale / fSN, f_len = fSN * kAccScale;   // values / v_length on raw accumulators (ray_transformer.hip)
+  const MatScale zk = mat_scale<M_RT_K>(ws), zv = mat_scale<M_RT_V>(ws);   // sweep 2 recomputes k, v from the forward planes
+  const float k_l2e = zk.dsc * kLog2e;
+  const float inv_len = zv.dsc / fSN, f_len = fSN * zv.asc;   // values / v_length on raw accumulators (ray_transformer.hip)
   const bool pow2_len = (SN & (SN - 1)) == 0;
 
   float* const a_base = reinterpret_cast<float*>(smem + kF16LdsBytes) + (threadIdx.x >> 6) * kRdAccFloats + lane;
@@ -153,7 +155,7 @@ __global__ void __launch_bounds__(kRdBlock, 2) ray_dgrad_kernel(const float* __r
       dy_st(DR_D2, dd2[0][0]);
       dd1[0][0] = dd1[0][1] = splat4(0.f);
     }
-    gemm_f16<M_DM2T, C, kRdWaves, false, true>(ws, dd2, dd1, wrap);
+    gemm_f16<M_DM2T, C, kRdWaves>(ws, dd2, dd1, wrap);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -162,7 +164,7 @@ __global__ void __launch_bounds__(kRdBlock, 2) ray_dgrad_kernel(const float* __r
     }
 #pragma unroll
     for (int t = 0; t < 6; ++t) dout[0][t] = splat4(0.f);
-    gemm_f16<M_DM0T, C, kRdWaves, false, true>(ws, dd1, dout, wrap);
+    gemm_f16<M_DM0T, C, kRdWaves>(ws, dd1, dout, wrap);
 
     // ---------------- LayerNorm2 backwards (transformer.py:56-58); o = x + LN2(opre): d x starts as d o (parked in DR_SCR)
     f32x4 dopre[C][6];
@@ -196,7 +198,7 @@ __global__ void __launch_bounds__(kRdBlock, 2) ray_dgrad_kernel(const float* __r
     f32x4 dhid[C][11];
 #pragma unroll
     for (int t = 0; t < 11; ++t) dhid[0][t] = splat4(0.f);
-    gemm_f16<M_RT_MLP2T, C, kRdWaves, false, true>(ws, dopre, dhid, wrap);
+    gemm_f16<M_RT_MLP2T, C, kRdWaves>(ws, dopre, dhid, wrap);
 #pragma unroll
     for (int t = 0; t < 11; ++t) {
 #pragma unroll
@@ -206,7 +208,7 @@ __global__ void __launch_bounds__(kRdBlock, 2) ray_dgrad_kernel(const float* __r
     f32x4 dcat[C][12];
 #pragma unroll
     for (int t = 0; t < 12; ++t) dcat[0][t] = splat4(0.f);
-    gemm_f16<M_RT_MLP0T, C, kRdWaves, false, true>(ws, dhid, dcat, wrap);
+    gemm_f16<M_RT_MLP0T, C, kRdWaves>(ws, dhid, dcat, wrap);
     // ---------------- LayerNorm1 backwards on the message half (transformer.py:52); the x half joins the scratch
     f32x4 dmpre[C][6];
     {
@@ -239,7 +241,7 @@ __global__ void __launch_bounds__(kRdBlock, 2) ray_dgrad_kernel(const float* __r
     f32x4 dmsg[C][6];
 #pragma unroll
     for (int t = 0; t < 6; ++t) dmsg[0][t] = splat4(0.f);
-    gemm_f16<M_RT_MERGET, C, kRdWaves, false, true>(ws, dmpre, dmsg, wrap);
+    gemm_f16<M_RT_MERGET, C, kRdWaves>(ws, dmpre, dmsg, wrap);
 
     // ---------------- linear attention backwards, query side (linear_attention.py:41-44):
     //   acc[v] = sum_d KV[d][v] Q'[d] (slot 3 of a head tile = the ones column: acc = Q'.sum K' = den),  Zs = SN / (den + eps),
@@ -284,7 +286,7 @@ __global__ void __launch_bounds__(kRdBlock, 2) ray_dgrad_kernel(const float* __r
     f32x4 dx[C][6];
 #pragma unroll
     for (int t = 0; t < 6; ++t) dx[0][t] = splat4(0.f);
-    gemm_f16<M_RT_QT, C, kRdWaves, false, true>(ws, dq, dx, wrap);
+    gemm_f16<M_RT_QT, C, kRdWaves>(ws, dq, dx, wrap);
 #pragma unroll
     for (int t = 0; t < 6; ++t) dy_st(DR_SCR + t, dx[0][t] + dy_ld(DR_SCR + t));
     wstream_f16_finish<B_RTB1, kRdWaves>(ws, wrap);
@@ -308,7 +310,7 @@ __global__ void __launch_bounds__(kRdBlock, 2) ray_dgrad_kernel(const float* __r
     for (int h = 0; h < 8; ++h) { kt[0][h] = splat4(0.f); vt[0][h] = splat4(0.f); }
     {  // k, v in the plain orientation: rows = the head tile's slots 4g + r, column = token; x is split once per k-step
       BWords<C> cur;
-      split_units<0, 0, 4 * C>(x, cur);
+      split_units<0, 0, 4 * C>(x, cur, zk.xs);
       static_for<3>([&](auto si) __attribute__((always_inline)) {
         constexpr int s = decltype(si)::value;
         BStep b[C];
@@ -317,7 +319,7 @@ __global__ void __launch_bounds__(kRdBlock, 2) ray_dgrad_kernel(const float* __r
           BWords<C> nxt;
           gemm_f16_panel<M_RT_K, s, C, kRdWaves, false, B_RTB2>(ws, b, kt, wrap, [&](auto ti) __attribute__((always_inline)) {
             constexpr int to = decltype(ti)::value;
-            split_units<s + 1, to * 4 * C / 8, (to + 1) * 4 * C / 8>(x, nxt);
+            split_units<s + 1, to * 4 * C / 8, (to + 1) * 4 * C / 8>(x, nxt, zk.xs);
           });
           gemm_f16_panel<M_RT_V, s, C, kRdWaves, false, B_RTB2>(ws, b, vt, wrap);
           cur = nxt;
@@ -335,7 +337,7 @@ __global__ void __launch_bounds__(kRdBlock, 2) ray_dgrad_kernel(const float* __r
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const bool slot_ok = head11_slot(4 * g + r) >= 0;
-        Kp[r] = slot_ok ? elu1_acc(kt[0][h][r]) : 0.f;
+        Kp[r] = slot_ok ? elu1_acc(kt[0][h][r], zk.dsc, k_l2e) : 0.f;
         const float vs = pow2_len ? vt[0][h][r] * inv_len : vt[0][h][r] / f_len;
         Vx[r] = slot_ok ? vs : ((g == 0 && r == 3) ? 1.f : 0.f);              // ones column (slot 3) <-> the K' sum
       }
@@ -358,8 +360,8 @@ __global__ void __launch_bounds__(kRdBlock, 2) ray_dgrad_kernel(const float* __r
     f32x4 dx[C][6];
 #pragma unroll
     for (int t = 0; t < 6; ++t) dx[0][t] = splat4(0.f);
-    gemm_f16<M_RT_KT, C, kRdWaves, false, true>(ws, dk, dx, wrap);
-    gemm_f16<M_RT_VT, C, kRdWaves, false, true>(ws, dv, dx, wrap);
+    gemm_f16<M_RT_KT, C, kRdWaves>(ws, dk, dx, wrap);
+    gemm_f16<M_RT_VT, C, kRdWaves>(ws, dv, dx, wrap);
     // ---------------- d token0 rows: features 0..79 of d x (the order code has no consumer)
     if (live) {
       const size_t slot = (size_t)ray * SN + 16 * it + j;

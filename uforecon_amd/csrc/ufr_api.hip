@@ -167,9 +167,9 @@ int status_slot(StatusSlot** out) {
 
 int status_message(int bits, const char* who) {
   return fail(UFR_ERR_RANGE, "%s: range status 0x%x:%s%s%s (include/ufr.h: ufr_status_poll)", who, bits,
-              (bits & 1) ? " a dense-layer input reached |x| >= 4094 (fp16 planes overflowed);" : "",
+              (bits & 1) ? " a dense-layer input left the range of its fp16 planes (a token feature beyond the input_abs_max the weights were packed for -- ufr_weights_pack_for -- or infinite);" : "",
               (bits & 2) ? " NaN among the token / dir inputs handed to a transformer kernel;" : "",
-              (bits & 4) ? " ufr_weights_pack met a weight that is not finite or |w| >= 255.8;" : "");
+              (bits & 4) ? " ufr_weights_pack met a parameter that is not finite (or an input bound that is not a positive finite number);" : "");
 }
 
 // what the last delivered copy says about the CURRENT generation, restricted to `mask`; reported bits are cleared on the
@@ -234,6 +234,8 @@ size_t ufr_packed_weights_bytes(void) { return (size_t)blob_floats() * sizeof(fl
 size_t ufr_packed_bwd_halfwords(void) { return (size_t)kBwdHalfwords; }
 size_t ufr_packed_fp32_floats(void) { return (size_t)blob_floats(); }
 size_t ufr_packed_f16_halfwords(void) { return (size_t)kF16Halfwords; }
+size_t ufr_packed_scale_table_offset(void) { return (size_t)scale_table_offset(); }
+int ufr_packed_scale_table_entries(void) { return M_COUNT; }
 
 int ufr_pack_plan_f16(int32_t* param_id, int32_t* elem, int32_t* plane) {
   UFR_REQUIRE(param_id && elem && plane, "ufr_pack_plan_f16: null output");
@@ -258,20 +260,27 @@ int ufr_pack_plan(int32_t* param_id, int32_t* elem) {
   return UFR_OK;
 }
 
-int ufr_weights_pack(const ufr_raw_weights* raw, void* packed, ufr_stream stream) {
+int ufr_weights_pack_for(const ufr_raw_weights* raw, void* packed, float input_abs_max, ufr_stream stream) {
   UFR_REQUIRE(raw && packed, "ufr_weights_pack: null argument");
   static_assert(sizeof(ufr_raw_weights) == sizeof(RawPtrs), "ufr_raw_weights must be P_COUNT pointers");
   RawPtrs rp;
   memcpy(&rp, raw, sizeof(rp));
   for (int i = 0; i < P_COUNT; ++i) UFR_REQUIRE(rp.p[i], "ufr_weights_pack: parameter %d is null", i);
+  UFR_REQUIRE(input_abs_max > 0.f && input_abs_max <= 3.0e38f, "ufr_weights_pack_for: input_abs_max=%g must be positive and finite",
+              (double)input_abs_max);
   hipStream_t s = static_cast<hipStream_t>(stream);
   StatusSlot* sl = nullptr;
   int rc = status_slot(&sl);
   if (rc != UFR_OK) return rc;
-  // the fp16 planes hold 2^8 w: a weight beyond +-255.8 (or a non-finite one) cannot be represented -- the pack kernel
-  // raises bit 2 of the sticky status (no synchronisation here: training re-packs after every optimizer step)
-  UFR_HIP(launch_pack_weights(rp, static_cast<float*>(packed), sl->dev, s));
+  // every exponent of the planes is chosen on the device from the parameters themselves (prep.hip: weight_scale_kernel):
+  // any finite weight fits; a non-finite one raises bit 2 of the sticky status (no synchronisation here: training re-packs
+  // after every optimizer step)
+  UFR_HIP(launch_pack_weights(rp, static_cast<float*>(packed), input_abs_max, sl->dev, s));
   return status_leave(sl, s);
+}
+
+int ufr_weights_pack(const ufr_raw_weights* raw, void* packed, ufr_stream stream) {
+  return ufr_weights_pack_for(raw, packed, kDefaultInputAbsMax, stream);
 }
 
 // ------------------------------------------------------------------ frame

@@ -119,7 +119,7 @@ struct FmtWeights {  // = ufr_fmt_layer_weights
 int fmt_state_parts(int S);   // per-wave partial states of one sample's source tokens
 hipError_t launch_fmt_layer(const FmtWeights& w, const float* x, const float* src, int N, int T, int S, float* out,
                             float* state, hipStream_t s);
-hipError_t launch_pack_weights(const RawPtrs& raw, float* packed, int* range_flag, hipStream_t s);
+hipError_t launch_pack_weights(const RawPtrs& raw, float* packed, float input_abs_max, int* range_flag, hipStream_t s);
 hipError_t launch_tsdf_integrate(float* tsdf, float* weight, float* color, const int* dim, const float* origin,
                                  float voxel_size, float trunc_margin, const float* K, const float* P,
                                  const float* depth_im, const float* color_im, int im_h, int im_w, float obs_weight,

@@ -248,8 +248,15 @@ __host__ __device__ constexpr int vec_offset(int v) {
   for (int i = 0; i < v; ++i) o += vec_floats(i);
   return o;
 }
-__host__ __device__ constexpr int vec_region_floats() { return vec_offset(V_COUNT) - vec_region_offset(); }
-__host__ __device__ constexpr int blob_floats() { return vec_offset(V_COUNT); }
+// The SCALE TABLE closes the vector region (so it reaches LDS with it): one float4 per forward matrix M,
+//   {xs, dsc, asc, ws} = {2^a_M, 2^-(s_M + a_M), 2^(s_M + a_M), 2^s_M}
+// s_M: exponent the fp16 planes of W_M carry (from max |w|), a_M: exponent the planes of the layer's INPUT carry (from an
+// analytic bound of the input's magnitude) -- both chosen by ufr_weights_pack (prep.hip: weight_scale_kernel), read by the
+// kernels at run time (weight_stream_f16.h: mat_scale).  Not a function of the parameters alone: plan_entry maps it to zero.
+constexpr int kScaleFloats = M_COUNT * 4;
+__host__ __device__ constexpr int scale_table_offset() { return vec_offset(V_COUNT); }
+__host__ __device__ constexpr int vec_region_floats() { return scale_table_offset() + kScaleFloats - vec_region_offset(); }
+__host__ __device__ constexpr int blob_floats() { return scale_table_offset() + kScaleFloats; }
 __host__ __device__ constexpr int mat_offset(int m) {  // first float of matrix m inside the blob
   return stream_base_floats(mat_stream(m)) + stream_mat_start(mat_stream(m), mat_stream_index(m)) * 256;
 }

@@ -9,10 +9,12 @@
 // so hi + lo carries 22 significand bits and a sign trick's worth more (|x - hi - lo| <= 2^-23 |x|), and a
 // product is three plane pairs accumulated in fp32 by the MFMA:
 //     w*x ~= w_lo*x_hi + w_hi*x_lo + w_hi*x_hi        (dropped: w_lo*x_lo <= 2^-22 |w||x|)
-// fp16's narrow exponent is handled with power-of-two scales (below): the planes hold 2^8 w and 2^4 x, which
-// keeps the lo planes of ordinary weights and activations in the normal range (the MFMA honours fp16
-// subnormals -- tools/dev/f16_probe.hip -- so smaller values lose precision gradually, with an absolute
-// floor of 2^-29 per activation); the accumulator is descaled exactly by 2^-12.
+// fp16's narrow exponent is handled with power-of-two scales (below): the planes hold 2^s_M w and 2^a_M x, exponents chosen
+// per MATRIX when the weights are packed -- s_M from max |w_M|, a_M from an analytic bound of the layer's input -- which
+// keeps the lo planes of weights and activations in the normal range (the MFMA honours fp16 subnormals --
+// tools/dev/f16_probe.hip -- so values far below the bound lose precision gradually, with an absolute floor of
+// 2^-25-a_M per activation); the accumulator carries 2^(s_M + a_M) and is descaled exactly where its consumer
+// multiplies anyway.
 // Measured (tests/accuracy_report.py, K = 80..176 layers of both chains against the fp32 oracle): the same
 // 4e-7 as the three-plane bf16 scheme ("bf16x6": six products) this replaces, at half the matrix
 // instructions, two thirds of the LDS weight traffic and 4 instead of 9 VALU instructions per split pair.
@@ -36,16 +38,16 @@
 namespace ufr {
 
 constexpr int kPlanes = 2;
-// fp16 planes carry power-of-two scales so that the low planes stay clear of the fp16 subnormal range:
-// weights are packed as 2^kWScaleLog2 w (|w| < 255.8, checked at pack time), activations are split as 2^kXScaleLog2 x
-// (|x| < 4094); a layer's accumulator is therefore 2^(kWScaleLog2 + kXScaleLog2) times the true value and is
-// descaled once, exactly, after its last k-step.
-#ifndef UFR_X_SCALE_LOG2
-#define UFR_X_SCALE_LOG2 4
-#endif
-constexpr int kWScaleLog2 = 8, kXScaleLog2 = UFR_X_SCALE_LOG2;
-constexpr float kWScale = (float)(1 << kWScaleLog2), kXScale = (float)(1 << kXScaleLog2);
-constexpr float kAccScale = kWScale * kXScale, kAccDescale = 1.f / kAccScale;
+// fp16 planes carry power-of-two scales so that the low planes stay clear of the fp16 subnormal range.  The exponents are
+// DATA, not constants (ufr_layout.h: the scale table at the end of the vector region):
+//   s_M  weights of matrix M are packed as 2^s_M w with 2^s_M max|w_M| in [2^14, 2^15): any finite weight fits
+//   a_M  the layer's input is split as 2^a_M x with 2^a_M B_M <= 2^15, B_M an upper bound of |x| derived at pack time from
+//        the bound of the token inputs the caller states (ufr_weights_pack_for; default kDefaultInputAbsMax), the
+//        matrices' infinity norms, the LayerNorm gains and the biases (prep.hip: weight_scale_kernel)
+// A layer's accumulator is 2^(s_M + a_M) times the true value.  kScaleExp*: the clamps of the exponents -- with them
+// every accumulator stays below 2^15 2^15 K < 2^38 and every table entry is a normal fp32 number.
+constexpr int kScaleExpWMin = -40, kScaleExpWMax = 24, kScaleExpXMin = -40, kScaleExpXMax = 12;
+constexpr float kDefaultInputAbsMax = 256.f;
 #ifndef UFR_F16_CHUNK
 #define UFR_F16_CHUNK 12
 #endif
@@ -194,19 +196,21 @@ __host__ __device__ constexpr int f16_col(int m, int s, int g, int i) {
 
 // source of halfword h of the plane regions (h < kF16Halfwords: fp16 forward streams; beyond: the bf16 backward streams):
 // parameter, element, plane (param -1 = zero)
-__host__ __device__ inline void plan_entry_f16(int h, int* param, int* elem, int* plane, int* is_bf16 = nullptr) {
+__host__ __device__ inline void plan_entry_f16(int h, int* param, int* elem, int* plane, int* is_bf16 = nullptr, int* mat = nullptr) {
   *param = -1; *elem = 0; *plane = 0;
   int f = h >> 9;                 // fragment
   const int lane = (h >> 3) & 63, i = h & 7;
   int S = 0;
   while (S + 1 < B_ALL && f >= f16_stream_base_frags(S + 1)) ++S;
   if (is_bf16) *is_bf16 = 0;
+  if (mat) *mat = -1;
   f -= f16_stream_base_frags(S);
   if (f >= f16_stream_frags(S)) return;  // tail padding of the stream's last chunk
   int pi = 0;
   while (f >= f16_panel_frags(S, pi)) { f -= f16_panel_frags(S, pi); ++pi; }
   const Panel p = f16_panel(S, pi);
   if (is_bf16) *is_bf16 = f16_mat_is_bf16(p.mat) ? 1 : 0;
+  if (mat) *mat = p.mat;
   const MatDesc d = mat_desc(p.mat);
   const int to = f / kPlanes;
   *plane = f % kPlanes;

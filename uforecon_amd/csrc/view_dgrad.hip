@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
       dy_st(DV_H2, c, dh2[c][0]);
       dh1[c][0] = splat4(0.f);
     }
-    gemm_f16<M_RW2T, C, kVdWaves, false, true>(ws, dh2, dh1, wrap);
+    gemm_f16<M_RW2T, C, kVdWaves>(ws, dh2, dh1, wrap);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const f32x4 h1 = tape_ld(TV_H1, c);
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
 #pragma unroll
       for (int t = 0; t < 5; ++t) dy[c][t] = splat4(0.f);
     }
-    gemm_f16<M_RW0T, C, kVdWaves, false, true>(ws, dh1, dy, wrap);
+    gemm_f16<M_RW0T, C, kVdWaves>(ws, dh1, dy, wrap);
     // + d token0 from the ray transformer's backward (view-token columns only)
 #pragma unroll
     for (int c = 0; c < C; ++c)
@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int t = 0; t < 10; ++t) dhid[c][t] = splat4(0.f);
-    gemm_f16<M_VT_MLP2T, C, kVdWaves, false, true>(ws, dopre, dhid, wrap);
+    gemm_f16<M_VT_MLP2T, C, kVdWaves>(ws, dopre, dhid, wrap);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int t = 0; t < 10; ++t) dcat[c][t] = splat4(0.f);
-    gemm_f16<M_VT_MLP0T, C, kVdWaves, false, true>(ws, dhid, dcat, wrap);
+    gemm_f16<M_VT_MLP0T, C, kVdWaves>(ws, dhid, dcat, wrap);
     // the x half of d cat joins d y in the scratch tiles (the attention phase below needs the registers; this lane wrote the
     // tile itself, so the load is ordered behind its store), the message half goes on
     f32x4 dmpre[C][5];
@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int t = 0; t < 5; ++t) dmsg[c][t] = splat4(0.f);
-    gemm_f16<M_VT_MERGET, C, kVdWaves, false, true>(ws, dmpre, dmsg, wrap);
+    gemm_f16<M_VT_MERGET, C, kVdWaves>(ws, dmpre, dmsg, wrap);
 
     // ---------------- linear attention backwards (linear_attention.py:31-45), score form, lane-local per (token, head):
     //   A[s][s'] = Q'_s . K'_s';  den_s = sum_s' A;  Zs = L / (den + eps);  msg_s = Zs sum_s' A[s][s'] V_s'
@@ -394,9 +394,9 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int t = 0; t < 5; ++t) dx[c][t] = splat4(0.f);
-    gemm_f16<M_VT_QT, C, kVdWaves, false, true>(ws, dq, dx, wrap);
-    gemm_f16<M_VT_KT, C, kVdWaves, false, true>(ws, dk, dx, wrap);
-    gemm_f16<M_VT_VT, C, kVdWaves, false, true>(ws, dv, dx, wrap);
+    gemm_f16<M_VT_QT, C, kVdWaves>(ws, dq, dx, wrap);
+    gemm_f16<M_VT_KT, C, kVdWaves>(ws, dk, dx, wrap);
+    gemm_f16<M_VT_VT, C, kVdWaves>(ws, dv, dx, wrap);
 
     // ---------------- outputs: d x = d y (residual) + d cat[0..79] + the projections.  Token columns 32..55 (frustum
     // features) and 56..71 (pre_sim_mlp) are the same for all NV view tokens of a point (ray_transformer.py:258-281):

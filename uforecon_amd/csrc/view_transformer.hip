@@ -35,14 +35,15 @@ __device__ __forceinline__ void zero_tiles(f32x4 (&t)[C][N]) {
     for (int i = 0; i < N; ++i) t[c][i] = splat4(0.f);
 }
 
-// LayerNorm over the 80 features of each token: 5 tiles x 4 regs in each of the 4 lane groups.  ACC: t holds raw
-// accumulators (2^kAccLog2 times the values): the normalised value is scale-free once the epsilon carries the square of
-// the scale, and with a power-of-two scale every intermediate is the exact multiple -- bit-identical to descaling first.
-// XH / RS (TAPE builds): the normalised input and 1 / sigma of the TRUE values (raw accumulators: kAccScale times the
-// raw one), which the backward needs.
-template <int C, int VW, int VB, bool ACC = false, class WS>
-__device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const WS& ws, int g, f32x4 (*XH)[5] = nullptr, float* RS = nullptr) {
-  constexpr float eps = ACC ? 1e-5f * kAccScale * kAccScale : 1e-5f;
+// LayerNorm over the 80 features of each token: 5 tiles x 4 regs in each of the 4 lane groups.  t holds raw accumulators
+// (asc = 2^(s_M + a_M) times the values; asc = 1: plain values): the normalised value is scale-free once the epsilon carries
+// the square of the scale, and with a power-of-two scale every intermediate is the exact multiple -- bit-identical to
+// descaling first.
+// XH / RS (TAPE builds): the normalised input and 1 / sigma of the TRUE values (asc times the raw one), which the
+// backward needs.
+template <int C, int VW, int VB, class WS>
+__device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const WS& ws, int g, float asc, f32x4 (*XH)[5] = nullptr, float* RS = nullptr) {
+  const float eps = 1e-5f * asc * asc;
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     float s = 0.f;
@@ -58,7 +59,7 @@ __device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const WS& ws, int
         q = fmaf(d, d, q);
       }
     const float rstd = 1.f / sqrtf(sum_groups(q) * (1.f / 80.f) + eps);
-    if (RS) RS[c] = ACC ? rstd * kAccScale : rstd;
+    if (RS) RS[c] = rstd * asc;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const f32x4 gw = vec_frag<VW>(ws, i, g), gb = vec_frag<VB>(ws, i, g);
@@ -118,6 +119,16 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
   auto ws = wstream_f16_begin<kVtWaves, LOWP>(packed, smem);
   wstream_f16_prime<B_VT, kVtWaves>(ws);
   const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+  // the layers' plane / accumulator scales (ufr_layout.h: scale table), wave-uniform for the whole launch.  q, k, v and
+  // mlp0 all split x: their a_M agree by construction (prep.hip), and the splits use ONE multiplier (xs_x) so that the
+  // compiler can merge them (41 of 171 value pairs per iteration).
+  const MatScale zq = mat_scale<M_VT_Q>(ws), zk = mat_scale<M_VT_K>(ws), zv = mat_scale<M_VT_V>(ws), zm = mat_scale<M_VT_MERGE>(ws);
+  const MatScale z0 = mat_scale<M_VT_MLP0>(ws), z2 = mat_scale<M_VT_MLP2>(ws);
+  const MatScale zr0 = mat_scale<M_RW0>(ws), zr2 = mat_scale<M_RW2>(ws), zr4 = mat_scale<M_RW4>(ws);
+  const float xs_x = zq.xs;
+  const float q_l2e = zq.dsc * kLog2e, k_l2e = zk.dsc * kLog2e;
+  const float v_mul = zv.dsc / (float)L;              // values / v_length on raw accumulators: exact when L is a power of two
+  const float v_div = (float)L * zv.asc;              // ... a true division otherwise (L = 6)
   // column (c, j) holds token tvv[c] of the wave's point ptw[c] (tvv == 0: view token)
   int ptw[C], tvv[C];
   bool okc[C];
@@ -254,7 +265,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     zero_tiles(q); zero_tiles(k);
     {
       BWords<C> cur;
-      split_units<0, 0, 4 * C>(x, cur);
+      split_units<0, 0, 4 * C>(x, cur, xs_x);
       static_for<3>([&](auto si) __attribute__((always_inline)) {
         constexpr int s = decltype(si)::value;
         BStep b[C];
@@ -263,7 +274,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
           BWords<C> nxt;
           gemm_f16_panel<M_VT_Q, s, C, kVtWaves, false>(ws, b, q, wrap, [&](auto ti) __attribute__((always_inline)) {
             constexpr int to = decltype(ti)::value;
-            split_units<s + 1, to * 4 * C / 5, (to + 1) * 4 * C / 5>(x, nxt);
+            split_units<s + 1, to * 4 * C / 5, (to + 1) * 4 * C / 5>(x, nxt, xs_x);
           });
           gemm_f16_panel<M_VT_K, s, C, kVtWaves>(ws, b, k, wrap);
           cur = nxt;
@@ -272,7 +283,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
           gemm_f16_panel<M_VT_K, s, C, kVtWaves>(ws, b, k, wrap);
         }
       });
-      probe_gemm(q, ws);   // q, k stay raw accumulators: elu1_acc
+      probe_gemm(q, ws);   // q, k stay raw accumulators: elu1_acc descales
       probe_gemm(k, ws);
     }
     if constexpr (TAPE) {
@@ -280,8 +291,8 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
       for (int c = 0; c < C; ++c)
 #pragma unroll
         for (int t = 0; t < 5; ++t) {
-          tape_st(TV_Q + t, c, f32x4{elu1_acc(q[c][t][0]), elu1_acc(q[c][t][1]), elu1_acc(q[c][t][2]), elu1_acc(q[c][t][3])});
-          tape_st(TV_K + t, c, f32x4{elu1_acc(k[c][t][0]), elu1_acc(k[c][t][1]), elu1_acc(k[c][t][2]), elu1_acc(k[c][t][3])});
+          tape_st(TV_Q + t, c, f32x4{elu1_acc(q[c][t][0], zq.dsc, q_l2e), elu1_acc(q[c][t][1], zq.dsc, q_l2e), elu1_acc(q[c][t][2], zq.dsc, q_l2e), elu1_acc(q[c][t][3], zq.dsc, q_l2e)});
+          tape_st(TV_K + t, c, f32x4{elu1_acc(k[c][t][0], zk.dsc, k_l2e), elu1_acc(k[c][t][1], zk.dsc, k_l2e), elu1_acc(k[c][t][2], zk.dsc, k_l2e), elu1_acc(k[c][t][3], zk.dsc, k_l2e)});
         }
     }
     UFR_PHASE(1)  // q,k GEMMs
@@ -299,8 +310,8 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
           for (int d = 0; d < 10; ++d) {
             const int s = 10 * hh + d;
-            Q[c][d] = elu1_acc(q[c][s >> 2][s & 3]);
-            K[c][d] = elu1_acc(k[c][s >> 2][s & 3]);
+            Q[c][d] = elu1_acc(q[c][s >> 2][s & 3], zq.dsc, q_l2e);
+            K[c][d] = elu1_acc(k[c][s >> 2][s & 3], zk.dsc, k_l2e);
           }
           float a = 0.f;
 #pragma unroll
@@ -331,8 +342,8 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
         for (int d = 0; d < 10; ++d) {
           const int s = 10 * hh + d;
-          Q[d] = elu1_acc(q[c][s >> 2][s & 3]);
-          K[d] = elu1_acc(k[c][s >> 2][s & 3]);
+          Q[d] = elu1_acc(q[c][s >> 2][s & 3], zq.dsc, q_l2e);
+          K[d] = elu1_acc(k[c][s >> 2][s & 3], zk.dsc, k_l2e);
         }
         float den = 0.f;
 #define UFR_ATT_STEP(S)                                                  \
@@ -356,7 +367,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     UFR_PHASE(2)  // scores
     f32x4 v[C][5];
     zero_tiles(v);
-    gemm_f16<M_VT_V, C, kVtWaves, false, true>(ws, x, v, wrap);   // raw accumulators: the descale joins the 1 / v_length
+    gemm_f16<M_VT_V, C, kVtWaves>(ws, x, v, wrap, xs_x);   // raw accumulators: the descale joins the 1 / v_length
     UFR_PHASE(3)  // v GEMM
     if constexpr (TAPE) {   // values / v_length, exactly as the message phase below forms them
 #pragma unroll
@@ -366,7 +377,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
           f32x4 vv;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            vv[r] = (L & (L - 1)) == 0 ? v[c][t][r] * (kAccDescale / (float)L) : v[c][t][r] / ((float)L * kAccScale);
+            vv[r] = (L & (L - 1)) == 0 ? v[c][t][r] * v_mul : v[c][t][r] / v_div;
           tape_st(TV_V + t, c, vv);
         }
     }
@@ -380,7 +391,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
           for (int d = 0; d < 10; ++d) {
             const int s = 10 * hh + d;
-            V[c][d] = v[c][s >> 2][s & 3] / ((float)L * kAccScale);   // values / v_length (L = 6: a true division)
+            V[c][d] = v[c][s >> 2][s & 3] / v_div;   // values / v_length (L = 6: a true division)
             acc[c][d] = A[c][hh][0] * V[c][d];
           }
         static_for<5>([&](auto sti) __attribute__((always_inline)) {
@@ -409,7 +420,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
         for (int d = 0; d < 10; ++d) {
           const int s = 10 * hh + d;
           // values / v_length: exact as a multiply when L is a power of two (NV = 3, 7)
-          V[d] = (L & (L - 1)) == 0 ? v[c][s >> 2][s & 3] * (kAccDescale / (float)L) : v[c][s >> 2][s & 3] / ((float)L * kAccScale);
+          V[d] = (L & (L - 1)) == 0 ? v[c][s >> 2][s & 3] * v_mul : v[c][s >> 2][s & 3] / v_div;
           acc[d] = 0.f;
         }
 #define UFR_ATT_STEP(S)                                                  \
@@ -442,18 +453,18 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     // ---------------- merge + LayerNorm1 (transformer.py:51-52)
     f32x4 m[C][5];
     zero_tiles(m);
-    gemm_f16<M_VT_MERGE, C, kVtWaves, false, true>(ws, msg, m, wrap);
+    gemm_f16<M_VT_MERGE, C, kVtWaves>(ws, msg, m, wrap, zm.xs);
     UFR_PHASE(5)  // merge GEMM
     float rstd1[C] = {}, rstd2[C] = {};
     if constexpr (TAPE) {
       f32x4 xh[C][5];
-      layer_norm80<C, V_VT_N1W, V_VT_N1B, true>(m, ws, g, xh, rstd1);
+      layer_norm80<C, V_VT_N1W, V_VT_N1B>(m, ws, g, zm.asc, xh, rstd1);
 #pragma unroll
       for (int c = 0; c < C; ++c)
 #pragma unroll
         for (int t = 0; t < 5; ++t) { tape_st(TV_XH1 + t, c, xh[c][t]); tape_st(TV_M + t, c, m[c][t]); }
     } else {
-      layer_norm80<C, V_VT_N1W, V_VT_N1B, true>(m, ws, g);
+      layer_norm80<C, V_VT_N1W, V_VT_N1B>(m, ws, g, zm.asc);
     }
 
     UFR_PHASE(6)  // LN1
@@ -464,7 +475,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
       for (int t = 0; t < 5; ++t) { cat[c][t] = x[c][t]; cat[c][5 + t] = m[c][t]; }
     zero_tiles(hid);
-    gemm_f16<M_VT_MLP0, C, kVtWaves, false, true>(ws, cat, hid, wrap);   // hid: raw accumulators through the ReLU
+    gemm_f16<M_VT_MLP0, C, kVtWaves>(ws, cat, hid, wrap, xs_x);   // hid: raw accumulators through the ReLU
     UFR_PHASE(7)  // MLP0
 #pragma unroll
     for (int c = 0; c < C; ++c)
@@ -476,10 +487,10 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
       for (int c = 0; c < C; ++c)
 #pragma unroll
-        for (int t = 0; t < 10; ++t) tape_st(TV_HID + t, c, hid[c][t] * kAccDescale);
+        for (int t = 0; t < 10; ++t) tape_st(TV_HID + t, c, hid[c][t] * z0.dsc);
     }
     zero_tiles(o);
-    gemm_f16<M_VT_MLP2, C, kVtWaves, true, true>(ws, hid, o, wrap);
+    gemm_f16<M_VT_MLP2, C, kVtWaves>(ws, hid, o, wrap, z2.xs * z0.dsc);
     // colour / mask / direction of this lane's (point, view): (issued here: hid is dead, so the 10 registers are free, and LayerNorm2 + the token stores cover the latency)
     f32x4 col[C];
     float dcomp[C];
@@ -497,13 +508,13 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     UFR_PHASE(8)  // relu + MLP2
     if constexpr (TAPE) {
       f32x4 xh[C][5];
-      layer_norm80<C, V_VT_N2W, V_VT_N2B, true>(o, ws, g, xh, rstd2);
+      layer_norm80<C, V_VT_N2W, V_VT_N2B>(o, ws, g, z2.asc, xh, rstd2);
 #pragma unroll
       for (int c = 0; c < C; ++c)
 #pragma unroll
         for (int t = 0; t < 5; ++t) tape_st(TV_XH2 + t, c, xh[c][t]);
     } else {
-      layer_norm80<C, V_VT_N2W, V_VT_N2B, true>(o, ws, g);
+      layer_norm80<C, V_VT_N2W, V_VT_N2B>(o, ws, g, z2.asc);
     }
 #pragma unroll
     for (int c = 0; c < C; ++c)
@@ -542,28 +553,28 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
       for (int t = 0; t < 5; ++t) rin[c][t] = o[c][t];
       rin[c][5] = f32x4{dcomp[c], 0.f, 0.f, 0.f};
       ws.bad_out |= __builtin_amdgcn_ballot_w64(dcomp[c] != dcomp[c]);
-      h1[c][0] = vec_frag<V_RW_B0>(ws, 0, g) * kAccScale;   // biases enter the scaled accumulators (weight_stream_f16.h)
-      h2[c][0] = vec_frag<V_RW_B2>(ws, 0, g) * kAccScale;
-      lg[c][0] = vec_frag<V_RW_B4>(ws, 0, g) * kAccScale;
+      h1[c][0] = vec_frag<V_RW_B0>(ws, 0, g) * zr0.asc;   // biases enter the scaled accumulators (weight_stream_f16.h)
+      h2[c][0] = vec_frag<V_RW_B2>(ws, 0, g) * zr2.asc;
+      lg[c][0] = vec_frag<V_RW_B4>(ws, 0, g) * zr4.asc;
     }
-    gemm_f16<M_RW0, C, kVtWaves, false, true>(ws, rin, h1, wrap);
+    gemm_f16<M_RW0, C, kVtWaves>(ws, rin, h1, wrap, zr0.xs);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) h1[c][0][r] = fmaxf(h1[c][0][r], 0.f);
-    gemm_f16<M_RW2, C, kVtWaves, true, true>(ws, h1, h2, wrap);
+    gemm_f16<M_RW2, C, kVtWaves>(ws, h1, h2, wrap, zr2.xs * zr0.dsc);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) h2[c][0][r] = fmaxf(h2[c][0][r], 0.f);
-    gemm_f16<M_RW4, C, kVtWaves, true, true>(ws, h2, lg, wrap);
+    gemm_f16<M_RW4, C, kVtWaves>(ws, h2, lg, wrap, zr4.xs * zr2.dsc);
     if constexpr (TAPE) {
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        tape_st(TV_H1, c, h1[c][0] * kAccDescale);
-        tape_st(TV_H2, c, h2[c][0] * kAccDescale);
+        tape_st(TV_H1, c, h1[c][0] * zr0.dsc);
+        tape_st(TV_H2, c, h2[c][0] * zr2.dsc);
         // the logit of column j sits in lane group 0, register 0: every lane group records it
-        tape_st(TV_MISC, c, f32x4{rstd1[c], rstd2[c], __shfl(lg[c][0][0], j) * kAccDescale, 0.f});
+        tape_st(TV_MISC, c, f32x4{rstd1[c], rstd2[c], __shfl(lg[c][0][0], j) * zr4.dsc, 0.f});
       }
     }
 
@@ -574,7 +585,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
       float logit[C], mx[C], e[C], den[C], cr[C], cg[C], cb[C];
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        logit[c] = lg[c][0][0] * kAccDescale;
+        logit[c] = lg[c][0][0] * zr4.dsc;
         if (col[c][3] == 0.f) logit[c] = -1e9f;
         if (tvv[c] == 0) logit[c] = -INFINITY;  // the view token is not a colour source
         mx[c] = logit[c];
@@ -612,7 +623,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const int tv = tvv[c];
-      float logit = lg[c][0][0] * kAccDescale;
+      float logit = lg[c][0][0] * zr4.dsc;
       if (col[c][3] == 0.f) logit = -1e9f;
       if (tv == 0) logit = -INFINITY;  // the view token is not a colour source
       float mx = logit;

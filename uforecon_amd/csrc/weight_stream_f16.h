@@ -16,28 +16,19 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kF16RingBytes = kF16Slots * kF16ChunkFrags * 1024;  // the ring: kF16Slots (3) slots of kF16ChunkFrags (12) KiB
 constexpr int kF16LdsBytes = kF16RingBytes + kVecBytes;
 
-// split of a value pair into fp16 planes of 2^kXScaleLog2 x: hi = fp16(x) 2^k (exact scaling; one v_cvt_pk_f16_f32 and one
-// v_pk_mul_f16), lo = fp16(2^k x - hi) (the difference is exact in fp32; one v_fma_mix per value): 4 VALU instructions.
-// The planes hold |x| < kActLimit only: beyond it hi overflows to inf, lo to -inf, and EVERY output of the layer for that
-// token is NaN (the products w_hi hi and w_hi lo are infinities of opposite sign, or 0 x inf) -- probe_gemm.
-constexpr float kActLimit = 4094.f;
+// Split of a value pair into the fp16 planes of m x, m a power of two from the scale table (mat_scale): hi = fp16(m x),
+// lo = fp16(m x - hi) -- four v_fma_mix{lo,hi}_f16 (the scaling rides on the conversion's multiplier; m x - hi is exact in
+// fp32).  For a layer's VALUES m = 2^a_M; for a producer's RAW accumulators (2^(s_P + a_P) times the value) m = 2^a_M 2^-(s_P
+// + a_P): the exact descale costs nothing.  (hipcc builds the same arithmetic from C source with 5..7 instructions: it
+// converts the second value twice rather than read a register's upper half.)
+// The planes hold m |x| < 65504 only: beyond it hi overflows to inf, lo to -inf, and EVERY output of the layer for that
+// token is NaN (the products w_hi hi and w_hi lo are infinities of opposite sign, or 0 x inf) -- probe_gemm.  a_M comes
+// from an upper bound of the layer's input (prep.hip: weight_scale_kernel), so this happens only when the caller's
+// stated input bound (ufr_weights_pack_for) was wrong.
 #ifndef UFR_RANGE_MODE
 #define UFR_RANGE_MODE 1   // 0: no range tracking (timing ablation)
 #endif
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& l) {
-  f16x2 hh = __builtin_convertvector(f32x2{a, b}, f16x2);
-  if constexpr (kXScaleLog2 != 0) hh *= f16x2{(_Float16)kXScale, (_Float16)kXScale};
-  const f16x2 ll = {(_Float16)__builtin_fmaf(a, kXScale, -(float)hh[0]), (_Float16)__builtin_fmaf(b, kXScale, -(float)hh[1])};
-  h = __builtin_bit_cast(unsigned, hh);
-  l = __builtin_bit_cast(unsigned, ll);
-}
-
-// The same planes straight from a layer's RAW accumulators (2^(kWScaleLog2 + kXScaleLog2) times the value): the exact
-// descale rides on the multiplier of the conversion, hi = fp16(2^-kWScaleLog2 acc), lo = fp16(2^-kWScaleLog2 acc - hi)
-// -- four v_fma_mix{lo,hi}_f16, no descale multiply and no plane scaling.  (hipcc builds the same arithmetic from C
-// source with 5..7 instructions: it converts the second value twice rather than read a register's upper half.)
-__device__ __forceinline__ void split_pair_acc(float a, float b, unsigned& h, unsigned& l) {
-  constexpr float m = kXScale * kAccDescale;
+__device__ __forceinline__ void split_pair(float a, float b, float m, unsigned& h, unsigned& l) {
   asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a), "s"(m));
   asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(b), "s"(m));
   asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a), "s"(m), "v"(h));
@@ -192,7 +183,7 @@ __device__ __forceinline__ void wstream_f16_prime(const WS& ws) {
   static_for<kF16Slots - 1>([&](auto ci) __attribute__((always_inline)) { wstream_f16_fetch<S, NWAVES, decltype(ci)::value>(ws); });
 }
 
-// Range tracking of the dense-layer inputs.  An input beyond kActLimit (or infinite) makes every accumulator of its token
+// Range tracking of the dense-layer inputs.  An input beyond the planes' range (or infinite) makes every accumulator of its token
 // column non-finite (split_pair), so one accumulator element per column and GEMM is classified (one v_cmp_class per column
 // tile) right after the last k-step -- before a ReLU, whose v_max_f32 returns the other operand for a NaN -- and the
 // wave's verdict is OR-ed into a SCALAR sticky mask: the transformer kernels sit at their 256-register budget, a vector
@@ -224,7 +215,7 @@ __device__ __forceinline__ void track_external(const f32x4 (&t)[C][N], WS& ws) {
 }
 
 // end of a kernel: raise the sticky range status (bit 0: a dense layer produced non-finite accumulators, i.e. one of its
-// inputs reached kActLimit; bit 1: NaN among the kernel's inputs -- which also raises bit 0).  One atomic per offending wave.
+// inputs left the planes' range; bit 1: NaN among the kernel's inputs -- which also raises bit 0).  One atomic per offending wave.
 template <class WS>
 __device__ __forceinline__ void wstream_report_range(const WS& ws, int* __restrict__ status) {
   const int bits = (ws.bad_in ? 1 : 0) | (ws.bad_out ? 2 : 0);
@@ -235,6 +226,23 @@ template <int V, class WS>
 __device__ __forceinline__ f32x4 vec_frag(const WS& ws, int t, int g) {
   constexpr int base = (vec_offset(V) - vec_region_offset()) / 4;
   return ws.vecs[base + t * 4 + g];
+}
+
+// scale table entry of forward matrix M (ufr_layout.h: scale_table_offset), as wave-uniform scalars
+struct MatScale {
+  float xs;    // 2^a_M: multiplier of the layer's input values when they are split into planes
+  float dsc;   // 2^-(s_M + a_M): raw accumulator -> value
+  float asc;   // 2^(s_M + a_M): value -> raw accumulator (biases, epsilons)
+};
+__device__ __forceinline__ float uniform_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+template <int M, class WS>
+__device__ __forceinline__ MatScale mat_scale(const WS& ws) {
+  static_assert(M >= 0 && M < M_COUNT, "forward matrices only: the transposed (bf16) ones carry no scale");
+  constexpr int idx = (scale_table_offset() - vec_region_offset()) / 4 + M;   // constexpr: else the offset walk runs on the device
+  const f32x4 e = ws.vecs[idx];
+  return MatScale{uniform_f32(e[0]), uniform_f32(e[1]), uniform_f32(e[2])};
 }
 
 __device__ __forceinline__ f32x4 mfma_f16(const f16x8& a, const f16x8& b, const f32x4& c) {
@@ -343,17 +351,15 @@ __device__ __forceinline__ void gemm_f16_panel(WS& ws, const BStep (&b)[C], f32x
 template <int C>
 struct BWords { unsigned w[C][kPlanes][4]; };
 
-// units [U0, U1) of k-step S of the tiles in[c][0..NIN); ACC: the tiles are raw accumulators (split_pair_acc)
-template <int S, int U0, int U1, bool ACC = false, bool BF = false, int C, int NIN>
-__device__ __forceinline__ void split_units(const f32x4 (&in)[C][NIN], BWords<C>& bw) {
-  static_assert(!(ACC && BF), "bf16 planes carry no scale: there are no raw accumulators to split");
+// units [U0, U1) of k-step S of the tiles in[c][0..NIN), scaled by m (split_pair; bf16 planes carry no scale)
+template <int S, int U0, int U1, bool BF = false, int C, int NIN>
+__device__ __forceinline__ void split_units(const f32x4 (&in)[C][NIN], BWords<C>& bw, float m) {
   static_for<U1 - U0>([&](auto ui) __attribute__((always_inline)) {
     constexpr int u = U0 + decltype(ui)::value;
     constexpr int c = u / 4, half = (u >> 1) & 1, q = u & 1, tile = 2 * S + half;
     if constexpr (tile < NIN) {
       if constexpr (BF) split_pair_bf16(in[c][tile][2 * q], in[c][tile][2 * q + 1], bw.w[c][0][2 * half + q], bw.w[c][1][2 * half + q]);
-      else if constexpr (ACC) split_pair_acc(in[c][tile][2 * q], in[c][tile][2 * q + 1], bw.w[c][0][2 * half + q], bw.w[c][1][2 * half + q]);
-      else split_pair(in[c][tile][2 * q], in[c][tile][2 * q + 1], bw.w[c][0][2 * half + q], bw.w[c][1][2 * half + q]);
+      else split_pair(in[c][tile][2 * q], in[c][tile][2 * q + 1], m, bw.w[c][0][2 * half + q], bw.w[c][1][2 * half + q]);
     } else {
       bw.w[c][0][2 * half + q] = bw.w[c][1][2 * half + q] = 0u;
     }
@@ -369,33 +375,32 @@ __device__ __forceinline__ void bwords_to_bstep(const BWords<C>& bw, BStep (&b)[
       b[c].p[p] = __builtin_bit_cast(f16x8, u32x4{bw.w[c][p][0], bw.w[c][p][1], bw.w[c][p][2], bw.w[c][p][3]});
 }
 
-constexpr int kAccLog2 = kWScaleLog2 + kXScaleLog2;
-__device__ __forceinline__ float elu1_acc(float a) { return elu1_scaled<-kAccLog2>(a); }   // elu(value) + 1 of a raw accumulator
-
-// the planes carry 2^kWScaleLog2 (weights) and 2^kXScaleLog2 (activations): exact descale of finished accumulators
-template <int C, int N>
-__device__ __forceinline__ void descale_tiles(f32x4 (&t)[C][N]) {
-#pragma unroll
-  for (int c = 0; c < C; ++c)
-#pragma unroll
-    for (int i = 0; i < N; ++i) t[c][i] *= kAccDescale;
+// elu(value) + 1 of a raw accumulator a = value / dsc (dsc a power of two; dsc_l2e = dsc log2(e), exact): bit-identical
+// to elu1(dsc * a), the scale rides on the fma / on the exponent's log2(e) multiply
+__device__ __forceinline__ float elu1_acc(float a, float dsc, float dsc_l2e) {
+#ifdef UFR_ACCURATE_EXP
+  return a > 0.f ? __builtin_fmaf(a, dsc, 1.f) : expf(a * dsc);
+#else
+  return a > 0.f ? __builtin_fmaf(a, dsc, 1.f) : __builtin_amdgcn_exp2f(dsc_l2e * a);
+#endif
 }
+constexpr float kLog2e = 0x1.715476p+0f;
 
-// out = 2^12 out + W_M x in over all k-steps of M, probed for the range (probe_gemm) and then, unless RAW_OUT, descaled
-// exactly by 2^-12.  in[c][0..NIN) are the producer's fp32 tiles -- values, or with ACC_IN its raw accumulators (ReLU
-// commutes with the scale; LayerNorm takes them with a scaled epsilon, elu / the attention fold the factor into a
-// multiply they do anyway: no layer of the two chains pays for a descale pass).  Callers that start from a bias pass
-// it pre-multiplied by kAccScale (exact).
+// out += 2^(s_M + a_M) W_M x in over all k-steps of M, probed for the range (probe_gemm); the output stays a RAW
+// accumulator.  in[c][0..NIN) are the producer's fp32 tiles and m the multiplier that turns them into the planes'
+// 2^a_M x: mat_scale<M>.xs for values, xs * (the producer's dsc) for the producer's raw accumulators (ReLU commutes with
+// the scale; LayerNorm takes raw accumulators with a scaled epsilon, elu / the attention fold the factor into a multiply
+// they do anyway: no layer of the two chains pays for a descale pass).  Callers that start from a bias pass it
+// pre-multiplied by mat_scale<M>.asc (exact).  bf16 matrices (the transposed ones of the backward): no scales, m unused.
 // The fp16 split of k-step s+1 is interleaved with the MFMAs of k-step s (only step 0's is exposed).
-template <int M, int C, int NWAVES, bool ACC_IN = false, bool RAW_OUT = false, int STREAM = -1, int NIN, class WS>
+template <int M, int C, int NWAVES, int STREAM = -1, int NIN, class WS>
 __device__ __forceinline__ void gemm_f16(WS& ws, const f32x4 (&in)[C][NIN], f32x4 (&out)[C][mat_desc(M).n_out],
-                                        bool wrap) {
+                                        bool wrap, float m = 1.f) {
   static_assert(NIN == mat_desc(M).n_in, "input tile count");
   constexpr int n_out = mat_desc(M).n_out, NU = 4 * C;
-  constexpr bool BF = f16_mat_is_bf16(M);   // bf16 planes: no scales, so the output is exact as it stands (RAW_OUT) and never probed
-  static_assert(!BF || (RAW_OUT && !ACC_IN), "bf16 streams: plain values in, plain values out");
+  constexpr bool BF = f16_mat_is_bf16(M);   // bf16 planes: no scales, so the output is exact as it stands and never probed
   BWords<C> cur;
-  split_units<0, 0, NU, ACC_IN, BF>(in, cur);
+  split_units<0, 0, NU, BF>(in, cur, m);
   static_for<ksteps(M)>([&](auto si) __attribute__((always_inline)) {
     constexpr int s = decltype(si)::value;
     BStep b[C];
@@ -409,16 +414,15 @@ __device__ __forceinline__ void gemm_f16(WS& ws, const f32x4 (&in)[C][NIN], f32x
       BWords<C> nxt;
       gemm_f16_panel<M, s, C, NWAVES, false, STREAM>(ws, b, out, wrap, [&](auto ti) __attribute__((always_inline)) {
         constexpr int to = decltype(ti)::value;
-        split_units<s + 1, to * NU / n_out, (to + 1) * NU / n_out, ACC_IN, BF>(in, nxt);
+        split_units<s + 1, to * NU / n_out, (to + 1) * NU / n_out, BF>(in, nxt, m);
       });
       cur = nxt;
     } else {
       gemm_f16_panel<M, s, C, NWAVES, false, STREAM>(ws, b, out, wrap);
-      if constexpr (s + 1 < ksteps(M)) split_units<s + 1, 0, NU, ACC_IN, BF>(in, cur);
+      if constexpr (s + 1 < ksteps(M)) split_units<s + 1, 0, NU, BF>(in, cur, m);
     }
   });
   if constexpr (!BF) probe_gemm(out, ws);
-  if constexpr (!RAW_OUT) descale_tiles(out);
 }
 
 }  // namespace ufr

@@ -189,7 +189,9 @@ class RayTransformer(nn.Module):
         if ent is None:
             if len(self._packed) >= 2:
                 self._packed.clear()
-            ent = self._packed[ptrs] = [ops.PackedWeights(params, precision), vers]
+            # args.ufr_input_abs_max (optional): the bound of the token features the fp16 planes are laid out for
+            bound = getattr(self.args, "ufr_input_abs_max", None) if self.args is not None else None
+            ent = self._packed[ptrs] = [ops.PackedWeights(params, precision, input_abs_max=bound), vers]
         elif ent[1] != vers:
             ent[0].repack()
             ent[1] = vers

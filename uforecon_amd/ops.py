@@ -84,11 +84,16 @@ def status_poll(synchronize: bool = True, mask: int = 7) -> int:
 
 class PackedWeights:
     """ufr_raw_weights (pointers into the live parameters) + the MFMA-ordered packed copy.  ``precision``: the matrix
-    precision the calls made with these weights use (None = the process default at call time)."""
+    precision the calls made with these weights use (None = the process default at call time).  ``input_abs_max``: an
+    upper bound of the token features these weights will meet (feature maps, volume features, pre-similarity features;
+    None = the library default, 256) -- it sets the exponents of the activations' fp16 planes (ufr_weights_pack_for);
+    weights of any finite magnitude pack without further ado."""
 
-    def __init__(self, params: Dict[str, torch.Tensor], precision: Optional[int] = None):
+    def __init__(self, params: Dict[str, torch.Tensor], precision: Optional[int] = None,
+                 input_abs_max: Optional[float] = None):
         lib = _lib.load()
         self.precision = precision
+        self.input_abs_max = input_abs_max
         self._keep = []
         ptrs = []
         for key, shape in zip(RAW_WEIGHT_KEYS, RAW_WEIGHT_SHAPES):
@@ -107,15 +112,30 @@ class PackedWeights:
         self.repack(check=True)
 
     def repack(self, check: bool = False) -> None:
-        """Call after the parameters changed in place (e.g. an optimizer step).  Asynchronous: a weight outside the
-        planes' range raises the sticky status, which the next compute call (or ``status_poll``) reports;
-        ``check=True`` synchronises and raises at once (construction does)."""
-        _lib.check(_lib.load().ufr_weights_pack(C.byref(self.raw), self.packed.data_ptr(), _stream()), "ufr_weights_pack")
+        """Call after the parameters changed in place (e.g. an optimizer step): the planes AND their exponents follow
+        the parameters.  Asynchronous: a non-finite parameter raises the sticky status, which the next compute call (or
+        ``status_poll``) reports; ``check=True`` synchronises and raises at once (construction does)."""
+        lib = _lib.load()
+        if self.input_abs_max is None:
+            rc = lib.ufr_weights_pack(C.byref(self.raw), self.packed.data_ptr(), _stream())
+        else:
+            rc = lib.ufr_weights_pack_for(C.byref(self.raw), self.packed.data_ptr(), float(self.input_abs_max), _stream())
+        _lib.check(rc, "ufr_weights_pack")
         if check:
             status_poll(True, mask=4)    # the pack's own bit: an unrelated, still unreported overflow must not fail a valid pack
 
     def mode(self) -> int:
         return resolve_precision(self.precision)
+
+    def scale_exponents(self) -> Dict[str, tuple]:
+        """(s_M, a_M) per dense matrix, read back from the packed blob's scale table (synchronises; for tests and reports)."""
+        import math
+        lib = _lib.load()
+        off, n = lib.ufr_packed_scale_table_offset(), lib.ufr_packed_scale_table_entries()
+        t = self.packed[off:off + 4 * n].cpu().view(n, 4)
+        names = ("vt_q", "vt_k", "vt_v", "vt_merge", "vt_mlp0", "vt_mlp2", "rt_q", "rt_k", "rt_v", "rt_merge", "rt_mlp0",
+                 "rt_mlp2", "dm0", "dm2", "dm4", "rw0", "rw2", "rw4")
+        return {nm: (int(round(math.log2(float(t[i, 3])))), int(round(math.log2(float(t[i, 0]))))) for i, nm in enumerate(names)}
 
     @property
     def variance(self) -> torch.Tensor:

@@ -35,7 +35,7 @@ def main():
         ops.set_matrix_precision(ops.PRECISION_16BIT)
     RN = int(os.environ.get("RN", 4096))
     SN = int(os.environ.get("SN", 128))
-    NV = 3
+    NV = int(os.environ.get("NV", 3))
     wz = np.load(os.path.join(ROOT, "tests", "golden", "ray_path_weights_seed0.npz"))
     W = ops.PackedWeights({k: torch.from_numpy(wz[k]).to(DEV) for k in wz.files})
     fr = make_frame(512, 640, NV, 0).to(DEV)

@@ -70,17 +70,26 @@ hipError_t launch_volume_pack(const float* feat, const float* weight, float* out
 // fragments (biases, LayerNorm, view token) of the fp32 region are read by the kernels: the fp32 A-fragment part in front
 // of them (the layout of the first, fp32-MFMA version; still described by ufr_pack_plan for the CPU layout tests) is not
 // written on the device any more.
-__global__ void __launch_bounds__(256) pack_weights_kernel(RawPtrs raw, float* __restrict__ packed, int first, int n) {
+// (like the plane regions below, through a per-device table of (param, elem): walking plan_entry per float took 18 us)
+__global__ void __launch_bounds__(256) vec_plan_kernel(int2* __restrict__ plan, int first, int n) {
   int i = first + blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int p, e;
   plan_entry(i, &p, &e);
-  packed[i] = p >= 0 ? raw.p[p][e] : 0.f;
+  plan[i - first] = make_int2(p, e);
+}
+__global__ void __launch_bounds__(256) pack_weights_kernel(RawPtrs raw, const int2* __restrict__ plan, float* __restrict__ packed,
+                                                            int first, int n) {
+  int i = first + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int2 src = plan[i - first];
+  packed[i] = src.x >= 0 ? raw.p[src.x][src.y] : 0.f;
 }
 
 // ---- the scale table (ufr_layout.h: scale_table_offset; ufr_layout_f16.h: what s_M and a_M mean).
-// One workgroup.  Per forward matrix: max |w| and the infinity norm (largest absolute row sum); per vector parameter: max
-// |.|.  Thread 0 then walks the two layer chains once, carrying an upper bound of every dense layer's input:
+// Per forward matrix: max |w| and the infinity norm (largest absolute row sum); per vector parameter: max |.|
+// (weight_stats_kernel).  One thread then walks the two layer chains once, carrying an upper bound of every dense
+// layer's input (weight_scale_kernel):
 //   projections     |x| <= X (the caller's bound of the token features; the learned view token counts)
 //   attention       the message is a (sub-)convex combination of the values (the scores Q'.K' are positive):
 //                   |msg| <= |v| <= ||W_v||_inf X
@@ -92,24 +101,6 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(RawPtrs raw, float* _
 // planes keep 22 significand bits for everything above 2^-17 of the bound.
 // A non-finite parameter raises bit 2 of the sticky status (include/ufr.h) and leaves default exponents.
 namespace {
-__device__ float block_max(float v, float* red) {
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-}
-__device__ float absmax_or_nan(const float* __restrict__ p, int n, float* red, bool& bad) {
-  float m = 0.f;
-  bool b = false;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const float a = fabsf(p[i]);
-    b |= !(a <= 3.0e38f);
-    m = fmaxf(m, a);
-  }
-  bad |= block_max(b ? 1.f : 0.f, red) != 0.f;
-  return block_max(m, red);
-}
 // largest exponent in [lo, hi] with 2^e bound <= 2^15 (bound > 0, finite; fp16 holds up to 65504)
 __device__ int plane_exponent(float bound, int lo, int hi) {
   int e;
@@ -118,33 +109,113 @@ __device__ int plane_exponent(float bound, int lo, int hi) {
 }
 }  // namespace
 
-__global__ void __launch_bounds__(256) weight_scale_kernel(RawPtrs raw, float* __restrict__ table, float x_max,
-                                                            int* __restrict__ flag, int fixed) {
-  __shared__ float red[4];
-  __shared__ float wmax[M_COUNT], ninf[M_COUNT], vmax[P_COUNT];
-  bool bad = false;
-  for (int m = 0; m < M_COUNT; ++m) {
-    const MatDesc d = mat_desc(m);
-    const float* w = raw.p[d.param];
-    float rs = 0.f;
-    for (int r = threadIdx.x; r < d.out_dim; r += 256) {
-      float a = 0.f;
-      for (int k = 0; k < d.k_raw; ++k) a += fabsf(w[r * d.k_raw + k]);
-      rs = fmaxf(rs, a);
+// first kernel: one workgroup per matrix (its max |w| and infinity norm) and per vector parameter (max |.|); the numbers
+// go to the table's own tail (the kernels' scalar lists, which the second kernel overwrites after reading them) --
+// training re-packs after every optimizer step, a single workgroup walking all 33 parameters took 0.3 ms
+constexpr int kStatVecs = 15;
+__device__ constexpr int kStatVecParam[kStatVecs][2] = {{P_VT_N1W, 80}, {P_VT_N1B, 80}, {P_VT_N2W, 80}, {P_VT_N2B, 80}, {P_RT_N1W, 88},
+                                                        {P_RT_N1B, 88}, {P_RT_N2W, 88}, {P_RT_N2B, 88}, {P_DM_B0, 32}, {P_DM_B2, 16},
+                                                        {P_DM_B4, 1}, {P_RW_B0, 16}, {P_RW_B2, 8}, {P_RW_B4, 1}, {P_VIEW_TOKEN, 80}};
+static_assert(2 * M_COUNT + kStatVecs <= 2 * kKernelScalars, "the statistics borrow the scalar lists' floats");
+constexpr int kStatThreads = 1024;
+__global__ void __launch_bounds__(kStatThreads) weight_stats_kernel(RawPtrs raw, float* __restrict__ stats, int* __restrict__ flag) {
+  __shared__ float red[3][kStatThreads / 64];
+  __shared__ float rowsum[176];
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float m = 0.f, rs = 0.f;
+  bool nf = false;
+  if (b < M_COUNT) {
+    const MatDesc d = mat_desc(b);
+    const float4* w4 = reinterpret_cast<const float4*>(raw.p[d.param]);
+    for (int r = threadIdx.x; r < d.out_dim; r += kStatThreads) rowsum[r] = 0.f;
+    __syncthreads();
+    // The parameters were just written by the optimizer, on other XCDs: every read is a round trip past the L2 (~2 us).
+    // So all of a thread's reads are issued before any is used: 8 independent 16-byte loads cover the largest matrix
+    // (176 x 176) with 1024 threads -- a loop that waits per element took 56 us, per step.
+    const int n4 = d.out_dim * d.k_raw / 4;     // every matrix's element count is a multiple of 4
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i4 = threadIdx.x + u * kStatThreads;
+      v[u] = w4[i4 < n4 ? i4 : n4 - 1];       // unconditional (a branch per load serialises them), masked below
     }
-    const float mx = absmax_or_nan(w, d.out_dim * d.k_raw, red, bad);
-    const float ni = block_max(rs, red);
-    if (threadIdx.x == 0) { wmax[m] = mx; ninf[m] = ni; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i4 = threadIdx.x + u * kStatThreads;
+      const bool in = i4 < n4;
+      const float e[4] = {in ? fabsf(v[u].x) : 0.f, in ? fabsf(v[u].y) : 0.f, in ? fabsf(v[u].z) : 0.f, in ? fabsf(v[u].w) : 0.f};
+      const float s4 = (e[0] + e[1]) + (e[2] + e[3]);
+      nf |= !(s4 <= 3.0e38f);
+      m = fmaxf(fmaxf(m, fmaxf(e[0], e[1])), fmaxf(e[2], e[3]));
+      // |w| into its row's sum: a wave whose 256 elements lie in one row adds once, the others per element
+      const int r0 = (4 * i4) / d.k_raw, r3 = (4 * i4 + 3) / d.k_raw;
+      const bool one_row = i4 < n4 && r0 == r3 && r0 == __shfl(r0, 0);
+      if (__builtin_amdgcn_ballot_w64(one_row) == ~0ull) {
+        float t = s4;
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        if (lane == 0) atomicAdd(&rowsum[r0], t);
+      } else if (i4 < n4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(&rowsum[(4 * i4 + k) / d.k_raw], e[k]);
+      }
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < d.out_dim; r += kStatThreads) rs = fmaxf(rs, rowsum[r]);
+  } else {
+    const int v = b - M_COUNT;
+    const float* p = raw.p[kStatVecParam[v][0]];
+    for (int i = threadIdx.x; i < kStatVecParam[v][1]; i += kStatThreads) {
+      const float a = fabsf(p[i]);
+      nf |= !(a <= 3.0e38f);
+      m = fmaxf(m, a);
+    }
   }
-  constexpr int vparams[][2] = {{P_VT_N1W, 80}, {P_VT_N1B, 80}, {P_VT_N2W, 80}, {P_VT_N2B, 80}, {P_RT_N1W, 88}, {P_RT_N1B, 88},
-                                {P_RT_N2W, 88}, {P_RT_N2B, 88}, {P_DM_B0, 32}, {P_DM_B2, 16}, {P_DM_B4, 1}, {P_RW_B0, 16},
-                                {P_RW_B2, 8}, {P_RW_B4, 1}, {P_VIEW_TOKEN, 80}};
-  for (const auto& vp : vparams) {
-    const float mx = absmax_or_nan(raw.p[vp[0]], vp[1], red, bad);
-    if (threadIdx.x == 0) vmax[vp[0]] = mx;
+  // block maxima of (non-finite seen, max |w|, largest row sum): one round
+  float t[3] = {nf ? 1.f : 0.f, m, rs};
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    for (int o = 32; o > 0; o >>= 1) t[q] = fmaxf(t[q], __shfl_xor(t[q], o));
+    if (lane == 0) red[q][wave] = t[q];
   }
   __syncthreads();
-  if (threadIdx.x != 0) return;
+  if (threadIdx.x < 3) {
+    float r = red[threadIdx.x][0];
+#pragma unroll
+    for (int i = 1; i < kStatThreads / 64; ++i) r = fmaxf(r, red[threadIdx.x][i]);
+    if (threadIdx.x == 0 && r != 0.f) atomicOr(flag, 4);
+    if (threadIdx.x == 1) stats[b < M_COUNT ? b : 2 * M_COUNT + (b - M_COUNT)] = r;
+    if (threadIdx.x == 2 && b < M_COUNT) stats[M_COUNT + b] = r;
+  }
+}
+
+// second kernel: the chain of bounds, the exponents, the table (one thread computes, the wave loads and stores)
+__device__ void weight_scale_chain(const float* stats, float* table, float x_max, int* __restrict__ flag, int fixed);
+__global__ void __launch_bounds__(64) weight_scale_kernel(float* __restrict__ table_out, float x_max, int* __restrict__ flag, int fixed) {
+  __shared__ float stats[2 * kKernelScalars];
+  __shared__ float table[kScaleFloats];          // built by thread 0, written out by the wave
+  constexpr int stats_at = view_scalars_offset() - scale_table_offset();   // (constexpr: or the offset walk runs on the device)
+  stats[threadIdx.x] = table_out[stats_at + threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) weight_scale_chain(stats, table, x_max, flag, fixed);
+  __syncthreads();
+  for (int i = threadIdx.x; i < kScaleFloats; i += 64) table_out[i] = table[i];
+}
+__device__ void weight_scale_chain(const float* stats, float* table, float x_max, int* __restrict__ flag, int fixed) {
+  float wmax[M_COUNT], ninf[M_COUNT], vmax[P_COUNT];
+  bool bad = false;
+  // (every loop below is unrolled: the arrays are indexed with constants and stay in registers -- as private memory they
+  // cost a 50 us kernel)
+#pragma unroll
+  for (int m = 0; m < M_COUNT; ++m) {
+    wmax[m] = stats[m];
+    ninf[m] = stats[M_COUNT + m];
+    bad |= !(wmax[m] <= 3.0e38f) || !(ninf[m] <= 3.0e38f);
+  }
+#pragma unroll
+  for (int v = 0; v < kStatVecs; ++v) {
+    vmax[kStatVecParam[v][0]] = stats[2 * M_COUNT + v];
+    bad |= !(stats[2 * M_COUNT + v] <= 3.0e38f);
+  }
   bad |= !(x_max > 0.f && x_max <= 3.0e38f);
   float in[M_COUNT];
   const float X = fmaxf(x_max, vmax[P_VIEW_TOKEN]);
@@ -167,8 +238,10 @@ __global__ void __launch_bounds__(256) weight_scale_kernel(RawPtrs raw, float* _
   in[M_DM0] = O;
   in[M_DM2] = ninf[M_DM0] * O + vmax[P_DM_B0];
   in[M_DM4] = ninf[M_DM2] * in[M_DM2] + vmax[P_DM_B2];
+#pragma unroll
   for (int m = 0; m < M_COUNT; ++m) bad |= !(in[m] <= 3.0e38f);
   if (bad) atomicOr(flag, 4);
+#pragma unroll
   for (int m = 0; m < M_COUNT; ++m) {
     // (matrices that share one split of their input -- q / k / v / mlp0 of either transformer -- get the same a_M: it
     // depends on the input's bound only)
@@ -180,6 +253,38 @@ __global__ void __launch_bounds__(256) weight_scale_kernel(RawPtrs raw, float* _
     table[4 * m + 2] = ldexpf(1.f, sw + ax);
     table[4 * m + 3] = ldexpf(1.f, sw);
   }
+  // the kernels' scalar lists (ufr_layout.h: ViewScalar / RayScalar); every product below is a product of powers of two
+  // (exact), except the two constants 1e-5 and log2(e)
+  auto xs = [&](int m) { return table[4 * m + 0]; };
+  auto dsc = [&](int m) { return table[4 * m + 1]; };
+  auto asc = [&](int m) { return table[4 * m + 2]; };
+  constexpr float l2e = 0x1.715476p+0f;
+  constexpr int vs_at = view_scalars_offset() - scale_table_offset(), rs_at = ray_scalars_offset() - scale_table_offset();
+  float* vs = table + vs_at;
+  float* rs = table + rs_at;
+  for (int i = 0; i < 2 * kKernelScalars; ++i) vs[i] = 0.f;
+  vs[VS_XS_X] = xs(M_VT_Q);
+  vs[VS_Q_DSC] = dsc(M_VT_Q);     vs[VS_Q_L2E] = dsc(M_VT_Q) * l2e;
+  vs[VS_K_DSC] = dsc(M_VT_K);     vs[VS_K_L2E] = dsc(M_VT_K) * l2e;
+  vs[VS_V_DSC] = dsc(M_VT_V);
+  vs[VS_M_XS] = xs(M_VT_MERGE);   vs[VS_EPS1] = 1e-5f * asc(M_VT_MERGE) * asc(M_VT_MERGE);   vs[VS_M_ASC] = asc(M_VT_MERGE);
+  vs[VS_MLP0_DSC] = dsc(M_VT_MLP0);
+  vs[VS_M_MLP2] = xs(M_VT_MLP2) * dsc(M_VT_MLP0);
+  vs[VS_EPS2] = 1e-5f * asc(M_VT_MLP2) * asc(M_VT_MLP2);   vs[VS_MLP2_ASC] = asc(M_VT_MLP2);
+  vs[VS_RW0_XS] = xs(M_RW0);      vs[VS_RW0_ASC] = asc(M_RW0);   vs[VS_RW0_DSC] = dsc(M_RW0);
+  vs[VS_M_RW2] = xs(M_RW2) * dsc(M_RW0);   vs[VS_RW2_ASC] = asc(M_RW2);   vs[VS_RW2_DSC] = dsc(M_RW2);
+  vs[VS_M_RW4] = xs(M_RW4) * dsc(M_RW2);   vs[VS_RW4_ASC] = asc(M_RW4);   vs[VS_RW4_DSC] = dsc(M_RW4);
+  rs[RS_XS_X] = xs(M_RT_K);
+  rs[RS_K_DSC] = dsc(M_RT_K);     rs[RS_K_L2E] = dsc(M_RT_K) * l2e;
+  rs[RS_V_DSC] = dsc(M_RT_V);     rs[RS_V_ASC] = asc(M_RT_V);
+  rs[RS_Q_DSC] = dsc(M_RT_Q);     rs[RS_Q_L2E] = dsc(M_RT_Q) * l2e;
+  rs[RS_M_XS] = xs(M_RT_MERGE);   rs[RS_EPS1] = 1e-5f * asc(M_RT_MERGE) * asc(M_RT_MERGE);   rs[RS_M_ASC] = asc(M_RT_MERGE);
+  rs[RS_MLP0_DSC] = dsc(M_RT_MLP0);
+  rs[RS_M_MLP2] = xs(M_RT_MLP2) * dsc(M_RT_MLP0);
+  rs[RS_EPS2] = 1e-5f * asc(M_RT_MLP2) * asc(M_RT_MLP2);   rs[RS_MLP2_ASC] = asc(M_RT_MLP2);
+  rs[RS_DM0_XS] = xs(M_DM0);      rs[RS_DM0_ASC] = asc(M_DM0);   rs[RS_DM0_DSC] = dsc(M_DM0);
+  rs[RS_M_DM2] = xs(M_DM2) * dsc(M_DM0);   rs[RS_DM2_ASC] = asc(M_DM2);   rs[RS_DM2_DSC] = dsc(M_DM2);
+  rs[RS_M_DM4] = xs(M_DM4) * dsc(M_DM2);   rs[RS_DM4_ASC] = asc(M_DM4);   rs[RS_DM4_DSC] = dsc(M_DM4);
 }
 
 // Plane regions (ufr_layout_f16.h).  Forward streams: halfword h = fp16 plane p of 2^s_M * raw[param][elem] (2^s_M from the
@@ -227,6 +332,7 @@ struct PlanCache {
   std::once_flag once[16];
   hipError_t err[16];
   PlaneSrc* plan[16];
+  int2* vec_plan[16];
 };
 PlanCache g_plan;
 }  // namespace
@@ -239,15 +345,22 @@ hipError_t launch_pack_weights(const RawPtrs& raw, float* packed, float input_ab
   std::call_once(g_plan.once[dev], [&] {      // process lifetime, 8 bytes per halfword (~13 MB)
     g_plan.err[dev] = hipMalloc(reinterpret_cast<void**>(&g_plan.plan[dev]), sizeof(PlaneSrc) * (size_t)n_half);
     if (g_plan.err[dev] != hipSuccess) return;
+    g_plan.err[dev] = hipMalloc(reinterpret_cast<void**>(&g_plan.vec_plan[dev]), sizeof(int2) * (size_t)(n_vec - first));
+    if (g_plan.err[dev] != hipSuccess) return;
+    hipLaunchKernelGGL(vec_plan_kernel, dim3((n_vec - first + 255) / 256), dim3(256), 0, s, g_plan.vec_plan[dev], first, n_vec);
     hipLaunchKernelGGL(plane_plan_kernel, dim3((n_half + 255) / 256), dim3(256), 0, s, g_plan.plan[dev], n_half);
     g_plan.err[dev] = hipGetLastError();
     if (g_plan.err[dev] == hipSuccess) g_plan.err[dev] = hipStreamSynchronize(s);   // other streams may pack next
   });
   if (g_plan.err[dev] != hipSuccess) return g_plan.err[dev];
-  hipLaunchKernelGGL(pack_weights_kernel, dim3((n_vec - first + 255) / 256), dim3(256), 0, s, raw, packed, first, n_vec);
-  float* table = packed + scale_table_offset();
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((n_vec - first + 255) / 256), dim3(256), 0, s, raw, g_plan.vec_plan[dev], packed, first,
+                     n_vec);
+  constexpr int table_at = scale_table_offset(), stats_at = view_scalars_offset();
+  float* table = packed + table_at;
   static const int fixed = [] { const char* e = getenv("UFR_DEBUG_FIXED_SCALES"); return (e && e[0] == '1') ? 1 : 0; }();
-  hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(256), 0, s, raw, table, input_abs_max, range_flag, fixed);
+  hipLaunchKernelGGL(weight_stats_kernel, dim3(M_COUNT + kStatVecs), dim3(kStatThreads), 0, s, raw,
+                     packed + stats_at, range_flag);
+  hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(64), 0, s, table, input_abs_max, range_flag, fixed);
   unsigned short* planes = reinterpret_cast<unsigned short*>(packed + n);
   hipLaunchKernelGGL(pack_weights_f16_kernel, dim3((n_half + 255) / 256), dim3(256), 0, s, raw, g_plan.plan[dev], table, planes,
                      n_half);

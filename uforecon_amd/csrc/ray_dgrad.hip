@@ -98,9 +98,9 @@ __global__ void __launch_bounds__(kRdBlock, 2) ray_dgrad_kernel(const float* __r
   const int ray = valid ? ray_raw : RN - 1;
   const int n_tiles = SN / 16, n2 = n_tiles + (n_tiles & 1), nb = n2 / 2;
   const float fSN = (float)SN;
-  const MatScale zk = mat_scale<M_RT_K>(ws), zv = mat_scale<M_RT_V>(ws);   // sweep 2 recomputes k, v from the forward planes
-  const float k_l2e = zk.dsc * kLog2e;
-  const float inv_len = zv.dsc / fSN, f_len = fSN * zv.asc;   // values / v_length on raw accumulators (ray_transformer.hip)
+  const auto sc = scalar_file<false, ray_scalars_offset()>(ws);   // sweep 2 recomputes k, v from the forward planes
+  const float xs_x = sc[RS_XS_X], k_dsc = sc[RS_K_DSC], k_l2e = sc[RS_K_L2E];
+  const float inv_len = uniform_f32(sc[RS_V_DSC] / fSN), f_len = uniform_f32(fSN * sc[RS_V_ASC]);   // values / v_length on raw accumulators (ray_transformer.hip)
   const bool pow2_len = (SN & (SN - 1)) == 0;
 
   float* const a_base = reinterpret_cast<float*>(smem + kF16LdsBytes) + (threadIdx.x >> 6) * kRdAccFloats + lane;
@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(kRdBlock, 2) ray_dgrad_kernel(const float* __r
     for (int h = 0; h < 8; ++h) { kt[0][h] = splat4(0.f); vt[0][h] = splat4(0.f); }
     {  // k, v in the plain orientation: rows = the head tile's slots 4g + r, column = token; x is split once per k-step
       BWords<C> cur;
-      split_units<0, 0, 4 * C>(x, cur, zk.xs);
+      split_units<0, 0, 4 * C>(x, cur, xs_x);
       static_for<3>([&](auto si) __attribute__((always_inline)) {
         constexpr int s = decltype(si)::value;
         BStep b[C];
@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(kRdBlock, 2) ray_dgrad_kernel(const float* __r
           BWords<C> nxt;
           gemm_f16_panel<M_RT_K, s, C, kRdWaves, false, B_RTB2>(ws, b, kt, wrap, [&](auto ti) __attribute__((always_inline)) {
             constexpr int to = decltype(ti)::value;
-            split_units<s + 1, to * 4 * C / 8, (to + 1) * 4 * C / 8>(x, nxt, zk.xs);
+            split_units<s + 1, to * 4 * C / 8, (to + 1) * 4 * C / 8>(x, nxt, xs_x);
           });
           gemm_f16_panel<M_RT_V, s, C, kRdWaves, false, B_RTB2>(ws, b, vt, wrap);
           cur = nxt;
@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(kRdBlock, 2) ray_dgrad_kernel(const float* __r
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const bool slot_ok = head11_slot(4 * g + r) >= 0;
-        Kp[r] = slot_ok ? elu1_acc(kt[0][h][r], zk.dsc, k_l2e) : 0.f;
+        Kp[r] = slot_ok ? elu1_acc(kt[0][h][r], k_dsc, k_l2e) : 0.f;
         const float vs = pow2_len ? vt[0][h][r] * inv_len : vt[0][h][r] / f_len;
         Vx[r] = slot_ok ? vs : ((g == 0 && r == 3) ? 1.f : 0.f);              // ones column (slot 3) <-> the K' sum
       }

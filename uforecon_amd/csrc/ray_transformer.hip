@@ -41,8 +41,8 @@ __device__ __forceinline__ void load_ray_tile(const float* __restrict__ token0, 
 // LayerNorm over 88 features in nat88 layout (tile 5: registers 0,1 real)
 // XH / RS (TAPE builds): the normalised input and 1 / sigma of the TRUE values, which the backward needs
 template <int VW, int VB, class WS>
-__device__ __forceinline__ void layer_norm88(f32x4 (&tt)[kRtC][6], const WS& ws, int g, float asc, f32x4 (*XH)[6] = nullptr, float* RS = nullptr) {
-  const float eps = 1e-5f * asc * asc;   // raw accumulators (asc times the values): view_transformer.hip layer_norm80
+__device__ __forceinline__ void layer_norm88(f32x4 (&tt)[kRtC][6], const WS& ws, int g, float eps, float asc, f32x4 (*XH)[6] = nullptr, float* RS = nullptr) {
+  // eps = 1e-5 asc^2: raw accumulators (asc times the values), view_transformer.hip layer_norm80
 #pragma unroll
   for (int c = 0; c < kRtC; ++c) {
     f32x4 (&t)[6] = tt[c];
@@ -120,14 +120,13 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
   const int n_iter = (n_tiles + C - 1) / C;   // an odd tile count leaves the last iteration's second tile empty (masked)
   // values / v_length (linear_attention.py:41): a multiply by 1/SN is exact only for power-of-two sample counts;
   // any other total (64 + 32, 48, ...) takes the true division the reference performs
-  // the layers' plane / accumulator scales (ufr_layout.h: scale table), wave-uniform for the whole launch.  q, k, v and
-  // mlp0 all split x: their a_M agree by construction (prep.hip), one multiplier (xs_x) serves the four.
-  const MatScale zk = mat_scale<M_RT_K>(ws), zv = mat_scale<M_RT_V>(ws), zq = mat_scale<M_RT_Q>(ws), zm = mat_scale<M_RT_MERGE>(ws);
-  const MatScale z0 = mat_scale<M_RT_MLP0>(ws), z2 = mat_scale<M_RT_MLP2>(ws);
-  const MatScale zd0 = mat_scale<M_DM0>(ws), zd2 = mat_scale<M_DM2>(ws), zd4 = mat_scale<M_DM4>(ws);
-  const float xs_x = zk.xs;
-  const float k_l2e = zk.dsc * kLog2e, q_l2e = zq.dsc * kLog2e;
-  const float inv_len = zv.dsc / (float)SN, f_len = (float)SN * zv.asc;   // applied to raw accumulators
+  // the layers' plane / accumulator scales (ufr_layout.h: RayScalar; weight_stream_f16.h: ScalarFile -- this kernel has the
+  // scalar registers to keep them all resident).  q, k, v and mlp0 all split x: their a_M agree by construction
+  // (prep.hip), one multiplier (RS_XS_X) serves the four.
+  const auto sc = scalar_file<false, ray_scalars_offset()>(ws);
+  const float xs_x = sc[RS_XS_X];
+  const float k_dsc = sc[RS_K_DSC], k_l2e = sc[RS_K_L2E], q_dsc = sc[RS_Q_DSC], q_l2e = sc[RS_Q_L2E];
+  const float inv_len = uniform_f32(sc[RS_V_DSC] / (float)SN), f_len = uniform_f32((float)SN * sc[RS_V_ASC]);   // applied to raw accumulators
   const bool pow2_len = (SN & (SN - 1)) == 0;
 
 #ifdef UFR_PHASE_TIMING
@@ -184,7 +183,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
       for (int h = 0; h < 8; ++h) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float kk = (slot_ok && live[c]) ? elu1_acc(kt[c][h][r], zk.dsc, k_l2e) : 0.f;           // padding slots / empty tile contribute nothing
+          const float kk = (slot_ok && live[c]) ? elu1_acc(kt[c][h][r], k_dsc, k_l2e) : 0.f;           // padding slots / empty tile contribute nothing
           const float vs = pow2_len ? vt[c][h][r] * inv_len : vt[c][h][r] / f_len;
           const float vv = slot_ok ? vs : (j == 3 ? 1.f : 0.f);                       // ones column (slot 3) -> sum of K'
 #ifdef UFR_ABL_NOKV   // ablation (timing only): no fp32 MFMAs for the per-head KV state
@@ -238,7 +237,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
         tape_st(RT_X + t, live[0] ? x[0][t] : splat4(0.f));
         f32x4 qq;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) qq[r] = quad11(t, g, r) >= 0 ? elu1_acc(q[0][t][r], zq.dsc, q_l2e) : 0.f;
+        for (int r = 0; r < 4; ++r) qq[r] = quad11(t, g, r) >= 0 ? elu1_acc(q[0][t][r], q_dsc, q_l2e) : 0.f;
         tape_st(RT_Q + t, qq);
       }
     }
@@ -250,7 +249,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
         f32x4 acc = splat4(0.f);
         static_for<3>([&](auto qi) __attribute__((always_inline)) {
           constexpr int qd = decltype(qi)::value, quad = 3 * h + qd;   // lane group g: head dim 3g + qd
-          const float qq = (3 * g + qd < 11) ? elu1_acc(q[c][quad >> 2][quad & 3], zq.dsc, q_l2e) : 0.f;
+          const float qq = (3 * g + qd < 11) ? elu1_acc(q[c][quad >> 2][quad & 3], q_dsc, q_l2e) : 0.f;
 #ifdef UFR_ABL_NOKV
           acc[qd] += KV[h][qd] * qq;
 #else
@@ -279,16 +278,16 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int t = 0; t < 6; ++t) m[c][t] = splat4(0.f);
-    gemm_f16<M_RT_MERGE, C, kRtWaves>(ws, msg, m, wrap, zm.xs);
+    gemm_f16<M_RT_MERGE, C, kRtWaves>(ws, msg, m, wrap, sc[RS_M_XS]);
     UFR_RT_PHASE(4)  // merge GEMM
     float rstd1[C] = {}, rstd2[C] = {};
     if constexpr (TAPE) {
       f32x4 xh[C][6];
-      layer_norm88<V_RT_N1W, V_RT_N1B>(m, ws, g, zm.asc, xh, rstd1);
+      layer_norm88<V_RT_N1W, V_RT_N1B>(m, ws, g, sc[RS_EPS1], sc[RS_M_ASC], xh, rstd1);
 #pragma unroll
       for (int t = 0; t < 6; ++t) { tape_st(RT_XH1 + t, xh[0][t]); tape_st(RT_M + t, m[0][t]); }
     } else {
-      layer_norm88<V_RT_N1W, V_RT_N1B>(m, ws, g, zm.asc);
+      layer_norm88<V_RT_N1W, V_RT_N1B>(m, ws, g, sc[RS_EPS1], 1.f);
     }
     UFR_RT_PHASE(5)  // LayerNorm 1
 
@@ -315,21 +314,21 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
     if constexpr (TAPE) {
 #pragma unroll
       for (int t = 0; t < 11; ++t) {
-        tape_st(RT_HID + t, hid[0][t] * z0.dsc);
+        tape_st(RT_HID + t, hid[0][t] * sc[RS_MLP0_DSC]);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (hid[0][t][r] > 0.f) relu_bits[(4 * t + r) >> 5] |= 1u << ((4 * t + r) & 31);
       }
     }
-    gemm_f16<M_RT_MLP2, C, kRtWaves>(ws, hid, o, wrap, z2.xs * z0.dsc);
+    gemm_f16<M_RT_MLP2, C, kRtWaves>(ws, hid, o, wrap, sc[RS_M_MLP2]);
     UFR_RT_PHASE(7)  // ReLU + MLP2
     if constexpr (TAPE) {
       f32x4 xh[C][6];
-      layer_norm88<V_RT_N2W, V_RT_N2B>(o, ws, g, z2.asc, xh, rstd2);
+      layer_norm88<V_RT_N2W, V_RT_N2B>(o, ws, g, sc[RS_EPS2], sc[RS_MLP2_ASC], xh, rstd2);
 #pragma unroll
       for (int t = 0; t < 6; ++t) tape_st(RT_XH2 + t, xh[0][t]);
     } else {
-      layer_norm88<V_RT_N2W, V_RT_N2B>(o, ws, g, z2.asc);
+      layer_norm88<V_RT_N2W, V_RT_N2B>(o, ws, g, sc[RS_EPS2], 1.f);
     }
     UFR_RT_PHASE(8)  // LayerNorm 2
 #pragma unroll
@@ -353,19 +352,19 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
     f32x4 d1[C][2], d2[C][1], d3[C][1];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      d1[c][0] = vec_frag<V_DM_B0>(ws, 0, g) * zd0.asc;   // biases enter the scaled accumulators (weight_stream_f16.h)
-      d1[c][1] = vec_frag<V_DM_B0>(ws, 1, g) * zd0.asc;
-      d2[c][0] = vec_frag<V_DM_B2>(ws, 0, g) * zd2.asc;
-      d3[c][0] = vec_frag<V_DM_B4>(ws, 0, g) * zd4.asc;
+      d1[c][0] = vec_frag<V_DM_B0>(ws, 0, g) * sc[RS_DM0_ASC];   // biases enter the scaled accumulators (weight_stream_f16.h)
+      d1[c][1] = vec_frag<V_DM_B0>(ws, 1, g) * sc[RS_DM0_ASC];
+      d2[c][0] = vec_frag<V_DM_B2>(ws, 0, g) * sc[RS_DM2_ASC];
+      d3[c][0] = vec_frag<V_DM_B4>(ws, 0, g) * sc[RS_DM4_ASC];
     }
-    gemm_f16<M_DM0, C, kRtWaves>(ws, o, d1, wrap, zd0.xs);
+    gemm_f16<M_DM0, C, kRtWaves>(ws, o, d1, wrap, sc[RS_DM0_XS]);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) d1[c][t][r] = fmaxf(d1[c][t][r], 0.f);
-    gemm_f16<M_DM2, C, kRtWaves>(ws, d1, d2, wrap, zd2.xs * zd0.dsc);
+    gemm_f16<M_DM2, C, kRtWaves>(ws, d1, d2, wrap, sc[RS_M_DM2]);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
@@ -373,21 +372,21 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
     if constexpr (TAPE) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        tape_st(RT_D1 + t, d1[0][t] * zd0.dsc);
+        tape_st(RT_D1 + t, d1[0][t] * sc[RS_DM0_DSC]);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (d1[0][t][r] > 0.f) relu_bits[(44 + 4 * t + r) >> 5] |= 1u << ((44 + 4 * t + r) & 31);
       }
-      tape_st(RT_D2, d2[0][0] * zd2.dsc);
+      tape_st(RT_D2, d2[0][0] * sc[RS_DM2_DSC]);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (d2[0][0][r] > 0.f) relu_bits[1] |= 1u << (52 + r - 32);
       tape_st(RT_MISC, f32x4{rstd1[0], rstd2[0], __builtin_bit_cast(float, relu_bits[0]), __builtin_bit_cast(float, relu_bits[1])});
     }
-    gemm_f16<M_DM4, C, kRtWaves>(ws, d2, d3, wrap, zd4.xs * zd2.dsc);
+    gemm_f16<M_DM4, C, kRtWaves>(ws, d2, d3, wrap, sc[RS_M_DM4]);
 #pragma unroll
     for (int c = 0; c < C; ++c)
-      if (g == 0 && valid && live[c]) srdf[(size_t)ray * SN + tbase[c] + j] = d3[c][0][0] * zd4.dsc;
+      if (g == 0 && valid && live[c]) srdf[(size_t)ray * SN + tbase[c] + j] = d3[c][0][0] * sc[RS_DM4_DSC];
     wstream_f16_finish<B_RT2, kRtWaves>(ws, wrap);
     UFR_RT_PHASE(9)  // residual, stores, DensityMLP
   }

@@ -252,9 +252,25 @@ __host__ __device__ constexpr int vec_offset(int v) {
 //   {xs, dsc, asc, ws} = {2^a_M, 2^-(s_M + a_M), 2^(s_M + a_M), 2^s_M}
 // s_M: exponent the fp16 planes of W_M carry (from max |w|), a_M: exponent the planes of the layer's INPUT carry (from an
 // analytic bound of the input's magnitude) -- both chosen by ufr_weights_pack (prep.hip: weight_scale_kernel), read by the
-// kernels at run time (weight_stream_f16.h: mat_scale).  Not a function of the parameters alone: plan_entry maps it to zero.
-constexpr int kScaleFloats = M_COUNT * 4;
+// kernels at run time (weight_stream_f16.h: ScalarFile).  Not a function of the parameters alone: plan_entry maps it to zero.
+// Behind the per-matrix entries: the scalars each transformer kernel actually consumes, derived ones included (epsilons,
+// log2(e) multiples, producer-descale x consumer-scale products), in the order of the kernel's enum below -- a kernel reads
+// its list into ONE vector register (lane k = scalar k) and takes a scalar with v_readlane where it needs it.
+constexpr int kKernelScalars = 32;
+constexpr int kScaleFloats = M_COUNT * 4 + 2 * kKernelScalars;
+enum ViewScalar : int {   // view_transformer.hip (forward, tape)
+  VS_XS_X = 0, VS_Q_DSC, VS_Q_L2E, VS_K_DSC, VS_K_L2E, VS_V_DSC, VS_M_XS, VS_EPS1, VS_M_ASC, VS_MLP0_DSC, VS_M_MLP2, VS_EPS2,
+  VS_MLP2_ASC, VS_RW0_XS, VS_RW0_ASC, VS_RW0_DSC, VS_M_RW2, VS_RW2_ASC, VS_RW2_DSC, VS_M_RW4, VS_RW4_ASC, VS_RW4_DSC, VS_COUNT
+};
+enum RayScalar : int {    // ray_transformer.hip (forward, tape), ray_dgrad.hip (the k / v recompute)
+  RS_XS_X = 0, RS_K_DSC, RS_K_L2E, RS_V_DSC, RS_V_ASC, RS_Q_DSC, RS_Q_L2E, RS_M_XS, RS_EPS1, RS_M_ASC, RS_MLP0_DSC, RS_M_MLP2,
+  RS_EPS2, RS_MLP2_ASC, RS_DM0_XS, RS_DM0_ASC, RS_DM0_DSC, RS_M_DM2, RS_DM2_ASC, RS_DM2_DSC, RS_M_DM4, RS_DM4_ASC, RS_DM4_DSC,
+  RS_COUNT
+};
+static_assert(VS_COUNT <= kKernelScalars && RS_COUNT <= kKernelScalars, "one register's worth of scalars per kernel");
 __host__ __device__ constexpr int scale_table_offset() { return vec_offset(V_COUNT); }
+__host__ __device__ constexpr int view_scalars_offset() { return scale_table_offset() + M_COUNT * 4; }
+__host__ __device__ constexpr int ray_scalars_offset() { return view_scalars_offset() + kKernelScalars; }
 __host__ __device__ constexpr int vec_region_floats() { return scale_table_offset() + kScaleFloats - vec_region_offset(); }
 __host__ __device__ constexpr int blob_floats() { return scale_table_offset() + kScaleFloats; }
 __host__ __device__ constexpr int mat_offset(int m) {  // first float of matrix m inside the blob

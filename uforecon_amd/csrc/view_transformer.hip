@@ -37,13 +37,12 @@ __device__ __forceinline__ void zero_tiles(f32x4 (&t)[C][N]) {
 
 // LayerNorm over the 80 features of each token: 5 tiles x 4 regs in each of the 4 lane groups.  t holds raw accumulators
 // (asc = 2^(s_M + a_M) times the values; asc = 1: plain values): the normalised value is scale-free once the epsilon carries
-// the square of the scale, and with a power-of-two scale every intermediate is the exact multiple -- bit-identical to
+// the square of the scale (eps = 1e-5 asc^2, formed once per launch), and with a power-of-two scale every intermediate is the exact multiple -- bit-identical to
 // descaling first.
 // XH / RS (TAPE builds): the normalised input and 1 / sigma of the TRUE values (asc times the raw one), which the
 // backward needs.
 template <int C, int VW, int VB, class WS>
-__device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const WS& ws, int g, float asc, f32x4 (*XH)[5] = nullptr, float* RS = nullptr) {
-  const float eps = 1e-5f * asc * asc;
+__device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const WS& ws, int g, float eps, float asc, f32x4 (*XH)[5] = nullptr, float* RS = nullptr) {
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     float s = 0.f;
@@ -89,8 +88,21 @@ __device__ unsigned long long g_vt_wave[4096 * 2];  // start / end tick of every
     t_prev = t_now;                                                                    \
   }
 #else
-#define UFR_PHASE(i)
+// production builds: optionally a scheduling fence at the phase boundaries (kPhaseFence).  Tried for the straddling L = 6
+// kernel while it ran 15 % slower than it should (the cause was scalar-register pressure: weight_stream_f16.h, ScalarFile):
+// no effect before or after that fix, so both knobs default to off.
+#define UFR_PHASE(i) \
+  { if constexpr (kPhaseFence) __builtin_amdgcn_sched_barrier(0); }
 #endif
+#ifndef UFR_VT_FENCE_ALL
+#define UFR_VT_FENCE_ALL 0
+#endif
+#ifndef UFR_VT_FENCE_STRADDLE
+#define UFR_VT_FENCE_STRADDLE 0
+#endif
+#ifndef UFR_VT_RELOAD_X
+#define UFR_VT_RELOAD_X 0   // 1: the L = 6 kernel re-reads the token rows for the residual (see there); measured 395 -> 444 ms per
+#endif                      // 600x800 / 5-view frame once the scalar pressure was fixed (it had helped before: 434 -> 428)
 constexpr int kVtBlock = UFR_VT_BLOCK;
 constexpr int kVtWaves = kVtBlock / 64;
 
@@ -115,20 +127,18 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
   constexpr bool STRADDLE = (L == 6 && C == 2 && !TAPE);   // the tape's consumers use the plain slot map
   static_assert(!TAPE || kBlockCols % C == 0, "tape blocks");
   constexpr int PPW = STRADDLE ? 5 : PPT * C;         // points per wave iteration
+  constexpr bool kReloadX = STRADDLE && UFR_VT_RELOAD_X;                 // the residual re-reads the token rows (see there)
+  constexpr bool kPhaseFence = (STRADDLE && UFR_VT_FENCE_STRADDLE) || UFR_VT_FENCE_ALL;
+  (void)kPhaseFence;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   auto ws = wstream_f16_begin<kVtWaves, LOWP>(packed, smem);
   wstream_f16_prime<B_VT, kVtWaves>(ws);
   const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
-  // the layers' plane / accumulator scales (ufr_layout.h: scale table), wave-uniform for the whole launch.  q, k, v and
-  // mlp0 all split x: their a_M agree by construction (prep.hip), and the splits use ONE multiplier (xs_x) so that the
+  // the layers' plane / accumulator scales (ufr_layout.h: ViewScalar; weight_stream_f16.h: ScalarFile).  q, k, v and mlp0
+  // all split x: their a_M agree by construction (prep.hip), and the splits use ONE multiplier (VS_XS_X) so that the
   // compiler can merge them (41 of 171 value pairs per iteration).
-  const MatScale zq = mat_scale<M_VT_Q>(ws), zk = mat_scale<M_VT_K>(ws), zv = mat_scale<M_VT_V>(ws), zm = mat_scale<M_VT_MERGE>(ws);
-  const MatScale z0 = mat_scale<M_VT_MLP0>(ws), z2 = mat_scale<M_VT_MLP2>(ws);
-  const MatScale zr0 = mat_scale<M_RW0>(ws), zr2 = mat_scale<M_RW2>(ws), zr4 = mat_scale<M_RW4>(ws);
-  const float xs_x = zq.xs;
-  const float q_l2e = zq.dsc * kLog2e, k_l2e = zk.dsc * kLog2e;
-  const float v_mul = zv.dsc / (float)L;              // values / v_length on raw accumulators: exact when L is a power of two
-  const float v_div = (float)L * zv.asc;              // ... a true division otherwise (L = 6)
+  constexpr bool kLocalScalars = (L == 6 && C == 2 && !TAPE);   // = STRADDLE, defined below
+  const auto sc = scalar_file<kLocalScalars, view_scalars_offset()>(ws);
   // column (c, j) holds token tvv[c] of the wave's point ptw[c] (tvv == 0: view token)
   int ptw[C], tvv[C];
   bool okc[C];
@@ -227,15 +237,12 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     f32x4 x[C][5];
     int pidx[C];
     bool valid[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      pidx[c] = grp * PPW + ptw[c];
-      valid[c] = okc[c] && grp < n_groups && pidx[c] < P;
+    // token columns 0..31 and 72..79 are per (point, view), 32..71 per point: one 80-column row in the public layout,
+    // a 40-column view row plus a 40-column point row in the compact one (ufr_internal.h)
+    // (32-bit element offsets from the scalar bases -- the launcher bounds P: 64-bit per-lane addresses that the
+    // optimiser hoists out of the loop cost this kernel spills it cannot afford)
+    auto load_x = [&](int c, f32x4 (&dst)[5]) __attribute__((always_inline)) {
       const int pp = valid[c] ? pidx[c] : 0;
-      // token columns 0..31 and 72..79 are per (point, view), 32..71 per point: one 80-column row in the public layout,
-      // a 40-column view row plus a 40-column point row in the compact one (ufr_internal.h)
-      // (32-bit element offsets from the scalar bases -- the launcher bounds P: 64-bit per-lane addresses that the
-      // optimiser hoists out of the loop cost this kernel spills it cannot afford)
       const int tv = tvv[c];
       const unsigned vrow = ((unsigned)pp * NV + (tv > 0 ? tv - 1 : 0)) * (x_point ? kViewCols : UFR_TOKEN_DIM);
       const unsigned prow_e = x_point ? (unsigned)pp * kPointCols : vrow + 32;
@@ -247,9 +254,15 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
       for (int t = 0; t < 5; ++t) {
         f32x4 tok = vec_frag<V_VIEW_TOKEN>(ws, t, g);
         f32x4 val = ld4(t < 2 ? row + 16 * t : t < 4 ? prow + 16 * (t - 2) : last);
-        x[c][t] = tv == 0 ? tok : val;                     // ray_transformer.py:284-286
-        if (!valid[c]) x[c][t] = splat4(0.f);
+        dst[t] = tv == 0 ? tok : val;                     // ray_transformer.py:284-286
+        if (!valid[c]) dst[t] = splat4(0.f);
       }
+    };
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      pidx[c] = grp * PPW + ptw[c];
+      valid[c] = okc[c] && grp < n_groups && pidx[c] < P;
+      load_x(c, x[c]);
     }
     track_external(x, ws);
     if constexpr (TAPE) {
@@ -265,6 +278,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     zero_tiles(q); zero_tiles(k);
     {
       BWords<C> cur;
+      const float xs_x = sc[VS_XS_X];
       split_units<0, 0, 4 * C>(x, cur, xs_x);
       static_for<3>([&](auto si) __attribute__((always_inline)) {
         constexpr int s = decltype(si)::value;
@@ -286,13 +300,14 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
       probe_gemm(q, ws);   // q, k stay raw accumulators: elu1_acc descales
       probe_gemm(k, ws);
     }
+    const float q_dsc = sc[VS_Q_DSC], q_l2e = sc[VS_Q_L2E], k_dsc = sc[VS_K_DSC], k_l2e = sc[VS_K_L2E];
     if constexpr (TAPE) {
 #pragma unroll
       for (int c = 0; c < C; ++c)
 #pragma unroll
         for (int t = 0; t < 5; ++t) {
-          tape_st(TV_Q + t, c, f32x4{elu1_acc(q[c][t][0], zq.dsc, q_l2e), elu1_acc(q[c][t][1], zq.dsc, q_l2e), elu1_acc(q[c][t][2], zq.dsc, q_l2e), elu1_acc(q[c][t][3], zq.dsc, q_l2e)});
-          tape_st(TV_K + t, c, f32x4{elu1_acc(k[c][t][0], zk.dsc, k_l2e), elu1_acc(k[c][t][1], zk.dsc, k_l2e), elu1_acc(k[c][t][2], zk.dsc, k_l2e), elu1_acc(k[c][t][3], zk.dsc, k_l2e)});
+          tape_st(TV_Q + t, c, f32x4{elu1_acc(q[c][t][0], q_dsc, q_l2e), elu1_acc(q[c][t][1], q_dsc, q_l2e), elu1_acc(q[c][t][2], q_dsc, q_l2e), elu1_acc(q[c][t][3], q_dsc, q_l2e)});
+          tape_st(TV_K + t, c, f32x4{elu1_acc(k[c][t][0], k_dsc, k_l2e), elu1_acc(k[c][t][1], k_dsc, k_l2e), elu1_acc(k[c][t][2], k_dsc, k_l2e), elu1_acc(k[c][t][3], k_dsc, k_l2e)});
         }
     }
     UFR_PHASE(1)  // q,k GEMMs
@@ -310,8 +325,8 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
           for (int d = 0; d < 10; ++d) {
             const int s = 10 * hh + d;
-            Q[c][d] = elu1_acc(q[c][s >> 2][s & 3], zq.dsc, q_l2e);
-            K[c][d] = elu1_acc(k[c][s >> 2][s & 3], zk.dsc, k_l2e);
+            Q[c][d] = elu1_acc(q[c][s >> 2][s & 3], q_dsc, q_l2e);
+            K[c][d] = elu1_acc(k[c][s >> 2][s & 3], k_dsc, k_l2e);
           }
           float a = 0.f;
 #pragma unroll
@@ -342,8 +357,8 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
         for (int d = 0; d < 10; ++d) {
           const int s = 10 * hh + d;
-          Q[d] = elu1_acc(q[c][s >> 2][s & 3], zq.dsc, q_l2e);
-          K[d] = elu1_acc(k[c][s >> 2][s & 3], zk.dsc, k_l2e);
+          Q[d] = elu1_acc(q[c][s >> 2][s & 3], q_dsc, q_l2e);
+          K[d] = elu1_acc(k[c][s >> 2][s & 3], k_dsc, k_l2e);
         }
         float den = 0.f;
 #define UFR_ATT_STEP(S)                                                  \
@@ -367,8 +382,12 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     UFR_PHASE(2)  // scores
     f32x4 v[C][5];
     zero_tiles(v);
-    gemm_f16<M_VT_V, C, kVtWaves>(ws, x, v, wrap, xs_x);   // raw accumulators: the descale joins the 1 / v_length
+    gemm_f16<M_VT_V, C, kVtWaves>(ws, x, v, wrap, sc[VS_XS_X]);   // raw accumulators: the descale joins the 1 / v_length
     UFR_PHASE(3)  // v GEMM
+    // values / v_length on raw accumulators: one exact multiply when L is a power of two; otherwise (L = 3, 5, 6, 7) a true
+    // division of the descaled value (the power-of-two descale is exact, so this is v / (L 2^(s+a)) bit for bit)
+    const float v_dsc = sc[VS_V_DSC];
+    const float v_mul = v_dsc / (float)L;
     if constexpr (TAPE) {   // values / v_length, exactly as the message phase below forms them
 #pragma unroll
       for (int c = 0; c < C; ++c)
@@ -377,7 +396,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
           f32x4 vv;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            vv[r] = (L & (L - 1)) == 0 ? v[c][t][r] * v_mul : v[c][t][r] / v_div;
+            vv[r] = (L & (L - 1)) == 0 ? v[c][t][r] * v_mul : (v[c][t][r] * v_dsc) / (float)L;
           tape_st(TV_V + t, c, vv);
         }
     }
@@ -391,7 +410,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
           for (int d = 0; d < 10; ++d) {
             const int s = 10 * hh + d;
-            V[c][d] = v[c][s >> 2][s & 3] / v_div;   // values / v_length (L = 6: a true division)
+            V[c][d] = (v[c][s >> 2][s & 3] * v_dsc) / (float)L;   // values / v_length (L = 6: a true division)
             acc[c][d] = A[c][hh][0] * V[c][d];
           }
         static_for<5>([&](auto sti) __attribute__((always_inline)) {
@@ -420,7 +439,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
         for (int d = 0; d < 10; ++d) {
           const int s = 10 * hh + d;
           // values / v_length: exact as a multiply when L is a power of two (NV = 3, 7)
-          V[d] = (L & (L - 1)) == 0 ? v[c][s >> 2][s & 3] * v_mul : v[c][s >> 2][s & 3] / v_div;
+          V[d] = (L & (L - 1)) == 0 ? v[c][s >> 2][s & 3] * v_mul : (v[c][s >> 2][s & 3] * v_dsc) / (float)L;
           acc[d] = 0.f;
         }
 #define UFR_ATT_STEP(S)                                                  \
@@ -453,18 +472,18 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     // ---------------- merge + LayerNorm1 (transformer.py:51-52)
     f32x4 m[C][5];
     zero_tiles(m);
-    gemm_f16<M_VT_MERGE, C, kVtWaves>(ws, msg, m, wrap, zm.xs);
+    gemm_f16<M_VT_MERGE, C, kVtWaves>(ws, msg, m, wrap, sc[VS_M_XS]);
     UFR_PHASE(5)  // merge GEMM
     float rstd1[C] = {}, rstd2[C] = {};
     if constexpr (TAPE) {
       f32x4 xh[C][5];
-      layer_norm80<C, V_VT_N1W, V_VT_N1B>(m, ws, g, zm.asc, xh, rstd1);
+      layer_norm80<C, V_VT_N1W, V_VT_N1B>(m, ws, g, sc[VS_EPS1], sc[VS_M_ASC], xh, rstd1);
 #pragma unroll
       for (int c = 0; c < C; ++c)
 #pragma unroll
         for (int t = 0; t < 5; ++t) { tape_st(TV_XH1 + t, c, xh[c][t]); tape_st(TV_M + t, c, m[c][t]); }
     } else {
-      layer_norm80<C, V_VT_N1W, V_VT_N1B>(m, ws, g, zm.asc);
+      layer_norm80<C, V_VT_N1W, V_VT_N1B>(m, ws, g, sc[VS_EPS1], 1.f);
     }
 
     UFR_PHASE(6)  // LN1
@@ -475,7 +494,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
       for (int t = 0; t < 5; ++t) { cat[c][t] = x[c][t]; cat[c][5 + t] = m[c][t]; }
     zero_tiles(hid);
-    gemm_f16<M_VT_MLP0, C, kVtWaves>(ws, cat, hid, wrap, xs_x);   // hid: raw accumulators through the ReLU
+    gemm_f16<M_VT_MLP0, C, kVtWaves>(ws, cat, hid, wrap, sc[VS_XS_X]);   // hid: raw accumulators through the ReLU
     UFR_PHASE(7)  // MLP0
 #pragma unroll
     for (int c = 0; c < C; ++c)
@@ -487,10 +506,10 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
       for (int c = 0; c < C; ++c)
 #pragma unroll
-        for (int t = 0; t < 10; ++t) tape_st(TV_HID + t, c, hid[c][t] * z0.dsc);
+        for (int t = 0; t < 10; ++t) tape_st(TV_HID + t, c, hid[c][t] * sc[VS_MLP0_DSC]);
     }
     zero_tiles(o);
-    gemm_f16<M_VT_MLP2, C, kVtWaves>(ws, hid, o, wrap, z2.xs * z0.dsc);
+    gemm_f16<M_VT_MLP2, C, kVtWaves>(ws, hid, o, wrap, sc[VS_M_MLP2]);
     // colour / mask / direction of this lane's (point, view): (issued here: hid is dead, so the 10 registers are free, and LayerNorm2 + the token stores cover the latency)
     f32x4 col[C];
     float dcomp[C];
@@ -508,18 +527,30 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     UFR_PHASE(8)  // relu + MLP2
     if constexpr (TAPE) {
       f32x4 xh[C][5];
-      layer_norm80<C, V_VT_N2W, V_VT_N2B>(o, ws, g, z2.asc, xh, rstd2);
+      layer_norm80<C, V_VT_N2W, V_VT_N2B>(o, ws, g, sc[VS_EPS2], sc[VS_MLP2_ASC], xh, rstd2);
 #pragma unroll
       for (int c = 0; c < C; ++c)
 #pragma unroll
         for (int t = 0; t < 5; ++t) tape_st(TV_XH2 + t, c, xh[c][t]);
     } else {
-      layer_norm80<C, V_VT_N2W, V_VT_N2B>(o, ws, g, z2.asc);
+      layer_norm80<C, V_VT_N2W, V_VT_N2B>(o, ws, g, sc[VS_EPS2], 1.f);
     }
+    // the residual.  UFR_VT_RELOAD_X (off): the straddling L = 6 kernel reads the token rows AGAIN here (they are in L2)
+    // instead of keeping 40 registers alive from the top of the iteration -- no spills then, but slower (see the macro)
+    if constexpr (kReloadX) {
 #pragma unroll
-    for (int c = 0; c < C; ++c)
+      for (int c = 0; c < C; ++c) {
+        f32x4 xr[5];
+        load_x(c, xr);
 #pragma unroll
-      for (int t = 0; t < 5; ++t) o[c][t] += x[c][t];
+        for (int t = 0; t < 5; ++t) o[c][t] += xr[t];
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int t = 0; t < 5; ++t) o[c][t] += x[c][t];
+    }
     if constexpr (TAPE) {
 #pragma unroll
       for (int c = 0; c < C; ++c) {
@@ -553,39 +584,40 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
       for (int t = 0; t < 5; ++t) rin[c][t] = o[c][t];
       rin[c][5] = f32x4{dcomp[c], 0.f, 0.f, 0.f};
       ws.bad_out |= __builtin_amdgcn_ballot_w64(dcomp[c] != dcomp[c]);
-      h1[c][0] = vec_frag<V_RW_B0>(ws, 0, g) * zr0.asc;   // biases enter the scaled accumulators (weight_stream_f16.h)
-      h2[c][0] = vec_frag<V_RW_B2>(ws, 0, g) * zr2.asc;
-      lg[c][0] = vec_frag<V_RW_B4>(ws, 0, g) * zr4.asc;
+      h1[c][0] = vec_frag<V_RW_B0>(ws, 0, g) * sc[VS_RW0_ASC];   // biases enter the scaled accumulators (weight_stream_f16.h)
+      h2[c][0] = vec_frag<V_RW_B2>(ws, 0, g) * sc[VS_RW2_ASC];
+      lg[c][0] = vec_frag<V_RW_B4>(ws, 0, g) * sc[VS_RW4_ASC];
     }
-    gemm_f16<M_RW0, C, kVtWaves>(ws, rin, h1, wrap, zr0.xs);
+    gemm_f16<M_RW0, C, kVtWaves>(ws, rin, h1, wrap, sc[VS_RW0_XS]);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) h1[c][0][r] = fmaxf(h1[c][0][r], 0.f);
-    gemm_f16<M_RW2, C, kVtWaves>(ws, h1, h2, wrap, zr2.xs * zr0.dsc);
+    gemm_f16<M_RW2, C, kVtWaves>(ws, h1, h2, wrap, sc[VS_M_RW2]);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) h2[c][0][r] = fmaxf(h2[c][0][r], 0.f);
-    gemm_f16<M_RW4, C, kVtWaves>(ws, h2, lg, wrap, zr4.xs * zr2.dsc);
+    gemm_f16<M_RW4, C, kVtWaves>(ws, h2, lg, wrap, sc[VS_M_RW4]);
     if constexpr (TAPE) {
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        tape_st(TV_H1, c, h1[c][0] * zr0.dsc);
-        tape_st(TV_H2, c, h2[c][0] * zr2.dsc);
+        tape_st(TV_H1, c, h1[c][0] * sc[VS_RW0_DSC]);
+        tape_st(TV_H2, c, h2[c][0] * sc[VS_RW2_DSC]);
         // the logit of column j sits in lane group 0, register 0: every lane group records it
-        tape_st(TV_MISC, c, f32x4{rstd1[c], rstd2[c], __shfl(lg[c][0][0], j) * zr4.dsc, 0.f});
+        tape_st(TV_MISC, c, f32x4{rstd1[c], rstd2[c], __shfl(lg[c][0][0], j) * sc[VS_RW4_DSC], 0.f});
       }
     }
 
     UFR_PHASE(10)  // radiance MLP
+    const float rw4_dsc = sc[VS_RW4_DSC];
     // ---------------- masked softmax over the NV view tokens + colour blend (ray_transformer.py:315-319)
     // logit of token j sits in lane group 0, register 0; lanes of group 0 do the point-local reduction
     if constexpr (STRADDLE) {
       float logit[C], mx[C], e[C], den[C], cr[C], cg[C], cb[C];
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        logit[c] = lg[c][0][0] * zr4.dsc;
+        logit[c] = lg[c][0][0] * rw4_dsc;
         if (col[c][3] == 0.f) logit[c] = -1e9f;
         if (tvv[c] == 0) logit[c] = -INFINITY;  // the view token is not a colour source
         mx[c] = logit[c];
@@ -623,7 +655,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const int tv = tvv[c];
-      float logit = lg[c][0][0] * zr4.dsc;
+      float logit = lg[c][0][0] * rw4_dsc;
       if (col[c][3] == 0.f) logit = -1e9f;
       if (tv == 0) logit = -INFINITY;  // the view token is not a colour source
       float mx = logit;

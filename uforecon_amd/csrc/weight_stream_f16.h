@@ -16,7 +16,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kF16RingBytes = kF16Slots * kF16ChunkFrags * 1024;  // the ring: kF16Slots (3) slots of kF16ChunkFrags (12) KiB
 constexpr int kF16LdsBytes = kF16RingBytes + kVecBytes;
 
-// Split of a value pair into the fp16 planes of m x, m a power of two from the scale table (mat_scale): hi = fp16(m x),
+// Split of a value pair into the fp16 planes of m x, m a power of two from the scale table (ScalarFile): hi = fp16(m x),
 // lo = fp16(m x - hi) -- four v_fma_mix{lo,hi}_f16 (the scaling rides on the conversion's multiplier; m x - hi is exact in
 // fp32).  For a layer's VALUES m = 2^a_M; for a producer's RAW accumulators (2^(s_P + a_P) times the value) m = 2^a_M 2^-(s_P
 // + a_P): the exact descale costs nothing.  (hipcc builds the same arithmetic from C source with 5..7 instructions: it
@@ -29,6 +29,10 @@ constexpr int kF16LdsBytes = kF16RingBytes + kVecBytes;
 #define UFR_RANGE_MODE 1   // 0: no range tracking (timing ablation)
 #endif
 __device__ __forceinline__ void split_pair(float a, float b, float m, unsigned& h, unsigned& l) {
+  if (__builtin_constant_p(a) && __builtin_constant_p(b) && a == 0.f && b == 0.f) {   // padding registers of a tile: the
+    h = l = 0u;                                                                      // compiler cannot fold the asm below
+    return;
+  }
   asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a), "s"(m));
   asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(b), "s"(m));
   asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a), "s"(m), "v"(h));
@@ -228,21 +232,31 @@ __device__ __forceinline__ f32x4 vec_frag(const WS& ws, int t, int g) {
   return ws.vecs[base + t * 4 + g];
 }
 
-// scale table entry of forward matrix M (ufr_layout.h: scale_table_offset), as wave-uniform scalars
-struct MatScale {
-  float xs;    // 2^a_M: multiplier of the layer's input values when they are split into planes
-  float dsc;   // 2^-(s_M + a_M): raw accumulator -> value
-  float asc;   // 2^(s_M + a_M): value -> raw accumulator (biases, epsilons)
-};
-__device__ __forceinline__ float uniform_f32(float v) {
+// A kernel's scalar list (ufr_layout.h: ViewScalar / RayScalar) in ONE vector register: lane k = scalar k; a scalar is
+// taken with v_readlane where it is needed.
+// LOCAL = false: the reads are loop-invariant, the compiler hoists them and the scalars live in scalar registers for the
+// whole launch (22 of them: fine where the kernel has the room).
+// LOCAL = true: every read goes through an opaque copy of the register, so it stays where it is written and the scalar
+// lives for one phase.  The straddling L = 6 view kernel needs this: with 22 more long-lived scalars it spilled 23
+// scalar registers, and the machine scheduler, seeing the scalar pressure above the budget, fell back to its
+// register-saving mode -- which serialised the attention's cross-lane exchanges through a single temporary
+// (339 instead of 53 s_waitcnt lgkmcnt(0) per iteration; the kernel ran 15 % slower).
+__device__ __forceinline__ float uniform_f32(float v) {   // a wave-uniform value into a scalar register
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
-template <int M, class WS>
-__device__ __forceinline__ MatScale mat_scale(const WS& ws) {
-  static_assert(M >= 0 && M < M_COUNT, "forward matrices only: the transposed (bf16) ones carry no scale");
-  constexpr int idx = (scale_table_offset() - vec_region_offset()) / 4 + M;   // constexpr: else the offset walk runs on the device
-  const f32x4 e = ws.vecs[idx];
-  return MatScale{uniform_f32(e[0]), uniform_f32(e[1]), uniform_f32(e[2])};
+template <bool LOCAL>
+struct ScalarFile {
+  float sv;
+  __device__ __forceinline__ float operator[](int k) const {
+    float v = sv;
+    if constexpr (LOCAL) asm volatile("" : "+v"(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
+  }
+};
+template <bool LOCAL, int OFFSET, class WS>
+__device__ __forceinline__ ScalarFile<LOCAL> scalar_file(const WS& ws) {
+  constexpr int base = OFFSET - vec_region_offset();
+  return ScalarFile<LOCAL>{reinterpret_cast<const float*>(ws.vecs)[base + (ws.lane & (kKernelScalars - 1))]};
 }
 
 __device__ __forceinline__ f32x4 mfma_f16(const f16x8& a, const f16x8& b, const f32x4& c) {
@@ -388,10 +402,10 @@ constexpr float kLog2e = 0x1.715476p+0f;
 
 // out += 2^(s_M + a_M) W_M x in over all k-steps of M, probed for the range (probe_gemm); the output stays a RAW
 // accumulator.  in[c][0..NIN) are the producer's fp32 tiles and m the multiplier that turns them into the planes'
-// 2^a_M x: mat_scale<M>.xs for values, xs * (the producer's dsc) for the producer's raw accumulators (ReLU commutes with
+// 2^a_M x: 2^a_M for values, xs * (the producer's dsc) for the producer's raw accumulators (ReLU commutes with
 // the scale; LayerNorm takes raw accumulators with a scaled epsilon, elu / the attention fold the factor into a multiply
 // they do anyway: no layer of the two chains pays for a descale pass).  Callers that start from a bias pass it
-// pre-multiplied by mat_scale<M>.asc (exact).  bf16 matrices (the transposed ones of the backward): no scales, m unused.
+// pre-multiplied by 2^(s_M + a_M) (exact).  bf16 matrices (the transposed ones of the backward): no scales, m unused.
 // The fp16 split of k-step s+1 is interleaved with the MFMAs of k-step s (only step 0's is exposed).
 template <int M, int C, int NWAVES, int STREAM = -1, int NIN, class WS>
 __device__ __forceinline__ void gemm_f16(WS& ws, const f32x4 (&in)[C][NIN], f32x4 (&out)[C][mat_desc(M).n_out],

@@ -111,8 +111,9 @@ int ufr_status_poll_bits(ufr_stream stream, int32_t synchronize, int32_t mask, i
  * contiguous 1 KiB wave loads.  Call again whenever the parameters change. */
 size_t ufr_packed_weights_bytes(void);
 int ufr_weights_pack(const ufr_raw_weights* raw, void* packed, ufr_stream stream);   /* input_abs_max = 256 */
-/* The same for token features bounded by input_abs_max (positive, finite): |x_tokens| of ufr_aggregate /
- * ufr_view_transform, i.e. the magnitude of the frame's feature maps, volumes and pre-similarity features.  The bound
+/* The same for feature maps and volume features bounded by input_abs_max (positive, finite) -- what the encoder hands to
+ * ufr_frame_prepare; for ufr_aggregate / ufr_view_transform callers: columns 0..55 and 72..79 of x_tokens (the 16
+ * pre-similarity columns are bounded from pre_sim_mlp's own weights, the positional columns by 1).  The bound
  * only sets the exponents the activations' planes carry (a pessimistic one costs no accuracy: the planes keep 22
  * significand bits down to 2^-17 of each layer's bound), so state it generously. */
 int ufr_weights_pack_for(const ufr_raw_weights* raw, void* packed, float input_abs_max, ufr_stream stream);

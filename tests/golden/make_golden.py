@@ -49,9 +49,13 @@ CASES = {
     "c4_full_interior": dict(H=600, W=800, NV=5, seed=3, RN=256, coarse=128, fine=128, interior=True, srdf64=True),
     # statistics of a TRAINED checkpoint instead of the default init (the real checkpoint is absent: .MISSING_LARGE_BLOBS):
     # every weight matrix x 8, LayerNorm gains up to 10 and biases in [-1, 1], 2-D feature maps x 30 -- dense-layer inputs
-    # reach ~1e3 (the split-precision planes hold |x| < 4094, |w| < 255.8).  The modified weights travel in the fixture.
+    # reach ~1e3.  The modified weights travel in the fixture.
     "c2_trained_like": dict(H=64, W=96, NV=3, seed=9, RN=128, coarse=64, fine=64, interior=True,
                             trained_like=dict(w=8.0, gamma=10.0, feat=30.0)),
+    # the same far beyond what fixed plane exponents could hold: every matrix x 64, feature maps x 300 (dense-layer inputs
+    # reach ~1e6; round 4's per-matrix / per-layer exponents, ufr_weights_pack_for)
+    "c2_trained_like_x64": dict(H=64, W=96, NV=3, seed=9, RN=128, coarse=64, fine=64, interior=True,
+                                trained_like=dict(w=64.0, gamma=10.0, feat=300.0)),
 }
 
 

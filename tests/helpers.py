@@ -25,6 +25,8 @@ CASES = {
     "c4_full_interior": dict(H=600, W=800, NV=5, seed=3, RN=256, coarse=128, fine=128, interior=True, srdf64=True),
     "c2_trained_like": dict(H=64, W=96, NV=3, seed=9, RN=128, coarse=64, fine=64, interior=True,
                             trained_like=dict(w=8.0, gamma=10.0, feat=30.0)),
+    "c2_trained_like_x64": dict(H=64, W=96, NV=3, seed=9, RN=128, coarse=64, fine=64, interior=True,
+                                trained_like=dict(w=64.0, gamma=10.0, feat=300.0)),
 }
 
 # same table as tests/golden/make_golden.py:GRAD_CASES (reference autograd of the training loss)

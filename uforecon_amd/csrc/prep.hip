@@ -90,7 +90,8 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(RawPtrs raw, const in
 // Per forward matrix: max |w| and the infinity norm (largest absolute row sum); per vector parameter: max |.|
 // (weight_stats_kernel).  One thread then walks the two layer chains once, carrying an upper bound of every dense
 // layer's input (weight_scale_kernel):
-//   projections     |x| <= X (the caller's bound of the token features; the learned view token counts)
+//   projections     |x| <= X = max(the caller's bound of the feature maps / volume features, the learned view token, the
+//                   bound of pre_sim_mlp's output on cosine similarities in [-1, 1])
 //   attention       the message is a (sub-)convex combination of the values (the scores Q'.K' are positive):
 //                   |msg| <= |v| <= ||W_v||_inf X
 //   LayerNorm       |(x - mean) / sigma| <= sqrt(D - 1), so |out| <= max|gamma| sqrt(D - 1) + max|beta|
@@ -112,11 +113,27 @@ __device__ int plane_exponent(float bound, int lo, int hi) {
 // first kernel: one workgroup per matrix (its max |w| and infinity norm) and per vector parameter (max |.|); the numbers
 // go to the table's own tail (the kernels' scalar lists, which the second kernel overwrites after reading them) --
 // training re-packs after every optimizer step, a single workgroup walking all 33 parameters took 0.3 ms
-constexpr int kStatVecs = 15;
+constexpr int kStatVecs = 18;
 __device__ constexpr int kStatVecParam[kStatVecs][2] = {{P_VT_N1W, 80}, {P_VT_N1B, 80}, {P_VT_N2W, 80}, {P_VT_N2B, 80}, {P_RT_N1W, 88},
                                                         {P_RT_N1B, 88}, {P_RT_N2W, 88}, {P_RT_N2B, 88}, {P_DM_B0, 32}, {P_DM_B2, 16},
-                                                        {P_DM_B4, 1}, {P_RW_B0, 16}, {P_RW_B2, 8}, {P_RW_B4, 1}, {P_VIEW_TOKEN, 80}};
-static_assert(2 * M_COUNT + kStatVecs <= 2 * kKernelScalars, "the statistics borrow the scalar lists' floats");
+                                                        {P_DM_B4, 1}, {P_RW_B0, 16}, {P_RW_B2, 8}, {P_RW_B4, 1}, {P_VIEW_TOKEN, 80},
+                                                        {P_PS_B0, 32}, {P_PS_B2, 32}, {P_PS_B4, 16}};
+// statistics "matrices": the M_COUNT dense matrices of the two transformers, then the three layers of pre_sim_mlp (8 -> 32
+// -> 32 -> 16, evaluated in fp32 by the gather kernel: only their infinity norms matter -- they bound the 16 pre-similarity
+// features among the token inputs)
+constexpr int kStatMats = M_COUNT + 3;
+__device__ inline void stat_mat(int b, int* param, int* k_raw, int* out_dim) {
+  if (b < M_COUNT) {
+    const MatDesc d = mat_desc(b);
+    *param = d.param; *k_raw = d.k_raw; *out_dim = d.out_dim;
+  } else {
+    *param = b == M_COUNT ? P_PS_W0 : b == M_COUNT + 1 ? P_PS_W2 : P_PS_W4;
+    *k_raw = b == M_COUNT ? 8 : 32;
+    *out_dim = b == M_COUNT + 2 ? 16 : 32;
+  }
+}
+// layout of the statistics: max |w| [kStatMats] | infinity norm [kStatMats] | vector maxima [kStatVecs]
+static_assert(2 * kStatMats + kStatVecs <= 2 * kKernelScalars, "the statistics borrow the scalar lists' floats");
 constexpr int kStatThreads = 1024;
 __global__ void __launch_bounds__(kStatThreads) weight_stats_kernel(RawPtrs raw, float* __restrict__ stats, int* __restrict__ flag) {
   __shared__ float red[3][kStatThreads / 64];
@@ -124,8 +141,9 @@ __global__ void __launch_bounds__(kStatThreads) weight_stats_kernel(RawPtrs raw,
   const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float m = 0.f, rs = 0.f;
   bool nf = false;
-  if (b < M_COUNT) {
-    const MatDesc d = mat_desc(b);
+  if (b < kStatMats) {
+    struct { int param, k_raw, out_dim; } d;
+    stat_mat(b, &d.param, &d.k_raw, &d.out_dim);
     const float4* w4 = reinterpret_cast<const float4*>(raw.p[d.param]);
     for (int r = threadIdx.x; r < d.out_dim; r += kStatThreads) rowsum[r] = 0.f;
     __syncthreads();
@@ -162,7 +180,7 @@ __global__ void __launch_bounds__(kStatThreads) weight_stats_kernel(RawPtrs raw,
     __syncthreads();
     for (int r = threadIdx.x; r < d.out_dim; r += kStatThreads) rs = fmaxf(rs, rowsum[r]);
   } else {
-    const int v = b - M_COUNT;
+    const int v = b - kStatMats;
     const float* p = raw.p[kStatVecParam[v][0]];
     for (int i = threadIdx.x; i < kStatVecParam[v][1]; i += kStatThreads) {
       const float a = fabsf(p[i]);
@@ -183,8 +201,8 @@ __global__ void __launch_bounds__(kStatThreads) weight_stats_kernel(RawPtrs raw,
 #pragma unroll
     for (int i = 1; i < kStatThreads / 64; ++i) r = fmaxf(r, red[threadIdx.x][i]);
     if (threadIdx.x == 0 && r != 0.f) atomicOr(flag, 4);
-    if (threadIdx.x == 1) stats[b < M_COUNT ? b : 2 * M_COUNT + (b - M_COUNT)] = r;
-    if (threadIdx.x == 2 && b < M_COUNT) stats[M_COUNT + b] = r;
+    if (threadIdx.x == 1) stats[b < kStatMats ? b : 2 * kStatMats + (b - kStatMats)] = r;
+    if (threadIdx.x == 2 && b < kStatMats) stats[kStatMats + b] = r;
   }
 }
 
@@ -201,24 +219,28 @@ __global__ void __launch_bounds__(64) weight_scale_kernel(float* __restrict__ ta
   for (int i = threadIdx.x; i < kScaleFloats; i += 64) table_out[i] = table[i];
 }
 __device__ void weight_scale_chain(const float* stats, float* table, float x_max, int* __restrict__ flag, int fixed) {
-  float wmax[M_COUNT], ninf[M_COUNT], vmax[P_COUNT];
+  float wmax[kStatMats], ninf[kStatMats], vmax[P_COUNT];
   bool bad = false;
   // (every loop below is unrolled: the arrays are indexed with constants and stay in registers -- as private memory they
   // cost a 50 us kernel)
 #pragma unroll
-  for (int m = 0; m < M_COUNT; ++m) {
+  for (int m = 0; m < kStatMats; ++m) {
     wmax[m] = stats[m];
-    ninf[m] = stats[M_COUNT + m];
+    ninf[m] = stats[kStatMats + m];
     bad |= !(wmax[m] <= 3.0e38f) || !(ninf[m] <= 3.0e38f);
   }
 #pragma unroll
   for (int v = 0; v < kStatVecs; ++v) {
-    vmax[kStatVecParam[v][0]] = stats[2 * M_COUNT + v];
-    bad |= !(stats[2 * M_COUNT + v] <= 3.0e38f);
+    vmax[kStatVecParam[v][0]] = stats[2 * kStatMats + v];
+    bad |= !(stats[2 * kStatMats + v] <= 3.0e38f);
   }
   bad |= !(x_max > 0.f && x_max <= 3.0e38f);
   float in[M_COUNT];
-  const float X = fmaxf(x_max, vmax[P_VIEW_TOKEN]);
+  // the token features: what the caller bounds (feature maps, volume features: x_max), the learned view token, and the 16
+  // pre-similarity features = pre_sim_mlp of 8 mean cosine similarities in [-1, 1]
+  const float ps1 = ninf[M_COUNT] + vmax[P_PS_B0], ps2 = ninf[M_COUNT + 1] * ps1 + vmax[P_PS_B2];
+  const float ps3 = ninf[M_COUNT + 2] * ps2 + vmax[P_PS_B4];
+  const float X = fmaxf(fmaxf(x_max, vmax[P_VIEW_TOKEN]), ps3);
   // q, k, v and mlp0 (whose input is [x | LayerNorm1 output]) all split the token x: ONE exponent for the four, so the
   // kernels split x once per phase with the same multiplier (and the compiler merges the repeats)
   const float vm = vmax[P_VT_N1W] * sqrtf(79.f) + vmax[P_VT_N1B];
@@ -358,7 +380,7 @@ hipError_t launch_pack_weights(const RawPtrs& raw, float* packed, float input_ab
   constexpr int table_at = scale_table_offset(), stats_at = view_scalars_offset();
   float* table = packed + table_at;
   static const int fixed = [] { const char* e = getenv("UFR_DEBUG_FIXED_SCALES"); return (e && e[0] == '1') ? 1 : 0; }();
-  hipLaunchKernelGGL(weight_stats_kernel, dim3(M_COUNT + kStatVecs), dim3(kStatThreads), 0, s, raw,
+  hipLaunchKernelGGL(weight_stats_kernel, dim3(kStatMats + kStatVecs), dim3(kStatThreads), 0, s, raw,
                      packed + stats_at, range_flag);
   hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(64), 0, s, table, input_abs_max, range_flag, fixed);
   unsigned short* planes = reinterpret_cast<unsigned short*>(packed + n);

@@ -85,8 +85,8 @@ def status_poll(synchronize: bool = True, mask: int = 7) -> int:
 class PackedWeights:
     """ufr_raw_weights (pointers into the live parameters) + the MFMA-ordered packed copy.  ``precision``: the matrix
     precision the calls made with these weights use (None = the process default at call time).  ``input_abs_max``: an
-    upper bound of the token features these weights will meet (feature maps, volume features, pre-similarity features;
-    None = the library default, 256) -- it sets the exponents of the activations' fp16 planes (ufr_weights_pack_for);
+    upper bound of the feature maps and volume features these weights will meet (the pre-similarity features are
+    bounded from pre_sim_mlp's own weights; None = the library default, 256) -- it sets the exponents of the activations' fp16 planes (ufr_weights_pack_for);
     weights of any finite magnitude pack without further ado."""
 
     def __init__(self, params: Dict[str, torch.Tensor], precision: Optional[int] = None,

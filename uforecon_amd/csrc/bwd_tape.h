@@ -38,7 +38,9 @@ enum ViewTape : int {
   TV_Y = 50,       // 6  layer output y (5) | dir (tile 5: register 0 of lane groups 0..2 = COL_RW0)     (bf16)
   TV_H1 = 56,      // 1  relu(rw0)                                                                        (bf16)
   TV_H2 = 57,      // 1  relu(rw2), rows 0..7                                                             (bf16)
-  TV_MISC = 58,    // 1  per column: {rstd1, rstd2, logit (before the mask), 0} in every lane group
+  TV_MISC = 58,    // 1  {ReLU bits 0..31, bits 32..47, a, b}: bit 4 t + r = hidden unit (t, r) of this lane > 0 for t < 10, then h1
+                   //    (40..43), h2 (44..47); (a, b) = (rstd1, rstd2) of the column in lane group 0, (logit before the mask, 0)
+                   //    in lane group 1 -- the data-gradient kernel reads masks, not the hidden activations
   TV_COUNT = 59
 };
 // ---- view transformer cotangents (A2 = view_dgrad_kernel); all bf16 in 16-bit mode except the scratch tiles
@@ -52,8 +54,9 @@ enum ViewGrad : int {
   DV_H1 = 35,      // 1  d (rw0 output, after the mask)
   DV_H2 = 36,      // 1  d (rw2 output, after the mask), rows 0..7
   DV_LG = 37,      // 1  d logit in row 0
-  DV_SCR = 38,     // 5  the data-gradient kernel's own scratch: the parts of d x that wait for the projections' share (fp32)
-  DV_COUNT = 43
+  DV_SCR = 38,     // 5  the data-gradient kernel's own scratch: the parts of d x that wait for the projections' share (fp32):
+  DV_SCR2 = 43,    // 5  d y (residual) in the first set, the x half of d cat in the second
+  DV_COUNT = 48
 };
 
 template <bool LOWP>
@@ -112,8 +115,10 @@ enum RayGrad : int {
   DR_D1 = 45,      // 2  d (dm0 output, masked)
   DR_D2 = 47,      // 1  d (dm2 output, masked)
   DR_SR = 48,      // 1  d srdf in row 0
-  DR_SCR = 49,     // 6  scratch: d x parts of sweep 1 waiting for sweep 2 (fp32)
-  DR_COUNT = 55
+  DR_SCR = 49,     // 6  scratch: the d x parts of sweep 1 waiting for sweep 2 (fp32): d o (residual),
+  DR_SCR2 = 55,    // 6  the x half of d cat,
+  DR_SCR3 = 61,    // 6  the query projection's share
+  DR_COUNT = 67
 };
 template <bool LOWP>
 struct RayTapeLayout {

@@ -135,7 +135,6 @@ __global__ void __launch_bounds__(kRdBlock, 2) ray_dgrad_kernel(const float* __r
     auto dy_st = [&](int tile, f32x4 v) __attribute__((always_inline)) {
       if (valid) tile_store<GradL>(dy_blk, tile, c, lane, v);       // a padding tile's cotangents are written too: zeros
     };
-    auto dy_ld = [&](int tile) __attribute__((always_inline)) -> f32x4 { return tile_load<GradL>(dy_blk, tile, c, lane); };
 
     const f32x4 misc = tape_ld(RT_MISC);
     const float rstd1 = misc[0], rstd2 = misc[1];
@@ -169,12 +168,15 @@ __global__ void __launch_bounds__(kRdBlock, 2) ray_dgrad_kernel(const float* __r
     // ---------------- LayerNorm2 backwards (transformer.py:56-58); o = x + LN2(opre): d x starts as d o (parked in DR_SCR)
     f32x4 dopre[C][6];
     {
+      // (loads before stores, and no read-modify-write of the scratch tiles: view_dgrad.hip on the order of memory operations)
       f32x4 xh[6], gy[6], dgam[6];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
+      for (int t = 0; t < 6; ++t) xh[t] = tape_ld(RT_XH2 + t);
+#pragma unroll
+      for (int t = 0; t < 6; ++t) dy_st(DR_SCR + t, dout[0][t]);
+#pragma unroll
       for (int t = 0; t < 6; ++t) {
-        dy_st(DR_SCR + t, dout[0][t]);
-        xh[t] = tape_ld(RT_XH2 + t);
         dgam[t] = dout[0][t] * xh[t];
         gy[t] = dout[0][t] * vec_frag<V_RT_N2W>(ws, t, g);        // gamma is zero in the padding slots
 #pragma unroll
@@ -215,9 +217,11 @@ __global__ void __launch_bounds__(kRdBlock, 2) ray_dgrad_kernel(const float* __r
       f32x4 xh[6], gm[6], dgam[6], dbet[6];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
+      for (int t = 0; t < 6; ++t) xh[t] = tape_ld(RT_XH1 + t);
+#pragma unroll
+      for (int t = 0; t < 6; ++t) dy_st(DR_SCR2 + t, dcat[0][t]);   // a second scratch set: sweep 2 adds the three up
+#pragma unroll
       for (int t = 0; t < 6; ++t) {
-        dy_st(DR_SCR + t, dcat[0][t] + dy_ld(DR_SCR + t));       // this lane wrote the tile itself
-        xh[t] = tape_ld(RT_XH1 + t);
         dbet[t] = dcat[0][6 + t];
         dgam[t] = dbet[t] * xh[t];
         gm[t] = dbet[t] * vec_frag<V_RT_N1W>(ws, t, g);
@@ -288,7 +292,7 @@ __global__ void __launch_bounds__(kRdBlock, 2) ray_dgrad_kernel(const float* __r
     for (int t = 0; t < 6; ++t) dx[0][t] = splat4(0.f);
     gemm_f16<M_RT_QT, C, kRdWaves>(ws, dq, dx, wrap);
 #pragma unroll
-    for (int t = 0; t < 6; ++t) dy_st(DR_SCR + t, dx[0][t] + dy_ld(DR_SCR + t));
+    for (int t = 0; t < 6; ++t) dy_st(DR_SCR3 + t, dx[0][t]);
     wstream_f16_finish<B_RTB1, kRdWaves>(ws, wrap);
   }
 
@@ -369,7 +373,8 @@ __global__ void __launch_bounds__(kRdBlock, 2) ray_dgrad_kernel(const float* __r
       float* pa = d_tok_a + row * UFR_TOKEN_DIM + 4 * g;
 #pragma unroll
       for (int t = 0; t < 5; ++t) {
-        f32x4 v = dx[0][t] + tile_load<GradL>(dy_blk, DR_SCR + t, c, lane);
+        f32x4 v = dx[0][t] + (tile_load<GradL>(dy_blk, DR_SCR + t, c, lane) + tile_load<GradL>(dy_blk, DR_SCR2 + t, c, lane)) +
+                  tile_load<GradL>(dy_blk, DR_SCR3 + t, c, lane);
         if (accumulate) v += ld4(pa + 16 * t);
         st4(pa + 16 * t, v);
       }

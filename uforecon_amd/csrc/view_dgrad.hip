@@ -157,12 +157,23 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
     }
 
     // ---------------- masked softmax over the views and its adjoint (ray_transformer.py:315-319): d logit of this column
+    // (memory-operation order, here and below: vmcnt counts loads AND stores in issue order on gfx950, so a load issued
+    // after a tile store cannot be waited for without waiting for that store's round trip to HBM.  Every phase therefore
+    // issues its tape loads first and its dY stores last, and the ReLU derivatives come from the bit masks of TV_MISC
+    // instead of 22 more tile loads: as "load, wait, mask, store" per tile the kernel spent 3/4 of its time in s_waitcnt.)
     float rstd1[C], rstd2[C], dl[C];
+    unsigned bits0[C], bits1[C];
+    f32x4 miscv[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) miscv[c] = tape_ld(TV_MISC, c);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      const f32x4 misc = tape_ld(TV_MISC, c);
-      rstd1[c] = misc[0];
-      rstd2[c] = misc[1];
+      const float m0 = miscv[c][0], m1 = miscv[c][1], m2 = miscv[c][2], m3 = miscv[c][3];   // (scalars first: hipcc mis-reads
+      bits0[c] = __builtin_bit_cast(unsigned, m0);                                          //  a vector ELEMENT in bit_cast)
+      bits1[c] = __builtin_bit_cast(unsigned, m1);
+      rstd1[c] = __shfl(m2, j);            // lane group 0 holds (rstd1, rstd2) of column j, lane group 1 (logit, 0)
+      rstd2[c] = __shfl(m3, j);
+      const float logit_raw = __shfl(m2, 16 + j);
       f32x4 col = splat4(0.f);
       float cd = 0.f;                                  // colour . d radiance of this (point, view)
       if (valid[c] && tv[c] > 0) {
@@ -170,7 +181,7 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
         const float* dr = d_radiance + (size_t)pidx[c] * 3;
         cd = col[0] * dr[0] + col[1] * dr[1] + col[2] * dr[2];
       }
-      float logit = misc[2];
+      float logit = logit_raw;
       if (col[3] == 0.f) logit = -1e9f;
       if (tv[c] == 0) logit = -INFINITY;               // the view token is not a colour source
       float mx = logit;
@@ -195,9 +206,9 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
     f32x4 dh2[C][1], dh1[C][1], dy[C][5];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      const f32x4 h2 = tape_ld(TV_H2, c), w4 = vec_frag<V_RW_W4>(ws, 0, g);   // rows 4g + r; rows >= 8 are zero
+      const f32x4 w4 = vec_frag<V_RW_W4>(ws, 0, g);   // rows 4g + r; rows >= 8 are zero
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dh2[c][0][r] = h2[r] > 0.f ? w4[r] * dl[c] : 0.f;
+      for (int r = 0; r < 4; ++r) dh2[c][0][r] = ((bits1[c] >> (12 + r)) & 1u) ? w4[r] * dl[c] : 0.f;
       dy_st(DV_LG, c, f32x4{g == 0 ? dl[c] : 0.f, 0.f, 0.f, 0.f});
       dy_st(DV_H2, c, dh2[c][0]);
       dh1[c][0] = splat4(0.f);
@@ -205,9 +216,8 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
     gemm_f16<M_RW2T, C, kVdWaves>(ws, dh2, dh1, wrap);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      const f32x4 h1 = tape_ld(TV_H1, c);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dh1[c][0][r] = h1[r] > 0.f ? dh1[c][0][r] : 0.f;
+      for (int r = 0; r < 4; ++r) dh1[c][0][r] = ((bits1[c] >> (8 + r)) & 1u) ? dh1[c][0][r] : 0.f;
       dy_st(DV_H1, c, dh1[c][0]);
 #pragma unroll
       for (int t = 0; t < 5; ++t) dy[c][t] = splat4(0.f);
@@ -230,29 +240,35 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
     // ---------------- LayerNorm2 backwards (transformer.py:56-58): y = x + LN2(opre), so d x starts as d y (parked in DV_SCR)
     f32x4 dopre[C][5];
     f32x4 dgam[5], dbet[5];     // d gamma2 = sum_t d y xhat2, d beta2 = sum_t d y: summed over the column tiles, then the lanes
+    {
+      f32x4 xh[C][5];
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-      f32x4 xh[5], gy[5];
-      float s1 = 0.f, s2 = 0.f;
+      for (int c = 0; c < C; ++c)
 #pragma unroll
-      for (int t = 0; t < 5; ++t) {
-        dy_st(DV_SCR + t, c, dy[c][t]);
-        xh[t] = tape_ld(TV_XH2 + t, c);
-        dgam[t] = c == 0 ? dy[c][t] * xh[t] : dgam[t] + dy[c][t] * xh[t];
-        dbet[t] = c == 0 ? dy[c][t] : dbet[t] + dy[c][t];
-        gy[t] = dy[c][t] * vec_frag<V_VT_N2W>(ws, t, g);
+        for (int t = 0; t < 5; ++t) xh[c][t] = tape_ld(TV_XH2 + t, c);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          s1 += gy[t][r];
-          s2 = fmaf(gy[t][r], xh[t][r], s2);
+      for (int c = 0; c < C; ++c) {
+        f32x4 gy[5];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+          dgam[t] = c == 0 ? dy[c][t] * xh[c][t] : dgam[t] + dy[c][t] * xh[c][t];
+          dbet[t] = c == 0 ? dy[c][t] : dbet[t] + dy[c][t];
+          gy[t] = dy[c][t] * vec_frag<V_VT_N2W>(ws, t, g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            s1 += gy[t][r];
+            s2 = fmaf(gy[t][r], xh[c][t][r], s2);
+          }
         }
-      }
-      const float m1 = sum_groups(s1) * (1.f / 80.f), m2 = sum_groups(s2) * (1.f / 80.f);
+        const float m1 = sum_groups(s1) * (1.f / 80.f), m2 = sum_groups(s2) * (1.f / 80.f);
 #pragma unroll
-      for (int t = 0; t < 5; ++t) {
-        dopre[c][t] = (gy[t] - m1 - xh[t] * m2) * rstd2[c];
-        dy_st(DV_OPRE + t, c, dopre[c][t]);
+        for (int t = 0; t < 5; ++t) dopre[c][t] = (gy[t] - m1 - xh[c][t] * m2) * rstd2[c];
       }
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int t = 0; t < 5; ++t) { dy_st(DV_SCR + t, c, dy[c][t]); dy_st(DV_OPRE + t, c, dopre[c][t]); }
     }
     reduce_acc80(dgam, a_n2w, j);       // (idle / padding columns carry zeros)
     reduce_acc80(dbet, a_n2b, j);
@@ -268,9 +284,11 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
     for (int c = 0; c < C; ++c)
 #pragma unroll
       for (int t = 0; t < 10; ++t) {
-        const f32x4 h = tape_ld(TV_HID + t, c);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dhid[c][t][r] = h[r] > 0.f ? dhid[c][t][r] : 0.f;
+        for (int r = 0; r < 4; ++r) {
+          const unsigned on = t < 8 ? (bits0[c] >> (4 * t + r)) & 1u : (bits1[c] >> (4 * (t - 8) + r)) & 1u;
+          dhid[c][t][r] = on ? dhid[c][t][r] : 0.f;
+        }
         dy_st(DV_HID + t, c, dhid[c][t]);
       }
     f32x4 dcat[C][10];
@@ -279,33 +297,39 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
 #pragma unroll
       for (int t = 0; t < 10; ++t) dcat[c][t] = splat4(0.f);
     gemm_f16<M_VT_MLP0T, C, kVdWaves>(ws, dhid, dcat, wrap);
-    // the x half of d cat joins d y in the scratch tiles (the attention phase below needs the registers; this lane wrote the
-    // tile itself, so the load is ordered behind its store), the message half goes on
+    // the x half of d cat is parked in a second set of scratch tiles (the attention phase below needs the registers; the
+    // output phase adds both sets to the projections' share), the message half goes on
     f32x4 dmpre[C][5];
+    {
+      f32x4 xh[C][5];
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-      f32x4 xh[5], gm[5];
-      float s1 = 0.f, s2 = 0.f;
+      for (int c = 0; c < C; ++c)
 #pragma unroll
-      for (int t = 0; t < 5; ++t) {
-        dy_st(DV_SCR + t, c, dcat[c][t] + dy_ld(DV_SCR + t, c));
-        xh[t] = tape_ld(TV_XH1 + t, c);
-        dgam[t] = c == 0 ? dcat[c][5 + t] * xh[t] : dgam[t] + dcat[c][5 + t] * xh[t];
-        dbet[t] = c == 0 ? dcat[c][5 + t] : dbet[t] + dcat[c][5 + t];
-        gm[t] = dcat[c][5 + t] * vec_frag<V_VT_N1W>(ws, t, g);
+        for (int t = 0; t < 5; ++t) xh[c][t] = tape_ld(TV_XH1 + t, c);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          s1 += gm[t][r];
-          s2 = fmaf(gm[t][r], xh[t][r], s2);
+      for (int c = 0; c < C; ++c) {
+        f32x4 gm[5];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+          dgam[t] = c == 0 ? dcat[c][5 + t] * xh[c][t] : dgam[t] + dcat[c][5 + t] * xh[c][t];
+          dbet[t] = c == 0 ? dcat[c][5 + t] : dbet[t] + dcat[c][5 + t];
+          gm[t] = dcat[c][5 + t] * vec_frag<V_VT_N1W>(ws, t, g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            s1 += gm[t][r];
+            s2 = fmaf(gm[t][r], xh[c][t][r], s2);
+          }
         }
-      }
-      // ---------------- LayerNorm1 backwards (transformer.py:52)
-      const float m1 = sum_groups(s1) * (1.f / 80.f), m2 = sum_groups(s2) * (1.f / 80.f);
+        // ---------------- LayerNorm1 backwards (transformer.py:52)
+        const float m1 = sum_groups(s1) * (1.f / 80.f), m2 = sum_groups(s2) * (1.f / 80.f);
 #pragma unroll
-      for (int t = 0; t < 5; ++t) {
-        dmpre[c][t] = (gm[t] - m1 - xh[t] * m2) * rstd1[c];
-        dy_st(DV_MPRE + t, c, dmpre[c][t]);
+        for (int t = 0; t < 5; ++t) dmpre[c][t] = (gm[t] - m1 - xh[c][t] * m2) * rstd1[c];
       }
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int t = 0; t < 5; ++t) { dy_st(DV_SCR2 + t, c, dcat[c][t]); dy_st(DV_MPRE + t, c, dmpre[c][t]); }
     }
     reduce_acc80(dgam, a_n1w, j);
     reduce_acc80(dbet, a_n1b, j);
@@ -322,11 +346,11 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
     //   d r_s = Zs d msg_s;  d den_s = -(d msg_s . r_s) Zs^2 / L;  d A[s][s'] = d r_s . V_s' + d den_s
     //   d Q'_s = sum_s' d A[s][s'] K'_s';  d K'_s' = sum_s d A[s][s'] Q'_s;  d V_s' = sum_s A[s][s'] d r_s
     f32x4 dq[C][5], dk[C][5], dv[C][5];
+    f32x4 qt[5], kt[5], vt[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) { qt[t] = tape_ld(TV_Q + t, 0); kt[t] = tape_ld(TV_K + t, 0); vt[t] = tape_ld(TV_V + t, 0); }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      f32x4 qt[5], kt[5], vt[5];
-#pragma unroll
-      for (int t = 0; t < 5; ++t) { qt[t] = tape_ld(TV_Q + t, c); kt[t] = tape_ld(TV_K + t, c); vt[t] = tape_ld(TV_V + t, c); }
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         float Q[10], K[10], V[10], dm[10];
@@ -384,6 +408,10 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
           dv[c][s >> 2][s & 3] = dV[d] * (1.f / (float)L);              // values = v / L (linear_attention.py:41)
         }
       }
+      if (c + 1 < C) {            // the next column tile's Q', K', V: issued before this one's stores
+#pragma unroll
+        for (int t = 0; t < 5; ++t) { qt[t] = tape_ld(TV_Q + t, c + 1); kt[t] = tape_ld(TV_K + t, c + 1); vt[t] = tape_ld(TV_V + t, c + 1); }
+      }
 #pragma unroll
       for (int t = 0; t < 5; ++t) { dy_st(DV_Q + t, c, dq[c][t]); dy_st(DV_K + t, c, dk[c][t]); dy_st(DV_V + t, c, dv[c][t]); }
     }
@@ -406,7 +434,7 @@ __global__ void __launch_bounds__(kVdBlock, 2) view_dgrad_kernel(const float* __
     for (int c = 0; c < C; ++c) {
 #pragma unroll
       for (int t = 0; t < 5; ++t) {
-        dx[c][t] += dy_ld(DV_SCR + t, c);
+        dx[c][t] += dy_ld(DV_SCR + t, c) + dy_ld(DV_SCR2 + t, c);
         const f32x4 v0 = (valid[c] && tv[c] == 0) ? dx[c][t] : splat4(0.f);
         dtok[t] = c == 0 ? v0 : dtok[t] + v0;
       }

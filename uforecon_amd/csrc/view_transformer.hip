@@ -502,11 +502,17 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
       for (int t = 0; t < 10; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) hid[c][t][r] = fmaxf(hid[c][t][r], 0.f);
+    unsigned relu_bits[C][2] = {};   // TAPE: bit 4 t + r <-> hidden unit (t, r) of this lane is active; then h1 (40..43), h2 (44..47)
     if constexpr (TAPE) {
 #pragma unroll
       for (int c = 0; c < C; ++c)
 #pragma unroll
-        for (int t = 0; t < 10; ++t) tape_st(TV_HID + t, c, hid[c][t] * sc[VS_MLP0_DSC]);
+        for (int t = 0; t < 10; ++t) {
+          tape_st(TV_HID + t, c, hid[c][t] * sc[VS_MLP0_DSC]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (hid[c][t][r] > 0.f) relu_bits[c][(4 * t + r) >> 5] |= 1u << ((4 * t + r) & 31);
+        }
     }
     zero_tiles(o);
     gemm_f16<M_VT_MLP2, C, kVtWaves>(ws, hid, o, wrap, sc[VS_M_MLP2]);
@@ -604,8 +610,16 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
       for (int c = 0; c < C; ++c) {
         tape_st(TV_H1, c, h1[c][0] * sc[VS_RW0_DSC]);
         tape_st(TV_H2, c, h2[c][0] * sc[VS_RW2_DSC]);
-        // the logit of column j sits in lane group 0, register 0: every lane group records it
-        tape_st(TV_MISC, c, f32x4{rstd1[c], rstd2[c], __shfl(lg[c][0][0], j) * sc[VS_RW4_DSC], 0.f});
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (h1[c][0][r] > 0.f) relu_bits[c][1] |= 1u << (8 + r);
+          if (h2[c][0][r] > 0.f) relu_bits[c][1] |= 1u << (12 + r);
+        }
+        // bwd_tape.h: TV_MISC = {this lane's ReLU bits (2 words), per-column scalars}: lane group 0 carries (rstd1, rstd2),
+        // lane group 1 (logit, 0) -- the logit of column j sits in lane group 0, register 0 of lg
+        const float lgt = __shfl(lg[c][0][0], j) * sc[VS_RW4_DSC];
+        tape_st(TV_MISC, c, f32x4{__builtin_bit_cast(float, relu_bits[c][0]), __builtin_bit_cast(float, relu_bits[c][1]),
+                                  g == 0 ? rstd1[c] : g == 1 ? lgt : 0.f, g == 0 ? rstd2[c] : 0.f});
       }
     }
 

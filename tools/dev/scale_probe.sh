@@ -1,9 +1,7 @@
-run() { python bench.py --steps 2 --warmup 1 --no-secondary --no-cpu-baseline --no-gpu-eager-baseline $ARGS 2>/dev/null | python -c "
-import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['config']['kernel_ms_per_frame_rank0']; print('$1', round(d['ms_per_step'],1), round(k['view_transformer'],1), round(k['ray_transformer'],1))"; }
-ARGS="--height 600 --width 800 --views 5 --coarse 128 --fine 128"
-run NEW
-for v in nf nr nfr; do UFR_LIB=$PWD/uforecon_amd/lib/libufr_$v.so run $v; done
-(cd _old_tree && run OLD)
-run NEW
-for v in nf nr nfr; do UFR_LIB=$PWD/uforecon_amd/lib/libufr_$v.so run $v; done
+for r in 1 2; do
+python tools/bench_train.py 2>/dev/null | tail -n 1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print('BARRIER', round(d['ms_per_step'],3), {k:round(v,3) for k,v in d['config']['kernel_ms_per_step_rank0'].items() if 'wgrad' in k})"
+UFR_LIB=$PWD/uforecon_amd/lib/libufr_nb.so python tools/bench_train.py 2>/dev/null | tail -n 1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print('FREE', round(d['ms_per_step'],3), {k:round(v,3) for k,v in d['config']['kernel_ms_per_step_rank0'].items() if 'wgrad' in k})"
+done
+python -m pytest tests/test_gpu_backward.py -m gpu -x -q 2>&1 | tail -n 1

@@ -166,7 +166,7 @@ __device__ __forceinline__ f32x4 contract_ones(const Frag& a, const f16x8& ones,
   return mfma_planes<true>(a.p[0], ones, acc);
 }
 
-template <const auto& TABLE, int IDX, bool LOWP, class TAPE_L, class DY_L>
+template <const auto& TABLE, int IDX, bool LOWP, class TAPE_L, class DY_L, bool BARRIER = false>
 __device__ __forceinline__ void run_role(const float* __restrict__ tape, const float* __restrict__ dbuf, int blk0, int blk1,
                                          const GradPtrs& gp, int lane) {
   constexpr Role R = TABLE[IDX];
@@ -183,6 +183,13 @@ __device__ __forceinline__ void run_role(const float* __restrict__ tape, const f
   for (int s = 0; s < NS; ++s) acc[s] = splat4(0.f);
 
   for (int blk = blk0; blk < blk1; ++blk) {
+    // The four waves of a workgroup read overlapping tiles of the SAME block (x for q / k / v, the halves of d hid for the
+    // quadrants of mlp0, d opre for the column ranges of mlp2): one barrier per block keeps them within a block of each
+    // other, so the second and third reader hit in the L2 (4 MB per XCD = 64 KB per resident workgroup: less than one
+    // block's tiles -- free-running waves drifted apart and every read went to HBM, 3.7 GB per launch for 2.3 GB of tiles).
+    // Nothing is exchanged: no LDS, no fence.
+    // Measured: view kernel 0.76 -> 0.70 ms; the ray kernel, whose roles are less even, 0.45 -> 0.51 ms: so only the former.
+    if constexpr (BARRIER) __builtin_amdgcn_s_barrier();
     // scalar block bases + 32-bit lane offsets
     const char* tb = reinterpret_cast<const char*>(tape) + (size_t)blk * (TAPE_L::block_units * 512);
     const char* db = reinterpret_cast<const char*>(dbuf) + (size_t)blk * (DY_L::block_units * 512);
@@ -274,9 +281,9 @@ __global__ void __launch_bounds__(256, 2) view_wgrad_kernel(const float* __restr
   const int blk0 = chunk * per, blk1 = min(n_blocks, blk0 + per);
   switch (__builtin_amdgcn_readfirstlane(type * 4 + wave)) {
 #ifdef UFR_WG_ONLY
-#define UFR_ROLE(i) case i: if constexpr (i == UFR_WG_ONLY) run_role<kViewRoles, i, LOWP, ViewTapeLayout<LOWP>, ViewGradLayout<LOWP>>(tape, dbuf, blk0, blk1, gp, lane); break;
+#define UFR_ROLE(i) case i: if constexpr (i == UFR_WG_ONLY) run_role<kViewRoles, i, LOWP, ViewTapeLayout<LOWP>, ViewGradLayout<LOWP>, true>(tape, dbuf, blk0, blk1, gp, lane); break;
 #else
-#define UFR_ROLE(i) case i: run_role<kViewRoles, i, LOWP, ViewTapeLayout<LOWP>, ViewGradLayout<LOWP>>(tape, dbuf, blk0, blk1, gp, lane); break;
+#define UFR_ROLE(i) case i: run_role<kViewRoles, i, LOWP, ViewTapeLayout<LOWP>, ViewGradLayout<LOWP>, true>(tape, dbuf, blk0, blk1, gp, lane); break;
 #endif
     UFR_ROLE(0) UFR_ROLE(1) UFR_ROLE(2) UFR_ROLE(3) UFR_ROLE(4) UFR_ROLE(5) UFR_ROLE(6) UFR_ROLE(7)
     UFR_ROLE(8) UFR_ROLE(9) UFR_ROLE(10) UFR_ROLE(11)

@@ -253,7 +253,12 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
       for (int t = 0; t < 5; ++t) {
         f32x4 tok = vec_frag<V_VIEW_TOKEN>(ws, t, g);
+#ifdef UFR_ABL_NOTOKLOAD   // ablation (timing only): what the token loads' latency costs
+        f32x4 val = splat4(0.001f * (float)(lane + t));
+        asm volatile("" : "+v"(val));
+#else
         f32x4 val = ld4(t < 2 ? row + 16 * t : t < 4 ? prow + 16 * (t - 2) : last);
+#endif
         dst[t] = tv == 0 ? tok : val;                     // ray_transformer.py:284-286
         if (!valid[c]) dst[t] = splat4(0.f);
       }

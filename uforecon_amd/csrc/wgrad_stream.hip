@@ -16,6 +16,7 @@
 // Work split: a wave owns a fixed set of (dY tile, X tile) accumulator tiles in registers -- a ROLE, by MATRIX: q, k, v,
 // merge, the four quadrants of mlp0, ... -- for a contiguous range of token blocks, and flushes them once with float atomics
 // into the reference-layout gradient tensors (undoing the row maps of ufr_layout.h).
+#include <cstdlib>
 #include "bwd_common.h"     // GradPtrs, atomic_add_f32
 #include "bwd_tape.h"
 #include "ufr_internal.h"
@@ -340,7 +341,8 @@ __global__ void __launch_bounds__(256, 2) ray_wgrad_kernel(const float* __restri
 hipError_t launch_ray_wgrad(const float* tape, const float* dbuf, int n_blocks, const GradPtrs& gp, bool lowp, hipStream_t s) {
   if (n_blocks <= 0) return hipErrorInvalidValue;
   int n_chunks = (n_blocks + 15) / 16;
-  if (n_chunks > 384) n_chunks = 384;
+  static const int cap = getenv("UFR_RW_CHUNKS") ? atoi(getenv("UFR_RW_CHUNKS")) : 384;
+  if (n_chunks > cap) n_chunks = cap;
   const dim3 grid(n_chunks * wgs::kRayTypes), block(256);
   if (lowp) hipLaunchKernelGGL(wgs::ray_wgrad_kernel<true>, grid, block, 0, s, tape, dbuf, n_blocks, n_chunks, gp);
   else hipLaunchKernelGGL(wgs::ray_wgrad_kernel<false>, grid, block, 0, s, tape, dbuf, n_blocks, n_chunks, gp);
@@ -349,9 +351,12 @@ hipError_t launch_ray_wgrad(const float* tape, const float* dbuf, int n_blocks, 
 
 hipError_t launch_view_wgrad(const float* tape, const float* dbuf, int n_blocks, const GradPtrs& gp, bool lowp, hipStream_t s) {
   if (n_blocks <= 0) return hipErrorInvalidValue;
-  // a workgroup flushes ~30 k atomics per wave: at least 32 blocks of work each, at most ~3 rounds of the resident slots
+  // a workgroup flushes ~30 k atomics per wave (0.6 GB of write traffic per launch at 512 chunks): at least 32 blocks of
+  // work each, and two rounds of the 512 resident slots (341 chunks x 3 types; 512 chunks = three rounds measured 5 %
+  // slower, 170 = one round as slow as 512).  UFR_VW_CHUNKS / UFR_RW_CHUNKS: development overrides.
   int n_chunks = (n_blocks + 31) / 32;
-  if (n_chunks > 512) n_chunks = 512;
+  static const int cap = getenv("UFR_VW_CHUNKS") ? atoi(getenv("UFR_VW_CHUNKS")) : 341;
+  if (n_chunks > cap) n_chunks = cap;
   const dim3 grid(n_chunks * wgs::kViewTypes), block(256);
   if (lowp) hipLaunchKernelGGL(wgs::view_wgrad_kernel<true>, grid, block, 0, s, tape, dbuf, n_blocks, n_chunks, gp);
   else hipLaunchKernelGGL(wgs::view_wgrad_kernel<false>, grid, block, 0, s, tape, dbuf, n_blocks, n_chunks, gp);

@@ -246,6 +246,9 @@ def run(a, dev, world=1, rank=0):
                         view_transformer=vb_ms * vb["launches"] / a.steps,
                         ray_transformer=sum(prof[k]["ms"] for k in ("ray_tape", "ray_dgrad", "ray_wgrad") if k in prof) / a.steps,
                         frustum_scatter=prof.get("gather_bwd", dict(ms=0.0))["ms"] / a.steps),
+                    backward_note=("the ray transformer's backward runs its coarse and fine pass side by side on two streams "
+                                   "(uforecon_amd/autograd.py): the ray_* intervals overlap and stretch each other, their sum "
+                                   "(ray_transformer above) exceeds the wall time they take (~1.3 ms fp32 / ~1.0 ms 16-bit)"),
                     loss=float(loss.detach()),
                     kernel_ms_per_step_rank0={k: v["ms"] / a.steps for k, v in prof.items()},
                     kernel_launches_per_step={k: v["launches"] / a.steps for k, v in prof.items()},

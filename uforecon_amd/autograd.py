@@ -66,6 +66,17 @@ class RenderPass(torch.autograd.Function):
         return (None, None, None, None, None, *out)
 
 
+_SIDE = {}
+
+
+def _side_stream(dev) -> "torch.cuda.Stream":
+    """One side stream per device for the two-stream backward of RenderTwoPass (created once: stream creation is slow)."""
+    key = torch.device(dev).index or 0
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(dev)
+    return _SIDE[key]
+
+
 class RenderTwoPass(torch.autograd.Function):
     """Both passes of ``infer`` (model.py:429-473) with the coarse samples' per-point work shared: the fine pass gathers
     and view-transforms only its PN new samples; the ray transformer and the compositor -- which do couple the samples of a
@@ -128,24 +139,35 @@ class RenderTwoPass(torch.autograd.Function):
         var = W.variance.reshape(1)
         grads = ops.GradBuffer(dev)
         d_var = torch.zeros((), dtype=torch.float32, device=dev)
-        # cotangent pools, same rows as the forward's: the fine pass writes every row once (each pool row is exactly one
-        # merged slot), the coarse pass then ADDS its own cotangents onto the coarse rows -- inside the kernels
+        # cotangent pools, same rows as the forward's.  The fine pass writes every row of pool_a once (each pool row is exactly
+        # one merged slot); the coarse pass writes its cotangents for the coarse rows into pool_b (whose other rows are zero);
+        # the view transformer's backward adds the two.  So the two ray-transformer backwards are INDEPENDENT and run on two
+        # streams: a launch group has one wave per ray -- 1 024 rays fill half of the GPU's 2 048 wave slots -- and side by
+        # side the coarse pass (half the work) hides behind the fine one.
         pool_a = torch.empty_like(pool_tok)
         pool_b = torch.empty_like(pool_tok)
+        pool_b[P1:].zero_()
         pool_drad = torch.empty_like(pool_rad)
-        # ---- fine pass: compositor and ray transformer over all merged slots
+        # ---- compositors (the coarse one ADDS its d radiance onto the fine one's rows: same stream, in order)
         _, d_srdf_s, _ = ops.composite_bwd(z2, pool_rad, srdf2, var, d_rgb2, d_depth2, d_opacity2, d_weight2, row=row,
                                            d_radiance=pool_drad, accumulate=False, d_variance=d_var)
         if d_srdf2 is not None:
             d_srdf_s = d_srdf_s + d_srdf2
-        ops.ray_transform_bwd(W, grads, pool_tok, RN, S2, d_srdf_s, row=row, out=(pool_a, pool_b), precision=prec)
-        # ---- coarse pass (its weights feed the importance sampler detached: model.py:456-457)
+        # (the coarse pass's weights feed the importance sampler detached: model.py:456-457)
         _, d_srdf_c, _ = ops.composite_bwd(z1, pool_rad[:P1].view(RN, SN, 3), srdf1, var, d_rgb, d_depth, d_opacity, d_weight,
                                            d_radiance=pool_drad[:P1], accumulate=True, d_variance=d_var)
         if d_srdf is not None:
             d_srdf_c = d_srdf_c + d_srdf
-        ops.ray_transform_bwd(W, grads, pool_tok[:P1], RN, SN, d_srdf_c, out=(pool_a[:P1], pool_b[:P1]), accumulate=True,
-                              precision=prec)
+        # ---- ray transformers backwards: fine on this stream, coarse beside it
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ops.ray_transform_bwd(W, grads, pool_tok[:P1], RN, SN, d_srdf_c, out=(pool_b[:P1], None), precision=prec)
+        ops.ray_transform_bwd(W, grads, pool_tok, RN, S2, d_srdf_s, row=row, out=(pool_a, None), precision=prec)
+        main.wait_stream(side)
+        for t in (d_srdf_c, pool_b, pool_tok, grads.flat):
+            t.record_stream(side)
         # ---- view transformer backwards, ONE launch over the pool: coarse samples once, with the cotangents of both passes,
         # and the new samples
         d_pv = torch.empty(pool_tok.shape[0], 40, dtype=torch.float32, device=dev)   # pool rows again

@@ -476,7 +476,8 @@ def ray_transform_bwd(weights: PackedWeights, grads: GradBuffer, token0: torch.T
                       _workspace_out: Optional[list] = None):
     """-> the two partial d token0 buffers of the ray kernel's sweeps (their sum is the gradient).  Plain form: (RN*SN,80)
     in slot order.  Pool form: ``row`` maps slots to rows of ``token0`` and of the two pool-sized buffers ``out=(a, b)``,
-    which are overwritten or, with ``accumulate``, added to."""
+    which are overwritten or, with ``accumulate``, added to.  ``b`` may be None: nothing is zero-filled then (the caller owns
+    the second buffer, e.g. lets another pass write it concurrently)."""
     lib = _lib.load()
     dev = token0.device
     if out is None:
@@ -488,7 +489,7 @@ def ray_transform_bwd(weights: PackedWeights, grads: GradBuffer, token0: torch.T
     d_srdf = d_srdf.contiguous()
     _lib.check(lib.ufr_ray_transform_bwd(C.byref(weights.raw), C.byref(grads.raw), weights.packed.data_ptr(), _dev(token0, "token0"),
                                          None if row is None else _dev(row, "row", torch.int32), RN, SN,
-                                         _dev(d_srdf, "d_srdf"), _dev(a, "d_token0_a"), _dev(b, "d_token0_b"), int(accumulate),
+                                         _dev(d_srdf, "d_srdf"), _dev(a, "d_token0_a"), _opt(b, "d_token0_b"), int(accumulate),
                                          ws.data_ptr(), weights.mode() if precision is None else precision, _stream()),
                "ufr_ray_transform_bwd")
     if _workspace_out is not None:      # development: the tape / cotangent tiles (tools/dev/ray_bwd_check.py)

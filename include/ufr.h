@@ -32,7 +32,7 @@ enum ufr_status {
 
 /* Version of this header's ABI (argument lists, struct layouts, packed-blob layout).  ufr_version() returns the value
  * the library was built with: a binding must refuse a library whose version differs (uforecon_amd/_lib.py does). */
-#define UFR_ABI_VERSION 401
+#define UFR_ABI_VERSION 402
 
 #define UFR_MAX_VIEWS 7
 #define UFR_NUM_STAGES 3
@@ -312,6 +312,22 @@ int ufr_view_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grad
                            const float* x_tokens, const float* rgb, const float* dir, const float* d_token0_a,
                            const float* d_token0_b, const float* d_radiance, int32_t P, int32_t NV, float* d_pv, void* workspace,
                            int32_t precision, ufr_stream stream);
+/* The same in stages, for callers that overlap them with independent work on other streams (uforecon_amd/autograd.py does):
+ *   TAPE   the forward again, recording the activations into the workspace -- needs only the forward's inputs, so it can run
+ *          beside the ray transformer's backward (pointers of later stages may be NULL);
+ *   DGRAD  the data-gradient chain: reads the tape, d_token0_a/b, d_radiance; writes d_pv and the cotangent tiles;
+ *   WGRAD  the weight-gradient contractions: read tape and cotangent tiles, add into `grads` -- nothing downstream waits for
+ *          them, so they can run beside ufr_project_gather_bwd (which needs d_pv only).
+ * The SAME workspace must be passed to every stage, and the stages must execute in this order (stream events are the
+ * caller's business).  stages = UFR_BWD_STAGE_ALL is ufr_view_transform_bwd. */
+#define UFR_BWD_STAGE_TAPE 1
+#define UFR_BWD_STAGE_DGRAD 2
+#define UFR_BWD_STAGE_WGRAD 4
+#define UFR_BWD_STAGE_ALL 7
+int ufr_view_transform_bwd_stages(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const void* packed_weights,
+                                  const float* x_tokens, const float* rgb, const float* dir, const float* d_token0_a,
+                                  const float* d_token0_b, const float* d_radiance, int32_t P, int32_t NV, float* d_pv,
+                                  void* workspace, int32_t stages, int32_t precision, ufr_stream stream);
 
 /* ------------------------------------------------------------------ whole-path inference
  * UFORecon.infer(extract_geometry=True) (model.py:393-478) for RN rays of one frame:

@@ -67,11 +67,12 @@ class RenderPass(torch.autograd.Function):
 
 
 _SIDE = {}
+OVERLAP = True     # False: every stage of RenderTwoPass.backward on the caller's stream (per-kernel timing, debugging)
 
 
-def _side_stream(dev) -> "torch.cuda.Stream":
-    """One side stream per device for the two-stream backward of RenderTwoPass (created once: stream creation is slow)."""
-    key = torch.device(dev).index or 0
+def _side_stream(dev, i: int = 0) -> "torch.cuda.Stream":
+    """Side streams per device for the multi-stream backward of RenderTwoPass (created once: stream creation is slow)."""
+    key = (torch.device(dev).index or 0, i)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(dev)
     return _SIDE[key]
@@ -158,20 +159,32 @@ class RenderTwoPass(torch.autograd.Function):
                                            d_radiance=pool_drad[:P1], accumulate=True, d_variance=d_var)
         if d_srdf is not None:
             d_srdf_c = d_srdf_c + d_srdf
-        # ---- ray transformers backwards: fine on this stream, coarse beside it
+        # ---- ray transformers backwards: fine on this stream, coarse beside it; and beside both, on a third stream, the TAPE
+        # stage of the view transformer's backward (the forward again, recording its activations: it needs only forward
+        # tensors, and it is bound by its 2 GB of stores while the ray kernels leave half of the GPU's wave slots empty)
         main = torch.cuda.current_stream(dev)
-        side = _side_stream(dev)
+        side, side2 = (_side_stream(dev, 0), _side_stream(dev, 1)) if OVERLAP else (main, main)
         side.wait_stream(main)
+        side2.wait_stream(main)
+        with torch.cuda.stream(side2):
+            vws = ops.view_transform_bwd_workspace(pool_tok.shape[0], pool_x.shape[1], dev)
+            ops.view_transform_bwd(W, grads, pool_x, pool_rgbm, pool_dirs, None, None, None, precision=prec,
+                                   stages=ops.STAGE_TAPE, workspace=vws)
         with torch.cuda.stream(side):
             ops.ray_transform_bwd(W, grads, pool_tok[:P1], RN, SN, d_srdf_c, out=(pool_b[:P1], None), precision=prec)
         ops.ray_transform_bwd(W, grads, pool_tok, RN, S2, d_srdf_s, row=row, out=(pool_a, None), precision=prec)
         main.wait_stream(side)
-        for t in (d_srdf_c, pool_b, pool_tok, grads.flat):
-            t.record_stream(side)
-        # ---- view transformer backwards, ONE launch over the pool: coarse samples once, with the cotangents of both passes,
-        # and the new samples
+        main.wait_stream(side2)
+        # ---- view transformer backwards, ONE launch group over the pool: coarse samples once, with the cotangents of both
+        # passes, and the new samples.  Data gradients here; the weight-gradient contractions -- nothing downstream waits
+        # for them -- beside the frustum scatter (one bound by HBM, the other by the L2's atomic rate)
         d_pv = torch.empty(pool_tok.shape[0], 40, dtype=torch.float32, device=dev)   # pool rows again
-        ops.view_transform_bwd(W, grads, pool_x, pool_rgbm, pool_dirs, pool_a, pool_b, pool_drad, precision=prec, d_pv=d_pv)
+        ops.view_transform_bwd(W, grads, pool_x, pool_rgbm, pool_dirs, pool_a, pool_b, pool_drad, precision=prec, d_pv=d_pv,
+                               stages=ops.STAGE_DGRAD, workspace=vws)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ops.view_transform_bwd(W, grads, pool_x, pool_rgbm, pool_dirs, None, None, None, precision=prec,
+                                   stages=ops.STAGE_WGRAD, workspace=vws)
         need = ctx.needs_input_grad[6:]
         if any(need[ctx.n_par:]):
             gvol = [torch.empty(s, dtype=torch.float32, device=dev) for s in ctx.vol_shapes]      # written whole: no zero-fill
@@ -183,6 +196,11 @@ class RenderTwoPass(torch.autograd.Function):
         # folding of gather_bwd.hip removes more corner records), d_pv / sim8 addressed through the slot -> row table
         ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z2, sim8_pool, d_pv, gf, gw, precision=prec, row=row,
                                accumulate=False)
+        main.wait_stream(side)
+        for t in (d_srdf_c, pool_a, pool_b, pool_tok, pool_x, pool_rgbm, pool_dirs, grads.flat, vws):
+            t.record_stream(side)
+        for t in (pool_x, pool_rgbm, pool_dirs, grads.flat):
+            t.record_stream(side2)
         gpar = [grads.grad(k) for k in ops.RAW_WEIGHT_KEYS]
         gpar[-1] = d_var.reshape(gpar[-1].shape)
         out = [g if (n and g is not None) else None for g, n in zip(gpar + gvol, need)]

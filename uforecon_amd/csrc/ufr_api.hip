@@ -506,19 +506,19 @@ static ViewBwdWs carve_view_bwd(Carver& c, int P, int NV) {
 }
 static int view_bwd_impl(const void* packed, const GradPtrs& gp, const float* x_tokens, const float* rgb, const float* dir,
                          const float* d_tok_a, const float* d_tok_b, const float* d_radiance, int P, int NV, float* d_pv,
-                         const ViewBwdWs& w, bool lowp, int* status, hipStream_t s) {
+                         const ViewBwdWs& w, bool lowp, int* status, hipStream_t s, int stages = UFR_BWD_STAGE_ALL) {
   UFR_REQUIRE((unsigned long long)P * (NV + 1) * UFR_TOKEN_DIM < (1ull << 30),
               "view transformer backward: %d points x %d tokens exceed the 2^30 token values one call addresses; chunk the points", P, NV + 1);
   const float* pk = static_cast<const float*>(packed);
-  {
+  if (stages & UFR_BWD_STAGE_TAPE) {
     ProfScope p("view_tape", s);
     UFR_HIP(launch_view_tape(pk, x_tokens, rgb, dir, P, NV, w.token0, w.radiance, w.tape, lowp, status, s));
   }
-  {
+  if (stages & UFR_BWD_STAGE_DGRAD) {
     ProfScope p("view_dgrad", s);
     UFR_HIP(launch_view_dgrad(pk, w.tape, rgb, d_tok_a, d_tok_b, d_radiance, P, NV, w.dbuf, d_pv, gp, lowp, s));
   }
-  {
+  if (stages & UFR_BWD_STAGE_WGRAD) {
     ProfScope p("view_wgrad", s);
     UFR_HIP(launch_view_wgrad(w.tape, w.dbuf, w.blocks, gp, lowp, s));
   }
@@ -720,12 +720,24 @@ int ufr_view_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grad
                            const float* x_tokens, const float* rgb, const float* dir, const float* d_token0_a,
                            const float* d_token0_b, const float* d_radiance, int32_t P, int32_t NV, float* d_pv, void* workspace,
                            int32_t precision, ufr_stream stream) {
+  return ufr_view_transform_bwd_stages(raw, grads, packed_weights, x_tokens, rgb, dir, d_token0_a, d_token0_b, d_radiance, P, NV, d_pv,
+                                       workspace, UFR_BWD_STAGE_ALL, precision, stream);
+}
+
+int ufr_view_transform_bwd_stages(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const void* packed_weights,
+                                  const float* x_tokens, const float* rgb, const float* dir, const float* d_token0_a,
+                                  const float* d_token0_b, const float* d_radiance, int32_t P, int32_t NV, float* d_pv,
+                                  void* workspace, int32_t stages, int32_t precision, ufr_stream stream) {
   RawPtrs rp;
   GradPtrs gp;
   int rc = raw_and_grads(raw, grads, rp, gp, "ufr_view_transform_bwd");
   if (rc != UFR_OK) return rc;
   UFR_PRECISION(precision, lowp, "ufr_view_transform_bwd");
-  UFR_REQUIRE(packed_weights && x_tokens && rgb && dir && d_token0_a && d_radiance && d_pv && workspace, "ufr_view_transform_bwd: null argument");
+  UFR_REQUIRE(stages > 0 && (stages & ~UFR_BWD_STAGE_ALL) == 0, "ufr_view_transform_bwd_stages: stages=%d", stages);
+  UFR_REQUIRE(packed_weights && workspace, "ufr_view_transform_bwd: null argument");
+  UFR_REQUIRE(!(stages & UFR_BWD_STAGE_TAPE) || (x_tokens && rgb && dir), "ufr_view_transform_bwd: the tape stage needs x_tokens, rgb, dir");
+  UFR_REQUIRE(!(stages & UFR_BWD_STAGE_DGRAD) || (rgb && d_token0_a && d_radiance && d_pv),
+              "ufr_view_transform_bwd: the data-gradient stage needs rgb, d_token0_a, d_radiance, d_pv");
   UFR_REQUIRE(NV >= 2 && NV <= UFR_MAX_VIEWS && P > 0, "ufr_view_transform_bwd: P=%d NV=%d", P, NV);
   hipStream_t s = static_cast<hipStream_t>(stream);
   Carver c(workspace);
@@ -733,7 +745,7 @@ int ufr_view_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grad
   StatusSlot* sl = nullptr;
   rc = status_slot(&sl);
   if (rc != UFR_OK) return rc;
-  return view_bwd_impl(packed_weights, gp, x_tokens, rgb, dir, d_token0_a, d_token0_b, d_radiance, P, NV, d_pv, vw, lowp, sl->dev, s);
+  return view_bwd_impl(packed_weights, gp, x_tokens, rgb, dir, d_token0_a, d_token0_b, d_radiance, P, NV, d_pv, vw, lowp, sl->dev, s, stages);
 }
 
 // ------------------------------------------------------------------ whole-path inference

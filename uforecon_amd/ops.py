@@ -497,21 +497,32 @@ def ray_transform_bwd(weights: PackedWeights, grads: GradBuffer, token0: torch.T
     return a, b
 
 
+STAGE_TAPE, STAGE_DGRAD, STAGE_WGRAD, STAGE_ALL = 1, 2, 4, 7
+
+
+def view_transform_bwd_workspace(P: int, NV: int, device) -> torch.Tensor:
+    """The tile buffers of the view transformer's backward (csrc/bwd_tape.h): pass the same tensor to every stage."""
+    return torch.empty(_lib.load().ufr_view_transform_bwd_workspace_bytes(P, NV) // 4, dtype=torch.float32, device=device)
+
+
 def view_transform_bwd(weights: PackedWeights, grads: GradBuffer, x, rgb, dirs, d_token0_a, d_token0_b, d_radiance,
-                       precision: Optional[int] = None, d_pv: Optional[torch.Tensor] = None):
+                       precision: Optional[int] = None, d_pv: Optional[torch.Tensor] = None, stages: int = STAGE_ALL,
+                       workspace: Optional[torch.Tensor] = None):
+    """``stages`` (include/ufr.h: ufr_view_transform_bwd_stages): STAGE_TAPE needs only x / rgb / dirs, STAGE_DGRAD the
+    cotangents (writes d_pv), STAGE_WGRAD nothing but the workspace -- a caller that splits them passes ONE ``workspace``
+    (view_transform_bwd_workspace) to all and orders them with stream events."""
     P, NV = x.shape[0], x.shape[1]
-    if d_pv is None:
+    if d_pv is None and (stages & STAGE_DGRAD):
         d_pv = torch.empty(P, 40, dtype=torch.float32, device=x.device)
-    ta = d_token0_a.contiguous()
+    ta = None if d_token0_a is None else d_token0_a.contiguous()
     tb = None if d_token0_b is None else d_token0_b.contiguous()
-    dr = d_radiance.contiguous()
+    dr = None if d_radiance is None else d_radiance.contiguous()
     lib = _lib.load()
-    # tape + cotangent tiles of the streaming backward (csrc/bwd_tape.h)
-    ws = torch.empty(lib.ufr_view_transform_bwd_workspace_bytes(P, NV) // 4, dtype=torch.float32, device=x.device)
-    _lib.check(lib.ufr_view_transform_bwd(
+    ws = workspace if workspace is not None else view_transform_bwd_workspace(P, NV, x.device)
+    _lib.check(lib.ufr_view_transform_bwd_stages(
         C.byref(weights.raw), C.byref(grads.raw), weights.packed.data_ptr(), _dev(x, "x_tokens"), _dev(rgb, "rgb"),
-        _dev(dirs, "dir"), _dev(ta, "d_token0_a"), _opt(tb, "d_token0_b"), _dev(dr, "d_radiance"), P, NV, _dev(d_pv, "d_pv"),
-        ws.data_ptr(), weights.mode() if precision is None else precision, _stream()), "ufr_view_transform_bwd")
+        _dev(dirs, "dir"), _opt(ta, "d_token0_a"), _opt(tb, "d_token0_b"), _opt(dr, "d_radiance"), P, NV, _opt(d_pv, "d_pv"),
+        ws.data_ptr(), stages, weights.mode() if precision is None else precision, _stream()), "ufr_view_transform_bwd")
     return d_pv
 
 

@@ -16,7 +16,10 @@ PMC_BENCH="bench.py --steps 1 --warmup 0 --streams 1 --no-cpu-baseline --no-gpu-
 rocprofv3 --kernel-trace --output-format csv --pmc $SQ -d $OUT -o pmc_sq -- python3 $PMC_BENCH > /dev/null 2> $OUT/pmc_sq_err.txt
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT -o pmc_fetch -- python3 $PMC_BENCH > /dev/null 2> $OUT/pmc_fetch_err.txt
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT -o pmc_write -- python3 $PMC_BENCH > /dev/null 2> $OUT/pmc_write_err.txt
-# training step (configs[4]): kernel trace + stats (forward + backward kernels), both precisions; counters in the fp32 mode
+# training step (configs[4]): kernel trace + stats (forward + backward kernels), both precisions; counters in the fp32 mode.
+# UFR_BT_OVERLAP=0: every stage of the backward on one stream, so that a kernel's duration is its own (the timed steps of
+# tools/bench_train.py overlap independent stages on three streams; its per-kernel numbers come from non-overlapped steps too)
+export UFR_BT_OVERLAP=0
 TRAIN="tools/bench_train.py --steps 3 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o train -- python3 $TRAIN > $OUT/train_line.json 2> $OUT/train_err.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o train16 -- python3 $TRAIN --precision 16bit > $OUT/train16_line.json 2> $OUT/train16_err.txt
@@ -24,6 +27,7 @@ TRAIN_PMC="tools/bench_train.py --steps 2 --warmup 0 --no-cpu-baseline"
 rocprofv3 --kernel-trace --output-format csv --pmc $SQ -d $OUT -o train_pmc_sq -- python3 $TRAIN_PMC > /dev/null 2> $OUT/train_pmc_sq_err.txt
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT -o train_pmc_fetch -- python3 $TRAIN_PMC > /dev/null 2> $OUT/train_pmc_fetch_err.txt
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT -o train_pmc_write -- python3 $TRAIN_PMC > /dev/null 2> $OUT/train_pmc_write_err.txt
+unset UFR_BT_OVERLAP
 # configs[3] (5 views, 800x600, 128+128): HBM traffic of the L = 6 kernels
 C4="tools/bench_c4.py --steps 1 --warmup 0 --streams 1 --no-cpu-baseline --no-gpu-eager-baseline"
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT -o c4_pmc_fetch -- python3 $C4 > /dev/null 2> $OUT/c4_pmc_fetch_err.txt

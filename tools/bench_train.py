@@ -174,15 +174,15 @@ def run(a, dev, world=1, rank=0):
             dist.barrier()
         torch.cuda.synchronize()
 
+    if os.environ.get("UFR_BT_OVERLAP") == "0":      # development / profiling: the whole backward on one stream
+        from uforecon_amd import autograd as _ag0
+        _ag0.OVERLAP = False
     for _ in range(a.warmup):
         step()
     fence()
     ar_events.clear()
     if os.environ.get("UFR_BT_PROF") == "1":
         ops.profile_enable(True)
-    if os.environ.get("UFR_BT_OVERLAP") == "0":
-        from uforecon_amd import autograd as _ag0
-        _ag0.OVERLAP = False
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
@@ -200,7 +200,7 @@ def run(a, dev, world=1, rank=0):
     fence()
     prof = ops.profile_read()
     ops.profile_enable(False)
-    _ag.OVERLAP = True
+    _ag.OVERLAP = os.environ.get("UFR_BT_OVERLAP") != "0"
     ops.status_poll(True)        # an activation / weight outside the split-precision planes' range fails the run loudly
     per_rank = None
     if world > 1:

@@ -32,7 +32,7 @@ enum ufr_status {
 
 /* Version of this header's ABI (argument lists, struct layouts, packed-blob layout).  ufr_version() returns the value
  * the library was built with: a binding must refuse a library whose version differs (uforecon_amd/_lib.py does). */
-#define UFR_ABI_VERSION 402
+#define UFR_ABI_VERSION 403
 
 #define UFR_MAX_VIEWS 7
 #define UFR_NUM_STAGES 3
@@ -320,6 +320,10 @@ int ufr_view_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grad
  *          them, so they can run beside ufr_project_gather_bwd (which needs d_pv only).
  * The SAME workspace must be passed to every stage, and the stages must execute in this order (stream events are the
  * caller's business).  stages = UFR_BWD_STAGE_ALL is ufr_view_transform_bwd. */
+int ufr_ray_transform_bwd_stages(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const void* packed_weights,
+                                 const float* token0, const int32_t* row, int32_t RN, int32_t SN, const float* d_srdf,
+                                 float* d_token0_a, float* d_token0_b, int32_t accumulate, void* workspace, int32_t stages,
+                                 int32_t precision, ufr_stream stream);   /* the ray transformer's backward likewise */
 #define UFR_BWD_STAGE_TAPE 1
 #define UFR_BWD_STAGE_DGRAD 2
 #define UFR_BWD_STAGE_WGRAD 4

@@ -70,6 +70,23 @@ _SIDE = {}
 OVERLAP = True     # False: every stage of RenderTwoPass.backward on the caller's stream (per-kernel timing, debugging)
 
 
+_WS = {}
+
+
+def _workspace(kind: str, dev, numel_of) -> torch.Tensor:
+    """Tile buffers of the backward kernels, kept between steps (a few GB at the training size).  As per-step
+    `torch.empty` they went through the caching allocator with `record_stream` marks from the side streams: the host runs
+    a step ahead of the GPU, the freed multi-GB blocks were still "in use" when the next step asked for them, and the
+    allocator fell back to hipMalloc / hipFree (which synchronises) -- steps of 9..15 ms instead of 5, now and then.
+    Ordering between steps: backward() ends with main waiting for the side streams, and starts with them waiting for main."""
+    n = int(numel_of())
+    key = (kind, torch.device(dev).index or 0)
+    t = _WS.get(key)
+    if t is None or t.numel() < n:
+        t = _WS[key] = torch.empty(n, dtype=torch.float32, device=dev)
+    return t
+
+
 def _side_stream(dev, i: int = 0) -> "torch.cuda.Stream":
     """Side streams per device for the multi-stream backward of RenderTwoPass (created once: stream creation is slow)."""
     key = (torch.device(dev).index or 0, i)
@@ -164,17 +181,30 @@ class RenderTwoPass(torch.autograd.Function):
         # tensors, and it is bound by its 2 GB of stores while the ray kernels leave half of the GPU's wave slots empty)
         main = torch.cuda.current_stream(dev)
         side, side2 = (_side_stream(dev, 0), _side_stream(dev, 1)) if OVERLAP else (main, main)
+        lib = ops._lib.load()
+        vws = _workspace("view", dev, lambda: lib.ufr_view_transform_bwd_workspace_bytes(pool_tok.shape[0], pool_x.shape[1]) // 4)
+        ws_c = _workspace("ray_c", dev, lambda: lib.ufr_ray_transform_bwd_workspace_bytes(RN, SN) // 4)
+        ws_f = _workspace("ray_f", dev, lambda: lib.ufr_ray_transform_bwd_workspace_bytes(RN, S2) // 4)
         side.wait_stream(main)
         side2.wait_stream(main)
         with torch.cuda.stream(side2):
-            vws = ops.view_transform_bwd_workspace(pool_tok.shape[0], pool_x.shape[1], dev)
             ops.view_transform_bwd(W, grads, pool_x, pool_rgbm, pool_dirs, None, None, None, precision=prec,
                                    stages=ops.STAGE_TAPE, workspace=vws)
+        # (the ray weight-gradient contractions feed nothing downstream either: tape + data gradients first, on both
+        # streams; the contractions afterwards on the side stream, beside the view transformer's data gradients)
         with torch.cuda.stream(side):
-            ops.ray_transform_bwd(W, grads, pool_tok[:P1], RN, SN, d_srdf_c, out=(pool_b[:P1], None), precision=prec)
-        ops.ray_transform_bwd(W, grads, pool_tok, RN, S2, d_srdf_s, row=row, out=(pool_a, None), precision=prec)
+            ops.ray_transform_bwd(W, grads, pool_tok[:P1], RN, SN, d_srdf_c, out=(pool_b[:P1], None), precision=prec,
+                                  stages=ops.STAGE_TAPE | ops.STAGE_DGRAD, workspace=ws_c)
+        ops.ray_transform_bwd(W, grads, pool_tok, RN, S2, d_srdf_s, row=row, out=(pool_a, None), precision=prec,
+                              stages=ops.STAGE_TAPE | ops.STAGE_DGRAD, workspace=ws_f)
         main.wait_stream(side)
         main.wait_stream(side2)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ops.ray_transform_bwd(W, grads, pool_tok[:P1], RN, SN, d_srdf_c, out=(pool_b[:P1], None), precision=prec,
+                                  stages=ops.STAGE_WGRAD, workspace=ws_c)
+            ops.ray_transform_bwd(W, grads, pool_tok, RN, S2, d_srdf_s, row=row, out=(pool_a, None), precision=prec,
+                                  stages=ops.STAGE_WGRAD, workspace=ws_f)
         # ---- view transformer backwards, ONE launch group over the pool: coarse samples once, with the cotangents of both
         # passes, and the new samples.  Data gradients here; the weight-gradient contractions -- nothing downstream waits
         # for them -- beside the frustum scatter (one bound by HBM, the other by the L2's atomic rate)
@@ -197,10 +227,9 @@ class RenderTwoPass(torch.autograd.Function):
         ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z2, sim8_pool, d_pv, gf, gw, precision=prec, row=row,
                                accumulate=False)
         main.wait_stream(side)
-        for t in (d_srdf_c, pool_a, pool_b, pool_tok, pool_x, pool_rgbm, pool_dirs, grads.flat, vws):
-            t.record_stream(side)
-        for t in (pool_x, pool_rgbm, pool_dirs, grads.flat):
-            t.record_stream(side2)
+        # (no record_stream marks: every tensor the side streams touch stays referenced until this function returns, i.e.
+        # until after the join above is enqueued -- whatever reuses its memory later on this stream is ordered behind it;
+        # the marks would only keep the allocator from reusing the blocks while the host runs ahead of the GPU)
         gpar = [grads.grad(k) for k in ops.RAW_WEIGHT_KEYS]
         gpar[-1] = d_var.reshape(gpar[-1].shape)
         out = [g if (n and g is not None) else None for g, n in zip(gpar + gvol, need)]

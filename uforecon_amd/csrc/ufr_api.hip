@@ -539,18 +539,18 @@ static RayBwdWs carve_ray_bwd(Carver& c, int RN, int SN) {
 }
 static int ray_bwd_impl(const void* packed, const GradPtrs& gp, const float* token0, const int* row, bool accumulate,
                         const float* d_srdf, int RN, int SN, float* d_tok_a, float* d_tok_b, const RayBwdWs& w, bool lowp,
-                        int* status, hipStream_t s) {
+                        int* status, hipStream_t s, int stages = UFR_BWD_STAGE_ALL) {
   const float* pk = static_cast<const float*>(packed);
-  UFR_HIP(launch_order_pe(w.order_pe, SN, s));
-  {
+  if (stages & UFR_BWD_STAGE_TAPE) {
+    UFR_HIP(launch_order_pe(w.order_pe, SN, s));
     ProfScope p("ray_tape", s);
     UFR_HIP(launch_ray_tape(pk, token0, row, w.order_pe, RN, SN, w.srdf, w.tape, w.state, lowp, status, s));
   }
-  {
+  if (stages & UFR_BWD_STAGE_DGRAD) {
     ProfScope p("ray_dgrad", s);
     UFR_HIP(launch_ray_dgrad(pk, w.tape, w.state, d_srdf, row, accumulate, RN, SN, w.dbuf, d_tok_a, d_tok_b, gp, lowp, s));
   }
-  {
+  if (stages & UFR_BWD_STAGE_WGRAD) {
     ProfScope p("ray_wgrad", s);
     UFR_HIP(launch_ray_wgrad(w.tape, w.dbuf, w.blocks, gp, lowp, s));
   }
@@ -700,12 +700,23 @@ int ufr_ray_transform(const void* packed_weights, const float* token0, const int
 int ufr_ray_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const void* packed_weights, const float* token0,
                           const int32_t* row, int32_t RN, int32_t SN, const float* d_srdf, float* d_token0_a, float* d_token0_b,
                           int32_t accumulate, void* workspace, int32_t precision, ufr_stream stream) {
+  return ufr_ray_transform_bwd_stages(raw, grads, packed_weights, token0, row, RN, SN, d_srdf, d_token0_a, d_token0_b, accumulate,
+                                      workspace, UFR_BWD_STAGE_ALL, precision, stream);
+}
+
+int ufr_ray_transform_bwd_stages(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const void* packed_weights,
+                                 const float* token0, const int32_t* row, int32_t RN, int32_t SN, const float* d_srdf,
+                                 float* d_token0_a, float* d_token0_b, int32_t accumulate, void* workspace, int32_t stages,
+                                 int32_t precision, ufr_stream stream) {
   RawPtrs rp;
   GradPtrs gp;
   int rc = raw_and_grads(raw, grads, rp, gp, "ufr_ray_transform_bwd");
   if (rc != UFR_OK) return rc;
   UFR_PRECISION(precision, lowp, "ufr_ray_transform_bwd");
-  UFR_REQUIRE(packed_weights && token0 && d_srdf && d_token0_a && workspace, "ufr_ray_transform_bwd: null argument");
+  UFR_REQUIRE(stages > 0 && (stages & ~UFR_BWD_STAGE_ALL) == 0, "ufr_ray_transform_bwd_stages: stages=%d", stages);
+  UFR_REQUIRE(packed_weights && workspace, "ufr_ray_transform_bwd: null argument");
+  UFR_REQUIRE(!(stages & UFR_BWD_STAGE_TAPE) || token0, "ufr_ray_transform_bwd: the tape stage needs token0");
+  UFR_REQUIRE(!(stages & UFR_BWD_STAGE_DGRAD) || (d_srdf && d_token0_a), "ufr_ray_transform_bwd: the data-gradient stage needs d_srdf, d_token0_a");
   UFR_REQUIRE(RN > 0 && SN >= 16 && SN % 16 == 0 && SN <= 256, "ufr_ray_transform_bwd: SN=%d must be a multiple of 16 in [16,256]", SN);
   hipStream_t s = static_cast<hipStream_t>(stream);
   Carver c(workspace);
@@ -713,7 +724,8 @@ int ufr_ray_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads
   StatusSlot* sl = nullptr;
   rc = status_slot(&sl);
   if (rc != UFR_OK) return rc;
-  return ray_bwd_impl(packed_weights, gp, token0, row, accumulate != 0, d_srdf, RN, SN, d_token0_a, d_token0_b, rw, lowp, sl->dev, s);
+  return ray_bwd_impl(packed_weights, gp, token0, row, accumulate != 0, d_srdf, RN, SN, d_token0_a, d_token0_b, rw, lowp, sl->dev, s,
+                      stages);
 }
 
 int ufr_view_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const void* packed_weights,

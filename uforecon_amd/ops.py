@@ -471,9 +471,13 @@ def ray_transform(weights: PackedWeights, token0: torch.Tensor, RN: int, SN: int
     return srdf
 
 
+def ray_transform_bwd_workspace(RN: int, SN: int, device) -> torch.Tensor:
+    return torch.empty(_lib.load().ufr_ray_transform_bwd_workspace_bytes(RN, SN) // 4, dtype=torch.float32, device=device)
+
+
 def ray_transform_bwd(weights: PackedWeights, grads: GradBuffer, token0: torch.Tensor, RN: int, SN: int, d_srdf: torch.Tensor,
                       row: Optional[torch.Tensor] = None, out=None, accumulate: bool = False, precision: Optional[int] = None,
-                      _workspace_out: Optional[list] = None):
+                      _workspace_out: Optional[list] = None, stages: int = 7, workspace: Optional[torch.Tensor] = None):
     """-> the two partial d token0 buffers of the ray kernel's sweeps (their sum is the gradient).  Plain form: (RN*SN,80)
     in slot order.  Pool form: ``row`` maps slots to rows of ``token0`` and of the two pool-sized buffers ``out=(a, b)``,
     which are overwritten or, with ``accumulate``, added to.  ``b`` may be None: nothing is zero-filled then (the caller owns
@@ -485,12 +489,15 @@ def ray_transform_bwd(weights: PackedWeights, grads: GradBuffer, token0: torch.T
         b = torch.empty(RN * SN, _lib.TOKEN_DIM, dtype=torch.float32, device=dev)
     else:
         a, b = out
-    ws = torch.empty(lib.ufr_ray_transform_bwd_workspace_bytes(RN, SN) // 4, dtype=torch.float32, device=dev)
+    ws = workspace if workspace is not None else ray_transform_bwd_workspace(RN, SN, dev)
     d_srdf = d_srdf.contiguous()
-    _lib.check(lib.ufr_ray_transform_bwd(C.byref(weights.raw), C.byref(grads.raw), weights.packed.data_ptr(), _dev(token0, "token0"),
-                                         None if row is None else _dev(row, "row", torch.int32), RN, SN,
-                                         _dev(d_srdf, "d_srdf"), _dev(a, "d_token0_a"), _opt(b, "d_token0_b"), int(accumulate),
-                                         ws.data_ptr(), weights.mode() if precision is None else precision, _stream()),
+    # stages (include/ufr.h: ufr_ray_transform_bwd_stages): tape + data gradients (3) write ``out``; the weight gradients (4)
+    # feed nothing downstream -- a caller may run them later / elsewhere on the same ``workspace``
+    _lib.check(lib.ufr_ray_transform_bwd_stages(C.byref(weights.raw), C.byref(grads.raw), weights.packed.data_ptr(),
+                                                _dev(token0, "token0"), None if row is None else _dev(row, "row", torch.int32),
+                                                RN, SN, _dev(d_srdf, "d_srdf"), _dev(a, "d_token0_a"), _opt(b, "d_token0_b"),
+                                                int(accumulate), ws.data_ptr(), stages,
+                                                weights.mode() if precision is None else precision, _stream()),
                "ufr_ray_transform_bwd")
     if _workspace_out is not None:      # development: the tape / cotangent tiles (tools/dev/ray_bwd_check.py)
         _workspace_out.append(ws)

@@ -227,12 +227,20 @@ def _train_step(name):
     return m, f, r, loss, g
 
 
+@pytest.mark.parametrize("overlap", [True, False])
 @pytest.mark.parametrize("name", ["c5_train_grads", "c5_train_grads_nv4"])
-def test_training_step_gradients_match_reference_autograd(name):
-    """loss.backward() through UFORecon.infer == the reference's autograd (golden), every parameter and volume."""
+def test_training_step_gradients_match_reference_autograd(name, overlap):
+    """loss.backward() through UFORecon.infer == the reference's autograd (golden), every parameter and volume -- with the
+    backward's independent stages side by side on three streams (autograd.OVERLAP, the default) and all on one."""
+    from uforecon_amd import autograd as ag
+
     m, f, r, loss, g = _train_step(name)
     assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
-    loss.backward()
+    ag.OVERLAP = overlap
+    try:
+        loss.backward()
+    finally:
+        ag.OVERLAP = True
     torch.cuda.synchronize()
     worst = {}
     for k, p in m.named_parameters():

@@ -273,7 +273,12 @@ int ufr_aggregate_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, co
  * added to when accumulate != 0 (the scatter itself goes into a channel-last record volume in `workspace`,
  * ufr_project_gather_bwd_workspace_bytes(frame) bytes = 1.33 x the volumes: nine lanes of one atomic instruction add the
  * nine values of a voxel corner as ONE L2 transaction, then one coalesced pass writes these tensors);
- * both arrays NULL: only the pre_sim_mlp gradients (accumulated into `grads`) are computed, no workspace needed. */
+ * both arrays NULL: only the pre_sim_mlp gradients (accumulated into `grads`) are computed, no workspace needed.
+ * `accumulate` is a bit set: UFR_GBWD_ACCUMULATE, and UFR_GBWD_WORKSPACE_ZEROED = the caller has zero-filled `workspace`
+ * (ordered before this call on `stream`), e.g. on another stream beside earlier work -- the library then skips its own
+ * memset (0.9 GB at the configs[4] size). */
+#define UFR_GBWD_ACCUMULATE 1
+#define UFR_GBWD_WORKSPACE_ZEROED 2
 size_t ufr_project_gather_bwd_workspace_bytes(const ufr_frame* frame);
 int ufr_project_gather_bwd(const ufr_frame* frame, const ufr_raw_weights* raw, const ufr_raw_grads* grads,
                            const float* ray_o, int32_t ray_o_stride, const float* ray_d, const float* z, int32_t RN,

@@ -187,9 +187,14 @@ class RenderTwoPass(torch.autograd.Function):
         ws_f = _workspace("ray_f", dev, lambda: lib.ufr_ray_transform_bwd_workspace_bytes(RN, S2) // 4)
         side.wait_stream(main)
         side2.wait_stream(main)
+        need = ctx.needs_input_grad[6:]
+        want_vol = any(need[ctx.n_par:])
+        gws = _workspace("gather_bwd", dev, lambda: ops.project_gather_bwd_workspace_floats(frame)) if want_vol else None
         with torch.cuda.stream(side2):
             ops.view_transform_bwd(W, grads, pool_x, pool_rgbm, pool_dirs, None, None, None, precision=prec,
                                    stages=ops.STAGE_TAPE, workspace=vws)
+            if gws is not None:
+                gws.zero_()           # the frustum scatter's record volume: zero-filled here, off the critical path
         # (the ray weight-gradient contractions feed nothing downstream either: tape + data gradients first, on both
         # streams; the contractions afterwards on the side stream, beside the view transformer's data gradients)
         with torch.cuda.stream(side):
@@ -215,8 +220,7 @@ class RenderTwoPass(torch.autograd.Function):
         with torch.cuda.stream(side):
             ops.view_transform_bwd(W, grads, pool_x, pool_rgbm, pool_dirs, None, None, None, precision=prec,
                                    stages=ops.STAGE_WGRAD, workspace=vws)
-        need = ctx.needs_input_grad[6:]
-        if any(need[ctx.n_par:]):
+        if want_vol:
             gvol = [torch.empty(s, dtype=torch.float32, device=dev) for s in ctx.vol_shapes]      # written whole: no zero-fill
             gf, gw = gvol[0::2], gvol[1::2]
         else:
@@ -225,7 +229,7 @@ class RenderTwoPass(torch.autograd.Function):
         # ONE frustum scatter over all merged samples of a ray (z2: sorted, twice the density of either pass -- the run
         # folding of gather_bwd.hip removes more corner records), d_pv / sim8 addressed through the slot -> row table
         ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z2, sim8_pool, d_pv, gf, gw, precision=prec, row=row,
-                               accumulate=False)
+                               accumulate=False, zeroed_workspace=gws)
         main.wait_stream(side)
         # (no record_stream marks: every tensor the side streams touch stays referenced until this function returns, i.e.
         # until after the join above is enqueued -- whatever reuses its memory later on this stream is ordered behind it;

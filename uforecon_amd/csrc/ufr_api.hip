@@ -637,7 +637,8 @@ int ufr_project_gather_bwd(const ufr_frame* frame, const ufr_raw_weights* raw, c
   if (scatter) {
     ProfScope p("gather_bwd", s);
     UFR_HIP(launch_gather_bwd(*f, grad_vol_feat, grad_vol_weight, ray_o, ray_o_stride, ray_d, z, d_pv, row, RN, SN,
-                              static_cast<float*>(workspace), accumulate != 0, s));
+                              static_cast<float*>(workspace), (accumulate & UFR_GBWD_ACCUMULATE) != 0,
+                              (accumulate & UFR_GBWD_WORKSPACE_ZEROED) != 0, s));
   }
   {
     ProfScope p("presim_bwd", s);

@@ -112,7 +112,7 @@ hipError_t launch_presim_bwd(const RawPtrs& wp, const GradPtrs& gp, const float*
 size_t gather_bwd_scratch_floats(const FrameDev& f);
 hipError_t launch_gather_bwd(const FrameDev& f, float* const* grad_feat, float* const* grad_weight, const float* ray_o,
                              int o_stride, const float* ray_d, const float* z, const float* d_pv, const int* pv_row, int RN,
-                             int SN, float* scratch, bool accumulate, hipStream_t s);
+                             int SN, float* scratch, bool accumulate, bool scratch_zeroed, hipStream_t s);
 struct FmtWeights {  // = ufr_fmt_layer_weights
   const float *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo, *w1, *b1, *w2, *b2, *n1w, *n1b, *n2w, *n2b;
 };

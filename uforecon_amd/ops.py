@@ -395,13 +395,19 @@ def aggregate_bwd(weights: PackedWeights, grads: GradBuffer, x, rgb, dirs, token
     return d_pv, dbg
 
 
+def project_gather_bwd_workspace_floats(frame: FrameHandle) -> int:
+    return _lib.load().ufr_project_gather_bwd_workspace_bytes(C.byref(frame.frame)) // 4
+
+
 def project_gather_bwd(frame: FrameHandle, weights: PackedWeights, grads: GradBuffer, ray_o, ray_d, z, sim8, d_pv,
                        grad_vol_feat, grad_vol_weight, precision: Optional[int] = None,
-                       row: Optional[torch.Tensor] = None, accumulate: bool = True) -> None:
+                       row: Optional[torch.Tensor] = None, accumulate: bool = True,
+                       zeroed_workspace: Optional[torch.Tensor] = None) -> None:
     """Writes the frustum gradients grad_vol_feat[s] (NV,8,D,Hs,Ws) / grad_vol_weight[s] (NV,1,D,Hs,Ws) -- added to what the
     tensors hold (``accumulate``, the default: pass zeros) or overwriting them whole (``accumulate=False``: pass
     ``torch.empty``, no zero-fill needed) -- and accumulates the pre_sim_mlp gradients into `grads`.  ``row`` (RN,SN) int32:
-    ``sim8`` / ``d_pv`` are pool tensors and slot (ray, s) owns ``d_pv[row[ray, s]]``."""
+    ``sim8`` / ``d_pv`` are pool tensors and slot (ray, s) owns ``d_pv[row[ray, s]]``.  ``zeroed_workspace``: the scatter's
+    record volume (project_gather_bwd_workspace_floats), already zero-filled by the caller -- ordered before this call."""
     RN, SN = z.shape
     lib = _lib.load()
     stride = 0 if ray_o.numel() == 3 else 3
@@ -409,12 +415,14 @@ def project_gather_bwd(frame: FrameHandle, weights: PackedWeights, grads: GradBu
     if grad_vol_feat is not None:
         gf = (C.c_void_p * 3)(*[_dev(t, "grad_vol_feat") for t in grad_vol_feat])
         gw = (C.c_void_p * 3)(*[_dev(t, "grad_vol_weight") for t in grad_vol_weight])
-        # channel-last record volume of the scatter (zeroed by the library)
-        ws = torch.empty(lib.ufr_project_gather_bwd_workspace_bytes(C.byref(frame.frame)) // 4, dtype=torch.float32, device=z.device)
+        # channel-last record volume of the scatter (zeroed by the library unless the caller did)
+        ws = zeroed_workspace if zeroed_workspace is not None else torch.empty(
+            project_gather_bwd_workspace_floats(frame), dtype=torch.float32, device=z.device)
     _lib.check(lib.ufr_project_gather_bwd(
         C.byref(frame.frame), C.byref(weights.raw), C.byref(grads.raw), _dev(ray_o, "ray_o"), stride, _dev(ray_d, "ray_d"),
         _dev(z, "z"), RN, SN, _dev(sim8, "sim8"), _dev(d_pv, "d_pv"), None if row is None else _dev(row, "row", torch.int32),
-        gf, gw, int(bool(accumulate)), None if ws is None else ws.data_ptr(),
+        gf, gw, int(bool(accumulate)) | (2 if (zeroed_workspace is not None and ws is not None) else 0),
+        None if ws is None else ws.data_ptr(),
         weights.mode() if precision is None else precision, _stream()), "ufr_project_gather_bwd")
 
 

@@ -32,7 +32,7 @@ enum ufr_status {
 
 /* Version of this header's ABI (argument lists, struct layouts, packed-blob layout).  ufr_version() returns the value
  * the library was built with: a binding must refuse a library whose version differs (uforecon_amd/_lib.py does). */
-#define UFR_ABI_VERSION 403
+#define UFR_ABI_VERSION 404
 
 #define UFR_MAX_VIEWS 7
 #define UFR_NUM_STAGES 3
@@ -325,6 +325,18 @@ int ufr_view_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grad
  *          them, so they can run beside ufr_project_gather_bwd (which needs d_pv only).
  * The SAME workspace must be passed to every stage, and the stages must execute in this order (stream events are the
  * caller's business).  stages = UFR_BWD_STAGE_ALL is ufr_view_transform_bwd. */
+/* Training forward WITH the tape: what ufr_view_transform / ufr_ray_transform compute (same numbers), recorded into the
+ * workspace of the matching backward call, whose TAPE stage is then skipped (stages = DGRAD | WGRAD): nothing is computed
+ * twice.  View: the points [p0, p0 + P) of a pool of P_total points that ONE backward will walk; x_tokens / rgb / dir /
+ * token0 / radiance point at the range's first row; p0 (and P, unless the range closes the pool) must be multiples of
+ * ufr_view_tape_block_points(NV); workspace: ufr_view_transform_bwd_workspace_bytes(P_total, NV).  Ray: one pass;
+ * workspace: ufr_ray_transform_bwd_workspace_bytes(RN, SN). */
+int32_t ufr_view_tape_block_points(int32_t NV);
+int ufr_view_transform_tape(const void* packed_weights, const float* x_tokens, const float* rgb, const float* dir, int32_t P,
+                            int32_t NV, float* token0, float* radiance, void* workspace, int32_t p0, int32_t P_total,
+                            int32_t precision, ufr_stream stream);
+int ufr_ray_transform_tape(const void* packed_weights, const float* token0, const int32_t* row, int32_t RN, int32_t SN,
+                           float* srdf, void* workspace, int32_t precision, ufr_stream stream);
 int ufr_ray_transform_bwd_stages(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const void* packed_weights,
                                  const float* token0, const int32_t* row, int32_t RN, int32_t SN, const float* d_srdf,
                                  float* d_token0_a, float* d_token0_b, int32_t accumulate, void* workspace, int32_t stages,

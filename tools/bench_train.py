@@ -262,9 +262,11 @@ def run(a, dev, world=1, rank=0):
                         ray_transformer=sum(prof[k]["ms"] for k in ("ray_tape", "ray_dgrad", "ray_wgrad") if k in prof) / a.steps,
                         frustum_scatter=prof.get("gather_bwd", dict(ms=0.0))["ms"] / a.steps),
                     kernel_ms_measured=("extra untimed steps after the timed region with the backward's stream overlap off; in "
-                                        "the timed steps the coarse / fine ray backwards and the view tape build run side by "
-                                        "side, and the view weight gradients beside the frustum scatter "
-                                        "(uforecon_amd/autograd.py), so ms_per_step is less than the kernels' sum"),
+                                        "the timed steps the coarse / fine ray backwards run side by side, and the weight "
+                                        "gradients beside the view data gradients / the frustum scatter "
+                                        "(uforecon_amd/autograd.py), so ms_per_step is less than the kernels' sum.  view_tape / "
+                                        "ray_tape ARE the training forward of the two transformers (they record the "
+                                        "backward's tape): there is no separate view_transformer / ray_transformer launch"),
                     loss=float(loss.detach()),
                     kernel_ms_per_step_rank0={k: v["ms"] / a.steps for k, v in prof.items()},
                     kernel_launches_per_step={k: v["launches"] / a.steps for k, v in prof.items()},

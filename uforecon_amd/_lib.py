@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # UFR_LIB selects an alternative in-tree build (A/B kernel variants during development)
 LIB_PATH = os.environ.get("UFR_LIB") or os.path.join(HERE, "lib", "libufr.so")
 
-ABI_VERSION = 403   # = UFR_ABI_VERSION of include/ufr.h; load() refuses a library built against another header
+ABI_VERSION = 404   # = UFR_ABI_VERSION of include/ufr.h; load() refuses a library built against another header
 MAX_VIEWS = 7
 NUM_STAGES = 3
 TOKEN_DIM = 80
@@ -108,6 +108,9 @@ SIGNATURES = {
     "ufr_ray_transform_bwd": (C.c_int, [C.POINTER(RawWeights), C.POINTER(RawGrads), vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, i32, vp]),
     "ufr_view_transform_bwd_workspace_bytes": (sz, [i32, i32]),
     "ufr_view_transform_bwd": (C.c_int, [C.POINTER(RawWeights), C.POINTER(RawGrads), vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, vp]),
+    "ufr_view_tape_block_points": (i32, [i32]),
+    "ufr_view_transform_tape": (C.c_int, [vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, vp]),
+    "ufr_ray_transform_tape": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, i32, vp]),
     "ufr_ray_transform_bwd_stages": (C.c_int, [C.POINTER(RawWeights), C.POINTER(RawGrads), vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, i32, i32, vp]),
     "ufr_view_transform_bwd_stages": (C.c_int, [C.POINTER(RawWeights), C.POINTER(RawGrads), vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp]),
     "ufr_render_workspace_bytes": (sz, [i32, i32, i32, i32]),

@@ -87,6 +87,30 @@ def _workspace(kind: str, dev, numel_of) -> torch.Tensor:
     return t
 
 
+_BUSY = {}          # key -> weak reference to the autograd context that holds the kept buffer between its forward and backward
+RECORD_TAPE = True  # the caller's hint: a backward will follow this forward (uforecon_amd.model sets it from the grad mode)
+
+
+def _acquire(kind: str, dev, numel_of, ctx):
+    """A tile buffer that must survive from a forward to its backward: the kept one (_workspace) when no live forward
+    holds it, else a private allocation (two forwards before a backward, e.g. gradient accumulation over frames).
+    Returns (tensor, key or None); _release(key) in the backward.  A holder that died without a backward (a graph that
+    was dropped) is detected through the weak reference."""
+    import weakref
+
+    key = (kind, torch.device(dev).index or 0)
+    holder = _BUSY.get(key)
+    if holder is not None and holder() is not None:
+        return torch.empty(int(numel_of()), dtype=torch.float32, device=dev), None
+    _BUSY[key] = weakref.ref(ctx)
+    return _workspace(kind, dev, numel_of), key
+
+
+def _release(key) -> None:
+    if key is not None:
+        _BUSY.pop(key, None)
+
+
 def _side_stream(dev, i: int = 0) -> "torch.cuda.Stream":
     """Side streams per device for the multi-stream backward of RenderTwoPass (created once: stream creation is slow)."""
     key = (torch.device(dev).index or 0, i)
@@ -127,14 +151,36 @@ class RenderTwoPass(torch.autograd.Function):
         pool_dirs = torch.empty(P1 + P2, NV, 4, dtype=torch.float32, device=dev)
         x1, rgbm1, dirs1, g1 = ops.project_gather(frame, weights, ray_o, ray_d, z1, want_xy=True, sim8_out=sim8_pool[:P1],
                                                   out=(pool_x[:P1], pool_rgbm[:P1], pool_dirs[:P1]))
-        ops.view_transform(weights, x1, rgbm1, dirs1, token0=pool_tok[:P1], radiance=pool_rad[:P1], precision=prec)
-        srdf1 = ops.ray_transform(weights, pool_tok[:P1], RN, SN, precision=prec)
+        # The forward kernels run in their TAPE instantiation and record the activations straight into the backward's
+        # workspaces (one view tape over the whole pool, one ray tape per pass): the backward starts at its data-gradient
+        # stage, nothing is computed twice.  (Needs the coarse rows to end on a tape block: else the backward records.)
+        lib = ops._lib.load()
+        taped = RECORD_TAPE and P1 % ops.view_tape_block_points(NV) == 0
+        ctx.ws_keys = []
+        if taped:
+            vws, k = _acquire("view", dev, lambda: lib.ufr_view_transform_bwd_workspace_bytes(P1 + P2, NV) // 4, ctx)
+            ctx.ws_keys.append(k)
+            ws_c, k = _acquire("ray_c", dev, lambda: lib.ufr_ray_transform_bwd_workspace_bytes(RN, SN) // 4, ctx)
+            ctx.ws_keys.append(k)
+            ws_f, k = _acquire("ray_f", dev, lambda: lib.ufr_ray_transform_bwd_workspace_bytes(RN, S2) // 4, ctx)
+            ctx.ws_keys.append(k)
+            ctx.tapes = (vws, ws_c, ws_f)
+            ops.view_transform_tape(weights, x1, rgbm1, dirs1, pool_tok[:P1], pool_rad[:P1], vws, 0, P1 + P2, precision=prec)
+            srdf1 = ops.ray_transform_tape(weights, pool_tok[:P1], RN, SN, ws_c, precision=prec)
+        else:
+            ctx.tapes = None
+            ops.view_transform(weights, x1, rgbm1, dirs1, token0=pool_tok[:P1], radiance=pool_rad[:P1], precision=prec)
+            srdf1 = ops.ray_transform(weights, pool_tok[:P1], RN, SN, precision=prec)
         rgb, depth, opacity, weight = ops.composite(z1, pool_rad[:P1].view(RN, SN, 3), srdf1, var)
         z2, z_new, row = ops.sample_importance_pool(weight, z1, U2)                  # model.py:455-470 (weights detached)
         x2, rgbm2, dirs2, g2 = ops.project_gather(frame, weights, ray_o, ray_d, z_new, want_xy=True, sim8_out=sim8_pool[P1:],
                                                   out=(pool_x[P1:], pool_rgbm[P1:], pool_dirs[P1:]))
-        ops.view_transform(weights, x2, rgbm2, dirs2, token0=pool_tok[P1:], radiance=pool_rad[P1:], precision=prec)
-        srdf2 = ops.ray_transform(weights, pool_tok, RN, S2, row=row, precision=prec)
+        if taped:
+            ops.view_transform_tape(weights, x2, rgbm2, dirs2, pool_tok[P1:], pool_rad[P1:], vws, P1, P1 + P2, precision=prec)
+            srdf2 = ops.ray_transform_tape(weights, pool_tok, RN, S2, ws_f, row=row, precision=prec)
+        else:
+            ops.view_transform(weights, x2, rgbm2, dirs2, token0=pool_tok[P1:], radiance=pool_rad[P1:], precision=prec)
+            srdf2 = ops.ray_transform(weights, pool_tok, RN, S2, row=row, precision=prec)
         rgb2, depth2, opacity2, weight2 = ops.composite(z2, pool_rad, srdf2, var, row=row)
         xy2 = torch.cat([g1["xy"], g2["xy"]], 1)[:, row.reshape(-1).long()]         # (NV, RN*S2, 2), a returned value only
         ctx.frame, ctx.weights, ctx.n_par, ctx.precision = frame, weights, n_par, prec
@@ -182,26 +228,32 @@ class RenderTwoPass(torch.autograd.Function):
         main = torch.cuda.current_stream(dev)
         side, side2 = (_side_stream(dev, 0), _side_stream(dev, 1)) if OVERLAP else (main, main)
         lib = ops._lib.load()
-        vws = _workspace("view", dev, lambda: lib.ufr_view_transform_bwd_workspace_bytes(pool_tok.shape[0], pool_x.shape[1]) // 4)
-        ws_c = _workspace("ray_c", dev, lambda: lib.ufr_ray_transform_bwd_workspace_bytes(RN, SN) // 4)
-        ws_f = _workspace("ray_f", dev, lambda: lib.ufr_ray_transform_bwd_workspace_bytes(RN, S2) // 4)
+        taped = ctx.tapes is not None
+        if taped:
+            vws, ws_c, ws_f = ctx.tapes
+        else:
+            vws = _workspace("view", dev, lambda: lib.ufr_view_transform_bwd_workspace_bytes(pool_tok.shape[0], pool_x.shape[1]) // 4)
+            ws_c = _workspace("ray_c", dev, lambda: lib.ufr_ray_transform_bwd_workspace_bytes(RN, SN) // 4)
+            ws_f = _workspace("ray_f", dev, lambda: lib.ufr_ray_transform_bwd_workspace_bytes(RN, S2) // 4)
+        ray_first = ops.STAGE_DGRAD if taped else (ops.STAGE_TAPE | ops.STAGE_DGRAD)
         side.wait_stream(main)
         side2.wait_stream(main)
         need = ctx.needs_input_grad[6:]
         want_vol = any(need[ctx.n_par:])
         gws = _workspace("gather_bwd", dev, lambda: ops.project_gather_bwd_workspace_floats(frame)) if want_vol else None
         with torch.cuda.stream(side2):
-            ops.view_transform_bwd(W, grads, pool_x, pool_rgbm, pool_dirs, None, None, None, precision=prec,
-                                   stages=ops.STAGE_TAPE, workspace=vws)
+            if not taped:
+                ops.view_transform_bwd(W, grads, pool_x, pool_rgbm, pool_dirs, None, None, None, precision=prec,
+                                       stages=ops.STAGE_TAPE, workspace=vws)
             if gws is not None:
                 gws.zero_()           # the frustum scatter's record volume: zero-filled here, off the critical path
         # (the ray weight-gradient contractions feed nothing downstream either: tape + data gradients first, on both
         # streams; the contractions afterwards on the side stream, beside the view transformer's data gradients)
         with torch.cuda.stream(side):
             ops.ray_transform_bwd(W, grads, pool_tok[:P1], RN, SN, d_srdf_c, out=(pool_b[:P1], None), precision=prec,
-                                  stages=ops.STAGE_TAPE | ops.STAGE_DGRAD, workspace=ws_c)
+                                  stages=ray_first, workspace=ws_c)
         ops.ray_transform_bwd(W, grads, pool_tok, RN, S2, d_srdf_s, row=row, out=(pool_a, None), precision=prec,
-                              stages=ops.STAGE_TAPE | ops.STAGE_DGRAD, workspace=ws_f)
+                              stages=ray_first, workspace=ws_f)
         main.wait_stream(side)
         main.wait_stream(side2)
         side.wait_stream(main)
@@ -234,6 +286,9 @@ class RenderTwoPass(torch.autograd.Function):
         # (no record_stream marks: every tensor the side streams touch stays referenced until this function returns, i.e.
         # until after the join above is enqueued -- whatever reuses its memory later on this stream is ordered behind it;
         # the marks would only keep the allocator from reusing the blocks while the host runs ahead of the GPU)
+        for k in getattr(ctx, "ws_keys", ()):
+            _release(k)
+        ctx.tapes = None
         gpar = [grads.grad(k) for k in ops.RAW_WEIGHT_KEYS]
         gpar[-1] = d_var.reshape(gpar[-1].shape)
         out = [g if (n and g is not None) else None for g, n in zip(gpar + gvol, need)]

@@ -676,6 +676,63 @@ int ufr_view_transform(const void* packed_weights, const float* x_tokens, const 
   return status_leave(sl, s);
 }
 
+// The forward WITH the tape (training): the TAPE instantiation of the forward kernel writes token0 / radiance like
+// ufr_view_transform and records the activations into the backward's workspace, so that the backward starts at its
+// data-gradient stage -- nothing is computed twice.
+int32_t ufr_view_tape_block_points(int32_t NV) {
+  return (NV >= 2 && NV <= UFR_MAX_VIEWS) ? (16 / (NV + 1)) * kBlockCols : 0;
+}
+
+int ufr_view_transform_tape(const void* packed_weights, const float* x_tokens, const float* rgb, const float* dir, int32_t P,
+                            int32_t NV, float* token0, float* radiance, void* workspace, int32_t p0, int32_t P_total,
+                            int32_t precision, ufr_stream stream) {
+  UFR_REQUIRE(packed_weights && x_tokens && rgb && dir && token0 && radiance && workspace, "ufr_view_transform_tape: null argument");
+  UFR_REQUIRE(NV >= 2 && NV <= UFR_MAX_VIEWS && P > 0 && p0 >= 0 && p0 + P <= P_total, "ufr_view_transform_tape: P=%d p0=%d P_total=%d NV=%d",
+              P, p0, P_total, NV);
+  const int ppw = ufr_view_tape_block_points(NV);
+  UFR_REQUIRE(p0 % ppw == 0 && (p0 + P == P_total || P % ppw == 0),
+              "ufr_view_transform_tape: the point range [%d, %d) must start and (unless it closes the pool) end on a multiple of %d points",
+              p0, p0 + P, ppw);
+  UFR_REQUIRE((unsigned long long)P_total * (NV + 1) * UFR_TOKEN_DIM < (1ull << 30),
+              "ufr_view_transform_tape: %d points x %d tokens exceed the 2^30 token values one backward addresses", P_total, NV + 1);
+  UFR_PRECISION(precision, lowp, "ufr_view_transform_tape");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Carver c(workspace);
+  const ViewBwdWs vw = carve_view_bwd(c, P_total, NV);
+  StatusSlot* sl = nullptr;
+  int rc = status_slot(&sl);
+  if (rc == UFR_OK) rc = status_enter(sl, s, "ufr_view_transform_tape");
+  if (rc != UFR_OK) return rc;
+  const size_t blk_floats = (size_t)(lowp ? ViewTapeLayout<true>::block_units : ViewTapeLayout<false>::block_units) * 128;
+  {
+    ProfScope p("view_tape", s);
+    UFR_HIP(launch_view_tape(static_cast<const float*>(packed_weights), x_tokens, rgb, dir, P, NV, token0, radiance,
+                             vw.tape + (size_t)(p0 / ppw) * blk_floats, lowp, sl->dev, s));
+  }
+  return status_leave(sl, s);
+}
+
+int ufr_ray_transform_tape(const void* packed_weights, const float* token0, const int32_t* row, int32_t RN, int32_t SN,
+                           float* srdf, void* workspace, int32_t precision, ufr_stream stream) {
+  UFR_REQUIRE(packed_weights && token0 && srdf && workspace, "ufr_ray_transform_tape: null argument");
+  UFR_REQUIRE(RN > 0 && SN >= 16 && SN % 16 == 0 && SN <= 256, "ufr_ray_transform_tape: SN=%d must be a multiple of 16 in [16,256]", SN);
+  UFR_PRECISION(precision, lowp, "ufr_ray_transform_tape");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Carver c(workspace);
+  const RayBwdWs rw = carve_ray_bwd(c, RN, SN);
+  StatusSlot* sl = nullptr;
+  int rc = status_slot(&sl);
+  if (rc == UFR_OK) rc = status_enter(sl, s, "ufr_ray_transform_tape");
+  if (rc != UFR_OK) return rc;
+  UFR_HIP(launch_order_pe(rw.order_pe, SN, s));
+  {
+    ProfScope p("ray_tape", s);
+    UFR_HIP(launch_ray_tape(static_cast<const float*>(packed_weights), token0, row, rw.order_pe, RN, SN, srdf, rw.tape, rw.state, lowp,
+                            sl->dev, s));
+  }
+  return status_leave(sl, s);
+}
+
 size_t ufr_ray_transform_workspace_bytes(int32_t SN) { return align_up((size_t)(SN > 0 ? SN : 1) * 8 * sizeof(float)); }
 
 int ufr_ray_transform(const void* packed_weights, const float* token0, const int32_t* row, int32_t RN, int32_t SN,

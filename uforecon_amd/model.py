@@ -364,6 +364,7 @@ class UFORecon(nn.Module):
         # samples' rows with the coarse pass, forwards and backwards (autograd.RenderTwoPass; same numbers as two sample2rgb
         # calls on z1 and on the merged z2, model.py:445, 472)
         params, vols = self._live_params(), ag.flat_volumes(feature_volume)
+        ag.RECORD_TAPE = _wants_grad(*params, *vols)     # a backward will follow: the forward records its tape (autograd.py)
         (rgb, depth, opacity, weight, srdf, xy1, rgb2, depth2, opacity2, weight2, srdf2, xy2, z2) = ag.RenderTwoPass.apply(
             fh, W, ray_o, ray_d, z1, U2, *params, *vols)
         S2 = z2.shape[1]

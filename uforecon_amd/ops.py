@@ -479,6 +479,34 @@ def ray_transform(weights: PackedWeights, token0: torch.Tensor, RN: int, SN: int
     return srdf
 
 
+def view_tape_block_points(NV: int) -> int:
+    return int(_lib.load().ufr_view_tape_block_points(NV))
+
+
+def view_transform_tape(weights: PackedWeights, x, rgb, dirs, token0, radiance, workspace: torch.Tensor, p0: int, P_total: int,
+                        precision: Optional[int] = None) -> None:
+    """Training forward of the view transformer for the pool rows [p0, p0 + P): writes ``token0`` / ``radiance`` (the
+    range's rows) like view_transform and records the tape into ``workspace`` (view_transform_bwd_workspace(P_total, NV)),
+    whose backward then runs with ``stages=STAGE_DGRAD | STAGE_WGRAD``."""
+    P, NV = x.shape[0], x.shape[1]
+    _lib.check(_lib.load().ufr_view_transform_tape(
+        weights.packed.data_ptr(), _dev(x, "x_tokens"), _dev(rgb, "rgb"), _dev(dirs, "dir"), P, NV, _dev(token0, "token0"),
+        _dev(radiance, "radiance"), workspace.data_ptr(), p0, P_total, weights.mode() if precision is None else precision,
+        _stream()), "ufr_view_transform_tape")
+
+
+def ray_transform_tape(weights: PackedWeights, token0: torch.Tensor, RN: int, SN: int, workspace: torch.Tensor,
+                       row: Optional[torch.Tensor] = None, precision: Optional[int] = None) -> torch.Tensor:
+    """Training forward of the ray transformer: srdf like ray_transform, the tape into ``workspace``
+    (ray_transform_bwd_workspace(RN, SN)); its backward then runs without STAGE_TAPE."""
+    srdf = torch.empty(RN, SN, dtype=torch.float32, device=token0.device)
+    _lib.check(_lib.load().ufr_ray_transform_tape(
+        weights.packed.data_ptr(), _dev(token0, "token0"), None if row is None else _dev(row, "row", torch.int32), RN, SN,
+        srdf.data_ptr(), workspace.data_ptr(), weights.mode() if precision is None else precision, _stream()),
+        "ufr_ray_transform_tape")
+    return srdf
+
+
 def ray_transform_bwd_workspace(RN: int, SN: int, device) -> torch.Tensor:
     return torch.empty(_lib.load().ufr_ray_transform_bwd_workspace_bytes(RN, SN) // 4, dtype=torch.float32, device=device)
 

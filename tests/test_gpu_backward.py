@@ -255,6 +255,43 @@ def test_training_step_gradients_match_reference_autograd(name, overlap):
     assert r[16].requires_grad                       # variance output stays differentiable (train/variance log)
 
 
+def test_two_forwards_before_one_backward_keep_their_own_tapes():
+    """The training forward records the backward's tape into a workspace that is kept between steps (autograd._acquire):
+    a second forward BEFORE the first one's backward (gradient accumulation over two ray batches, one loss) must not
+    overwrite it -- it gets a private buffer.  (a + b).backward() == a.backward() then b.backward(), up to the order of
+    the float atomics."""
+    name = "c5_train_grads"
+    c = CASES[name]
+    fr, idx, U1, U2, g = case_inputs(name)
+    f = fr.to(DEV)
+    for st in f.feature_volume:
+        for k in f.feature_volume[st]:
+            f.feature_volume[st][k].requires_grad_(True)
+    idx2 = (idx + 7).clamp_max(c["H"] * c["W"] - 1)
+
+    def run(joint: bool):
+        m = M.UFORecon(_args(c)).to(DEV)
+        m.load_state_dict(load_weights(), strict=True)
+        m.train()
+        for st in f.feature_volume:
+            for k in f.feature_volume[st]:
+                f.feature_volume[st][k].grad = None
+        losses = []
+        for ix in (idx, idx2):
+            r = m.infer(f.batch, ix.to(DEV), f.source_imgs_feat, f.feature_volume, match_feature=f.match_feature, uniforms=(U1, U2))
+            losses.append(_loss_from_tuple(r, f.batch, ix.to(DEV)))
+            if not joint:
+                losses[-1].backward()
+        if joint:
+            (losses[0] + losses[1]).backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    ga, gb = run(True), run(False)
+    for k in ga:
+        assert grad_rel_err(ga[k], gb[k]) < 2e-4, k
+
+
 def test_parameter_only_backward_matches_and_skips_the_volume_scatter():
     """Frustums without requires_grad (e.g. a frozen cost_reg_2): parameter gradients are unchanged and no volume gradient
     is produced."""

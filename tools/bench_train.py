@@ -221,7 +221,9 @@ def run(a, dev, world=1, rank=0):
     # the view transformer's backward = three kernels per launch (csrc/bwd_tape.h): forward with a tape, data gradients,
     # weight-gradient contraction
     parts = [prof[k] for k in ("view_tape", "view_dgrad", "view_wgrad") if k in prof]
-    vb = dict(ms=sum(p["ms"] for p in parts), launches=max([p["launches"] for p in parts] or [1]))
+    # (a launch GROUP = one data-gradient launch; the tape build of a group is two launches since the training forward
+    # records it: the coarse rows and the new rows of the sample pool)
+    vb = dict(ms=sum(p["ms"] for p in parts), launches=prof.get("view_dgrad", dict(launches=1))["launches"] or 1)
     vb_ms = vb["ms"] / max(vb["launches"], 1)
     # the fine pass evaluates only its new samples at the point level: coarse + fine points per ray over the launches
     vb_pts = a.rays * S * a.steps / max(vb["launches"], 1)

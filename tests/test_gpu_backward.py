@@ -227,14 +227,19 @@ def _train_step(name):
     return m, f, r, loss, g
 
 
-@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("overlap,tape_in_forward", [(True, True), (False, True), (True, False)])
 @pytest.mark.parametrize("name", ["c5_train_grads", "c5_train_grads_nv4"])
-def test_training_step_gradients_match_reference_autograd(name, overlap):
+def test_training_step_gradients_match_reference_autograd(name, overlap, tape_in_forward):
     """loss.backward() through UFORecon.infer == the reference's autograd (golden), every parameter and volume -- with the
-    backward's independent stages side by side on three streams (autograd.OVERLAP, the default) and all on one."""
+    backward's independent stages side by side on three streams (autograd.OVERLAP, the default) and all on one; with the
+    tape recorded by the forward (the default) and by the backward (what unaligned pools fall back to)."""
     from uforecon_amd import autograd as ag
 
-    m, f, r, loss, g = _train_step(name)
+    ag.TAPE_IN_FORWARD = tape_in_forward
+    try:
+        m, f, r, loss, g = _train_step(name)
+    finally:
+        ag.TAPE_IN_FORWARD = True
     assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
     ag.OVERLAP = overlap
     try:

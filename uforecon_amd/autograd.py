@@ -89,6 +89,7 @@ def _workspace(kind: str, dev, numel_of) -> torch.Tensor:
 
 _BUSY = {}          # key -> weak reference to the autograd context that holds the kept buffer between its forward and backward
 RECORD_TAPE = True  # the caller's hint: a backward will follow this forward (uforecon_amd.model sets it from the grad mode)
+TAPE_IN_FORWARD = True   # False (tests, debugging): the plain forward kernels, the backward records the tape itself
 
 
 def _acquire(kind: str, dev, numel_of, ctx):
@@ -155,7 +156,7 @@ class RenderTwoPass(torch.autograd.Function):
         # workspaces (one view tape over the whole pool, one ray tape per pass): the backward starts at its data-gradient
         # stage, nothing is computed twice.  (Needs the coarse rows to end on a tape block: else the backward records.)
         lib = ops._lib.load()
-        taped = RECORD_TAPE and P1 % ops.view_tape_block_points(NV) == 0
+        taped = RECORD_TAPE and TAPE_IN_FORWARD and P1 % ops.view_tape_block_points(NV) == 0
         ctx.ws_keys = []
         if taped:
             vws, k = _acquire("view", dev, lambda: lib.ufr_view_transform_bwd_workspace_bytes(P1 + P2, NV) // 4, ctx)

@@ -325,6 +325,14 @@ int ufr_view_transform_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grad
  *          them, so they can run beside ufr_project_gather_bwd (which needs d_pv only).
  * The SAME workspace must be passed to every stage, and the stages must execute in this order (stream events are the
  * caller's business).  stages = UFR_BWD_STAGE_ALL is ufr_view_transform_bwd. */
+#define UFR_BWD_STAGE_TAPE 1
+#define UFR_BWD_STAGE_DGRAD 2
+#define UFR_BWD_STAGE_WGRAD 4
+#define UFR_BWD_STAGE_ALL 7
+int ufr_view_transform_bwd_stages(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const void* packed_weights,
+                                  const float* x_tokens, const float* rgb, const float* dir, const float* d_token0_a,
+                                  const float* d_token0_b, const float* d_radiance, int32_t P, int32_t NV, float* d_pv,
+                                  void* workspace, int32_t stages, int32_t precision, ufr_stream stream);
 /* Training forward WITH the tape: what ufr_view_transform / ufr_ray_transform compute (same numbers), recorded into the
  * workspace of the matching backward call, whose TAPE stage is then skipped (stages = DGRAD | WGRAD): nothing is computed
  * twice.  View: the points [p0, p0 + P) of a pool of P_total points that ONE backward will walk; x_tokens / rgb / dir /
@@ -341,14 +349,6 @@ int ufr_ray_transform_bwd_stages(const ufr_raw_weights* raw, const ufr_raw_grads
                                  const float* token0, const int32_t* row, int32_t RN, int32_t SN, const float* d_srdf,
                                  float* d_token0_a, float* d_token0_b, int32_t accumulate, void* workspace, int32_t stages,
                                  int32_t precision, ufr_stream stream);   /* the ray transformer's backward likewise */
-#define UFR_BWD_STAGE_TAPE 1
-#define UFR_BWD_STAGE_DGRAD 2
-#define UFR_BWD_STAGE_WGRAD 4
-#define UFR_BWD_STAGE_ALL 7
-int ufr_view_transform_bwd_stages(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const void* packed_weights,
-                                  const float* x_tokens, const float* rgb, const float* dir, const float* d_token0_a,
-                                  const float* d_token0_b, const float* d_radiance, int32_t P, int32_t NV, float* d_pv,
-                                  void* workspace, int32_t stages, int32_t precision, ufr_stream stream);
 
 /* ------------------------------------------------------------------ whole-path inference
  * UFORecon.infer(extract_geometry=True) (model.py:393-478) for RN rays of one frame:

@@ -61,16 +61,18 @@ __device__ __forceinline__ void layer_norm88(f32x4 (&tt)[kRtC][6], const WS& ws,
           q = fmaf(d, d, q);
         }
       }
-    const float rstd = 1.f / sqrtf(sum_groups(q) * (1.f / 88.f) + eps);
+    const float rstd = fast_rsqrt(sum_groups(q) * (1.f / 88.f) + eps);
     if (RS) RS[c] = rstd * asc;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const f32x4 gw = vec_frag<VW>(ws, i, g), gb = vec_frag<VB>(ws, i, g);  // zero in the padding slots
-      if (XH) {
-        XH[c][i] = (t[i] - mean) * rstd;
-        if (i == 5) { XH[c][i][2] = 0.f; XH[c][i][3] = 0.f; }                 // nat88: registers 2, 3 of tile 5 are padding
+      // element by element: f32x4 expressions become packed-f32 VALU, an anti-lever beside MFMAs (view_transformer.hip)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float xh = (t[i][r] - mean) * rstd;
+        if (XH) XH[c][i][r] = (i == 5 && r >= 2) ? 0.f : xh;                  // nat88: registers 2, 3 of tile 5 are padding
+        t[i][r] = xh * gw[r] + gb[r];
       }
-      t[i] = (t[i] - mean) * rstd * gw + gb;
     }
   }
 }
@@ -177,20 +179,44 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
       probe_gemm(vt, ws);
     }
     UFR_RT_PHASE(0)  // sweep 1: token load + K, V GEMMs
+    // KV_h += K'_h^T V_h: the operands of all 32 products first (branch-free: the division by a non-power-of-two sample
+    // count is chosen once per tile, padding slots by selects), then the MFMAs register-major over the heads, so that
+    // consecutive matrix instructions add into different accumulators (a head's own four still run r = 0..3: same bits).
+    // Written per (head, register) this phase compiled into 32 x {exec-masked elu, a uniform branch around an IEEE
+    // division, one MFMA}: 128 branches per tile and nothing for the scheduler to overlap.
+    const float pad_v = j == 3 ? 1.f : 0.f;                                               // ones column (slot 3) -> sum of K'
 #pragma unroll
     for (int c = 0; c < C; ++c) {
+      float kk[8][4], vv[8][4];
+      if (pow2_len) {
 #pragma unroll
-      for (int h = 0; h < 8; ++h) {
+        for (int h = 0; h < 8; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vv[h][r] = vt[c][h][r] * inv_len;
+      } else {
+#pragma unroll
+        for (int h = 0; h < 8; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vv[h][r] = vt[c][h][r] / f_len;
+      }
+      const bool k_ok = slot_ok && live[c];                                               // padding slots / empty tile contribute nothing
+#pragma unroll
+      for (int h = 0; h < 8; ++h)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float kk = (slot_ok && live[c]) ? elu1_acc(kt[c][h][r], k_dsc, k_l2e) : 0.f;           // padding slots / empty tile contribute nothing
-          const float vs = pow2_len ? vt[c][h][r] * inv_len : vt[c][h][r] / f_len;
-          const float vv = slot_ok ? vs : (j == 3 ? 1.f : 0.f);                       // ones column (slot 3) -> sum of K'
+          const float e = elu1_acc(kt[c][h][r], k_dsc, k_l2e);
+          kk[h][r] = k_ok ? e : 0.f;
+          vv[h][r] = slot_ok ? vv[h][r] : pad_v;
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
 #ifdef UFR_ABL_NOKV   // ablation (timing only): no fp32 MFMAs for the per-head KV state
-          KV[h][r] += kk * vv;
+          KV[h][r] += kk[h][r] * vv[h][r];
 #else
-          KV[h] = mfma16(kk, vv, KV[h]);
-          if constexpr (TAPE) KVT[h] = mfma16(vv, kk, KVT[h]);   // [V slot][K slot]: the A operand of d Q' = KV d acc
+          KV[h] = mfma16(kk[h][r], vv[h][r], KV[h]);
+          if constexpr (TAPE) KVT[h] = mfma16(vv[h][r], kk[h][r], KVT[h]);   // [V slot][K slot]: the A operand of d Q' = KV d acc
 #endif
         }
       }
@@ -257,7 +283,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
 #endif
         });
         const float den = __shfl(acc[3], j);         // slot 3 lives in lane group 0, register 3
-        const float Z = 1.f / (den + 1e-6f);         // linear_attention.py:43
+        const float Z = fast_rcp(den + 1e-6f);         // linear_attention.py:43
         const float zs = Z * (float)SN;              // :44
         if constexpr (TAPE) zs_all[h] = zs;
         static_for<3>([&](auto ri) __attribute__((always_inline)) {
@@ -306,7 +332,7 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
 #pragma unroll
       for (int t = 0; t < 11; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hid[c][t][r] = fmaxf(hid[c][t][r], 0.f);
+        for (int r = 0; r < 4; ++r) hid[c][t][r] = relu_acc(hid[c][t][r]);
 #pragma unroll
       for (int t = 0; t < 6; ++t) o[c][t] = splat4(0.f);
     }
@@ -334,7 +360,9 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
 #pragma unroll
     for (int c = 0; c < C; ++c) {
 #pragma unroll
-      for (int t = 0; t < 6; ++t) o[c][t] += x[c][t];
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[c][t][r] += x[c][t][r];   // scalar adds: no v_pk_add_f32 (layer_norm88)
       if constexpr (TAPE) {
 #pragma unroll
         for (int t = 0; t < 6; ++t) tape_st(RT_O + t, o[c][t]);
@@ -363,12 +391,12 @@ __global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) d1[c][t][r] = fmaxf(d1[c][t][r], 0.f);
+        for (int r = 0; r < 4; ++r) d1[c][t][r] = relu_acc(d1[c][t][r]);
     gemm_f16<M_DM2, C, kRtWaves>(ws, d1, d2, wrap, sc[RS_M_DM2]);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) d2[c][0][r] = fmaxf(d2[c][0][r], 0.f);
+      for (int r = 0; r < 4; ++r) d2[c][0][r] = relu_acc(d2[c][0][r]);
     if constexpr (TAPE) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {

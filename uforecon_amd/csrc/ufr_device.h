@@ -14,6 +14,34 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// 1 / x and 1 / sqrt(x) as the hardware approximations (v_rcp_f32 / v_rsq_f32: 1 ulp) for the normalisers INSIDE the
+// two transformer kernels (attention 1 / (Q.sum K + eps), LayerNorm 1 / sigma, the softmax denominator): an IEEE
+// division is ten vector instructions, a correctly rounded sqrt a dozen more -- 5 % of those kernels' vector work for
+// bits far below their own accumulation noise (4e-7, tests/accuracy_report.py).  -DUFR_FAST_DIV=0 restores the divisions.
+#ifndef UFR_FAST_DIV
+#define UFR_FAST_DIV 1
+#endif
+__device__ __forceinline__ float fast_rcp(float x) {
+#if UFR_FAST_DIV
+  return __builtin_amdgcn_rcpf(x);
+#else
+  return 1.f / x;
+#endif
+}
+__device__ __forceinline__ float fast_rsqrt(float x) {
+#if UFR_FAST_DIV
+  return __builtin_amdgcn_rsqf(x);
+#else
+  return 1.f / sqrtf(x);
+#endif
+}
+// ReLU of a matrix-core accumulator as ONE instruction (v_med3_f32 x, 0, FLT_MAX; an infinite accumulator is reported by the probe).  fmaxf(x, 0.f) compiles to two: hipcc
+// first canonicalises an operand it cannot prove quiet (v_max_f32 x, x, x), then takes the maximum -- 96 extra vector
+// instructions per view-transformer iteration.  NOT inline assembly: the compiler's hazard recogniser does not look
+// inside an asm statement, and a VALU read of an MFMA result needs software wait states on gfx950 -- a v_max_f32 written
+// as asm right behind a layer's last MFMA read stale accumulators (view_out off by 0.1).  NaN never reaches a ReLU
+// unreported: the range probe of the dense layer runs on the accumulators first (weight_stream_f16.h: probe_gemm).
+__device__ __forceinline__ float relu_acc(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 0x1.fffffep+127f); }   // FLT_MAX: with +inf hipcc folds the median back into canonicalise + max
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ f32x4 splat4(float v) { return f32x4{v, v, v, v}; }

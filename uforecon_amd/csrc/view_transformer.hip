@@ -57,13 +57,19 @@ __device__ __forceinline__ void layer_norm80(f32x4 (&t)[C][5], const WS& ws, int
         float d = t[c][i][r] - mean;
         q = fmaf(d, d, q);
       }
-    const float rstd = 1.f / sqrtf(sum_groups(q) * (1.f / 80.f) + eps);
+    const float rstd = fast_rsqrt(sum_groups(q) * (1.f / 80.f) + eps);
     if (RS) RS[c] = rstd * asc;
+    // element by element on purpose: f32x4 expressions become v_pk_mul / v_pk_fma_f32, which cost more beside the
+    // partner wave's MFMAs than the two scalar instructions they replace (MI355X_MICROARCH.md, price of a filler)
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const f32x4 gw = vec_frag<VW>(ws, i, g), gb = vec_frag<VB>(ws, i, g);
-      if (XH) XH[c][i] = (t[c][i] - mean) * rstd;
-      t[c][i] = (t[c][i] - mean) * rstd * gw + gb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float xh = (t[c][i][r] - mean) * rstd;
+        if (XH) XH[c][i][r] = xh;
+        t[c][i][r] = xh * gw[r] + gb[r];
+      }
     }
   }
 }
@@ -351,7 +357,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
           A[1][hh][1 + st] = a1; den[1] += a1;
         });
 #pragma unroll
-        for (int c = 0; c < C; ++c) Zs[c][hh] = (float)L / (den[c] + 1e-6f);   // Z * v_length (linear_attention.py:43-44)
+        for (int c = 0; c < C; ++c) Zs[c][hh] = (float)L * fast_rcp(den[c] + 1e-6f);   // Z * v_length (linear_attention.py:43-44)
       });
     } else {
 #pragma unroll
@@ -380,7 +386,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
         UFR_ATT_STEP(0) UFR_ATT_STEP(1) UFR_ATT_STEP(2) UFR_ATT_STEP(3)
         UFR_ATT_STEP(4) UFR_ATT_STEP(5) UFR_ATT_STEP(6) UFR_ATT_STEP(7)
 #undef UFR_ATT_STEP
-        Zs[c][hh] = (float)L / (den + 1e-6f);             // Z * v_length (linear_attention.py:43-44)
+        Zs[c][hh] = (float)L * fast_rcp(den + 1e-6f);             // Z * v_length (linear_attention.py:43-44)
       }
     }
     }
@@ -506,7 +512,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
       for (int t = 0; t < 10; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hid[c][t][r] = fmaxf(hid[c][t][r], 0.f);
+        for (int r = 0; r < 4; ++r) hid[c][t][r] = relu_acc(hid[c][t][r]);
     unsigned relu_bits[C][2] = {};   // TAPE: bit 4 t + r <-> hidden unit (t, r) of this lane is active; then h1 (40..43), h2 (44..47)
     if constexpr (TAPE) {
 #pragma unroll
@@ -560,7 +566,9 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
       for (int c = 0; c < C; ++c)
 #pragma unroll
-        for (int t = 0; t < 5; ++t) o[c][t] += x[c][t];
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[c][t][r] += x[c][t][r];   // scalar adds: no v_pk_add_f32 (layer_norm80)
     }
     if constexpr (TAPE) {
 #pragma unroll
@@ -603,12 +611,12 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) h1[c][0][r] = fmaxf(h1[c][0][r], 0.f);
+      for (int r = 0; r < 4; ++r) h1[c][0][r] = relu_acc(h1[c][0][r]);
     gemm_f16<M_RW2, C, kVtWaves>(ws, h1, h2, wrap, sc[VS_M_RW2]);
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) h2[c][0][r] = fmaxf(h2[c][0][r], 0.f);
+      for (int r = 0; r < 4; ++r) h2[c][0][r] = relu_acc(h2[c][0][r]);
     gemm_f16<M_RW4, C, kVtWaves>(ws, h2, lg, wrap, sc[VS_M_RW4]);
     if constexpr (TAPE) {
 #pragma unroll
@@ -666,9 +674,10 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
       for (int c = 0; c < C; ++c)
         if (valid[c] && tvv[c] == 0 && g == 0) {
           float* dst = at32(radiance, (unsigned)pidx[c] * 3u);
-          dst[0] = cr[c] / den[c];
-          dst[1] = cg[c] / den[c];
-          dst[2] = cb[c] / den[c];
+          const float rden = fast_rcp(den[c]);
+          dst[0] = cr[c] * rden;
+          dst[1] = cg[c] * rden;
+          dst[2] = cb[c] * rden;
         }
     } else {
 #pragma unroll
@@ -694,9 +703,10 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #undef UFR_SUM_STEP
       if (valid[c] && tv == 0 && g == 0) {
         float* dst = at32(radiance, (unsigned)pidx[c] * 3u);
-        dst[0] = cr / den;
-        dst[1] = cg / den;
-        dst[2] = cb / den;
+        const float rden = fast_rcp(den);
+        dst[0] = cr * rden;
+        dst[1] = cg * rden;
+        dst[2] = cb * rden;
       }
     }
     }

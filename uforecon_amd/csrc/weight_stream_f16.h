@@ -12,6 +12,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));   // operand of v_mf
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kF16RingBytes = kF16Slots * kF16ChunkFrags * 1024;  // the ring: kF16Slots (3) slots of kF16ChunkFrags (12) KiB
 constexpr int kF16LdsBytes = kF16RingBytes + kVecBytes;
@@ -62,6 +63,8 @@ struct WStreamF16T {
   const char* src;     // fp16 plane region of the packed blob (global, wave-uniform)
   char* ring;          // LDS: the ring of kF16Slots chunk slots
   unsigned ring_lds;   // ... as an LDS byte address (scalar)
+  i32x4 rsrc;          // buffer descriptor of the plane region shifted by this wave's 1 KiB (lds_dma_piece)
+  unsigned lds_wave;   // ring_lds + this wave's 1 KiB
   const f32x4* vecs;   // LDS: vector fragments (fp32)
   int wave, lane;
   unsigned long long bad_in, bad_out;   // sticky wave masks (scalar registers): probe_gemm / track_external
@@ -75,9 +78,20 @@ __device__ __forceinline__ WStreamF16T<LOWP, BF16> wstream_f16_begin(const float
   ws.lane = threadIdx.x & 63;
   ws.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   ws.bad_in = ws.bad_out = 0ull;
-  ws.src = reinterpret_cast<const char*>(packed) + (size_t)blob_floats() * 4;
+  // a constexpr VARIABLE: left as a call, hipcc walks the layout tables on the device at every workgroup start (a
+  // two-level scalar loop with dependent s_loads: ~1 500 scalar instructions, ~5 % of a 4-iteration workgroup's life)
+  constexpr size_t kPlaneRegion = (size_t)blob_floats() * 4;
+  ws.src = reinterpret_cast<const char*>(packed) + kPlaneRegion;
   ws.ring = smem;
   ws.ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem);
+  {
+    const unsigned long long base = reinterpret_cast<unsigned long long>(ws.src) + (unsigned long long)ws.wave * 1024ull;
+    ws.rsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(base & 0xffffffffull));
+    ws.rsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((base >> 32) & 0xffffull));   // stride 0: raw buffer
+    ws.rsrc[2] = -1;                                                                          // no bound (offsets are layout constants)
+    ws.rsrc[3] = 0x00020000;                                                                  // gfx9 family: 32-bit data format
+    ws.lds_wave = ws.ring_lds + (unsigned)ws.wave * 1024u;
+  }
 #ifdef UFR_ABL_NOLDS
   for (int d = 0; d < kF16Depth; ++d)
     for (int p = 0; p < kPlanes; ++p) ws.pre[d][p] = __builtin_bit_cast(f16x8, u32x4{0x3c003c00u + ws.lane, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u});
@@ -103,6 +117,22 @@ __device__ __forceinline__ WStreamF16T<LOWP, BF16> wstream_f16_begin(const float
 __device__ __forceinline__ void lds_dma_16(const char* g_uniform, unsigned lane_off, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(g_uniform), "v"(lane_off), "s"(lds_addr) : "memory");
 }
+// The same piece through the BUFFER form: rsrc = the plane region shifted by the wave's 1 KiB, GOFF / LOFF = the piece's
+// byte offsets in the region / in the ring as literals.  Two scalar instructions per piece (m0, soffset) instead of
+// the eight to ten the 64-bit address of the global form costs (s_mov, s_ashr, three 64-bit adds, m0, s_nop): ~550
+// fewer issue slots per view-transformer iteration.  The soffset move sits between the m0 write and the DMA, which is
+// the wait state the hardware wants there.
+#ifndef UFR_DMA_BUFFER
+#define UFR_DMA_BUFFER 1
+#endif
+template <unsigned GOFF, unsigned LOFF>
+__device__ __forceinline__ void lds_dma_piece(const i32x4& rsrc, unsigned lds_wave, unsigned lane_off) {
+  unsigned soff;
+  asm volatile("s_add_u32 m0, %3, %5\n\ts_mov_b32 %0, %4\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds"
+               : "=&s"(soff)
+               : "v"(lane_off), "s"(rsrc), "s"(lds_wave), "n"(GOFF), "n"(LOFF)
+               : "memory", "scc");
+}
 
 // fetch pieces [P0, P1) of this wave's share of chunk CHK of stream S into the chunk's ring slot (a piece = one
 // 1 KiB LDS-DMA wave instruction; the wave's share is every NWAVES-th fragment)
@@ -112,12 +142,20 @@ __device__ __forceinline__ void wstream_f16_fetch(const WS& ws) {
   if constexpr (P1 > P0) {
     constexpr size_t goff = ((size_t)f16_stream_base_frags(S) + (size_t)CHK * kF16ChunkFrags) * 1024;
     constexpr int soff = (CHK % kF16Slots) * (kF16ChunkFrags * 1024);
+    const unsigned lane_off = ws.lane * 16;
+#if UFR_DMA_BUFFER
+    static_assert(goff + (size_t)kF16ChunkFrags * 1024 < (1ull << 31), "buffer offsets are 32-bit");
+    static_for<P1 - P0>([&](auto ki) __attribute__((always_inline)) {
+      constexpr unsigned k = P0 + decltype(ki)::value;
+      lds_dma_piece<(unsigned)goff + k * NWAVES * 1024u, (unsigned)soff + k * NWAVES * 1024u>(ws.rsrc, ws.lds_wave, lane_off);
+    });
+#else
     int zero = 0;
     asm volatile("" : "+s"(zero));  // keep the loop-invariant source address out of LICM's hands
     const char* g = ws.src + zero + goff + ws.wave * 1024;   // wave-uniform: scalar base + 32-bit lane offset
-    const unsigned lane_off = ws.lane * 16;
 #pragma unroll
     for (int k = P0; k < P1; ++k) lds_dma_16(g + k * NWAVES * 1024, lane_off, ws.ring_lds + soff + ws.wave * 1024 + k * NWAVES * 1024);
+#endif
   }
 }
 

@@ -32,7 +32,7 @@ enum ufr_status {
 
 /* Version of this header's ABI (argument lists, struct layouts, packed-blob layout).  ufr_version() returns the value
  * the library was built with: a binding must refuse a library whose version differs (uforecon_amd/_lib.py does). */
-#define UFR_ABI_VERSION 404
+#define UFR_ABI_VERSION 500
 
 #define UFR_MAX_VIEWS 7
 #define UFR_NUM_STAGES 3
@@ -86,12 +86,17 @@ int ufr_get_matrix_precision(void);
 
 /* Sticky range status of the current device.  The dense layers run on fp16 planes whose power-of-two scales are chosen
  * when the weights are packed: per matrix from max |w| (any finite weight fits), per layer from an analytic upper bound
- * of the layer's input that starts at the bound of the token features the caller states (ufr_weights_pack_for; default
- * 256) and is carried through the matrices' infinity norms, the LayerNorm gains and the biases.  With a true input bound
- * no layer can overflow.  The kernels never synchronise, so a violation raises a device-side sticky flag instead of
- * failing the launch:
- *   bit 0  a dense-layer input of a transformer kernel left the range of its planes: a token feature beyond the stated
- *          bound, or +-inf -- repack with a larger input_abs_max
+ * of the layer's input that starts at the bound of the token features and is carried through the matrices' infinity
+ * norms, the LayerNorm gains and the biases.  The bound of the token features is MEASURED: ufr_frame_prepare takes the
+ * maximum magnitude of the frame's feature maps and volume features while it re-lays them out, and ufr_render_rays /
+ * ufr_weights_fit_frame re-derive the layer exponents (scalars of the table; the weight planes do not change) for a frame
+ * beyond the bound the table serves -- ufr_weights_pack_for's input_abs_max, default 4094, is only the floor and an
+ * optional override.  With a true input bound no layer can overflow.  The kernels never synchronise, so a violation
+ * (tokens handed to ufr_aggregate / ufr_view_transform directly, beyond the floor and without a frame) raises a
+ * device-side sticky flag instead of failing the launch:
+ *   bit 0  a dense-layer input of a transformer kernel left the range of its planes: a token feature beyond the bound
+ *          the table serves, or +-inf -- ufr_weights_fit_frame with the frame the tokens come from, or repack with a
+ *          larger input_abs_max
  *   bit 1  NaN among the externally supplied inputs of a transformer kernel (token rows, dir); +-inf inputs and
  *          internally produced overflows raise bit 0
  *   bit 2  ufr_weights_pack met a parameter that is not finite
@@ -110,13 +115,14 @@ int ufr_status_poll_bits(ufr_stream stream, int32_t synchronize, int32_t mask, i
  * input features = 64 lanes x float4, zero padded) so the kernels stream them with
  * contiguous 1 KiB wave loads.  Call again whenever the parameters change. */
 size_t ufr_packed_weights_bytes(void);
-int ufr_weights_pack(const ufr_raw_weights* raw, void* packed, ufr_stream stream);   /* input_abs_max = 256 */
+int ufr_weights_pack(const ufr_raw_weights* raw, void* packed, ufr_stream stream);   /* input_abs_max = 4094 */
 /* The same for feature maps and volume features bounded by input_abs_max (positive, finite) -- what the encoder hands to
  * ufr_frame_prepare; for ufr_aggregate / ufr_view_transform callers: columns 0..55 and 72..79 of x_tokens (the 16
  * pre-similarity columns are bounded from pre_sim_mlp's own weights, the positional columns by 1).  The bound
  * only sets the exponents the activations' planes carry (a pessimistic one costs no accuracy: the planes keep 22
  * significand bits down to 2^-17 of each layer's bound), so state it generously. */
 int ufr_weights_pack_for(const ufr_raw_weights* raw, void* packed, float input_abs_max, ufr_stream stream);
+/* (ufr_weights_fit_frame, declared with the frame handle below: the table follows a frame's measured bound) */
 /* Host-only description of that re-ordering (for tests / other bindings): for every packed
  * float, param_id (index into the pointer list of ufr_raw_weights in declaration order, -1 =
  * zero padding) and elem (flat element index inside that parameter).  Arrays of
@@ -131,7 +137,8 @@ int ufr_pack_plan(int32_t* param_id, int32_t* elem);
  * ufr_pack_plan_f16 describes it like ufr_pack_plan (one entry per halfword, plus the plane).  Of the fp32 region
  * ufr_weights_pack fills only the trailing vector fragments (biases, LayerNorm, view token) and, behind them, the scale
  * table: per dense matrix M (ufr_packed_scale_table_offset() floats into the blob, 4 floats each, in the order of
- * csrc/ufr_layout.h: Mat) {2^a_M, 2^-(s_M + a_M), 2^(s_M + a_M), 2^s_M}; the kernels read nothing else of the region.
+ * csrc/ufr_layout.h: Mat) {2^a_M, 2^-(s_M + a_M), 2^(s_M + a_M), 2^s_M}, then the two kernels' scalar lists and the weight
+ * statistics the exponents derive from (kept for ufr_weights_fit_frame); the kernels read nothing else of the region.
  * ufr_weights_pack does not synchronise: a parameter that is not finite raises bit 2 of the sticky status -- call
  * ufr_status_poll(stream, 1, ...) after packing to fail at once (uforecon_amd.ops.PackedWeights does), or let the next
  * compute entry point report it. */
@@ -146,7 +153,8 @@ int ufr_pack_plan_f16(int32_t* param_id, int32_t* elem, int32_t* plane);
 /* ------------------------------------------------------------------ frame
  * Per-frame tensors produced by the encoder (model.py:780-808), in the reference layout.
  * ufr_frame_prepare re-lays them out channel-last into `workspace` (one tap = one
- * contiguous line) and records the camera constants; the result is immutable during the
+ * contiguous line), measures max |value| of the feature maps and volume features on the way (a device word inside
+ * `workspace`: what ufr_weights_fit_frame reads) and records the camera constants; the result is immutable during the
  * ray loop (model.py:814-823). */
 typedef struct ufr_frame_desc {
   int32_t NV, H, W;               /* full-resolution image size; feature maps are H/4 x W/4          */
@@ -174,6 +182,14 @@ typedef struct ufr_frame { uint64_t opaque[160]; } ufr_frame;
 size_t ufr_frame_workspace_bytes(const ufr_frame_desc* d);
 int ufr_frame_prepare(const ufr_frame_desc* d, void* workspace, size_t workspace_bytes, ufr_frame* out,
                       ufr_stream stream);
+/* The activation exponents of `packed` follow a frame: when the feature bound ufr_frame_prepare measured for `frame`
+ * exceeds the one the table was derived for, the table is re-derived on the device for the next power of two above it
+ * (one 64-thread kernel; otherwise it returns at once).  Asynchronous, no host read-back.  The bound only grows until the
+ * next ufr_weights_pack, so the backward of an earlier forward stays in range whatever frames are fitted in between.
+ * ufr_render_rays does this itself; callers of the stepwise entry points (ufr_project_gather -> ufr_aggregate ...) call it
+ * once per (frame, pack) -- uforecon_amd.ops does, in FrameHandle-taking calls.  Replaces "state input_abs_max for this
+ * checkpoint": the reference loads any checkpoint without side information (main.py:186-190). */
+int ufr_weights_fit_frame(void* packed, const ufr_frame* frame, ufr_stream stream);
 
 /* ------------------------------------------------------------------ per-op entry points
  * (each mirrors one reference function; used by the drop-in Python classes and the parity

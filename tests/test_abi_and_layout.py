@@ -43,7 +43,8 @@ def test_struct_sizes_match_the_header(lib):
     n_vec = 16 * (5 * 4 + 6 * 4 + 2 + 5 + 5 + 1 + 1)   # + rw4 and dm4 as vectors
     assert lib.ufr_packed_scale_table_offset() == E.vec_region_offset() + n_vec
     assert lib.ufr_packed_scale_table_entries() == 18          # one {2^a, 2^-(s+a), 2^(s+a), 2^s} per dense matrix
-    assert lib.ufr_packed_fp32_floats() == E.vec_region_offset() + n_vec + 4 * 18 + 2 * 32   # + the two kernels' scalar lists
+    # + the two kernels' scalar lists + the weight statistics the exponents derive from (kept for ufr_weights_fit_frame)
+    assert lib.ufr_packed_fp32_floats() == E.vec_region_offset() + n_vec + 4 * 18 + 2 * 32 + 3 * 32
     assert lib.ufr_packed_weights_bytes() == (4 * lib.ufr_packed_fp32_floats() + 2 * lib.ufr_packed_f16_halfwords()
                                               + 2 * lib.ufr_packed_bwd_halfwords() + 16)  # + flag tail
     assert lib.ufr_packed_bwd_halfwords() % (12 * 512) == 0
@@ -136,7 +137,7 @@ def test_vector_fragments(plan, raw_and_blob):
                     row = E.row_map(rm, t, 4 * g + r, dim)
                     assert frag[t, g, r] == (raw[param][row] if row >= 0 else 0.0)
         off += nt * 16
-    assert off + 4 * 18 + 2 * 32 == blob.shape[0]   # then the scale table: no parameter maps there (the pack kernel derives it)
+    assert off + 4 * 18 + 2 * 32 + 3 * 32 == blob.shape[0]   # then the scale table, scalar lists, statistics: no parameter maps there (the pack kernel derives them)
     assert not blob[off:].any()
 
 

@@ -211,10 +211,10 @@ def test_project_gather_bwd_matches_oracle_autograd():
             assert grad_rel_err(grads.grad(k), Pg[k].grad) < 1e-4, k
 
 
-def _train_step(name):
+def _train_step(name, **model_options):
     c = CASES[name]
     fr, idx, U1, U2, g = case_inputs(name)
-    m = M.UFORecon(_args(c)).to(DEV)
+    m = M.UFORecon(_args(c), **model_options).to(DEV)
     m.load_state_dict(load_weights(), strict=True)
     m.train()
     f = fr.to(DEV)
@@ -231,21 +231,12 @@ def _train_step(name):
 @pytest.mark.parametrize("name", ["c5_train_grads", "c5_train_grads_nv4"])
 def test_training_step_gradients_match_reference_autograd(name, overlap, tape_in_forward):
     """loss.backward() through UFORecon.infer == the reference's autograd (golden), every parameter and volume -- with the
-    backward's independent stages side by side on three streams (autograd.OVERLAP, the default) and all on one; with the
-    tape recorded by the forward (the default) and by the backward (what unaligned pools fall back to)."""
-    from uforecon_amd import autograd as ag
-
-    ag.TAPE_IN_FORWARD = tape_in_forward
-    try:
-        m, f, r, loss, g = _train_step(name)
-    finally:
-        ag.TAPE_IN_FORWARD = True
+    backward's independent stages side by side on three streams (UFORecon(overlap=True), the default) and all on one; with
+    the tape recorded by the forward (the default) and by the backward (what unaligned pools fall back to).  Both are
+    arguments of the model (autograd.RenderOptions): nothing process-wide is flipped."""
+    m, f, r, loss, g = _train_step(name, overlap=overlap, tape_in_forward=tape_in_forward)
     assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
-    ag.OVERLAP = overlap
-    try:
-        loss.backward()
-    finally:
-        ag.OVERLAP = True
+    loss.backward()
     torch.cuda.synchronize()
     worst = {}
     for k, p in m.named_parameters():
@@ -260,11 +251,14 @@ def test_training_step_gradients_match_reference_autograd(name, overlap, tape_in
     assert r[16].requires_grad                       # variance output stays differentiable (train/variance log)
 
 
-def test_two_forwards_before_one_backward_keep_their_own_tapes():
+@pytest.mark.parametrize("second_taped", [True, False])
+def test_two_forwards_before_one_backward_keep_their_own_tapes(second_taped):
     """The training forward records the backward's tape into a workspace that is kept between steps (autograd._acquire):
     a second forward BEFORE the first one's backward (gradient accumulation over two ray batches, one loss) must not
     overwrite it -- it gets a private buffer.  (a + b).backward() == a.backward() then b.backward(), up to the order of
-    the float atomics."""
+    the float atomics.  second_taped = False: the second forward does NOT record its tape (what a pool that does not end
+    on a tape block falls back to), so ITS backward records one -- into a private buffer as well while the first
+    forward's tape is alive in the kept one (round-4 advisor finding: it used to take the kept buffer unasked)."""
     name = "c5_train_grads"
     c = CASES[name]
     fr, idx, U1, U2, g = case_inputs(name)
@@ -282,7 +276,8 @@ def test_two_forwards_before_one_backward_keep_their_own_tapes():
             for k in f.feature_volume[st]:
                 f.feature_volume[st][k].grad = None
         losses = []
-        for ix in (idx, idx2):
+        for n, ix in enumerate((idx, idx2)):
+            m.tape_in_forward = second_taped or n == 0
             r = m.infer(f.batch, ix.to(DEV), f.source_imgs_feat, f.feature_volume, match_feature=f.match_feature, uniforms=(U1, U2))
             losses.append(_loss_from_tuple(r, f.batch, ix.to(DEV)))
             if not joint:
@@ -378,7 +373,13 @@ def test_full_size_training_step_properties():
     L12 = 0.7 * (((rgb - rgb_gt) ** 2).mean() + ((rgb2 - rgb_gt) ** 2).mean()) \
         - 1.3 * ((depth - depth_gt).abs().mean() + (depth2 - depth_gt).abs().mean())
     g12 = grads_of(L12)
-    for a, b, ab in zip(g1, g2, g12):                                   # (a) linearity (atomics reorder sums: 1e-4)
+    names = [k for k, _ in m.named_parameters()]
+    shift_w = g12[names.index(SHIFT_BIAS.replace("bias", "weight"))]
+    for n, (a, b, ab) in enumerate(zip(g1, g2, g12)):                   # (a) linearity (atomics reorder sums: 1e-4)
+        if n < len(names) and names[n] == SHIFT_BIAS:
+            # true gradient zero (softmax over views is shift-invariant): all three hold rounding noise, not a linear map
+            assert float(ab.abs().max()) < 1e-2 * float(shift_w.abs().max())
+            continue
         want = 0.7 * a - 1.3 * b
         assert float((ab - want).abs().max()) <= 2e-4 * max(float(want.abs().max()), 1e-6)
     # (c) sparsity: a frustum voxel no sample touches receives exactly zero
@@ -440,6 +441,9 @@ def test_training_step_16bit_mode(name, sixteen_bit_mode):
     dot = na = nb = 0.0
     for k, p in m.named_parameters():
         assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+        if k == SHIFT_BIAS:   # true gradient zero: rounding noise on both sides (bf16 tiles here), bounded by its layer's scale
+            assert float(p.grad.abs().max()) < 1e-2 * float(dict(m.named_parameters())[k.replace("bias", "weight")].grad.abs().max())
+            continue
         worst[k] = grad_rel_err(p.grad, g["grad." + k])
         ref = torch.from_numpy(g["grad." + k]).to(p.grad).reshape(p.grad.shape)
         dot += float((p.grad * ref).sum()); na += float((p.grad * p.grad).sum()); nb += float((ref * ref).sum())

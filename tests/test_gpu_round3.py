@@ -124,10 +124,11 @@ def test_trained_like_statistics(name, bound):
 
 # ------------------------------------------------------------------------------------------------ range status
 def test_activation_overflow_raises_the_sticky_status(weights):
-    """A token feature far beyond the bound the weights were packed for (default 256; the planes of the first layers
-    hold 2^7 x < 65504, i.e. |x| < 511.7) cannot be held by the fp16 planes: the launch must not pass silently.  The kernels
-    raise the device's sticky status; ufr_status_poll reports it at once, and WITHOUT a poll the next compute call fails
-    (one call late, no host synchronisation in between)."""
+    """The backstop behind the measured bound (test_frame_features_far_beyond_the_floor_render_without_a_stated_bound): tokens
+    handed to ufr_aggregate DIRECTLY, without a frame, far beyond the floor the weights were packed for (default 4094; the
+    planes of the first layers hold 2^3 x < 65504, i.e. |x| < 8188) cannot be held by the fp16 planes: the launch must not
+    pass silently.  The kernels raise the device's sticky status; ufr_status_poll reports it at once, and WITHOUT a poll the
+    next compute call fails (one call late, no host synchronisation in between)."""
     fr, idx, U1, U2, g = case_inputs("rows_small")
     want = {}
     with torch.no_grad():
@@ -143,7 +144,7 @@ def test_activation_overflow_raises_the_sticky_status(weights):
     assert ops.status_poll(True) == 0
     # one token feature of one point beyond the planes' range
     x_bad = x_ok.clone()
-    x_bad[5, 1, 17] = 600.0
+    x_bad[5, 1, 17] = 9000.0
     ops.aggregate(weights, x_bad, rgbm, dirs, RN, SN)
     with pytest.raises(UfrError, match="input_abs_max"):
         ops.status_poll(True)
@@ -163,10 +164,61 @@ def test_activation_overflow_raises_the_sticky_status(weights):
         ops.status_poll(True)
     # the same through the 16-bit mode and through the whole-path entry point's kernels (values just inside pass)
     x_edge = x_ok.clone()
-    x_edge[5, 1, 17] = 500.0
+    x_edge[5, 1, 17] = 8000.0
     ops.aggregate(weights, x_edge, rgbm, dirs, RN, SN, precision=ops.PRECISION_16BIT)
     assert ops.status_poll(True) == 0
     ops.aggregate(weights, x_bad, rgbm, dirs, RN, SN, precision=ops.PRECISION_16BIT)
+    with pytest.raises(UfrError, match="input_abs_max"):
+        ops.status_poll(True)
+
+
+def test_frame_features_far_beyond_the_floor_render_without_a_stated_bound():
+    """A checkpoint whose backbone features are four orders of magnitude above the synthetic scene's loads and renders with
+    no side information (the reference: main.py:186-190 loads any checkpoint): ufr_frame_prepare MEASURES the bound of the
+    feature maps and volume features, the table of layer exponents follows it (ufr_weights_fit_frame; the weight planes
+    do not change), and the rows come out within 1e-4 of the float64 oracle on the same tokens -- status clear.  The same
+    tokens through weights that never saw the frame (ufr_aggregate directly) trip the sticky status: the backstop."""
+    from test_gpu_parity import _ray_setup
+
+    fr, idx, U1, U2, g = case_inputs("rows_small")
+    scale = 1.0e4
+    fr.source_imgs_feat = fr.source_imgs_feat * scale
+    for st in fr.feature_volume:
+        fr.feature_volume[st]["feature_volume"] = fr.feature_volume[st]["feature_volume"] * scale
+    P = load_weights()
+    W = ops.PackedWeights({k: v.to(DEV) for k, v in P.items()})            # no stated bound
+    a_before = W.scale_exponents()["vt_q"][1]
+    fh = _frame_handle(fr)
+    ray_o, ray_d, near, far = _ray_setup(fr, idx)
+    z = ops.sample_fixed(near.to(DEV), far.to(DEV), U1.to(DEV))
+    RN, SN = z.shape
+    x, rgbm, dirs, _ = ops.project_gather(fh, W, ray_o.to(DEV), ray_d.to(DEV), z)     # fits W to the frame
+    a_after = W.scale_exponents()["vt_q"][1]
+    assert a_after < a_before and float(x.abs().max()) * 2.0 ** a_after < 65504.0, (a_before, a_after)
+    radiance, srdf, dbg = ops.aggregate(W, x, rgbm, dirs, RN, SN, debug=True)
+    assert ops.status_poll(True) == 0
+    NV = x.shape[1]
+    ref, ref32 = {}, {}
+    with torch.no_grad():
+        xc, mc, dc, cc = x.cpu(), rgbm[..., 3].cpu(), dirs[..., :3].cpu(), rgbm[..., :3].cpu()
+        rad32, srdf32 = O.aggregate_tokens(P, xc, cc, mc, dc, RN, SN, want=ref32)
+        rad64, srdf64 = O.aggregate_tokens({k: v.double() for k, v in P.items()}, xc.double(), cc.double(), mc.double(),
+                                           dc.double(), RN, SN, want=ref)
+    err = dict(view_out=rel_err(dbg["view_out"], ref["view_out"]), ray_out=rel_err(dbg["ray_out"].reshape(RN, SN, 88), ref["ray_out"]),
+               srdf=rel_err(srdf, srdf64), radiance=rel_err(radiance, rad64))
+    fp32 = dict(view_out=rel_err(ref32["view_out"], ref["view_out"]), ray_out=rel_err(ref32["ray_out"], ref["ray_out"]),
+                srdf=rel_err(srdf32, srdf64), radiance=rel_err(rad32, rad64))
+    print(f"features x {scale:g}, no stated bound: {err} (the fp32 oracle: {fp32}); a(vt_q) {a_before} -> {a_after}")
+    for k in err:
+        assert err[k] < 1e-4, (k, err, fp32)
+    # the whole-path call fits by itself
+    W2 = ops.PackedWeights({k: v.to(DEV) for k, v in P.items()})
+    out = ops.render_rays(fh, W2, idx.to(DEV), U1.to(DEV), U2.to(DEV))
+    assert ops.status_poll(True) == 0 and bool(torch.isfinite(out["depth"]).all())
+    assert W2.scale_exponents()["vt_q"][1] == a_after
+    # ... and weights that never met the frame do not hold these tokens: reported, not rendered
+    W3 = ops.PackedWeights({k: v.to(DEV) for k, v in P.items()})
+    ops.aggregate(W3, x, rgbm, dirs, RN, SN)
     with pytest.raises(UfrError, match="input_abs_max"):
         ops.status_poll(True)
 

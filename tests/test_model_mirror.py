@@ -38,8 +38,65 @@ def test_unsupported_configurations_fail_loudly():
     m = M.UFORecon(_args())
     with pytest.raises(ops.UfrError, match="fea_volume"):       # featuregrid-style call without the frustum lookup
         m.ray_transformer(torch.zeros(1, 2, 16, 3), {}, torch.zeros(1, 3, 32, 4, 4))
-    with pytest.raises(ops.UfrError, match="B=1"):
-        m.ray_transformer(torch.zeros(2, 2, 16, 3), {}, torch.zeros(2, 3, 32, 4, 4))
+
+
+def test_batch_elements_are_split_frame_major():
+    """B > 1 (main.py:43 defaults to --batch_size 2): the mirror walks the batch one frame at a time.  The slicing helpers
+    on CPU: tensors with a leading B are cut, scalars pass through, volumes arrive as one dict per frame or stacked
+    frame-major along the view dim (the reference indexes them by view, model.py:363-364)."""
+    batch = {"source_imgs": torch.zeros(2, 3, 3, 8, 8), "ray_o": torch.arange(6.).reshape(2, 3), "start_idx": 0,
+             "meta": ["a-1-2", "b-3-4"]}
+    b1 = M._frame_of(batch, 1, 2)
+    assert tuple(b1["source_imgs"].shape) == (1, 3, 3, 8, 8) and b1["start_idx"] == 0 and b1["meta"] == ["b-3-4"]
+    assert torch.equal(b1["ray_o"], torch.tensor([[3., 4., 5.]]))
+    vol = {"stage1": {"feature_volume": torch.arange(6.).reshape(6, 1, 1, 1, 1).expand(6, 8, 2, 2, 2),
+                      "weight_volume": torch.zeros(6, 1, 2, 2, 2)}}
+    v1 = M._volumes_of(vol, 1, 2)
+    assert tuple(v1["stage1"]["feature_volume"].shape) == (3, 8, 2, 2, 2) and float(v1["stage1"]["feature_volume"][0, 0, 0, 0, 0]) == 3.0
+    assert M._volumes_of([vol, "second"], 1, 2) == "second"
+    with pytest.raises(ops.UfrError, match="multiple of the batch size"):
+        M._volumes_of({"stage1": {"feature_volume": torch.zeros(5, 8, 2, 2, 2), "weight_volume": torch.zeros(5, 1, 2, 2, 2)}}, 0, 2)
+    assert M._match_of([torch.zeros(2, 3, 64, 4, 4)], 1)[0].shape[0] == 1
+
+
+@pytest.mark.gpu
+def test_infer_over_a_batch_of_two_frames_equals_two_calls():
+    """`infer` over B = 2 (model.py:409-427 is written over a leading B): every output equals the per-frame call's, laid out
+    frame-major -- both signatures (extract_geometry 4-tuple, training 17-tuple)."""
+    from uforecon_amd.scene import make_frame, sampler_uniforms
+
+    dev = "cuda:0"
+    H, W, RN = 64, 96, 48
+    frames = [make_frame(H, W, 3, seed, train_layout=True).to(dev) for seed in (3, 4)]
+    batch = {}
+    for k, v in frames[0].batch.items():
+        batch[k] = torch.cat([fr.batch[k] for fr in frames], 0) if isinstance(v, torch.Tensor) else v
+    feat = torch.cat([fr.source_imgs_feat for fr in frames], 0)
+    match = [torch.cat([fr.match_feature[0] for fr in frames], 0)]
+    vols_stacked = {st: {k: torch.cat([fr.feature_volume[st][k] for fr in frames], 0) for k in frames[0].feature_volume[st]}
+                    for st in frames[0].feature_volume}
+    vols_list = [fr.feature_volume for fr in frames]
+    g = torch.Generator().manual_seed(5)
+    idx = torch.stack([torch.randperm(H * W, generator=g)[:RN] for _ in range(2)]).to(dev)
+    U1, U2 = sampler_uniforms(9, 64, 64, 2 * RN)
+    for extract in (True, False):
+        m = M.UFORecon(_args(extract_geometry=extract)).to(dev)
+        m.load_state_dict(load_weights(), strict=True)
+        with torch.no_grad():
+            both = m.infer(batch, idx, feat, vols_stacked, extract_geometry=extract, match_feature=match, uniforms=(U1, U2))
+            both_l = m.infer(batch, idx, feat, vols_list, extract_geometry=extract, match_feature=match, uniforms=(U1, U2))
+            single = [m.infer(fr.batch, idx[b:b + 1], fr.source_imgs_feat, fr.feature_volume, extract_geometry=extract,
+                              match_feature=fr.match_feature, uniforms=(U1[:, b * RN:(b + 1) * RN], U2[:, b * RN:(b + 1) * RN]))
+                      for b, fr in enumerate(frames)]
+        assert len(both) == (4 if extract else 17)
+        for i in range(len(both)):
+            if not extract and i == 16:
+                assert torch.equal(both[i], single[0][i])
+                continue
+            want = torch.cat([s_[i] for s_ in single], 0)
+            assert both[i].shape == want.shape, i
+            assert torch.equal(both[i], want) and torch.equal(both_l[i], want), i
+        assert both[2].shape[0] == 2                 # depth: (B, RN)
 
 
 @pytest.mark.gpu

@@ -175,8 +175,7 @@ def run(a, dev, world=1, rank=0):
         torch.cuda.synchronize()
 
     if os.environ.get("UFR_BT_OVERLAP") == "0":      # development / profiling: the whole backward on one stream
-        from uforecon_amd import autograd as _ag0
-        _ag0.OVERLAP = False
+        m.overlap = False
     for _ in range(a.warmup):
         step()
     fence()
@@ -192,15 +191,14 @@ def run(a, dev, world=1, rank=0):
     # per-kernel durations from the same number of extra, UNTIMED steps with the backward's stream overlap switched off
     # (uforecon_amd/autograd.py runs independent stages side by side: overlapped, the HIP-event intervals of the kernels
     # include their neighbours -- like bench.py's extra single-stream frame)
-    from uforecon_amd import autograd as _ag
-    _ag.OVERLAP = False
+    m.overlap = False
     ops.profile_enable(True)
     for _ in range(a.steps):
         step()
     fence()
     prof = ops.profile_read()
     ops.profile_enable(False)
-    _ag.OVERLAP = os.environ.get("UFR_BT_OVERLAP") != "0"
+    m.overlap = os.environ.get("UFR_BT_OVERLAP") != "0"
     ops.status_poll(True)        # an activation / weight outside the split-precision planes' range fails the run loudly
     per_rank = None
     if world > 1:

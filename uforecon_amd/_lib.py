@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # UFR_LIB selects an alternative in-tree build (A/B kernel variants during development)
 LIB_PATH = os.environ.get("UFR_LIB") or os.path.join(HERE, "lib", "libufr.so")
 
-ABI_VERSION = 404   # = UFR_ABI_VERSION of include/ufr.h; load() refuses a library built against another header
+ABI_VERSION = 500   # = UFR_ABI_VERSION of include/ufr.h; load() refuses a library built against another header
 MAX_VIEWS = 7
 NUM_STAGES = 3
 TOKEN_DIM = 80
@@ -75,6 +75,7 @@ SIGNATURES = {
     "ufr_packed_weights_bytes": (sz, []),
     "ufr_weights_pack": (C.c_int, [C.POINTER(RawWeights), vp, vp]),
     "ufr_weights_pack_for": (C.c_int, [C.POINTER(RawWeights), vp, C.c_float, vp]),
+    "ufr_weights_fit_frame": (C.c_int, [vp, C.POINTER(Frame), vp]),
     "ufr_packed_scale_table_offset": (sz, []),
     "ufr_packed_scale_table_entries": (C.c_int, []),
     "ufr_pack_plan": (C.c_int, [C.POINTER(i32), C.POINTER(i32)]),

@@ -8,6 +8,8 @@ parameter, ``deviation_network.variance`` and the six sampled volumes.  Sample p
 """
 from __future__ import annotations
 
+import dataclasses
+
 import torch
 
 from . import ops
@@ -67,7 +69,19 @@ class RenderPass(torch.autograd.Function):
 
 
 _SIDE = {}
-OVERLAP = True     # False: every stage of RenderTwoPass.backward on the caller's stream (per-kernel timing, debugging)
+
+
+@dataclasses.dataclass(frozen=True)
+class RenderOptions:
+    """How ONE RenderTwoPass node schedules its work -- an argument of the node (UFORecon(...) owns the values), so two
+    models in a process, or a test next to a trainer, cannot change each other's backward.
+    overlap: the backward's independent stages on three streams (False: all on the caller's stream -- per-kernel timing).
+    tape_in_forward: the forward kernels run in their tape instantiation and record the backward's activations (False:
+    plain forward kernels, the backward records the tape itself).
+    record_tape: the caller's statement that a backward will follow this forward (model.py derives it from the grad mode)."""
+    overlap: bool = True
+    tape_in_forward: bool = True
+    record_tape: bool = True
 
 
 _WS = {}
@@ -88,8 +102,6 @@ def _workspace(kind: str, dev, numel_of) -> torch.Tensor:
 
 
 _BUSY = {}          # key -> weak reference to the autograd context that holds the kept buffer between its forward and backward
-RECORD_TAPE = True  # the caller's hint: a backward will follow this forward (uforecon_amd.model sets it from the grad mode)
-TAPE_IN_FORWARD = True   # False (tests, debugging): the plain forward kernels, the backward records the tape itself
 
 
 def _acquire(kind: str, dev, numel_of, ctx):
@@ -101,7 +113,7 @@ def _acquire(kind: str, dev, numel_of, ctx):
 
     key = (kind, torch.device(dev).index or 0)
     holder = _BUSY.get(key)
-    if holder is not None and holder() is not None:
+    if holder is not None and holder() is not None and holder() is not ctx:
         return torch.empty(int(numel_of()), dtype=torch.float32, device=dev), None
     _BUSY[key] = weakref.ref(ctx)
     return _workspace(kind, dev, numel_of), key
@@ -128,11 +140,12 @@ class RenderTwoPass(torch.autograd.Function):
     third less gather / view-transformer work forwards AND backwards: the cotangents that the fine pass sends to the coarse
     samples' token-0 rows and colours are added to the coarse pass's own before ONE view-transformer backward over them.
 
-    ``apply(frame, weights, ray_o, ray_d, z1, U2, *params, *volumes)`` ->
+    ``apply(frame, weights, ray_o, ray_d, z1, U2, options, *params, *volumes)`` (``options``: RenderOptions or None) ->
     ``rgb, depth, opacity, weight, srdf, xy   (coarse)   rgb2, depth2, opacity2, weight2, srdf2, xy2, z2   (fine)``."""
 
     @staticmethod
-    def forward(ctx, frame, weights, ray_o, ray_d, z1, U2, *tensors):
+    def forward(ctx, frame, weights, ray_o, ray_d, z1, U2, options, *tensors):
+        opt = ctx.options = options if options is not None else RenderOptions()
         n_par = len(ops.RAW_WEIGHT_KEYS)
         RN, SN = z1.shape
         PN = U2.shape[0]
@@ -156,7 +169,7 @@ class RenderTwoPass(torch.autograd.Function):
         # workspaces (one view tape over the whole pool, one ray tape per pass): the backward starts at its data-gradient
         # stage, nothing is computed twice.  (Needs the coarse rows to end on a tape block: else the backward records.)
         lib = ops._lib.load()
-        taped = RECORD_TAPE and TAPE_IN_FORWARD and P1 % ops.view_tape_block_points(NV) == 0
+        taped = opt.record_tape and opt.tape_in_forward and P1 % ops.view_tape_block_points(NV) == 0
         ctx.ws_keys = []
         if taped:
             vws, k = _acquire("view", dev, lambda: lib.ufr_view_transform_bwd_workspace_bytes(P1 + P2, NV) // 4, ctx)
@@ -227,19 +240,26 @@ class RenderTwoPass(torch.autograd.Function):
         # stage of the view transformer's backward (the forward again, recording its activations: it needs only forward
         # tensors, and it is bound by its 2 GB of stores while the ray kernels leave half of the GPU's wave slots empty)
         main = torch.cuda.current_stream(dev)
-        side, side2 = (_side_stream(dev, 0), _side_stream(dev, 1)) if OVERLAP else (main, main)
+        side, side2 = (_side_stream(dev, 0), _side_stream(dev, 1)) if ctx.options.overlap else (main, main)
         lib = ops._lib.load()
         taped = ctx.tapes is not None
         if taped:
             vws, ws_c, ws_f = ctx.tapes
         else:
-            vws = _workspace("view", dev, lambda: lib.ufr_view_transform_bwd_workspace_bytes(pool_tok.shape[0], pool_x.shape[1]) // 4)
-            ws_c = _workspace("ray_c", dev, lambda: lib.ufr_ray_transform_bwd_workspace_bytes(RN, SN) // 4)
-            ws_f = _workspace("ray_f", dev, lambda: lib.ufr_ray_transform_bwd_workspace_bytes(RN, S2) // 4)
+            # the same ownership rule as the forward's: a kept buffer that a LIVE forward of another node recorded its tape
+            # into must not be overwritten by this node's tape stage (two frames with different view counts under one
+            # (l0 + l1).backward(): one taped, one not) -- a private buffer then.  Released with the others below.
+            ctx.ws_keys = list(getattr(ctx, "ws_keys", ()))
+            vws, k = _acquire("view", dev, lambda: lib.ufr_view_transform_bwd_workspace_bytes(pool_tok.shape[0], pool_x.shape[1]) // 4, ctx)
+            ctx.ws_keys.append(k)
+            ws_c, k = _acquire("ray_c", dev, lambda: lib.ufr_ray_transform_bwd_workspace_bytes(RN, SN) // 4, ctx)
+            ctx.ws_keys.append(k)
+            ws_f, k = _acquire("ray_f", dev, lambda: lib.ufr_ray_transform_bwd_workspace_bytes(RN, S2) // 4, ctx)
+            ctx.ws_keys.append(k)
         ray_first = ops.STAGE_DGRAD if taped else (ops.STAGE_TAPE | ops.STAGE_DGRAD)
         side.wait_stream(main)
         side2.wait_stream(main)
-        need = ctx.needs_input_grad[6:]
+        need = ctx.needs_input_grad[7:]
         want_vol = any(need[ctx.n_par:])
         gws = _workspace("gather_bwd", dev, lambda: ops.project_gather_bwd_workspace_floats(frame)) if want_vol else None
         with torch.cuda.stream(side2):
@@ -293,7 +313,7 @@ class RenderTwoPass(torch.autograd.Function):
         gpar = [grads.grad(k) for k in ops.RAW_WEIGHT_KEYS]
         gpar[-1] = d_var.reshape(gpar[-1].shape)
         out = [g if (n and g is not None) else None for g, n in zip(gpar + gvol, need)]
-        return (None, None, None, None, None, None, *out)
+        return (None, None, None, None, None, None, None, *out)
 
 
 class Aggregate(torch.autograd.Function):

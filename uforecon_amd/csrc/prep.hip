@@ -12,57 +12,84 @@ namespace ufr {
 
 // in: (N,C,S) -> out: (N,S,Cpad).  Reads are coalesced over s for every channel; each thread
 // then writes its Cpad-float row with 16-byte stores.
-template <int CPAD>
-__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                            int C, int S) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  int n = blockIdx.y;
-  if (s >= S) return;
-  const float* src = in + (size_t)n * C * S + s;
-  float v[CPAD];
+// abs_max (optional): the largest |value| that passes through, as the bit pattern of a non-negative float (an unsigned
+// maximum orders those like the floats; NaN patterns lie above +inf, so a NaN or an infinity in the maps surfaces as a
+// non-finite bound, which the table derivation reports -- weight_scale_chain).  One atomic per wave.
+__device__ __forceinline__ void wave_abs_max(float m, unsigned* __restrict__ abs_max) {
+  unsigned b = __builtin_bit_cast(unsigned, m);
 #pragma unroll
-  for (int c = 0; c < CPAD; ++c) v[c] = c < C ? src[(size_t)c * S] : 0.f;
-  float4* dst = reinterpret_cast<float4*>(out + ((size_t)n * S + s) * CPAD);
-#pragma unroll
-  for (int c = 0; c < CPAD / 4; ++c) dst[c] = make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+  for (int o = 32; o > 0; o >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, o));
+  if ((threadIdx.x & 63) == 0 && b != 0u) atomicMax(abs_max, b);
 }
 
-hipError_t launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int S, int Cpad, hipStream_t s) {
+template <int CPAD>
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            int C, int S, unsigned* __restrict__ abs_max) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  int n = blockIdx.y;
+  float m = 0.f;
+  if (s < S) {
+    const float* src = in + (size_t)n * C * S + s;
+    float v[CPAD];
+#pragma unroll
+    for (int c = 0; c < CPAD; ++c) v[c] = c < C ? src[(size_t)c * S] : 0.f;
+    float4* dst = reinterpret_cast<float4*>(out + ((size_t)n * S + s) * CPAD);
+#pragma unroll
+    for (int c = 0; c < CPAD / 4; ++c) dst[c] = make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+    if (abs_max) {
+      unsigned mb = 0u;     // integer maximum of the magnitudes' bit patterns: a NaN is not dropped (fmaxf would)
+#pragma unroll
+      for (int c = 0; c < CPAD; ++c) mb = max(mb, __builtin_bit_cast(unsigned, v[c]) & 0x7fffffffu);
+      m = __builtin_bit_cast(float, mb);
+    }
+  }
+  if (abs_max) wave_abs_max(m, abs_max);
+}
+
+hipError_t launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int S, int Cpad, hipStream_t s, unsigned* abs_max) {
   dim3 grid((S + 255) / 256, N), block(256);
   switch (Cpad) {
-    case 4: hipLaunchKernelGGL(nchw_to_nhwc_kernel<4>, grid, block, 0, s, in, out, C, S); break;
-    case 32: hipLaunchKernelGGL(nchw_to_nhwc_kernel<32>, grid, block, 0, s, in, out, C, S); break;
-    case 64: hipLaunchKernelGGL(nchw_to_nhwc_kernel<64>, grid, block, 0, s, in, out, C, S); break;
-    case 96: hipLaunchKernelGGL(nchw_to_nhwc_kernel<96>, grid, block, 0, s, in, out, C, S); break;
-    case 128: hipLaunchKernelGGL(nchw_to_nhwc_kernel<128>, grid, block, 0, s, in, out, C, S); break;
-    case 160: hipLaunchKernelGGL(nchw_to_nhwc_kernel<160>, grid, block, 0, s, in, out, C, S); break;
-    case 192: hipLaunchKernelGGL(nchw_to_nhwc_kernel<192>, grid, block, 0, s, in, out, C, S); break;
+    case 4: hipLaunchKernelGGL(nchw_to_nhwc_kernel<4>, grid, block, 0, s, in, out, C, S, abs_max); break;
+    case 32: hipLaunchKernelGGL(nchw_to_nhwc_kernel<32>, grid, block, 0, s, in, out, C, S, abs_max); break;
+    case 64: hipLaunchKernelGGL(nchw_to_nhwc_kernel<64>, grid, block, 0, s, in, out, C, S, abs_max); break;
+    case 96: hipLaunchKernelGGL(nchw_to_nhwc_kernel<96>, grid, block, 0, s, in, out, C, S, abs_max); break;
+    case 128: hipLaunchKernelGGL(nchw_to_nhwc_kernel<128>, grid, block, 0, s, in, out, C, S, abs_max); break;
+    case 160: hipLaunchKernelGGL(nchw_to_nhwc_kernel<160>, grid, block, 0, s, in, out, C, S, abs_max); break;
+    case 192: hipLaunchKernelGGL(nchw_to_nhwc_kernel<192>, grid, block, 0, s, in, out, C, S, abs_max); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
 // feature volume (N,8,S) + weight volume (N,1,S) -> (N,S,12) = [f0..f7, w, 0, 0, 0]
+// (abs_max: the 8 feature channels only -- the weight channel blends them, model.py:376-386, it is not a token feature)
 __global__ void __launch_bounds__(256) volume_pack_kernel(const float* __restrict__ feat,
                                                            const float* __restrict__ weight,
-                                                           float* __restrict__ out, int S) {
+                                                           float* __restrict__ out, int S, unsigned* __restrict__ abs_max) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   int n = blockIdx.y;
-  if (s >= S) return;
-  const float* f = feat + (size_t)n * 8 * S + s;
-  float v[8];
+  float m = 0.f;
+  if (s < S) {
+    const float* f = feat + (size_t)n * 8 * S + s;
+    float v[8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) v[c] = f[(size_t)c * S];
-  float w = weight[(size_t)n * S + s];
-  float4* dst = reinterpret_cast<float4*>(out + ((size_t)n * S + s) * kVolCh);
-  dst[0] = make_float4(v[0], v[1], v[2], v[3]);
-  dst[1] = make_float4(v[4], v[5], v[6], v[7]);
-  dst[2] = make_float4(w, 0.f, 0.f, 0.f);
+    for (int c = 0; c < 8; ++c) v[c] = f[(size_t)c * S];
+    float w = weight[(size_t)n * S + s];
+    float4* dst = reinterpret_cast<float4*>(out + ((size_t)n * S + s) * kVolCh);
+    dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+    dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+    dst[2] = make_float4(w, 0.f, 0.f, 0.f);
+    unsigned mb = 0u;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) mb = max(mb, __builtin_bit_cast(unsigned, v[c]) & 0x7fffffffu);
+    m = __builtin_bit_cast(float, mb);
+  }
+  if (abs_max) wave_abs_max(m, abs_max);
 }
 
-hipError_t launch_volume_pack(const float* feat, const float* weight, float* out, int N, int S, hipStream_t s) {
+hipError_t launch_volume_pack(const float* feat, const float* weight, float* out, int N, int S, hipStream_t s, unsigned* abs_max) {
   dim3 grid((S + 255) / 256, N), block(256);
-  hipLaunchKernelGGL(volume_pack_kernel, grid, block, 0, s, feat, weight, out, S);
+  hipLaunchKernelGGL(volume_pack_kernel, grid, block, 0, s, feat, weight, out, S, abs_max);
   return hipGetLastError();
 }
 
@@ -133,7 +160,7 @@ __device__ inline void stat_mat(int b, int* param, int* k_raw, int* out_dim) {
   }
 }
 // layout of the statistics: max |w| [kStatMats] | infinity norm [kStatMats] | vector maxima [kStatVecs]
-static_assert(2 * kStatMats + kStatVecs <= 2 * kKernelScalars, "the statistics borrow the scalar lists' floats");
+static_assert(2 * kStatMats + kStatVecs <= kStatBoundSlot && kStatBoundSlot < kStatFloats, "the statistics region of the scale table (ufr_layout.h)");
 constexpr int kStatThreads = 1024;
 __global__ void __launch_bounds__(kStatThreads) weight_stats_kernel(RawPtrs raw, float* __restrict__ stats, int* __restrict__ flag) {
   __shared__ float red[3][kStatThreads / 64];
@@ -206,17 +233,31 @@ __global__ void __launch_bounds__(kStatThreads) weight_stats_kernel(RawPtrs raw,
   }
 }
 
-// second kernel: the chain of bounds, the exponents, the table (one thread computes, the wave loads and stores)
+// second kernel: the chain of bounds, the exponents, the table (one thread computes, the wave loads and stores).
+// frame_bound == nullptr: the pack -- the table for the caller's bound x_max.  Otherwise the REFIT for a frame
+// (ufr_weights_fit_frame): *frame_bound is the frame's measured feature bound (ufr_frame_prepare); nothing happens unless it
+// exceeds the bound the table serves, else the table is re-derived for the next power of two above it.  The bound only
+// grows between two packs, so a forward and its backward see compatible tables whatever frames come in between.
 __device__ void weight_scale_chain(const float* stats, float* table, float x_max, int* __restrict__ flag, int fixed);
-__global__ void __launch_bounds__(64) weight_scale_kernel(float* __restrict__ table_out, float x_max, int* __restrict__ flag, int fixed) {
-  __shared__ float stats[2 * kKernelScalars];
+__global__ void __launch_bounds__(64) weight_scale_kernel(float* __restrict__ table_out, float x_max, const unsigned* __restrict__ frame_bound,
+                                                          int* __restrict__ flag, int fixed) {
+  __shared__ float stats[kStatFloats];
   __shared__ float table[kScaleFloats];          // built by thread 0, written out by the wave
-  constexpr int stats_at = view_scalars_offset() - scale_table_offset();   // (constexpr: or the offset walk runs on the device)
-  stats[threadIdx.x] = table_out[stats_at + threadIdx.x];
+  constexpr int stats_at = stats_offset() - scale_table_offset();   // (constexpr: or the offset walk runs on the device)
+  constexpr int n_table = stats_at;                                 // everything in front of the statistics is derived
+  for (int i = threadIdx.x; i < kStatFloats; i += 64) stats[i] = table_out[stats_at + i];
   __syncthreads();
+  if (frame_bound) {
+    const float fb = __builtin_bit_cast(float, *frame_bound);       // NaN / inf pass: the chain reports them (bit 2)
+    if (fb <= stats[kStatBoundSlot]) return;                        // (uniform) the table already covers this frame
+    int e;
+    const float f = frexpf(fb, &e);
+    x_max = (fb <= 3.0e38f) ? (f == 0.5f ? fb : ldexpf(1.f, e)) : fb;
+  }
   if (threadIdx.x == 0) weight_scale_chain(stats, table, x_max, flag, fixed);
   __syncthreads();
-  for (int i = threadIdx.x; i < kScaleFloats; i += 64) table_out[i] = table[i];
+  for (int i = threadIdx.x; i < n_table; i += 64) table_out[i] = table[i];
+  if (threadIdx.x == 0) table_out[stats_at + kStatBoundSlot] = x_max;
 }
 __device__ void weight_scale_chain(const float* stats, float* table, float x_max, int* __restrict__ flag, int fixed) {
   float wmax[kStatMats], ninf[kStatMats], vmax[P_COUNT];
@@ -284,7 +325,7 @@ __device__ void weight_scale_chain(const float* stats, float* table, float x_max
   constexpr int vs_at = view_scalars_offset() - scale_table_offset(), rs_at = ray_scalars_offset() - scale_table_offset();
   float* vs = table + vs_at;
   float* rs = table + rs_at;
-  for (int i = 0; i < 2 * kKernelScalars; ++i) vs[i] = 0.f;
+  for (int i = 0; i < 2 * kKernelScalars; ++i) vs[i] = 0.f;     // (the two lists are adjacent)
   vs[VS_XS_X] = xs(M_VT_Q);
   vs[VS_Q_DSC] = dsc(M_VT_Q);     vs[VS_Q_L2E] = dsc(M_VT_Q) * l2e;
   vs[VS_K_DSC] = dsc(M_VT_K);     vs[VS_K_L2E] = dsc(M_VT_K) * l2e;
@@ -377,15 +418,24 @@ hipError_t launch_pack_weights(const RawPtrs& raw, float* packed, float input_ab
   if (g_plan.err[dev] != hipSuccess) return g_plan.err[dev];
   hipLaunchKernelGGL(pack_weights_kernel, dim3((n_vec - first + 255) / 256), dim3(256), 0, s, raw, g_plan.vec_plan[dev], packed, first,
                      n_vec);
-  constexpr int table_at = scale_table_offset(), stats_at = view_scalars_offset();
+  constexpr int table_at = scale_table_offset(), stats_at = stats_offset();
   float* table = packed + table_at;
   static const int fixed = [] { const char* e = getenv("UFR_DEBUG_FIXED_SCALES"); return (e && e[0] == '1') ? 1 : 0; }();
   hipLaunchKernelGGL(weight_stats_kernel, dim3(kStatMats + kStatVecs), dim3(kStatThreads), 0, s, raw,
                      packed + stats_at, range_flag);
-  hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(64), 0, s, table, input_abs_max, range_flag, fixed);
+  hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(64), 0, s, table, input_abs_max, (const unsigned*)nullptr, range_flag, fixed);
   unsigned short* planes = reinterpret_cast<unsigned short*>(packed + n);
   hipLaunchKernelGGL(pack_weights_f16_kernel, dim3((n_half + 255) / 256), dim3(256), 0, s, raw, g_plan.plan[dev], table, planes,
                      n_half);
+  return hipGetLastError();
+}
+
+
+// ufr_weights_fit_frame: the table of an already packed blob follows a frame's measured feature bound (weight_scale_kernel)
+hipError_t launch_refit_weights(float* packed, const unsigned* frame_bound, int* range_flag, hipStream_t s) {
+  constexpr int table_at = scale_table_offset();
+  static const int fixed = [] { const char* e = getenv("UFR_DEBUG_FIXED_SCALES"); return (e && e[0] == '1') ? 1 : 0; }();
+  hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(64), 0, s, packed + table_at, 0.f, frame_bound, range_flag, fixed);
   return hipGetLastError();
 }
 

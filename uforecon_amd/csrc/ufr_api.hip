@@ -279,6 +279,17 @@ int ufr_weights_pack_for(const ufr_raw_weights* raw, void* packed, float input_a
   return status_leave(sl, s);
 }
 
+int ufr_weights_fit_frame(void* packed, const ufr_frame* frame, ufr_stream stream) {
+  const FrameDev* f = frame_of(frame);
+  UFR_REQUIRE(packed && f, "ufr_weights_fit_frame: null weights / frame handle not prepared");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  StatusSlot* sl = nullptr;
+  int rc = status_slot(&sl);
+  if (rc != UFR_OK) return rc;
+  UFR_HIP(launch_refit_weights(static_cast<float*>(packed), f->abs_max, sl->dev, s));
+  return UFR_OK;
+}
+
 int ufr_weights_pack(const ufr_raw_weights* raw, void* packed, ufr_stream stream) {
   return ufr_weights_pack_for(raw, packed, kDefaultInputAbsMax, stream);
 }
@@ -317,6 +328,7 @@ size_t ufr_frame_workspace_bytes(const ufr_frame_desc* d) {
   c.f32(NV * (size_t)d->H * d->W * 4);
   if (d->vol_feat[0])
     for (int s = 0; s < UFR_NUM_STAGES; ++s) c.f32(NV * (size_t)d->vol_D[s] * d->vol_H[s] * d->vol_W[s] * kVolCh);
+  c.f32(64);    // the frame's measured feature bound (one word; its own 256 bytes)
   return c.off;
 }
 
@@ -338,13 +350,17 @@ int ufr_frame_prepare(const ufr_frame_desc* d, void* workspace, size_t workspace
   if (has_vol)
     for (int st = 0; st < UFR_NUM_STAGES; ++st)
       vol[st] = c.f32((size_t)NV * d->vol_D[st] * d->vol_H[st] * d->vol_W[st] * kVolCh);
+  unsigned* abs_max = reinterpret_cast<unsigned*>(c.f32(64));
 
-  UFR_HIP(launch_nchw_to_nhwc(d->feat, feat, NV, 32, h * w, 32, s));
+  // the passes that re-lay the token features out also measure their magnitude (the matching features only enter as cosine
+  // similarities, the colours only the blend: neither is a dense-layer input)
+  UFR_HIP(hipMemsetAsync(abs_max, 0, 256, s));
+  UFR_HIP(launch_nchw_to_nhwc(d->feat, feat, NV, 32, h * w, 32, s, abs_max));
   if (match) UFR_HIP(launch_nchw_to_nhwc(d->match, match, NV, 32 * (NV - 1), h * w, 32 * (NV - 1), s));
   UFR_HIP(launch_nchw_to_nhwc(d->source_imgs, rgb, NV, 3, d->H * d->W, 4, s));
   if (has_vol)
     for (int st = 0; st < UFR_NUM_STAGES; ++st)
-      UFR_HIP(launch_volume_pack(d->vol_feat[st], d->vol_weight[st], vol[st], NV, d->vol_D[st] * d->vol_H[st] * d->vol_W[st], s));
+      UFR_HIP(launch_volume_pack(d->vol_feat[st], d->vol_weight[st], vol[st], NV, d->vol_D[st] * d->vol_H[st] * d->vol_W[st], s, abs_max));
 
   FrameDev f;
   memset(&f, 0, sizeof(f));
@@ -361,6 +377,7 @@ int ufr_frame_prepare(const ufr_frame_desc* d, void* workspace, size_t workspace
   }
   memcpy(f.ref_pos, d->ref_cam_pos, 3 * sizeof(float));
   f.vol_near = d->vol_near; f.vol_far = d->vol_far;
+  f.abs_max = abs_max;
   f.magic = kFrameMagic;
   memset(out, 0, sizeof(*out));
   memcpy(out, &f, sizeof(f));
@@ -992,6 +1009,9 @@ int ufr_render_rays(const ufr_render_args* a, ufr_stream stream) {
   int src = status_slot(&sl);
   if (src == UFR_OK) src = status_enter(sl, s, "ufr_render_rays");
   if (src != UFR_OK) return src;
+  // the planes' activation exponents follow THIS frame's measured feature bound (a no-op kernel unless the frame exceeds
+  // what the table serves; ufr_weights_fit_frame) -- on the caller's stream, in front of the fork to the side streams
+  UFR_HIP(launch_refit_weights(static_cast<float*>(const_cast<void*>(a->packed_weights)), f->abs_max, sl->dev, s));
   int lanes = a->n_streams > 1 ? a->n_streams : 1;
   if (lanes > kMaxLanes) lanes = kMaxLanes;
   if ((size_t)lanes * need > a->workspace_bytes) lanes = (int)(a->workspace_bytes / need);  // one workspace per lane

@@ -27,6 +27,9 @@ struct FrameDev {
   float ref_pos[3];
   float vol_near, vol_far;
   uint32_t magic;
+  // device word: the largest |value| among the frame's feature maps and volume features, as a float's bit pattern --
+  // measured by the re-layout kernels (prep.hip), consumed by ufr_weights_fit_frame
+  const unsigned* abs_max;
 };
 static_assert(sizeof(FrameDev) <= sizeof(ufr_frame), "ufr_frame too small");
 constexpr uint32_t kFrameMagic = 0x55465246u;  // "UFRF"
@@ -49,8 +52,8 @@ struct LdsAttrOnce {
 };
 
 // kernel launchers (one per .hip file); all enqueue on `s` and return hipGetLastError()
-hipError_t launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int S, int Cpad, hipStream_t s);
-hipError_t launch_volume_pack(const float* feat, const float* weight, float* out, int N, int S, hipStream_t s);
+hipError_t launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int S, int Cpad, hipStream_t s, unsigned* abs_max = nullptr);
+hipError_t launch_volume_pack(const float* feat, const float* weight, float* out, int N, int S, hipStream_t s, unsigned* abs_max = nullptr);
 hipError_t launch_ray_setup(const int64_t* ray_idx, const float* ray_d, const float* cam_ray_d, int HW, float near_z,
                             float far_z, int RN, float* rd_out, float* near_out, float* far_out, float* camz_out,
                             const float* ray_o_host, float* ray_o_out, hipStream_t s);
@@ -120,6 +123,7 @@ int fmt_state_parts(int S);   // per-wave partial states of one sample's source 
 hipError_t launch_fmt_layer(const FmtWeights& w, const float* x, const float* src, int N, int T, int S, float* out,
                             float* state, hipStream_t s);
 hipError_t launch_pack_weights(const RawPtrs& raw, float* packed, float input_abs_max, int* range_flag, hipStream_t s);
+hipError_t launch_refit_weights(float* packed, const unsigned* frame_bound, int* range_flag, hipStream_t s);
 hipError_t launch_tsdf_integrate(float* tsdf, float* weight, float* color, const int* dim, const float* origin,
                                  float voxel_size, float trunc_margin, const float* K, const float* P,
                                  const float* depth_im, const float* color_im, int im_h, int im_w, float obs_weight,

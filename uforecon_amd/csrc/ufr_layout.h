@@ -257,7 +257,13 @@ __host__ __device__ constexpr int vec_offset(int v) {
 // log2(e) multiples, producer-descale x consumer-scale products), in the order of the kernel's enum below -- a kernel reads
 // its list into ONE vector register (lane k = scalar k) and takes a scalar with v_readlane where it needs it.
 constexpr int kKernelScalars = 32;
-constexpr int kScaleFloats = M_COUNT * 4 + 2 * kKernelScalars;
+// ... and behind the two lists the STATISTICS the exponents were derived from (prep.hip: weight_stats_kernel: max |w| and
+// infinity norm per matrix, max |.| per vector parameter) plus, in slot kStatBoundSlot, the input bound the table currently
+// serves.  They stay, so that the table can be re-derived for a frame whose measured feature bound is larger
+// (ufr_weights_fit_frame: prep.hip weight_refit_kernel) without touching the parameters again.
+constexpr int kStatFloats = 3 * kKernelScalars;
+constexpr int kStatBoundSlot = 2 * kKernelScalars;      // the statistics proper occupy the slots below it (static_assert in prep.hip)
+constexpr int kScaleFloats = M_COUNT * 4 + 2 * kKernelScalars + kStatFloats;
 enum ViewScalar : int {   // view_transformer.hip (forward, tape)
   VS_XS_X = 0, VS_Q_DSC, VS_Q_L2E, VS_K_DSC, VS_K_L2E, VS_V_DSC, VS_M_XS, VS_EPS1, VS_M_ASC, VS_MLP0_DSC, VS_M_MLP2, VS_EPS2,
   VS_MLP2_ASC, VS_RW0_XS, VS_RW0_ASC, VS_RW0_DSC, VS_M_RW2, VS_RW2_ASC, VS_RW2_DSC, VS_M_RW4, VS_RW4_ASC, VS_RW4_DSC, VS_COUNT
@@ -271,6 +277,7 @@ static_assert(VS_COUNT <= kKernelScalars && RS_COUNT <= kKernelScalars, "one reg
 __host__ __device__ constexpr int scale_table_offset() { return vec_offset(V_COUNT); }
 __host__ __device__ constexpr int view_scalars_offset() { return scale_table_offset() + M_COUNT * 4; }
 __host__ __device__ constexpr int ray_scalars_offset() { return view_scalars_offset() + kKernelScalars; }
+__host__ __device__ constexpr int stats_offset() { return ray_scalars_offset() + kKernelScalars; }
 __host__ __device__ constexpr int vec_region_floats() { return scale_table_offset() + kScaleFloats - vec_region_offset(); }
 __host__ __device__ constexpr int blob_floats() { return scale_table_offset() + kScaleFloats; }
 __host__ __device__ constexpr int mat_offset(int m) {  // first float of matrix m inside the blob

@@ -47,7 +47,10 @@ constexpr int kPlanes = 2;
 // A layer's accumulator is 2^(s_M + a_M) times the true value.  kScaleExp*: the clamps of the exponents -- with them
 // every accumulator stays below 2^15 2^15 K < 2^38 and every table entry is a normal fp32 number.
 constexpr int kScaleExpWMin = -40, kScaleExpWMax = 24, kScaleExpXMin = -40, kScaleExpXMax = 12;
-constexpr float kDefaultInputAbsMax = 256.f;
+// The bound of the token features when the caller states none: the range the round-3 fixed scale 2^4 accepted (|x| < 4094).
+// It is only the FLOOR: ufr_frame_prepare measures the frame's feature maps and volume features, and the table is re-derived
+// for a frame beyond it (ufr_weights_fit_frame) -- a checkpoint loads and renders without side information (main.py:186-190).
+constexpr float kDefaultInputAbsMax = 4094.f;
 #ifndef UFR_F16_CHUNK
 #define UFR_F16_CHUNK 12
 #endif

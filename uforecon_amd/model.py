@@ -28,6 +28,44 @@ def _wants_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
 
 
+# ---- B > 1: one frame per batch element.  The reference writes `infer` over a leading B (model.py:409-427) and ships
+# `--batch_size 2` as the default (main.py:43); its volume lookup indexes the cost volumes by VIEW along dim 0
+# (model.py:363-364), so the volumes of several frames can only arrive stacked frame-major along that dim, or as one dict
+# per frame.  Every element is an independent frame: the mirror walks them with one FrameHandle each and concatenates the
+# results the way the reference's `(B RN) ...` rearranges lay them out.
+def _frame_of(batch: dict, b: int, B: int) -> dict:
+    out = {}
+    for k, v in batch.items():
+        if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == B:
+            out[k] = v[b:b + 1]
+        elif isinstance(v, (list, tuple)) and len(v) == B and k != "start_idx":
+            out[k] = type(v)(v[b:b + 1])
+        else:
+            out[k] = v
+    return out
+
+
+def _volumes_of(feature_volume, b: int, B: int):
+    if feature_volume is None:
+        return None
+    if isinstance(feature_volume, (list, tuple)):
+        if len(feature_volume) != B:
+            raise UfrError(f"feature_volume: {len(feature_volume)} frames for a batch of {B}")
+        return feature_volume[b]
+    out = {}
+    for st, d in feature_volume.items():
+        n = d["feature_volume"].shape[0]
+        if n % B:
+            raise UfrError(f"feature_volume[{st}]: leading dim {n} is not a multiple of the batch size {B}")
+        nv = n // B
+        out[st] = {k: v[b * nv:(b + 1) * nv] for k, v in d.items()}
+    return out
+
+
+def _match_of(match_feature, b: int):
+    return None if match_feature is None else [t[b:b + 1] for t in match_feature]
+
+
 # --------------------------------------------------------------------------- small modules
 class SingleVarianceNetwork(nn.Module):
     """code1/encoder_utils/single_variance_network.py:5-11 (state_dict key: ``variance``)."""
@@ -212,19 +250,25 @@ class RayTransformer(nn.Module):
         (bit-identical arithmetic) and returns it as ``points_in_pixel``.  Differentiable w.r.t. ``fea_volume`` and the
         parameters."""
         B, RN, SN, _ = point3D.shape
-        if B != 1:
-            raise UfrError("B=1 only (one frame per call)")
         if fea_volume is None or cond_info is None or "feat_info" not in cond_info:
             raise UfrError("RayTransformer.forward needs fea_volume and cond_info['feat_info'] "
                            "(the shipped configuration: correlation volumes + explicit similarity)")
+        if B != 1:      # one frame per batch element; radiance / srdf are "(B RN SN) C" / "(B RN) SN 1" upstream
+            outs = [self.forward(point3D[b:b + 1], _frame_of(batch, b, B), source_imgs_feat[b:b + 1], fea_volume[b:b + 1],
+                                 {"feat_info": cond_info["feat_info"][b:b + 1]}) for b in range(B)]
+            return tuple(torch.cat([o[i] for o in outs], 0) for i in range(3))
         dev = source_imgs_feat.device
         keyed = [source_imgs_feat] + [batch[k] for k in ("source_imgs", "depth_info", "source_poses", "source_poses_inv",
                                                           "ref_pose_inv", "w2cs")]
         key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in keyed) + (batch.get("start_idx", 1),)
-        if key != getattr(self, "_lite_key", None):
-            self._lite_frame = ops.FrameHandle(batch, source_imgs_feat, None, None)
-            self._lite_key = key
-            self._lite_keyed = keyed      # pins the keyed tensors (their addresses are the cache key)
+        lite = getattr(self, "_lite", None)
+        if lite is None:
+            lite = self._lite = {}
+        if key not in lite:               # a few frames are kept: the elements of a batch alternate
+            if len(lite) >= 4:
+                lite.clear()
+            lite[key] = (ops.FrameHandle(batch, source_imgs_feat, None, None), keyed)   # pins the keyed tensors (their addresses are the key)
+        frame = lite[key][0]
         variance = getattr(self, "_variance_stub", None)
         if variance is None or variance.device != dev:
             variance = self._variance_stub = torch.zeros((), device=dev)       # not an input of this module
@@ -235,7 +279,7 @@ class RayTransformer(nn.Module):
         sim8 = cond_info["feat_info"].reshape(P, 8).detach().float().contiguous()
         sd = dict(self.named_parameters())
         params = [sd[k[len("ray_transformer."):]] for k in ops.RAW_WEIGHT_KEYS[:-1]] + [variance]
-        radiance, srdf, xy = ag.Aggregate.apply(self._lite_frame, W, pts, RN, SN, vol24, sim8, *params)
+        radiance, srdf, xy = ag.Aggregate.apply(frame, W, pts, RN, SN, vol24, sim8, *params)
         points_in_pixel = xy.reshape(1, -1, RN, SN, 2).permute(0, 1, 4, 2, 3)
         return radiance, srdf.reshape(B * RN, SN, 1), points_in_pixel
 
@@ -246,13 +290,17 @@ class UFORecon(nn.Module):
     reference's names (``ray_transformer.*``, ``deviation_network.variance``), so a reference
     checkpoint loads with ``load_state_dict(strict=False)`` (the encoder keys are not ours)."""
 
-    def __init__(self, args, precision: Optional[int] = None):
+    def __init__(self, args, precision: Optional[int] = None, overlap: bool = True, tape_in_forward: bool = True):
         """``precision``: matrix precision of this model's dense layers (ops.PRECISION_FP32 / PRECISION_16BIT; None = the
         process default at call time, include/ufr.h).  It travels with every call -- there is no global state to flip
-        between a forward and its backward."""
+        between a forward and its backward.
+        ``overlap`` / ``tape_in_forward``: how the training step's backward is scheduled (autograd.RenderOptions): its
+        independent stages on three streams or all on the caller's; the activation tape recorded by the forward kernels
+        or by the backward.  Same gradients either way (tests/test_gpu_backward.py); per model, not per process."""
         super().__init__()
         self.args = args
         self.precision = precision
+        self.overlap, self.tape_in_forward = bool(overlap), bool(tape_in_forward)
         if getattr(args, "extract_geometry", False):
             self.point_num, self.point_num_2 = args.test_sample_coarse, args.test_sample_fine
         else:
@@ -262,8 +310,7 @@ class UFORecon(nn.Module):
         self.deviation_network = SingleVarianceNetwork(0.3)
         self.renderer = VolumeRenderer(args)
         self.ray_transformer = RayTransformer(args=args)
-        self._frame_key = None
-        self._frame: Optional[ops.FrameHandle] = None
+        self._frames = {}         # frame key -> (FrameHandle, the keyed tensors); a few entries: the elements of a batch alternate
         self._ws: Optional[ops.RenderWorkspace] = None
 
     # ---- per-frame state: channel-last copies are cached on the identity of the frame tensors
@@ -276,11 +323,13 @@ class UFORecon(nn.Module):
                                      "near_fars", "ray_o", "ray_d", "cam_ray_d") if k in batch]
         keyed += ag.flat_volumes(feature_volume)
         key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in keyed) + (batch.get("start_idx", 1),)
-        if key != self._frame_key:
-            self._frame = ops.FrameHandle(batch, source_imgs_feat, feature_volume, match_feature)
-            self._frame_key = key
-            self._frame_keyed = keyed     # pins every keyed tensor: its address cannot be recycled while the entry is cached
-        return self._frame
+        ent = self._frames.get(key)
+        if ent is None:
+            if len(self._frames) >= max(2, int(batch["source_imgs"].shape[0])):
+                self._frames.clear()
+            # the entry pins every keyed tensor: its address cannot be recycled while the entry is cached
+            ent = self._frames[key] = (ops.FrameHandle(batch, source_imgs_feat, feature_volume, match_feature), keyed)
+        return ent[0]
 
     def _weights(self) -> ops.PackedWeights:
         return self.ray_transformer.packed_weights(self.deviation_network.variance, self.precision)
@@ -289,8 +338,12 @@ class UFORecon(nn.Module):
         """model.py:308-348.  ``points_x`` must be ``ray_o + z_val * ray_d`` (it always is in the reference);
         the kernels recompute the positions from ``z_val``."""
         B, RN, SN, _ = points_x.shape
-        if B != 1:
-            raise UfrError("B=1 only (one frame per call)")
+        if B != 1:      # one frame per element (ray_d is "(B RN) 3" upstream, model.py:409-410)
+            rd = ray_d.reshape(B, RN, 3)
+            outs = [self.sample2rgb(_frame_of(batch, b, B), points_x[b:b + 1], z_val[b:b + 1], rd[b], ray_idx[b:b + 1],
+                                    source_imgs_feat[b:b + 1], _volumes_of(feature_volume, b, B), _match_of(match_feature, b))
+                    for b in range(B)]
+            return tuple(torch.cat([o[i] for o in outs], 0) for i in range(6)) + (outs[0][6],)
         fh = self.frame_handle(batch, source_imgs_feat, feature_volume, match_feature)
         ray_o = batch["ray_o"][0].float().contiguous()
         z = z_val.reshape(RN, SN).detach().float().contiguous()
@@ -328,8 +381,16 @@ class UFORecon(nn.Module):
         """model.py:393-482.  ``uniforms=(U1 (SN,RN), U2 (PN,RN))`` pins the sampler randomness; by default
         they are drawn from the CPU generator in the reference's order and shapes."""
         B, RN = ray_idx.shape
-        if B != 1:
-            raise UfrError("B=1 only (one frame per call)")
+        if B != 1:      # one frame per element; the sampler draws are (SN, B*RN) with "(B RN)" columns (sampler.py:42, 86)
+            outs = []
+            for b in range(B):
+                u = None if uniforms is None else tuple(None if U is None else U[:, b * RN:(b + 1) * RN] for U in uniforms)
+                outs.append(self.infer(_frame_of(batch, b, B), ray_idx[b:b + 1], source_imgs_feat[b:b + 1],
+                                       _volumes_of(feature_volume, b, B), extract_geometry, _match_of(match_feature, b),
+                                       ray_idx_all, is_train, u))
+            n = len(outs[0])
+            # every entry is "B ..." or "(B RN) ..." upstream: frame-major along dim 0; the variance (last of the 17) is shared
+            return tuple(outs[0][i] if (n == 17 and i == 16) else torch.cat([o[i] for o in outs], 0) for i in range(n))
         dev = source_imgs_feat.device
         coarse_only = bool(extract_geometry and getattr(self.args, "test_coarse_only", False))
         if uniforms is None:
@@ -364,9 +425,11 @@ class UFORecon(nn.Module):
         # samples' rows with the coarse pass, forwards and backwards (autograd.RenderTwoPass; same numbers as two sample2rgb
         # calls on z1 and on the merged z2, model.py:445, 472)
         params, vols = self._live_params(), ag.flat_volumes(feature_volume)
-        ag.RECORD_TAPE = _wants_grad(*params, *vols)     # a backward will follow: the forward records its tape (autograd.py)
+        # a backward will follow <=> something upstream wants a gradient: then the forward records its tape (autograd.py)
+        opt = ag.RenderOptions(overlap=self.overlap, tape_in_forward=self.tape_in_forward,
+                               record_tape=_wants_grad(*params, *vols))
         (rgb, depth, opacity, weight, srdf, xy1, rgb2, depth2, opacity2, weight2, srdf2, xy2, z2) = ag.RenderTwoPass.apply(
-            fh, W, ray_o, ray_d, z1, U2, *params, *vols)
+            fh, W, ray_o, ray_d, z1, U2, opt, *params, *vols)
         S2 = z2.shape[1]
         pip = xy1.reshape(1, -1, RN, self.point_num, 2).permute(0, 1, 4, 2, 3)
         pip2 = xy2.reshape(1, -1, RN, S2, 2).permute(0, 1, 4, 2, 3)
@@ -382,8 +445,10 @@ class UFORecon(nn.Module):
         ``depths (H,W) float32`` = ray depth * cam_ray_d.z * scale_mat[0][0,0] (model.py:818-826) and
         ``rgbs (H,W,3) float32`` in [0,1], both on the device."""
         B, L, _, imgH, imgW = batch["source_imgs"].shape
-        if B != 1:
-            raise UfrError("B=1 only (one frame per call)")
+        if B != 1:      # one depth map per element: (B, H, W), (B, H, W, 3)
+            outs = [self.render_depth_map(_frame_of(batch, b, B), source_imgs_feat[b:b + 1], _volumes_of(feature_volume, b, B),
+                                          _match_of(match_feature, b), uniforms) for b in range(B)]
+            return torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs])
         dev = source_imgs_feat.device
         HW = imgH * imgW
         coarse_only = bool(getattr(self.args, "test_coarse_only", False))

@@ -85,9 +85,10 @@ def status_poll(synchronize: bool = True, mask: int = 7) -> int:
 class PackedWeights:
     """ufr_raw_weights (pointers into the live parameters) + the MFMA-ordered packed copy.  ``precision``: the matrix
     precision the calls made with these weights use (None = the process default at call time).  ``input_abs_max``: an
-    upper bound of the feature maps and volume features these weights will meet (the pre-similarity features are
-    bounded from pre_sim_mlp's own weights; None = the library default, 256) -- it sets the exponents of the activations' fp16 planes (ufr_weights_pack_for);
-    weights of any finite magnitude pack without further ado."""
+    OPTIONAL floor of the bound of the feature maps and volume features (None = the library default, 4094): the exponents of
+    the activations' fp16 planes follow the bound MEASURED per frame (``fit``: ufr_frame_prepare measures, ufr_weights_fit_frame
+    re-derives the table when a frame exceeds what it serves), so no side information about a checkpoint's feature scale
+    is needed.  Weights of any finite magnitude pack without further ado."""
 
     def __init__(self, params: Dict[str, torch.Tensor], precision: Optional[int] = None,
                  input_abs_max: Optional[float] = None):
@@ -109,6 +110,7 @@ class PackedWeights:
         C.memmove(C.byref(self.raw), (C.c_void_p * 40)(*ptrs), C.sizeof(self.raw))
         self.device = self._keep[0].device
         self.packed = torch.empty(lib.ufr_packed_weights_bytes() // 4, dtype=torch.float32, device=self.device)
+        self.epoch = 0          # bumped by every pack: a frame is fitted once per (frame, epoch)
         self.repack(check=True)
 
     def repack(self, check: bool = False) -> None:
@@ -121,8 +123,20 @@ class PackedWeights:
         else:
             rc = lib.ufr_weights_pack_for(C.byref(self.raw), self.packed.data_ptr(), float(self.input_abs_max), _stream())
         _lib.check(rc, "ufr_weights_pack")
+        self.epoch += 1
         if check:
             status_poll(True, mask=4)    # the pack's own bit: an unrelated, still unreported overflow must not fail a valid pack
+
+    def fit(self, frame: "FrameHandle") -> None:
+        """The activation exponents follow ``frame``'s measured feature bound (ufr_weights_fit_frame): one tiny asynchronous
+        kernel, issued once per (frame, pack) -- a no-op on the device unless the frame exceeds the bound the table serves."""
+        key = (id(self), self.epoch)
+        if key in frame._fitted:
+            return
+        _lib.check(_lib.load().ufr_weights_fit_frame(self.packed.data_ptr(), C.byref(frame.frame), _stream()), "ufr_weights_fit_frame")
+        if len(frame._fitted) > 8:
+            frame._fitted.clear()
+        frame._fitted.add(key)
 
     def mode(self) -> int:
         return resolve_precision(self.precision)
@@ -207,6 +221,7 @@ class FrameHandle:
         _lib.check(lib.ufr_frame_prepare(C.byref(d), self.workspace.data_ptr(), nbytes, C.byref(self.frame), _stream()),
                    "ufr_frame_prepare")
         self.NV, self.H, self.W = NV, H, W
+        self._fitted = set()    # (id(PackedWeights), its pack epoch) this frame's feature bound was handed to
         self.near_z, self.far_z = float(d.vol_near), float(d.vol_far)
         # view-dependent state of the whole-frame renderer (absent when the handle only serves RayTransformer.forward)
         self.ray_o = [float(v) for v in batch["ray_o"][0].detach().cpu()] if "ray_o" in batch else None
@@ -270,6 +285,7 @@ def project_gather(frame: FrameHandle, weights: PackedWeights, ray_o: torch.Tens
         if want_xy:     # points_in_pixel of the reference's return tuples
             dbg["xy"] = torch.empty(NV, P, 2, device=dev)
     stride = 0 if ray_o.numel() == 3 else 3
+    weights.fit(frame)      # the tokens gathered here meet `weights`' dense layers next: their exponents follow this frame
     _lib.check(_lib.load().ufr_project_gather(
         C.byref(frame.frame), C.byref(weights.raw), _dev(ray_o, "ray_o"), stride, _dev(ray_d, "ray_d"), _dev(z, "z"),
         RN, SN, x.data_ptr(), rgb.data_ptr(), dirs.data_ptr(), _opt(dbg.get("sim8"), "sim8"),

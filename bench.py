@@ -15,9 +15,11 @@ timed region (same inputs, same launches); with --streams 1 they come from the t
 
 After the timed configs[1] region, a single-GPU run also measures the other single-GPU configurations of BASELINE.json
 and attaches them to the same line as `secondary` (each entry a complete line of its own: value, ms_per_step, kernel
-split, `roofline`, `cpu_baseline`): configs[3] (5 views, 800x600, 128+128 samples; two frames) and the configs[4]
-training step (1024 rays, forward + backward + Adam) in both matrix precisions (tools/bench_train.py's loop).
-`--no-secondary` skips them.
+split, `roofline`): the per-frame producers, the configs[4] training step (1024 rays, forward + backward + Adam) in both
+matrix precisions (tools/bench_train.py's loop), the configs[2] evaluation loop on this one GPU and -- last, so that it
+survives a truncated log -- configs[3] (5 views, 800x600, 128+128 samples; two frames); a short `digest` of all of them
+closes the line.  `--full-secondary` adds the CPU / GPU-eager baselines of those entries and the evaluation loop without
+the producer overlap (minutes of host time); `--no-secondary` skips them all.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -73,13 +75,18 @@ def parse(argv=None):
     p.add_argument("--no-secondary", action="store_true", help="skip the configs[3] / configs[4] measurements attached as "
                                                                 "`secondary` to a single-GPU line")
     p.add_argument("--secondary-train-steps", type=int, default=10)
+    p.add_argument("--full-secondary", action="store_true",
+                   help="also: the evaluation loop a second time without the producer overlap, and the CPU / GPU-eager baselines "
+                        "of configs[3] and of the training step (minutes of host time; the default run carries the headline's "
+                        "own two baselines only and finishes within ~5 minutes on a cold box)")
     p.add_argument("--config", default="", help="c3: BASELINE configs[2], the evaluation loop over 15 scenes x 3 render views "
                                                  "(per-frame producers + sharded ray path + all-gather, uforecon_amd/evalset.py) "
                                                  "instead of one pre-encoded frame")
     p.add_argument("--frames", type=int, default=45, help="--config c3: frames of the evaluation set")
-    p.add_argument("--producers", default="replicated", choices=["replicated", "sharded"],
+    p.add_argument("--producers", default=None, choices=["replicated", "sharded"],
                    help="--config c3, N > 1: every rank encodes every frame, or the frames' producers are dealt over the "
-                        "ranks and broadcast")
+                        "ranks and broadcast (default: sharded when N > 1 -- replicated producers bound the frame at the "
+                        "encode time whatever N is)")
     p.add_argument("--no-overlap", action="store_true", help="--config c3: encode frame k+1 only after frame k's rays")
     p.add_argument("--dump-depths", default="", help="--config c3: rank 0 writes all depth maps here (.npy, frames x H x W)")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
@@ -423,21 +430,11 @@ def measure_evalset(a, dev, world, rank):
 
 
 def secondary_measurements(a, dev):
-    """The other single-GPU configurations of BASELINE.json, measured in the same process after the headline run."""
+    """The other single-GPU configurations of BASELINE.json, measured in the same process after the headline run.
+    Insertion order = print order: the driver keeps only the tail of a long stdout line, so the entries it has asked for by
+    name come LAST (configs[4], configs[2]@1gpu, configs[3]) and a few-hundred-byte `digest` of all of them closes the line."""
     sec = {}
-    c3 = parse(["--views", "5", "--height", "600", "--width", "800", "--coarse", "128", "--fine", "128", "--steps", "2",
-                "--warmup", "1", "--streams", str(a.streams), "--cpu-rays", "64", "--cpu-calls", "2", "--eager-chunks", "2"])
-    c3.no_cpu_baseline, c3.no_gpu_eager_baseline = a.no_cpu_baseline, a.no_gpu_eager_baseline
-    sec["configs[3]"] = measure_frames(c3, dev, 1, 0)
-    # configs[2] on this one GPU: the whole evaluation loop, producers included, with and without the producer overlap
-    ev = parse(["--config", "c3", "--frames", "45", "--streams", str(a.streams)])
-    sec["configs[2]@1gpu"] = measure_evalset(ev, dev, 1, 0)
-    ev_serial = parse(["--config", "c3", "--frames", "9", "--streams", str(a.streams), "--no-overlap"])
-    serial = measure_evalset(ev_serial, dev, 1, 0)
-    sec["configs[2]@1gpu"]["config"]["without_overlap"] = dict(
-        frames=9, depth_map_ms_per_frame_inclusive=serial["ms_per_step"], encode_frame_ms=serial["config"]["encode_frame_ms"],
-        ray_path_ms_per_frame=serial["config"]["ray_path_ms_per_frame_rank0"])
-    torch.cuda.empty_cache()
+    full = a.full_secondary
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_correlate
     import bench_encoder
@@ -450,18 +447,85 @@ def secondary_measurements(a, dev):
     sec["tsdf"] = bench_tsdf.measure(384, reps=10)
     torch.cuda.empty_cache()
 
-    # both GPU measurements first, the CPU leg after them (its worker threads keep spinning for a while and slow the
-    # host side of a step that follows)
+    # both GPU measurements first, the CPU leg (--full-secondary) after them (its worker threads keep spinning for a while
+    # and slow the host side of a step that follows)
     for prec in ("fp32", "16bit"):
         ta = bench_train.parse(["--steps", str(a.secondary_train_steps), "--warmup", "3", "--precision", prec, "--no-cpu-baseline"])
         sec[f"configs[4]_{prec}"] = bench_train.run(ta, dev, 1, 0)
         torch.cuda.empty_cache()
-    if not a.no_cpu_baseline:
+    if full and not a.no_cpu_baseline:
         base = bench_train.cpu_baseline_standalone(bench_train.parse([]))
         sec["configs[4]_fp32"]["cpu_baseline"] = base
         # the CPU leg has one arithmetic (fp32): the 16-bit entry points at the same measurement
         sec["configs[4]_16bit"]["cpu_baseline"] = dict(base, note="same measurement as configs[4]_fp32 (the oracle is fp32)")
+    # configs[2] on this one GPU: the whole evaluation loop, producers included (--full-secondary: again without the overlap)
+    ev = parse(["--config", "c3", "--frames", "45", "--streams", str(a.streams)])
+    sec["configs[2]@1gpu"] = measure_evalset(ev, dev, 1, 0)
+    if full:
+        ev_serial = parse(["--config", "c3", "--frames", "9", "--streams", str(a.streams), "--no-overlap"])
+        serial = measure_evalset(ev_serial, dev, 1, 0)
+        sec["configs[2]@1gpu"]["config"]["without_overlap"] = dict(
+            frames=9, depth_map_ms_per_frame_inclusive=serial["ms_per_step"], encode_frame_ms=serial["config"]["encode_frame_ms"],
+            ray_path_ms_per_frame=serial["config"]["ray_path_ms_per_frame_rank0"])
+    torch.cuda.empty_cache()
+    c3 = parse(["--views", "5", "--height", "600", "--width", "800", "--coarse", "128", "--fine", "128", "--steps", "2",
+                "--warmup", "1", "--streams", str(a.streams), "--cpu-rays", "64", "--cpu-calls", "2", "--eager-chunks", "2"])
+    c3.no_cpu_baseline = a.no_cpu_baseline or not full
+    c3.no_gpu_eager_baseline = a.no_gpu_eager_baseline or not full
+    sec["configs[3]"] = measure_frames(c3, dev, 1, 0)
     return sec
+
+
+def projection(line):
+    """What the multi-GPU legs should measure, written down BEFORE any multi-GPU run exists (no such box in the build
+    environment): per-rank ray-path time, the producers' share under both modes, the bytes on the wire.  Assumptions are
+    spelled out so that the first real N = 2 / 4 / 8 line can be checked against them."""
+    from uforecon_amd.evalset import _frame_tensor_shapes
+
+    sec = line.get("secondary") or {}
+    ray_ms = line["ms_per_step"]
+    enc = (sec.get("encode_frame") or {}).get("encode_frame_ms")
+    bcast = 4 * sum(int(torch.Size(s).numel()) for _, s in _frame_tensor_shapes(512, 640, 3))
+    gather = 512 * 640 * 16
+    xgmi = 100.0      # GB/s assumed for a one-to-all broadcast (7 links x ~153 GB/s per GPU, a ring / tree keeps one busy)
+    out = dict(assumptions=f"rays are independent: the ray path divides by N (row tiles of >= 2048-ray chunks); producers one "
+                           f"frame ahead on a side stream hide behind the rays only while they are shorter; broadcast at "
+                           f"{xgmi:g} GB/s effective over xGMI (assumed, unmeasured); fp32 on the wire -- fp16 frustums were "
+                           f"checked and REJECTED: the oracle on c2_hier_512x640_interior moves depth by 3.3e-4 (bf16: 3.5e-3)",
+               broadcast_bytes_per_frame=bcast, all_gather_bytes_per_frame=gather, per_n={})
+    for n in (2, 4, 8):
+        e = dict(ray_path_ms_per_rank=ray_ms / n)
+        if enc:
+            b_ms = bcast / (xgmi * 1e9) * 1e3
+            e["replicated"] = dict(encode_ms_per_rank=enc, frame_ms=max(ray_ms / n, enc))
+            e["sharded"] = dict(encode_ms_per_rank=enc / n, broadcast_ms=b_ms, frame_ms=max(ray_ms / n, enc / n + b_ms))
+            e["ray_only_scaling"] = n
+            e["frame_scaling_replicated"] = ray_ms / e["replicated"]["frame_ms"]
+            e["frame_scaling_sharded"] = ray_ms / e["sharded"]["frame_ms"]
+        out["per_n"][str(n)] = e
+    return out
+
+
+def digest(line):
+    """The numbers a reader of a TRUNCATED line needs, at its very end."""
+    sec = line.get("secondary") or {}
+    d = dict(frame_ms=round(line["ms_per_step"], 2), rays_per_s=round(line["value"]),
+             view_t_ms=round(line["roofline"]["avg_launch_ms"], 4), view_t_frac=round(line["roofline"]["frac"], 3),
+             ray_t_ms=round(line["roofline"]["ray_transformer"]["avg_launch_ms"], 4),
+             ray_t_frac=round(line["roofline"]["ray_transformer"]["frac"], 3))
+    c3 = sec.get("configs[3]")
+    if c3:
+        d["configs[3]"] = dict(rays_per_s=round(c3["value"]), frame_ms=round(c3["ms_per_step"], 1), view_t_frac=round(c3["roofline"]["frac"], 3),
+                               gather_ms=round(c3["config"]["kernel_ms_per_frame_rank0"].get("gather", 0.0), 1))
+    c2 = sec.get("configs[2]@1gpu")
+    if c2:
+        d["configs[2]@1gpu"] = dict(frame_ms_inclusive=round(c2["ms_per_step"], 1), encode_frame_ms=round(c2["config"]["encode_frame_ms"], 1))
+    for k in ("configs[4]_fp32", "configs[4]_16bit"):
+        if sec.get(k):
+            d[k] = dict(step_ms=round(sec[k]["ms_per_step"], 2), frac=round(sec[k]["roofline"]["frac"], 3))
+    if sec.get("encode_frame"):
+        d["encode_frame_ms"] = round(sec["encode_frame"]["encode_frame_ms"], 1)
+    return d
 
 
 def main():
@@ -482,6 +546,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(a.backend)
+    if a.producers is None:
+        a.producers = "sharded" if world > 1 else "replicated"
     if a.config == "c3":
         line = measure_evalset(a, dev, world, rank)
         if rank == 0:
@@ -494,6 +560,9 @@ def main():
     if rank == 0:
         if world == 1 and not a.no_secondary and config_name(a) == "configs[1]":
             line["secondary"] = secondary_measurements(a, dev)
+        if world == 1 and config_name(a) == "configs[1]":
+            line["projected"] = projection(line)
+        line["digest"] = digest(line)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

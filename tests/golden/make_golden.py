@@ -50,11 +50,11 @@ CASES = {
     # statistics of a TRAINED checkpoint instead of the default init (the real checkpoint is absent: .MISSING_LARGE_BLOBS):
     # every weight matrix x 8, LayerNorm gains up to 10 and biases in [-1, 1], 2-D feature maps x 30 -- dense-layer inputs
     # reach ~1e3.  The modified weights travel in the fixture.
-    "c2_trained_like": dict(H=64, W=96, NV=3, seed=9, RN=128, coarse=64, fine=64, interior=True,
+    "c2_trained_like": dict(H=64, W=96, NV=3, seed=9, RN=128, coarse=64, fine=64, interior=True, render64=True,
                             trained_like=dict(w=8.0, gamma=10.0, feat=30.0)),
     # the same far beyond what fixed plane exponents could hold: every matrix x 64, feature maps x 300 (dense-layer inputs
     # reach ~1e6; round 4's per-matrix / per-layer exponents, ufr_weights_pack_for)
-    "c2_trained_like_x64": dict(H=64, W=96, NV=3, seed=9, RN=128, coarse=64, fine=64, interior=True,
+    "c2_trained_like_x64": dict(H=64, W=96, NV=3, seed=9, RN=128, coarse=64, fine=64, interior=True, render64=True,
                                 trained_like=dict(w=64.0, gamma=10.0, feat=300.0)),
 }
 
@@ -161,7 +161,7 @@ def clean_ray_indices(model, fr, H, W, RN, sampler_seed, train, relu_margin=0.0,
     raise RuntimeError("could not find a clean ray set")
 
 
-def srdf_in_float64(model, fr, pts):
+def srdf_in_float64(model, fr, pts, want_render=False):
     """srdf (RN,SN) at the sample positions `pts` (RN,SN,3) with EVERYTHING after the positions in float64: projection,
     gathers, pair similarity, frustum lookup, depth code, both transformers, DensityMLP -- through the functional
     restatement oracle/ufo_oracle.py (which reproduces the reference's fp32 rows to 2e-6) on float64 copies of the frame
@@ -191,7 +191,11 @@ def srdf_in_float64(model, fr, pts):
         dirp = dirs.permute(1, 2, 0, 3).reshape(RN * SN, NV, 3).double()
         maskp = mask.permute(1, 2, 0).reshape(RN * SN, NV).double()
         rgbp = rgb.permute(2, 3, 0, 1).reshape(RN * SN, NV, 3).double()
-        _, srdf = O.aggregate_tokens(P, x.double(), rgbp, maskp, dirp, RN, SN)
+        radiance, srdf = O.aggregate_tokens(P, x.double(), rgbp, maskp, dirp, RN, SN)
+        if want_render:     # ... and the compositor on top: depth / colour of the rays at these positions
+            z = (pts - batch["ray_o"][0]).norm(dim=-1)
+            rgb, depth = O.composite(z, radiance.reshape(RN, SN, 3), srdf.reshape(RN, SN), P["deviation_network.variance"])[:2]
+            return srdf.reshape(RN, SN), depth, rgb
     return srdf.reshape(RN, SN)
 
 
@@ -294,6 +298,15 @@ def run_case(name, c, weight_seed=0, sampler_seed=1):
         out["srdf64"] = srdf_in_float64(model, fr, torch.from_numpy(out["points"])).numpy().astype(np.float32)
         e = np.abs(out["srdf64"] - out["srdf"]).max() / np.abs(out["srdf"]).max()
         print(f"  float64 evaluation vs the reference's fp32 srdf at its own positions: {e:.2e} of scale")
+    if c.get("render64"):
+        # `depth64` / `rgb64`: the rays rendered in float64 from the reference's own sample positions on -- the yardstick of
+        # a network that amplifies rounding (trained-like statistics).  The reference's fp32 run is one rounding realisation
+        # of it; how far it sits from it is the scale of what any fp32 evaluation may deviate (tests/test_gpu_round3.py).
+        s64, d64, c64 = srdf_in_float64(model, fr, torch.from_numpy(out["points"]), want_render=True)
+        out["depth64"], out["rgb64"] = d64.numpy(), c64.numpy()
+        e_d = float(np.abs(out["depth64"] - out["depth"]).max() / np.abs(out["depth64"]).max())
+        e_c = float(np.abs(out["rgb64"] - out["rgb"]).max())
+        print(f"  float64 rendering vs the reference's fp32 outputs at its own positions: depth {e_d:.2e} of scale, rgb {e_c:.2e}")
     np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
     print(f"{name}: {len(out)} arrays, {os.path.getsize(os.path.join(HERE, name + '.npz')) / 1e6:.2f} MB")
     return model

@@ -150,6 +150,41 @@ def test_render_rays_matches_reference_golden(name, weights):
     assert rel_err(out["srdf"], g["srdf"]) < 1e-3
 
 
+@pytest.mark.parametrize("name", ["c1_coarse_only", "c2_hier_small", "c4_nv5_128", "c2_hier_512x640"])
+def test_render_rays_rgb_on_every_ray_with_the_border_decision_passed_in(name, weights):
+    """RGB on 100 % of the rays of every golden fixture, border-degenerate ones included.  A sample that projects ONTO an
+    image border of a source view is in or out of the reference's inclusive mask (grid_sample.py:13-17) by the last ulp of
+    its position: the reference is a step function there, and the only thing the mask does is send that view's blend
+    logit to -1e9 (ray_transformer.py:315-317) -- so a border sample has exactly two admissible colours.  Checked here:
+    (a) the kernels' in-image decision differs from the reference arithmetic's (the oracle on this host, at the kernels'
+    own sample positions) ONLY at samples within 2e-5 of a border; (b) with that decision passed in, the reference
+    arithmetic reproduces the kernels' RGB within 1e-4 on EVERY ray -- i.e. every sample's colour is one of its two
+    admissible values; depth does not depend on the decision and is asserted against the golden elsewhere."""
+    c = CASES[name]
+    fr, idx, U1, U2, g = case_inputs(name)
+    fh = _frame_handle(fr)
+    out = ops.render_rays(fh, weights, idx.to(DEV), U1.to(DEV), U2.to(DEV), coarse_only=c.get("coarse_only", False))
+    ray_o, ray_d, _, _ = _ray_setup(fr, idx)
+    z = out["z_all"].cpu()
+    RN, S = z.shape
+    NV = fh.NV
+    # the kernels' own decision at these positions (the same gather kernel, one call: test_chunk_invariance pins that)
+    _, rgbm, _, dbg = ops.project_gather(fh, weights, ray_o.to(DEV), ray_d.to(DEV), out["z_all"].contiguous(), debug=True)
+    ours = rgbm[..., 3].reshape(RN, S, NV).permute(2, 0, 1).cpu()
+    pts = ray_o[None, None, :] + z[..., None] * ray_d[:, None, :]
+    rows = {}
+    with torch.no_grad():
+        O.render_pass(load_weights(), fr.batch, pts, z, fr.source_imgs_feat, fr.feature_volume, fr.match_feature, want=rows)
+        rgb_o, depth_o = O.render_pass(load_weights(), fr.batch, pts, z, fr.source_imgs_feat, fr.feature_volume,
+                                       fr.match_feature, mask_override=ours)[:2]
+    near = ((rows["xy"].abs() - 1.0).abs() < 2e-5).any(-1)                  # (NV,RN,S): within 2e-5 of a border
+    differs = ours != rows["mask"]
+    assert not bool((differs & ~near).any()), "in-image decisions differ away from the borders"
+    print(f"{name}: {int(near.any(0).any(-1).sum())} of {RN} rays touch a border; the decision differs on {int(differs.sum())} samples")
+    assert max_rel_elem(out["rgb"], rgb_o, floor=0.05) < REL_TOL             # every ray
+    assert max_rel_elem(out["depth"], depth_o, floor=1e-3) < REL_TOL
+
+
 @pytest.mark.parametrize("name", ["c2_hier_interior", "c4_nv5_interior"])
 def test_render_rays_interior_rays_full_coverage(name, weights):
     """Rays strictly inside the image (no sample projects onto an image border of a source view, where the

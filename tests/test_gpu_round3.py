@@ -96,30 +96,31 @@ def test_full_size_configs3_frame_is_chunk_and_slot_invariant(weights):
     assert ops.status_poll(True) == 0
 
 
-@pytest.mark.parametrize("name,bound", [("c2_trained_like", None), ("c2_trained_like_x64", 1024.0)])
+@pytest.mark.parametrize("name,bound", [("c2_trained_like", None), ("c2_trained_like_x64", None)])
 def test_trained_like_statistics(name, bound):
     """A checkpoint-like parameter set (every matrix x 8, LayerNorm gains up to 10, biases in [-1,1]) on feature maps x 30:
     dense-layer inputs reach ~1e3, three orders of magnitude above the default init -- and the same at x 64 / x 300 (inputs
-    ~1e6, token features up to ~510: packed with input_abs_max = 1024); the planes' exponents follow the weights and the
-    stated input bound (ufr_layout_f16.h).  The reference itself amplifies rounding here (the srdf head has gain ~1e3 / 5e5,
-    and its float32 elu(q) + 1 loses the small K' of strongly negative q), so the oracle on this host is the yardstick: the
-    kernels must be as close to the reference's golden as the oracle is (within a factor), and the range status must stay
-    clear."""
+    ~1e6, token features up to ~510) -- packed with NO stated bound: the planes' exponents follow the weights and the
+    frame's measured feature bound (ufr_layout_f16.h, ufr_weights_fit_frame).  FIXED bounds, nothing derived on this host: depth and RGB within the north-star
+    1e-4 of the reference's golden on every ray, and -- the yardstick stored in the fixture (make_golden: render64) -- no
+    further from the float64 rendering at the golden's own sample positions than the 1e-4 either (the reference's own fp32
+    run sits 7e-7 / 3e-5 (depth / rgb) from it at x 8, 4e-7 / 4e-6 at x 64); the range status must stay clear."""
     fr, idx, U1, U2, g = case_inputs(name)
     P = case_weights(name)
-    with torch.no_grad():
-        _, _, d_o, c_o = O.infer(P, fr.batch, idx, fr.source_imgs_feat, fr.feature_volume, fr.match_feature, U1, U2)
     W = ops.PackedWeights({k: v.to(DEV) for k, v in P.items()}, input_abs_max=bound)
     out = ops.render_rays(_frame_handle(fr), W, idx.to(DEV), U1.to(DEV), U2.to(DEV))
     assert ops.status_poll(True) == 0
-    e_oracle_d = max_rel_elem(d_o.reshape(-1), g["depth"], floor=1e-3)
-    e_oracle_c = max_rel_elem(c_o.reshape(-1, 3), g["rgb"], floor=0.05)
     e_d = max_rel_elem(out["depth"], g["depth"], floor=1e-3)
     e_c = max_rel_elem(out["rgb"], g["rgb"], floor=0.05)
-    print(f"{name}: depth err {e_d:.2e} (oracle {e_oracle_d:.2e}), rgb err {e_c:.2e} (oracle {e_oracle_c:.2e})")
+    e_d64 = max_rel_elem(out["depth"], g["depth64"], floor=1e-3)
+    e_c64 = max_rel_elem(out["rgb"], g["rgb64"], floor=0.05)
+    r_d64 = max_rel_elem(g["depth"], g["depth64"], floor=1e-3)
+    r_c64 = max_rel_elem(g["rgb"], g["rgb64"], floor=0.05)
+    print(f"{name}: vs the golden: depth {e_d:.2e}, rgb {e_c:.2e}; vs float64 at the golden's positions: depth {e_d64:.2e}, "
+          f"rgb {e_c64:.2e} (the reference's own fp32 run: {r_d64:.2e}, {r_c64:.2e})")
     assert bool(torch.isfinite(out["depth"]).all()) and bool(torch.isfinite(out["rgb"]).all())
-    assert e_d < max(REL_TOL, 4 * e_oracle_d)
-    assert e_c < max(REL_TOL, 4 * e_oracle_c)
+    assert e_d < REL_TOL and e_c < REL_TOL
+    assert e_d64 < REL_TOL and e_c64 < REL_TOL
 
 
 # ------------------------------------------------------------------------------------------------ range status

@@ -101,6 +101,16 @@ def test_gradient_allreduce_world2_gloo():
     assert all(ok for _, ok in res)
 
 
+def _two_rank_backend():
+    """(backend, env) of the 2-rank launcher tests: RCCL with one device per rank where the box has two, else both ranks on
+    the one device over gloo (UFR_BENCH_SHARE_GPU: diagnostics mode of the bench scripts)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if torch.cuda.device_count() >= 2:
+        return "nccl", env
+    env["UFR_BENCH_SHARE_GPU"] = "1"
+    return "gloo", env
+
+
 @pytest.mark.gpu
 def test_two_rank_bench_renders_the_one_rank_frame(tmp_path):
     """The real N > 1 path of bench.py (launcher -> one process per rank -> row-tile sharding -> all-gather) with 2 ranks
@@ -115,7 +125,7 @@ def test_two_rank_bench_renders_the_one_rank_frame(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     common = ["--height", "64", "--width", "96", "--steps", "1", "--warmup", "1", "--fixed-uniforms", "7", "--no-cpu-baseline",
               "--no-gpu-eager-baseline", "--chunk", "2048"]
-    env = dict(os.environ, UFR_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    backend, env = _two_rank_backend()
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dump-depth", str(tmp_path / "d1.npy"),
                           *common], capture_output=True, text=True, env=env, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
@@ -123,7 +133,7 @@ def test_two_rank_bench_renders_the_one_rank_frame(tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", backend,
                           "--dump-depth", str(tmp_path / "d2.npy"), *common], capture_output=True, text=True, env=env, timeout=900)
     assert two.returncode == 0, two.stderr[-2000:]
     d1, d2 = np.load(tmp_path / "d1.npy"), np.load(tmp_path / "d2.npy")
@@ -151,7 +161,7 @@ def test_two_rank_evaluation_loop_renders_the_one_rank_depth_maps(tmp_path, prod
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     common = ["--config", "c3", "--frames", "4", "--height", "128", "--width", "160", "--fixed-uniforms", "5", "--chunk", "2048",
               "--producers", producers]
-    env = dict(os.environ, UFR_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    backend, env = _two_rank_backend()
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dump-depths", str(tmp_path / "d1.npy"),
                           *common], capture_output=True, text=True, env=env, timeout=900)
     assert one.returncode == 0, one.stderr[-2000:]
@@ -159,7 +169,7 @@ def test_two_rank_evaluation_loop_renders_the_one_rank_depth_maps(tmp_path, prod
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", backend,
                           "--dump-depths", str(tmp_path / "d2.npy"), *common], capture_output=True, text=True, env=env, timeout=1200)
     assert two.returncode == 0, two.stderr[-2000:]
     d1, d2 = np.load(tmp_path / "d1.npy"), np.load(tmp_path / "d2.npy")
@@ -189,7 +199,7 @@ def test_two_rank_training_step_allreduces_to_the_mean(tmp_path):
     script = os.path.join(root, "tools", "bench_train.py")
     common = ["--height", "64", "--width", "96", "--rays", "128", "--steps", "1", "--warmup", "0", "--fixed-seed", "3",
               "--no-cpu-baseline"]
-    env = dict(os.environ, UFR_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    backend, env = _two_rank_backend()
     for r in (0, 1):
         one = subprocess.run([sys.executable, script, "--gpus", "1", "--data-rank", str(r), "--dump-grads", str(tmp_path / f"g{r}.pt"),
                               *common], capture_output=True, text=True, env=env, timeout=600)
@@ -198,7 +208,7 @@ def test_two_rank_training_step_allreduces_to_the_mean(tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", str(port), script, "--gpus", "2", "--backend", "gloo", "--dump-grads",
+                          "127.0.0.1", "--master-port", str(port), script, "--gpus", "2", "--backend", backend, "--dump-grads",
                           str(tmp_path / "g2.pt"), *common], capture_output=True, text=True, env=env, timeout=900)
     assert two.returncode == 0, two.stderr[-2000:]
     g0, g1, g2 = (torch.load(tmp_path / f"g{k}.pt") for k in ("0", "1", "2"))

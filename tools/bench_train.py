@@ -32,8 +32,11 @@ sys.path.insert(0, ROOT)
 # view-transformer flop per point (q/k/v/merge 204 800 + MLP 307 200 + attention 13 440 + radiance MLP 8 784
 # at NV = 3); the backward kernel recomputes the layer, forms the data gradients and the weight gradients: 3 x
 VIEWT_FLOP_PER_POINT = {3: 534_224, 5: (204_800 + 307_200) * 6 // 4 + 20_160 + 14_640}
-PEAK_FP32_MFMA_TFLOPS = 157.3     # the fp32 mode's backward GEMMs issue v_mfma_f32_16x16x4_f32
-PEAK_16BIT_MFMA_TFLOPS = 2516.6   # the 16-bit mode's issue v_mfma_f32_16x16x16_bf16
+PEAK_FP32_MFMA_TFLOPS = 157.3     # v_mfma_f32_16x16x4_f32 (side field only: no kernel of the step issues it for its dense layers)
+PEAK_16BIT_MFMA_TFLOPS = 2516.6   # v_mfma_f32_16x16x32_{f16,bf16}: the 16-bit mode issues one per product ...
+# ... and the fp32 mode three (fp16 planes forwards, bf16 hi / lo planes in the backward chains and contractions): the same
+# basis as bench.py's headline
+PEAK_F32_VIA_3_PLANE_PRODUCTS_TFLOPS = PEAK_16BIT_MFMA_TFLOPS / 3.0
 
 
 def parse(argv=None):
@@ -227,17 +230,23 @@ def run(a, dev, world=1, rank=0):
     vb_pts = a.rays * S * a.steps / max(vb["launches"], 1)
     vb_flop = 3.0 * VIEWT_FLOP_PER_POINT.get(a.views, 0) * vb_pts
     achieved = vb_flop / (vb_ms * 1e-3) / 1e12 if vb_ms > 0 else 0.0
-    peak = PEAK_16BIT_MFMA_TFLOPS if a.precision == "16bit" else PEAK_FP32_MFMA_TFLOPS
+    peak = PEAK_16BIT_MFMA_TFLOPS if a.precision == "16bit" else PEAK_F32_VIA_3_PLANE_PRODUCTS_TFLOPS
     traffic, traffic_src = None, None
     try:
         import glob
         pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_train_pmc.json")))[-1]
         tot = 0.0
+        # EVERY launch of the group: the training forward records the tape in two launches (coarse rows, new rows) per
+        # data-gradient launch
+        tape_per_group = prof.get("view_tape", dict(launches=0))["launches"] / max(vb["launches"], 1)
         for k, v in json.load(open(pj)).items():
             # the three kernels of the view transformer's backward (the TAPE instantiation has four template arguments)
-            if (("view_dgrad_kernel" in k or "view_wgrad_kernel" in k or ("view_transformer_kernel" in k and k.count(",") >= 3))
-                    and v.get("hbm_bytes_per_launch")):
+            if not v.get("hbm_bytes_per_launch"):
+                continue
+            if "view_dgrad_kernel" in k or "view_wgrad_kernel" in k:
                 tot += v["hbm_bytes_per_launch"]
+            elif "view_transformer_kernel" in k and k.count(",") >= 3:
+                tot += v["hbm_bytes_per_launch"] * max(tape_per_group, 1.0)
         if tot > 0 and a.precision == "fp32":     # the committed counter pass ran the fp32 mode (the 16-bit mode stores bf16 tiles)
             traffic, traffic_src = tot, os.path.relpath(pj, ROOT)
     except Exception:  # noqa: BLE001
@@ -274,12 +283,14 @@ def run(a, dev, world=1, rank=0):
         roofline=dict(bound="mfma", achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak, traffic=traffic,
                       traffic_source=traffic_src, kernel="view_transformer_kernel<TAPE> + view_dgrad_kernel + view_wgrad_kernel", avg_launch_ms=vb_ms, launches=vb["launches"],
                       algorithmic_flop_per_launch=vb_flop,
-                      peak_basis=("dense fp32 MFMA peak" if a.precision == "fp32" else "dense bf16 MFMA peak")
+                      peak_basis=("dense 16-bit MFMA peak / 3 plane products per fp32 product (the fp32 mode issues bf16 hi / lo "
+                                  "planes: the headline's basis)" if a.precision == "fp32" else "dense bf16 MFMA peak")
                                  + "; algorithmic flop = 3 x the forward view-transformer flop per point (recompute + data "
                                    "gradients + weight gradients); the three kernels are bound by the tile traffic between them "
                                    "(`traffic` bytes per launch group at `hbm_gbps`), not by the matrix cores",
                       hbm_gbps=(traffic / (vb_ms * 1e-3) / 1e9) if (traffic and vb_ms > 0) else None,
-                      frac_of_f16x3_peak=(achieved / (PEAK_16BIT_MFMA_TFLOPS / 3.0)) if a.precision == "fp32" else None))
+                      frac_of_fp32_mfma_peak=(achieved / PEAK_FP32_MFMA_TFLOPS) if a.precision == "fp32" else None,
+                      bwd_operand_dtype="bf16x3 (hi + lo planes, 16 significand bits per operand)" if a.precision == "fp32" else "bf16"))
     if not a.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(a, frame_cpu, weights_cpu)
     return line

@@ -441,6 +441,21 @@ int ufr_conv3d(const float* in, const float* weight, const float* weight2, const
                const float* bn_shift, const float* skip, float* out, float* out2, int32_t B, int32_t D, int32_t H,
                int32_t W, int32_t cin, int32_t cout, int32_t cout2, int32_t mode, int32_t relu, int32_t out_ncdhw,
                ufr_stream stream);
+/* Backward of the plain layers (bias, no BatchNorm / activation): CostRegNetWeight, i.e. `feature_volume.cost_reg_2` -- the
+ * one producer the reference trains (model.py:72-87; module.py:502-543).  B, D, H, W, cin, cout, mode describe the FORWARD
+ * layer (its input extent and channels); tensors are channel-last.
+ *   ufr_conv3d_bwd_data    d_in (B,D,H,W,cin) = adjoint of the layer applied to d_out (the layer's output extent, cout
+ *                          channels) [+ accumulate (same shape as d_in, nullable): a gradient that arrives on two paths,
+ *                          the U-Net's skip additions].  The forward kernel itself: mirrored taps for stride 1, the
+ *                          transposed / strided twin for the strided / transposed layers, all on the forward weight as it
+ *                          stands.  cin = 1: no `accumulate`.
+ *   ufr_conv3d_bwd_weight  d_weight (the reference's parameter layout: (cout,cin,3,3,3); transposed: (cin,cout,3,3,3)) +=
+ *                          sum over voxels of d_out x in per tap; d_bias (cout, nullable) += column sums of d_out.
+ *                          Both are ACCUMULATED into (zero them, or keep a running sum over frames). */
+int ufr_conv3d_bwd_data(const float* d_out, const float* weight, const float* accumulate, float* d_in, int32_t B, int32_t D,
+                        int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t mode, ufr_stream stream);
+int ufr_conv3d_bwd_weight(const float* in, const float* d_out, float* d_weight, float* d_bias, int32_t B, int32_t D, int32_t H,
+                          int32_t W, int32_t cin, int32_t cout, int32_t mode, ufr_stream stream);
 
 /* ---- TSDF fusion -------------------------------------------------------------------
  * Replaces the reference's `integrate` kernel (tsdf_fusion.py:77-152, a CUDA string compiled through pycuda) and the

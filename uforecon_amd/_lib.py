@@ -120,6 +120,8 @@ SIGNATURES = {
     "ufr_correlate_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "ufr_frustum_correlate": (C.c_int, [vp, vp, C.POINTER(C.c_float), vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
     "ufr_conv3d": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ufr_conv3d_bwd_data": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ufr_conv3d_bwd_weight": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ufr_tsdf_integrate": (C.c_int, [vp, vp, vp, C.POINTER(i32), C.POINTER(C.c_float), C.c_float, C.c_float,
                                      C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp, i32, i32, C.c_float, i32, vp]),
     "ufr_deform_conv2d_workspace_bytes": (sz, [i32, i32, i32, i32]),

@@ -38,6 +38,8 @@ struct Conv3dArgs {
   int Do, Ho, Wo;       // output extent
   int cout_real, cout2; // real output channels of weight / weight2
   int relu, ncdhw;
+  int flip;             // stride-1 only: `weight` is the layer's FORWARD weight [cin of this launch][cout_real][27] and the taps
+                        // are mirrored -- the data gradient of a stride-1 convolution (launch_conv3d_bwd_data)
 };
 
 // LDS weights: [tap in chunk][cin][COUT]
@@ -101,7 +103,8 @@ __global__ void __launch_bounds__(256) conv3d_kernel(Conv3dArgs a) {
       const int k = (tap_k(tz, nz, pz) * 3 + tap_k(ty, ny, py)) * 3 + tap_k(tx, nx, px);
       float w = 0.f;
       if (co < a.cout_real) {
-        w = MODE == kDeconvS2 ? a.weight[((size_t)ci * a.cout_real + co) * 27 + k] : a.weight[((size_t)co * CIN + ci) * 27 + k];
+        if (MODE == kConvS1 && a.flip) w = a.weight[((size_t)ci * a.cout_real + co) * 27 + (26 - k)];
+        else w = MODE == kDeconvS2 ? a.weight[((size_t)ci * a.cout_real + co) * 27 + k] : a.weight[((size_t)co * CIN + ci) * 27 + k];
       } else if (a.weight2 && co < a.cout_real + a.cout2) {
         w = a.weight2[((size_t)(co - a.cout_real) * CIN + ci) * 27 + k];
       }
@@ -204,8 +207,9 @@ hipError_t launch_conv_t(const Conv3dArgs& a, hipStream_t s) {
 // cout_pad: COUT of the instantiation (cout_real (+ cout2) rounded up to a multiple of 4)
 hipError_t launch_conv3d(const float* in, const float* weight, const float* weight2, const float* bias, const float* scale,
                          const float* shift, const float* skip, float* out, float* out2, int B, int D, int H, int W,
-                         int cin, int cout, int cout2, int mode, int relu, int ncdhw, hipStream_t s) {
+                         int cin, int cout, int cout2, int mode, int relu, int ncdhw, hipStream_t s, int flip) {
   Conv3dArgs a;
+  a.flip = flip;
   a.in = in; a.weight = weight; a.weight2 = weight2; a.bias = bias; a.scale = scale; a.shift = shift; a.skip = skip;
   a.out = out; a.out2 = out2; a.B = B; a.D = D; a.H = H; a.W = W;
   a.cout_real = cout; a.cout2 = cout2; a.relu = relu; a.ncdhw = ncdhw;
@@ -231,6 +235,252 @@ hipError_t launch_conv3d(const float* in, const float* weight, const float* weig
   UFR_CONV_CASE(8, 8, kConvS1, 2)       // features alone
 #undef UFR_CONV_CASE
   return hipErrorInvalidValue;
+}
+
+
+// =====================================================================================================================
+// Backward of the plain (bias, no activation) layers of CostRegNetWeight -- the one producer the reference trains
+// (model.py:72-87: every parameter outside `transmvsnet`; module.py:502-543).
+//
+// DATA gradients are the forward kernel again: the adjoint of a k3 p1 convolution is
+//   stride 1            -> the stride-1 convolution with the taps mirrored and the channel roles swapped (Conv3dArgs::flip),
+//   stride 2            -> the transposed stride-2 convolution, whose weight layout [in][out][27] IS the forward
+//                          weight [cout][cin][27] read with the roles swapped,
+//   transposed stride 2 -> the stride-2 convolution, likewise on the forward weight [cin][cout][27] as it stands;
+// and the U-Net's skip additions become the fused `skip` operand (a gradient that arrives on two paths).
+hipError_t launch_conv3d_bwd_data(const float* d_out, const float* weight, const float* accumulate, float* d_in, int B, int D,
+                                  int H, int W, int cin, int cout, int mode, hipStream_t s) {
+  if (mode == kConvS1) {    // d_out (B,D,H,W,cout) -> d_in (B,D,H,W,cin)
+    // a 1-channel d_in: the instantiation computes 4 padded channels, so it stores through the (B,C,D,H,W) path, which
+    // writes the real channels only -- the same bytes as (B,D,H,W,1); that path has no fused addition
+    if (cin == 1 && accumulate) return hipErrorInvalidValue;
+    return launch_conv3d(d_out, weight, nullptr, nullptr, nullptr, nullptr, accumulate, d_in, nullptr, B, D, H, W, cout, cin, 0,
+                         kConvS1, 0, cin == 1 ? 1 : 0, s, 1);
+  }
+  if (mode == kConvS2)      // d_out (B,D/2,H/2,W/2,cout) -> d_in (B,D,H,W,cin)
+    return launch_conv3d(d_out, weight, nullptr, nullptr, nullptr, nullptr, accumulate, d_in, nullptr, B, D / 2, H / 2, W / 2, cout,
+                         cin, 0, kDeconvS2, 0, 0, s, 0);
+  // transposed: d_out (B,2D,2H,2W,cout) -> d_in (B,D,H,W,cin)
+  return launch_conv3d(d_out, weight, nullptr, nullptr, nullptr, nullptr, accumulate, d_in, nullptr, B, 2 * D, 2 * H, 2 * W, cout, cin,
+                       0, kConvS2, 0, 0, s, 0);
+}
+
+// WEIGHT gradients.  One formulation for the three layer kinds: pairs of voxels (p, q = S p + k - 1) of a coarse grid P
+// and a fine grid Q (the same grid for stride 1), tensors TP [P][CA] and TQ [Q][CB], and
+//     dW[a][b][k] += sum_p TP[p][a] TQ[S p + k - 1][b]
+// with (TP, TQ) = (d_out, in) for the convolutions -- dW = [cout][cin][27] -- and (in, d_out) for the transposed one --
+// dW = [cin][cout][27]: the reference's parameter layout in both cases.  blockIdx.y = the tap k.
+struct WgradArgs {
+  const float* tp;   // [B][Dp][Hp][Wp][CA]
+  const float* tq;   // [B][Dq][Hq][Wq][CB]
+  float* dw;         // [CA][CB][27], accumulated into
+  int B, Dp, Hp, Wp, Dq, Hq, Wq;
+  long long n_p;     // B Dp Hp Wp
+  int vox_per_block;
+};
+
+namespace {
+
+__device__ __forceinline__ bool wgrad_q(const WgradArgs& a, long long n, int S, int kz, int ky, int kx, size_t* q) {
+  const int x = (int)(n % a.Wp);
+  long long m = n / a.Wp;
+  const int y = (int)(m % a.Hp);
+  m /= a.Hp;
+  const int z = (int)(m % a.Dp), b = (int)(m / a.Dp);
+  const int qz = z * S + kz - 1, qy = y * S + ky - 1, qx = x * S + kx - 1;
+  const bool ok = qz >= 0 && qz < a.Dq && qy >= 0 && qy < a.Hq && qx >= 0 && qx < a.Wq;
+  *q = ok ? (((size_t)b * a.Dq + qz) * a.Hq + qy) * a.Wq + qx : 0;
+  return ok;
+}
+
+// few channel pairs (CA CB <= 128: the full-resolution layers): one voxel per thread and step, the CA x CB products of a
+// tap in registers, one shuffle reduction and one atomic per value and wave at the end
+template <int CA, int CB, int S>
+__global__ void __launch_bounds__(256) conv3d_wgrad_voxel_kernel(WgradArgs a) {
+  const int k = blockIdx.y, kz = k / 9, ky = (k / 3) % 3, kx = k % 3;
+  float acc[CA][CB];
+#pragma unroll
+  for (int i = 0; i < CA; ++i)
+#pragma unroll
+    for (int j = 0; j < CB; ++j) acc[i][j] = 0.f;
+  const long long first = (long long)blockIdx.x * a.vox_per_block;
+  const long long last = first + a.vox_per_block < a.n_p ? first + a.vox_per_block : a.n_p;
+  for (long long n = first + threadIdx.x; n < last; n += 256) {
+    size_t q;
+    if (!wgrad_q(a, n, S, kz, ky, kx, &q)) continue;
+    float vp[CA], vq[CB];
+    const float* pp = a.tp + (size_t)n * CA;
+    const float* pq = a.tq + q * CB;
+    if constexpr (CA % 4 == 0) {
+#pragma unroll
+      for (int i = 0; i < CA / 4; ++i) { const f32x4 v = ld4(pp + 4 * i); vp[4 * i] = v[0]; vp[4 * i + 1] = v[1]; vp[4 * i + 2] = v[2]; vp[4 * i + 3] = v[3]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < CA; ++i) vp[i] = pp[i];
+    }
+    if constexpr (CB % 4 == 0) {
+#pragma unroll
+      for (int j = 0; j < CB / 4; ++j) { const f32x4 v = ld4(pq + 4 * j); vq[4 * j] = v[0]; vq[4 * j + 1] = v[1]; vq[4 * j + 2] = v[2]; vq[4 * j + 3] = v[3]; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < CB; ++j) vq[j] = pq[j];
+    }
+#pragma unroll
+    for (int i = 0; i < CA; ++i)
+#pragma unroll
+      for (int j = 0; j < CB; ++j) acc[i][j] = fmaf(vp[i], vq[j], acc[i][j]);
+  }
+#pragma unroll
+  for (int i = 0; i < CA; ++i)
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+      float v = acc[i][j];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(a.dw + ((size_t)i * CB + j) * 27 + k, v);
+    }
+}
+
+// many channel pairs: 16 x 16 threads, each owning a (CA / 16) x (CB / 16) register tile of the tap's CA x CB products;
+// 64 voxel pairs at a time are staged through LDS (coalesced loads, broadcast reads)
+template <int CA, int CB, int S>
+__global__ void __launch_bounds__(256) conv3d_wgrad_pair_kernel(WgradArgs a) {
+  constexpr int TA = CA / 16, TB = CB / 16, NV = 64;
+  __shared__ __attribute__((aligned(16))) float sp[NV][CA];
+  __shared__ __attribute__((aligned(16))) float sq[NV][CB];
+  const int k = blockIdx.y, kz = k / 9, ky = (k / 3) % 3, kx = k % 3;
+  const int ta = threadIdx.x >> 4, tb = threadIdx.x & 15;
+  float acc[TA][TB];
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j) acc[i][j] = 0.f;
+  const long long first = (long long)blockIdx.x * a.vox_per_block;
+  const long long last = first + a.vox_per_block < a.n_p ? first + a.vox_per_block : a.n_p;
+  for (long long n0 = first; n0 < last; n0 += NV) {
+    __syncthreads();
+    // stage: thread t loads float4 pieces; a voxel's row is CA / 4 (CB / 4) pieces
+    for (int i = threadIdx.x; i < NV * (CA / 4); i += 256) {
+      const int v = i / (CA / 4), c4 = i % (CA / 4);
+      const long long n = n0 + v;
+      f32x4 val = splat4(0.f);
+      if (n < last) val = ld4(a.tp + (size_t)n * CA + 4 * c4);
+      *reinterpret_cast<f32x4*>(&sp[v][4 * c4]) = val;
+    }
+    for (int i = threadIdx.x; i < NV * (CB / 4); i += 256) {
+      const int v = i / (CB / 4), c4 = i % (CB / 4);
+      const long long n = n0 + v;
+      f32x4 val = splat4(0.f);
+      size_t q;
+      if (n < last && wgrad_q(a, n, S, kz, ky, kx, &q)) val = ld4(a.tq + q * CB + 4 * c4);
+      *reinterpret_cast<f32x4*>(&sq[v][4 * c4]) = val;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int v = 0; v < NV; ++v) {
+      float vp[TA], vq[TB];
+#pragma unroll
+      for (int i = 0; i < TA; ++i) vp[i] = sp[v][ta + 16 * i];
+#pragma unroll
+      for (int j = 0; j < TB; ++j) vq[j] = sq[v][tb + 16 * j];
+#pragma unroll
+      for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) acc[i][j] = fmaf(vp[i], vq[j], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TB; ++j)
+      if (acc[i][j] != 0.f) atomicAdd(a.dw + ((size_t)(ta + 16 * i) * CB + (tb + 16 * j)) * 27 + k, acc[i][j]);
+}
+
+// bias gradient: column sums of d_out [N][C]
+template <int C>
+__global__ void __launch_bounds__(256) channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, long long N, int rows_per_block) {
+  float acc[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) acc[c] = 0.f;
+  const long long first = (long long)blockIdx.x * rows_per_block;
+  const long long last = first + rows_per_block < N ? first + rows_per_block : N;
+  for (long long n = first + threadIdx.x; n < last; n += 256) {
+    const float* p = x + (size_t)n * C;
+    if constexpr (C % 4 == 0) {
+#pragma unroll
+      for (int i = 0; i < C / 4; ++i) { const f32x4 v = ld4(p + 4 * i); acc[4 * i] += v[0]; acc[4 * i + 1] += v[1]; acc[4 * i + 2] += v[2]; acc[4 * i + 3] += v[3]; }
+    } else {
+#pragma unroll
+      for (int c = 0; c < C; ++c) acc[c] += p[c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    float v = acc[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(out + c, v);
+  }
+}
+
+template <int CA, int CB, int S>
+hipError_t launch_wgrad_t(WgradArgs a, hipStream_t s) {
+  // blocks: enough to fill the chip per tap, few enough that the closing atomics stay negligible
+  long long blocks = (a.n_p + 8191) / 8192;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  a.vox_per_block = (int)(((a.n_p + blocks - 1) / blocks + 63) / 64 * 64);
+  blocks = (a.n_p + a.vox_per_block - 1) / a.vox_per_block;
+  if constexpr (CA * CB <= 128)
+    hipLaunchKernelGGL((conv3d_wgrad_voxel_kernel<CA, CB, S>), dim3((unsigned)blocks, 27), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv3d_wgrad_pair_kernel<CA, CB, S>), dim3((unsigned)blocks, 27), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+// d_weight (reference layout) and d_bias (nullable) are ACCUMULATED into: the caller zeroes them (or keeps a running sum)
+hipError_t launch_conv3d_bwd_weight(const float* in, const float* d_out, float* d_weight, float* d_bias, int B, int D, int H, int W,
+                                    int cin, int cout, int mode, hipStream_t s) {
+  WgradArgs a;
+  a.dw = d_weight; a.B = B; a.vox_per_block = 0;
+  int ca, cb, S;
+  long long n_out;
+  if (mode == kConvS1) {
+    a.tp = d_out; a.tq = in; a.Dp = D; a.Hp = H; a.Wp = W; a.Dq = D; a.Hq = H; a.Wq = W; ca = cout; cb = cin; S = 1;
+    n_out = (long long)B * D * H * W;
+  } else if (mode == kConvS2) {
+    a.tp = d_out; a.tq = in; a.Dp = D / 2; a.Hp = H / 2; a.Wp = W / 2; a.Dq = D; a.Hq = H; a.Wq = W; ca = cout; cb = cin; S = 2;
+    n_out = (long long)B * (D / 2) * (H / 2) * (W / 2);
+  } else {
+    a.tp = in; a.tq = d_out; a.Dp = D; a.Hp = H; a.Wp = W; a.Dq = 2 * D; a.Hq = 2 * H; a.Wq = 2 * W; ca = cin; cb = cout; S = 2;
+    n_out = (long long)B * 8 * D * H * W;
+  }
+  a.n_p = (long long)B * a.Dp * a.Hp * a.Wp;
+  hipError_t e = hipErrorInvalidValue;
+#define UFR_WG_CASE(A_, B_, S_) if (ca == A_ && cb == B_ && S == S_) e = launch_wgrad_t<A_, B_, S_>(a, s);
+  UFR_WG_CASE(8, 1, 1)     // conv0
+  UFR_WG_CASE(16, 8, 2)    // conv1, conv11
+  UFR_WG_CASE(16, 16, 1)   // conv2
+  UFR_WG_CASE(32, 16, 2)   // conv3, conv9
+  UFR_WG_CASE(32, 32, 1)   // conv4
+  UFR_WG_CASE(64, 32, 2)   // conv5, conv7
+  UFR_WG_CASE(64, 64, 1)   // conv6
+  UFR_WG_CASE(8, 8, 1)     // features head
+  UFR_WG_CASE(1, 8, 1)     // weights head
+#undef UFR_WG_CASE
+  if (e != hipSuccess) return e;
+  if (d_bias) {
+    const int rows = 16384;
+    const long long blocks = (n_out + rows - 1) / rows;
+#define UFR_CS_CASE(C_) if (cout == C_) hipLaunchKernelGGL((channel_sum_kernel<C_>), dim3((unsigned)blocks), dim3(256), 0, s, d_out, d_bias, n_out, rows);
+    UFR_CS_CASE(1) UFR_CS_CASE(8) UFR_CS_CASE(16) UFR_CS_CASE(32) UFR_CS_CASE(64)
+#undef UFR_CS_CASE
+    if (cout != 1 && cout != 8 && cout != 16 && cout != 32 && cout != 64) return hipErrorInvalidValue;
+    e = hipGetLastError();
+  }
+  return e;
 }
 
 }  // namespace ufr

@@ -1116,6 +1116,39 @@ int ufr_conv3d(const float* in, const float* weight, const float* weight2, const
   return UFR_OK;
 }
 
+// backward of the plain layers (CostRegNetWeight: the producer the reference trains) -- conv3d.hip, second half
+int ufr_conv3d_bwd_data(const float* d_out, const float* weight, const float* accumulate, float* d_in, int32_t B, int32_t D,
+                        int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t mode, ufr_stream stream) {
+  UFR_REQUIRE(d_out && weight && d_in, "ufr_conv3d_bwd_data: null argument");
+  UFR_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "ufr_conv3d_bwd_data: B=%d D=%d H=%d W=%d", B, D, H, W);
+  UFR_REQUIRE(mode == UFR_CONV3D_S1 || mode == UFR_CONV3D_S2 || mode == UFR_CONV3D_T2, "ufr_conv3d_bwd_data: unknown mode %d", mode);
+  UFR_REQUIRE(mode != UFR_CONV3D_S2 || (D % 2 == 0 && H % 2 == 0 && W % 2 == 0), "ufr_conv3d_bwd_data: stride 2 needs even extents");
+  UFR_REQUIRE(cin == 1 || cin % 4 == 0, "ufr_conv3d_bwd_data: cin=%d", cin);
+  UFR_REQUIRE(!(cin == 1 && accumulate), "ufr_conv3d_bwd_data: no fused addition into a 1-channel gradient");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ProfScope p("conv3d_dgrad", s);
+  const hipError_t e = launch_conv3d_bwd_data(d_out, weight, accumulate, d_in, B, D, H, W, cin, cout, mode, s);
+  if (e == hipErrorInvalidValue)
+    return fail(UFR_ERR_ARG, "ufr_conv3d_bwd_data: (cin %d, cout %d, mode %d) is not a layer of CostRegNetWeight", cin, cout, mode);
+  UFR_HIP(e);
+  return UFR_OK;
+}
+
+int ufr_conv3d_bwd_weight(const float* in, const float* d_out, float* d_weight, float* d_bias, int32_t B, int32_t D, int32_t H,
+                          int32_t W, int32_t cin, int32_t cout, int32_t mode, ufr_stream stream) {
+  UFR_REQUIRE(in && d_out && d_weight, "ufr_conv3d_bwd_weight: null argument");
+  UFR_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "ufr_conv3d_bwd_weight: B=%d D=%d H=%d W=%d", B, D, H, W);
+  UFR_REQUIRE(mode == UFR_CONV3D_S1 || mode == UFR_CONV3D_S2 || mode == UFR_CONV3D_T2, "ufr_conv3d_bwd_weight: unknown mode %d", mode);
+  UFR_REQUIRE(mode != UFR_CONV3D_S2 || (D % 2 == 0 && H % 2 == 0 && W % 2 == 0), "ufr_conv3d_bwd_weight: stride 2 needs even extents");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ProfScope p("conv3d_wgrad", s);
+  const hipError_t e = launch_conv3d_bwd_weight(in, d_out, d_weight, d_bias, B, D, H, W, cin, cout, mode, s);
+  if (e == hipErrorInvalidValue)
+    return fail(UFR_ERR_ARG, "ufr_conv3d_bwd_weight: (cin %d, cout %d, mode %d) is not a layer of CostRegNetWeight", cin, cout, mode);
+  UFR_HIP(e);
+  return UFR_OK;
+}
+
 // ------------------------------------------------------------------ TSDF fusion
 int ufr_tsdf_integrate(float* tsdf, float* weight, float* color, const int32_t* dim, const float* origin,
                        float voxel_size, float trunc_margin, const float* cam_intr, const float* cam_pose,

@@ -132,7 +132,11 @@ hipError_t launch_deform_conv3x3(const float* in_cl, const float* offset, const 
                                  const float* bias, float* out, int B, int C, int Cout, int H, int W, hipStream_t s);
 hipError_t launch_conv3d(const float* in, const float* weight, const float* weight2, const float* bias, const float* scale,
                          const float* shift, const float* skip, float* out, float* out2, int B, int D, int H, int W,
-                         int cin, int cout, int cout2, int mode, int relu, int ncdhw, hipStream_t s);
+                         int cin, int cout, int cout2, int mode, int relu, int ncdhw, hipStream_t s, int flip = 0);
+hipError_t launch_conv3d_bwd_data(const float* d_out, const float* weight, const float* accumulate, float* d_in, int B, int D,
+                                  int H, int W, int cin, int cout, int mode, hipStream_t s);
+hipError_t launch_conv3d_bwd_weight(const float* in, const float* d_out, float* d_weight, float* d_bias, int B, int D, int H, int W,
+                                    int cin, int cout, int mode, hipStream_t s);
 hipError_t launch_chw_to_hwc(const float* in, float* out, int N, int C, int S, hipStream_t s);
 hipError_t launch_correlate(const float* ref_cl, const float* src_cl, const float* proj_host, int NS, const float* depth,
                             const float* vw, float* sim, float* agg, int C, int H, int W, int D, hipStream_t s);

@@ -724,3 +724,29 @@ def conv3d(x_cl: torch.Tensor, weight: torch.Tensor, mode: int = CONV3D_S1, bias
                                       _opt(out2, "out2"), B, D, H, W, cin, cout, cout2, int(mode), int(bool(relu)),
                                       int(bool(out_ncdhw)), _stream()), "ufr_conv3d")
     return (out, out2) if cout2 else out
+
+
+def conv3d_bwd_data(d_out_cl: torch.Tensor, weight: torch.Tensor, mode: int, in_shape, accumulate: Optional[torch.Tensor] = None):
+    """Data gradient of one plain 3x3x3 layer (ufr_conv3d_bwd_data): ``d_out_cl`` channel-last at the layer's output extent,
+    ``weight`` the layer's forward weight in the checkpoint's layout, ``in_shape`` = (B,D,H,W,cin) of the layer's input.
+    ``accumulate`` (same shape): added -- a gradient arriving on two paths (the U-Net's skip additions)."""
+    B, D, H, W, cin = in_shape
+    cout = d_out_cl.shape[-1]
+    d_in = torch.empty(in_shape, dtype=torch.float32, device=d_out_cl.device)
+    w = weight.detach().contiguous()
+    _lib.check(_lib.load().ufr_conv3d_bwd_data(_dev(d_out_cl, "d_out"), _dev(w, "weight"), _opt(accumulate, "accumulate"),
+                                               d_in.data_ptr(), B, D, H, W, cin, cout, int(mode), _stream()), "ufr_conv3d_bwd_data")
+    return d_in
+
+
+def conv3d_bwd_weight(x_cl: torch.Tensor, d_out_cl: torch.Tensor, mode: int, weight_shape, want_bias: bool = True):
+    """Weight (and bias) gradient of one plain 3x3x3 layer (ufr_conv3d_bwd_weight) -> (d_weight in the checkpoint's
+    layout, d_bias or None)."""
+    B, D, H, W, cin = x_cl.shape
+    cout = d_out_cl.shape[-1]
+    dw = torch.zeros(weight_shape, dtype=torch.float32, device=x_cl.device)
+    db = torch.zeros(cout, dtype=torch.float32, device=x_cl.device) if want_bias else None
+    _lib.check(_lib.load().ufr_conv3d_bwd_weight(_dev(x_cl, "in"), _dev(d_out_cl, "d_out"), dw.data_ptr(), _opt(db, "d_bias"),
+                                                 B, D, H, W, cin, cout, int(mode), _stream()), "ufr_conv3d_bwd_weight")
+    return dw, db
+

@@ -68,30 +68,87 @@ def _needs_grad(m, x: torch.Tensor) -> bool:
     return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in m.parameters()))
 
 
-def _cost_reg_net_weight_trainable(m, x: torch.Tensor):
-    """The same network through the module's own layers (library convolutions on the GPU): differentiable, which the
-    forward-only `ufr_conv3d` plan is not.  `feature_volume.cost_reg_2` is the one producer the reference trains
-    (model.py:75-83: everything but `transmvsnet.*`); its gradients arrive through the frustum scatter of
-    `ufr_project_gather_bwd`, so this path must keep the autograd graph (module.py:530-543)."""
-    if not x.is_cuda:
-        raise UfrError("the frustum U-Nets run on the GPU only (no CPU implementation)")
-    c0 = m.conv0(x)
-    c2 = m.conv2(m.conv1(c0))
-    c4 = m.conv4(m.conv3(c2))
-    y = m.conv6(m.conv5(c4))
-    y = c4 + m.conv7(y)
-    y = c2 + m.conv9(y)
-    y = c0 + m.conv11(y)
-    return m.features(y), torch.sigmoid(m.weights(y))
+# the layers of CostRegNetWeight in execution order: (name, mode, skip source or None)
+_LAYERS = (("conv0", S1), ("conv1", S2), ("conv2", S1), ("conv3", S2), ("conv4", S1), ("conv5", S2), ("conv6", S1),
+           ("conv7", T2), ("conv9", T2), ("conv11", T2))
+# ... their parameters, then the two bias-free heads
+_PARAM_NAMES = tuple(f"{n}.{k}" for n, _ in _LAYERS for k in ("weight", "bias")) + ("features.weight", "weights.weight")
+
+
+class CostRegNetWeightFn(torch.autograd.Function):
+    """CostRegNetWeight.forward (module.py:530-543) with its adjoint on the HIP kernels: `feature_volume.cost_reg_2` is the
+    one producer the reference trains (model.py:72-87); its gradients arrive through the frustum scatter of
+    ufr_project_gather_bwd as d feature_volume / d weight_volume.  ``apply(x, *parameters in _PARAM_NAMES order)`` ->
+    ``(features (B,8,D,H,W), sigmoid(weights) (B,1,D,H,W))``.
+    Forward = the inference plan, keeping every layer's input; backward = per layer ufr_conv3d_bwd_data (the forward kernel
+    on the same weights: mirrored taps / the strided-transposed twin) and ufr_conv3d_bwd_weight, the skip additions riding
+    in the data-gradient launches as fused accumulations."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        P = dict(zip(_PARAM_NAMES, params))
+        x_cl = _input_cl(x)
+        acts = {"x": x_cl}
+
+        def layer(name, t, mode, skip):
+            acts["in." + name] = t
+            return ops.conv3d(t, P[name + ".weight"], mode, bias=P[name + ".bias"], skip=skip)
+
+        y = _unet(x_cl, layer)
+        feat, wsig = ops.conv3d(y, P["features.weight"], S1, out_ncdhw=True, weight2=P["weights.weight"])
+        ctx.acts, ctx.y, ctx.params = acts, y, params
+        ctx.save_for_backward(wsig)
+        ctx.x_needs_grad = x.requires_grad
+        return feat, wsig
+
+    @staticmethod
+    def backward(ctx, d_feat, d_wsig):
+        (wsig,) = ctx.saved_tensors
+        P = dict(zip(_PARAM_NAMES, ctx.params))
+        acts, y = ctx.acts, ctx.y
+        B, D, H, W, _ = y.shape
+        grads = {}
+        cl = lambda t: t.permute(0, 2, 3, 4, 1).contiguous()       # (B,C,D,H,W) -> channel-last
+        zeros = lambda c: torch.zeros(B, D, H, W, c, dtype=torch.float32, device=y.device)
+        d_f = cl(d_feat.float()) if d_feat is not None else zeros(8)
+        # sigmoid'(z) = s (1 - s)
+        d_w = cl((d_wsig.float() * wsig * (1.0 - wsig))) if d_wsig is not None else zeros(1)
+        grads["features.weight"] = ops.conv3d_bwd_weight(y, d_f, S1, P["features.weight"].shape, want_bias=False)[0]
+        grads["weights.weight"] = ops.conv3d_bwd_weight(y, d_w, S1, P["weights.weight"].shape, want_bias=False)[0]
+        d_y = ops.conv3d_bwd_data(d_f, P["features.weight"], S1, tuple(y.shape))
+        d_y = ops.conv3d_bwd_data(d_w, P["weights.weight"], S1, tuple(y.shape), accumulate=d_y)
+
+        def back(name, mode, d_out, accumulate=None, need_data=True):
+            t = acts["in." + name]
+            grads[name + ".weight"], grads[name + ".bias"] = ops.conv3d_bwd_weight(t, d_out, mode, P[name + ".weight"].shape)
+            return ops.conv3d_bwd_data(d_out, P[name + ".weight"], mode, tuple(t.shape), accumulate=accumulate) if need_data else None
+
+        # y = c0 + conv11(x9), x9 = c2 + conv9(x7), x7 = c4 + conv7(x6), x6 = conv6(conv5(c4)), c4 = conv4(conv3(c2)), ...
+        d_x9 = back("conv11", T2, d_y)
+        d_x7 = back("conv9", T2, d_x9)
+        d_x6 = back("conv7", T2, d_x7)
+        d_x5 = back("conv6", S1, d_x6)
+        d_c4 = back("conv5", S2, d_x5, accumulate=d_x7)          # c4 feeds conv5 and the skip into x7
+        d_x3 = back("conv4", S1, d_c4)
+        d_c2 = back("conv3", S2, d_x3, accumulate=d_x9)          # c2 feeds conv3 and the skip into x9
+        d_x1 = back("conv2", S1, d_c2)
+        d_c0 = back("conv1", S2, d_x1, accumulate=d_y)           # c0 feeds conv1 and the skip into y
+        d_x = back("conv0", S1, d_c0, need_data=ctx.x_needs_grad)
+        if d_x is not None:
+            d_x = d_x.view(B, D, H, W, 1).permute(0, 4, 1, 2, 3)
+        need = ctx.needs_input_grad[1:]
+        return (d_x, *[(grads[n].reshape(p.shape) if nd else None) for n, p, nd in zip(_PARAM_NAMES, ctx.params, need)])
 
 
 def cost_reg_net_weight(m, x: torch.Tensor):
     """(B,1,D,H,W) cost volume -> feature frustum (B,8,D,H,W), weight frustum (B,1,D,H,W) = sigmoid.  Plain convolutions with
     bias, no activation between them (as upstream); the two heads share one pass over the last feature map.
-    When a gradient is wanted (grad mode on and the input or a parameter requires grad) the differentiable
-    library-convolution expression runs instead: the HIP plan is forward-only and would silently cut the graph."""
+    With a gradient wanted (grad mode on and the input or a parameter requires grad) the same kernels run under
+    CostRegNetWeightFn, whose backward is ufr_conv3d_bwd_data / ufr_conv3d_bwd_weight: one implementation, no library
+    convolutions in either direction."""
     if _needs_grad(m, x):
-        return _cost_reg_net_weight_trainable(m, x)
+        sd = dict(m.named_parameters())
+        return CostRegNetWeightFn.apply(x, *[sd[n] for n in _PARAM_NAMES])
     with torch.no_grad():
         return _cost_reg_net_weight_hip(m, x)
 

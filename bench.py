@@ -453,6 +453,10 @@ def secondary_measurements(a, dev):
         ta = bench_train.parse(["--steps", str(a.secondary_train_steps), "--warmup", "3", "--precision", prec, "--no-cpu-baseline"])
         sec[f"configs[4]_{prec}"] = bench_train.run(ta, dev, 1, 0)
         torch.cuda.empty_cache()
+    # ... and the step with the producer the reference trains in front of it (feature_volume.cost_reg_2 on ufr_conv3d / _bwd)
+    ta = bench_train.parse(["--steps", "3", "--warmup", "1", "--precision", "fp32", "--no-cpu-baseline", "--cost-reg"])
+    sec["configs[4]+cost_reg_2"] = bench_train.run(ta, dev, 1, 0)
+    torch.cuda.empty_cache()
     if full and not a.no_cpu_baseline:
         base = bench_train.cpu_baseline_standalone(bench_train.parse([]))
         sec["configs[4]_fp32"]["cpu_baseline"] = base
@@ -520,7 +524,7 @@ def digest(line):
     c2 = sec.get("configs[2]@1gpu")
     if c2:
         d["configs[2]@1gpu"] = dict(frame_ms_inclusive=round(c2["ms_per_step"], 1), encode_frame_ms=round(c2["config"]["encode_frame_ms"], 1))
-    for k in ("configs[4]_fp32", "configs[4]_16bit"):
+    for k in ("configs[4]_fp32", "configs[4]_16bit", "configs[4]+cost_reg_2"):
         if sec.get(k):
             d[k] = dict(step_ms=round(sec[k]["ms_per_step"], 2), frac=round(sec[k]["roofline"]["frac"], 3))
     if sec.get("encode_frame"):

@@ -363,9 +363,65 @@ def run_grad_case(name, c, weight_seed=0, sampler_seed=1):
     print(f"{name}: loss {float(loss):.6f}, {len(out)} arrays, {os.path.getsize(os.path.join(HERE, name + '.npz')) / 1e6:.2f} MB")
 
 
+COSTREG_CASES = {
+    # the training step WITH the one producer the reference trains in front of it (model.py:72-87, 517-524): seeded cost
+    # volumes -> MVSVolume (cost_reg_2) -> frustums -> infer -> loss; gradients of feature_volume.cost_reg_2.*
+    "c5_train_grads_costreg": dict(H=64, W=96, NV=3, seed=5, RN=64, coarse=64, fine=64, costreg_seed=31),
+}
+COSTREG_SAMPLE = 4096     # tensors beyond 20 000 elements are stored as a strided sample + their sum and squared norm
+
+
+def costreg_sample_index(n):
+    return torch.arange(n) if n <= 20_000 else (torch.arange(COSTREG_SAMPLE) * (n // COSTREG_SAMPLE))
+
+
+def run_costreg_grad_case(name, c, weight_seed=0, sampler_seed=1):
+    from uforecon_amd.scene import fill_state_dict, make_cost_volumes
+
+    model = build_reference_model(weight_seed, test_sample_coarse=c["coarse"], test_sample_fine=c["fine"],
+                                  coarse_sample=c["coarse"], fine_sample=c["fine"], test_n_view=c["NV"],
+                                  extract_geometry=False)
+    model.train()
+    fill_state_dict(model.feature_volume, c["costreg_seed"])
+    fr = make_frame(c["H"], c["W"], c["NV"], c["seed"], train_layout=True)
+    cost = make_cost_volumes(c["H"], c["W"], c["NV"], c["seed"])
+
+    def build():
+        vols = {}
+        for st in ("stage1", "stage2", "stage3"):
+            f, w = model.feature_volume(fr.batch, cost[st])                      # model.py:517-519: build_mvs_volume
+            vols[st] = {"feature_volume": f, "weight_volume": w}
+        return vols
+
+    with torch.no_grad():
+        fr.feature_volume = build()
+    idx = clean_ray_indices(model, fr, c["H"], c["W"], c["RN"], sampler_seed, True, relu_margin=5e-6)
+    fr.feature_volume = build()
+    torch.manual_seed(sampler_seed)
+    r = model.infer(batch=fr.batch, ray_idx=idx, source_imgs_feat=fr.source_imgs_feat,
+                    feature_volume=fr.feature_volume, match_feature=fr.match_feature)
+    loss = training_loss(r, fr.batch)
+    loss.backward()
+    out = {"ray_idx": idx.numpy(), "sampler_seed": np.int64(sampler_seed), "weight_seed": np.int64(weight_seed),
+           "costreg_seed": np.int64(c["costreg_seed"]), "loss": loss.detach().numpy()}
+    for k, p in model.named_parameters():
+        if k.startswith("feature_volume.cost_reg_2."):
+            assert p.grad is not None, k
+            g = p.grad.reshape(-1)
+            out["grad." + k] = g[costreg_sample_index(g.numel())].numpy()
+            out["gsum." + k] = np.float64(g.double().sum())
+            out["gsq." + k] = np.float64((g.double() ** 2).sum())
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    print(f"{name}: loss {float(loss):.6f}, {len(out)} arrays, {os.path.getsize(os.path.join(HERE, name + '.npz')) / 1e6:.2f} MB")
+
+
 def main():
     model = None
     only = sys.argv[1:]
+    for name, c in COSTREG_CASES.items():
+        if only and name not in only:
+            continue
+        run_costreg_grad_case(name, c)
     for name, c in GRAD_CASES.items():
         if only and name not in only:
             continue

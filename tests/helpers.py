@@ -34,7 +34,12 @@ GRAD_CASES = {
     "c5_train_grads": dict(H=64, W=96, NV=3, seed=5, RN=64, coarse=64, fine=64, train=True),
     "c5_train_grads_nv4": dict(H=32, W=48, NV=4, seed=6, RN=24, coarse=32, fine=32, train=True),
 }
+# same table as tests/golden/make_golden.py:COSTREG_CASES (the training step with `feature_volume.cost_reg_2` in front)
+COSTREG_CASES = {
+    "c5_train_grads_costreg": dict(H=64, W=96, NV=3, seed=5, RN=64, coarse=64, fine=64, train=True, costreg_seed=31),
+}
 CASES.update(GRAD_CASES)
+CASES.update(COSTREG_CASES)
 VOLUME_KEYS = [f"{st}.{k}" for st in ("stage1", "stage2", "stage3") for k in ("feature_volume", "weight_volume")]
 
 # north_star tolerance: per-pixel depth and RGB within 1e-4 relative of the reference.

@@ -84,3 +84,59 @@ def test_cost_reg_net_weight_gradients_match_autograd_of_the_reference_expressio
     with torch.no_grad():
         f3, w3 = m(x)
     assert f3.grad_fn is None and torch.equal(f3, f2.detach()) and torch.equal(w3, w2.detach())
+
+
+def test_cost_reg_2_gradients_match_the_references_autograd():
+    """The training step with the one producer the reference trains in front of it (model.py:72-87, 517-524): seeded cost
+    volumes -> MVSVolume (cost_reg_2) -> frustums -> infer -> loss.  Gradients of every `feature_volume.cost_reg_2.*`
+    parameter against the REFERENCE's own autograd (tests/golden/make_golden.py:run_costreg_grad_case ran the reference's
+    MVSVolume and infer): they pass through ufr_project_gather_bwd (frustum scatter) and ufr_conv3d_bwd_*."""
+    import argparse
+    import os
+    import sys
+
+    import numpy as np
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import CASES, case_frame, load_golden, load_weights
+    from test_gpu_backward import _args, _loss_from_tuple
+    from uforecon_amd import model as M
+    from uforecon_amd.scene import fill_state_dict, make_cost_volumes, sampler_uniforms
+
+    name = "c5_train_grads_costreg"
+    c, g = CASES[name], load_golden(name)
+    fr = case_frame(name)
+    f = fr.to(DEV)
+    mvs = cascade.MVSVolume(1, 8)
+    fill_state_dict(mvs, c["costreg_seed"])
+    mvs = mvs.to(DEV).train()
+    m = M.UFORecon(_args(c)).to(DEV)
+    m.load_state_dict(load_weights(), strict=True)
+    m.train()
+    cost = {st: v.to(DEV) for st, v in make_cost_volumes(c["H"], c["W"], c["NV"], c["seed"]).items()}
+    vols = {}
+    for st in ("stage1", "stage2", "stage3"):
+        feat, w = mvs(f.batch, cost[st])
+        vols[st] = {"feature_volume": feat, "weight_volume": w}
+    idx = torch.from_numpy(g["ray_idx"]).to(DEV)
+    U1, U2 = sampler_uniforms(int(g["sampler_seed"]), c["coarse"], c["fine"], c["RN"])
+    r = m.infer(f.batch, idx, f.source_imgs_feat, vols, match_feature=f.match_feature, uniforms=(U1, U2))
+    loss = _loss_from_tuple(r, f.batch, idx)
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    loss.backward()
+    worst = {}
+    for k, p in mvs.named_parameters():
+        key = "feature_volume." + k
+        got = p.grad.reshape(-1).double().cpu()
+        n = got.numel()
+        sel = torch.arange(n) if n <= 20_000 else torch.arange(4096) * (n // 4096)          # make_golden.costreg_sample_index
+        want = torch.from_numpy(g["grad." + key]).double()
+        scale = max(float(np.sqrt(float(g["gsq." + key]) / n)) * 10, float(want.abs().max()), 1e-12)
+        worst[k] = float((got[sel] - want).abs().max()) / scale
+        # the whole tensor, through its stored sum and squared norm
+        assert abs(float(got.sum()) - float(g["gsum." + key])) < 1e-3 * (abs(float(g["gsum." + key])) + scale * n ** 0.5), k
+        assert abs(float((got ** 2).sum()) - float(g["gsq." + key])) < 1e-3 * float(g["gsq." + key]) + 1e-30, k
+    bad = {k: e for k, e in worst.items() if not e < 1e-3}
+    print("cost_reg_2 gradients vs the reference's autograd, worst of each tensor:", max(worst.values()), max(worst, key=worst.get))
+    assert not bad, bad
+

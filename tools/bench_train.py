@@ -53,6 +53,10 @@ def parse(argv=None):
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--precision", choices=("fp32", "16bit"), default="fp32",
                     help="16bit: UFR_PRECISION_16BIT, the mixed-precision mode BASELINE configs[4] names")
+    ap.add_argument("--cost-reg", action="store_true",
+                    help="the step WITH the one producer the reference trains in front of the ray path (model.py:72-87, 517-524): "
+                         "seeded cost volumes -> MVSVolume (feature_volume.cost_reg_2, ufr_conv3d) -> frustums -> infer -> loss -> "
+                         "backward through ufr_project_gather_bwd and ufr_conv3d_bwd_* -> Adam over both parameter sets")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=64)
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -130,13 +134,24 @@ def run(a, dev, world=1, rank=0):
     weights_cpu = {k: torch.from_numpy(wz[k]) for k in wz.files}
     m = M.UFORecon(args, precision=precision).to(dev).train()     # the mode travels with the model, not with the process
     m.load_state_dict(weights_cpu, strict=True)
-    opt = torch.optim.Adam(m.parameters(), lr=1e-4)                       # model.py:72-87 (uforecon_lr)
     drank = rank if a.data_rank < 0 else a.data_rank
     frame_cpu = make_frame(a.height, a.width, a.views, seed=drank, train_layout=True)
     f = frame_cpu.to(dev)
-    vols = [f.feature_volume[st][k] for st in f.feature_volume for k in f.feature_volume[st]]
-    for v in vols:
-        v.requires_grad_(True)
+    mvs, cost = None, None
+    if a.cost_reg:
+        from uforecon_amd import cascade
+        from uforecon_amd.scene import fill_state_dict, make_cost_volumes
+
+        mvs = cascade.MVSVolume(1, 8)
+        fill_state_dict(mvs, 31)
+        mvs = mvs.to(dev).train()
+        cost = {st: v.to(dev) for st, v in make_cost_volumes(a.height, a.width, a.views, drank).items()}
+        vols = []
+    else:
+        vols = [f.feature_volume[st][k] for st in f.feature_volume for k in f.feature_volume[st]]
+        for v in vols:
+            v.requires_grad_(True)
+    opt = torch.optim.Adam(list(m.parameters()) + (list(mvs.parameters()) if mvs is not None else []), lr=1e-4)   # model.py:72-87
     HW = a.height * a.width
     gen = torch.Generator(device=dev).manual_seed(100 + drank if a.fixed_seed < 0 else a.fixed_seed * 1000 + drank)
     ar_events = []
@@ -148,7 +163,13 @@ def run(a, dev, world=1, rank=0):
         for v in vols:
             v.grad = None
         opt.zero_grad(set_to_none=True)
-        r = m.infer(f.batch, idx, f.source_imgs_feat, f.feature_volume, match_feature=f.match_feature, uniforms=(U1, U2))
+        fv = f.feature_volume
+        if mvs is not None:      # model.py:517-524: the three stages' frustums from the trainable U-Net
+            fv = {}
+            for st in ("stage1", "stage2", "stage3"):
+                vf, vw = mvs(f.batch, cost[st])
+                fv[st] = {"feature_volume": vf, "weight_volume": vw}
+        r = m.infer(f.batch, idx, f.source_imgs_feat, fv, match_feature=f.match_feature, uniforms=(U1, U2))
         rgb_gt, rgb, depth, depth_gt, rgb2, depth2 = r[0], r[1], r[2], r[3], r[8], r[9]
         nf = f.batch["near_fars"]
         mask = (depth_gt != 0) & (depth_gt >= nf[:, 0, 0:1]) & (depth_gt <= nf[:, 0, 1:2])
@@ -164,7 +185,7 @@ def run(a, dev, world=1, rank=0):
             # the per-ray parameters; the volumes are per-rank frames (every rank trains on its own scene), so their
             # gradients stay local -- in the real pipeline they flow on into feature_volume.cost_reg_2.*, whose own
             # gradients would join this bucket
-            allreduce_gradients(list(m.parameters()), world)
+            allreduce_gradients(list(m.parameters()) + (list(mvs.parameters()) if mvs is not None else []), world)
             e1.record()
             ar_events.append((e0, e1))
         if a.dump_grads:
@@ -258,7 +279,10 @@ def run(a, dev, world=1, rank=0):
         dtype="f32" if a.precision == "fp32" else "bf16", data="synthetic",
         config=dict(workload=f"configs[4]: {a.views} source views + GT view, {a.rays} random rays per rank of a "
                              f"{a.height}x{a.width} frame, {a.coarse}+{a.fine} samples ({pts} point evaluations per rank and "
-                             f"step), frustum gradients on, Adam step included",
+                             f"step), frustum gradients on, Adam step included"
+                             + (" -- WITH feature_volume.cost_reg_2 (the 3-D U-Net the reference trains, module.py:502-543) in "
+                                "front: three stages' frustums rebuilt from seeded cost volumes every step (ufr_conv3d), its "
+                                "backward through ufr_conv3d_bwd_data / ufr_conv3d_bwd_weight" if a.cost_reg else ""),
                     arithmetic=("fp32 mode: forward dense layers as three fp16 plane products (fp32-grade); backward data-gradient "
                                 "chains and weight-gradient contractions as three bf16 plane products (16 significand bits per "
                                 "operand, fp32 accumulate; every gradient tensor within 3e-5 of the reference's autograd)"

@@ -281,71 +281,107 @@ struct WgradArgs {
 
 namespace {
 
-__device__ __forceinline__ bool wgrad_q(const WgradArgs& a, long long n, int S, int kz, int ky, int kx, size_t* q) {
-  const int x = (int)(n % a.Wp);
-  long long m = n / a.Wp;
-  const int y = (int)(m % a.Hp);
-  m /= a.Hp;
-  const int z = (int)(m % a.Dp), b = (int)(m / a.Dp);
+// (32-bit voxel indices: the launcher bounds n_p below 2^31 -- a 64-bit division per voxel and tap was most of these kernels' time)
+__device__ __forceinline__ bool wgrad_q(const WgradArgs& a, unsigned n, int S, int kz, int ky, int kx, size_t* q) {
+  const int x = (int)(n % (unsigned)a.Wp);
+  unsigned m = n / (unsigned)a.Wp;
+  const int y = (int)(m % (unsigned)a.Hp);
+  m /= (unsigned)a.Hp;
+  const int z = (int)(m % (unsigned)a.Dp), b = (int)(m / (unsigned)a.Dp);
   const int qz = z * S + kz - 1, qy = y * S + ky - 1, qx = x * S + kx - 1;
   const bool ok = qz >= 0 && qz < a.Dq && qy >= 0 && qy < a.Hq && qx >= 0 && qx < a.Wq;
   *q = ok ? (((size_t)b * a.Dq + qz) * a.Hq + qy) * a.Wq + qx : 0;
   return ok;
 }
 
-// few channel pairs (CA CB <= 128: the full-resolution layers): one voxel per thread and step, the CA x CB products of a
-// tap in registers, one shuffle reduction and one atomic per value and wave at the end
-template <int CA, int CB, int S>
-__global__ void __launch_bounds__(256) conv3d_wgrad_voxel_kernel(WgradArgs a) {
-  const int k = blockIdx.y, kz = k / 9, ky = (k / 3) % 3, kx = k % 3;
-  float acc[CA][CB];
+// few channels (CB <= 8 on the fine side: the full-resolution layers, where the traffic is): a thread takes one voxel p per
+// step, a group of CAG coarse-side channels (blockIdx.y) and a run of NT consecutive taps (blockIdx.z), reads TP[p] once and
+// the NT neighbours TQ[S p + k - 1] through the L1, and keeps the NT x CAG x CB products in registers (<= 192: two to four
+// waves per SIMD); one shuffle reduction and one atomic per value and wave at the end.
+// What bounds it is the L1: a wave's tap visit moves 64 x 4 CB bytes at 64 B/clk, so every fetched neighbour must meet as
+// many coarse-side channels as the registers allow.  Measured at 3 x 8 x 512 x 640 voxels, features head (8 x 8 channels):
+// one channel per thread and nine taps per pass (24 passes over TQ) 4.0 ms; all 27 taps per thread (446 registers, one
+// wave per SIMD) worse still; one block per TAP streaming both tensors 27 times: 30 ms per training step for all layers.
+template <int CAG, int CB, int NT, int S>
+__global__ void __launch_bounds__(256) conv3d_wgrad_voxel_kernel(WgradArgs a, int CA) {
+  static_assert(NT * CAG * CB <= 192 && 27 % NT == 0, "accumulators per thread");
+  const int a0 = blockIdx.y * CAG, k0 = blockIdx.z * NT;
+  float acc[NT][CAG][CB];
 #pragma unroll
-  for (int i = 0; i < CA; ++i)
+  for (int k = 0; k < NT; ++k)
 #pragma unroll
-    for (int j = 0; j < CB; ++j) acc[i][j] = 0.f;
-  const long long first = (long long)blockIdx.x * a.vox_per_block;
-  const long long last = first + a.vox_per_block < a.n_p ? first + a.vox_per_block : a.n_p;
-  for (long long n = first + threadIdx.x; n < last; n += 256) {
-    size_t q;
-    if (!wgrad_q(a, n, S, kz, ky, kx, &q)) continue;
-    float vp[CA], vq[CB];
-    const float* pp = a.tp + (size_t)n * CA;
-    const float* pq = a.tq + q * CB;
-    if constexpr (CA % 4 == 0) {
+    for (int i = 0; i < CAG; ++i)
 #pragma unroll
-      for (int i = 0; i < CA / 4; ++i) { const f32x4 v = ld4(pp + 4 * i); vp[4 * i] = v[0]; vp[4 * i + 1] = v[1]; vp[4 * i + 2] = v[2]; vp[4 * i + 3] = v[3]; }
+      for (int j = 0; j < CB; ++j) acc[k][i][j] = 0.f;
+  const unsigned first = blockIdx.x * (unsigned)a.vox_per_block;
+  const unsigned last = first + a.vox_per_block < (unsigned)a.n_p ? first + a.vox_per_block : (unsigned)a.n_p;
+  for (unsigned n = first + threadIdx.x; n < last; n += 256) {
+    const int x = (int)(n % (unsigned)a.Wp);
+    unsigned m = n / (unsigned)a.Wp;
+    const int y = (int)(m % (unsigned)a.Hp);
+    m /= (unsigned)a.Hp;
+    const int z = (int)(m % (unsigned)a.Dp), b = (int)(m / (unsigned)a.Dp);
+    float vp[CAG];
+    const float* pp = a.tp + (size_t)n * CA + a0;
+    if constexpr (CAG % 4 == 0) {
+#pragma unroll
+      for (int i = 0; i < CAG / 4; ++i) { const f32x4 v = ld4(pp + 4 * i); vp[4 * i] = v[0]; vp[4 * i + 1] = v[1]; vp[4 * i + 2] = v[2]; vp[4 * i + 3] = v[3]; }
     } else {
 #pragma unroll
-      for (int i = 0; i < CA; ++i) vp[i] = pp[i];
-    }
-    if constexpr (CB % 4 == 0) {
-#pragma unroll
-      for (int j = 0; j < CB / 4; ++j) { const f32x4 v = ld4(pq + 4 * j); vq[4 * j] = v[0]; vq[4 * j + 1] = v[1]; vq[4 * j + 2] = v[2]; vq[4 * j + 3] = v[3]; }
-    } else {
-#pragma unroll
-      for (int j = 0; j < CB; ++j) vq[j] = pq[j];
+      for (int i = 0; i < CAG; ++i) vp[i] = pp[i];
     }
 #pragma unroll
-    for (int i = 0; i < CA; ++i)
+    for (int t = 0; t < NT; ++t) {
+      const int k = k0 + t;
+      const int qz = z * S + k / 9 - 1, qy = y * S + (k / 3) % 3 - 1, qx = x * S + k % 3 - 1;
+      const bool ok = qz >= 0 && qz < a.Dq && qy >= 0 && qy < a.Hq && qx >= 0 && qx < a.Wq;
+      const float* pq = a.tq + ((((size_t)b * a.Dq + (ok ? qz : 0)) * a.Hq + (ok ? qy : 0)) * a.Wq + (ok ? qx : 0)) * CB;
+      float vq[CB];
+      if constexpr (CB % 4 == 0) {
 #pragma unroll
-      for (int j = 0; j < CB; ++j) acc[i][j] = fmaf(vp[i], vq[j], acc[i][j]);
+        for (int j = 0; j < CB / 4; ++j) {
+          f32x4 v = ld4(pq + 4 * j);
+          if (!ok) v = splat4(0.f);
+          vq[4 * j] = v[0]; vq[4 * j + 1] = v[1]; vq[4 * j + 2] = v[2]; vq[4 * j + 3] = v[3];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < CB; ++j) vq[j] = ok ? pq[j] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < CAG; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j) acc[t][i][j] = fmaf(vp[i], vq[j], acc[t][i][j]);
+    }
   }
+  // wave sums -> LDS -> ONE atomic per value and block: atomics on one address serialise in the L2 (a few hundred ns each),
+  // and with an atomic per wave the few hundred addresses of a small layer took most of the kernel's time
+  __shared__ float red[4][NT * CAG * CB];
 #pragma unroll
-  for (int i = 0; i < CA; ++i)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int j = 0; j < CB; ++j) {
-      float v = acc[i][j];
+    for (int i = 0; i < CAG; ++i)
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-      if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(a.dw + ((size_t)i * CB + j) * 27 + k, v);
-    }
+      for (int j = 0; j < CB; ++j) {
+        float v = acc[t][i][j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][(t * CAG + i) * CB + j] = v;
+      }
+  __syncthreads();
+  for (int e = threadIdx.x; e < NT * CAG * CB; e += 256) {
+    const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    const int j = e % CB, i = (e / CB) % CAG, t = e / (CB * CAG);
+    if (v != 0.f) atomicAdd(a.dw + ((size_t)(a0 + i) * CB + j) * 27 + k0 + t, v);
+  }
 }
 
 // many channel pairs: 16 x 16 threads, each owning a (CA / 16) x (CB / 16) register tile of the tap's CA x CB products;
 // 64 voxel pairs at a time are staged through LDS (coalesced loads, broadcast reads)
 template <int CA, int CB, int S>
 __global__ void __launch_bounds__(256) conv3d_wgrad_pair_kernel(WgradArgs a) {
-  constexpr int TA = CA / 16, TB = CB / 16, NV = 64;
+  // voxel pairs per LDS stage: as many as 32 KiB hold (several 16-byte loads per thread in flight per stage)
+  constexpr int TA = CA / 16, TB = CB / 16, NV = (CA + CB) <= 32 ? 256 : (CA + CB) <= 64 ? 128 : 64;
   __shared__ __attribute__((aligned(16))) float sp[NV][CA];
   __shared__ __attribute__((aligned(16))) float sq[NV][CB];
   const int k = blockIdx.y, kz = k / 9, ky = (k / 3) % 3, kx = k % 3;
@@ -355,21 +391,21 @@ __global__ void __launch_bounds__(256) conv3d_wgrad_pair_kernel(WgradArgs a) {
   for (int i = 0; i < TA; ++i)
 #pragma unroll
     for (int j = 0; j < TB; ++j) acc[i][j] = 0.f;
-  const long long first = (long long)blockIdx.x * a.vox_per_block;
-  const long long last = first + a.vox_per_block < a.n_p ? first + a.vox_per_block : a.n_p;
-  for (long long n0 = first; n0 < last; n0 += NV) {
+  const unsigned first = blockIdx.x * (unsigned)a.vox_per_block;
+  const unsigned last = first + a.vox_per_block < (unsigned)a.n_p ? first + a.vox_per_block : (unsigned)a.n_p;
+  for (unsigned n0 = first; n0 < last; n0 += NV) {
     __syncthreads();
     // stage: thread t loads float4 pieces; a voxel's row is CA / 4 (CB / 4) pieces
     for (int i = threadIdx.x; i < NV * (CA / 4); i += 256) {
       const int v = i / (CA / 4), c4 = i % (CA / 4);
-      const long long n = n0 + v;
+      const unsigned n = n0 + v;
       f32x4 val = splat4(0.f);
       if (n < last) val = ld4(a.tp + (size_t)n * CA + 4 * c4);
       *reinterpret_cast<f32x4*>(&sp[v][4 * c4]) = val;
     }
     for (int i = threadIdx.x; i < NV * (CB / 4); i += 256) {
       const int v = i / (CB / 4), c4 = i % (CB / 4);
-      const long long n = n0 + v;
+      const unsigned n = n0 + v;
       f32x4 val = splat4(0.f);
       size_t q;
       if (n < last && wgrad_q(a, n, S, kz, ky, kx, &q)) val = ld4(a.tq + q * CB + 4 * c4);
@@ -404,6 +440,7 @@ __global__ void __launch_bounds__(256) channel_sum_kernel(const float* __restric
   for (int c = 0; c < C; ++c) acc[c] = 0.f;
   const long long first = (long long)blockIdx.x * rows_per_block;
   const long long last = first + rows_per_block < N ? first + rows_per_block : N;
+#pragma unroll 4
   for (long long n = first + threadIdx.x; n < last; n += 256) {
     const float* p = x + (size_t)n * C;
     if constexpr (C % 4 == 0) {
@@ -414,27 +451,45 @@ __global__ void __launch_bounds__(256) channel_sum_kernel(const float* __restric
       for (int c = 0; c < C; ++c) acc[c] += p[c];
     }
   }
+  __shared__ float red[4][C];
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     float v = acc[c];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(out + c, v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < C) {      // one atomic per channel and block (same-address atomics serialise in the L2)
+    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (v != 0.f) atomicAdd(out + threadIdx.x, v);
   }
 }
 
 template <int CA, int CB, int S>
 hipError_t launch_wgrad_t(WgradArgs a, hipStream_t s) {
-  // blocks: enough to fill the chip per tap, few enough that the closing atomics stay negligible
-  long long blocks = (a.n_p + 8191) / 8192;
-  if (blocks > 2048) blocks = 2048;
-  if (blocks < 1) blocks = 1;
-  a.vox_per_block = (int)(((a.n_p + blocks - 1) / blocks + 63) / 64 * 64);
-  blocks = (a.n_p + a.vox_per_block - 1) / a.vox_per_block;
-  if constexpr (CA * CB <= 128)
-    hipLaunchKernelGGL((conv3d_wgrad_voxel_kernel<CA, CB, S>), dim3((unsigned)blocks, 27), dim3(256), 0, s, a);
-  else
+  if constexpr (CB <= 8 && CA * CB <= 128) {
+    // CAG coarse-side channels per thread (CAG CB <= 64), the groups on blockIdx.y; NT taps per pass (NT CAG CB <= 192), the
+    // passes on blockIdx.z
+    constexpr int CAG = CA < 8 ? CA : 8;
+    constexpr int NT = CAG * CB <= 8 ? 9 : 3;
+    static_assert(CA % CAG == 0, "channel groups");
+    long long blocks = (a.n_p + 16383) / 16384;      // >= 64 voxels per thread: the closing reduction stays a small share
+    if (blocks > 512) blocks = 512;                   // ... and few same-address atomics
+    if (blocks < 1) blocks = 1;
+    a.vox_per_block = (int)(((a.n_p + blocks - 1) / blocks + 255) / 256 * 256);
+    blocks = (a.n_p + a.vox_per_block - 1) / a.vox_per_block;
+    hipLaunchKernelGGL((conv3d_wgrad_voxel_kernel<CAG, CB, NT, S>), dim3((unsigned)blocks, CA / CAG, 27 / NT), dim3(256), 0, s, a, CA);
+  } else {
+    // blocks per tap: enough that 27 taps fill the chip even at the coarsest level (15 k voxels), few enough that the
+    // closing atomics (one per value and block) stay negligible
+    long long blocks = (a.n_p + 8191) / 8192;
+    if (blocks < 40) blocks = 40;
+    if (blocks > 2048) blocks = 2048;
+    a.vox_per_block = (int)(((a.n_p + blocks - 1) / blocks + 255) / 256 * 256);
+    blocks = (a.n_p + a.vox_per_block - 1) / a.vox_per_block;
     hipLaunchKernelGGL((conv3d_wgrad_pair_kernel<CA, CB, S>), dim3((unsigned)blocks, 27), dim3(256), 0, s, a);
+  }
   return hipGetLastError();
 }
 
@@ -458,6 +513,7 @@ hipError_t launch_conv3d_bwd_weight(const float* in, const float* d_out, float* 
     n_out = (long long)B * 8 * D * H * W;
   }
   a.n_p = (long long)B * a.Dp * a.Hp * a.Wp;
+  if (a.n_p >= (1ll << 31) - 65536 || n_out >= (1ll << 40)) return hipErrorInvalidValue;     // the kernels index voxels with 32 bits
   hipError_t e = hipErrorInvalidValue;
 #define UFR_WG_CASE(A_, B_, S_) if (ca == A_ && cb == B_ && S == S_) e = launch_wgrad_t<A_, B_, S_>(a, s);
   UFR_WG_CASE(8, 1, 1)     // conv0
@@ -472,7 +528,7 @@ hipError_t launch_conv3d_bwd_weight(const float* in, const float* d_out, float* 
 #undef UFR_WG_CASE
   if (e != hipSuccess) return e;
   if (d_bias) {
-    const int rows = 16384;
+    const int rows = 16384;    // 64 rows per thread, four loads in flight; ~500 blocks: few same-address atomics
     const long long blocks = (n_out + rows - 1) / rows;
 #define UFR_CS_CASE(C_) if (cout == C_) hipLaunchKernelGGL((channel_sum_kernel<C_>), dim3((unsigned)blocks), dim3(256), 0, s, d_out, d_bias, n_out, rows);
     UFR_CS_CASE(1) UFR_CS_CASE(8) UFR_CS_CASE(16) UFR_CS_CASE(32) UFR_CS_CASE(64)

@@ -101,7 +101,7 @@ __device__ unsigned long long g_rt_phase[32];
 // TAPE: the instantiation the backward launches (bwd_tape.h): the same arithmetic, plus one store per activation tile, the
 // transposed per-head state KV_h^T beside KV_h, and an even number of sweep-2 tiles (blocks of two).
 template <bool LOWP, bool TAPE = false>
-__global__ void __launch_bounds__(kRtBlock, UFR_RT_MINW) ray_transformer_kernel(const float* __restrict__ packed,
+__global__ void __launch_bounds__(kRtBlock, TAPE ? 2 : UFR_RT_MINW) ray_transformer_kernel(const float* __restrict__ packed,
                                                                   const float* __restrict__ token0,
                                                                   const int* __restrict__ tok_row,
                                                                   const float* __restrict__ order_pe, int RN, int SN,

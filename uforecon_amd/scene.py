@@ -173,6 +173,14 @@ def make_frame(H: int = 64, W: int = 96, NV: int = 3, seed: int = 0, offset_dist
     return Frame(batch, feat, vol, match, H, W, NV)
 
 
+def make_cost_volumes(H: int, W: int, NV: int, seed: int) -> dict:
+    """Seeded 1-channel cost volumes of the three cascade stages, (NV,1,D,H/s,W/s): what `MVSVolume` (feature_volume.py:
+    100-121, i.e. `cost_reg_2`) turns into the feature / weight frustums -- the input of the one producer the reference
+    trains.  Used by the gradient fixture of `feature_volume.cost_reg_2.*` and its test."""
+    g = torch.Generator().manual_seed(90_000 + seed)
+    return {st: _unit_uniform((NV, 1, STAGE_SHAPE[st][0], H // STAGE_SHAPE[st][1], W // STAGE_SHAPE[st][1]), g) for st in STAGES}
+
+
 def sampler_uniforms(seed: int, point_num: int, point_num_2: int, RN: int):
     """The two uniform draws of one ``infer`` call, in the reference's order and shapes.
 

@@ -72,8 +72,12 @@ typedef struct ufr_raw_weights {
  * (uforecon_amd/autograd.py records the forward's in the autograd context).
  *   UFR_PRECISION_DEFAULT the process default, FP32 unless ufr_set_matrix_precision changed it (a convenience for
  *                       command-line tools; library code that pairs a forward with a backward passes an explicit mode)
- *   UFR_PRECISION_FP32  fp32-grade: every product as three fp16 plane products, fp32 accumulate; the backward
- *                       kernels on the fp32 matrix instructions.  This is the mode all 1e-4 parity statements refer to.
+ *   UFR_PRECISION_FP32  fp32-grade FORWARD: every product as three fp16 plane products (22+ significand bits per operand),
+ *                       fp32 accumulate -- the mode all 1e-4 parity statements refer to.  The BACKWARD of this mode splits
+ *                       its operands into bf16 hi + lo planes (16 significand bits per operand, three products, fp32
+ *                       accumulate: "bf16x3"): gradient-grade, not fp32-grade -- every gradient tensor within 5e-5 of its
+ *                       scale of the reference's fp32 autograd (tests/test_gpu_backward.py; the bench line says
+ *                       `bwd_operand_dtype`).
  *   UFR_PRECISION_16BIT the "bf16" training mode of the reference's mixed-precision recipe (BASELINE configs[4]): one
  *                       16-bit plane per operand (fp16 hi planes in the forward, bf16 operands in the backward GEMMs and
  *                       weight gradients), fp32 accumulation, LayerNorm / attention / softmax / compositor in fp32.
@@ -105,7 +109,9 @@ int ufr_get_matrix_precision(void);
  * EARLIER poll / launch has already delivered.  ufr_render_rays, ufr_aggregate, ufr_view_transform and
  * ufr_ray_transform poll lazily: each enqueues the copy after its kernels and fails with UFR_ERR_RANGE on entry when a
  * previous call's copy arrived set -- one call late, without a host synchronisation in the ray loop.  `flags_out`
- * (nullable) receives the bits. */
+ * (nullable) receives the bits.  Across streams: every copy waits (on its own stream) for the last report-and-clear, so a
+ * poll on another stream than the one that reported cannot miss bits raised since; a bit raised again between a report's
+ * copy and its clear is reported with the next violation rather than at once (reports can be late, never spurious). */
 int ufr_status_poll(ufr_stream stream, int32_t synchronize, int32_t* flags_out);
 /* The same, restricted to the bits of `mask`: other bits stay set for whoever polls for them (uforecon_amd.ops.PackedWeights
  * checks a fresh pack with mask 4, so that an unrelated, still unreported activation overflow does not fail a valid pack). */
@@ -273,12 +279,12 @@ int ufr_composite_bwd(const float* z, const float* radiance, const int32_t* row,
  * point -- the input of ufr_project_gather_bwd.  packed_weights: ufr_weights_pack of the same parameters (the view
  * transformer's backward re-runs the forward kernel with a tape and walks the chain backwards on transposed weight planes
  * of the packed blob; its weight gradients are one streaming contraction over the tokens).  The workspace holds the tape
- * and the cotangent tiles: ~15 KB per point at NV = 3.  debug_ray (P,440): optional dump of the ray kernel's intermediate
- * gradients (development), may be NULL. */
+ * and the cotangent tiles: ~15 KB per point at NV = 3.  (ABI 500: the `debug_ray` dump argument of earlier versions, ignored
+ * since the round-4 kernels, is gone.) */
 size_t ufr_aggregate_bwd_workspace_bytes(int32_t RN, int32_t SN, int32_t NV);
 int ufr_aggregate_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const void* packed_weights, const float* x_tokens,
                       const float* rgb, const float* dir, const float* token0, int32_t RN, int32_t SN, int32_t NV,
-                      const float* d_radiance, const float* d_srdf, float* d_pv, void* workspace, float* debug_ray,
+                      const float* d_radiance, const float* d_srdf, float* d_pv, void* workspace,
                       int32_t precision, ufr_stream stream);
 
 /* Adjoint of ufr_project_gather w.r.t. the sampled volumes and pre_sim_mlp (autograd of model.py:350-390 and

@@ -35,7 +35,7 @@ int main(void) {
   if (ufr_deform_conv2d(0, 0, 0, 0, 0, 0, 1, 32, 32, 8, 8, 0, 0, 0) >= 0) return 15;
   if (ufr_render_workspace_bytes(4096, 64, 64, 3) == 0) return 16;
   if (ufr_composite_bwd(0, 0, 0, 0, 0, 4, 64, 0, 0, 0, 0, 0, 0, 0, 0, 0) >= 0) return 18;
-  if (ufr_aggregate_bwd(0, 0, 0, 0, 0, 0, 0, 4, 64, 3, 0, 0, 0, 0, 0, UFR_PRECISION_DEFAULT, 0) >= 0) return 19;
+  if (ufr_aggregate_bwd(0, 0, 0, 0, 0, 0, 0, 4, 64, 3, 0, 0, 0, 0, UFR_PRECISION_DEFAULT, 0) >= 0) return 19;
   /* an unknown precision is an argument error, not a silent default */
   if (ufr_view_transform((const void*)1, (const float*)1, (const float*)1, (const float*)1, 4, 3, (float*)1, (float*)1, 7, 0) != UFR_ERR_ARG) return 21;
   if (ufr_aggregate_bwd_workspace_bytes(1024, 128, 3) == 0) return 20;

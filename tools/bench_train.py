@@ -57,6 +57,11 @@ def parse(argv=None):
                     help="the step WITH the one producer the reference trains in front of the ray path (model.py:72-87, 517-524): "
                          "seeded cost volumes -> MVSVolume (feature_volume.cost_reg_2, ufr_conv3d) -> frustums -> infer -> loss -> "
                          "backward through ufr_project_gather_bwd and ufr_conv3d_bwd_* -> Adam over both parameter sets")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one whole step (forward, loss, backward on its three streams, re-pack, Adam) in a HIP graph after "
+                         "the warm-up and REPLAY it in the timed region: the ~60 few-microsecond launches of the caller's side "
+                         "(loss arithmetic, Adam, re-pack) stop bounding the step.  Single rank, without --cost-reg; the ray "
+                         "indices / uniforms of a step are drawn outside the graph into static buffers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=64)
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -151,15 +156,27 @@ def run(a, dev, world=1, rank=0):
         vols = [f.feature_volume[st][k] for st in f.feature_volume for k in f.feature_volume[st]]
         for v in vols:
             v.requires_grad_(True)
-    opt = torch.optim.Adam(list(m.parameters()) + (list(mvs.parameters()) if mvs is not None else []), lr=1e-4)   # model.py:72-87
+    use_graph = bool(a.graph) and world == 1 and mvs is None
+    opt = torch.optim.Adam(list(m.parameters()) + (list(mvs.parameters()) if mvs is not None else []), lr=1e-4,
+                           capturable=use_graph)   # model.py:72-87
     HW = a.height * a.width
     gen = torch.Generator(device=dev).manual_seed(100 + drank if a.fixed_seed < 0 else a.fixed_seed * 1000 + drank)
     ar_events = []
 
-    def step():
-        idx = torch.randperm(HW, device=dev, generator=gen)[: a.rays][None]              # model.py:537
-        U1 = torch.rand(a.coarse, a.rays, device=dev, generator=gen)
-        U2 = torch.rand(a.fine, a.rays, device=dev, generator=gen)
+    # --graph: the step's random inputs live in static buffers that a replayed graph reads
+    idx_buf = torch.zeros(1, a.rays, dtype=torch.int64, device=dev)
+    U1_buf = torch.zeros(a.coarse, a.rays, device=dev)
+    U2_buf = torch.zeros(a.fine, a.rays, device=dev)
+
+    def draw():
+        idx_buf.copy_(torch.randperm(HW, device=dev, generator=gen)[: a.rays][None])      # model.py:537
+        U1_buf.copy_(torch.rand(a.coarse, a.rays, device=dev, generator=gen))
+        U2_buf.copy_(torch.rand(a.fine, a.rays, device=dev, generator=gen))
+
+    def step(drawn: bool = False):
+        if not drawn:
+            draw()
+        idx, U1, U2 = idx_buf, U1_buf, U2_buf
         for v in vols:
             v.grad = None
         opt.zero_grad(set_to_none=True)
@@ -206,9 +223,29 @@ def run(a, dev, world=1, rank=0):
     ar_events.clear()
     if os.environ.get("UFR_BT_PROF") == "1":
         ops.profile_enable(True)
+    graph, graph_note = None, "eager launches"
+    if use_graph:
+        try:
+            # capture on a side stream (torch.cuda.graph does that), after the warm-up made every lazily created object
+            # (workspaces, side streams, kernel attributes, the frame handle) exist
+            draw()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                g_loss = step(drawn=True)
+            graph.replay()
+            fence()
+            graph_note = "one HIP graph per step (captured after the warm-up), replayed"
+        except Exception as e:  # noqa: BLE001 -- a box whose runtime cannot capture this step still measures it, and says so
+            graph, graph_note = None, f"eager launches (HIP graph capture failed: {type(e).__name__}: {str(e)[:160]})"
+            torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        loss = step()
+        if graph is not None:
+            draw()
+            graph.replay()
+            loss = g_loss
+        else:
+            loss = step()
     fence()
     dt = time.perf_counter() - t0
     timed_grads = getattr(step, "last_grads", None)
@@ -301,6 +338,7 @@ def run(a, dev, world=1, rank=0):
                                         "ray_tape ARE the training forward of the two transformers (they record the "
                                         "backward's tape): there is no separate view_transformer / ray_transformer launch"),
                     loss=float(loss.detach()),
+                    launch=graph_note,
                     kernel_ms_per_step_rank0={k: v["ms"] / a.steps for k, v in prof.items()},
                     kernel_launches_per_step={k: v["launches"] / a.steps for k, v in prof.items()},
                     per_rank=per_rank),

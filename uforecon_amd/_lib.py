@@ -97,7 +97,7 @@ SIGNATURES = {
     "ufr_composite_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
     "ufr_aggregate_bwd_workspace_bytes": (sz, [i32, i32, i32]),
     "ufr_aggregate_bwd": (C.c_int, [C.POINTER(RawWeights), C.POINTER(RawGrads), vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp,
-                                    vp, vp, i32, vp]),
+                                    vp, i32, vp]),
     "ufr_project_gather_bwd_workspace_bytes": (sz, [C.POINTER(Frame)]),
     "ufr_project_gather_bwd": (C.c_int, [C.POINTER(Frame), C.POINTER(RawWeights), C.POINTER(RawGrads), vp, i32, vp, vp,
                                          i32, i32, vp, vp, vp, C.POINTER(vp), C.POINTER(vp), i32, vp, i32, vp]),

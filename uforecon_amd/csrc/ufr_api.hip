@@ -133,6 +133,11 @@ struct StatusSlot {
   volatile int* host = nullptr;
   std::atomic<int> gen{0};
   std::mutex report_mu;
+  // recorded behind every report-and-clear kernel; the copies that deliver the words wait for it on THEIR stream, so a poll
+  // on another stream than the one the last report was issued on cannot fetch the old tag and miss newly raised bits
+  // (round-4 advisor finding: reports could be delayed or dropped across streams)
+  hipEvent_t upd = nullptr;
+  std::atomic<bool> upd_recorded{false};
 };
 constexpr int kStatusDevices = 16;
 StatusSlot g_status[kStatusDevices];
@@ -159,6 +164,7 @@ int status_slot(StatusSlot** out) {
     h[0] = h[1] = 0;
     sl.host = h;
     sl.dev = d;
+    if (hipEventCreateWithFlags(&sl.upd, hipEventDisableTiming) != hipSuccess) sl.upd = nullptr;
   });
   if (sl.rc != UFR_OK) return fail(sl.rc, "status: could not allocate the device's status words");
   *out = &sl;
@@ -185,15 +191,19 @@ int status_consume(StatusSlot* sl, hipStream_t s, int mask, const char* who, int
   sl->gen.store(next, std::memory_order_relaxed);
   hipLaunchKernelGGL(status_update_kernel, dim3(1), dim3(1), 0, s, sl->dev, ~hit, next);
   UFR_HIP(hipGetLastError());
+  if (sl->upd && hipEventRecord(sl->upd, s) == hipSuccess) sl->upd_recorded.store(true, std::memory_order_release);
   return status_message(hit, who);
 }
 // entry of a compute call: report (and clear) what an earlier call's copy delivered
 int status_enter(StatusSlot* sl, hipStream_t s, const char* who) { return status_consume(sl, s, kStatusAll, who, nullptr); }
 // exit of a compute call: deliver the words as of the end of this call's kernels
-int status_leave(StatusSlot* sl, hipStream_t s) {
+int status_fetch(StatusSlot* sl, hipStream_t s) {
+  // behind the last report-and-clear, whatever stream issued it (a completed event costs nothing to wait for)
+  if (sl->upd_recorded.load(std::memory_order_acquire)) UFR_HIP(hipStreamWaitEvent(s, sl->upd, 0));
   UFR_HIP(hipMemcpyAsync(const_cast<int*>(sl->host), sl->dev, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
   return UFR_OK;
 }
+int status_leave(StatusSlot* sl, hipStream_t s) { return status_fetch(sl, s); }
 }  // namespace
 
 extern "C" {
@@ -211,7 +221,8 @@ int ufr_status_poll_bits(ufr_stream stream, int32_t synchronize, int32_t mask, i
   if (rc != UFR_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (synchronize) {
-    UFR_HIP(hipMemcpyAsync(const_cast<int*>(sl->host), sl->dev, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    rc = status_fetch(sl, s);
+    if (rc != UFR_OK) return rc;
     UFR_HIP(hipStreamSynchronize(s));
   }
   int flags = 0;
@@ -600,7 +611,7 @@ size_t ufr_aggregate_bwd_workspace_bytes(int32_t RN, int32_t SN, int32_t NV) {
 
 int ufr_aggregate_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, const void* packed_weights, const float* x_tokens,
                       const float* rgb, const float* dir, const float* token0, int32_t RN, int32_t SN, int32_t NV,
-                      const float* d_radiance, const float* d_srdf, float* d_pv, void* workspace, float* debug_ray,
+                      const float* d_radiance, const float* d_srdf, float* d_pv, void* workspace,
                       int32_t precision, ufr_stream stream) {
   RawPtrs rp;
   GradPtrs gp;
@@ -618,7 +629,6 @@ int ufr_aggregate_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, co
   StatusSlot* sl = nullptr;
   rc = status_slot(&sl);
   if (rc != UFR_OK) return rc;
-  (void)debug_ray;
   rc = ray_bwd_impl(packed_weights, gp, token0, nullptr, false, d_srdf, RN, SN, d_tok, nullptr, rw, lowp, sl->dev, s);
   if (rc != UFR_OK) return rc;
   return view_bwd_impl(packed_weights, gp, x_tokens, rgb, dir, d_tok, nullptr, d_radiance, RN * SN, NV, d_pv, vw, lowp, sl->dev, s);

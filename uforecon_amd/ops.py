@@ -393,22 +393,20 @@ def composite_bwd(z, radiance, srdf, variance, d_rgb, d_depth, d_opacity, d_weig
 
 
 def aggregate_bwd(weights: PackedWeights, grads: GradBuffer, x, rgb, dirs, token0, RN: int, SN: int, d_radiance, d_srdf,
-                  debug: bool = False, precision: Optional[int] = None):
+                  precision: Optional[int] = None):
+    """-> (d_pv (P,40), {}) -- the empty dict keeps the call sites of the former debug dump (gone with ABI 500)."""
     lib = _lib.load()
     NV, dev = x.shape[1], x.device
     P = RN * SN
     d_pv = torch.empty(P, 40, dtype=torch.float32, device=dev)
     ws = torch.empty(lib.ufr_aggregate_bwd_workspace_bytes(RN, SN, NV) // 4, dtype=torch.float32, device=dev)
-    dbg = {}
-    if debug:
-        dbg = dict(ray=torch.zeros(P, 440, device=dev))
     _lib.check(lib.ufr_aggregate_bwd(
         C.byref(weights.raw), C.byref(grads.raw), weights.packed.data_ptr(), _dev(x, "x_tokens"), _dev(rgb, "rgb"),
         _dev(dirs, "dir"), _dev(token0, "token0"), RN, SN, NV, _dev(d_radiance.contiguous(), "d_radiance"),
-        _dev(d_srdf.contiguous(), "d_srdf"), d_pv.data_ptr(), ws.data_ptr(), _opt(dbg.get("ray"), "debug_ray"),
+        _dev(d_srdf.contiguous(), "d_srdf"), d_pv.data_ptr(), ws.data_ptr(),
         weights.mode() if precision is None else precision, _stream()),
         "ufr_aggregate_bwd")
-    return d_pv, dbg
+    return d_pv, {}
 
 
 def project_gather_bwd_workspace_floats(frame: FrameHandle) -> int:

@@ -23,10 +23,17 @@
 namespace ufr {
 
 // load the ray-transformer input tile: [token-0 feature (80) | order PE (8)] in nat88 layout
-#ifndef UFR_RT_C
-#define UFR_RT_C 1   // 16-token column tiles per wave and iteration
+// Column tiles per wave and iteration.  Sweep 1 (K, V and the per-head state) always walks ONE 16-token tile: its two sets of
+// eight head tiles fill the registers.  Sweep 2 (Q, message, merge, MLP, DensityMLP: three quarters of the weight stream)
+// walks UFR_RT_C2 tiles per pass over the weights.  C2 = 2 (a weight fragment read from LDS feeds 6 MFMAs and the stream
+// is fetched half as often per token; the registers come from the per-head state KV_h waiting in LDS between the sweeps,
+// 8 KiB per wave) was built and measured in round 5: bit-identical output, static instructions per two tiles 8 166 ->
+// ~6 900, but 256 registers with 36 spilled and 0.391 vs 0.377 ms per 4096 x 128 launch on the same box -- like the
+// round-2 attempt over both sweeps (0.706 vs 0.641), the ray kernel is not bound by its weight stream.  Kept as a switch.
+#ifndef UFR_RT_C2
+#define UFR_RT_C2 1
 #endif
-constexpr int kRtC = UFR_RT_C;
+constexpr int kRtC2 = UFR_RT_C2;
 
 __device__ __forceinline__ void load_ray_tile(const float* __restrict__ token0, const int* __restrict__ tok_row,
                                               const float* __restrict__ order_pe, size_t tok_base, int s_base, int g,
@@ -40,11 +47,11 @@ __device__ __forceinline__ void load_ray_tile(const float* __restrict__ token0, 
 
 // LayerNorm over 88 features in nat88 layout (tile 5: registers 0,1 real)
 // XH / RS (TAPE builds): the normalised input and 1 / sigma of the TRUE values, which the backward needs
-template <int VW, int VB, class WS>
-__device__ __forceinline__ void layer_norm88(f32x4 (&tt)[kRtC][6], const WS& ws, int g, float eps, float asc, f32x4 (*XH)[6] = nullptr, float* RS = nullptr) {
+template <int VW, int VB, int C, class WS>
+__device__ __forceinline__ void layer_norm88(f32x4 (&tt)[C][6], const WS& ws, int g, float eps, float asc, f32x4 (*XH)[6] = nullptr, float* RS = nullptr) {
   // eps = 1e-5 asc^2: raw accumulators (asc times the values), view_transformer.hip layer_norm80
 #pragma unroll
-  for (int c = 0; c < kRtC; ++c) {
+  for (int c = 0; c < C; ++c) {
     f32x4 (&t)[6] = tt[c];
     float s = 0.f;
 #pragma unroll
@@ -100,7 +107,8 @@ __device__ unsigned long long g_rt_phase[32];
 
 // TAPE: the instantiation the backward launches (bwd_tape.h): the same arithmetic, plus one store per activation tile, the
 // transposed per-head state KV_h^T beside KV_h, and an even number of sweep-2 tiles (blocks of two).
-template <bool LOWP, bool TAPE = false>
+constexpr int kRtKvLdsBytes = kRtWaves * 8 * 1024;     // the waves' per-head states between the sweeps (C2 > 1)
+template <bool LOWP, bool TAPE = false, int C2 = 1>
 __global__ void __launch_bounds__(kRtBlock, TAPE ? 2 : UFR_RT_MINW) ray_transformer_kernel(const float* __restrict__ packed,
                                                                   const float* __restrict__ token0,
                                                                   const int* __restrict__ tok_row,
@@ -109,7 +117,8 @@ __global__ void __launch_bounds__(kRtBlock, TAPE ? 2 : UFR_RT_MINW) ray_transfor
                                                                   float* __restrict__ ray_out,
                                                                   int* __restrict__ status, float* __restrict__ tape = nullptr,
                                                                   float* __restrict__ ray_state = nullptr) {
-  static_assert(!TAPE || kRtC == 1, "the tape build walks one tile per iteration");
+  static_assert(!TAPE || C2 == 1, "the tape build walks one tile per iteration");
+  constexpr bool kKvLds = C2 > 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   auto ws = wstream_f16_begin<kRtWaves, LOWP>(packed, smem);
   wstream_f16_prime<B_RT1, kRtWaves>(ws);
@@ -118,8 +127,7 @@ __global__ void __launch_bounds__(kRtBlock, TAPE ? 2 : UFR_RT_MINW) ray_transfor
   const bool valid = ray_raw < RN;           // no early exit: every wave meets every chunk barrier
   const int ray = valid ? ray_raw : RN - 1;
   const int n_tiles = SN / 16;
-  constexpr int C = kRtC;
-  const int n_iter = (n_tiles + C - 1) / C;   // an odd tile count leaves the last iteration's second tile empty (masked)
+  const int n_iter = n_tiles;                 // sweep 1: one tile per iteration
   // values / v_length (linear_attention.py:41): a multiply by 1/SN is exact only for power-of-two sample counts;
   // any other total (64 + 32, 48, ...) takes the true division the reference performs
   // the layers' plane / accumulator scales (ufr_layout.h: RayScalar; weight_stream_f16.h: ScalarFile -- this kernel has the
@@ -142,6 +150,7 @@ __global__ void __launch_bounds__(kRtBlock, TAPE ? 2 : UFR_RT_MINW) ray_transfor
 #pragma unroll
   for (int h = 0; h < (TAPE ? 8 : 1); ++h) KVT[h] = splat4(0.f);
   for (int it = 0; it < n_iter; ++it) {
+    constexpr int C = 1;
     const bool wrap = it + 1 < n_iter;
     const bool slot_ok = head11_slot(j) >= 0;   // column j of a head tile carries a head dim
     f32x4 x[C][6], kt[C][8], vt[C][8];
@@ -234,7 +243,17 @@ __global__ void __launch_bounds__(kRtBlock, TAPE ? 2 : UFR_RT_MINW) ray_transfor
   }
   // ---------------- sweep 2 (slot 0 is free: every wave passed the barrier that opened sweep 1's last chunk)
   wstream_f16_prime<B_RT2, kRtWaves>(ws);
-  const int n_iter2 = TAPE ? n_iter + (n_iter & 1) : n_iter;     // TAPE: whole blocks of two tiles (a padding tile is not live)
+  // C2 > 1: the per-head state leaves the registers (the wave's own 8 KiB behind the ring and the vector fragments; only
+  // this wave reads it back: program order within the wave is all the ordering it needs)
+  f32x4* const kv_lds = reinterpret_cast<f32x4*>(smem + kF16LdsBytes) + (threadIdx.x >> 6) * 512 + lane;
+  if constexpr (kKvLds) {
+#pragma unroll
+    for (int h = 0; h < 8; ++h) kv_lds[h * 64] = KV[h];
+  }
+  constexpr int C = C2;
+  // TAPE: whole blocks of two tiles (a padding tile is not live); C2 > 1: an odd tile count leaves the last iteration's
+  // second tile empty (masked)
+  const int n_iter2 = TAPE ? n_iter + (n_iter & 1) : (n_tiles + C - 1) / C;
   typedef RayTapeLayout<LOWP> TapeL;
   for (int it = 0; it < n_iter2; ++it) {
     const bool wrap = it + 1 < n_iter2;
@@ -273,13 +292,16 @@ __global__ void __launch_bounds__(kRtBlock, TAPE ? 2 : UFR_RT_MINW) ray_transfor
       static_for<8>([&](auto hi) __attribute__((always_inline)) {
         constexpr int h = decltype(hi)::value;
         f32x4 acc = splat4(0.f);
+        f32x4 kvh;
+        if constexpr (kKvLds) kvh = kv_lds[h * 64];
+        else kvh = KV[h];
         static_for<3>([&](auto qi) __attribute__((always_inline)) {
           constexpr int qd = decltype(qi)::value, quad = 3 * h + qd;   // lane group g: head dim 3g + qd
           const float qq = (3 * g + qd < 11) ? elu1_acc(q[c][quad >> 2][quad & 3], q_dsc, q_l2e) : 0.f;
 #ifdef UFR_ABL_NOKV
-          acc[qd] += KV[h][qd] * qq;
+          acc[qd] += kvh[qd] * qq;
 #else
-          acc = mfma16(KV[h][qd], qq, acc);          // rows = V slots: sum_d KV[d][v] Q'[d]; slot 3 = Q'.sum(K')
+          acc = mfma16(kvh[qd], qq, acc);            // rows = V slots: sum_d KV[d][v] Q'[d]; slot 3 = Q'.sum(K')
 #endif
         });
         const float den = __shfl(acc[3], j);         // slot 3 lives in lane group 0, register 3
@@ -309,11 +331,11 @@ __global__ void __launch_bounds__(kRtBlock, TAPE ? 2 : UFR_RT_MINW) ray_transfor
     float rstd1[C] = {}, rstd2[C] = {};
     if constexpr (TAPE) {
       f32x4 xh[C][6];
-      layer_norm88<V_RT_N1W, V_RT_N1B>(m, ws, g, sc[RS_EPS1], sc[RS_M_ASC], xh, rstd1);
+      layer_norm88<V_RT_N1W, V_RT_N1B, C>(m, ws, g, sc[RS_EPS1], sc[RS_M_ASC], xh, rstd1);
 #pragma unroll
       for (int t = 0; t < 6; ++t) { tape_st(RT_XH1 + t, xh[0][t]); tape_st(RT_M + t, m[0][t]); }
     } else {
-      layer_norm88<V_RT_N1W, V_RT_N1B>(m, ws, g, sc[RS_EPS1], 1.f);
+      layer_norm88<V_RT_N1W, V_RT_N1B, C>(m, ws, g, sc[RS_EPS1], 1.f);
     }
     UFR_RT_PHASE(5)  // LayerNorm 1
 
@@ -350,11 +372,11 @@ __global__ void __launch_bounds__(kRtBlock, TAPE ? 2 : UFR_RT_MINW) ray_transfor
     UFR_RT_PHASE(7)  // ReLU + MLP2
     if constexpr (TAPE) {
       f32x4 xh[C][6];
-      layer_norm88<V_RT_N2W, V_RT_N2B>(o, ws, g, sc[RS_EPS2], sc[RS_MLP2_ASC], xh, rstd2);
+      layer_norm88<V_RT_N2W, V_RT_N2B, C>(o, ws, g, sc[RS_EPS2], sc[RS_MLP2_ASC], xh, rstd2);
 #pragma unroll
       for (int t = 0; t < 6; ++t) tape_st(RT_XH2 + t, xh[0][t]);
     } else {
-      layer_norm88<V_RT_N2W, V_RT_N2B>(o, ws, g, sc[RS_EPS2], 1.f);
+      layer_norm88<V_RT_N2W, V_RT_N2B, C>(o, ws, g, sc[RS_EPS2], 1.f);
     }
     UFR_RT_PHASE(8)  // LayerNorm 2
 #pragma unroll
@@ -429,9 +451,11 @@ template <bool LOWP, bool TAPE = false>
 static hipError_t launch_rt(const float* packed, const float* token0, const int* tok_row, const float* order_pe, int RN,
                             int SN, float* srdf, float* ray_out, int* status, hipStream_t s, float* tape = nullptr,
                             float* ray_state = nullptr) {
+  constexpr int C2 = TAPE ? 1 : kRtC2;
+  constexpr int lds = kF16LdsBytes + (C2 > 1 ? kRtKvLdsBytes : 0);
   static LdsAttrOnce lds_attr;   // per instantiation; thread-safe, once per device
-  if (const hipError_t attr = lds_attr.set(reinterpret_cast<const void*>(&ray_transformer_kernel<LOWP, TAPE>), kF16LdsBytes); attr != hipSuccess) return attr;
-  hipLaunchKernelGGL((ray_transformer_kernel<LOWP, TAPE>), dim3((RN + kRtWaves - 1) / kRtWaves), dim3(kRtBlock), kF16LdsBytes, s,
+  if (const hipError_t attr = lds_attr.set(reinterpret_cast<const void*>(&ray_transformer_kernel<LOWP, TAPE, C2>), lds); attr != hipSuccess) return attr;
+  hipLaunchKernelGGL((ray_transformer_kernel<LOWP, TAPE, C2>), dim3((RN + kRtWaves - 1) / kRtWaves), dim3(kRtBlock), lds, s,
                      packed, token0, tok_row, order_pe, RN, SN, srdf, ray_out, status, tape, ray_state);
   return hipGetLastError();
 }

@@ -202,6 +202,137 @@ hipError_t launch_conv_t(const Conv3dArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The 16..64-channel layers on the matrix cores (round 5): an implicit GEMM on v_mfma_f32_16x16x4_f32 -- EXACT fp32
+// products and sums (no planes, no scales: the winner-take-all depth of the cascade and the parity bounds stay where
+// they are), rows = 16 output channels, columns = 16 output voxels, k = 4 input channels of one tap per instruction.
+//  * a wave owns VT tiles of 16 consecutive voxels of the (sub-)grid; lane (g, j) loads channels 16 cb + 4g .. + 3 of its
+//    voxel j's tap neighbour with ONE 16-byte load -- the B operands of four MFMAs (k = lane group g, r = 0..3);
+//  * the A operands come from LDS: one chunk = ALL 27 taps of one (16-channel input block, 16-channel output tile) pair,
+//    27.6 KiB, staged from the checkpoint's layout in runs of 432 contiguous floats per output channel (coalesced; the
+//    per-tap chunks of the vector kernel read with a stride of 27 floats) and stored in operand order, so a lane's four
+//    k-values of a tap are one ds_read_b128;
+//  * loop order: output tile > input block (stage, barrier) > tap > voxel tile: the accumulators of one output tile are
+//    all that lives across the taps (4 registers per voxel tile), the tile is finished and stored before the next starts;
+//    the activations are re-read once per output tile (L1 / L2), one load per four MFMAs;
+//  * bias / folded BatchNorm / ReLU / skip ride in the store: the accumulator tile's lane (g, j) holds channels 4g .. 4g + 3
+//    of voxel j -- one 16-byte channel-last store.
+// The vector kernel runs these layers at 4..15 % of the fp32 peak (its 64 -> 64 layer at 1/8 resolution has 60 blocks of
+// work for 256 CUs); measured per layer in tools/dev/conv3d_bwd_probe.py.
+template <int CIN, int COUT, int MODE, int VT>
+__global__ void __launch_bounds__(256) conv3d_mfma_kernel(Conv3dArgs a) {
+  static_assert(CIN % 16 == 0 && COUT % 16 == 0, "whole 16-channel blocks");
+  constexpr int NCB = CIN / 16, NTL = COUT / 16;
+  __shared__ __attribute__((aligned(16))) float wlds[27 * 256];   // [tap][lane 64][r 4]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
+  int pz = 0, py = 0, px = 0;
+  int Ds = a.Do, Hs = a.Ho, Ws = a.Wo;
+  if (MODE == kDeconvS2) {
+    pz = (blockIdx.y >> 2) & 1; py = (blockIdx.y >> 1) & 1; px = blockIdx.y & 1;
+    Ds = a.Do / 2; Hs = a.Ho / 2; Ws = a.Wo / 2;
+  }
+  const long long n_sub = (long long)a.B * Ds * Hs * Ws;
+  const int nz = MODE == kDeconvS2 ? 1 + pz : 3, ny = MODE == kDeconvS2 ? 1 + py : 3, nx = MODE == kDeconvS2 ? 1 + px : 3;
+  const int n_taps = nz * ny * nx;
+  auto tap_k = [&](int t, int par) -> int { return MODE != kDeconvS2 ? t : (par == 0 ? 1 : (t == 0 ? 0 : 2)); };
+  auto tap_di = [&](int t, int par) -> int { return MODE != kDeconvS2 ? t - 1 : (par == 0 ? 0 : (t == 0 ? 1 : 0)); };
+
+  int vb[VT], vz[VT], vy[VT], vx[VT];
+  bool live[VT];
+#pragma unroll
+  for (int v = 0; v < VT; ++v) {
+    long long n = (((long long)blockIdx.x * 4 + wave) * VT + v) * 16 + j;
+    live[v] = n < n_sub;
+    if (!live[v]) n = 0;
+    vx[v] = (int)(n % Ws); n /= Ws;
+    vy[v] = (int)(n % Hs); n /= Hs;
+    vz[v] = (int)(n % Ds);
+    vb[v] = (int)(n / Ds);
+  }
+  constexpr int s = MODE == kConvS2 ? 2 : 1;
+
+  for (int t = 0; t < NTL; ++t) {
+    f32x4 acc[VT];
+#pragma unroll
+    for (int v = 0; v < VT; ++v) acc[v] = splat4(0.f);
+    for (int cb = 0; cb < NCB; ++cb) {
+      __syncthreads();   // the previous chunk's readers are done
+      // ---- stage W[16 t + i][16 cb + c][k], all 27 k: per output channel i one run of 16 x 27 contiguous floats
+      // (conv layout [co][ci][27]; transposed / mirrored layers read [ci][co][27]: runs of 27 per (ci, co))
+      for (int e = tid; e < 16 * 16 * 27; e += 256) {
+        int i, c, k;
+        float w;
+        if (MODE == kDeconvS2 || (MODE == kConvS1 && a.flip)) {
+          k = e % 27; i = (e / 27) % 16; c = e / (27 * 16);          // source [ci][co][27]: co fastest among the runs
+          w = a.weight[((size_t)(16 * cb + c) * COUT + 16 * t + i) * 27 + k];
+          if (MODE == kConvS1) k = 26 - k;                            // mirrored taps (the data gradient of a stride-1 layer)
+        } else {
+          k = e % 27; c = (e / 27) % 16; i = e / (27 * 16);          // source [co][ci][27]
+          w = a.weight[((size_t)(16 * t + i) * CIN + 16 * cb + c) * 27 + k];
+        }
+        wlds[(k * 64 + (c >> 2) * 16 + i) * 4 + (c & 3)] = w;         // operand order: lane = (g = c / 4, i), r = c % 4
+      }
+      __syncthreads();
+      for (int tl = 0; tl < n_taps; ++tl) {
+        const int tz = tl / (ny * nx), ty = (tl / nx) % ny, tx = tl % nx;
+        const int k = (tap_k(tz, pz) * 3 + tap_k(ty, py)) * 3 + tap_k(tx, px);
+        const int dz = tap_di(tz, pz), dy = tap_di(ty, py), dx = tap_di(tx, px);
+        const f32x4 wa = *reinterpret_cast<const f32x4*>(&wlds[(k * 64 + lane) * 4]);
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+          const int iz = vz[v] * s + dz, iy = vy[v] * s + dy, ix = vx[v] * s + dx;
+          const bool ok = live[v] && iz >= 0 && iz < a.D && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+          const float* p = a.in + ((((size_t)vb[v] * a.D + (ok ? iz : 0)) * a.H + (ok ? iy : 0)) * a.W + (ok ? ix : 0)) * CIN +
+                           16 * cb + 4 * g;
+          f32x4 xb = ld4(p);
+          if (!ok) xb = splat4(0.f);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[v] = mfma16(wa[r], xb[r], acc[v]);
+        }
+      }
+    }
+    // ---- epilogue of output tile t: lane (g, j) holds channels 16 t + 4 g + r of voxel j
+    const int c0 = 16 * t + 4 * g;
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+      if (!live[v]) continue;
+      const int oz = MODE == kDeconvS2 ? 2 * vz[v] + pz : vz[v], oy = MODE == kDeconvS2 ? 2 * vy[v] + py : vy[v],
+                ox = MODE == kDeconvS2 ? 2 * vx[v] + px : vx[v];
+      const size_t vox = (((size_t)vb[v] * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
+      f32x4 y = acc[v];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float q = y[r];
+        if (a.bias) q += a.bias[c0 + r];
+        if (a.scale) q = fmaf(q, a.scale[c0 + r], a.shift[c0 + r]);
+        if (a.relu) q = fmaxf(q, 0.f);
+        y[r] = q;
+      }
+      if (a.skip) y += ld4(a.skip + vox * COUT + c0);
+      st4(a.out + vox * COUT + c0, y);
+    }
+  }
+}
+
+template <int CIN, int COUT, int MODE>
+hipError_t launch_conv_mfma_t(const Conv3dArgs& a, hipStream_t s) {
+  const bool de = MODE == kDeconvS2;
+  const long long n_sub = (long long)a.B * (de ? a.Do / 2 : a.Do) * (de ? a.Ho / 2 : a.Ho) * (de ? a.Wo / 2 : a.Wo);
+  const long long tiles = (n_sub + 15) / 16;
+  // four voxel tiles per wave amortise the weight staging; small grids (the 1/8-resolution layers: ~1 000 tiles) take one,
+  // so that every CU gets work
+  if (tiles >= 16384) {
+    const long long blocks = (tiles + 15) / 16;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv3d_mfma_kernel<CIN, COUT, MODE, 4>), dim3((unsigned)blocks, de ? 8 : 1), dim3(256), 0, s, a);
+  } else {
+    const long long blocks = (tiles + 3) / 4;
+    hipLaunchKernelGGL((conv3d_mfma_kernel<CIN, COUT, MODE, 1>), dim3((unsigned)blocks, de ? 8 : 1), dim3(256), 0, s, a);
+  }
+  return hipGetLastError();
+}
+
 }  // namespace
 
 // cout_pad: COUT of the instantiation (cout_real (+ cout2) rounded up to a multiple of 4)
@@ -217,6 +348,21 @@ hipError_t launch_conv3d(const float* in, const float* weight, const float* weig
   else if (mode == kConvS2) { a.Do = (D + 1) / 2; a.Ho = (H + 1) / 2; a.Wo = (W + 1) / 2; }   // k3 p1 s2: floor((n-1)/2)+1
   else { a.Do = 2 * D; a.Ho = 2 * H; a.Wo = 2 * W; }                                           // k3 p1 s2 output_padding 1
   const int ct = cout + cout2;
+#ifndef UFR_CONV3D_VALU_ONLY
+  // whole 16-channel blocks on both sides, channel-last output, one head: the matrix-core kernel
+  if (!ncdhw && cout2 == 0 && weight2 == nullptr) {
+#define UFR_MFMA_CASE(CI, CO, MO) if (cin == CI && cout == CO && mode == MO) return launch_conv_mfma_t<CI, CO, MO>(a, s);
+    // where it wins (per-layer table of tools/dev/conv3d_bwd_probe.py, 3 x 8 x 512 x 640 stage): the stride-1 and stride-2
+    // layers from 32 channels up -- 64 -> 64 0.48 -> 0.17 ms, 32 -> 64 0.30 -> 0.09, 32 -> 32 0.22 -> 0.17, 16 -> 32 0.125
+    // -> 0.096, and the data gradients of the transposed layers, which run as stride-2 convolutions (64 -> 32: 0.31 ->
+    // 0.09).  NOT the 16 -> 16 layer at half resolution (0.26 vs 0.23: bound by re-reading the activations once per tap,
+    // whichever unit multiplies) and not the transposed mode (eight parity classes each staging all 27 taps: 0.27 vs 0.12).
+    UFR_MFMA_CASE(32, 32, kConvS1) UFR_MFMA_CASE(64, 64, kConvS1)
+    UFR_MFMA_CASE(16, 32, kConvS2) UFR_MFMA_CASE(32, 64, kConvS2)
+    UFR_MFMA_CASE(32, 16, kConvS2) UFR_MFMA_CASE(64, 32, kConvS2)      // = data gradients of conv9 / conv7
+#undef UFR_MFMA_CASE
+  }
+#endif
 #define UFR_CONV_CASE(CI, CO, MO, RR) \
   if (cin == CI && ct <= CO && ct > CO - 4 && mode == MO) return launch_conv_t<CI, CO, MO, RR>(a, s);
   // the layers of CostRegNet / CostRegNetWeight with base_channels = 8 (module.py:469-543)

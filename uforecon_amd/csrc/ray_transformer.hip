@@ -34,6 +34,12 @@ namespace ufr {
 #define UFR_RT_C2 1
 #endif
 constexpr int kRtC2 = UFR_RT_C2;
+// The NEXT tile's token rows are requested at the top of an iteration (24 registers): per-phase cycle counters put the
+// K / V and Q GEMMs -- the phases that open with the row-table lookup and the dependent row loads -- at 57 and 72 cycles
+// per MFMA against 33 for MLP0.
+#ifndef UFR_RT_PREFETCH
+#define UFR_RT_PREFETCH 0   // measured round 5: 0.378 vs 0.379 ms per 4096 x 128 launch -- the partner wave already covers those loads (as in round 3)
+#endif
 
 __device__ __forceinline__ void load_ray_tile(const float* __restrict__ token0, const int* __restrict__ tok_row,
                                               const float* __restrict__ order_pe, size_t tok_base, int s_base, int g,
@@ -149,6 +155,9 @@ __global__ void __launch_bounds__(kRtBlock, TAPE ? 2 : UFR_RT_MINW) ray_transfor
   for (int h = 0; h < 8; ++h) KV[h] = splat4(0.f);
 #pragma unroll
   for (int h = 0; h < (TAPE ? 8 : 1); ++h) KVT[h] = splat4(0.f);
+  constexpr bool kPrefetch = UFR_RT_PREFETCH && C2 == 1 && !TAPE;   // (the tape build has no registers to spare)
+  f32x4 xn[6];     // kPrefetch: the next tile's rows, in flight
+  if constexpr (kPrefetch) load_ray_tile(token0, tok_row, order_pe, (size_t)ray * SN, 0, g, j, xn);
   for (int it = 0; it < n_iter; ++it) {
     constexpr int C = 1;
     const bool wrap = it + 1 < n_iter;
@@ -160,7 +169,14 @@ __global__ void __launch_bounds__(kRtBlock, TAPE ? 2 : UFR_RT_MINW) ray_transfor
       const int tile = it * C + c;
       live[c] = tile < n_tiles;
       const int tl = live[c] ? tile : n_tiles - 1;
-      load_ray_tile(token0, tok_row, order_pe, (size_t)ray * SN + tl * 16, tl * 16, g, j, x[c]);
+      if constexpr (kPrefetch) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) x[c][t] = xn[t];
+        const int nx = wrap ? tl + 1 : 0;        // after the last tile: sweep 2's first one
+        load_ray_tile(token0, tok_row, order_pe, (size_t)ray * SN + nx * 16, nx * 16, g, j, xn);
+      } else {
+        load_ray_tile(token0, tok_row, order_pe, (size_t)ray * SN + tl * 16, tl * 16, g, j, x[c]);
+      }
 #pragma unroll
       for (int h = 0; h < 8; ++h) { kt[c][h] = splat4(0.f); vt[c][h] = splat4(0.f); }
     }
@@ -269,7 +285,14 @@ __global__ void __launch_bounds__(kRtBlock, TAPE ? 2 : UFR_RT_MINW) ray_transfor
       const int tile = it * C + c;
       live[c] = tile < n_tiles;
       tbase[c] = (live[c] ? tile : n_tiles - 1) * 16;
-      load_ray_tile(token0, tok_row, order_pe, (size_t)ray * SN + tbase[c], tbase[c], g, j, x[c]);
+      if constexpr (kPrefetch) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) x[c][t] = xn[t];
+        const int nx = (tile + 1 < n_tiles ? tile + 1 : n_tiles - 1) * 16;
+        if (wrap) load_ray_tile(token0, tok_row, order_pe, (size_t)ray * SN + nx, nx, g, j, xn);
+      } else {
+        load_ray_tile(token0, tok_row, order_pe, (size_t)ray * SN + tbase[c], tbase[c], g, j, x[c]);
+      }
 #pragma unroll
       for (int t = 0; t < 6; ++t) q[c][t] = splat4(0.f);
     }

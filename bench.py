@@ -377,6 +377,8 @@ def measure_evalset(a, dev, world, rank):
     net.load_state_dict({k: torch.from_numpy(wz[k]) for k in wz.files}, strict=False)     # the per-ray path's seed-0 weights
     batches = [make_eval_batch(a.height, a.width, a.views, k, dev) for k in range(a.frames)]
     shard = RayShard(a.height, a.width, world, rank)
+    if a.producers is None:      # N > 1: deal the producers over the ranks (replicated ones bound the frame at the encode time)
+        a.producers = "sharded" if world > 1 else "replicated"
     loop = EvalLoop(net, shard, n_streams=a.streams, overlap=not a.no_overlap, producers=a.producers, chunk_rays=a.chunk)
     uni = None
     if a.fixed_uniforms >= 0:
@@ -563,7 +565,12 @@ def main():
     line = measure_frames(a, dev, world, rank)
     if rank == 0:
         if world == 1 and not a.no_secondary and config_name(a) == "configs[1]":
-            line["secondary"] = secondary_measurements(a, dev)
+            try:
+                line["secondary"] = secondary_measurements(a, dev)
+            except Exception as e:  # noqa: BLE001 -- the headline line must reach the driver whatever a secondary leg does
+                import traceback
+                line["secondary_error"] = f"{type(e).__name__}: {e}"
+                traceback.print_exc(file=sys.stderr)
         if world == 1 and config_name(a) == "configs[1]":
             line["projected"] = projection(line)
         line["digest"] = digest(line)

@@ -132,7 +132,11 @@ __device__ __forceinline__ void presim_block(const PreSim& ps, const float* sim,
 // (NV >= 4: a slot is NPAIR * 8 >= 48 floats).  The footprint of a block bounds the CU's occupancy -- of this kernel, and
 // of the mix when it runs beside the transformer kernels of another chunk (side streams): 31 -> 29 KB at NV = 3 (no
 // effect: 4 blocks per CU are enough there), 66 -> 46 KB at NV = 5 (2 -> 3 blocks per CU).
-__global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, const float* __restrict__ ray_o,
+// NVT: the view count as a compile-time constant (round 5): the item / NV, item / npair divisions and the pair-index walk
+// of the cooperative loops sit in the address chains of the gathers; as run-time values they were 143 32-bit multiplies
+// and two ~20-instruction divisions per item.
+template <int NVT>
+__global__ void __launch_bounds__(64 * NVT) gather_kernel(FrameDev f, PreSim ps, const float* __restrict__ ray_o,
                                                       int o_stride, const float* __restrict__ ray_d,
                                                       const float* __restrict__ zval, int P, int SN,
                                                       float* __restrict__ x_tokens, float* __restrict__ x_point,
@@ -143,17 +147,17 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
                                                       const float* __restrict__ vol24_in,
                                                       const float* __restrict__ sim8_in) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int NV = f.NV;
-  const int npair = NV * (NV - 1) / 2;
+  constexpr int NV = NVT;
+  constexpr int npair = NV * (NV - 1) / 2;
   float* sh_sim = smem;                        // 64*npair*8
   float* sh_tapF = sh_sim + 64 * npair * 8;    // NV*64*8: feature-map footprint (align_corners=False, zeros)
   float* sh_tapM = sh_tapF + NV * 64 * 8;      // NV*64*8: matching-map footprint (align_corners=True, border)
   float* sh_vol = sh_tapF;                     // 64*(NV-1)*25, written after the last footprint read
-  const int sim_slot = npair * 8;              // floats per point in sh_sim
-  const bool out_in_sim = sim_slot >= 48;      // [64][40] = frustum blend 24 | pre_sim_mlp 16 ...
-  const int region2 = 2 * NV * 64 * 8 > 64 * (NV - 1) * 25 ? 2 * NV * 64 * 8 : 64 * (NV - 1) * 25;
+  constexpr int sim_slot = npair * 8;              // floats per point in sh_sim
+  constexpr bool out_in_sim = sim_slot >= 48;      // [64][40] = frustum blend 24 | pre_sim_mlp 16 ...
+  constexpr int region2 = 2 * NV * 64 * 8 > 64 * (NV - 1) * 25 ? 2 * NV * 64 * 8 : 64 * (NV - 1) * 25;
   float* sh_out = out_in_sim ? sh_sim + 8 : sh_tapF + region2;   // ... behind the point's 8 pre_sim_mlp inputs, or on its own
-  const int out_stride = out_in_sim ? sim_slot : 40;
+  constexpr int out_stride = out_in_sim ? sim_slot : 40;
 
   const int v = threadIdx.x >> 6, p = threadIdx.x & 63;
   // XCD-aware block -> point-group map: workgroups are dealt round-robin to the 8 XCDs (private L2 each), so
@@ -237,7 +241,8 @@ __global__ void __launch_bounds__(448) gather_kernel(FrameDev f, PreSim ps, cons
   __syncthreads();
 
   // ---- cooperative 32-channel gathers: lane group of 8 = one footprint, lane c8 = channels 4*c8..4*c8+3
-  const int c8 = threadIdx.x & 7, grp = threadIdx.x >> 3, n_grp = blockDim.x >> 3;
+  const int c8 = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  constexpr int n_grp = 64 * NV / 8;
   // image features of (point, view) -> token columns 0..31 (ray_transformer.py:222-226)
 #ifdef UFR_GABL_NOCOOP  // ablation build: no 32-channel gathers (timing only)
   if (false)
@@ -372,8 +377,16 @@ hipError_t launch_gather(const FrameDev& f, const PreSim& ps, const float* ray_o
   const int npair = NV * (NV - 1) / 2;
   const size_t taps = 2 * (size_t)NV * 64 * 8, volp = (size_t)64 * (NV - 1) * 25, outv = npair * 8 >= 48 ? 0 : 64 * 40;
   size_t lds = sizeof(float) * ((size_t)64 * npair * 8 + (taps > volp ? taps : volp) + outv);
-  hipLaunchKernelGGL(gather_kernel, dim3((P + 63) / 64), dim3(64 * NV), lds, s, f, ps, ray_o, o_stride, ray_d, z, P, SN,
-                     x_tokens, x_point, rgb, dir, sim8, vol24, xy, mask_z, vol24_in, sim8_in);
+  switch (NV) {
+#define UFR_GATHER_CASE(N)                                                                                                   \
+    case N:                                                                                                                  \
+      hipLaunchKernelGGL(gather_kernel<N>, dim3((P + 63) / 64), dim3(64 * N), lds, s, f, ps, ray_o, o_stride, ray_d, z, P, SN, \
+                         x_tokens, x_point, rgb, dir, sim8, vol24, xy, mask_z, vol24_in, sim8_in);                          \
+      break;
+    UFR_GATHER_CASE(2) UFR_GATHER_CASE(3) UFR_GATHER_CASE(4) UFR_GATHER_CASE(5) UFR_GATHER_CASE(6) UFR_GATHER_CASE(7)
+#undef UFR_GATHER_CASE
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

@@ -86,11 +86,17 @@ __global__ void __launch_bounds__(256) conv3d_kernel(Conv3dArgs a) {
     vz[r] = (int)(n % Ds);
     vb[r] = (int)(n / Ds);
   }
-  float acc[R][COUT];
+  // accumulators as PAIRS of output channels: the multiply-adds below are written on 2-vectors so that they become
+  // v_pk_fma_f32 (two IEEE fmas per instruction: the same bits as the scalar form; no MFMA runs beside this kernel for the
+  // packed form to disturb).  Measured round 5: halving the FMA instructions changes NOTHING (heads 0.58 ms either way),
+  // and neither do four voxels per thread (half the LDS weight reads per FMA): the full-resolution layers are bound by
+  // neither the VALU nor the LDS -- the 27 bounds-checked neighbour loads per voxel and their address arithmetic remain
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 acc[R][COUT / 2];
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int c = 0; c < COUT; ++c) acc[r][c] = 0.f;
+    for (int c = 0; c < COUT / 2; ++c) acc[r][c] = f32x2{0.f, 0.f};
 
   for (int t0 = 0; t0 < n_taps; t0 += TC) {
     const int tn = (n_taps - t0) < TC ? (n_taps - t0) : TC;
@@ -140,12 +146,12 @@ __global__ void __launch_bounds__(256) conv3d_kernel(Conv3dArgs a) {
 #pragma unroll
         for (int c4 = 0; c4 < COUT / 4; ++c4) {
           const f32x4 w = w4[ci * (COUT / 4) + c4];          // same address in every lane: LDS broadcast
+          const f32x2 wlo = {w[0], w[1]}, whi = {w[2], w[3]};
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            acc[r][4 * c4 + 0] = fmaf(w[0], x[r][ci], acc[r][4 * c4 + 0]);
-            acc[r][4 * c4 + 1] = fmaf(w[1], x[r][ci], acc[r][4 * c4 + 1]);
-            acc[r][4 * c4 + 2] = fmaf(w[2], x[r][ci], acc[r][4 * c4 + 2]);
-            acc[r][4 * c4 + 3] = fmaf(w[3], x[r][ci], acc[r][4 * c4 + 3]);
+            const f32x2 xx = {x[r][ci], x[r][ci]};
+            acc[r][2 * c4 + 0] = __builtin_elementwise_fma(wlo, xx, acc[r][2 * c4 + 0]);
+            acc[r][2 * c4 + 1] = __builtin_elementwise_fma(whi, xx, acc[r][2 * c4 + 1]);
           }
         }
     }
@@ -161,7 +167,7 @@ __global__ void __launch_bounds__(256) conv3d_kernel(Conv3dArgs a) {
     float y[COUT];
 #pragma unroll
     for (int c = 0; c < COUT; ++c) {
-      float v = acc[r][c];
+      float v = acc[r][c >> 1][c & 1];
       if (c < a.cout_real) {
         if (a.bias) v += a.bias[c];
         if (a.scale) v = fmaf(v, a.scale[c], a.shift[c]);

@@ -37,6 +37,9 @@ constexpr int kRtC2 = UFR_RT_C2;
 // The NEXT tile's token rows are requested at the top of an iteration (24 registers): per-phase cycle counters put the
 // K / V and Q GEMMs -- the phases that open with the row-table lookup and the dependent row loads -- at 57 and 72 cycles
 // per MFMA against 33 for MLP0.
+#ifndef UFR_RT_LOCAL_DEN
+#define UFR_RT_LOCAL_DEN 1   // forward-only build: the ones column in every lane group's padding slot (see the KV accumulation)
+#endif
 #ifndef UFR_RT_PREFETCH
 #define UFR_RT_PREFETCH 0   // measured round 5: 0.378 vs 0.379 ms per 4096 x 128 launch -- the partner wave already covers those loads (as in round 3)
 #endif
@@ -209,7 +212,10 @@ __global__ void __launch_bounds__(kRtBlock, TAPE ? 2 : UFR_RT_MINW) ray_transfor
     // consecutive matrix instructions add into different accumulators (a head's own four still run r = 0..3: same bits).
     // Written per (head, register) this phase compiled into 32 x {exec-masked elu, a uniform branch around an IEEE
     // division, one MFMA}: 128 branches per tile and nothing for the scheduler to overlap.
-    const float pad_v = j == 3 ? 1.f : 0.f;                                               // ones column (slot 3) -> sum of K'
+    // ones column -> sum of K'.  The forward-only build puts it into EVERY lane group's padding slot (3, 7, 11, 15): the
+    // normaliser Q'.sum K' then comes out of the message MFMAs in register 3 of every lane group -- no cross-lane exchange
+    // (8 ds_bpermute round trips per tile); the tape build keeps slot 3 alone (the backward reads the state's layout)
+    const float pad_v = (!(UFR_RT_LOCAL_DEN && !TAPE) ? j == 3 : (j & 3) == 3) ? 1.f : 0.f;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       float kk[8][4], vv[8][4];
@@ -327,7 +333,7 @@ __global__ void __launch_bounds__(kRtBlock, TAPE ? 2 : UFR_RT_MINW) ray_transfor
           acc = mfma16(kvh[qd], qq, acc);            // rows = V slots: sum_d KV[d][v] Q'[d]; slot 3 = Q'.sum(K')
 #endif
         });
-        const float den = __shfl(acc[3], j);         // slot 3 lives in lane group 0, register 3
+        const float den = (UFR_RT_LOCAL_DEN && !TAPE) ? acc[3] : __shfl(acc[3], j);   // every group's own / slot 3 of lane group 0
         const float Z = fast_rcp(den + 1e-6f);         // linear_attention.py:43
         const float zs = Z * (float)SN;              // :44
         if constexpr (TAPE) zs_all[h] = zs;

@@ -618,8 +618,273 @@ __global__ void __launch_bounds__(256) channel_sum_kernel(const float* __restric
   }
 }
 
+// ---- weight gradients on the matrix cores (round 5): dW_k[a][b] = sum over voxel pairs of TP[p][a] TQ[q_k(p)][b] IS a
+// matrix product with the VOXELS as the k axis -- v_mfma_f32_16x16x4_f32 takes four voxel pairs per instruction, exact fp32.
+// Lane (i, kk) supplies TP[p0 + kk][a0 + i] as the A operand and TQ[q_k(p0 + kk)][b0 + i] as the B operand (a wave-load =
+// four 64-byte channel runs); the accumulator tiles (rows a, columns b) of NT consecutive taps live in registers across the
+// whole voxel range of the wave, so TP is read once per NT taps, the neighbours TQ[q_k] of consecutive taps hit in the L1,
+// and there is no LDS stage and no barrier in the loop.  Every load is UNCONDITIONAL (address clamped to element 0, value
+// selected afterwards): a load under a divergent condition is a branch with its own wait, and a chain of them made the
+// first version of this kernel 3x slower than the VALU one.  blockIdx.y = tap group; the block's four waves split its voxel
+// range and are summed through LDS before ONE atomic per value and block.
+// Operand loads of the two kernels below go through BUFFER descriptors: a neighbour outside the volume (or a voxel past the
+// wave's range) gets the offset kWgOut, which is past the descriptor's extent, and the hardware returns 0 -- no branch, no
+// select, and nothing for the compiler to sink a load under (with `ok ? p[i] : 0` it moved the load into a divergent block
+// with its own wait, one memory round trip per tap).  The launcher keeps both tensors below 2^31 bytes.
+constexpr unsigned kWgOut = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const float* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float wg_load(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+
+struct WgradVoxel {
+  unsigned base;   // ((b Dq + z S) Hq + y S) Wq + x S: the centre tap's Q voxel
+  int z, y, x;     // z S, y S, x S
+};
+template <int S>
+__device__ __forceinline__ WgradVoxel wgrad_voxel(const WgradArgs& a, unsigned n) {
+  WgradVoxel v;
+  v.x = (int)(n % (unsigned)a.Wp) * S;
+  unsigned m = n / (unsigned)a.Wp;
+  v.y = (int)(m % (unsigned)a.Hp) * S;
+  m /= (unsigned)a.Hp;
+  v.z = (int)(m % (unsigned)a.Dp) * S;
+  const unsigned b = m / (unsigned)a.Dp;
+  v.base = ((b * (unsigned)a.Dq + v.z) * (unsigned)a.Hq + v.y) * (unsigned)a.Wq + v.x;
+  return v;
+}
+
+template <int CA, int CB, int S, int NT>
+__global__ void __launch_bounds__(256) conv3d_wgrad_mfma_kernel(WgradArgs a) {
+  static_assert(CA % 16 == 0 && CB % 16 == 0 && 27 % NT == 0, "whole 16-channel tiles, whole tap groups");
+  constexpr int NA = CA / 16, NB = CB / 16;
+  __shared__ __attribute__((aligned(16))) f32x4 red[NT * NA * NB][64];
+  const int k0 = blockIdx.y * NT;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
+  f32x4 acc[NT][NA][NB];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int ta = 0; ta < NA; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < NB; ++tb) acc[t][ta][tb] = splat4(0.f);
+  const unsigned first = blockIdx.x * (unsigned)a.vox_per_block;
+  const unsigned last = first + a.vox_per_block < (unsigned)a.n_p ? first + a.vox_per_block : (unsigned)a.n_p;
+  const unsigned per_wave = (unsigned)a.vox_per_block / 4;        // a multiple of 4 (launcher)
+  const unsigned w0 = first + wave * per_wave, w1 = w0 + per_wave < last ? w0 + per_wave : last;
+  // two operand sets in flight: the loads of the next four voxel pairs are issued before the MFMAs of the current ones (a
+  // wave otherwise spends two memory round trips per step with nothing to do; occupancy is 1-3 waves per SIMD)
+  struct Operands {
+    float ap[NA], bq[NT][NB];
+  };
+  const __amdgpu_buffer_rsrc_t rp = wg_rsrc(a.tp, (unsigned)a.n_p * CA * 4u);
+  const __amdgpu_buffer_rsrc_t rq = wg_rsrc(a.tq, (unsigned)(a.B * a.Dq * a.Hq * a.Wq) * CB * 4u);
+  auto load = [&](unsigned p0, Operands& o) {
+    const unsigned n = p0 + kk;
+    const bool okp = n < w1;
+    const unsigned nn = okp ? n : w0;
+    const WgradVoxel v = wgrad_voxel<S>(a, nn);
+    const unsigned poff = okp ? (nn * CA + i) * 4u : kWgOut;
+#pragma unroll
+    for (int ta = 0; ta < NA; ++ta) o.ap[ta] = wg_load(rp, poff + 64u * ta);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int k = k0 + t, dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;       // wave-uniform
+      const bool ok = okp && (unsigned)(v.z + dz) < (unsigned)a.Dq && (unsigned)(v.y + dy) < (unsigned)a.Hq &&
+                      (unsigned)(v.x + dx) < (unsigned)a.Wq;
+      const unsigned qoff = ok ? ((v.base + (unsigned)((dz * a.Hq + dy) * a.Wq + dx)) * CB + i) * 4u : kWgOut;
+#pragma unroll
+      for (int tb = 0; tb < NB; ++tb) o.bq[t][tb] = wg_load(rq, qoff + 64u * tb);
+    }
+  };
+  auto contract = [&](const Operands& o) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int ta = 0; ta < NA; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < NB; ++tb) acc[t][ta][tb] = mfma16(o.ap[ta], o.bq[t][tb], acc[t][ta][tb]);
+  };
+  if (w0 < w1) {
+    Operands A, B;
+    load(w0, A);
+    for (unsigned p0 = w0; p0 < w1; p0 += 8) {      // (a set past the end is zeros: at most one idle contraction)
+      load(p0 + 4, B);
+      contract(A);
+      load(p0 + 8, A);
+      contract(B);
+    }
+  }
+  // the four waves' partial tiles -> wave 0 (three rounds through one tile set of LDS), then one atomic per value
+  for (int w = 1; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int ta = 0; ta < NA; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < NB; ++tb) red[(t * NA + ta) * NB + tb][lane] = acc[t][ta][tb];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int ta = 0; ta < NA; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < NB; ++tb) acc[t][ta][tb] += red[(t * NA + ta) * NB + tb][lane];
+    }
+  }
+  if (wave == 0) {     // lane (g, j): rows a = 16 ta + 4 g + r, column b = 16 tb + j
+    const int g = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int ta = 0; ta < NA; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < NB; ++tb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float x = acc[t][ta][tb][r];
+            if (x != 0.f) atomicAdd(a.dw + ((size_t)(16 * ta + 4 * g + r) * CB + 16 * tb + j) * 27 + k0 + t, x);
+          }
+  }
+}
+
+// ... and the layers with 8 channels on the fine side (the 8 x 8 head at full resolution, 16 x 8 of conv1 / conv11): TWO taps
+// share an instruction -- columns (t, b) = 2 taps x 8 channels, rows a (8 of 16 used for CA = 8); the 27 taps are 14
+// instructions per four voxel pairs, TP[p] is loaded once for all of them.  The validity of the 27 neighbours is one bit
+// mask per voxel; the lane's tap of pair m is bit 2 m of the mask shifted by the lane's half.
+template <int CA, int S>
+__global__ void __launch_bounds__(256) conv3d_wgrad_mfma8_kernel(WgradArgs a) {
+  static_assert(CA == 8 || CA == 16, "rows");
+  constexpr int CB = 8, NP = 14;                       // tap pairs (2 m, 2 m + 1); the last one is tap 26 alone
+  __shared__ __attribute__((aligned(16))) f32x4 red[NP][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4, h = i >> 3;
+  f32x4 acc[NP];
+#pragma unroll
+  for (int m = 0; m < NP; ++m) acc[m] = splat4(0.f);
+  const unsigned first = blockIdx.x * (unsigned)a.vox_per_block;
+  const unsigned last = first + a.vox_per_block < (unsigned)a.n_p ? first + a.vox_per_block : (unsigned)a.n_p;
+  const unsigned per_wave = (unsigned)a.vox_per_block / 4;
+  const unsigned w0 = first + wave * per_wave, w1 = w0 + per_wave < last ? w0 + per_wave : last;
+  const int HW = a.Hq * a.Wq;
+  struct Operands {
+    float ap, bq[NP];
+  };
+  const __amdgpu_buffer_rsrc_t rp = wg_rsrc(a.tp, (unsigned)a.n_p * CA * 4u);
+  const __amdgpu_buffer_rsrc_t rq = wg_rsrc(a.tq, (unsigned)(a.B * a.Dq * a.Hq * a.Wq) * CB * 4u);
+  auto load = [&](unsigned p0, Operands& o) {
+    const unsigned n = p0 + kk;
+    const bool okp = n < w1;
+    const unsigned nn = okp ? n : w0;
+    const WgradVoxel v = wgrad_voxel<S>(a, nn);
+    o.ap = wg_load(rp, (okp && i < CA) ? (nn * CA + i) * 4u : kWgOut);
+    // 27 validity bits, bit k = tap k
+    unsigned mx = 0, my = 0, mz = 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      mx |= ((unsigned)(v.x + d - 1) < (unsigned)a.Wq ? 1u : 0u) << d;
+      my |= ((unsigned)(v.y + d - 1) < (unsigned)a.Hq ? 1u : 0u) << d;
+      mz |= ((unsigned)(v.z + d - 1) < (unsigned)a.Dq ? 1u : 0u) << d;
+    }
+    const unsigned m9 = ((my & 1u) ? mx : 0u) | ((my & 2u) ? mx << 3 : 0u) | ((my & 4u) ? mx << 6 : 0u);
+    unsigned m27 = ((mz & 1u) ? m9 : 0u) | ((mz & 2u) ? m9 << 9 : 0u) | ((mz & 4u) ? m9 << 18 : 0u);
+    m27 = okp ? m27 >> h : 0u;
+    const unsigned lane_base = v.base * CB + (unsigned)(i & 7);
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+      const int ka = 2 * m, kb = 2 * m + 1 < 27 ? 2 * m + 1 : 26;
+      const int da = ((ka / 9 - 1) * HW + ((ka / 3) % 3 - 1) * a.Wq + ka % 3 - 1) * CB;      // wave-uniform
+      const int db = ((kb / 9 - 1) * HW + ((kb / 3) % 3 - 1) * a.Wq + kb % 3 - 1) * CB;
+      const bool ok = (m27 >> (2 * m)) & 1u;
+      o.bq[m] = wg_load(rq, ok ? (lane_base + (unsigned)(h ? db : da)) * 4u : kWgOut);
+    }
+  };
+  auto contract = [&](const Operands& o) {
+#pragma unroll
+    for (int m = 0; m < NP; ++m) acc[m] = mfma16(o.ap, o.bq[m], acc[m]);
+  };
+  if (w0 < w1) {
+    Operands A, B;
+    load(w0, A);
+    for (unsigned p0 = w0; p0 < w1; p0 += 8) {      // (two operand sets in flight, as above)
+      load(p0 + 4, B);
+      contract(A);
+      load(p0 + 8, A);
+      contract(B);
+    }
+  }
+  for (int w = 1; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int m = 0; m < NP; ++m) red[m][lane] = acc[m];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int m = 0; m < NP; ++m) acc[m] += red[m][lane];
+    }
+  }
+  if (wave == 0) {     // lane (g, j): rows a = 4 g + r, column j = (tap 2 m + (j >> 3), b = j & 7)
+    const int g = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int m = 0; m < NP; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int aa = 4 * g + r, k = 2 * m + (j >> 3);
+        const float x = acc[m][r];
+        if (aa < CA && k < 27 && x != 0.f) atomicAdd(a.dw + ((size_t)aa * CB + (j & 7)) * 27 + k, x);
+      }
+  }
+}
+
+#ifndef UFR_CONV3D_WGRAD_MFMA
+#define UFR_CONV3D_WGRAD_MFMA 1
+#endif
+#ifndef UFR_WG_NT_SMALL
+#define UFR_WG_NT_SMALL 9
+#endif
+#ifndef UFR_WG_NT_MID
+#define UFR_WG_NT_MID 3
+#endif
+#ifndef UFR_WG_TAP_BLOCKS
+#define UFR_WG_TAP_BLOCKS 96
+#endif
+#ifndef UFR_WG_M8_BLOCKS
+#define UFR_WG_M8_BLOCKS 1536
+#endif
 template <int CA, int CB, int S>
 hipError_t launch_wgrad_t(WgradArgs a, hipStream_t s) {
+#if UFR_CONV3D_WGRAD_MFMA
+  // (the MFMA kernels address both tensors with 32-bit byte offsets below kWgOut)
+  const bool small = a.n_p * CA * 4 < (1ll << 31) && (long long)a.B * a.Dq * a.Hq * a.Wq * CB * 4 < (1ll << 31);
+  if constexpr (CA % 16 == 0 && CB % 16 == 0) {
+    if (small) {
+    constexpr int NT = CA * CB <= 256 ? UFR_WG_NT_SMALL : CA * CB <= 1024 ? UFR_WG_NT_MID : 1;      // 4 NT (CA/16) (CB/16) accumulator registers
+    // (the kernel is latency-bound per wave: the more waves in flight the better, up to a few per SIMD)
+    long long blocks = (a.n_p + 1023) / 1024;
+    if (blocks > UFR_WG_TAP_BLOCKS * NT) blocks = UFR_WG_TAP_BLOCKS * NT;
+    a.vox_per_block = (int)(((a.n_p + blocks - 1) / blocks + 15) / 16 * 16);
+    blocks = (a.n_p + a.vox_per_block - 1) / a.vox_per_block;
+    hipLaunchKernelGGL((conv3d_wgrad_mfma_kernel<CA, CB, S, NT>), dim3((unsigned)blocks, 27 / NT), dim3(256), 0, s, a);
+    return hipGetLastError();
+    }
+  } else if constexpr (CB == 8 && (CA == 8 || CA == 16)) {
+    if (small) {
+    long long blocks = (a.n_p + 1023) / 1024;
+    if (blocks > UFR_WG_M8_BLOCKS) blocks = UFR_WG_M8_BLOCKS;
+    a.vox_per_block = (int)(((a.n_p + blocks - 1) / blocks + 15) / 16 * 16);
+    blocks = (a.n_p + a.vox_per_block - 1) / a.vox_per_block;
+    hipLaunchKernelGGL((conv3d_wgrad_mfma8_kernel<CA, S>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+    }
+  }
+#endif
   if constexpr (CB <= 8 && CA * CB <= 128) {
     // CAG coarse-side channels per thread (CAG CB <= 64), the groups on blockIdx.y; NT taps per pass (NT CAG CB <= 192), the
     // passes on blockIdx.z

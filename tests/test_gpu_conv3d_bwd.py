@@ -45,6 +45,32 @@ def test_single_layer_gradients(mode, cin, cout):
         assert _rel(d_in2, cl(x.grad) + extra) < 2e-5
 
 
+# volumes large enough for the matrix-core weight-gradient kernels (conv3d.hip launch_wgrad_t: >= 100 000 voxel pairs for
+# the 16-channel tiles, >= 500 000 for the 8-channel layers); widths that are not whole segments / not multiples of four
+@pytest.mark.parametrize("mode,cin,cout,dims", [
+    (ops.CONV3D_S1, 16, 16, (16, 64, 104)), (ops.CONV3D_S1, 32, 32, (16, 64, 104)), (ops.CONV3D_S1, 64, 64, (16, 64, 104)),
+    (ops.CONV3D_S2, 16, 32, (32, 128, 208)), (ops.CONV3D_S2, 32, 64, (32, 128, 208)),
+    (ops.CONV3D_T2, 32, 16, (16, 64, 104)), (ops.CONV3D_T2, 64, 32, (16, 64, 104)),
+    (ops.CONV3D_S1, 8, 8, (16, 128, 250)), (ops.CONV3D_S2, 8, 16, (32, 256, 500)), (ops.CONV3D_T2, 16, 8, (16, 128, 250))])
+def test_weight_gradients_at_matrix_core_sizes(mode, cin, cout, dims):
+    """ufr_conv3d_bwd_weight where it runs on the fp32 MFMA kernels, against torch's autograd of the same convolution (two
+    fp32 sums of 1e5 .. 5e5 terms in different orders: 1e-4 of the tensor's scale)."""
+    g = torch.Generator().manual_seed(cin * 100 + cout + mode)
+    D, H, W = dims
+    x = torch.randn(1, cin, D, H, W, generator=g).to(DEV)
+    if mode == ops.CONV3D_T2:
+        conv = torch.nn.ConvTranspose3d(cin, cout, 3, stride=2, padding=1, output_padding=1)
+    else:
+        conv = torch.nn.Conv3d(cin, cout, 3, stride=2 if mode == ops.CONV3D_S2 else 1, padding=1)
+    conv = conv.to(DEV)
+    y = conv(x)
+    d_out = torch.randn(y.shape, generator=g).to(DEV)
+    y.backward(d_out)
+    cl = lambda t: t.detach().permute(0, 2, 3, 4, 1).contiguous()
+    dw, db = ops.conv3d_bwd_weight(cl(x), cl(d_out), mode, conv.weight.shape)
+    assert _rel(dw, conv.weight.grad) < 1e-4 and _rel(db, conv.bias.grad) < 1e-4
+
+
 @pytest.mark.parametrize("shape", [(3, 8, 16, 24), (1, 16, 8, 8)])
 def test_cost_reg_net_weight_gradients_match_autograd_of_the_reference_expression(shape):
     """The whole network: parameters' and input's gradients of a scalar function of both heads, HIP forward + backward

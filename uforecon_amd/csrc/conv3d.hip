@@ -429,6 +429,7 @@ struct WgradArgs {
   int B, Dp, Hp, Wp, Dq, Hq, Wq;
   long long n_p;     // B Dp Hp Wp
   int vox_per_block;
+  int seg, nseg;      // the matrix-core kernels: a wave's unit = seg voxels of a row, nseg of them per row
 };
 
 namespace {
@@ -621,17 +622,20 @@ __global__ void __launch_bounds__(256) channel_sum_kernel(const float* __restric
 // ---- weight gradients on the matrix cores (round 5): dW_k[a][b] = sum over voxel pairs of TP[p][a] TQ[q_k(p)][b] IS a
 // matrix product with the VOXELS as the k axis -- v_mfma_f32_16x16x4_f32 takes four voxel pairs per instruction, exact fp32.
 // Lane (i, kk) supplies TP[p0 + kk][a0 + i] as the A operand and TQ[q_k(p0 + kk)][b0 + i] as the B operand (a wave-load =
-// four 64-byte channel runs); the accumulator tiles (rows a, columns b) of NT consecutive taps live in registers across the
-// whole voxel range of the wave, so TP is read once per NT taps, the neighbours TQ[q_k] of consecutive taps hit in the L1,
-// and there is no LDS stage and no barrier in the loop.  Every load is UNCONDITIONAL (address clamped to element 0, value
-// selected afterwards): a load under a divergent condition is a branch with its own wait, and a chain of them made the
-// first version of this kernel 3x slower than the VALU one.  blockIdx.y = tap group; the block's four waves split its voxel
-// range and are summed through LDS before ONE atomic per value and block.
-// Operand loads of the two kernels below go through BUFFER descriptors: a neighbour outside the volume (or a voxel past the
-// wave's range) gets the offset kWgOut, which is past the descriptor's extent, and the hardware returns 0 -- no branch, no
-// select, and nothing for the compiler to sink a load under (with `ok ? p[i] : 0` it moved the load into a divergent block
-// with its own wait, one memory round trip per tap).  The launcher keeps both tensors below 2^31 bytes.
-constexpr unsigned kWgOut = 0x80000000u;
+// four 64-byte channel runs); the accumulator tiles (rows a, columns b) of NT consecutive taps stay in registers for the
+// whole launch, TP is read once per NT taps and the neighbours TQ[q_k] of consecutive taps hit in the L1.  No LDS stage, no
+// barrier in the loop.
+//
+// What bounds these kernels is the address arithmetic around each 32-cycle MFMA, so the work unit is a ROW SEGMENT: a wave
+// takes (b, z, y) of the P grid and `seg` consecutive x.  Everything that depends on the row -- the neighbour rows' byte
+// offsets, whether z + dz / y + dy leave the volume -- is wave-uniform and computed once per unit; per step of four voxels a
+// tap costs one add.  Loads go through BUFFER descriptors: an operand that does not exist (a neighbour outside the volume,
+// a voxel past the segment) gets an offset past the descriptor's extent and the hardware returns 0 -- no branch, no select,
+// nothing for the compiler to sink a load under (with `ok ? p[i] : 0` it moved each load into a divergent block with its
+// own wait: one memory round trip per tap).  Two operand sets are in flight: the loads of the next step are issued before
+// the MFMAs of the current one.  The launcher keeps both tensors below 2^30 bytes (else: the VALU kernels above).
+constexpr unsigned kWgOut = 0x80000000u;     // a lane's "no such voxel"; stays out of range after adding a row offset < 2^30
+constexpr unsigned kWgOutRow = 0x40000000u;  // a row's "no such row"; pushes every lane offset (< 2^30, or kWgOut) out of range
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const float* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
 }
@@ -639,21 +643,24 @@ __device__ __forceinline__ float wg_load(__amdgpu_buffer_rsrc_t r, unsigned byte
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
 }
 
-struct WgradVoxel {
-  unsigned base;   // ((b Dq + z S) Hq + y S) Wq + x S: the centre tap's Q voxel
-  int z, y, x;     // z S, y S, x S
+// unit u -> row (b, z, y) of the P grid and the x range [xs, xe) of its segment (all wave-uniform)
+struct WgradUnit {
+  int b, z, y, xs, xe;
 };
-template <int S>
-__device__ __forceinline__ WgradVoxel wgrad_voxel(const WgradArgs& a, unsigned n) {
-  WgradVoxel v;
-  v.x = (int)(n % (unsigned)a.Wp) * S;
-  unsigned m = n / (unsigned)a.Wp;
-  v.y = (int)(m % (unsigned)a.Hp) * S;
-  m /= (unsigned)a.Hp;
-  v.z = (int)(m % (unsigned)a.Dp) * S;
-  const unsigned b = m / (unsigned)a.Dp;
-  v.base = ((b * (unsigned)a.Dq + v.z) * (unsigned)a.Hq + v.y) * (unsigned)a.Wq + v.x;
-  return v;
+__device__ __forceinline__ WgradUnit wgrad_unit(const WgradArgs& a, unsigned u) {
+  WgradUnit w;
+  // (segment-major: the four waves of a block take the same segment of four consecutive rows y, and share the rows
+  // y - 1 .. y + 4 of the fine grid in the L1)
+  const unsigned rows = (unsigned)(a.B * a.Dp * a.Hp);
+  const unsigned sg = u / rows;
+  unsigned r = u % rows;
+  w.y = (int)(r % (unsigned)a.Hp);
+  r /= (unsigned)a.Hp;
+  w.z = (int)(r % (unsigned)a.Dp);
+  w.b = (int)(r / (unsigned)a.Dp);
+  w.xs = (int)sg * a.seg;
+  w.xe = w.xs + a.seg < a.Wp ? w.xs + a.seg : a.Wp;
+  return w;
 }
 
 template <int CA, int CB, int S, int NT>
@@ -662,7 +669,7 @@ __global__ void __launch_bounds__(256) conv3d_wgrad_mfma_kernel(WgradArgs a) {
   constexpr int NA = CA / 16, NB = CB / 16;
   __shared__ __attribute__((aligned(16))) f32x4 red[NT * NA * NB][64];
   const int k0 = blockIdx.y * NT;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
   f32x4 acc[NT][NA][NB];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -670,50 +677,57 @@ __global__ void __launch_bounds__(256) conv3d_wgrad_mfma_kernel(WgradArgs a) {
     for (int ta = 0; ta < NA; ++ta)
 #pragma unroll
       for (int tb = 0; tb < NB; ++tb) acc[t][ta][tb] = splat4(0.f);
-  const unsigned first = blockIdx.x * (unsigned)a.vox_per_block;
-  const unsigned last = first + a.vox_per_block < (unsigned)a.n_p ? first + a.vox_per_block : (unsigned)a.n_p;
-  const unsigned per_wave = (unsigned)a.vox_per_block / 4;        // a multiple of 4 (launcher)
-  const unsigned w0 = first + wave * per_wave, w1 = w0 + per_wave < last ? w0 + per_wave : last;
-  // two operand sets in flight: the loads of the next four voxel pairs are issued before the MFMAs of the current ones (a
-  // wave otherwise spends two memory round trips per step with nothing to do; occupancy is 1-3 waves per SIMD)
+  const __amdgpu_buffer_rsrc_t rp = wg_rsrc(a.tp, (unsigned)a.n_p * CA * 4u);
+  const __amdgpu_buffer_rsrc_t rq = wg_rsrc(a.tq, (unsigned)(a.B * a.Dq * a.Hq * a.Wq) * CB * 4u);
   struct Operands {
     float ap[NA], bq[NT][NB];
   };
-  const __amdgpu_buffer_rsrc_t rp = wg_rsrc(a.tp, (unsigned)a.n_p * CA * 4u);
-  const __amdgpu_buffer_rsrc_t rq = wg_rsrc(a.tq, (unsigned)(a.B * a.Dq * a.Hq * a.Wq) * CB * 4u);
-  auto load = [&](unsigned p0, Operands& o) {
-    const unsigned n = p0 + kk;
-    const bool okp = n < w1;
-    const unsigned nn = okp ? n : w0;
-    const WgradVoxel v = wgrad_voxel<S>(a, nn);
-    const unsigned poff = okp ? (nn * CA + i) * 4u : kWgOut;
-#pragma unroll
-    for (int ta = 0; ta < NA; ++ta) o.ap[ta] = wg_load(rp, poff + 64u * ta);
+  const unsigned units = (unsigned)(a.B * a.Dp * a.Hp) * (unsigned)a.nseg;
+  for (unsigned u = blockIdx.x * 4 + wave; u < units; u += gridDim.x * 4) {
+    const WgradUnit w = wgrad_unit(a, u);
+    const unsigned prow = (unsigned)((w.b * a.Dp + w.z) * a.Hp + w.y) * (unsigned)a.Wp;      // voxel index of the P row
+    unsigned qrow[NT];                                                                       // byte offset of tap t's Q row
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int k = k0 + t, dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;       // wave-uniform
-      const bool ok = okp && (unsigned)(v.z + dz) < (unsigned)a.Dq && (unsigned)(v.y + dy) < (unsigned)a.Hq &&
-                      (unsigned)(v.x + dx) < (unsigned)a.Wq;
-      const unsigned qoff = ok ? ((v.base + (unsigned)((dz * a.Hq + dy) * a.Wq + dx)) * CB + i) * 4u : kWgOut;
-#pragma unroll
-      for (int tb = 0; tb < NB; ++tb) o.bq[t][tb] = wg_load(rq, qoff + 64u * tb);
+      const int k = k0 + t, qz = w.z * S + k / 9 - 1, qy = w.y * S + (k / 3) % 3 - 1;
+      const bool ok = (unsigned)qz < (unsigned)a.Dq && (unsigned)qy < (unsigned)a.Hq;
+      qrow[t] = ok ? (unsigned)((w.b * a.Dq + qz) * a.Hq + qy) * (unsigned)a.Wq * (CB * 4u) : kWgOutRow;
     }
-  };
-  auto contract = [&](const Operands& o) {
+    auto load = [&](int x0, Operands& o) {
+      const int x = x0 + kk;
+      const bool okp = x < w.xe;
+      const unsigned poff = okp ? ((prow + (unsigned)x) * CA + i) * 4u : kWgOut;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+      for (int ta = 0; ta < NA; ++ta) o.ap[ta] = wg_load(rp, poff + 64u * ta);
+      unsigned qx[3];                                  // the lane's byte offset within a Q row, per dx
 #pragma unroll
-      for (int ta = 0; ta < NA; ++ta)
+      for (int d = 0; d < 3; ++d) {
+        const int xq = x * S + d - 1;
+        qx[d] = (okp && (unsigned)xq < (unsigned)a.Wq) ? ((unsigned)xq * CB + i) * 4u : kWgOut;
+      }
 #pragma unroll
-        for (int tb = 0; tb < NB; ++tb) acc[t][ta][tb] = mfma16(o.ap[ta], o.bq[t][tb], acc[t][ta][tb]);
-  };
-  if (w0 < w1) {
+      for (int t = 0; t < NT; ++t) {
+        // (k0 is a multiple of 3 unless NT = 1, where the tap's dx is a wave-uniform pick)
+        const unsigned qxt = NT % 3 == 0 ? qx[t % 3] : (k0 % 3 == 0 ? qx[0] : k0 % 3 == 1 ? qx[1] : qx[2]);
+        const unsigned qoff = qxt + qrow[t];
+#pragma unroll
+        for (int tb = 0; tb < NB; ++tb) o.bq[t][tb] = wg_load(rq, qoff + 64u * tb);
+      }
+    };
+    auto contract = [&](const Operands& o) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int ta = 0; ta < NA; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < NB; ++tb) acc[t][ta][tb] = mfma16(o.ap[ta], o.bq[t][tb], acc[t][ta][tb]);
+    };
     Operands A, B;
-    load(w0, A);
-    for (unsigned p0 = w0; p0 < w1; p0 += 8) {      // (a set past the end is zeros: at most one idle contraction)
-      load(p0 + 4, B);
+    load(w.xs, A);
+    for (int x0 = w.xs; x0 < w.xe; x0 += 8) {      // (a set past the end is zeros: at most one idle contraction)
+      load(x0 + 4, B);
       contract(A);
-      load(p0 + 8, A);
+      load(x0 + 8, A);
       contract(B);
     }
   }
@@ -756,65 +770,66 @@ __global__ void __launch_bounds__(256) conv3d_wgrad_mfma_kernel(WgradArgs a) {
 
 // ... and the layers with 8 channels on the fine side (the 8 x 8 head at full resolution, 16 x 8 of conv1 / conv11): TWO taps
 // share an instruction -- columns (t, b) = 2 taps x 8 channels, rows a (8 of 16 used for CA = 8); the 27 taps are 14
-// instructions per four voxel pairs, TP[p] is loaded once for all of them.  The validity of the 27 neighbours is one bit
-// mask per voxel; the lane's tap of pair m is bit 2 m of the mask shifted by the lane's half.
+// instructions per four voxel pairs, TP[p] is loaded once for all of them.  The lane's tap of pair m is 2 m + h (h = the
+// lane's column half), so the row offsets are per lane here (14 registers per unit); which of its taps look left / right
+// of x is a per-lane constant bit mask, and a step turns "x - 1 / x + 1 leaves the row" into the set of pairs to blank.
 template <int CA, int S>
 __global__ void __launch_bounds__(256) conv3d_wgrad_mfma8_kernel(WgradArgs a) {
   static_assert(CA == 8 || CA == 16, "rows");
   constexpr int CB = 8, NP = 14;                       // tap pairs (2 m, 2 m + 1); the last one is tap 26 alone
   __shared__ __attribute__((aligned(16))) f32x4 red[NP][64];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4, h = i >> 3;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4, h = i >> 3;
   f32x4 acc[NP];
 #pragma unroll
   for (int m = 0; m < NP; ++m) acc[m] = splat4(0.f);
-  const unsigned first = blockIdx.x * (unsigned)a.vox_per_block;
-  const unsigned last = first + a.vox_per_block < (unsigned)a.n_p ? first + a.vox_per_block : (unsigned)a.n_p;
-  const unsigned per_wave = (unsigned)a.vox_per_block / 4;
-  const unsigned w0 = first + wave * per_wave, w1 = w0 + per_wave < last ? w0 + per_wave : last;
-  const int HW = a.Hq * a.Wq;
+  const __amdgpu_buffer_rsrc_t rp = wg_rsrc(a.tp, (unsigned)a.n_p * CA * 4u);
+  const __amdgpu_buffer_rsrc_t rq = wg_rsrc(a.tq, (unsigned)(a.B * a.Dq * a.Hq * a.Wq) * CB * 4u);
+  // bit m of mdx[d]: this lane's tap of pair m has dx = d - 1
+  unsigned mdx[3] = {0u, 0u, 0u};
+#pragma unroll
+  for (int m = 0; m < NP; ++m) {
+    const int k = 2 * m + h;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) mdx[d] |= (k % 3 == d ? 1u : 0u) << m;
+  }
   struct Operands {
     float ap, bq[NP];
   };
-  const __amdgpu_buffer_rsrc_t rp = wg_rsrc(a.tp, (unsigned)a.n_p * CA * 4u);
-  const __amdgpu_buffer_rsrc_t rq = wg_rsrc(a.tq, (unsigned)(a.B * a.Dq * a.Hq * a.Wq) * CB * 4u);
-  auto load = [&](unsigned p0, Operands& o) {
-    const unsigned n = p0 + kk;
-    const bool okp = n < w1;
-    const unsigned nn = okp ? n : w0;
-    const WgradVoxel v = wgrad_voxel<S>(a, nn);
-    o.ap = wg_load(rp, (okp && i < CA) ? (nn * CA + i) * 4u : kWgOut);
-    // 27 validity bits, bit k = tap k
-    unsigned mx = 0, my = 0, mz = 0;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      mx |= ((unsigned)(v.x + d - 1) < (unsigned)a.Wq ? 1u : 0u) << d;
-      my |= ((unsigned)(v.y + d - 1) < (unsigned)a.Hq ? 1u : 0u) << d;
-      mz |= ((unsigned)(v.z + d - 1) < (unsigned)a.Dq ? 1u : 0u) << d;
-    }
-    const unsigned m9 = ((my & 1u) ? mx : 0u) | ((my & 2u) ? mx << 3 : 0u) | ((my & 4u) ? mx << 6 : 0u);
-    unsigned m27 = ((mz & 1u) ? m9 : 0u) | ((mz & 2u) ? m9 << 9 : 0u) | ((mz & 4u) ? m9 << 18 : 0u);
-    m27 = okp ? m27 >> h : 0u;
-    const unsigned lane_base = v.base * CB + (unsigned)(i & 7);
+  const unsigned units = (unsigned)(a.B * a.Dp * a.Hp) * (unsigned)a.nseg;
+  for (unsigned u = blockIdx.x * 4 + wave; u < units; u += gridDim.x * 4) {
+    const WgradUnit w = wgrad_unit(a, u);
+    const unsigned prow = (unsigned)((w.b * a.Dp + w.z) * a.Hp + w.y) * (unsigned)a.Wp;
+    // byte offset of (the lane's tap of pair m, channel i & 7) for the voxel x = 0 of the row; "negative" values wrap and come
+    // back in range when x is added, or are blanked because x - 1 is outside
+    unsigned qrow[NP];
 #pragma unroll
     for (int m = 0; m < NP; ++m) {
-      const int ka = 2 * m, kb = 2 * m + 1 < 27 ? 2 * m + 1 : 26;
-      const int da = ((ka / 9 - 1) * HW + ((ka / 3) % 3 - 1) * a.Wq + ka % 3 - 1) * CB;      // wave-uniform
-      const int db = ((kb / 9 - 1) * HW + ((kb / 3) % 3 - 1) * a.Wq + kb % 3 - 1) * CB;
-      const bool ok = (m27 >> (2 * m)) & 1u;
-      o.bq[m] = wg_load(rq, ok ? (lane_base + (unsigned)(h ? db : da)) * 4u : kWgOut);
+      const int k = 2 * m + h, qz = w.z * S + k / 9 - 1, qy = w.y * S + (k / 3) % 3 - 1, dx = k % 3 - 1;
+      const bool ok = k < 27 && (unsigned)qz < (unsigned)a.Dq && (unsigned)qy < (unsigned)a.Hq;
+      qrow[m] = ok ? ((unsigned)((w.b * a.Dq + qz) * a.Hq + qy) * (unsigned)a.Wq + (unsigned)(kk * S + dx)) * (CB * 4u) + (unsigned)(i & 7) * 4u
+                   : kWgOut;
     }
-  };
-  auto contract = [&](const Operands& o) {
+    auto load = [&](int x0, Operands& o) {
+      const int x = x0 + kk;
+      const bool okp = x < w.xe;
+      o.ap = wg_load(rp, (okp && i < CA) ? ((prow + (unsigned)x) * CA + i) * 4u : kWgOut);
+      unsigned blank = 0u;
 #pragma unroll
-    for (int m = 0; m < NP; ++m) acc[m] = mfma16(o.ap, o.bq[m], acc[m]);
-  };
-  if (w0 < w1) {
+      for (int d = 0; d < 3; ++d) blank |= (okp && (unsigned)(x * S + d - 1) < (unsigned)a.Wq) ? 0u : mdx[d];
+      const unsigned xb = (unsigned)x0 * (S * CB * 4u);       // wave-uniform
+#pragma unroll
+      for (int m = 0; m < NP; ++m) o.bq[m] = wg_load(rq, ((blank >> m) & 1u) ? kWgOut : qrow[m] + xb);
+    };
+    auto contract = [&](const Operands& o) {
+#pragma unroll
+      for (int m = 0; m < NP; ++m) acc[m] = mfma16(o.ap, o.bq[m], acc[m]);
+    };
     Operands A, B;
-    load(w0, A);
-    for (unsigned p0 = w0; p0 < w1; p0 += 8) {      // (two operand sets in flight, as above)
-      load(p0 + 4, B);
+    load(w.xs, A);
+    for (int x0 = w.xs; x0 < w.xe; x0 += 8) {
+      load(x0 + 4, B);
       contract(A);
-      load(p0 + 8, A);
+      load(x0 + 8, A);
       contract(B);
     }
   }
@@ -852,36 +867,41 @@ __global__ void __launch_bounds__(256) conv3d_wgrad_mfma8_kernel(WgradArgs a) {
 #ifndef UFR_WG_NT_MID
 #define UFR_WG_NT_MID 3
 #endif
-#ifndef UFR_WG_TAP_BLOCKS
-#define UFR_WG_TAP_BLOCKS 96
+#ifndef UFR_WG_WAVES
+#define UFR_WG_WAVES 4096       // waves in flight per launch: 4 per SIMD
 #endif
-#ifndef UFR_WG_M8_BLOCKS
-#define UFR_WG_M8_BLOCKS 1536
+#ifndef UFR_WG_WAVES8
+#define UFR_WG_WAVES8 3072      // ... 3 per SIMD at the 8-channel kernel's ~150 registers
 #endif
 template <int CA, int CB, int S>
 hipError_t launch_wgrad_t(WgradArgs a, hipStream_t s) {
 #if UFR_CONV3D_WGRAD_MFMA
-  // (the MFMA kernels address both tensors with 32-bit byte offsets below kWgOut)
-  const bool small = a.n_p * CA * 4 < (1ll << 31) && (long long)a.B * a.Dq * a.Hq * a.Wq * CB * 4 < (1ll << 31);
-  if constexpr (CA % 16 == 0 && CB % 16 == 0) {
-    if (small) {
-    constexpr int NT = CA * CB <= 256 ? UFR_WG_NT_SMALL : CA * CB <= 1024 ? UFR_WG_NT_MID : 1;      // 4 NT (CA/16) (CB/16) accumulator registers
-    // (the kernel is latency-bound per wave: the more waves in flight the better, up to a few per SIMD)
-    long long blocks = (a.n_p + 1023) / 1024;
-    if (blocks > UFR_WG_TAP_BLOCKS * NT) blocks = UFR_WG_TAP_BLOCKS * NT;
-    a.vox_per_block = (int)(((a.n_p + blocks - 1) / blocks + 15) / 16 * 16);
-    blocks = (a.n_p + a.vox_per_block - 1) / a.vox_per_block;
-    hipLaunchKernelGGL((conv3d_wgrad_mfma_kernel<CA, CB, S, NT>), dim3((unsigned)blocks, 27 / NT), dim3(256), 0, s, a);
-    return hipGetLastError();
-    }
-  } else if constexpr (CB == 8 && (CA == 8 || CA == 16)) {
-    if (small) {
-    long long blocks = (a.n_p + 1023) / 1024;
-    if (blocks > UFR_WG_M8_BLOCKS) blocks = UFR_WG_M8_BLOCKS;
-    a.vox_per_block = (int)(((a.n_p + blocks - 1) / blocks + 15) / 16 * 16);
-    blocks = (a.n_p + a.vox_per_block - 1) / a.vox_per_block;
-    hipLaunchKernelGGL((conv3d_wgrad_mfma8_kernel<CA, S>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-    return hipGetLastError();
+  // (the matrix-core kernels address both tensors with byte offsets below kWgOutRow)
+  const bool small = a.n_p * CA * 4 < (1ll << 30) && (long long)a.B * a.Dq * a.Hq * a.Wq * CB * 4 < (1ll << 30);
+  constexpr bool kPair = CA % 16 == 0 && CB % 16 == 0, kEight = CB == 8 && (CA == 8 || CA == 16);
+  if constexpr (kPair || kEight) {
+    // measured per layer at the three stages' sizes (tools/dev/conv3d_bwd_probe.py): below these volumes the per-unit setup and the
+    // closing reduction outweigh the contraction, and the VALU kernels below win
+    const bool large = a.n_p >= (kPair ? 100000 : 500000);
+    if (small && large) {
+      // units: whole rows, halved until there are a few per wave slot (never below 32 voxels = 8 steps)
+      const long long rows = (long long)a.B * a.Dp * a.Hp;
+      a.seg = (a.Wp + 3) / 4 * 4;
+      while (rows * ((a.Wp + a.seg - 1) / a.seg) < 4 * UFR_WG_WAVES && a.seg > 32) a.seg = (a.seg / 2 + 3) / 4 * 4;
+      a.nseg = (a.Wp + a.seg - 1) / a.seg;
+      const long long units = rows * a.nseg;
+      if constexpr (kPair) {
+        constexpr int NT = CA * CB <= 256 ? UFR_WG_NT_SMALL : CA * CB <= 1024 ? UFR_WG_NT_MID : 1;   // 4 NT (CA/16) (CB/16) accumulator registers
+        long long blocks = UFR_WG_WAVES / 4 * NT / 27;
+        if (blocks < 16) blocks = 16;
+        if (blocks > (units + 3) / 4) blocks = (units + 3) / 4;
+        hipLaunchKernelGGL((conv3d_wgrad_mfma_kernel<CA, CB, S, NT>), dim3((unsigned)blocks, 27 / NT), dim3(256), 0, s, a);
+      } else {
+        long long blocks = UFR_WG_WAVES8 / 4;       // exactly the resident waves: the units are dealt round-robin
+        if (blocks > (units + 3) / 4) blocks = (units + 3) / 4;
+        hipLaunchKernelGGL((conv3d_wgrad_mfma8_kernel<CA, S>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+      }
+      return hipGetLastError();
     }
   }
 #endif
@@ -916,7 +936,7 @@ hipError_t launch_wgrad_t(WgradArgs a, hipStream_t s) {
 hipError_t launch_conv3d_bwd_weight(const float* in, const float* d_out, float* d_weight, float* d_bias, int B, int D, int H, int W,
                                     int cin, int cout, int mode, hipStream_t s) {
   WgradArgs a;
-  a.dw = d_weight; a.B = B; a.vox_per_block = 0;
+  a.dw = d_weight; a.B = B; a.vox_per_block = 0; a.seg = 0; a.nseg = 0;
   int ca, cb, S;
   long long n_out;
   if (mode == kConvS1) {

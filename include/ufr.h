@@ -32,7 +32,7 @@ enum ufr_status {
 
 /* Version of this header's ABI (argument lists, struct layouts, packed-blob layout).  ufr_version() returns the value
  * the library was built with: a binding must refuse a library whose version differs (uforecon_amd/_lib.py does). */
-#define UFR_ABI_VERSION 500
+#define UFR_ABI_VERSION 501
 
 #define UFR_MAX_VIEWS 7
 #define UFR_NUM_STAGES 3
@@ -270,6 +270,18 @@ int ufr_composite_bwd(const float* z, const float* radiance, const int32_t* row,
                       int32_t RN, int32_t SN, const float* d_rgb, const float* d_depth, const float* d_opacity,
                       const float* d_weight, float* d_radiance, int32_t accumulate, float* d_srdf, float* d_variance,
                       ufr_stream stream);
+
+/* The training loss of a ray batch and its cotangents in one launch (code1/model.py:552-566):
+ *   loss = weight_rgb (mse(rgb_c, rgb_gt) + mse(rgb_f, rgb_gt)) + weight_depth (l1(depth_c, depth_gt | valid) + l1(depth_f, ...)),
+ *   valid = (depth_gt != 0) & (depth_gt >= near) & (depth_gt <= far), the two L1 terms 0 when no ray is valid.
+ * rgb_* (B*RN,3), depth_* (B*RN): both passes' rendered colours / ray depths and the ground truth, batch-major;
+ * near_far: near = near_far[b * nf_stride], far = near_far[b * nf_stride + 1] of batch element b (batch['near_fars'][b, 0]:
+ * nf_stride = V*2).  Outputs: loss[5] = {total, rgb_c, rgb_f, depth_c, depth_f} (the reference logs all five);
+ * d_rgb_c (B*RN,3), d_depth_c (B*RN), d_rgb_f, d_depth_f = d total / d input (sign(0) = 0 in the L1 terms, as torch). */
+int ufr_render_loss(const float* rgb_c, const float* depth_c, const float* rgb_f, const float* depth_f, const float* rgb_gt,
+                    const float* depth_gt, const float* near_far, int32_t nf_stride, int32_t B, int32_t RN, float weight_rgb,
+                    float weight_depth, float* loss, float* d_rgb_c, float* d_depth_c, float* d_rgb_f, float* d_depth_f,
+                    ufr_stream stream);
 
 /* Adjoint of ufr_aggregate (autograd of ray_transformer.py:283-320).  x_tokens / rgb / dir: the forward's inputs;
  * token0 (P,80): the view transformer's token-0 output = the first RN*SN*80 floats of the forward's workspace;

@@ -15,7 +15,7 @@ int main(void) {
       (const void*)ufr_pack_plan_f16, (const void*)ufr_frame_workspace_bytes, (const void*)ufr_frame_prepare,
       (const void*)ufr_sample_fixed, (const void*)ufr_sample_importance_merge, (const void*)ufr_points,
       (const void*)ufr_project_gather, (const void*)ufr_aggregate_workspace_bytes, (const void*)ufr_aggregate,
-      (const void*)ufr_composite, (const void*)ufr_composite_bwd, (const void*)ufr_aggregate_bwd_workspace_bytes,
+      (const void*)ufr_composite, (const void*)ufr_composite_bwd, (const void*)ufr_render_loss, (const void*)ufr_aggregate_bwd_workspace_bytes,
       (const void*)ufr_aggregate_bwd, (const void*)ufr_project_gather_bwd, (const void*)ufr_project_gather_bwd_workspace_bytes, (const void*)ufr_sample_importance_pool, (const void*)ufr_view_transform,
       (const void*)ufr_ray_transform_workspace_bytes, (const void*)ufr_ray_transform, (const void*)ufr_ray_transform_bwd, (const void*)ufr_ray_transform_bwd_workspace_bytes,
       (const void*)ufr_view_transform_bwd, (const void*)ufr_view_transform_bwd_stages, (const void*)ufr_ray_transform_bwd_stages, (const void*)ufr_view_transform_tape, (const void*)ufr_ray_transform_tape,
@@ -35,6 +35,7 @@ int main(void) {
   if (ufr_deform_conv2d(0, 0, 0, 0, 0, 0, 1, 32, 32, 8, 8, 0, 0, 0) >= 0) return 15;
   if (ufr_render_workspace_bytes(4096, 64, 64, 3) == 0) return 16;
   if (ufr_composite_bwd(0, 0, 0, 0, 0, 4, 64, 0, 0, 0, 0, 0, 0, 0, 0, 0) >= 0) return 18;
+  if (ufr_render_loss(0, 0, 0, 0, 0, 0, 0, 2, 1, 4, 1.f, 1.f, 0, 0, 0, 0, 0, 0) >= 0) return 31;
   if (ufr_aggregate_bwd(0, 0, 0, 0, 0, 0, 0, 4, 64, 3, 0, 0, 0, 0, UFR_PRECISION_DEFAULT, 0) >= 0) return 19;
   /* an unknown precision is an argument error, not a silent default */
   if (ufr_view_transform((const void*)1, (const float*)1, (const float*)1, (const float*)1, 4, 3, (float*)1, (float*)1, 7, 0) != UFR_ERR_ARG) return 21;

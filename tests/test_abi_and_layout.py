@@ -64,6 +64,7 @@ def test_argument_errors_are_reported_not_fatal(lib):
                                   None, None, None, None) == -1
     assert b"not prepared" in lib.ufr_last_error()
     assert lib.ufr_composite_bwd(None, None, None, None, None, 4, 64, None, None, None, None, None, 0, None, None, None) == -1
+    assert lib.ufr_render_loss(None, None, None, None, None, None, None, 2, 1, 4, 1.0, 1.0, None, None, None, None, None, None) == -1
     assert lib.ufr_aggregate_bwd(None, None, None, None, None, None, None, 4, 64, 3, None, None, None, None, -1, None) == -1
     assert b"null" in lib.ufr_last_error()
     assert lib.ufr_project_gather_bwd(C.byref(fr), None, None, None, 0, None, None, 1, 16, None, None, None, None, None, 0, None, -1, None) == -1

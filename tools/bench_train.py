@@ -62,6 +62,8 @@ def parse(argv=None):
                          "the warm-up and REPLAY it in the timed region: the ~60 few-microsecond launches of the caller's side "
                          "(loss arithmetic, Adam, re-pack) stop bounding the step.  Single rank, without --cost-reg; the ray "
                          "indices / uniforms of a step are drawn outside the graph into static buffers")
+    ap.add_argument("--torch-loss", action="store_true", help="the loss of model.py:552-566 as torch expressions instead of "
+                    "UFORecon.training_loss (ufr_render_loss): the A/B of the fused loss node")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=64)
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -169,11 +171,25 @@ def run(a, dev, world=1, rank=0):
     U2_buf = torch.zeros(a.fine, a.rays, device=dev)
 
     def draw():
-        idx_buf.copy_(torch.randperm(HW, device=dev, generator=gen)[: a.rays][None])      # model.py:537
+        # model.py:537 takes the first train_ray_num entries of argsort(rand(H W)): a uniform sample without replacement in
+        # random order -- as is the top-k of the same uniforms (a radix select instead of the full sort: ~20 launches fewer)
+        idx_buf.copy_(torch.rand(HW, device=dev, generator=gen).topk(a.rays, sorted=False).indices[None])
         U1_buf.copy_(torch.rand(a.coarse, a.rays, device=dev, generator=gen))
         U2_buf.copy_(torch.rand(a.fine, a.rays, device=dev, generator=gen))
 
+    phase_marks = []      # UFR_BT_PHASES=1 (development): events on the main stream at the phase boundaries of every step
+    want_phases = os.environ.get("UFR_BT_PHASES") == "1"
+
+    def mark(row):
+        if want_phases:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            row.append(e)
+
     def step(drawn: bool = False):
+        row = []
+        phase_marks.append(row)
+        mark(row)
         if not drawn:
             draw()
         idx, U1, U2 = idx_buf, U1_buf, U2_buf
@@ -186,16 +202,24 @@ def run(a, dev, world=1, rank=0):
             for st in ("stage1", "stage2", "stage3"):
                 vf, vw = mvs(f.batch, cost[st])
                 fv[st] = {"feature_volume": vf, "weight_volume": vw}
+        mark(row)
         r = m.infer(f.batch, idx, f.source_imgs_feat, fv, match_feature=f.match_feature, uniforms=(U1, U2))
-        rgb_gt, rgb, depth, depth_gt, rgb2, depth2 = r[0], r[1], r[2], r[3], r[8], r[9]
-        nf = f.batch["near_fars"]
-        mask = (depth_gt != 0) & (depth_gt >= nf[:, 0, 0:1]) & (depth_gt <= nf[:, 0, 1:2])
-        # model.py:552-566.  The masked L1 means are written without boolean indexing: `depth[mask]` makes the host wait for
-        # the forward (it needs the count) before it can enqueue the backward -- same value, no pipeline bubble
-        n_valid = mask.sum().clamp_min(1)
-        l1 = lambda d: ((d - depth_gt).abs() * mask).sum() / n_valid
-        loss = torch.nn.functional.mse_loss(rgb, rgb_gt) + torch.nn.functional.mse_loss(rgb2, rgb_gt) + l1(depth) + l1(depth2)
+        mark(row)
+        if a.torch_loss:
+            # model.py:552-566 as torch expressions (the A/B of --torch-loss).  The masked L1 means are written without
+            # boolean indexing: `depth[mask]` makes the host wait for the forward (it needs the count) before it can enqueue
+            # the backward -- same value, no pipeline bubble
+            rgb_gt, rgb, depth, depth_gt, rgb2, depth2 = r[0], r[1], r[2], r[3], r[8], r[9]
+            nf = f.batch["near_fars"]
+            mask = (depth_gt != 0) & (depth_gt >= nf[:, 0, 0:1]) & (depth_gt <= nf[:, 0, 1:2])
+            n_valid = mask.sum().clamp_min(1)
+            l1 = lambda d: ((d - depth_gt).abs() * mask).sum() / n_valid
+            loss = torch.nn.functional.mse_loss(rgb, rgb_gt) + torch.nn.functional.mse_loss(rgb2, rgb_gt) + l1(depth) + l1(depth2)
+        else:
+            loss, _ = m.training_loss(r, f.batch)      # the same loss as one node on one kernel (ufr_render_loss)
+        mark(row)
         loss.backward()
+        mark(row)
         if world > 1:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -208,6 +232,7 @@ def run(a, dev, world=1, rank=0):
         if a.dump_grads:
             step.last_grads = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
         opt.step()
+        mark(row)
         return loss
 
     def fence():
@@ -248,6 +273,14 @@ def run(a, dev, world=1, rank=0):
             loss = step()
     fence()
     dt = time.perf_counter() - t0
+    if want_phases and rank == 0:
+        rows = [r for r in phase_marks[-a.steps:] if len(r) == 6]
+        names = ("draw+zero_grad", "infer", "loss", "backward", "optimizer")
+        avg = [sum(r[i].elapsed_time(r[i + 1]) for r in rows) / len(rows) for i in range(5)]
+        gaps = sum(rows[i][5].elapsed_time(rows[i + 1][0]) for i in range(len(rows) - 1)) / max(1, len(rows) - 1)
+        print("phases_ms", {n: round(v, 3) for n, v in zip(names, avg)}, "between steps", round(gaps, 3), file=sys.stderr)
+    phase_marks.clear()
+    want_phases = False
     timed_grads = getattr(step, "last_grads", None)
     # per-kernel durations from the same number of extra, UNTIMED steps with the backward's stream overlap switched off
     # (uforecon_amd/autograd.py runs independent stages side by side: overlapped, the HIP-event intervals of the kernels

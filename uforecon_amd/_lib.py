@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # UFR_LIB selects an alternative in-tree build (A/B kernel variants during development)
 LIB_PATH = os.environ.get("UFR_LIB") or os.path.join(HERE, "lib", "libufr.so")
 
-ABI_VERSION = 500   # = UFR_ABI_VERSION of include/ufr.h; load() refuses a library built against another header
+ABI_VERSION = 501   # = UFR_ABI_VERSION of include/ufr.h; load() refuses a library built against another header
 MAX_VIEWS = 7
 NUM_STAGES = 3
 TOKEN_DIM = 80
@@ -95,6 +95,7 @@ SIGNATURES = {
     "ufr_aggregate": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]),
     "ufr_composite": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
     "ufr_composite_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
+    "ufr_render_loss": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp]),
     "ufr_aggregate_bwd_workspace_bytes": (sz, [i32, i32, i32]),
     "ufr_aggregate_bwd": (C.c_int, [C.POINTER(RawWeights), C.POINTER(RawGrads), vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp,
                                     vp, i32, vp]),

@@ -316,6 +316,31 @@ class RenderTwoPass(torch.autograd.Function):
         return (None, None, None, None, None, None, None, *out)
 
 
+class RenderLoss(torch.autograd.Function):
+    """The training loss of a ray batch (code1/model.py:552-566) as ONE node on one kernel (ufr_render_loss): the forward
+    launch also writes d loss / d (rgb, depth, rgb_2, depth_2), the backward scales them by the upstream gradient.
+    ``apply(rgb, depth, rgb_2, depth_2, rgb_gt, depth_gt, near_fars, weight_rgb, weight_depth)`` -> ``loss ()``,
+    ``parts (4,)`` = [rgb coarse, rgb fine, depth coarse, depth fine] (what the reference logs; not differentiable).
+    As torch expressions the same loss is ~25 launches and ~30 autograd nodes over 1 024-ray tensors -- 0.9 ms of a 4.7 ms
+    step with the GPU idle in between (tools/dev/step_timeline.py)."""
+
+    @staticmethod
+    def forward(ctx, rgb, depth, rgb2, depth2, rgb_gt, depth_gt, near_fars, weight_rgb, weight_depth):
+        loss, *cot = ops.render_loss(rgb, depth, rgb2, depth2, rgb_gt, depth_gt, near_fars, weight_rgb, weight_depth)
+        ctx.cot = cot
+        parts = loss[1:]
+        ctx.mark_non_differentiable(parts)
+        return loss[0], parts
+
+    @staticmethod
+    def backward(ctx, g, _gparts):
+        cot, ctx.cot = ctx.cot, None
+        need = ctx.needs_input_grad[:4]
+        out = torch._foreach_mul([c for c, n in zip(cot, need) if n], g)      # one launch
+        it = iter(out)
+        return (*[(next(it) if n else None) for n in need], None, None, None, None, None)
+
+
 class Aggregate(torch.autograd.Function):
     """RayTransformer.forward (ray_transformer.py:175-322) as the reference exposes it: the frustum lookup `fea_volume`
     and the pair similarity cond_info['feat_info'] are INPUTS.  ``apply(frame, weights, points (P,3), RN, SN,

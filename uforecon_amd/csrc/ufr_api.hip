@@ -519,6 +519,20 @@ int ufr_composite_bwd(const float* z, const float* radiance, const int32_t* row,
   return UFR_OK;
 }
 
+int ufr_render_loss(const float* rgb_c, const float* depth_c, const float* rgb_f, const float* depth_f, const float* rgb_gt,
+                    const float* depth_gt, const float* near_far, int32_t nf_stride, int32_t B, int32_t RN, float weight_rgb,
+                    float weight_depth, float* loss, float* d_rgb_c, float* d_depth_c, float* d_rgb_f, float* d_depth_f,
+                    ufr_stream stream) {
+  UFR_REQUIRE(rgb_c && depth_c && rgb_f && depth_f && rgb_gt && depth_gt && near_far && loss && d_rgb_c && d_depth_c && d_rgb_f && d_depth_f,
+              "ufr_render_loss: null argument");
+  UFR_REQUIRE(B > 0 && RN > 0 && nf_stride >= 2 && (long long)B * RN < (1ll << 24), "ufr_render_loss: B=%d RN=%d nf_stride=%d", B, RN, nf_stride);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ProfScope p("render_loss", s);
+  UFR_HIP(launch_render_loss(rgb_c, depth_c, rgb_f, depth_f, rgb_gt, depth_gt, near_far, nf_stride, B, RN, weight_rgb, weight_depth,
+                             loss, d_rgb_c, d_depth_c, d_rgb_f, d_depth_f, s));
+  return UFR_OK;
+}
+
 // The three kernels of the view transformer's backward (bwd_tape.h) over a caller workspace:
 // [tape | dY tiles | token0 scratch | radiance scratch]
 struct ViewBwdWs { float *tape, *dbuf, *token0, *radiance; int blocks; };

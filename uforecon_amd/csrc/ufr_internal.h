@@ -86,6 +86,11 @@ hipError_t launch_ray_transformer(const float* packed, const float* token0, cons
 hipError_t launch_composite(const float* z, const float* radiance, const int* rad_row, const float* srdf,
                             const float* variance, int RN, int SN, float* rgb, float* depth, float* opacity, float* weight,
                             const float* camz, float* depth_z, hipStream_t s);
+// render_loss.hip: the training loss of a ray batch and its cotangents (model.py:552-566), one launch
+hipError_t launch_render_loss(const float* rgb_c, const float* depth_c, const float* rgb_f, const float* depth_f,
+                              const float* rgb_gt, const float* depth_gt, const float* near_far, int nf_stride, int B, int RN,
+                              float weight_rgb, float weight_depth, float* loss, float* d_rgb_c, float* d_depth_c,
+                              float* d_rgb_f, float* d_depth_f, hipStream_t s);
 hipError_t launch_composite_bwd(const float* z, const float* radiance, const int* rad_row, bool accumulate, const float* srdf,
                                 const float* variance, int RN, int SN, const float* d_rgb, const float* d_depth,
                                 const float* d_opacity, const float* d_weight, float* d_radiance, float* d_srdf,

@@ -439,6 +439,18 @@ class UFORecon(nn.Module):
                 z1[None], z2[None], variance)                                                # model.py:480-482
 
     # ---- frame-level entry: the per-ray loop and post-processing of extract_geometry (model.py:810-842)
+    def training_loss(self, outputs, batch):
+        """The loss of ``training_step`` (code1/model.py:552-566) on the 17-tuple ``infer`` returns (model.py:480-482):
+        ``weight_rgb (mse(rgb) + mse(rgb_2)) + weight_depth (l1(depth | valid gt) + l1(depth_2 | valid gt))``, as one
+        autograd node on one kernel (ufr_render_loss).  -> ``loss ()``, ``parts`` = dict of the four terms the reference
+        logs (train/rgb_coarse, rgb_fine, depth_ray_coarse, depth_ray_fine), detached.  GPU only."""
+        rgb_gt, rgb, depth, depth_gt, rgb2, depth2 = (outputs[i] for i in (0, 1, 2, 3, 8, 9))
+        if not depth_gt.is_cuda:
+            raise UfrError("training_loss runs on the GPU only (no CPU implementation; oracle/ufo_oracle.py:training_loss is the checker)")
+        loss, parts = ag.RenderLoss.apply(rgb, depth, rgb2, depth2, rgb_gt, depth_gt, batch["near_fars"],
+                                          float(getattr(self.args, "weight_rgb", 1.0)), float(getattr(self.args, "weight_depth", 1.0)))
+        return loss, {"rgb_coarse": parts[0], "rgb_fine": parts[1], "depth_ray_coarse": parts[2], "depth_ray_fine": parts[3]}
+
     def render_depth_map(self, batch, source_imgs_feat, feature_volume, match_feature, uniforms=None):
         """Every pixel of the render view in ONE call (the reference loops over chunks of ``test_ray_num`` = 800
         rays, model.py:815; here chunking is internal to ufr_render_rays and invisible).  Returns

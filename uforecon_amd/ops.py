@@ -392,6 +392,28 @@ def composite_bwd(z, radiance, srdf, variance, d_rgb, d_depth, d_opacity, d_weig
     return d_radiance, d_srdf, d_variance
 
 
+def render_loss(rgb, depth, rgb2, depth2, rgb_gt, depth_gt, near_fars, weight_rgb: float = 1.0, weight_depth: float = 1.0):
+    """ufr_render_loss (code1/model.py:552-566): both passes' colours (B,RN,3) / ray depths (B,RN), the ground truth of the
+    same shapes, ``near_fars`` = batch['near_fars'] (B,V,2).  -> ``loss (5,)`` = [total, rgb coarse, rgb fine, depth coarse,
+    depth fine] and the cotangents ``d_rgb, d_depth, d_rgb2, d_depth2`` of the total, shaped as the inputs."""
+    B, RN = depth_gt.shape
+    dev = depth_gt.device
+    c = lambda t: t.detach().float().contiguous()
+    rgb, depth, rgb2, depth2, rgb_gt, depth_gt, nf = c(rgb), c(depth), c(rgb2), c(depth2), c(rgb_gt), c(depth_gt), c(near_fars)
+    if tuple(rgb.shape) != (B, RN, 3) or tuple(rgb2.shape) != (B, RN, 3) or tuple(rgb_gt.shape) != (B, RN, 3) or \
+            tuple(depth.shape) != (B, RN) or tuple(depth2.shape) != (B, RN) or nf.shape[0] != B or nf.shape[-1] != 2:
+        raise UfrError(f"render_loss: shapes {tuple(rgb.shape)} {tuple(depth.shape)} {tuple(rgb2.shape)} {tuple(depth2.shape)} "
+                            f"{tuple(rgb_gt.shape)} {tuple(depth_gt.shape)} {tuple(nf.shape)}")
+    out = torch.empty(5 + 8 * B * RN, dtype=torch.float32, device=dev)       # one allocation: loss | d_rgb | d_depth | d_rgb2 | d_depth2
+    n = B * RN
+    loss, d_rgb, d_depth, d_rgb2, d_depth2 = out[:5], out[5:5 + 3 * n], out[5 + 3 * n:5 + 4 * n], out[5 + 4 * n:5 + 7 * n], out[5 + 7 * n:]
+    _lib.check(_lib.load().ufr_render_loss(
+        _dev(rgb, "rgb"), _dev(depth, "depth"), _dev(rgb2, "rgb2"), _dev(depth2, "depth2"), _dev(rgb_gt, "rgb_gt"),
+        _dev(depth_gt, "depth_gt"), _dev(nf, "near_fars"), nf[0].numel(), B, RN, float(weight_rgb), float(weight_depth),
+        loss.data_ptr(), d_rgb.data_ptr(), d_depth.data_ptr(), d_rgb2.data_ptr(), d_depth2.data_ptr(), _stream()), "ufr_render_loss")
+    return loss, d_rgb.view(B, RN, 3), d_depth.view(B, RN), d_rgb2.view(B, RN, 3), d_depth2.view(B, RN)
+
+
 def aggregate_bwd(weights: PackedWeights, grads: GradBuffer, x, rgb, dirs, token0, RN: int, SN: int, d_radiance, d_srdf,
                   precision: Optional[int] = None):
     """-> (d_pv (P,40), {}) -- the empty dict keeps the call sites of the former debug dump (gone with ABI 500)."""

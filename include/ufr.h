@@ -32,7 +32,7 @@ enum ufr_status {
 
 /* Version of this header's ABI (argument lists, struct layouts, packed-blob layout).  ufr_version() returns the value
  * the library was built with: a binding must refuse a library whose version differs (uforecon_amd/_lib.py does). */
-#define UFR_ABI_VERSION 501
+#define UFR_ABI_VERSION 502
 
 #define UFR_MAX_VIEWS 7
 #define UFR_NUM_STAGES 3
@@ -486,6 +486,16 @@ int ufr_tsdf_integrate(float* tsdf, float* weight, float* color, const int32_t* 
                        const float* depth_im, const float* color_im, int32_t im_h, int32_t im_w, float obs_weight,
                        int32_t integrate_color, ufr_stream stream);
 
+/* Pixel-wise view weights of the first cascade stage and the weighted aggregate (DepthNet.forward,
+ * code1/encoder_utils/fmt/TransMVSNet.py:80-97 with PixelwiseNet :23-41), one pass over the similarity volume:
+ *   view_weights[i] = max_d sigmoid(conv2(relu(bn1(conv1(relu(bn0(conv0(similarity[i]))))))))      (1x1x1 convolutions)
+ *   aggregated[d]   = (sum_i similarity[i][d] view_weights[i]) / (1e-5 + sum_i view_weights[i])       (nullable)
+ * similarity [NS][D][H][W], view_weights [NS][H][W], aggregated [D][H][W]: device fp32.  params: 185 device floats
+ * [a0 16 | b0 16 | W1 8x16 | a1 8 | b1 8 | w2 8 | b2 1], the eval-mode BatchNorms folded by the caller: a0 = conv0.weight *
+ * scale0, b0 = shift0, W1 = conv1.weight, a1 = scale1, b1 = shift1, w2 = conv2.weight, b2 = conv2.bias. */
+int ufr_pixelwise_view_weights(const float* similarity, const float* params, float* view_weights, float* aggregated, int32_t NS,
+                               int32_t D, int32_t H, int32_t W, ufr_stream stream);
+
 /* ---- deformable convolution of the feature backbone -------------------------------------------------------
  * Replaces torchvision.ops.deform_conv2d as called by DCN.forward (code1/encoder_utils/fmt/dcn.py:66-80; every use in
  * FeatureNet, code1/encoder_utils/fmt/module.py:407-440, is 3x3, stride 1, padding 1, dilation 1, one offset group,
@@ -496,6 +506,35 @@ size_t ufr_deform_conv2d_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_
 int ufr_deform_conv2d(const float* input, const float* offset, const float* mask, const float* weight,
                       const float* bias, float* output, int32_t B, int32_t C, int32_t Cout, int32_t H, int32_t W,
                       void* workspace, size_t workspace_bytes, ufr_stream stream);
+
+/* ---- the feature backbone on channel-last tensors (ABI 502) --------------------------------------------------
+ * FeatureNet.forward (code1/encoder_utils/fmt/module.py:388-468) is convolution -> BatchNorm -> ReLU blocks (module.py:26-62),
+ * 1x1 lateral connections added to a nearest-upsampled map (:452-466), and deformable layers whose offsets / masks come from
+ * a plain convolution (fmt/dcn.py:41-80).  These two entry points run that chain without a layout change and without a
+ * separate elementwise pass; `uforecon_amd/featurenet.py` is the plan that calls them.
+ *
+ * ufr_conv2d: out = [relu]( conv(input, weight) * scale + shift ) [+ up2(skip)], zero padding ksize / 2.
+ *   input [B][H][W][cin] (UFR_CONV2D_IN_PLANAR: [B][3][H][W], the image); weight [cout][cin][ksize][ksize]; scale / shift
+ *   [cout], nullable (eval-mode BatchNorm and / or bias folded by the caller); skip [B][Ho/2][Wo/2][cout], nullable: added
+ *   after nearest 2x upsampling (F.interpolate(scale_factor=2, mode='nearest')); output [B][Ho][Wo][cout], or planar
+ *   [B][cout][Ho][Wo] with UFR_CONV2D_OUT_PLANAR; sigmoid_from >= 0: sigmoid on output channels >= sigmoid_from (the mask
+ *   channels 18..26 of DCN.conv_offset_mask, whose planar output IS ufr_deform_conv2d*'s offset | mask pair), < 0: none.
+ *   Shapes: the layer shapes of FeatureNet (cin in {3 planar, 8, 16, 32}, ksize 1 / 3 / 5, stride 1 / 2, cout <= 32);
+ *   anything else returns UFR_ERR_ARG.  fp32 products and sums (v_mfma_f32_16x16x4_f32).
+ * ufr_deform_conv2d_cl: ufr_deform_conv2d on a channel-last input [B][H][W][32] (no re-layout, no workspace) with the
+ *   epilogue out = [relu]((dcn + bias) * scale + shift); offset_mask [B][27][H][W] = planes 0..17 the offsets (2k = dy,
+ *   2k+1 = dx of tap k), planes 18..26 the masks (after the sigmoid) -- ufr_conv2d(..., UFR_CONV2D_OUT_PLANAR, sigmoid_from
+ *   = 18) of DCN.conv_offset_mask; output channel-last [B][H][W][Cout] unless UFR_CONV2D_OUT_PLANAR. */
+#define UFR_CONV2D_RELU 1
+#define UFR_CONV2D_IN_PLANAR 2
+#define UFR_CONV2D_OUT_PLANAR 4
+int ufr_conv2d(const float* input, const float* weight, const float* scale, const float* shift, const float* skip, float* output,
+               int32_t B, int32_t cin, int32_t cout, int32_t H, int32_t W, int32_t ksize, int32_t stride, int32_t flags,
+               int32_t sigmoid_from, ufr_stream stream);
+int ufr_deform_conv2d_cl(const float* input_cl, const float* offset_mask, const float* weight, const float* bias,
+                         const float* scale, const float* shift, float* output, int32_t B, int32_t C, int32_t Cout, int32_t H,
+                         int32_t W, int32_t flags, ufr_stream stream);
+
 
 /* ---- feature-matching transformer layer ----------------------------------------------
  * One EncoderLayer of the FMT (code1/encoder_utils/fmt/FMT.py:82-113: linear attention with the elu+1 feature map, FMT.py:17-39,

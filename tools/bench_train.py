@@ -166,16 +166,29 @@ def run(a, dev, world=1, rank=0):
     ar_events = []
 
     # --graph: the step's random inputs live in static buffers that a replayed graph reads
-    idx_buf = torch.zeros(1, a.rays, dtype=torch.int64, device=dev)
-    U1_buf = torch.zeros(a.coarse, a.rays, device=dev)
-    U2_buf = torch.zeros(a.fine, a.rays, device=dev)
+    # Two sets: while a step runs on set k, the NEXT step's rays and uniforms are drawn into set 1 - k on a side stream --
+    # they depend on nothing (the reference draws them inline, model.py:537; a data loader would hand them over), and as
+    # the first launches of a step they cost 0.2 ms of an otherwise idle GPU.  (--graph: one set, drawn between replays.)
+    bufs = [dict(idx=torch.zeros(1, a.rays, dtype=torch.int64, device=dev), U1=torch.zeros(a.coarse, a.rays, device=dev),
+                 U2=torch.zeros(a.fine, a.rays, device=dev), ready=None) for _ in range(2)]
+    idx_buf, U1_buf, U2_buf = bufs[0]["idx"], bufs[0]["U1"], bufs[0]["U2"]
+    draw_stream = torch.cuda.Stream(dev)
+    turn = [0]
 
-    def draw():
+    def draw(b=None):
+        b = bufs[0] if b is None else b
         # model.py:537 takes the first train_ray_num entries of argsort(rand(H W)): a uniform sample without replacement in
         # random order -- as is the top-k of the same uniforms (a radix select instead of the full sort: ~20 launches fewer)
-        idx_buf.copy_(torch.rand(HW, device=dev, generator=gen).topk(a.rays, sorted=False).indices[None])
-        U1_buf.copy_(torch.rand(a.coarse, a.rays, device=dev, generator=gen))
-        U2_buf.copy_(torch.rand(a.fine, a.rays, device=dev, generator=gen))
+        b["idx"].copy_(torch.rand(HW, device=dev, generator=gen).topk(a.rays, sorted=False).indices[None])
+        b["U1"].copy_(torch.rand(a.coarse, a.rays, device=dev, generator=gen))
+        b["U2"].copy_(torch.rand(a.fine, a.rays, device=dev, generator=gen))
+
+    def draw_ahead(b):
+        draw_stream.wait_stream(torch.cuda.current_stream(dev))      # the set's previous readers are done
+        with torch.cuda.stream(draw_stream):
+            draw(b)
+            b["ready"] = torch.cuda.Event()
+            b["ready"].record()
 
     phase_marks = []      # UFR_BT_PHASES=1 (development): events on the main stream at the phase boundaries of every step
     want_phases = os.environ.get("UFR_BT_PHASES") == "1"
@@ -190,9 +203,16 @@ def run(a, dev, world=1, rank=0):
         row = []
         phase_marks.append(row)
         mark(row)
-        if not drawn:
-            draw()
-        idx, U1, U2 = idx_buf, U1_buf, U2_buf
+        if drawn:
+            idx, U1, U2 = idx_buf, U1_buf, U2_buf
+        else:
+            cur, nxt = bufs[turn[0]], bufs[1 - turn[0]]
+            turn[0] = 1 - turn[0]
+            if cur["ready"] is None:
+                draw_ahead(cur)                       # the very first step
+            torch.cuda.current_stream(dev).wait_event(cur["ready"])
+            draw_ahead(nxt)
+            idx, U1, U2 = cur["idx"], cur["U1"], cur["U2"]
         for v in vols:
             v.grad = None
         opt.zero_grad(set_to_none=True)

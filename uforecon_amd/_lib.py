@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # UFR_LIB selects an alternative in-tree build (A/B kernel variants during development)
 LIB_PATH = os.environ.get("UFR_LIB") or os.path.join(HERE, "lib", "libufr.so")
 
-ABI_VERSION = 501   # = UFR_ABI_VERSION of include/ufr.h; load() refuses a library built against another header
+ABI_VERSION = 502   # = UFR_ABI_VERSION of include/ufr.h; load() refuses a library built against another header
 MAX_VIEWS = 7
 NUM_STAGES = 3
 TOKEN_DIM = 80
@@ -125,8 +125,11 @@ SIGNATURES = {
     "ufr_conv3d_bwd_weight": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ufr_tsdf_integrate": (C.c_int, [vp, vp, vp, C.POINTER(i32), C.POINTER(C.c_float), C.c_float, C.c_float,
                                      C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp, i32, i32, C.c_float, i32, vp]),
+    "ufr_pixelwise_view_weights": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ufr_deform_conv2d_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "ufr_deform_conv2d": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
+    "ufr_conv2d": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ufr_deform_conv2d_cl": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "ufr_fmt_layer_workspace_bytes": (sz, [i32, i32]),
     "ufr_fmt_layer": (C.c_int, [C.POINTER(FmtLayerWeights), vp, vp, i32, i32, i32, vp, vp, vp]),
     "ufr_profile_enable": (None, [C.c_int]),

@@ -132,7 +132,12 @@ class DepthNet(nn.Module):
             sim, agg = frustum.correlate(ref_feature[b].contiguous(), src, ref_proj[b], [p[b] for p in src_projs],
                                          depth_values[b].contiguous(), None if first_stage else view_weights[b].contiguous(),
                                          want_similarity=first_stage)
-            if first_stage:         # the weights come out of the similarity itself (TransMVSNet.py:80-82)
+            if first_stage and sim.is_cuda and not self.training and not torch.is_grad_enabled():
+                # the weights come out of the similarity itself (TransMVSNet.py:80-97): PixelwiseNet + the weighted aggregate
+                # as one pass over the volume (ufr_pixelwise_view_weights)
+                vw, agg = frustum.view_weights(self.pixel_wise_net, sim)
+                new_weights.append(vw)
+            elif first_stage:       # the same, layer by layer (library ops: training, and the statement of what the kernel computes)
                 vw = torch.cat([self.pixel_wise_net(sim[i][None, None]) for i in range(sim.shape[0])], dim=1)[0]   # (NS,H,W)
                 s_sum = torch.zeros_like(sim[0])
                 w_sum = torch.full_like(vw[0], 1e-5)

@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) deform_conv3x3_mfma_kernel(const float* _
                                                                    const float* __restrict__ weight,  // [Cout][32][3][3]
                                                                    const float* __restrict__ bias,    // [Cout] or null
                                                                    float* __restrict__ out,           // [B][Cout][H][W]
-                                                                   int Cout, int H, int W) {
+                                                                   int Cout, int H, int W, DcnEpilogue ep) {
   constexpr int C = 32, T = 4;
   extern __shared__ __attribute__((aligned(16))) float a_lds[];   // [NT][9][8][64]: A fragment of (row tile, tap, r)
   for (int i = threadIdx.x; i < NT * 72 * 64; i += blockDim.x) {
@@ -110,9 +110,12 @@ __global__ void __launch_bounds__(256) deform_conv3x3_mfma_kernel(const float* _
     for (int t = 0; t < T; ++t) {
       const int p_raw = wave_base + 16 * t + j, p = p_raw < HW ? p_raw : HW - 1;
       const int py = p / W, px = p - py * W;
-      const float y = (float)(py - 1 + ki) + offset[((size_t)b * 18 + 2 * k) * HW + p];
-      const float x = (float)(px - 1 + kj) + offset[((size_t)b * 18 + 2 * k + 1) * HW + p];
-      const float m = mask ? mask[((size_t)b * 9 + k) * HW + p] : 1.f;
+      // (ep.om_planes: offsets and masks of an image are ONE block of that many planes -- the planar output of the offset |
+      // mask convolution, conv2d.hip -- instead of two tensors of 18 and 9)
+      const size_t ob = (size_t)b * (ep.om_planes ? ep.om_planes : 18) * HW, mb = (size_t)b * (ep.om_planes ? ep.om_planes : 9) * HW;
+      const float y = (float)(py - 1 + ki) + offset[ob + (size_t)(2 * k) * HW + p];
+      const float x = (float)(px - 1 + kj) + offset[ob + (size_t)(2 * k + 1) * HW + p];
+      const float m = mask ? mask[mb + (size_t)k * HW + p] : 1.f;
       const bool in = !(y <= -1.f || y >= (float)H || x <= -1.f || x >= (float)W);
       const float yl = floorf(y), xl = floorf(x);
       const int y0 = in ? (int)yl : 0, x0 = in ? (int)xl : 0, y1 = y0 + 1, x1 = x0 + 1;
@@ -145,27 +148,43 @@ __global__ void __launch_bounds__(256) deform_conv3x3_mfma_kernel(const float* _
     const int p = wave_base + 16 * t + j;
     if (p >= HW) continue;
 #pragma unroll
-    for (int to = 0; to < NT; ++to)
+    for (int to = 0; to < NT; ++to) {
+      // epilogue of the channel-last pipeline (featurenet.py): the BatchNorm + ReLU that follow a deformable layer
+      float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int o = 16 * to + 4 * g + r;
-        if (o < Cout) out[((size_t)b * Cout + o) * HW + p] = acc[t][to][r];
+        float x = acc[t][to][r];
+        if (ep.scale && o < Cout) x = fmaf(x, ep.scale[o], ep.shift[o]);
+        v[r] = ep.relu ? fmaxf(x, 0.f) : x;
       }
+      if (ep.out_cl) {
+        if (16 * to + 4 * g + 3 < Cout) st4(out + ((size_t)b * HW + p) * Cout + 16 * to + 4 * g, f32x4{v[0], v[1], v[2], v[3]});
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = 16 * to + 4 * g + r;
+          if (o < Cout) out[((size_t)b * Cout + o) * HW + p] = v[r];
+        }
+      }
+    }
   }
 }
 
 hipError_t launch_deform_conv3x3(const float* in_cl, const float* offset, const float* mask, const float* weight,
-                                 const float* bias, float* out, int B, int C, int Cout, int H, int W, hipStream_t s) {
+                                 const float* bias, float* out, int B, int C, int Cout, int H, int W, hipStream_t s,
+                                 DcnEpilogue ep) {
   if (C == 32) {   // every deformable layer of the reference's FeatureNet
     const dim3 grid((H * W + 255) / 256, B), block(256);
     if (Cout <= 16)
       hipLaunchKernelGGL(deform_conv3x3_mfma_kernel<1>, grid, block, 72 * 64 * sizeof(float), s, in_cl, offset, mask, weight, bias,
-                         out, Cout, H, W);
+                         out, Cout, H, W, ep);
     else
       hipLaunchKernelGGL(deform_conv3x3_mfma_kernel<2>, grid, block, 2 * 72 * 64 * sizeof(float), s, in_cl, offset, mask, weight,
-                         bias, out, Cout, H, W);
+                         bias, out, Cout, H, W, ep);
     return hipGetLastError();
   }
+  if (ep.scale || ep.relu || ep.out_cl) return hipErrorInvalidValue;     // the epilogue exists in the C = 32 kernel only
   const dim3 grid((H * W + 255) / 256, B), block(256);
   const size_t lds = (size_t)9 * C * Cout * sizeof(float);
   switch (Cout) {

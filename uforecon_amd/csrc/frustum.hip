@@ -86,6 +86,70 @@ __global__ void __launch_bounds__(256) correlate_kernel(const float* __restrict_
   }
 }
 
+// ---- pixel-wise view weights of the first cascade stage (PixelwiseNet, code1/encoder_utils/fmt/TransMVSNet.py:23-41) and
+// the weighted aggregate that follows (:80-97), fused.  PixelwiseNet is three 1x1x1 convolutions (1 -> 16 -> 8 -> 1, BatchNorm +
+// ReLU after the first two), a sigmoid and a max over the depth hypotheses: per voxel 152 multiply-adds on ONE input value.
+// As library convolutions it wrote a 16-channel and an 8-channel copy of the similarity volume (BatchNorm and ReLU as further
+// passes): 0.44 ms per source view at stage 1, 2.6 ms per frame.  Here a thread owns a pixel of a source view, walks its D
+// hypotheses and keeps the maximum: the volume is read once, nothing but the (NS,H,W) weights is written.
+// params: [a0 16 | b0 16 | W1 8 x 16 | a1 8 | b1 8 | w2 8 | b2 1] with the eval-mode BatchNorms folded (a0 = w0 * scale0,
+// b0 = shift0; a1 = scale1, b1 = shift1): h0 = relu(a0 x + b0), h1 = relu(a1 (W1 h0) + b1), o = w2 . h1 + b2.
+constexpr int kPixelwiseParams = 16 + 16 + 128 + 8 + 8 + 8 + 1;
+__global__ void __launch_bounds__(256) pixelwise_weight_kernel(const float* __restrict__ sim, const float* __restrict__ params,
+                                                              float* __restrict__ vw, int D, int HW) {
+  __shared__ float P[kPixelwiseParams];
+  for (int i = threadIdx.x; i < kPixelwiseParams; i += blockDim.x) P[i] = params[i];
+  __syncthreads();
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (pix >= HW) return;
+  const float* a0 = P, *b0 = P + 16, *W1 = P + 32, *a1 = P + 160, *b1 = P + 168, *w2 = P + 176;
+  const float b2 = P[184];
+  const float* col = sim + (size_t)i * D * HW + pix;
+  float best = 0.f;      // sigmoid > 0
+  for (int d = 0; d < D; ++d) {
+    const float x = col[(size_t)d * HW];
+    float h0[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) h0[c] = fmaxf(fmaf(a0[c], x, b0[c]), 0.f);
+    float o = b2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) t = fmaf(W1[j * 16 + c], h0[c], t);
+      o = fmaf(w2[j], fmaxf(fmaf(a1[j], t, b1[j]), 0.f), o);
+    }
+    best = fmaxf(best, 1.f / (1.f + __expf(-o)));
+  }
+  vw[(size_t)i * HW + pix] = best;
+}
+
+// aggregated[d] = (sum_i sim_i[d] vw_i) / (1e-5 + sum_i vw_i), in the reference's order (TransMVSNet.py:86-97)
+__global__ void __launch_bounds__(256) weighted_aggregate_kernel(const float* __restrict__ sim, const float* __restrict__ vw,
+                                                                float* __restrict__ agg, int NS, int D, int HW) {
+  const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= (size_t)D * HW) return;
+  const int pix = (int)(v % HW);
+  float s_sum = 0.f, w_sum = 1e-5f;
+  for (int i = 0; i < NS; ++i) {
+    const float w = vw[(size_t)i * HW + pix];
+    s_sum = s_sum + sim[(size_t)i * D * HW + v] * w;
+    w_sum = w_sum + w;
+  }
+  agg[v] = s_sum / w_sum;
+}
+
+hipError_t launch_pixelwise_weights(const float* sim, const float* params, float* vw, float* agg, int NS, int D, int H, int W,
+                                    hipStream_t s) {
+  const int HW = H * W;
+  hipLaunchKernelGGL(pixelwise_weight_kernel, dim3((HW + 255) / 256, NS), dim3(256), 0, s, sim, params, vw, D, HW);
+  if (agg) {
+    const size_t n = (size_t)D * HW;
+    hipLaunchKernelGGL(weighted_aggregate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sim, vw, agg, NS, D, HW);
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_chw_to_hwc(const float* in, float* out, int N, int C, int S, hipStream_t s) {
   hipLaunchKernelGGL(chw_to_hwc_kernel, dim3((S + 255) / 256, N), dim3(256), 0, s, in, out, C, S);
   return hipGetLastError();

@@ -34,6 +34,27 @@ __device__ __forceinline__ f32x4 lerp_tap4(const float* __restrict__ base, int s
   return acc;
 }
 
+#ifndef UFR_GATHER_BUFFER
+#define UFR_GATHER_BUFFER 1     // taps through bounded buffer loads (ufr_device.h); 0 = the conditional global loads (A/B)
+#endif
+// the same through a bounded descriptor: texel t.o[k] of the map that starts at byte `base` of the descriptor, channels from
+// byte c4; masked corners (t.o[k] < 0) read zeros from kBufOut -- all four loads in flight at once
+__device__ __forceinline__ f32x4 lerp_tap4_buf(__amdgpu_buffer_rsrc_t r, unsigned base, int stride_bytes, const Tap2& t, unsigned c4) {
+  f32x4 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    v[k] = buf_ld4(r, t.o[k] >= 0 ? base + __umul24((unsigned)t.o[k], (unsigned)stride_bytes) + c4 : kBufOut);
+  f32x4 acc;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float a = mul_rn(v[0][e], t.w[0]);
+    a = fmaf(v[1][e], t.w[1], a);
+    a = fmaf(v[2][e], t.w[2], a);
+    acc[e] = fmaf(v[3][e], t.w[3], a);
+  }
+  return acc;
+}
+
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void put_tap(float* dst, const Tap2& t) {
@@ -160,6 +181,7 @@ __global__ void __launch_bounds__(64 * NVT) gather_kernel(FrameDev f, PreSim ps,
   constexpr int out_stride = out_in_sim ? sim_slot : 40;
 
   const int v = threadIdx.x >> 6, p = threadIdx.x & 63;
+  const int vu = __builtin_amdgcn_readfirstlane(v);      // a wave = one view: per-view descriptors live in scalar registers
   // XCD-aware block -> point-group map: workgroups are dealt round-robin to the 8 XCDs (private L2 each), so
   // giving XCD x the x-th contiguous eighth of the launch keeps the texels that neighbouring rays share in ONE L2
   // instead of eight
@@ -204,15 +226,26 @@ __global__ void __launch_bounds__(64 * NVT) gather_kernel(FrameDev f, PreSim ps,
     put_tap(sh_tapF + (v * 64 + p) * 8, taps_zeros(unnorm2d_nac(x, f.w), unnorm2d_nac(y, f.h), f.w, f.h));
     put_tap(sh_tapM + (v * 64 + p) * 8, taps_border(unnorm2d_ac(x, f.w), unnorm2d_ac(y, f.h), f.w, f.h));
     Tap2 tf = taps_zeros(unnorm2d_nac(x, f.W), unnorm2d_nac(y, f.H), f.W, f.H);
+#if UFR_GATHER_BUFFER
+    const unsigned img_px = (unsigned)(f.H * f.W);
+    f32x4 c4 = lerp_tap4_buf(buf_rsrc(f.rgb + (size_t)vu * img_px * 4, img_px * 16u), 0u, 16, tf, 0u);
+#else
     f32x4 c4 = lerp_tap4(f.rgb + (size_t)v * f.H * f.W * 4, 4, tf, 0);
+#endif
     const float inb = (x <= 1.f && x >= -1.f && y <= 1.f && y >= -1.f) ? 1.f : 0.f;  // inclusive mask
     c4[3] = inb * mask_z;                                                             // ray_transformer.py:251-252
     if (active) st4(rgb_out + ((size_t)pidx * NV + v) * 4, c4);
     // MVS depth guide + positional encoding (ray_transformer.py:229-247, 29-73)
-    const float* dmap = f.depth + (size_t)v * f.H * f.W;
     float dv[4];
+#if UFR_GATHER_BUFFER
+    const __amdgpu_buffer_rsrc_t rdepth = buf_rsrc(f.depth + (size_t)vu * img_px, img_px * 4u);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dv[k] = buf_ld1(rdepth, tf.o[k] >= 0 ? (unsigned)tf.o[k] * 4u : kBufOut);
+#else
+    const float* dmap = f.depth + (size_t)v * f.H * f.W;
 #pragma unroll
     for (int k = 0; k < 4; ++k) dv[k] = tf.o[k] >= 0 ? dmap[tf.o[k]] : 0.f;
+#endif
     const float dm = fmaf(dv[3], tf.w[3], fmaf(dv[2], tf.w[2], fmaf(dv[1], tf.w[1], mul_rn(dv[0], tf.w[0]))));
     const float* R = f.w2c_z[v];
     float zc = fmaf(R[2], pz, fmaf(R[1], py, mul_rn(R[0], px))) + R[3];
@@ -243,6 +276,12 @@ __global__ void __launch_bounds__(64 * NVT) gather_kernel(FrameDev f, PreSim ps,
   // ---- cooperative 32-channel gathers: lane group of 8 = one footprint, lane c8 = channels 4*c8..4*c8+3
   const int c8 = threadIdx.x & 7, grp = threadIdx.x >> 3;
   constexpr int n_grp = 64 * NV / 8;
+#if UFR_GATHER_BUFFER
+  // one descriptor over all views' maps (the item's view differs per lane group): [NV][h][w][32] and [NV][h][w][match_ch]
+  const unsigned map_px = (unsigned)(f.h * f.w);
+  const __amdgpu_buffer_rsrc_t rfeat = buf_rsrc(f.feat, (unsigned)NV * map_px * 128u);
+  const __amdgpu_buffer_rsrc_t rmatch = buf_rsrc(f.match, (unsigned)NV * map_px * (unsigned)f.match_ch * 4u);
+#endif
   // image features of (point, view) -> token columns 0..31 (ray_transformer.py:222-226)
 #ifdef UFR_GABL_NOCOOP  // ablation build: no 32-channel gathers (timing only)
   if (false)
@@ -252,8 +291,13 @@ __global__ void __launch_bounds__(64 * NVT) gather_kernel(FrameDev f, PreSim ps,
     const int ipidx = blk * 64 + ip;
     if (ipidx < P) {
       const Tap2 t = get_tap(sh_tapF + (iv * 64 + ip) * 8);
+#if UFR_GATHER_BUFFER
+      st4(x_tokens + ((size_t)ipidx * NV + iv) * row_cols + 4 * c8,
+          lerp_tap4_buf(rfeat, (unsigned)iv * map_px * 128u, 128, t, 16u * c8));
+#else
       st4(x_tokens + ((size_t)ipidx * NV + iv) * row_cols + 4 * c8,
           lerp_tap4(f.feat + (size_t)iv * f.h * f.w * 32, 32, t, 4 * c8));
+#endif
     }
   }
   // pairwise similarity (model.py:271-283): pair q = (a, b), sides (view a, chunk b) / (view b+1, chunk a);
@@ -271,8 +315,14 @@ __global__ void __launch_bounds__(64 * NVT) gather_kernel(FrameDev f, PreSim ps,
     const Tap2 ta = get_tap(sh_tapM + (va * 64 + ip) * 8), tb = get_tap(sh_tapM + (vb * 64 + ip) * 8);
     const float* ba = f.match + (size_t)va * f.h * f.w * f.match_ch + 32 * ca;
     const float* bb = f.match + (size_t)vb * f.h * f.w * f.match_ch + 32 * cb;
+#if UFR_GATHER_BUFFER
+    const unsigned mrow = (unsigned)f.match_ch * 4u;
+    f32x4 fa = lerp_tap4_buf(rmatch, (unsigned)va * map_px * mrow + 128u * ca, (int)mrow, ta, 16u * c8);
+    f32x4 fb = lerp_tap4_buf(rmatch, (unsigned)vb * map_px * mrow + 128u * cb, (int)mrow, tb, 16u * c8);
+#else
     f32x4 fa = lerp_tap4(ba, f.match_ch, ta, 4 * c8);
     f32x4 fb = lerp_tap4(bb, f.match_ch, tb, 4 * c8);
+#endif
     float na = fmaxf(sqrtf(fa[0] * fa[0] + fa[1] * fa[1] + fa[2] * fa[2] + fa[3] * fa[3]), 1e-8f);
     float nb = fmaxf(sqrtf(fb[0] * fb[0] + fb[1] * fb[1] + fb[2] * fb[2] + fb[3] * fb[3]), 1e-8f);
     // F.normalize(x) = x / max(|x|, eps) as x * (1 / max(|x|, eps)): two reciprocals instead of eight IEEE divisions
@@ -298,7 +348,13 @@ __global__ void __launch_bounds__(64 * NVT) gather_kernel(FrameDev f, PreSim ps,
 #ifdef UFR_GABL_NOVOL   // ablation build: no frustum taps (timing only)
       for (int c = 0; c < 8; ++c) fs[c] = x; ws = y;
 #else
+#if UFR_GATHER_BUFFER
+      const unsigned vox = (unsigned)(f.vD[s] * f.vH[s] * f.vW[s]);
+      sample_volume_buf(buf_rsrc(f.vol[s] + (size_t)vu * vox * kVolCh, vox * (unsigned)(kVolCh * 4)), f.vD[s], f.vH[s], f.vW[s], x, y,
+                        zn, fs, ws);
+#else
       sample_volume(vol, f.vD[s], f.vH[s], f.vW[s], x, y, zn, fs, ws);
+#endif
 #endif
 #pragma unroll
       for (int c = 0; c < 8; ++c) fl[8 * s + c] = fs[c];

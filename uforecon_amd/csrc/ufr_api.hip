@@ -1190,6 +1190,16 @@ int ufr_tsdf_integrate(float* tsdf, float* weight, float* color, const int32_t* 
   return UFR_OK;
 }
 
+int ufr_pixelwise_view_weights(const float* similarity, const float* params, float* view_weights, float* aggregated, int32_t NS,
+                               int32_t D, int32_t H, int32_t W, ufr_stream stream) {
+  UFR_REQUIRE(similarity && params && view_weights, "ufr_pixelwise_view_weights: null argument");
+  UFR_REQUIRE(NS >= 1 && NS <= UFR_MAX_VIEWS && D >= 1 && H >= 1 && W >= 1, "ufr_pixelwise_view_weights: NS=%d D=%d H=%d W=%d", NS, D, H, W);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ProfScope p("pixelwise_view_weights", s);
+  UFR_HIP(launch_pixelwise_weights(similarity, params, view_weights, aggregated, NS, D, H, W, s));
+  return UFR_OK;
+}
+
 // ------------------------------------------------------------------ deformable convolution
 size_t ufr_deform_conv2d_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W) {
   Carver c(nullptr);
@@ -1212,6 +1222,49 @@ int ufr_deform_conv2d(const float* input, const float* offset, const float* mask
   ProfScope p("deform_conv2d", s);
   UFR_HIP(launch_chw_to_hwc(input, in_cl, B, C, H * W, s));
   UFR_HIP(launch_deform_conv3x3(in_cl, offset, mask, weight, bias, output, B, C, Cout, H, W, s));
+  return UFR_OK;
+}
+
+// channel-last pipeline of the feature backbone (conv2d.hip; featurenet.py is the plan)
+int ufr_conv2d(const float* input, const float* weight, const float* scale, const float* shift, const float* skip, float* output,
+               int32_t B, int32_t cin, int32_t cout, int32_t H, int32_t W, int32_t ksize, int32_t stride, int32_t flags,
+               int32_t sigmoid_from, ufr_stream stream) {
+  UFR_REQUIRE(input && weight && output, "ufr_conv2d: null argument");
+  UFR_REQUIRE(B > 0 && H > 0 && W > 0 && cout > 0 && cout <= 32, "ufr_conv2d: B=%d H=%d W=%d cout=%d", B, H, W, cout);
+  UFR_REQUIRE((ksize == 1 || ksize == 3 || ksize == 5) && (stride == 1 || stride == 2), "ufr_conv2d: ksize=%d stride=%d", ksize, stride);
+  UFR_REQUIRE((unsigned long long)H * W * (cin > 3 ? cin : 4) * 4ull < (1ull << 31), "ufr_conv2d: %d x %d x %d exceeds 2^31 bytes per image", H, W, cin);
+  Conv2dArgs a;
+  a.in = input; a.w = weight; a.scale = scale; a.shift = shift; a.skip = skip; a.out = output;
+  a.B = B; a.H = H; a.W = W; a.cout = cout;
+  a.Ho = (H + 2 * (ksize / 2) - ksize) / stride + 1;
+  a.Wo = (W + 2 * (ksize / 2) - ksize) / stride + 1;
+  a.relu = (flags & UFR_CONV2D_RELU) != 0;
+  a.out_planar = (flags & UFR_CONV2D_OUT_PLANAR) != 0;
+  a.sigmoid_from = sigmoid_from;
+  UFR_REQUIRE(!skip || (a.Ho % 2 == 0 && a.Wo % 2 == 0 && cout % 4 == 0), "ufr_conv2d: the upsampled skip needs even output extents and cout %% 4 == 0");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ProfScope p("conv2d", s);
+  const hipError_t e = launch_conv2d(a, cin, ksize, stride, (flags & UFR_CONV2D_IN_PLANAR) != 0, s);
+  if (e == hipErrorInvalidValue)
+    return fail(UFR_ERR_ARG, "ufr_conv2d: %d -> %d channels, %dx%d, stride %d is not a layer shape of FeatureNet (conv2d.hip)", cin, cout, ksize, ksize, stride);
+  UFR_HIP(e);
+  return UFR_OK;
+}
+
+int ufr_deform_conv2d_cl(const float* input_cl, const float* offset_mask, const float* weight, const float* bias,
+                         const float* scale, const float* shift, float* output, int32_t B, int32_t C, int32_t Cout, int32_t H,
+                         int32_t W, int32_t flags, ufr_stream stream) {
+  const float* offset = offset_mask;
+  UFR_REQUIRE(input_cl && offset && weight && output, "ufr_deform_conv2d_cl: null argument");
+  const float* mask = offset_mask + (size_t)18 * H * W;
+  UFR_REQUIRE(C == 32, "ufr_deform_conv2d_cl: C=%d (the channel-last form exists for the 32-channel layers of FeatureNet)", C);
+  UFR_REQUIRE(Cout == 8 || Cout == 16 || Cout == 32, "ufr_deform_conv2d_cl: Cout=%d unsupported (8, 16, 32)", Cout);
+  UFR_REQUIRE(B > 0 && H > 0 && W > 0, "ufr_deform_conv2d_cl: B=%d H=%d W=%d", B, H, W);
+  UFR_REQUIRE((scale == nullptr) == (shift == nullptr), "ufr_deform_conv2d_cl: scale and shift come together");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ProfScope p("deform_conv2d", s);
+  UFR_HIP(launch_deform_conv3x3(input_cl, offset, mask, weight, bias, output, B, C, Cout, H, W, s,
+                                DcnEpilogue{scale, shift, (flags & UFR_CONV2D_RELU) != 0, (flags & UFR_CONV2D_OUT_PLANAR) == 0, 27}));
   return UFR_OK;
 }
 

@@ -44,6 +44,22 @@ __device__ __forceinline__ float fast_rsqrt(float x) {
 __device__ __forceinline__ float relu_acc(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 0x1.fffffep+127f); }   // FLT_MAX: with +inf hipcc folds the median back into canonicalise + max
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// ---- bounded loads: a raw buffer descriptor over a tensor (< 2^31 bytes); an element that does not exist -- a texel outside
+// the map, a masked corner -- is asked for at kBufOut, past the extent, and the hardware returns 0.  No branch and no select
+// around the load: `ok ? p[i] : 0` compiles to a divergent block with its own s_waitcnt per load (the gather kernel had 110
+// branches and 116 waits for 147 loads), so a thread's taps went to memory one round trip after the other.
+constexpr unsigned kBufOut = 0x80000000u;
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+__device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
 __device__ __forceinline__ f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
 
 __host__ __device__ constexpr int in_steps(int cm, int t) {

@@ -133,8 +133,28 @@ hipError_t launch_tsdf_integrate(float* tsdf, float* weight, float* color, const
                                  float voxel_size, float trunc_margin, const float* K, const float* P,
                                  const float* depth_im, const float* color_im, int im_h, int im_w, float obs_weight,
                                  int integrate_color, hipStream_t s);
+// conv2d.hip: the plain 2-D convolutions of FeatureNet on channel-last tensors, epilogue fused (see the file header)
+struct Conv2dArgs {
+  const float* in;      // [B][H][W][CIN] (the stem: planar [B][3][H][W])
+  const float* w;       // [cout][CIN][KS][KS]
+  const float* scale;   // [cout] or null (= 1)
+  const float* shift;   // [cout] or null (= 0)
+  const float* skip;    // [B][Ho/2][Wo/2][cout] added after nearest 2x upsampling, or null
+  float* out;           // [B][Ho][Wo][cout], or planar [B][cout][Ho][Wo]
+  int B, H, W, Ho, Wo, cout;
+  int relu, out_planar, sigmoid_from;   // sigmoid on channels >= sigmoid_from (< 0: none)
+};
+hipError_t launch_conv2d(const Conv2dArgs& a, int cin, int ks, int stride, int in_planar, hipStream_t s);
+// dcn.hip, channel-last form: epilogue out = [relu]((dcn + bias) * scale + shift), channel-last or planar output
+struct DcnEpilogue {
+  const float* scale;
+  const float* shift;
+  int relu, out_cl;
+  int om_planes;      // 0: offset [B][18][H][W] and mask [B][9][H][W]; 27: one [B][27][H][W] block, mask = offset + 18 planes
+};
 hipError_t launch_deform_conv3x3(const float* in_cl, const float* offset, const float* mask, const float* weight,
-                                 const float* bias, float* out, int B, int C, int Cout, int H, int W, hipStream_t s);
+                                 const float* bias, float* out, int B, int C, int Cout, int H, int W, hipStream_t s,
+                                 DcnEpilogue ep = DcnEpilogue{nullptr, nullptr, 0, 0, 0});
 hipError_t launch_conv3d(const float* in, const float* weight, const float* weight2, const float* bias, const float* scale,
                          const float* shift, const float* skip, float* out, float* out2, int B, int D, int H, int W,
                          int cin, int cout, int cout2, int mode, int relu, int ncdhw, hipStream_t s, int flip = 0);
@@ -143,6 +163,8 @@ hipError_t launch_conv3d_bwd_data(const float* d_out, const float* weight, const
 hipError_t launch_conv3d_bwd_weight(const float* in, const float* d_out, float* d_weight, float* d_bias, int B, int D, int H, int W,
                                     int cin, int cout, int mode, hipStream_t s);
 hipError_t launch_chw_to_hwc(const float* in, float* out, int N, int C, int S, hipStream_t s);
+hipError_t launch_pixelwise_weights(const float* sim, const float* params, float* vw, float* agg, int NS, int D, int H, int W,
+                                    hipStream_t s);
 hipError_t launch_correlate(const float* ref_cl, const float* src_cl, const float* proj_host, int NS, const float* depth,
                             const float* vw, float* sim, float* agg, int C, int H, int W, int D, hipStream_t s);
 

@@ -3,8 +3,13 @@
 Mirrors, with the reference's class names and state_dict keys,
   Conv2d, FeatureNet     code1/encoder_utils/fmt/module.py:26-62, 388-468
   DCN (DCNv2)            code1/encoder_utils/fmt/dcn.py:15-80
-The plain convolutions / batch norms are library ops; `deform_conv2d` -- torchvision's operator in the reference, a
-dependency that does not exist in this image -- is the HIP kernel of csrc/dcn.hip behind `ufr_deform_conv2d`.
+`FeatureNet.forward` runs the whole backbone on HIP kernels over channel-last tensors (`feature_net`, below: the plan):
+`ufr_conv2d` (csrc/conv2d.hip: every plain convolution with its BatchNorm / bias / ReLU / lateral addition folded into the
+store, the offset-and-mask convolution of a deformable layer writing what the deformable kernel reads) and
+`ufr_deform_conv2d_cl` (csrc/dcn.hip) -- `deform_conv2d` is torchvision's operator in the reference, a dependency that does
+not exist in this image.  No library convolution, no layout change between layers.  The modules keep the reference's
+layer-by-layer `forward`s (library ops + `deform_conv2d`) as the readable statement of what the plan computes; the CPU
+test-suite and the GPU parity test (tests/test_gpu_featurenet.py) run them against the plan.
 No CPU fallback: CPU tensors raise UfrError.  Inference only.  Parity of the deformable part is UNPINNED (no torchvision
 to produce reference outputs): see oracle/dcn_oracle.py.
 """
@@ -107,6 +112,12 @@ class FeatureNet(nn.Module):
         self.out_channels = [4 * b, b * 2, b]
 
     def forward(self, x):
+        if x.is_cuda and not self.training and not torch.is_grad_enabled():
+            return feature_net(self, x)
+        return self.forward_layers(x)
+
+    def forward_layers(self, x):
+        """module.py:443-468 layer by layer (library convolutions + `deform_conv2d`): what `feature_net` computes."""
         conv0 = self.conv0(x)
         conv1 = self.conv1(conv0)
         conv2 = self.conv2(conv1)
@@ -117,3 +128,96 @@ class FeatureNet(nn.Module):
         intra = F.interpolate(intra, scale_factor=2, mode="nearest") + self.inner2(conv0)
         outputs["stage3"] = self.out3(intra)
         return outputs
+
+
+# ---- the execution plan on HIP kernels ------------------------------------------------------------------------------
+def _fold(conv: nn.Conv2d, bn):
+    """(scale, shift) of `bn(conv(x) + bias)` in eval mode, or of the bias alone."""
+    dev = conv.weight.device
+    if bn is None:
+        return None, (None if conv.bias is None else conv.bias.detach().float().contiguous())
+    scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+    shift = bn.bias.detach() - bn.running_mean * scale
+    if conv.bias is not None:
+        shift = shift + conv.bias.detach() * scale
+    return scale.float().contiguous().to(dev), shift.float().contiguous().to(dev)
+
+
+def _plan_params(m: "FeatureNet"):
+    """Folded parameters of every layer, cached on the module until a parameter or buffer changes."""
+    key = tuple((t.data_ptr(), t._version) for t in list(m.parameters()) + list(m.buffers()))
+    cached = getattr(m, "_ufr_plan", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    P = {}
+
+    def block(name, blk: Conv2d):
+        sc, sh = _fold(blk.conv, blk.bn)
+        P[name] = dict(w=blk.conv.weight.detach().float().contiguous(), scale=sc, shift=sh, relu=blk.relu,
+                       stride=blk.conv.stride[0])
+
+    for seq in ("conv0", "conv1", "conv2"):
+        for i, blk in enumerate(getattr(m, seq)):
+            block(f"{seq}.{i}", blk)
+    for name in ("inner1", "inner2"):
+        c = getattr(m, name)
+        P[name] = dict(w=c.weight.detach().float().contiguous(), scale=None, shift=c.bias.detach().float().contiguous(),
+                       relu=False, stride=1)
+    for name in ("out1", "out2", "out3"):
+        head = getattr(m, name)                      # [Conv2d, DCN, BN, ReLU, DCN, BN, ReLU, DCN]
+        block(f"{name}.0", head[0])
+        for i, bn_i in ((1, 2), (4, 5), (7, None)):
+            d = head[i]
+            om = d.conv_offset_mask
+            ent = dict(w_om=om.weight.detach().float().contiguous(), b_om=om.bias.detach().float().contiguous(),
+                       w=d.weight.detach().float().contiguous(), bias=None if d.bias is None else d.bias.detach().float().contiguous(),
+                       scale=None, shift=None, relu=False)
+            if bn_i is not None:
+                bn = head[bn_i]
+                sc = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+                ent.update(scale=sc.float().contiguous(), shift=(bn.bias.detach() - bn.running_mean * sc).float().contiguous(), relu=True)
+            P[f"{name}.{i}"] = ent
+    m._ufr_plan = (key, P)
+    return P
+
+
+@torch.no_grad()
+def feature_net(m: "FeatureNet", x: torch.Tensor):
+    """FeatureNet.forward (module.py:443-468) on the HIP kernels: image (B,3,H,W) -> the reference's dict of (B,C,h,w) maps.
+    Every intermediate map is channel-last; BatchNorm (eval) / bias / ReLU ride in the producing kernel's store, the FPN's
+    `interpolate(intra, 2, 'nearest') + inner(conv)` is the 1x1 convolution's fused skip, a deformable layer is two launches
+    (offsets | sigmoid(masks) planar, then the sampler + contraction)."""
+    from . import ops
+    if m.training:
+        raise UfrError("FeatureNet: inference only (BatchNorm in eval mode)")
+    if not x.is_cuda:
+        raise UfrError("FeatureNet runs on the GPU only (no CPU implementation)")
+    B, C, H, W = x.shape
+    if C != 3 or H % 4 or W % 4:
+        raise UfrError(f"FeatureNet: image {tuple(x.shape)}: 3 channels, extents multiples of 4 (two stride-2 levels)")
+    P = _plan_params(m)
+
+    def conv(name, t, skip=None, in_planar=False):
+        p = P[name]
+        return ops.conv2d(t, p["w"], p["stride"], p["scale"], p["shift"], p["relu"], skip=skip, in_planar=in_planar)
+
+    def dcn(name, t, out_planar=False):
+        p = P[name]
+        om = ops.conv2d(t, p["w_om"], 1, None, p["b_om"], False, out_planar=True, sigmoid_from=18)
+        return ops.deform_conv2d_cl(t, om, p["w"], p["bias"], p["scale"], p["shift"], p["relu"], out_planar=out_planar)
+
+    def head(name, t):
+        t = conv(f"{name}.0", t)
+        t = dcn(f"{name}.1", t)
+        t = dcn(f"{name}.4", t)
+        return dcn(f"{name}.7", t, out_planar=True)
+
+    c0 = conv("conv0.1", conv("conv0.0", x.detach().float().contiguous(), in_planar=True))
+    c1 = conv("conv1.2", conv("conv1.1", conv("conv1.0", c0)))
+    c2 = conv("conv2.2", conv("conv2.1", conv("conv2.0", c1)))
+    out = {"stage1": head("out1", c2)}
+    intra = conv("inner1", c1, skip=c2)                  # interpolate(conv2, 2x nearest) + inner1(conv1)
+    out["stage2"] = head("out2", intra)
+    intra = conv("inner2", c0, skip=intra)
+    out["stage3"] = head("out3", intra)
+    return out

@@ -64,3 +64,38 @@ def correlate(ref_fea: torch.Tensor, src_feas: torch.Tensor, ref_proj_pair: torc
         _dev(depth_values, "depth_values"), _opt(view_weights, "view_weights"), Cc, H, W, D, NS,
         _opt(sim, "similarity"), _opt(agg, "aggregated"), ws.data_ptr(), nbytes, _stream()), "ufr_frustum_correlate")
     return sim, agg
+
+
+def pixelwise_params(net) -> torch.Tensor:
+    """The 185 floats ufr_pixelwise_view_weights reads, from a PixelwiseNet (cascade.py; eval-mode BatchNorms folded), cached
+    on the module until one of its tensors changes."""
+    key = tuple((t.data_ptr(), t._version) for t in list(net.parameters()) + list(net.buffers()))
+    cached = getattr(net, "_ufr_params", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+
+    def fold(bn):
+        scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+        return scale, bn.bias.detach() - bn.running_mean * scale
+
+    s0, h0 = fold(net.conv0.bn)
+    s1, h1 = fold(net.conv1.bn)
+    p = torch.cat([net.conv0.conv.weight.detach().reshape(16) * s0, h0, net.conv1.conv.weight.detach().reshape(128), s1, h1,
+                   net.conv2.weight.detach().reshape(8), net.conv2.bias.detach().reshape(1)]).float().contiguous()
+    net._ufr_params = (key, p)
+    return p
+
+
+def view_weights(net, similarity: torch.Tensor, want_aggregate: bool = True):
+    """PixelwiseNet on every source view's similarity volume and the weighted aggregate (TransMVSNet.py:80-97) in one pass:
+    ``similarity`` (NS,D,H,W) -> ``view_weights (NS,H,W)``, ``aggregated (D,H,W)`` (or None)."""
+    if net.training:
+        raise _lib.UfrError("view_weights: inference only (BatchNorm in eval mode)")
+    NS, D, H, W = similarity.shape
+    dev = similarity.device
+    vw = torch.empty(NS, H, W, dtype=torch.float32, device=dev)
+    agg = torch.empty(D, H, W, dtype=torch.float32, device=dev) if want_aggregate else None
+    p = pixelwise_params(net)
+    _lib.check(_lib.load().ufr_pixelwise_view_weights(_dev(similarity, "similarity"), _dev(p, "params"), vw.data_ptr(),
+                                                      _opt(agg, "aggregated"), NS, D, H, W, _stream()), "ufr_pixelwise_view_weights")
+    return vw, agg

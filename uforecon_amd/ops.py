@@ -746,6 +746,51 @@ def conv3d(x_cl: torch.Tensor, weight: torch.Tensor, mode: int = CONV3D_S1, bias
     return (out, out2) if cout2 else out
 
 
+CONV2D_RELU, CONV2D_IN_PLANAR, CONV2D_OUT_PLANAR = 1, 2, 4
+
+
+def conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, scale: Optional[torch.Tensor] = None,
+           shift: Optional[torch.Tensor] = None, relu: bool = False, skip: Optional[torch.Tensor] = None,
+           in_planar: bool = False, out_planar: bool = False, sigmoid_from: int = -1):
+    """One plain convolution of FeatureNet (ufr_conv2d): ``x`` channel-last (B,H,W,cin) -- or, with ``in_planar``, the image
+    (B,3,H,W); ``weight`` (cout,cin,k,k), zero padding k // 2; ``out = [relu](conv * scale + shift) [+ up2(skip)]``; returns
+    channel-last (B,Ho,Wo,cout) or with ``out_planar`` (B,cout,Ho,Wo); ``sigmoid_from``: sigmoid on channels >= it."""
+    if in_planar:
+        B, cin, H, W = x.shape
+    else:
+        B, H, W, cin = x.shape
+    cout, cin_w, k, k2 = weight.shape
+    if cin_w != cin or k != k2:
+        raise UfrError(f"conv2d: weight {tuple(weight.shape)} does not match {cin} input channels")
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    out = torch.empty((B, cout, Ho, Wo) if out_planar else (B, Ho, Wo, cout), dtype=torch.float32, device=x.device)
+    if skip is not None and tuple(skip.shape) != (B, Ho // 2, Wo // 2, cout):
+        raise UfrError(f"conv2d: skip {tuple(skip.shape)} is not the half-resolution map {(B, Ho // 2, Wo // 2, cout)}")
+    flags = (CONV2D_RELU if relu else 0) | (CONV2D_IN_PLANAR if in_planar else 0) | (CONV2D_OUT_PLANAR if out_planar else 0)
+    _lib.check(_lib.load().ufr_conv2d(_dev(x, "x"), _dev(weight, "weight"), _opt(scale, "scale"), _opt(shift, "shift"),
+                                      _opt(skip, "skip"), out.data_ptr(), B, cin, cout, H, W, k, int(stride), flags,
+                                      int(sigmoid_from), _stream()), "ufr_conv2d")
+    return out
+
+
+def deform_conv2d_cl(x_cl: torch.Tensor, offset_mask: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                     scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, relu: bool = False,
+                     out_planar: bool = False):
+    """The deformable 3x3 layer on a channel-last input (ufr_deform_conv2d_cl): ``x_cl`` (B,H,W,32); ``offset_mask``
+    (B,27,H,W) planar = DCN.conv_offset_mask's output with the sigmoid already on channels 18..26 (``conv2d(...,
+    out_planar=True, sigmoid_from=18)``); ``out = [relu]((dcn + bias) * scale + shift)``, channel-last or planar."""
+    B, H, W, C = x_cl.shape
+    Cout = weight.shape[0]
+    if tuple(offset_mask.shape) != (B, 27, H, W) or tuple(weight.shape) != (Cout, C, 3, 3):
+        raise UfrError(f"deform_conv2d_cl: shapes {tuple(x_cl.shape)} {tuple(offset_mask.shape)} {tuple(weight.shape)}")
+    out = torch.empty((B, Cout, H, W) if out_planar else (B, H, W, Cout), dtype=torch.float32, device=x_cl.device)
+    flags = (CONV2D_RELU if relu else 0) | (CONV2D_OUT_PLANAR if out_planar else 0)
+    _lib.check(_lib.load().ufr_deform_conv2d_cl(_dev(x_cl, "x"), _dev(offset_mask, "offset_mask"), _dev(weight, "weight"),
+                                                _opt(bias, "bias"), _opt(scale, "scale"), _opt(shift, "shift"), out.data_ptr(),
+                                                B, C, Cout, H, W, flags, _stream()), "ufr_deform_conv2d_cl")
+    return out
+
+
 def conv3d_bwd_data(d_out_cl: torch.Tensor, weight: torch.Tensor, mode: int, in_shape, accumulate: Optional[torch.Tensor] = None):
     """Data gradient of one plain 3x3x3 layer (ufr_conv3d_bwd_data): ``d_out_cl`` channel-last at the layer's output extent,
     ``weight`` the layer's forward weight in the checkpoint's layout, ``in_shape`` = (B,D,H,W,cin) of the layer's input.

@@ -308,9 +308,12 @@ int ufr_aggregate_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, co
  * ufr_project_gather_bwd_workspace_bytes(frame) bytes = 1.33 x the volumes: nine lanes of one atomic instruction add the
  * nine values of a voxel corner as ONE L2 transaction, then one coalesced pass writes these tensors);
  * both arrays NULL: only the pre_sim_mlp gradients (accumulated into `grads`) are computed, no workspace needed.
- * `accumulate` is a bit set: UFR_GBWD_ACCUMULATE, and UFR_GBWD_WORKSPACE_ZEROED = the caller has zero-filled `workspace`
- * (ordered before this call on `stream`), e.g. on another stream beside earlier work -- the library then skips its own
- * memset (0.9 GB at the configs[4] size). */
+ * `accumulate` is a bit set: UFR_GBWD_ACCUMULATE, and UFR_GBWD_WORKSPACE_ZEROED = `workspace` is all zero on entry
+ * (ordered before this call on `stream`) -- the library then skips its own memset (0.9 GB at the configs[4] size).
+ * The call LEAVES THE WORKSPACE ZERO: the scatter marks the groups of 8 voxels it adds into, and the pass that writes the
+ * gradient tensors reads -- and zeroes again -- only those (a step's rays reach a fraction of the voxels).  A caller that
+ * keeps the workspace between calls therefore zero-fills it once and passes UFR_GBWD_WORKSPACE_ZEROED from then on (a
+ * call that returned an error leaves it undefined: fill it again). */
 #define UFR_GBWD_ACCUMULATE 1
 #define UFR_GBWD_WORKSPACE_ZEROED 2
 size_t ufr_project_gather_bwd_workspace_bytes(const ufr_frame* frame);

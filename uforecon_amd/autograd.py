@@ -101,6 +101,7 @@ def _workspace(kind: str, dev, numel_of) -> torch.Tensor:
     return t
 
 
+_GWS_STATE = {}     # data_ptr of a kept frustum-scatter workspace -> "zero" (as the last call left it) | "in use"
 _BUSY = {}          # key -> weak reference to the autograd context that holds the kept buffer between its forward and backward
 
 
@@ -266,8 +267,10 @@ class RenderTwoPass(torch.autograd.Function):
             if not taped:
                 ops.view_transform_bwd(W, grads, pool_x, pool_rgbm, pool_dirs, None, None, None, precision=prec,
                                        stages=ops.STAGE_TAPE, workspace=vws)
-            if gws is not None:
-                gws.zero_()           # the frustum scatter's record volume: zero-filled here, off the critical path
+            if gws is not None and _GWS_STATE.get(gws.data_ptr()) != "zero":
+                # the frustum scatter's record volume: ufr_project_gather_bwd leaves it zero again (it reads and re-zeroes
+                # only what the scatter touched), so it is filled once per allocation -- or after a call that did not return
+                gws.zero_()
         # (the ray weight-gradient contractions feed nothing downstream either: tape + data gradients first, on both
         # streams; the contractions afterwards on the side stream, beside the view transformer's data gradients)
         with torch.cuda.stream(side):
@@ -301,8 +304,12 @@ class RenderTwoPass(torch.autograd.Function):
             gf = gw = None
         # ONE frustum scatter over all merged samples of a ray (z2: sorted, twice the density of either pass -- the run
         # folding of gather_bwd.hip removes more corner records), d_pv / sim8 addressed through the slot -> row table
+        if gws is not None:
+            _GWS_STATE[gws.data_ptr()] = "in use"
         ops.project_gather_bwd(frame, W, grads, ray_o, ray_d, z2, sim8_pool, d_pv, gf, gw, precision=prec, row=row,
                                accumulate=False, zeroed_workspace=gws)
+        if gws is not None:
+            _GWS_STATE[gws.data_ptr()] = "zero"
         main.wait_stream(side)
         # (no record_stream marks: every tensor the side streams touch stays referenced until this function returns, i.e.
         # until after the join above is enqueued -- whatever reuses its memory later on this stream is ordered behind it;

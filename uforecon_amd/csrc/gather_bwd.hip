@@ -42,13 +42,20 @@ __device__ __forceinline__ T row_up(T v) {
 }
 
 struct VolGrads {
-  float* rec[UFR_NUM_STAGES];     // channel-last scratch of a stage: [NV][D][H][W][kVolCh], zero on entry
+  float* rec[UFR_NUM_STAGES];             // channel-last scratch of a stage: [NV][D][H][W][kVolCh], zero on entry
+  unsigned char* touch[UFR_NUM_STAGES];   // one byte per kTouchGroup consecutive voxels of [NV][D H W]: set by the scatter
 };
+// The rays of a step reach a fraction of the voxels (1 024 rays: a fifth), but the reference-layout gradient tensors are
+// dense.  The scatter marks the groups of 8 consecutive voxels it adds into (a plain byte store: idempotent, no atomic);
+// volume_unpack_kernel reads -- and zeroes again -- only the marked groups and writes zeros for the rest, so the record
+// volume is read where it was written instead of whole, and it LEAVES THE WORKSPACE ZERO: a caller that keeps the workspace
+// zero-fills it once, not 0.9 GB per step (UFR_GBWD_WORKSPACE_ZEROED).
+constexpr int kTouchGroup = 8;
 
 // wave-level: the lanes with `alive` add their 9-float records val[0..8] at float offset key * kVolCh of `base`.
 // slot: this wave's LDS staging area, 64 x 10 floats.
-__device__ __forceinline__ void scatter_records(float* __restrict__ base, bool alive, int key, const float (&val)[9],
-                                                float* slot, int lane) {
+__device__ __forceinline__ void scatter_records(float* __restrict__ base, unsigned char* __restrict__ touch, bool alive, int key,
+                                                const float (&val)[9], float* slot, int lane) {
   const unsigned long long mask = __builtin_amdgcn_ballot_w64(alive);
   if (mask == 0ull) return;                                  // wave-uniform
   const int n = __builtin_popcountll(mask);
@@ -67,7 +74,9 @@ __device__ __forceinline__ void scatter_records(float* __restrict__ base, bool a
     const int rec = r0 + sub;
     if (sub < 7 && rec < n) {
       const float* r = slot + rec * 10;
-      unsafeAtomicAdd(base + (size_t)__builtin_bit_cast(int, r[0]) * kVolCh + c, r[1 + c]);
+      const int k = __builtin_bit_cast(int, r[0]);
+      unsafeAtomicAdd(base + (size_t)k * kVolCh + c, r[1 + c]);
+      if (c == 0) touch[k / kTouchGroup] = 1;
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -136,6 +145,7 @@ __global__ void __launch_bounds__(448) gather_bwd_kernel(FrameDev f, VolGrads vg
     const int D = f.vD[s], H = f.vH[s], W = f.vW[s];
     const size_t plane = (size_t)D * H * W;
     float* grec = vg.rec[s] + (size_t)v * plane * kVolCh;
+    unsigned char* gtouch = vg.touch[s] + (size_t)v * ((plane + kTouchGroup - 1) / kTouchGroup);
     const float ix = unnorm3d_ac(x, W), iy = unnorm3d_ac(y, H), iz = unnorm3d_ac(zn, D);
     const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
     const float wx[2] = {(fx + 1.f) - ix, ix - fx}, wy[2] = {(fy + 1.f) - iy, iy - fy}, wz[2] = {(fz + 1.f) - iz, iz - fz};
@@ -195,27 +205,46 @@ __global__ void __launch_bounds__(448) gather_bwd_kernel(FrameDev f, VolGrads vg
             }
             if (absorbed) alive[dz] = false;
           });
-          scatter_records(grec, alive[dz], off[dz], val[dz], rec_slot, threadIdx.x & 63);
+          scatter_records(grec, gtouch, alive[dz], off[dz], val[dz], rec_slot, threadIdx.x & 63);
         }
       }
   }
 }
 
-// channel-last scratch -> reference layout: feat (N,8,S) and weight (N,1,S) from rec (N,S,12); accumulate: += instead of =
-__global__ void __launch_bounds__(256) volume_unpack_kernel(const float* __restrict__ rec, float* __restrict__ feat,
-                                                             float* __restrict__ weight, int S, int accumulate) {
+// channel-last scratch -> reference layout: feat (N,8,S) and weight (N,1,S) from rec (N,S,12); accumulate: += instead of =.
+// Only the groups the scatter marked are read (and zeroed again, with their mark); the others are zeros (or, accumulating,
+// nothing).  A group's 8 voxels are 8 consecutive threads of one wave: the mark is read by all of them in one instruction
+// and cleared by the first after it.
+__global__ void __launch_bounds__(256) volume_unpack_kernel(float* __restrict__ rec, unsigned char* __restrict__ touch,
+                                                             float* __restrict__ feat, float* __restrict__ weight, int S,
+                                                             int accumulate) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
   if (s >= S) return;
-  const f32x4* src = reinterpret_cast<const f32x4*>(rec + ((size_t)n * S + s) * kVolCh);
-  const f32x4 a = src[0], b = src[1];
-  const float w = rec[((size_t)n * S + s) * kVolCh + 8];
+  const size_t groups = ((size_t)S + kTouchGroup - 1) / kTouchGroup;
+  unsigned char* mark = touch + (size_t)n * groups + s / kTouchGroup;
+  const bool touched = *mark != 0;
+  float v[8], w = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v[c] = 0.f;
+  if (touched) {
+    float* r = rec + ((size_t)n * S + s) * kVolCh;
+    const f32x4 a = ld4(r), b = ld4(r + 4);
+    w = r[8];
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    st4(r, splat4(0.f));
+    st4(r + 4, splat4(0.f));
+    r[8] = 0.f;
+    if (s % kTouchGroup == 0) *mark = 0;     // (behind the wave's read of it: the branch above needed the value)
+  }
   float* fo = feat + (size_t)n * 8 * S + s;
   float* wo = weight + (size_t)n * S + s;
-  const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
   if (accumulate) {
+    if (touched) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) fo[(size_t)c * S] += v[c];
-    *wo += w;
+      for (int c = 0; c < 8; ++c) fo[(size_t)c * S] += v[c];
+      *wo += w;
+    }
   } else {
 #pragma unroll
     for (int c = 0; c < 8; ++c) fo[(size_t)c * S] = v[c];
@@ -223,10 +252,17 @@ __global__ void __launch_bounds__(256) volume_unpack_kernel(const float* __restr
   }
 }
 
+static size_t touch_bytes(const FrameDev& f, int i) {     // per stage: NV maps, each padded to a multiple of 16 bytes
+  const size_t groups = ((size_t)f.vD[i] * f.vH[i] * f.vW[i] + kTouchGroup - 1) / kTouchGroup;
+  return (size_t)f.NV * groups;
+}
 size_t gather_bwd_scratch_floats(const FrameDev& f) {
-  size_t n = 0;
-  for (int i = 0; i < UFR_NUM_STAGES; ++i) n += (size_t)f.NV * f.vD[i] * f.vH[i] * f.vW[i] * kVolCh;
-  return n;
+  size_t n = 0, t = 0;
+  for (int i = 0; i < UFR_NUM_STAGES; ++i) {
+    n += (size_t)f.NV * f.vD[i] * f.vH[i] * f.vW[i] * kVolCh;
+    t += (touch_bytes(f, i) + 15) / 16 * 16;
+  }
+  return n + t / 4;
 }
 
 hipError_t launch_gather_bwd(const FrameDev& f, float* const* grad_feat, float* const* grad_weight, const float* ray_o,
@@ -243,13 +279,18 @@ hipError_t launch_gather_bwd(const FrameDev& f, float* const* grad_feat, float* 
     vg.rec[i] = scratch + off;
     off += (size_t)NV * f.vD[i] * f.vH[i] * f.vW[i] * kVolCh;
   }
+  unsigned char* tb = reinterpret_cast<unsigned char*>(scratch + off);
+  for (int i = 0; i < UFR_NUM_STAGES; ++i) {
+    vg.touch[i] = tb;
+    tb += (touch_bytes(f, i) + 15) / 16 * 16;
+  }
   const size_t lds = sizeof(float) * (64 * NV * 25 + NV * 640);
   hipLaunchKernelGGL(gather_bwd_kernel, dim3((P + 63) / 64), dim3(64 * NV), lds, s, f, vg, ray_o, o_stride, ray_d, z, d_pv, pv_row,
                      P, SN);
   for (int i = 0; i < UFR_NUM_STAGES; ++i) {
     const int S = f.vD[i] * f.vH[i] * f.vW[i];
-    hipLaunchKernelGGL(volume_unpack_kernel, dim3((S + 255) / 256, NV), dim3(256), 0, s, vg.rec[i], grad_feat[i], grad_weight[i], S,
-                       accumulate ? 1 : 0);
+    hipLaunchKernelGGL(volume_unpack_kernel, dim3((S + 255) / 256, NV), dim3(256), 0, s, vg.rec[i], vg.touch[i], grad_feat[i],
+                       grad_weight[i], S, accumulate ? 1 : 0);
   }
   return hipGetLastError();
 }

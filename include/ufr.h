@@ -316,6 +316,8 @@ int ufr_aggregate_bwd(const ufr_raw_weights* raw, const ufr_raw_grads* grads, co
  * call that returned an error leaves it undefined: fill it again). */
 #define UFR_GBWD_ACCUMULATE 1
 #define UFR_GBWD_WORKSPACE_ZEROED 2
+#define UFR_GBWD_NO_PRESIM 4 /* the volume scatter only: the pre_sim_mlp gradients come from another call (both arrays NULL),
+                                which a caller may put on another stream -- the two halves share no output */
 size_t ufr_project_gather_bwd_workspace_bytes(const ufr_frame* frame);
 int ufr_project_gather_bwd(const ufr_frame* frame, const ufr_raw_weights* raw, const ufr_raw_grads* grads,
                            const float* ray_o, int32_t ray_o_stride, const float* ray_d, const float* z, int32_t RN,

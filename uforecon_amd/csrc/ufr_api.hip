@@ -681,7 +681,7 @@ int ufr_project_gather_bwd(const ufr_frame* frame, const ufr_raw_weights* raw, c
                               static_cast<float*>(workspace), (accumulate & UFR_GBWD_ACCUMULATE) != 0,
                               (accumulate & UFR_GBWD_WORKSPACE_ZEROED) != 0, s));
   }
-  {
+  if (!(accumulate & UFR_GBWD_NO_PRESIM)) {
     ProfScope p("presim_bwd", s);
     UFR_HIP(launch_presim_bwd(rp, gp, sim8, d_pv, RN * SN, lowp, s));
   }

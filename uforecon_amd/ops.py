@@ -438,12 +438,13 @@ def project_gather_bwd_workspace_floats(frame: FrameHandle) -> int:
 def project_gather_bwd(frame: FrameHandle, weights: PackedWeights, grads: GradBuffer, ray_o, ray_d, z, sim8, d_pv,
                        grad_vol_feat, grad_vol_weight, precision: Optional[int] = None,
                        row: Optional[torch.Tensor] = None, accumulate: bool = True,
-                       zeroed_workspace: Optional[torch.Tensor] = None) -> None:
+                       zeroed_workspace: Optional[torch.Tensor] = None, presim: bool = True) -> None:
     """Writes the frustum gradients grad_vol_feat[s] (NV,8,D,Hs,Ws) / grad_vol_weight[s] (NV,1,D,Hs,Ws) -- added to what the
     tensors hold (``accumulate``, the default: pass zeros) or overwriting them whole (``accumulate=False``: pass
     ``torch.empty``, no zero-fill needed) -- and accumulates the pre_sim_mlp gradients into `grads`.  ``row`` (RN,SN) int32:
     ``sim8`` / ``d_pv`` are pool tensors and slot (ray, s) owns ``d_pv[row[ray, s]]``.  ``zeroed_workspace``: the scatter's
-    record volume (project_gather_bwd_workspace_floats), already zero-filled by the caller -- ordered before this call."""
+    record volume (project_gather_bwd_workspace_floats), already zero-filled by the caller -- ordered before this call.
+    ``presim=False``: the volume scatter only (UFR_GBWD_NO_PRESIM); the pre_sim_mlp half is the call with both lists None."""
     RN, SN = z.shape
     lib = _lib.load()
     stride = 0 if ray_o.numel() == 3 else 3
@@ -457,7 +458,7 @@ def project_gather_bwd(frame: FrameHandle, weights: PackedWeights, grads: GradBu
     _lib.check(lib.ufr_project_gather_bwd(
         C.byref(frame.frame), C.byref(weights.raw), C.byref(grads.raw), _dev(ray_o, "ray_o"), stride, _dev(ray_d, "ray_d"),
         _dev(z, "z"), RN, SN, _dev(sim8, "sim8"), _dev(d_pv, "d_pv"), None if row is None else _dev(row, "row", torch.int32),
-        gf, gw, int(bool(accumulate)) | (2 if (zeroed_workspace is not None and ws is not None) else 0),
+        gf, gw, int(bool(accumulate)) | (2 if (zeroed_workspace is not None and ws is not None) else 0) | (0 if presim else 4),
         None if ws is None else ws.data_ptr(),
         weights.mode() if precision is None else precision, _stream()), "ufr_project_gather_bwd")
 

@@ -536,6 +536,12 @@ int ufr_deform_conv2d(const float* input, const float* offset, const float* mask
 int ufr_conv2d(const float* input, const float* weight, const float* scale, const float* shift, const float* skip, float* output,
                int32_t B, int32_t cin, int32_t cout, int32_t H, int32_t W, int32_t ksize, int32_t stride, int32_t flags,
                int32_t sigmoid_from, ufr_stream stream);
+/* The sum the smoothing convolutions of the FMT's top-down pathway read (FMT_with_pathway, code1/encoder_utils/fmt/FMT.py:
+ * 226-255: smooth(interpolate(reduce(coarse), size = fine, mode = 'bilinear') + fine)): output_cl [B][2h][2w][C] =
+ * bilinear 2x of reduced_cl [B][h][w][C] (align_corners = False, torch's tap order) + fine [B][C][2h][2w] (planar, as the
+ * reference holds the backbone's maps).  C in {8, 16}.  The reduction and the smoothing are ufr_conv2d calls. */
+int ufr_upsample_add(const float* reduced_cl, const float* fine, float* output_cl, int32_t B, int32_t C, int32_t h, int32_t w,
+                     ufr_stream stream);
 int ufr_deform_conv2d_cl(const float* input_cl, const float* offset_mask, const float* weight, const float* bias,
                          const float* scale, const float* shift, float* output, int32_t B, int32_t C, int32_t Cout, int32_t H,
                          int32_t W, int32_t flags, ufr_stream stream);

@@ -21,7 +21,7 @@ int main(void) {
       (const void*)ufr_view_transform_bwd, (const void*)ufr_view_transform_bwd_stages, (const void*)ufr_ray_transform_bwd_stages, (const void*)ufr_view_transform_tape, (const void*)ufr_ray_transform_tape,
       (const void*)ufr_view_tape_block_points, (const void*)ufr_view_transform_bwd_workspace_bytes, (const void*)ufr_packed_bwd_halfwords, (const void*)ufr_pack_plan_bwd, (const void*)ufr_status_poll_bits, (const void*)ufr_render_workspace_bytes, (const void*)ufr_default_chunk_rays,
       (const void*)ufr_render_rays, (const void*)ufr_correlate_workspace_bytes, (const void*)ufr_frustum_correlate,
-      (const void*)ufr_conv3d, (const void*)ufr_tsdf_integrate, (const void*)ufr_deform_conv2d_workspace_bytes, (const void*)ufr_deform_conv2d, (const void*)ufr_pixelwise_view_weights, (const void*)ufr_conv2d, (const void*)ufr_deform_conv2d_cl, (const void*)ufr_fmt_layer_workspace_bytes, (const void*)ufr_fmt_layer,
+      (const void*)ufr_conv3d, (const void*)ufr_tsdf_integrate, (const void*)ufr_deform_conv2d_workspace_bytes, (const void*)ufr_deform_conv2d, (const void*)ufr_pixelwise_view_weights, (const void*)ufr_conv2d, (const void*)ufr_upsample_add, (const void*)ufr_deform_conv2d_cl, (const void*)ufr_fmt_layer_workspace_bytes, (const void*)ufr_fmt_layer,
       (const void*)ufr_profile_enable, (const void*)ufr_profile_read};
   unsigned i, n = sizeof(syms) / sizeof(syms[0]);
   for (i = 0; i < n; ++i)

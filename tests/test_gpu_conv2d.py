@@ -131,3 +131,26 @@ def test_pixelwise_view_weights_equal_the_module_and_the_reference_aggregate(NS,
     assert vw.shape == (NS, H, W) and agg.shape == (D, H, W)
     assert float((vw - want_vw).abs().max()) < 2e-6 and _rel(agg, want_agg) < 1e-5
     assert frustum.view_weights(net, sim, want_aggregate=False)[1] is None
+
+
+def test_fmt_pathway_on_hip_kernels_equals_the_library_expression():
+    """FMT_with_pathway's two `_push_down` steps (FMT.py:226-255) through ufr_conv2d + ufr_upsample_add against the
+    layer-by-layer torch expression (1x1 conv, F.interpolate bilinear, add, 3x3 conv) -- odd extents at the coarse level."""
+    from uforecon_amd import fmt
+
+    m = fill_state_dict(fmt.FMT_with_pathway(8), 5).eval().to(DEV)
+    g = torch.Generator().manual_seed(9)
+    B, h, w = 2, 17, 23
+    s1 = torch.randn(B, 32, h, w, generator=g).to(DEV)
+    f2 = torch.randn(B, 16, 2 * h, 2 * w, generator=g).to(DEV)
+    f3 = torch.randn(B, 8, 4 * h, 4 * w, generator=g).to(DEV)
+    with torch.no_grad():
+        want2 = m._push_down(s1, f2, m.dim_reduction_1, m.smooth_1)
+        want3 = m._push_down(want2, f3, m.dim_reduction_2, m.smooth_2)
+        got2, got3 = m._pathway_hip(s1, f2, f3)
+    assert got2.shape == want2.shape and got3.shape == want3.shape and got2.is_contiguous() and got3.is_contiguous()
+    assert _rel(got2, want2) < 2e-5 and _rel(got3, want3) < 2e-5
+    # the sum the smoothing convolution reads
+    r = torch.randn(B, h, w, 16, generator=g).to(DEV)
+    want = F.interpolate(r.permute(0, 3, 1, 2), size=(2 * h, 2 * w), mode="bilinear") + f2
+    assert _rel(ops.upsample_add(r, f2).permute(0, 3, 1, 2), want) < 1e-6

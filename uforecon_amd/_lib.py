@@ -129,6 +129,7 @@ SIGNATURES = {
     "ufr_deform_conv2d_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "ufr_deform_conv2d": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
     "ufr_conv2d": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ufr_upsample_add": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "ufr_deform_conv2d_cl": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "ufr_fmt_layer_workspace_bytes": (sz, [i32, i32]),
     "ufr_fmt_layer": (C.c_int, [C.POINTER(FmtLayerWeights), vp, vp, i32, i32, i32, vp, vp, vp]),

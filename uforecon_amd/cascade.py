@@ -212,6 +212,10 @@ class TransMVSNetCascade(nn.Module):
         H, W = img_hw
         B = depth_values.shape[0]
         depth_min, depth_max = float(depth_values[0, 0].cpu()), float(depth_values[0, -1].cpu())
+        # the projection matrices go to the host ONCE here (the correlate kernel takes the 12 numbers of a relative projection
+        # by value: frustum.relative_projections): fetched per stage and frame they were nine device-to-host round trips per
+        # frame, each draining the queue in the middle of the cascade
+        proj_matrices = {k: v.detach().float().cpu() for k, v in proj_matrices.items()}
         depth_interval = (depth_max - depth_min) / depth_values.size(1)
         outputs, depth, view_weights = {}, None, None
         dev, dt = features[0]["stage1"].device, features[0]["stage1"].dtype

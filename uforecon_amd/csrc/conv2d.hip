@@ -201,6 +201,33 @@ __global__ void __launch_bounds__(256) conv2d_stem_kernel(Conv2dArgs a) {
   }
 }
 
+// The top-down pathway of the FMT (FMT_with_pathway._push_down, code1/encoder_utils/fmt/FMT.py:226-235): the sum that the
+// smoothing convolution reads, out = bilinear_2x(reduced) + fine, written channel-last.  reduced [B][h][w][C] channel-last
+// (the 1x1 reduction of the coarser level), fine [B][C][2h][2w] planar (the backbone's map as the reference holds it).
+// F.interpolate(size = 2x, mode = 'bilinear', align_corners = False): source coordinate max(0.5 (d + 0.5) - 0.5, 0), the
+// second tap clamped at the border, value = h0 (w0 v00 + w1 v01) + h1 (w0 v10 + w1 v11) -- torch's order.
+template <int C>
+__global__ void __launch_bounds__(256) upsample_add_kernel(const float* __restrict__ reduced, const float* __restrict__ fine,
+                                                          float* __restrict__ out, int h, int w) {
+  constexpr int Q = C / 4;
+  const int H = 2 * h, W = 2 * w, b = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= H * W * Q) return;
+  const int q = t % Q, p = t / Q, y = p / W, x = p - y * W;
+  const float sy = fmaxf(0.5f * ((float)y + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * ((float)x + 0.5f) - 0.5f, 0.f);
+  const int y0 = (int)sy, x0 = (int)sx, y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+  const float h1 = sy - (float)y0, h0 = 1.f - h1, w1 = sx - (float)x0, w0 = 1.f - w1;
+  const float* r = reduced + (size_t)b * h * w * C + 4 * q;
+  const f32x4 v00 = ld4(r + ((size_t)y0 * w + x0) * C), v01 = ld4(r + ((size_t)y0 * w + x1) * C),
+              v10 = ld4(r + ((size_t)y1 * w + x0) * C), v11 = ld4(r + ((size_t)y1 * w + x1) * C);
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    o[e] = (h0 * (w0 * v00[e] + w1 * v01[e]) + h1 * (w0 * v10[e] + w1 * v11[e])) +
+           fine[((size_t)b * C + 4 * q + e) * H * W + p];
+  st4(out + ((size_t)b * H * W + p) * C + 4 * q, o);
+}
+
 template <int CIN, int KS, int S, int NT>
 hipError_t launch_conv2d_t(const Conv2dArgs& a, hipStream_t s) {
   const int n_groups = (a.Ho * a.Wo + 255) / 256;
@@ -230,8 +257,19 @@ hipError_t launch_conv2d(const Conv2dArgs& a, int cin, int ks, int stride, int i
   UFR_C2_CASE(32, 1, 1, 2)     // out1.0
   UFR_C2_CASE(16, 1, 1, 2)     // inner1 (16 -> 32)
   UFR_C2_CASE(8, 1, 1, 2)      // inner2 (8 -> 32)
+  UFR_C2_CASE(32, 1, 1, 1)     // FMT pathway: dim_reduction_1 (32 -> 16)
+  UFR_C2_CASE(16, 1, 1, 1)     // FMT pathway: dim_reduction_2 (16 -> 8)
 #undef UFR_C2_CASE
   return hipErrorInvalidValue;
+}
+
+hipError_t launch_upsample_add(const float* reduced, const float* fine, float* out, int B, int C, int h, int w, hipStream_t s) {
+  const int n = 4 * h * w * (C / 4);
+  const dim3 grid((n + 255) / 256, B), block(256);
+  if (C == 16) hipLaunchKernelGGL(upsample_add_kernel<16>, grid, block, 0, s, reduced, fine, out, h, w);
+  else if (C == 8) hipLaunchKernelGGL(upsample_add_kernel<8>, grid, block, 0, s, reduced, fine, out, h, w);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
 }
 
 }  // namespace ufr

@@ -1251,6 +1251,16 @@ int ufr_conv2d(const float* input, const float* weight, const float* scale, cons
   return UFR_OK;
 }
 
+int ufr_upsample_add(const float* reduced_cl, const float* fine, float* output_cl, int32_t B, int32_t C, int32_t h, int32_t w,
+                     ufr_stream stream) {
+  UFR_REQUIRE(reduced_cl && fine && output_cl, "ufr_upsample_add: null argument");
+  UFR_REQUIRE((C == 8 || C == 16) && B > 0 && h > 0 && w > 0, "ufr_upsample_add: B=%d C=%d h=%d w=%d (C in {8, 16})", B, C, h, w);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ProfScope p("upsample_add", s);
+  UFR_HIP(launch_upsample_add(reduced_cl, fine, output_cl, B, C, h, w, s));
+  return UFR_OK;
+}
+
 int ufr_deform_conv2d_cl(const float* input_cl, const float* offset_mask, const float* weight, const float* bias,
                          const float* scale, const float* shift, float* output, int32_t B, int32_t C, int32_t Cout, int32_t H,
                          int32_t W, int32_t flags, ufr_stream stream) {

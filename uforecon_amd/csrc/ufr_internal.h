@@ -145,6 +145,7 @@ struct Conv2dArgs {
   int relu, out_planar, sigmoid_from;   // sigmoid on channels >= sigmoid_from (< 0: none)
 };
 hipError_t launch_conv2d(const Conv2dArgs& a, int cin, int ks, int stride, int in_planar, hipStream_t s);
+hipError_t launch_upsample_add(const float* reduced, const float* fine, float* out, int B, int C, int h, int w, hipStream_t s);
 // dcn.hip, channel-last form: epilogue out = [relu]((dcn + bias) * scale + shift), channel-last or planar output
 struct DcnEpilogue {
   const float* scale;

@@ -153,6 +153,18 @@ class FMT_with_pathway(nn.Module):
         up = F.interpolate(reduce(coarse), size=fine.shape[-2:], mode="bilinear")
         return smooth(up + fine)
 
+    def _pathway_hip(self, s1, f2, f3):
+        """The two `_push_down` steps of one view on HIP kernels (ufr_conv2d, ufr_upsample_add): 1x1 reduction, bilinear 2x +
+        the backbone's map, 3x3 smoothing -- channel-last in between, the reference's (B,C,H,W) maps out.  Needs the levels to
+        be exact factors of two apart (they are: the backbone's stages)."""
+        from . import ops
+        w = lambda c: c.weight.detach().float().contiguous()
+        s1_cl = s1.detach().float().permute(0, 2, 3, 1).contiguous()
+        t2 = ops.upsample_add(ops.conv2d(s1_cl, w(self.dim_reduction_1)), f2.detach().float().contiguous())
+        s2_cl = ops.conv2d(t2, w(self.smooth_1))
+        t3 = ops.upsample_add(ops.conv2d(s2_cl, w(self.dim_reduction_2)), f3.detach().float().contiguous())
+        return s2_cl.permute(0, 3, 1, 2).contiguous(), ops.conv2d(t3, w(self.smooth_2), out_planar=True)
+
     def forward(self, features, ref_idx=0):
         """``features``: per view {"stage1","stage2","stage3"} backbone maps (updated in place, FMT.py:237-255).  The
         reference view goes first because the source views attend to its intermediates."""
@@ -165,8 +177,13 @@ class FMT_with_pathway(nn.Module):
                 f["stage1"] = ref_levels[-1]
             else:
                 f["stage1"] = self.FMT(ref_levels, f["stage1"], feat="src")
-            f["stage2"] = self._push_down(f["stage1"], f["stage2"], self.dim_reduction_1, self.smooth_1)
-            f["stage3"] = self._push_down(f["stage2"], f["stage3"], self.dim_reduction_2, self.smooth_2)
+            s1, f2, f3 = f["stage1"], f["stage2"], f["stage3"]
+            if (s1.is_cuda and not torch.is_grad_enabled() and f2.shape[-2:] == (2 * s1.shape[-2], 2 * s1.shape[-1])
+                    and f3.shape[-2:] == (2 * f2.shape[-2], 2 * f2.shape[-1]) and self.dim_reduction_1.weight.shape[:2] == (16, 32)):
+                f["stage2"], f["stage3"] = self._pathway_hip(s1, f2, f3)
+            else:       # layer by layer (library ops): the statement of what the kernels compute; other channel counts
+                f["stage2"] = self._push_down(s1, f2, self.dim_reduction_1, self.smooth_1)
+                f["stage3"] = self._push_down(f["stage2"], f3, self.dim_reduction_2, self.smooth_2)
         return features
 
     def pair_features(self, features):

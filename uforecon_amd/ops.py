@@ -774,6 +774,18 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, scale: Option
     return out
 
 
+def upsample_add(reduced_cl: torch.Tensor, fine: torch.Tensor) -> torch.Tensor:
+    """``bilinear_2x(reduced_cl (B,h,w,C)) + fine (B,C,2h,2w)`` -> channel-last (B,2h,2w,C) (ufr_upsample_add: the sum the
+    smoothing convolutions of the FMT pathway read)."""
+    B, h, w, Cc = reduced_cl.shape
+    if tuple(fine.shape) != (B, Cc, 2 * h, 2 * w):
+        raise UfrError(f"upsample_add: fine {tuple(fine.shape)} is not (B,C,2h,2w) of reduced {tuple(reduced_cl.shape)}")
+    out = torch.empty(B, 2 * h, 2 * w, Cc, dtype=torch.float32, device=fine.device)
+    _lib.check(_lib.load().ufr_upsample_add(_dev(reduced_cl, "reduced"), _dev(fine, "fine"), out.data_ptr(), B, Cc, h, w, _stream()),
+               "ufr_upsample_add")
+    return out
+
+
 def deform_conv2d_cl(x_cl: torch.Tensor, offset_mask: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
                      scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, relu: bool = False,
                      out_planar: bool = False):

@@ -18,11 +18,17 @@
 #include "ufr_internal.h"
 #include "weight_stream.h"   // static_for
 
+#ifndef UFR_C3_FOLD
+#define UFR_C3_FOLD 1
+#endif
+
 namespace ufr {
 
 namespace {
 
 enum ConvMode : int { kConvS1 = 0, kConvS2 = 1, kDeconvS2 = 2 };
+// kernel-internal: the transposed mode with the x parity FOLDED into the channel axis (conv3d_kernel below)
+constexpr int kDeconvS2F = 3;
 
 struct Conv3dArgs {
   const float* in;      // [B][D][H][W][CIN]
@@ -50,6 +56,15 @@ constexpr int taps_per_chunk() {
 
 template <int CIN, int COUT, int MODE, int R>
 __global__ void __launch_bounds__(256) conv3d_kernel(Conv3dArgs a) {
+  // kDeconvS2F (round 5): a thread owns BOTH x parities of its output pair (2 m, 2 m + 1): template COUT = 2 x the layer's
+  // channels, [parity 0 | parity 1].  The per-class form wrote every other voxel of a row from a block -- 32-byte pieces at a
+  // 64-byte stride, the other halves arriving later from another block, usually on another XCD: two partial writes per line.
+  // Folded, a lane's store is its pair's 2 x cout contiguous floats and a wave's is one contiguous run.  Taps along x become
+  // the two inputs m (kx = 1 for parity 0, kx = 2 for parity 1) and m + 1 (kx = 0 for parity 1; a zero block for parity 0:
+  // a quarter of the multiply-adds idle, on layers that are bound by their stores).
+  constexpr bool FOLD = MODE == kDeconvS2F;
+  constexpr bool DE = MODE == kDeconvS2 || FOLD;
+  constexpr int CO = FOLD ? COUT / 2 : COUT;       // channels of one output voxel
   constexpr int TC = taps_per_chunk<CIN, COUT>();
   __shared__ __attribute__((aligned(16))) float wlds[TC * CIN * COUT];
   const int tid = threadIdx.x;
@@ -57,20 +72,21 @@ __global__ void __launch_bounds__(256) conv3d_kernel(Conv3dArgs a) {
   // ---- which output voxels, and the tap list of this block
   int pz = 0, py = 0, px = 0;            // transposed: parity class of the outputs
   int Ds = a.Do, Hs = a.Ho, Ws = a.Wo;   // extent of the (sub-)grid this block's threads enumerate
-  if (MODE == kDeconvS2) {
-    pz = (blockIdx.y >> 2) & 1; py = (blockIdx.y >> 1) & 1; px = blockIdx.y & 1;
+  if (DE) {
+    if (FOLD) { pz = (blockIdx.y >> 1) & 1; py = blockIdx.y & 1; px = 0; }
+    else { pz = (blockIdx.y >> 2) & 1; py = (blockIdx.y >> 1) & 1; px = blockIdx.y & 1; }
     Ds = a.Do / 2; Hs = a.Ho / 2; Ws = a.Wo / 2;
   }
   const long long n_sub = (long long)a.B * Ds * Hs * Ws;
   // taps: conv: all 27 (kz,ky,kx); transposed, per dimension: parity 0 -> {k=1, i=m}; parity 1 -> {k=0, i=m+1}, {k=2, i=m}
-  const int nz = MODE == kDeconvS2 ? 1 + pz : 3, ny = MODE == kDeconvS2 ? 1 + py : 3, nx = MODE == kDeconvS2 ? 1 + px : 3;
+  const int nz = DE ? 1 + pz : 3, ny = DE ? 1 + py : 3, nx = FOLD ? 2 : (DE ? 1 + px : 3);
   const int n_taps = nz * ny * nx;
   auto tap_k = [&](int t, int n, int par) -> int {      // kernel index of local tap t in one dimension
-    if (MODE != kDeconvS2) return t;
+    if (!DE) return t;
     return par == 0 ? 1 : (t == 0 ? 0 : 2);
   };
   auto tap_di = [&](int t, int par) -> int {            // input offset of that tap relative to the base index
-    if (MODE == kConvS1 || MODE == kConvS2) return t - 1;
+    if (!DE) return t - 1;
     return par == 0 ? 0 : (t == 0 ? 1 : 0);
   };
 
@@ -106,11 +122,16 @@ __global__ void __launch_bounds__(256) conv3d_kernel(Conv3dArgs a) {
       const int co = i % COUT, ci = (i / COUT) % CIN, tl = i / (COUT * CIN);
       const int t = t0 + tl;
       const int tz = t / (ny * nx), ty = (t / nx) % ny, tx = t % nx;
-      const int k = (tap_k(tz, nz, pz) * 3 + tap_k(ty, ny, py)) * 3 + tap_k(tx, nx, px);
+      int k = (tap_k(tz, nz, pz) * 3 + tap_k(ty, ny, py)) * 3 + tap_k(tx, nx, px);
       float w = 0.f;
-      if (co < a.cout_real) {
+      if (FOLD) {     // co = [x parity][channel]; input m (tx = 0): kx = 1 | 2, input m + 1 (tx = 1): none | 0
+        const int par = co / CO, cr = co - par * CO;
+        const int kx = tx == 0 ? 1 + par : (par == 0 ? -1 : 0);
+        k = (tap_k(tz, nz, pz) * 3 + tap_k(ty, ny, py)) * 3 + kx;
+        if (kx >= 0 && cr < a.cout_real) w = a.weight[((size_t)ci * a.cout_real + cr) * 27 + k];
+      } else if (co < a.cout_real) {
         if (MODE == kConvS1 && a.flip) w = a.weight[((size_t)ci * a.cout_real + co) * 27 + (26 - k)];
-        else w = MODE == kDeconvS2 ? a.weight[((size_t)ci * a.cout_real + co) * 27 + k] : a.weight[((size_t)co * CIN + ci) * 27 + k];
+        else w = DE ? a.weight[((size_t)ci * a.cout_real + co) * 27 + k] : a.weight[((size_t)co * CIN + ci) * 27 + k];
       } else if (a.weight2 && co < a.cout_real + a.cout2) {
         w = a.weight2[((size_t)(co - a.cout_real) * CIN + ci) * 27 + k];
       }
@@ -120,7 +141,7 @@ __global__ void __launch_bounds__(256) conv3d_kernel(Conv3dArgs a) {
     for (int tl = 0; tl < tn; ++tl) {
       const int t = t0 + tl;
       const int tz = t / (ny * nx), ty = (t / nx) % ny, tx = t % nx;
-      const int dz = tap_di(tz, pz), dy = tap_di(ty, py), dx = tap_di(tx, px);
+      const int dz = tap_di(tz, pz), dy = tap_di(ty, py), dx = FOLD ? tx : tap_di(tx, px);
       float x[R][CIN];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -161,16 +182,16 @@ __global__ void __launch_bounds__(256) conv3d_kernel(Conv3dArgs a) {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     if (!live[r]) continue;
-    const int oz = MODE == kDeconvS2 ? 2 * vz[r] + pz : vz[r], oy = MODE == kDeconvS2 ? 2 * vy[r] + py : vy[r],
-              ox = MODE == kDeconvS2 ? 2 * vx[r] + px : vx[r];
+    const int oz = DE ? 2 * vz[r] + pz : vz[r], oy = DE ? 2 * vy[r] + py : vy[r], ox = DE ? 2 * vx[r] + px : vx[r];
     const size_t vox = (((size_t)vb[r] * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
     float y[COUT];
 #pragma unroll
     for (int c = 0; c < COUT; ++c) {
       float v = acc[r][c >> 1][c & 1];
-      if (c < a.cout_real) {
-        if (a.bias) v += a.bias[c];
-        if (a.scale) v = fmaf(v, a.scale[c], a.shift[c]);
+      const int cr = FOLD ? c % CO : c;      // the layer's channel of slot c
+      if (cr < a.cout_real) {
+        if (a.bias) v += a.bias[cr];
+        if (a.scale) v = fmaf(v, a.scale[cr], a.shift[cr]);
         if (a.relu) v = fmaxf(v, 0.f);
       }
       y[c] = v;
@@ -184,8 +205,8 @@ __global__ void __launch_bounds__(256) conv3d_kernel(Conv3dArgs a) {
           a.out2[((size_t)vb[r] * a.cout2 + (c - a.cout_real)) * plane + sp] = 1.f / (1.f + expf(-y[c]));
       }
     } else {
-      float* o = a.out + vox * COUT;
-      const float* sk = a.skip ? a.skip + vox * COUT : nullptr;
+      float* o = a.out + vox * CO;          // FOLD: the pair's 2 CO floats are contiguous (x is the fastest voxel axis)
+      const float* sk = a.skip ? a.skip + vox * CO : nullptr;
       if constexpr (COUT % 4 == 0) {
 #pragma unroll
         for (int c4 = 0; c4 < COUT / 4; ++c4) {
@@ -200,11 +221,12 @@ __global__ void __launch_bounds__(256) conv3d_kernel(Conv3dArgs a) {
 
 template <int CIN, int COUT, int MODE, int R>
 hipError_t launch_conv_t(const Conv3dArgs& a, hipStream_t s) {
-  const bool de = MODE == kDeconvS2;
+  const bool de = MODE == kDeconvS2 || MODE == kDeconvS2F;
   const long long n_sub = (long long)a.B * (de ? a.Do / 2 : a.Do) * (de ? a.Ho / 2 : a.Ho) * (de ? a.Wo / 2 : a.Wo);
   const long long blocks = (n_sub + 256LL * R - 1) / (256LL * R);
   if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((conv3d_kernel<CIN, COUT, MODE, R>), dim3((unsigned)blocks, de ? 8 : 1), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((conv3d_kernel<CIN, COUT, MODE, R>), dim3((unsigned)blocks, MODE == kDeconvS2F ? 4 : (de ? 8 : 1)), dim3(256), 0,
+                     s, a);
   return hipGetLastError();
 }
 
@@ -380,6 +402,11 @@ hipError_t launch_conv3d(const float* in, const float* weight, const float* weig
   UFR_CONV_CASE(32, 64, kConvS2, 1)     // conv5
   UFR_CONV_CASE(64, 64, kConvS1, 1)     // conv6
   UFR_CONV_CASE(64, 32, kDeconvS2, 2)   // conv7
+#if UFR_C3_FOLD
+  // (transposed layers that write the two finest grids: the x parity folded into the channel axis, see conv3d_kernel)
+  if (cin == 32 && ct == 16 && mode == kDeconvS2 && !a.ncdhw && a.Wo % 2 == 0) return launch_conv_t<32, 32, kDeconvS2F, 1>(a, s);
+  if (cin == 16 && ct == 8 && mode == kDeconvS2 && !a.ncdhw && a.Wo % 2 == 0) return launch_conv_t<16, 16, kDeconvS2F, 2>(a, s);
+#endif
   UFR_CONV_CASE(32, 16, kDeconvS2, 2)   // conv9
   UFR_CONV_CASE(16, 8, kDeconvS2, 2)    // conv11
   UFR_CONV_CASE(8, 4, kConvS1, 2)       // prob (1 channel)

@@ -181,7 +181,10 @@ def test_frame_features_far_beyond_the_floor_render_without_a_stated_bound():
     tokens through weights that never saw the frame (ufr_aggregate directly) trip the sticky status: the backstop."""
     from test_gpu_parity import _ray_setup
 
+    import copy
+
     fr, idx, U1, U2, g = case_inputs("rows_small")
+    fr = copy.deepcopy(fr)          # (helpers.case_frame caches the frame object: scale a private copy, not the suite's)
     scale = 1.0e4
     fr.source_imgs_feat = fr.source_imgs_feat * scale
     for st in fr.feature_volume:

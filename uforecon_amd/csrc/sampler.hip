@@ -197,6 +197,47 @@ __global__ void __launch_bounds__(256) importance_merge_kernel(const float* __re
   // re-evaluates only the new points and reads the coarse ones back through this table.
   const int T = SN + PN;
   float* out = z_all + (size_t)ray * T;
+  // The rank of every sample in the concatenation, ties broken by index (a stable sort, as torch.sort of model.py:466).
+  // Fast path: when the coarse positions arrive sorted (FixedSampler's always do) the 128 x 128 comparisons become the
+  // 64 x 64 that sort the new samples plus one binary search per sample -- a third of the kernel's time.
+  bool sorted_coarse = true;
+  for (int k = lane; k + 1 < SN; k += 64) sorted_coarse = sorted_coarse && all[k] <= all[k + 1];
+  if (__builtin_amdgcn_ballot_w64(!sorted_coarse) == 0ull) {
+    float* fs = cdf;                 // the cdf is dead: the new samples, sorted
+    for (int k = lane; k < PN; k += 64) {
+      const float v = zf[k];
+      int r = 0;
+      for (int j = 0; j < PN; ++j) {
+        const float o = zf[j];
+        r += (o < v || (o == v && j < k)) ? 1 : 0;
+      }
+      fs[r] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // coarse sample k: behind it come the new samples that are strictly smaller (an equal new sample has the larger index)
+    for (int k = lane; k < SN; k += 64) {
+      const float v = all[k];
+      int lo = 0, hi = PN;
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (fs[mid] < v) lo = mid + 1; else hi = mid; }
+      // (equal coarse samples keep their order: k counts the coarse samples before this one)
+      const int rank = k + lo;
+      out[rank] = v;
+      if (src_row) src_row[(size_t)ray * T + rank] = ray * SN + k;
+    }
+    // new sample of sorted rank r: in front of it the r new ones before it and the coarse ones that are <= it
+    for (int r = lane; r < PN; r += 64) {
+      const float v = fs[r];
+      int lo = 0, hi = SN;
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (all[mid] <= v) lo = mid + 1; else hi = mid; }
+      const int rank = r + lo;
+      out[rank] = v;
+      if (src_row) src_row[(size_t)ray * T + rank] = RN * SN + ray * PN + r;
+      if (z_new) z_new[(size_t)ray * PN + r] = v;
+    }
+    return;
+  }
   for (int k = lane; k < T; k += 64) {
     float v = all[k];
     int rank = 0, rank_new = 0;   // among all merged samples / among the new ones only

@@ -9,8 +9,9 @@
 // into 160 register accumulators, wave reduction, one PARTIAL per wave -- summed in a fixed order by `fmt_state_sum_kernel`,
 // not with float atomics: the frame encoder must give the same bits in every process, or a frame rendered by two ranks
 // would not equal the same frame rendered by one) and `fmt_apply_kernel` (one token per thread: 6 272 FMAs with
-// the weights broadcast from LDS).  d = 32 is too narrow for the matrix cores to pay (a 16x16x4 tile chain would be all
-// latency); on the VALU the whole stage of a 512x640 3-view frame (about 70 layer passes over 20 480 tokens) is ~9 GFMA.
+// the weights broadcast from LDS).  Those are the round-3 vector kernels (kept behind UFR_FMT_MFMA = 0 as the A/B); since
+// round 5 both run on the fp32 matrix cores with tokens as MFMA columns (`fmt_state_mfma_kernel`, `fmt_apply_mfma_kernel`
+// below: 3.5 -> 1.1 ms per frame), same fixed-order partial sums.
 #include "ufr_device.h"
 #include "ufr_internal.h"
 
@@ -205,6 +206,284 @@ __global__ void __launch_bounds__(256) fmt_apply_kernel(FmtWeights w, const floa
   for (int i = 0; i < 8; ++i) st4(dst + 4 * i, f32x4{hsum[4 * i], hsum[4 * i + 1], hsum[4 * i + 2], hsum[4 * i + 3]});
 }
 
+// ---- the same two kernels on the fp32 matrix cores (round 5).  "d = 32 is too narrow for the matrix cores" was wrong the
+// way the vector kernels were built: one token per thread is 6 272 dependent FMAs behind 1 568 LDS weight reads with ONE
+// wave per SIMD (61 440 tokens = 960 waves), i.e. all latency: 52 us per call for 0.4 GFLOP.  With tokens as the 16 MFMA
+// columns (four column tiles = 64 tokens per wave), a layer's accumulator tile -- lane (g, j): features 16 t + 4 g + r of
+// token j -- IS the B operand of the next layer's k-step (tile t, r), the chain pre_sim_mlp runs in the gather kernel
+// (gather.hip: presim_block); the A operands are the weights in LDS, stored in fragment order (lane (g, j): row 16 to + j,
+// column 16 ti + 4 g + r).  A lane's four values of a tile are the four dimensions of ONE head (h = 4 t + g), so the linear
+// attention -- phi(q) . KV_h, the normaliser -- is lane-local; LayerNorm reduces over the four lane groups with two
+// shuffles.  v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 sums.
+template <int OUT, int IN>
+__device__ __forceinline__ void fmt_stage_frags(float* __restrict__ dst, const float* __restrict__ w, int tid, int nthreads) {
+  // dst[((to * (IN / 16) + ti) * 4 + r) * 64 + lane] = w[(16 to + j) * IN + 16 ti + 4 g + r], lane = 16 g + j: the matrix is READ
+  // in its own order (coalesced; a strided gather per fragment element was most of the kernel's prologue) and scattered into LDS
+  for (int i = tid; i < OUT * IN; i += nthreads) {
+    const int o = i / IN, c = i - o * IN;
+    const int to = o >> 4, j = o & 15, ti = c >> 4, g = (c >> 2) & 3, r = c & 3;
+    dst[((to * (IN / 16) + ti) * 4 + r) * 64 + 16 * g + j] = w[i];
+  }
+}
+// out[u][to] += W in[u]:  NI input tiles, NO output tiles, four column tiles
+template <int NO, int NI>
+__device__ __forceinline__ void fmt_gemm(const float* __restrict__ frags, int lane, const f32x4 (&in)[4][NI], f32x4 (&out)[4][NO]) {
+#pragma unroll
+  for (int ti = 0; ti < NI; ++ti)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int to = 0; to < NO; ++to) {
+        const float a = frags[((to * NI + ti) * 4 + r) * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) out[u][to] = mfma16(a, in[u][ti][r], out[u][to]);
+      }
+}
+// LayerNorm over the 32 features of a token held as y[2] (tiles) x 4 registers in each of the four lane groups of column j
+__device__ __forceinline__ void fmt_layer_norm(f32x4 (&y)[2], const float* __restrict__ gam, const float* __restrict__ bet, int g) {
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s += y[t][r];
+  s += __shfl_xor(s, 16);
+  s += __shfl_xor(s, 32);
+  const float mean = s * (1.f / 32);
+  float q = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float c = y[t][r] - mean;
+      q = fmaf(c, c, q);
+    }
+  q += __shfl_xor(q, 16);
+  q += __shfl_xor(q, 32);
+  const float rstd = 1.f / sqrtf(q * (1.f / 32) + 1e-5f);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const f32x4 gg = ld4(gam + 16 * t + 4 * g), bb = ld4(bet + 16 * t + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[t][r] = fmaf((y[t][r] - mean) * rstd, gg[r], bb[r]);
+  }
+}
+
+constexpr int kFmtTokPerBlockMfma = 256;    // one 64-token step per wave: four times the workgroups of the vector kernel
+__global__ void __launch_bounds__(256) fmt_state_mfma_kernel(FmtWeights w, const float* __restrict__ src, int S,
+                                                              float* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) float sw[2 * 1024 + 64 + 4 * kFmtState];
+  float* fk = sw;
+  float* fv = sw + 1024;
+  float* sbk = fv + 1024;
+  float* sbv = sbk + 32;
+  float* red = sbv + 32;          // [wave][160]
+  fmt_stage_frags<32, 32>(fk, w.wk, threadIdx.x, 256);
+  fmt_stage_frags<32, 32>(fv, w.wv, threadIdx.x, 256);
+  if (threadIdx.x < 32) { sbk[threadIdx.x] = w.bk[threadIdx.x]; sbv[threadIdx.x] = w.bv[threadIdx.x]; }
+  __syncthreads();
+  const int n = blockIdx.y, lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
+  // this lane's heads: h = 4 to + g (to = 0, 1); kv[to][m][d], ks[to][d] over the lane's token columns
+  float kv[2][4][4], ks[2][4];
+#pragma unroll
+  for (int to = 0; to < 2; ++to)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      ks[to][d] = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) kv[to][m][d] = 0.f;
+    }
+  const int t0 = blockIdx.x * kFmtTokPerBlockMfma + wave * 64;
+  if (t0 < S) {
+    f32x4 x[4][2], kk[4][2], vv[4][2];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + 16 * u + j;
+      ok[u] = t < S;
+      const float* px = src + ((size_t)n * S + (ok[u] ? t : S - 1)) * kFmtD + 4 * g;
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) {
+        x[u][ti] = ld4(px + 16 * ti);
+        kk[u][ti] = ld4(sbk + 16 * ti + 4 * g);
+        vv[u][ti] = ld4(sbv + 16 * ti + 4 * g);
+      }
+    }
+    fmt_gemm<2, 2>(fk, lane, x, kk);
+    fmt_gemm<2, 2>(fv, lane, x, vv);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int to = 0; to < 2; ++to)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const float kp = ok[u] ? elu1(kk[u][to][d]) : 0.f;
+          ks[to][d] += kp;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) kv[to][m][d] = fmaf(kp, vv[u][to][m], kv[to][m][d]);
+        }
+  }
+  // sum over the 16 token columns of the lane group, the four waves through LDS in wave order: one PARTIAL per workgroup
+#pragma unroll
+  for (int to = 0; to < 2; ++to)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) ks[to][d] += __shfl_xor(ks[to][d], o);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) kv[to][m][d] += __shfl_xor(kv[to][m][d], o);
+    }
+  if (j == 0) {
+    float* dst = red + wave * kFmtState;
+#pragma unroll
+    for (int to = 0; to < 2; ++to) {
+      const int h = 4 * to + g;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) dst[h * 16 + m * 4 + d] = kv[to][m][d];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) dst[128 + 4 * h + d] = ks[to][d];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kFmtState) {
+    const int i = threadIdx.x;
+    partial[((size_t)n * gridDim.x + blockIdx.x) * kFmtState + i] =
+        ((red[i] + red[kFmtState + i]) + red[2 * kFmtState + i]) + red[3 * kFmtState + i];
+  }
+}
+
+// (the state arrives as the per-workgroup partials of fmt_state_mfma_kernel: every workgroup sums them itself, in index order --
+// the fixed order the separate sum kernel used, one launch and 19 us per layer less)
+__global__ void __launch_bounds__(256) fmt_apply_mfma_kernel(FmtWeights w, const float* __restrict__ x_in, int T,
+                                                              const float* __restrict__ partial, int parts,
+                                                              float* __restrict__ out) {
+  // LDS: fragments of wq | wo | w1 | w2, then bq bo b1 b2 | n1w n1b n2w n2b | state
+  __shared__ __attribute__((aligned(16))) float sw[2 * 1024 + 2 * 2048 + 32 + 32 + 64 + 32 + 4 * 32 + kFmtState];
+  float* fq = sw;
+  float* fo = fq + 1024;
+  float* f1 = fo + 1024;
+  float* f2 = f1 + 2048;
+  float* sbq = f2 + 2048;
+  float* sbo = sbq + 32;
+  float* sb1 = sbo + 32;
+  float* sb2 = sb1 + 64;
+  float* sn = sb2 + 32;           // n1w n1b n2w n2b
+  float* sst = sn + 128;
+  const int n = blockIdx.y;
+  fmt_stage_frags<32, 32>(fq, w.wq, threadIdx.x, 256);
+  fmt_stage_frags<32, 32>(fo, w.wo, threadIdx.x, 256);
+  fmt_stage_frags<64, 32>(f1, w.w1, threadIdx.x, 256);
+  fmt_stage_frags<32, 64>(f2, w.w2, threadIdx.x, 256);
+  if (threadIdx.x < 32) {
+    const int i = threadIdx.x;
+    sbq[i] = w.bq[i]; sbo[i] = w.bo[i]; sb2[i] = w.b2[i];
+    sn[i] = w.n1w[i]; sn[32 + i] = w.n1b[i]; sn[64 + i] = w.n2w[i]; sn[96 + i] = w.n2b[i];
+  }
+  if (threadIdx.x < 64) sb1[threadIdx.x] = w.b1[threadIdx.x];
+  if (threadIdx.x < kFmtState) {
+    const float* pp = partial + (size_t)n * parts * kFmtState + threadIdx.x;
+    float acc = 0.f;
+#pragma unroll 16      // (sixteen loads in flight; the additions stay in index order)
+    for (int k = 0; k < parts; ++k) acc += pp[(size_t)k * kFmtState];
+    sst[threadIdx.x] = acc;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
+  const int t0 = (blockIdx.x * 4 + wave) * 64;
+  if (t0 >= T) return;
+  f32x4 x[4][2], q[4][2];
+  int tok[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int t = t0 + 16 * u + j;
+    tok[u] = t < T ? t : -1;
+    const float* px = x_in + ((size_t)n * T + (t < T ? t : T - 1)) * kFmtD + 4 * g;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+      x[u][ti] = ld4(px + 16 * ti);
+      q[u][ti] = ld4(sbq + 16 * ti + 4 * g);
+    }
+  }
+  fmt_gemm<2, 2>(fq, lane, x, q);
+  // attention message (FMT.py:36-38): this lane's head of tile t is h = 4 t + g
+  f32x4 att[4][2];
+#pragma unroll
+  for (int to = 0; to < 2; ++to) {
+    const int h = 4 * to + g;
+    float kvh[4][4], ksh[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const f32x4 r4 = ld4(sst + h * 16 + m * 4);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) kvh[m][d] = r4[d];
+    }
+    {
+      const f32x4 r4 = ld4(sst + 128 + 4 * h);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) ksh[d] = r4[d];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float qp[4], den = 1e-6f;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        qp[d] = elu1(q[u][to][d]);
+        den = fmaf(qp[d], ksh[d], den);
+      }
+      const float z = 1.f / den;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) sacc = fmaf(qp[d], kvh[m][d], sacc);
+        att[u][to][m] = sacc * z;
+      }
+    }
+  }
+  // y = LN1(x + out_projection(att))
+  f32x4 y[4][2];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int to = 0; to < 2; ++to) y[u][to] = x[u][to] + ld4(sbo + 16 * to + 4 * g);
+  fmt_gemm<2, 2>(fo, lane, att, y);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) fmt_layer_norm(y[u], sn, sn + 32, g);
+  // out = LN2(y + linear2(relu(linear1(y))))
+  f32x4 hid[4][4], o[4][2];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+#pragma unroll
+    for (int to = 0; to < 4; ++to) hid[u][to] = ld4(sb1 + 16 * to + 4 * g);
+#pragma unroll
+    for (int to = 0; to < 2; ++to) o[u][to] = y[u][to] + ld4(sb2 + 16 * to + 4 * g);
+  }
+  fmt_gemm<4, 2>(f1, lane, y, hid);
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int to = 0; to < 4; ++to)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hid[u][to][r] = fmaxf(hid[u][to][r], 0.f);
+  fmt_gemm<2, 4>(f2, lane, hid, o);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    fmt_layer_norm(o[u], sn + 64, sn + 96, g);
+    if (tok[u] >= 0) {
+      float* dst = out + ((size_t)n * T + tok[u]) * kFmtD + 4 * g;
+      st4(dst, o[u][0]);
+      st4(dst + 16, o[u][1]);
+    }
+  }
+}
+
+#ifndef UFR_FMT_MFMA
+#define UFR_FMT_MFMA 1
+#endif
+
 int fmt_state_parts(int S) { return 4 * ((S + kFmtTokPerBlock - 1) / kFmtTokPerBlock); }
 
 // state: N x 160 floats followed by N x fmt_state_parts(S) x 160 floats of per-wave partials
@@ -212,9 +491,15 @@ hipError_t launch_fmt_layer(const FmtWeights& w, const float* x, const float* sr
                             float* state, hipStream_t s) {
   const int parts = fmt_state_parts(S);
   float* partial = state + (size_t)N * kFmtState;
+#if UFR_FMT_MFMA
+  const int blocks = (S + kFmtTokPerBlockMfma - 1) / kFmtTokPerBlockMfma;      // <= parts: the workspace holds them
+  hipLaunchKernelGGL(fmt_state_mfma_kernel, dim3(blocks, N), dim3(256), 0, s, w, src, S, partial);
+  hipLaunchKernelGGL(fmt_apply_mfma_kernel, dim3((T + 255) / 256, N), dim3(256), 0, s, w, x, T, partial, blocks, out);
+#else
   hipLaunchKernelGGL(fmt_state_kernel, dim3(parts / 4, N), dim3(256), 0, s, w, src, S, partial);
   hipLaunchKernelGGL(fmt_state_sum_kernel, dim3(N), dim3(kFmtState), 0, s, partial, parts, state);
   hipLaunchKernelGGL(fmt_apply_kernel, dim3((T + 255) / 256, N), dim3(256), 0, s, w, x, T, state, out);
+#endif
   return hipGetLastError();
 }
 

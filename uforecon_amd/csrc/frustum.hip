@@ -49,7 +49,14 @@ __global__ void __launch_bounds__(256) correlate_kernel(const float* __restrict_
   if (vw)
     for (int i = 0; i < cv.NS; ++i) wsum += vw[(size_t)i * HW + pix];
   const float half_w = (float)(W - 1) / 2.f, half_h = (float)(H - 1) / 2.f;  // python float (W-1)/2 is exact in fp32 here
-  for (int d = 0; d < D; ++d) {
+  // The hypotheses are independent: blockIdx.y takes a run of them (round 5).  A lane group walking all D x NS hypotheses
+  // one dependent bilinear footprint after the other left the coarse stages with 2.5 waves per SIMD and nothing to overlap
+  // (141 us for 32 MB of traffic); with the runs spread over workgroups and the four taps of a footprint as bounded buffer
+  // loads (ufr_device.h: a masked corner reads zeros from past the descriptor's extent -- no branch, all four in flight)
+  // the same work has 8+ waves per SIMD.
+  const int d_per = (D + (int)gridDim.y - 1) / (int)gridDim.y, d0 = (int)blockIdx.y * d_per, d1 = min(D, d0 + d_per);
+  const __amdgpu_buffer_rsrc_t rsrc_v = buf_rsrc(src_cl, (unsigned)((size_t)cv.NS * HW * C * 4));
+  for (int d = d0; d < d1; ++d) {
     const float dep = depth[(size_t)d * HW + pix];
     float ssum = 0.f;
     for (int i = 0; i < cv.NS; ++i) {
@@ -63,10 +70,10 @@ __global__ void __launch_bounds__(256) correlate_kernel(const float* __restrict_
       float xn = (qx / qz) / half_w - 1.f, yn = (qy / qz) / half_h - 1.f;  // :355-358
       if (invalid) { xn = -99.f; yn = -99.f; }
       const Tap2 t = taps_zeros(unnorm2d_ac(xn, W), unnorm2d_ac(yn, H), W, H);
-      const float* base = src_cl + (size_t)i * HW * C + 4 * cl;
+      const unsigned base = ((unsigned)i * (unsigned)HW * C + 4u * cl) * 4u;
       f32x4 v[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = t.o[k] >= 0 ? ld4(base + (size_t)t.o[k] * C) : splat4(0.f);
+      for (int k = 0; k < 4; ++k) v[k] = buf_ld4(rsrc_v, t.o[k] >= 0 ? base + (unsigned)t.o[k] * (C * 4u) : kBufOut);
       float part = 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -163,7 +170,12 @@ hipError_t launch_correlate(const float* ref_cl, const float* src_cl, const floa
     for (int k = 0; k < 12; ++k) cv.m[i][k] = proj_host[i * 12 + k];
   const int LP = C / 4;
   const size_t threads = (size_t)H * W * LP;
-  const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+  // runs of hypotheses per workgroup row: enough for ~8 waves per SIMD, at least 4 hypotheses per run
+  int dsplit = (int)((8192 * 64 + threads - 1) / threads);
+  if (dsplit > D / 4) dsplit = D / 4;
+  if (dsplit < 1) dsplit = 1;
+  if ((size_t)NS * H * W * C * 4 >= (1ull << 31)) return hipErrorInvalidValue;      // (bounded loads: 2^31 bytes of source maps)
+  const dim3 grid((unsigned)((threads + 255) / 256), (unsigned)dsplit), block(256);
   switch (LP) {
     case 1: hipLaunchKernelGGL(correlate_kernel<1>, grid, block, 0, s, ref_cl, src_cl, cv, depth, vw, sim, agg, H, W, D); break;
     case 2: hipLaunchKernelGGL(correlate_kernel<2>, grid, block, 0, s, ref_cl, src_cl, cv, depth, vw, sim, agg, H, W, D); break;

@@ -493,6 +493,7 @@ hipError_t launch_fmt_layer(const FmtWeights& w, const float* x, const float* sr
   float* partial = state + (size_t)N * kFmtState;
 #if UFR_FMT_MFMA
   const int blocks = (S + kFmtTokPerBlockMfma - 1) / kFmtTokPerBlockMfma;      // <= parts: the workspace holds them
+  if (blocks > parts) return hipErrorInvalidValue;
   hipLaunchKernelGGL(fmt_state_mfma_kernel, dim3(blocks, N), dim3(256), 0, s, w, src, S, partial);
   hipLaunchKernelGGL(fmt_apply_mfma_kernel, dim3((T + 255) / 256, N), dim3(256), 0, s, w, x, T, partial, blocks, out);
 #else

@@ -169,6 +169,7 @@ constexpr int kStatThreads = 1024;
 __global__ void __launch_bounds__(kStatThreads) weight_stats_kernel(RawPtrs raw, float* __restrict__ stats, int* __restrict__ flag) {
   __shared__ float red[3][kStatThreads / 64];
   __shared__ float rowsum[176];
+  __shared__ float part[8 * kStatThreads];      // one slot per float4 of the largest matrix (176 x 176 = 7 744 of them)
   const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float m = 0.f, rs = 0.f;
   bool nf = false;
@@ -182,6 +183,7 @@ __global__ void __launch_bounds__(kStatThreads) weight_stats_kernel(RawPtrs raw,
     // So all of a thread's reads are issued before any is used: 8 independent 16-byte loads cover the largest matrix
     // (176 x 176) with 1024 threads -- a loop that waits per element took 56 us, per step.
     const int n4 = d.out_dim * d.k_raw / 4;     // every matrix's element count is a multiple of 4
+    const bool quads = d.k_raw % 4 == 0;
     float4 v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -196,7 +198,14 @@ __global__ void __launch_bounds__(kStatThreads) weight_stats_kernel(RawPtrs raw,
       const float s4 = (e[0] + e[1]) + (e[2] + e[3]);
       nf |= !(s4 <= 3.0e38f);
       m = fmaxf(fmaxf(m, fmaxf(e[0], e[1])), fmaxf(e[2], e[3]));
-      // |w| into its row's sum: a wave whose 256 elements lie in one row adds once, the others per element
+      // |w| into its row's sum.  Rows that are whole float4s (every matrix but the 83-column rw0): the float4's sum goes to
+      // its own LDS slot and one thread per row adds the row's slots afterwards, in order -- no atomics (per element they were
+      // 32 LDS atomics per thread onto <= 176 addresses: most of this kernel's 55 us, on the critical path of every training
+      // step's re-pack).  Otherwise: a wave whose 256 elements lie in one row adds once, the others per element.
+      if (quads) {
+        if (i4 < n4) part[i4] = s4;
+        continue;
+      }
       const int r0 = (4 * i4) / d.k_raw, r3 = (4 * i4 + 3) / d.k_raw;
       const bool one_row = i4 < n4 && r0 == r3 && r0 == __shfl(r0, 0);
       if (__builtin_amdgcn_ballot_w64(one_row) == ~0ull) {
@@ -209,7 +218,16 @@ __global__ void __launch_bounds__(kStatThreads) weight_stats_kernel(RawPtrs raw,
       }
     }
     __syncthreads();
-    for (int r = threadIdx.x; r < d.out_dim; r += kStatThreads) rs = fmaxf(rs, rowsum[r]);
+    if (quads) {
+      const int q = d.k_raw / 4;
+      for (int r = threadIdx.x; r < d.out_dim; r += kStatThreads) {
+        float t = 0.f;
+        for (int k = 0; k < q; ++k) t += part[r * q + k];
+        rs = fmaxf(rs, t);
+      }
+    } else {
+      for (int r = threadIdx.x; r < d.out_dim; r += kStatThreads) rs = fmaxf(rs, rowsum[r]);
+    }
   } else {
     const int v = b - kStatMats;
     const float* p = raw.p[kStatVecParam[v][0]];

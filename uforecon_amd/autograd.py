@@ -28,6 +28,7 @@ class RenderPass(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, frame, weights, ray_o, ray_d, z, *tensors):
+        ctx.set_materialize_grads(False)     # an unused output's gradient arrives as None, not as a zero tensor (a fill launch each)
         n_par = len(ops.RAW_WEIGHT_KEYS)
         RN, SN = z.shape
         prec = weights.mode()     # resolved ONCE: the backward of this node runs in the mode its forward ran in
@@ -146,6 +147,7 @@ class RenderTwoPass(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, frame, weights, ray_o, ray_d, z1, U2, options, *tensors):
+        ctx.set_materialize_grads(False)     # an unused output's gradient arrives as None, not as a zero tensor (a fill launch each)
         opt = ctx.options = options if options is not None else RenderOptions()
         n_par = len(ops.RAW_WEIGHT_KEYS)
         RN, SN = z1.shape
@@ -341,6 +343,7 @@ class RenderLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rgb, depth, rgb2, depth2, rgb_gt, depth_gt, near_fars, weight_rgb, weight_depth):
+        ctx.set_materialize_grads(False)     # an unused output's gradient arrives as None, not as a zero tensor (a fill launch each)
         loss, *cot = ops.render_loss(rgb, depth, rgb2, depth2, rgb_gt, depth_gt, near_fars, weight_rgb, weight_depth)
         ctx.cot = cot
         parts = loss[1:]
@@ -350,6 +353,8 @@ class RenderLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gparts):
         cot, ctx.cot = ctx.cot, None
+        if g is None:
+            return (None,) * 9
         need = ctx.needs_input_grad[:4]
         out = torch._foreach_mul([c for c, n in zip(cot, need) if n], g)      # one launch
         it = iter(out)
@@ -364,6 +369,7 @@ class Aggregate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, frame, weights, points, RN, SN, vol24, sim8, *params):
+        ctx.set_materialize_grads(False)     # an unused output's gradient arrives as None, not as a zero tensor (a fill launch each)
         P = RN * SN
         zeros3 = torch.zeros(P, 3, dtype=torch.float32, device=points.device)
         # every point is its own "ray" of one sample: position = o + 0 * d, exact
@@ -401,6 +407,7 @@ class Composite(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, radiance, srdf, variance):
+        ctx.set_materialize_grads(False)     # an unused output's gradient arrives as None, not as a zero tensor (a fill launch each)
         rgb, depth, opacity, weight = ops.composite(z, radiance, srdf, variance.detach().reshape(1))
         ctx.save_for_backward(z, radiance, srdf, variance)
         return rgb, depth, opacity, weight

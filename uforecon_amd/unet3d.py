@@ -94,6 +94,7 @@ class CostRegNetWeightFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, *params):
+        ctx.set_materialize_grads(False)     # a head nobody differentiates arrives as None (backward handles it), not as zeros
         P = dict(zip(_PARAM_NAMES, params))
         x_cl = _input_cl(x)
         acts = {"x": x_cl}

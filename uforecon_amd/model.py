@@ -425,6 +425,9 @@ class UFORecon(nn.Module):
         # samples' rows with the coarse pass, forwards and backwards (autograd.RenderTwoPass; same numbers as two sample2rgb
         # calls on z1 and on the merged z2, model.py:445, 472)
         params, vols = self._live_params(), ag.flat_volumes(feature_volume)
+        # (the returned `variance` is five tiny launches on a scalar: queued HERE, in front of the render kernels, they run
+        # while the host is still enqueueing those; behind them they sat on the step's critical path)
+        variance = self._variance_out()
         # a backward will follow <=> something upstream wants a gradient: then the forward records its tape (autograd.py)
         opt = ag.RenderOptions(overlap=self.overlap, tape_in_forward=self.tape_in_forward,
                                record_tape=_wants_grad(*params, *vols))
@@ -433,7 +436,6 @@ class UFORecon(nn.Module):
         S2 = z2.shape[1]
         pip = xy1.reshape(1, -1, RN, self.point_num, 2).permute(0, 1, 4, 2, 3)
         pip2 = xy2.reshape(1, -1, RN, S2, 2).permute(0, 1, 4, 2, 3)
-        variance = self._variance_out()
         return (rgb_gt, rgb[None], depth[None], depth_gt, srdf.reshape(RN, -1, 1), opacity[None], weight[None], pip,
                 rgb2[None], depth2[None], srdf2.reshape(RN, S2, 1), opacity2[None], weight2[None], pip2,
                 z1[None], z2[None], variance)                                                # model.py:480-482

@@ -34,6 +34,11 @@ __device__ __forceinline__ f32x4 lerp_tap4(const float* __restrict__ base, int s
   return acc;
 }
 
+#ifndef UFR_GATHER_PAIR
+#define UFR_GATHER_PAIR 0       // 1: frustum lookups shared by lane pairs (volume_sample.h: sample_volume_pair) -- bit-identical, and
+                                // MEASURED SLOWER (gather 0.467 vs 0.458 ms per 524 288 points, frame 123.5 vs 121.5 ms): the DPP adds and the
+                                // doubled chain cost more than the halved line accesses save.  Kept as the A/B.
+#endif
 #ifndef UFR_GATHER_BUFFER
 #define UFR_GATHER_BUFFER 1     // taps through bounded buffer loads (ufr_device.h); 0 = the conditional global loads (A/B)
 #endif
@@ -341,6 +346,28 @@ __global__ void __launch_bounds__(64 * NVT) gather_kernel(FrameDev f, PreSim ps,
   } else {
     const float zn = ((qz - f.vol_near) / (f.vol_far - f.vol_near)) * 2.f - 1.f;  // camera.py:400-401
     float fl[24], wl = 0.f;
+#if UFR_GATHER_PAIR && UFR_GATHER_BUFFER && !defined(UFR_GABL_NOVOL)
+    // lanes 2q, 2q + 1 (two consecutive samples of a ray, the same view) share every lookup: first the even lane's, then the
+    // odd lane's, per stage -- the owner loads the x0 side and keeps the result (volume_sample.h: sample_volume_pair)
+    {
+      const int odd = threadIdx.x & 1;
+      const float xo = pair_swap(x), yo = pair_swap(y), zo = pair_swap(zn);
+#pragma unroll
+      for (int s = 0; s < UFR_NUM_STAGES; ++s) {
+        const unsigned vox = (unsigned)(f.vD[s] * f.vH[s] * f.vW[s]);
+        const __amdgpu_buffer_rsrc_t rv = buf_rsrc(f.vol[s] + (size_t)vu * vox * kVolCh, vox * (unsigned)(kVolCh * 4));
+        float ev[9], od[9];
+        // the even lane's lookup: the even lane is the owner (side 0), the odd lane helps with ITS partner's coordinates
+        sample_volume_pair(rv, f.vD[s], f.vH[s], f.vW[s], odd ? xo : x, odd ? yo : y, odd ? zo : zn, odd, ev);
+        // the odd lane's lookup
+        sample_volume_pair(rv, f.vD[s], f.vH[s], f.vW[s], odd ? x : xo, odd ? y : yo, odd ? zn : zo, odd ^ 1, od);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) fl[8 * s + c] = odd ? od[c] : ev[c];
+        const float ws = odd ? od[8] : ev[8];
+        wl = s == 0 ? ws : wl + ws;                                               // :375-378
+      }
+    }
+#else
 #pragma unroll
     for (int s = 0; s < UFR_NUM_STAGES; ++s) {
       float fs[8], ws;
@@ -360,6 +387,7 @@ __global__ void __launch_bounds__(64 * NVT) gather_kernel(FrameDev f, PreSim ps,
       for (int c = 0; c < 8; ++c) fl[8 * s + c] = fs[c];
       wl = s == 0 ? ws : wl + ws;                                                 // :375-378
     }
+#endif
 #pragma unroll
     for (int c = 0; c < 24; ++c) own[c] = fl[c] * wl;                             // features_L * weights_L
     own[24] = wl;

@@ -57,6 +57,13 @@ def test_batch_elements_are_split_frame_major():
     with pytest.raises(ops.UfrError, match="multiple of the batch size"):
         M._volumes_of({"stage1": {"feature_volume": torch.zeros(5, 8, 2, 2, 2), "weight_volume": torch.zeros(5, 1, 2, 2, 2)}}, 0, 2)
     assert M._match_of([torch.zeros(2, 3, 64, 4, 4)], 1)[0].shape[0] == 1
+    # depth_info in the reference's (1, B*V, H, W) layout: frame b gets ITS maps; a leading-B layout is sliced like the rest
+    d = torch.arange(6.0).reshape(1, 6, 1, 1).expand(1, 6, 2, 2)
+    f1 = M._frame_of({"depth_info": d, "x": torch.zeros(2, 5)}, 1, 2)
+    assert f1["depth_info"].shape == (1, 3, 2, 2) and f1["depth_info"][0, :, 0, 0].tolist() == [3.0, 4.0, 5.0] and f1["x"].shape == (1, 5)
+    assert M._frame_of({"depth_info": torch.zeros(2, 3, 2, 2)}, 1, 2)["depth_info"].shape == (1, 3, 2, 2)
+    with pytest.raises(ops.UfrError, match="multiple of the batch size"):
+        M._frame_of({"depth_info": torch.zeros(1, 5, 2, 2)}, 0, 2)
 
 
 @pytest.mark.gpu
@@ -71,6 +78,9 @@ def test_infer_over_a_batch_of_two_frames_equals_two_calls():
     batch = {}
     for k, v in frames[0].batch.items():
         batch[k] = torch.cat([fr.batch[k] for fr in frames], 0) if isinstance(v, torch.Tensor) else v
+    # the reference's own layout of the MVS depth guide: "(B V) H W" unsqueezed (model.py:530-531), not a leading B
+    batch_ref = dict(batch, depth_info=torch.cat([fr.batch["depth_info"] for fr in frames], 1))
+    assert tuple(batch_ref["depth_info"].shape) == (1, 6, H, W)
     feat = torch.cat([fr.source_imgs_feat for fr in frames], 0)
     match = [torch.cat([fr.match_feature[0] for fr in frames], 0)]
     vols_stacked = {st: {k: torch.cat([fr.feature_volume[st][k] for fr in frames], 0) for k in frames[0].feature_volume[st]}
@@ -84,7 +94,7 @@ def test_infer_over_a_batch_of_two_frames_equals_two_calls():
         m.load_state_dict(load_weights(), strict=True)
         with torch.no_grad():
             both = m.infer(batch, idx, feat, vols_stacked, extract_geometry=extract, match_feature=match, uniforms=(U1, U2))
-            both_l = m.infer(batch, idx, feat, vols_list, extract_geometry=extract, match_feature=match, uniforms=(U1, U2))
+            both_l = m.infer(batch_ref, idx, feat, vols_list, extract_geometry=extract, match_feature=match, uniforms=(U1, U2))
             single = [m.infer(fr.batch, idx[b:b + 1], fr.source_imgs_feat, fr.feature_volume, extract_geometry=extract,
                               match_feature=fr.match_feature, uniforms=(U1[:, b * RN:(b + 1) * RN], U2[:, b * RN:(b + 1) * RN]))
                       for b, fr in enumerate(frames)]

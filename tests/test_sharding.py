@@ -126,7 +126,7 @@ def test_two_rank_bench_renders_the_one_rank_frame(tmp_path):
     common = ["--height", "64", "--width", "96", "--steps", "1", "--warmup", "1", "--fixed-uniforms", "7", "--no-cpu-baseline",
               "--no-gpu-eager-baseline", "--chunk", "2048"]
     backend, env = _two_rank_backend()
-    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dump-depth", str(tmp_path / "d1.npy"),
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--details", str(tmp_path / "one.json"), "--dump-depth", str(tmp_path / "d1.npy"),
                           *common], capture_output=True, text=True, env=env, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     with socket.socket() as s:
@@ -134,14 +134,18 @@ def test_two_rank_bench_renders_the_one_rank_frame(tmp_path):
         port = s.getsockname()[1]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", backend,
-                          "--dump-depth", str(tmp_path / "d2.npy"), *common], capture_output=True, text=True, env=env, timeout=900)
+                          "--details", str(tmp_path / "two.json"), "--dump-depth", str(tmp_path / "d2.npy"), *common], capture_output=True, text=True, env=env, timeout=900)
     assert two.returncode == 0, two.stderr[-2000:]
     d1, d2 = np.load(tmp_path / "d1.npy"), np.load(tmp_path / "d2.npy")
     assert d1.shape == d2.shape == (64, 96)
     assert np.array_equal(d1, d2)
-    line = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and len(line["config"]["per_rank"]) == 2
-    for r in line["config"]["per_rank"]:
+    out = [ln for ln in two.stdout.splitlines() if ln.startswith("{")]
+    assert len(out) == 1 and len(out[0]) < 4096              # ONE short headline on stdout; the tables are in --details
+    line = json.loads(out[0])
+    assert line["n_gpus"] == 2 and [r[:2] for r in line["config"]["per_rank"]] == [[0, 32 * 96], [1, 32 * 96]]
+    full = json.load(open(tmp_path / "two.json"))
+    assert full["value"] == pytest.approx(line["value"], rel=1e-8) and len(full["config"]["per_rank"]) == 2
+    for r in full["config"]["per_rank"]:
         assert r["rays"] == 32 * 96 and "view_transformer" in r["kernel_ms_per_frame"] and r["all_gather_ms_per_step"] >= 0
 
 
@@ -162,7 +166,7 @@ def test_two_rank_evaluation_loop_renders_the_one_rank_depth_maps(tmp_path, prod
     common = ["--config", "c3", "--frames", "4", "--height", "128", "--width", "160", "--fixed-uniforms", "5", "--chunk", "2048",
               "--producers", producers]
     backend, env = _two_rank_backend()
-    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dump-depths", str(tmp_path / "d1.npy"),
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--details", str(tmp_path / "one.json"), "--dump-depths", str(tmp_path / "d1.npy"),
                           *common], capture_output=True, text=True, env=env, timeout=900)
     assert one.returncode == 0, one.stderr[-2000:]
     with socket.socket() as s:
@@ -170,13 +174,17 @@ def test_two_rank_evaluation_loop_renders_the_one_rank_depth_maps(tmp_path, prod
         port = s.getsockname()[1]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", backend,
-                          "--dump-depths", str(tmp_path / "d2.npy"), *common], capture_output=True, text=True, env=env, timeout=1200)
+                          "--details", str(tmp_path / "two.json"), "--dump-depths", str(tmp_path / "d2.npy"), *common], capture_output=True, text=True, env=env, timeout=1200)
     assert two.returncode == 0, two.stderr[-2000:]
     d1, d2 = np.load(tmp_path / "d1.npy"), np.load(tmp_path / "d2.npy")
     assert d1.shape == d2.shape == (4, 128, 160)
     assert np.isfinite(d1).all() and len({d1[k].tobytes() for k in range(4)}) == 4       # four different frames
     assert np.array_equal(d1, d2)
-    line = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    out = [ln for ln in two.stdout.splitlines() if ln.startswith("{")]
+    assert len(out) == 1 and len(out[0]) < 4096
+    head = json.loads(out[0])
+    assert head["n_gpus"] == 2 and head["config"]["frames"] == 4 and len(head["config"]["per_rank"]) == 2
+    line = json.load(open(tmp_path / "two.json"))
     assert line["n_gpus"] == 2 and line["config"]["frames"] == 4 and len(line["config"]["per_rank"]) == 2
     encodes = sorted(r["encodes"] for r in line["config"]["per_rank"])
     assert encodes == ([4, 4] if producers == "replicated" else [2, 2])

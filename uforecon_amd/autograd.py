@@ -99,10 +99,21 @@ def _workspace(kind: str, dev, numel_of) -> torch.Tensor:
     t = _WS.get(key)
     if t is None or t.numel() < n:
         t = _WS[key] = torch.empty(n, dtype=torch.float32, device=dev)
+        _GWS_STATE.pop(key, None)        # a fresh allocation is uninitialised, whatever address the allocator handed back
     return t
 
 
-_GWS_STATE = {}     # data_ptr of a kept frustum-scatter workspace -> "zero" (as the last call left it) | "in use"
+# kept frustum-scatter workspace, per _WS key: (the tensor OBJECT the state describes, "zero" as the last call left it |
+# "in use").  Never keyed on a raw address: the caching allocator hands a freed block's address to the next, larger,
+# uninitialised workspace, and a stale "zero" entry would skip its memset.
+_GWS_STATE = {}
+
+
+def _gws_is_zero(key, t) -> bool:
+    held = _GWS_STATE.get(key)
+    return held is not None and held[0] is t and held[1] == "zero"
+
+
 _BUSY = {}          # key -> weak reference to the autograd context that holds the kept buffer between its forward and backward
 
 
@@ -265,11 +276,12 @@ class RenderTwoPass(torch.autograd.Function):
         need = ctx.needs_input_grad[7:]
         want_vol = any(need[ctx.n_par:])
         gws = _workspace("gather_bwd", dev, lambda: ops.project_gather_bwd_workspace_floats(frame)) if want_vol else None
+        gkey = ("gather_bwd", torch.device(dev).index or 0)
         with torch.cuda.stream(side2):
             if not taped:
                 ops.view_transform_bwd(W, grads, pool_x, pool_rgbm, pool_dirs, None, None, None, precision=prec,
                                        stages=ops.STAGE_TAPE, workspace=vws)
-            if gws is not None and _GWS_STATE.get(gws.data_ptr()) != "zero":
+            if gws is not None and not _gws_is_zero(gkey, gws):
                 # the frustum scatter's record volume: ufr_project_gather_bwd leaves it zero again (it reads and re-zeroes
                 # only what the scatter touched), so it is filled once per allocation -- or after a call that did not return
                 gws.zero_()
@@ -309,7 +321,7 @@ class RenderTwoPass(torch.autograd.Function):
         # ONE frustum scatter over all merged samples of a ray (z2: sorted, twice the density of either pass -- the run
         # folding of gather_bwd.hip removes more corner records), d_pv / sim8 addressed through the slot -> row table
         if gws is not None:
-            _GWS_STATE[gws.data_ptr()] = "in use"
+            _GWS_STATE[gkey] = (gws, "in use")
         if want_vol and ctx.options.overlap:
             # the two halves share no output: pre_sim_mlp's weight gradients (0.09 ms) beside the scatter, not behind it
             side2.wait_stream(main)
@@ -319,7 +331,7 @@ class RenderTwoPass(torch.autograd.Function):
                                accumulate=False, zeroed_workspace=gws, presim=not (want_vol and ctx.options.overlap))
         main.wait_stream(side2)
         if gws is not None:
-            _GWS_STATE[gws.data_ptr()] = "zero"
+            _GWS_STATE[gkey] = (gws, "zero")
         main.wait_stream(side)
         # (no record_stream marks: every tensor the side streams touch stays referenced until this function returns, i.e.
         # until after the join above is enqueued -- whatever reuses its memory later on this stream is ordered behind it;

@@ -314,6 +314,14 @@ static int frame_check(const ufr_frame_desc* d) {
   UFR_REQUIRE(d->source_imgs && d->depth_info && d->feat, "null frame tensor");
   UFR_REQUIRE((long long)d->H * d->W < (1 << 24) && (long long)(d->H / 4) * (d->W / 4) * 32 * (d->NV - 1) < (1ll << 32),
               "image of %dx%d is too large for the gather's 24-bit texel indices", d->H, d->W);
+  // the gathers read through raw buffer descriptors whose masked taps are sent to offset 0x80000000 (kBufOut) and rely on
+  // that offset lying OUTSIDE the buffer: every descriptor must stay below 2^31 bytes (gather.hip:236-288, 358)
+  {
+    const long long px = (long long)d->H * d->W, mpx = (long long)(d->H / 4) * (d->W / 4), lim = 1ll << 31;
+    UFR_REQUIRE(px * 16 < lim && d->NV * mpx * 128 < lim && d->NV * mpx * 32 * (d->NV - 1) * 4 < lim,
+                "frame of %dx%d with %d views: an image / feature-map buffer reaches 2 GiB (the gathers' zero-fill offset)",
+                d->H, d->W, d->NV);
+  }
   // match / volumes may be absent: such a frame only serves ufr_project_gather calls that pass sim8_in / vol24_in
   const bool has_vol = d->vol_feat[0] != nullptr;
   for (int s = 0; s < UFR_NUM_STAGES; ++s) {
@@ -323,8 +331,8 @@ static int frame_check(const ufr_frame_desc* d) {
     // the gathers index texels with 24-bit multiplies and 32-bit float offsets inside one view
     if (has_vol)
       UFR_REQUIRE((long long)d->vol_D[s] * d->vol_H[s] < (1 << 24) && (long long)d->vol_W[s] * kVolCh < (1 << 24) &&
-                      (long long)d->vol_D[s] * d->vol_H[s] * d->vol_W[s] * kVolCh < (1ll << 32),
-                  "volume of stage %d is too large for the gather's 32-bit texel offsets", s + 1);
+                      (long long)d->vol_D[s] * d->vol_H[s] * d->vol_W[s] * kVolCh * 4 < (1ll << 31),
+                  "volume of stage %d is too large for the gather's 31-bit byte offsets (per view: < 2 GiB)", s + 1);
   }
   UFR_REQUIRE(d->source_poses && d->source_cam_pos && d->ref_cam_pos && d->w2c_row2, "null camera constants");
   return UFR_OK;

@@ -36,7 +36,14 @@ def _wants_grad(*tensors) -> bool:
 def _frame_of(batch: dict, b: int, B: int) -> dict:
     out = {}
     for k, v in batch.items():
-        if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == B:
+        if k == "depth_info" and isinstance(v, torch.Tensor) and v.dim() == 4 and v.shape[0] == 1 and B > 1:
+            # the reference's layout: stage-3 depth "(B V) H W" unsqueezed to (1, B*V, H, W) (model.py:530-531): view-major
+            # per frame, like the volumes (_volumes_of)
+            if v.shape[1] % B:
+                raise UfrError(f"depth_info: {v.shape[1]} maps are not a multiple of the batch size {B}")
+            nv = v.shape[1] // B
+            out[k] = v[:, b * nv:(b + 1) * nv]
+        elif isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == B:
             out[k] = v[b:b + 1]
         elif isinstance(v, (list, tuple)) and len(v) == B and k != "start_idx":
             out[k] = type(v)(v[b:b + 1])
@@ -382,6 +389,9 @@ class UFORecon(nn.Module):
         they are drawn from the CPU generator in the reference's order and shapes."""
         B, RN = ray_idx.shape
         if B != 1:      # one frame per element; the sampler draws are (SN, B*RN) with "(B RN)" columns (sampler.py:42, 86)
+            if uniforms is None:       # ONE draw per pass for the whole batch, in the reference's order and shapes
+                only_coarse = bool(extract_geometry and getattr(self.args, "test_coarse_only", False))
+                uniforms = (torch.rand(self.point_num, B * RN), None if only_coarse else torch.rand(self.point_num_2, B * RN))
             outs = []
             for b in range(B):
                 u = None if uniforms is None else tuple(None if U is None else U[:, b * RN:(b + 1) * RN] for U in uniforms)

@@ -175,6 +175,9 @@ class FrameHandle:
         )
         if match_feature is not None:
             self._keep["match"] = f32(match_feature[0][0])
+        if tuple(self._keep["depth"].shape) != (NV, H, W):
+            # (1, B*V, H, W) of a B > 1 batch handed over whole would silently render every frame with frame 0's maps
+            raise UfrError(f"depth_info shape {tuple(batch['depth_info'].shape)}: expected (1, {NV}, {H}, {W})")
         d = _lib.FrameDesc()
         d.NV, d.H, d.W = NV, H, W
         d.source_imgs = _dev(self._keep["imgs"], "source_imgs")

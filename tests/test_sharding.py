@@ -101,6 +101,45 @@ def test_gradient_allreduce_world2_gloo():
     assert all(ok for _, ok in res)
 
 
+def _bcast_worker(rank, world, port, q):
+    """Frame k's tile all-gather (default group) while frame k+1's frustum broadcast is still in flight on ITS OWN group
+    (uforecon_amd/evalset.py: EvalLoop.bcast_group): on one group the all-gather would queue behind the broadcast."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = dist.new_group()
+        big = torch.full((48 << 20,), float(rank))                 # 192 MB: frame k+1's frustums, owner = rank 1
+        work = dist.broadcast(big, src=1, group=g, async_op=True)
+        shard = RayShard(8, 6, world, rank)
+        idx = shard.ray_indices("cpu")
+        d, _ = all_gather_tiles(idx.float(), None, shard)          # frame k's depth map
+        pending_when_gathered = not work.is_completed()
+        work.wait()
+        ok = torch.equal(d.reshape(-1), torch.arange(48).float()) and bool((big == 1.0).all())
+        q.put((rank, bool(ok), bool(pending_when_gathered)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_gather_is_not_queued_behind_the_frustum_broadcast_world2_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    # the depth map was complete while the 192 MB broadcast was still moving, on at least one of the two ranks (a loaded
+    # host can finish the broadcast first on one of them; both would mean the two collectives were serialised)
+    assert any(pending for _, _, pending in res)
+
+
 def _two_rank_backend():
     """(backend, env) of the 2-rank launcher tests: RCCL with one device per rank where the box has two, else both ranks on
     the one device over gloo (UFR_BENCH_SHARE_GPU: diagnostics mode of the bench scripts)."""

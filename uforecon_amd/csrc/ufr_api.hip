@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -935,7 +936,14 @@ int side_pool_get(int n, SidePool** out) {
   SidePool& p = g_side_by_device[dev];
   if (!p.fork) UFR_HIP(hipEventCreateWithFlags(&p.fork, hipEventDisableTiming));
   for (; p.n < n; ++p.n) {
-    UFR_HIP(hipStreamCreateWithFlags(&p.s[p.n], hipStreamNonBlocking));
+    // the ray path's chunks at the device's HIGHEST stream priority: whatever the caller runs beside a frame (the next
+    // frame's producers on a default- or low-priority stream, uforecon_amd/evalset.py) then fills the gaps the ray kernels
+    // leave instead of taking turns with them
+    int least = 0, greatest = 0;
+    UFR_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    // (measured round 6, configs[2] on one GPU, 24 frames, two runs each: 137.5 / 139.4 ms per frame against 140.5 / 140.6
+    // with flat priorities and 145.4 / 143.8 without the overlap: tools/dev/prio_ab.sh)
+    UFR_HIP(hipStreamCreateWithPriority(&p.s[p.n], hipStreamNonBlocking, greatest));
     UFR_HIP(hipEventCreateWithFlags(&p.join[p.n], hipEventDisableTiming));
   }
   *out = &p;

@@ -64,6 +64,13 @@ def _frame_tensor_shapes(H: int, W: int, NV: int):
     return shapes
 
 
+def _lowest_priority() -> int:
+    try:
+        return int(torch.cuda.Stream.priority_range()[0])       # (least, greatest): least = numerically largest = lowest
+    except Exception:  # noqa: BLE001 -- older torch: no query; 0 is always valid
+        return 0
+
+
 class EvalLoop:
     def __init__(self, net, shard: RayShard, n_streams: int = 3, overlap: bool = True, producers: str = "replicated",
                  chunk_rays: int = 0):
@@ -72,7 +79,13 @@ class EvalLoop:
         self.net, self.shard, self.overlap, self.producers = net, shard, overlap, producers
         self.dev = next(net.parameters()).device
         self.main = torch.cuda.current_stream(self.dev)
-        self.enc_stream = torch.cuda.Stream(self.dev) if overlap else self.main
+        # the producers' stream at the LOWEST priority the device offers (torch: larger number = lower priority): frame
+        # k+1's encode kernels are dispatched into what frame k's ray kernels (highest priority: csrc/ufr_api.hip
+        # side_pool_get) leave free, instead of taking turns with them
+        self.enc_stream = torch.cuda.Stream(self.dev, priority=_lowest_priority()) if overlap else self.main
+        # the frustum broadcast of frame k+1 on its OWN process group (= its own communicator and stream under RCCL): on the
+        # default group it would sit in front of frame k's all-gather in one queue -- 0.7 GB ahead of 5 MB
+        self.bcast_group = dist.new_group() if (producers == "sharded" and shard.world > 1) else None
         self.n_streams, self.chunk_rays = n_streams, chunk_rays
         self.ray_idx = shard.ray_indices(self.dev)
         self._ws = None
@@ -102,7 +115,7 @@ class EvalLoop:
                     for st in STAGES:
                         views[st + ".f"].copy_(fr[st]["feature_volume"])
                         views[st + ".w"].copy_(fr[st]["weight_volume"])
-                dist.broadcast(flat, src=owner)
+                dist.broadcast(flat, src=owner, group=self.bcast_group)
                 feat, match = views["feat"], [views["match"]]
                 fr = {st: {"feature_volume": views[st + ".f"], "weight_volume": views[st + ".w"]} for st in STAGES}
                 depth_info = views["depth_info"]

@@ -32,7 +32,7 @@ enum ufr_status {
 
 /* Version of this header's ABI (argument lists, struct layouts, packed-blob layout).  ufr_version() returns the value
  * the library was built with: a binding must refuse a library whose version differs (uforecon_amd/_lib.py does). */
-#define UFR_ABI_VERSION 502
+#define UFR_ABI_VERSION 503
 
 #define UFR_MAX_VIEWS 7
 #define UFR_NUM_STAGES 3
@@ -479,6 +479,27 @@ int ufr_conv3d_bwd_data(const float* d_out, const float* weight, const float* ac
                         int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t mode, ufr_stream stream);
 int ufr_conv3d_bwd_weight(const float* in, const float* d_out, float* d_weight, float* d_bias, int32_t B, int32_t D, int32_t H,
                           int32_t W, int32_t cin, int32_t cout, int32_t mode, ufr_stream stream);
+
+/* ---- the same layers on the 16-bit matrix cores (ABI 503) -------------------------------------------------------
+ * The stride-1 layers with 8 or 16 input channels (the full- and half-resolution layers of the U-Nets: module.py:502-543
+ * conv2, `features` + `weights`; and, with flip != 0, their data gradients) as an implicit GEMM on
+ * v_mfma_f32_16x16x32_f16 with the input brick staged once through LDS (csrc/conv3d_planes.hip).  Every fp32 product is
+ * three fp16 plane products accumulated in fp32 (22 significand bits): not bit-identical to ufr_conv3d, within ~1e-6 of it.
+ *   in_absmax   device pointer to ONE float >= max |in| (> 0 unless the tensor is zero): the planes' power-of-two scale.
+ *               ufr_absmax measures it; a layer's out_absmax is the next layer's in_absmax.
+ *   out_absmax  (nullable, channel-last outputs only) device float the caller has zeroed; raised to max |out| (skip included)
+ *   flip        0: `weight` (cout,cin,3,3,3).  1: the data gradient of a stride-1 layer -- `weight` is that layer's FORWARD
+ *               weight (cin of this call, cout of this call, 3,3,3) and the taps are mirrored (ufr_conv3d_bwd_data, S1).
+ *   workspace   ufr_conv3d_planes_workspace_bytes(cin, cout, cout2) bytes (the weights' planes); 0 = combination not
+ *               supported here (use ufr_conv3d): cin in {8, 16}, cout + cout2 <= 16.
+ * bias / bn_scale / bn_shift / relu / skip / out_ncdhw / weight2 / out2 as for ufr_conv3d.                              */
+size_t ufr_conv3d_planes_workspace_bytes(int32_t cin, int32_t cout, int32_t cout2);
+int ufr_conv3d_planes(const float* in, const float* in_absmax, const float* weight, const float* weight2, const float* bias,
+                      const float* bn_scale, const float* bn_shift, const float* skip, float* out, float* out2,
+                      float* out_absmax, int32_t B, int32_t D, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t cout2,
+                      int32_t relu, int32_t out_ncdhw, int32_t flip, void* workspace, size_t workspace_bytes, ufr_stream stream);
+/* *absmax = max(*absmax, max |x[0..n)|) (device float; zero it first).  One pass at HBM speed.                          */
+int ufr_absmax(const float* x, size_t n, float* absmax, ufr_stream stream);
 
 /* ---- TSDF fusion -------------------------------------------------------------------
  * Replaces the reference's `integrate` kernel (tsdf_fusion.py:77-152, a CUDA string compiled through pycuda) and the

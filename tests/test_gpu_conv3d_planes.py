@@ -1,0 +1,90 @@
+"""ufr_conv3d_planes (csrc/conv3d_planes.hip): the stride-1 8- / 16-channel layers of the frustum U-Nets on the 16-bit matrix
+cores against the fp32 kernels (ufr_conv3d / ufr_conv3d_bwd_data) AND against a float64 torch convolution -- the layers of
+CostRegNetWeight, code1/encoder_utils/fmt/module.py:502-543.  The plane products carry 22 significand bits: the bound
+asserted here is the one the fp32 kernel itself meets against float64 (x 4), not a loosened one."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _ref64(x_cl, w, bias=None, skip=None, flip=False):
+    x = x_cl.double().permute(0, 4, 1, 2, 3)
+    if flip:       # data gradient of a stride-1 layer with forward weight w (cout_fwd = cin here, cin_fwd, 3,3,3)
+        y = torch.nn.functional.conv_transpose3d(x, w.double(), padding=1)
+    else:
+        y = torch.nn.functional.conv3d(x, w.double(), None if bias is None else bias.double(), padding=1)
+    y = y.permute(0, 2, 3, 4, 1)
+    return y if skip is None else y + skip.double()
+
+
+def _err(a, ref):
+    return float((a.double() - ref).abs().max() / ref.abs().max())
+
+
+@pytest.mark.parametrize("cin,cout,shape", [(8, 8, (2, 4, 12, 70)), (16, 16, (1, 3, 9, 37)), (8, 8, (1, 8, 32, 128)), (16, 16, (3, 2, 16, 64))])
+@pytest.mark.parametrize("flip", [False, True])
+def test_planes_layer_matches_fp32_kernel_and_float64(cin, cout, shape, flip):
+    from uforecon_amd import ops
+
+    torch.manual_seed(cin * 100 + cout + int(flip))
+    B, D, H, W = shape
+    x = torch.randn(B, D, H, W, cin, device=DEV) * 3.0
+    x[0, 0, 0, :5] *= 40.0                                        # a few large values: the scale follows the measured maximum
+    w = torch.randn((cin, cout, 3, 3, 3) if flip else (cout, cin, 3, 3, 3), device=DEV) * 0.2
+    bias = None if flip else torch.randn(cout, device=DEV)
+    skip = torch.randn(B, D, H, W, cout, device=DEV)
+    amax = ops.absmax(x)
+    assert float(amax) == float(x.abs().max())
+    y, ymax = ops.conv3d_planes(x, amax, w, bias=bias, skip=skip, flip=flip)
+    if flip:
+        y32 = ops.conv3d_bwd_data(x, w, ops.CONV3D_S1, (B, D, H, W, cout), accumulate=skip)
+    else:
+        y32 = ops.conv3d(x, w, ops.CONV3D_S1, bias=bias, skip=skip)
+    ref = _ref64(x, w, bias, skip, flip)
+    e16, e32 = _err(y, ref), _err(y32, ref)
+    print(f"cin {cin} cout {cout} flip {flip} {shape}: planes {e16:.2e}  fp32 kernel {e32:.2e} of the output scale")
+    assert e16 < max(4 * e32, 1e-6)
+    assert float(ymax) == float(y.abs().max())                    # the bound handed to the next layer is the true maximum
+
+
+def test_planes_heads_write_the_reference_layout():
+    """features (8) + sigmoid(weights (1)) in one pass, (B,C,D,H,W) outputs (module.py:541-543)."""
+    from uforecon_amd import ops
+
+    torch.manual_seed(3)
+    B, D, H, W = 2, 3, 10, 66
+    x = torch.randn(B, D, H, W, 8, device=DEV)
+    wf, ww = torch.randn(8, 8, 3, 3, 3, device=DEV) * 0.2, torch.randn(1, 8, 3, 3, 3, device=DEV) * 0.2
+    f, s, _ = ops.conv3d_planes(x, ops.absmax(x), wf, out_ncdhw=True, weight2=ww)
+    f32, s32 = ops.conv3d(x, wf, ops.CONV3D_S1, out_ncdhw=True, weight2=ww)
+    assert f.shape == (B, 8, D, H, W) and s.shape == (B, 1, D, H, W)
+    rf = _ref64(x, wf).permute(0, 4, 1, 2, 3)
+    rs = torch.sigmoid(_ref64(x, ww).permute(0, 4, 1, 2, 3))
+    assert _err(f, rf) < max(4 * _err(f32, rf), 1e-6) and _err(s, rs) < max(4 * _err(s32, rs), 1e-6)
+
+
+def test_planes_bn_relu_and_zero_input():
+    from uforecon_amd import ops
+
+    torch.manual_seed(4)
+    x = torch.randn(1, 2, 8, 32, 16, device=DEV)
+    w = torch.randn(16, 16, 3, 3, 3, device=DEV) * 0.1
+    sc, sh = torch.rand(16, device=DEV) + 0.5, torch.randn(16, device=DEV)
+    y, _ = ops.conv3d_planes(x, ops.absmax(x), w, bn_scale=sc, bn_shift=sh, relu=True)
+    y32 = ops.conv3d(x, w, ops.CONV3D_S1, bn_scale=sc, bn_shift=sh, relu=True)
+    assert float((y - y32).abs().max()) < 2e-5 * float(y32.abs().max())
+    z = torch.zeros_like(x)
+    yz, zmax = ops.conv3d_planes(z, ops.absmax(z), w, bias=sh)
+    assert torch.equal(yz, sh.expand_as(yz)) and float(zmax) == float(sh.abs().max())
+
+
+def test_planes_refuses_other_layers():
+    from uforecon_amd import ops
+
+    assert ops.conv3d_planes_supported(8, 8, 1) and ops.conv3d_planes_supported(16, 16) and not ops.conv3d_planes_supported(32, 32)
+    x = torch.randn(1, 2, 8, 8, 32, device=DEV)
+    with pytest.raises(ops.UfrError, match="not a layer of this kernel family"):
+        ops.conv3d_planes(x, ops.absmax(x), torch.randn(32, 32, 3, 3, 3, device=DEV))

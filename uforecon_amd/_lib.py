@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # UFR_LIB selects an alternative in-tree build (A/B kernel variants during development)
 LIB_PATH = os.environ.get("UFR_LIB") or os.path.join(HERE, "lib", "libufr.so")
 
-ABI_VERSION = 502   # = UFR_ABI_VERSION of include/ufr.h; load() refuses a library built against another header
+ABI_VERSION = 503   # = UFR_ABI_VERSION of include/ufr.h; load() refuses a library built against another header
 MAX_VIEWS = 7
 NUM_STAGES = 3
 TOKEN_DIM = 80
@@ -121,6 +121,10 @@ SIGNATURES = {
     "ufr_correlate_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "ufr_frustum_correlate": (C.c_int, [vp, vp, C.POINTER(C.c_float), vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
     "ufr_conv3d": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ufr_conv3d_planes_workspace_bytes": (sz, [i32, i32, i32]),
+    "ufr_conv3d_planes": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp,
+                                    sz, vp]),
+    "ufr_absmax": (C.c_int, [vp, sz, vp, vp]),
     "ufr_conv3d_bwd_data": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ufr_conv3d_bwd_weight": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ufr_tsdf_integrate": (C.c_int, [vp, vp, vp, C.POINTER(i32), C.POINTER(C.c_float), C.c_float, C.c_float,

@@ -750,6 +750,63 @@ def conv3d(x_cl: torch.Tensor, weight: torch.Tensor, mode: int = CONV3D_S1, bias
     return (out, out2) if cout2 else out
 
 
+def absmax(x: torch.Tensor, into: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """max |x| as a one-element device tensor (ufr_absmax: one pass at HBM speed, no host round trip); ``into``: a running
+    maximum to raise instead of a fresh zero."""
+    x = x.detach()
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        x = x.float().contiguous()
+    out = torch.zeros(1, dtype=torch.float32, device=x.device) if into is None else into
+    _lib.check(_lib.load().ufr_absmax(_dev(x, "x"), x.numel(), out.data_ptr(), _stream()), "ufr_absmax")
+    return out
+
+
+def conv3d_planes_supported(cin: int, cout: int, cout2: int = 0) -> bool:
+    return _lib.load().ufr_conv3d_planes_workspace_bytes(cin, cout, cout2) > 0
+
+
+def conv3d_planes(x_cl: torch.Tensor, x_absmax: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                  bn_scale: Optional[torch.Tensor] = None, bn_shift: Optional[torch.Tensor] = None, relu: bool = False,
+                  skip: Optional[torch.Tensor] = None, out_ncdhw: bool = False, weight2: Optional[torch.Tensor] = None,
+                  flip: bool = False, want_absmax: bool = True):
+    """A stride-1 3x3x3 layer with 8 or 16 input channels on the 16-bit matrix cores (ufr_conv3d_planes: fp16 plane
+    products, fp32 accumulate, the input brick staged through LDS).  ``x_absmax``: one-element device tensor >= max |x_cl|
+    (`absmax`, or the previous layer's returned bound).  ``flip``: the data gradient of a stride-1 layer -- ``weight`` is
+    that layer's forward weight (cin of this call = its cout).  Returns ``(out, out_absmax or None)``, with a second head
+    ``(out, sigmoid(out2), None)``."""
+    B, D, H, W, cin = x_cl.shape
+    if flip:
+        if tuple(weight.shape[2:]) != (3, 3, 3) or weight.shape[0] != cin:
+            raise UfrError(f"conv3d_planes(flip): weight {tuple(weight.shape)} does not match {cin} input channels")
+        cout = weight.shape[1]
+    else:
+        if tuple(weight.shape[1:]) != (cin, 3, 3, 3):
+            raise UfrError(f"conv3d_planes: weight {tuple(weight.shape)} does not match {cin} input channels")
+        cout = weight.shape[0]
+    cout2 = 0 if weight2 is None else weight2.shape[0]
+    lib = _lib.load()
+    nbytes = lib.ufr_conv3d_planes_workspace_bytes(cin, cout, cout2)
+    if not nbytes:
+        raise UfrError(f"conv3d_planes: (cin {cin}, cout {cout}+{cout2}) is not a layer of this kernel family")
+    dev = x_cl.device
+    out = torch.empty((B, cout, D, H, W) if out_ncdhw else (B, D, H, W, cout), dtype=torch.float32, device=dev)
+    out2 = torch.empty((B, cout2, D, H, W), dtype=torch.float32, device=dev) if cout2 else None
+    if skip is not None and tuple(skip.shape) != tuple(out.shape):
+        raise UfrError(f"conv3d_planes: skip {tuple(skip.shape)} does not match the output {tuple(out.shape)}")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    omax = torch.zeros(1, dtype=torch.float32, device=dev) if (want_absmax and not out_ncdhw) else None
+    keep = [t.detach().contiguous() for t in (weight, weight2, bias, bn_scale, bn_shift) if t is not None]
+    it = iter(keep)
+    ptr = lambda t, n: None if t is None else _dev(next(it), n)
+    w_p, w2_p, b_p, s_p, h_p = ptr(weight, "weight"), ptr(weight2, "weight2"), ptr(bias, "bias"), ptr(bn_scale, "bn_scale"), \
+        ptr(bn_shift, "bn_shift")
+    _lib.check(lib.ufr_conv3d_planes(_dev(x_cl, "x"), _dev(x_absmax, "x_absmax"), w_p, w2_p, b_p, s_p, h_p, _opt(skip, "skip"),
+                                     out.data_ptr(), _opt(out2, "out2"), _opt(omax, "out_absmax"), B, D, H, W, cin, cout, cout2,
+                                     int(bool(relu)), int(bool(out_ncdhw)), int(bool(flip)), ws.data_ptr(), nbytes, _stream()),
+               "ufr_conv3d_planes")
+    return (out, out2, None) if cout2 else (out, omax)
+
+
 CONV2D_RELU, CONV2D_IN_PLANAR, CONV2D_OUT_PLANAR = 1, 2, 4
 
 

@@ -44,6 +44,23 @@ def _input_cl(x: torch.Tensor) -> torch.Tensor:
     return x.detach().float().contiguous().view(B, D, H, W, 1)
 
 
+def _s1(t, weight, planes: bool, **kw):
+    """One stride-1 layer: on the 16-bit matrix cores (ufr_conv3d_planes: fp16 plane products, fp32 accumulate, the input
+    brick staged through LDS -- the full- and half-resolution layers run 2 .. 2.4 x faster there, csrc/conv3d_planes.hip)
+    when `planes` and the kernel family has the layer, else the fp32 kernel.  The planes' scale comes from the input's
+    measured |max| (one pass at HBM speed).  Returns what ops.conv3d returns."""
+    cin = t.shape[-1]
+    flip = kw.pop("flip", False)
+    w2 = kw.get("weight2")
+    cout = weight.shape[1] if flip else weight.shape[0]
+    if planes and ops.conv3d_planes_supported(cin, cout, 0 if w2 is None else w2.shape[0]):
+        r = ops.conv3d_planes(t, ops.absmax(t), weight, flip=flip, want_absmax=False, **kw)
+        return (r[0], r[1]) if w2 is not None else r[0]
+    if flip:
+        return ops.conv3d_bwd_data(t, weight, S1, (*t.shape[:4], cout), accumulate=kw.get("skip"))
+    return ops.conv3d(t, weight, S1, **kw)
+
+
 def _unet(x_cl, layer):
     """The shared body: three stride-2 levels down, three transposed convolutions up with skip additions.
     `layer(name, x, mode, skip)` runs one named layer."""
@@ -57,7 +74,7 @@ def _unet(x_cl, layer):
 
 
 @torch.no_grad()
-def cost_reg_net(m, x: torch.Tensor) -> torch.Tensor:
+def cost_reg_net(m, x: torch.Tensor, planes: bool = True) -> torch.Tensor:
     """(B,1,D,H,W) similarity volume -> (B,1,D,H,W) cost volume.  Every inner layer = convolution + BatchNorm (eval mode,
     folded to one fma after the sum) + ReLU in one kernel."""
     if m.training:
@@ -66,10 +83,12 @@ def cost_reg_net(m, x: torch.Tensor) -> torch.Tensor:
     def layer(name, t, mode, skip):
         blk = getattr(m, name)
         scale, shift = _bn_fold(blk.bn)
+        if mode == S1:
+            return _s1(t, blk.conv.weight, planes, bn_scale=scale, bn_shift=shift, relu=True, skip=skip)
         return ops.conv3d(t, blk.conv.weight, mode, bn_scale=scale, bn_shift=shift, relu=True, skip=skip)
 
     x = _unet(_input_cl(x), layer)
-    return ops.conv3d(x, m.prob.weight, S1, out_ncdhw=True)
+    return _s1(x, m.prob.weight, planes, out_ncdhw=True)
 
 
 def _needs_grad(m, x: torch.Tensor) -> bool:
@@ -101,10 +120,12 @@ class CostRegNetWeightFn(torch.autograd.Function):
 
         def layer(name, t, mode, skip):
             acts["in." + name] = t
+            if mode == S1:
+                return _s1(t, P[name + ".weight"], True, bias=P[name + ".bias"], skip=skip)
             return ops.conv3d(t, P[name + ".weight"], mode, bias=P[name + ".bias"], skip=skip)
 
         y = _unet(x_cl, layer)
-        feat, wsig = ops.conv3d(y, P["features.weight"], S1, out_ncdhw=True, weight2=P["weights.weight"])
+        feat, wsig = _s1(y, P["features.weight"], True, out_ncdhw=True, weight2=P["weights.weight"])
         ctx.acts, ctx.y, ctx.params = acts, y, params
         ctx.save_for_backward(wsig)
         ctx.x_needs_grad = x.requires_grad
@@ -124,13 +145,18 @@ class CostRegNetWeightFn(torch.autograd.Function):
         d_w = cl((d_wsig.float() * wsig * (1.0 - wsig))) if d_wsig is not None else zeros(1)
         grads["features.weight"] = ops.conv3d_bwd_weight(y, d_f, S1, P["features.weight"].shape, want_bias=False)[0]
         grads["weights.weight"] = ops.conv3d_bwd_weight(y, d_w, S1, P["weights.weight"].shape, want_bias=False)[0]
-        d_y = ops.conv3d_bwd_data(d_f, P["features.weight"], S1, tuple(y.shape))
-        d_y = ops.conv3d_bwd_data(d_w, P["weights.weight"], S1, tuple(y.shape), accumulate=d_y)
+        # the 1-channel head's adjoint on the fp32 kernel, then the 8-channel one on the matrix cores with the sum fused
+        d_y = ops.conv3d_bwd_data(d_w, P["weights.weight"], S1, tuple(y.shape))
+        d_y = _s1(d_f, P["features.weight"], True, flip=True, skip=d_y)
 
         def back(name, mode, d_out, accumulate=None, need_data=True):
             t = acts["in." + name]
             grads[name + ".weight"], grads[name + ".bias"] = ops.conv3d_bwd_weight(t, d_out, mode, P[name + ".weight"].shape)
-            return ops.conv3d_bwd_data(d_out, P[name + ".weight"], mode, tuple(t.shape), accumulate=accumulate) if need_data else None
+            if not need_data:
+                return None
+            if mode == S1 and t.shape[-1] > 1:
+                return _s1(d_out, P[name + ".weight"], True, flip=True, skip=accumulate)
+            return ops.conv3d_bwd_data(d_out, P[name + ".weight"], mode, tuple(t.shape), accumulate=accumulate)
 
         # y = c0 + conv11(x9), x9 = c2 + conv9(x7), x7 = c4 + conv7(x6), x6 = conv6(conv5(c4)), c4 = conv4(conv3(c2)), ...
         d_x9 = back("conv11", T2, d_y)
@@ -162,10 +188,12 @@ def cost_reg_net_weight(m, x: torch.Tensor):
         return _cost_reg_net_weight_hip(m, x)
 
 
-def _cost_reg_net_weight_hip(m, x: torch.Tensor):
+def _cost_reg_net_weight_hip(m, x: torch.Tensor, planes: bool = True):
     def layer(name, t, mode, skip):
         conv = getattr(m, name)
+        if mode == S1:
+            return _s1(t, conv.weight, planes, bias=conv.bias, skip=skip)
         return ops.conv3d(t, conv.weight, mode, bias=conv.bias, skip=skip)
 
     x = _unet(_input_cl(x), layer)
-    return ops.conv3d(x, m.features.weight, S1, out_ncdhw=True, weight2=m.weights.weight)
+    return _s1(x, m.features.weight, planes, out_ncdhw=True, weight2=m.weights.weight)

@@ -44,12 +44,21 @@ constexpr int kRtC2 = UFR_RT_C2;
 #define UFR_RT_PREFETCH 0   // measured round 5: 0.378 vs 0.379 ms per 4096 x 128 launch -- the partner wave already covers those loads (as in round 3)
 #endif
 
+// UFR_RT_NT (development): bit 0 / bit 1 = sweep 1 / sweep 2 read the token rows with the non-temporal hint.  The rows are
+// read twice (2.05 x the algorithmic bytes reach the fabric: profiles/r5_pmc.json); measured round 6, see DESIGN.md.
+#ifndef UFR_RT_NT
+#define UFR_RT_NT 0
+#endif
+template <bool NT = false>
 __device__ __forceinline__ void load_ray_tile(const float* __restrict__ token0, const int* __restrict__ tok_row,
                                               const float* __restrict__ order_pe, size_t tok_base, int s_base, int g,
                                               int j, f32x4 (&x)[6]) {
   const float* row = token0 + (tok_row ? (size_t)tok_row[tok_base + j] : tok_base + j) * UFR_TOKEN_DIM;
 #pragma unroll
-  for (int t = 0; t < 5; ++t) x[t] = ld4(row + 16 * t + 4 * g);
+  for (int t = 0; t < 5; ++t) {
+    if constexpr (NT) x[t] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + 16 * t + 4 * g));
+    else x[t] = ld4(row + 16 * t + 4 * g);
+  }
   const float* pe = order_pe + (size_t)(s_base + j) * 8 + 2 * g;  // features 80+2g, 81+2g in registers 0,1
   x[5] = f32x4{pe[0], pe[1], 0.f, 0.f};
 }
@@ -178,7 +187,7 @@ __global__ void __launch_bounds__(kRtBlock, TAPE ? 2 : UFR_RT_MINW) ray_transfor
         const int nx = wrap ? tl + 1 : 0;        // after the last tile: sweep 2's first one
         load_ray_tile(token0, tok_row, order_pe, (size_t)ray * SN + nx * 16, nx * 16, g, j, xn);
       } else {
-        load_ray_tile(token0, tok_row, order_pe, (size_t)ray * SN + tl * 16, tl * 16, g, j, x[c]);
+        load_ray_tile<(UFR_RT_NT & 1) != 0>(token0, tok_row, order_pe, (size_t)ray * SN + tl * 16, tl * 16, g, j, x[c]);
       }
 #pragma unroll
       for (int h = 0; h < 8; ++h) { kt[c][h] = splat4(0.f); vt[c][h] = splat4(0.f); }
@@ -297,7 +306,7 @@ __global__ void __launch_bounds__(kRtBlock, TAPE ? 2 : UFR_RT_MINW) ray_transfor
         const int nx = (tile + 1 < n_tiles ? tile + 1 : n_tiles - 1) * 16;
         if (wrap) load_ray_tile(token0, tok_row, order_pe, (size_t)ray * SN + nx, nx, g, j, xn);
       } else {
-        load_ray_tile(token0, tok_row, order_pe, (size_t)ray * SN + tbase[c], tbase[c], g, j, x[c]);
+        load_ray_tile<(UFR_RT_NT & 2) != 0>(token0, tok_row, order_pe, (size_t)ray * SN + tbase[c], tbase[c], g, j, x[c]);
       }
 #pragma unroll
       for (int t = 0; t < 6; ++t) q[c][t] = splat4(0.f);

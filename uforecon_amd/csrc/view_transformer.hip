@@ -106,6 +106,9 @@ __device__ unsigned long long g_vt_wave[4096 * 2];  // start / end tick of every
 #ifndef UFR_VT_FENCE_STRADDLE
 #define UFR_VT_FENCE_STRADDLE 0
 #endif
+#ifndef UFR_VT_SCORES_HOOK
+#define UFR_VT_SCORES_HOOK 1   // the attention scores ride on the v GEMM's MFMAs (L = 4, two column tiles).  Round 6, same box, two runs each: alone 0.3635-0.3641 vs 0.3648-0.3662 ms per launch (nothing); with UFR_HOOK_VALU 6 frame 122.1-122.3 vs 123.4-123.6 ms
+#endif
 #ifndef UFR_VT_RELOAD_X
 #define UFR_VT_RELOAD_X 0   // 1: the L = 6 kernel re-reads the token rows for the residual (see there); measured 395 -> 444 ms per
 #endif                      // 600x800 / 5-view frame once the scalar pressure was fixed (it had helped before: 434 -> 428)
@@ -135,6 +138,7 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
   constexpr int PPW = STRADDLE ? 5 : PPT * C;         // points per wave iteration
   constexpr bool kReloadX = STRADDLE && UFR_VT_RELOAD_X;                 // the residual re-reads the token rows (see there)
   constexpr bool kPhaseFence = (STRADDLE && UFR_VT_FENCE_STRADDLE) || UFR_VT_FENCE_ALL;
+  constexpr bool kScoresHook = UFR_VT_SCORES_HOOK && L == 4 && C == 2 && !TAPE;
   (void)kPhaseFence;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   auto ws = wstream_f16_begin<kVtWaves, LOWP>(packed, smem);
@@ -359,6 +363,9 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
 #pragma unroll
         for (int c = 0; c < C; ++c) Zs[c][hh] = (float)L * fast_rcp(den[c] + 1e-6f);   // Z * v_length (linear_attention.py:43-44)
       });
+    } else if constexpr (kScoresHook) {
+      // round-6 experiment (UFR_VT_SCORES_HOOK): the scores of (column tile, head) pair u = 2 c + hh ride on the v GEMM's
+      // stages 3 u .. 3 u + 2 (elu of Q | elu of K | the L dot products, the normaliser) instead of running in front of it
     } else {
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -393,7 +400,31 @@ __global__ void __launch_bounds__(kVtBlock, UFR_VT_MINW) view_transformer_kernel
     UFR_PHASE(2)  // scores
     f32x4 v[C][5];
     zero_tiles(v);
-    gemm_f16<M_VT_V, C, kVtWaves>(ws, x, v, wrap, sc[VS_XS_X]);   // raw accumulators: the descale joins the 1 / v_length
+    if constexpr (kScoresHook) {
+      float Qs[10], Ks[10];
+      gemm_f16<M_VT_V, C, kVtWaves>(ws, x, v, wrap, sc[VS_XS_X], [&](auto ui) __attribute__((always_inline)) {
+        constexpr int slot = decltype(ui)::value, u = slot / 3, part = slot % 3;
+        if constexpr (u < 2 * C) {
+          constexpr int c = u / 2, hh = u % 2;
+          if constexpr (part == 0) {
+#pragma unroll
+            for (int d = 0; d < 10; ++d) Qs[d] = elu1_acc(q[c][(10 * hh + d) >> 2][(10 * hh + d) & 3], q_dsc, q_l2e);
+          } else if constexpr (part == 1) {
+#pragma unroll
+            for (int d = 0; d < 10; ++d) Ks[d] = elu1_acc(k[c][(10 * hh + d) >> 2][(10 * hh + d) & 3], k_dsc, k_l2e);
+          } else {
+            float a0 = 0.f;
+#pragma unroll
+            for (int d = 0; d < 10; ++d) a0 = fmaf(Qs[d], Ks[d], a0);
+            const float a1 = dot10_rot4<1>(Qs, Ks), a2 = dot10_rot4<2>(Qs, Ks), a3 = dot10_rot4<3>(Qs, Ks);
+            A[c][hh][0] = a0; A[c][hh][1] = a1; A[c][hh][2] = a2; A[c][hh][3] = a3;
+            Zs[c][hh] = (float)L * fast_rcp((((0.f + a0) + a1) + a2) + a3 + 1e-6f);
+          }
+        }
+      });
+    } else {
+      gemm_f16<M_VT_V, C, kVtWaves>(ws, x, v, wrap, sc[VS_XS_X]);   // raw accumulators: the descale joins the 1 / v_length
+    }
     UFR_PHASE(3)  // v GEMM
     // values / v_length on raw accumulators: one exact multiply when L is a power of two; otherwise (L = 3, 5, 6, 7) a true
     // division of the descaled value (the power-of-two descale is exact, so this is v / (L 2^(s+a)) bit for bit)

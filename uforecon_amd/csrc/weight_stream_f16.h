@@ -315,7 +315,7 @@ __device__ __forceinline__ f32x4 mfma_planes(const f16x8& a, const f16x8& b, con
 // operands): it is interleaved with the stage's MFMAs -- the 16-bit matrix pipe runs ~2 independent VALU
 // instructions per MFMA for free (tools/dev/mfma_valu2), so the split costs nothing once it sits there.
 #ifndef UFR_HOOK_VALU
-#define UFR_HOOK_VALU 2   // VALU instructions of the hook issued after each MFMA
+#define UFR_HOOK_VALU 6   // VALU instructions of the hook issued after each MFMA (2 until round 6: see UFR_VT_SCORES_HOOK)
 #endif
 constexpr int kProducts = 3;   // MFMAs per fp32 product
 #ifndef UFR_SETPRIO
@@ -445,12 +445,15 @@ constexpr float kLog2e = 0x1.715476p+0f;
 // they do anyway: no layer of the two chains pays for a descale pass).  Callers that start from a bias pass it
 // pre-multiplied by 2^(s_M + a_M) (exact).  bf16 matrices (the transposed ones of the backward): no scales, m unused.
 // The fp16 split of k-step s+1 is interleaved with the MFMAs of k-step s (only step 0's is exposed).
-template <int M, int C, int NWAVES, int STREAM = -1, int NIN, class WS>
+template <int M, int C, int NWAVES, int STREAM = -1, int NIN, class WS, class UHook = NoHook>
 __device__ __forceinline__ void gemm_f16(WS& ws, const f32x4 (&in)[C][NIN], f32x4 (&out)[C][mat_desc(M).n_out],
-                                        bool wrap, float m = 1.f) {
+                                        bool wrap, float m = 1.f, UHook&& uhook = NoHook{}) {
+  // uhook(integral_constant<k-step * n_out + out tile>): the CALLER's VALU work that does not depend on this GEMM, issued
+  // with the stage's MFMAs like the operand split (round 6 experiment: the attention scores under the v GEMM)
   static_assert(NIN == mat_desc(M).n_in, "input tile count");
   constexpr int n_out = mat_desc(M).n_out, NU = 4 * C;
   constexpr bool BF = f16_mat_is_bf16(M);   // bf16 planes: no scales, so the output is exact as it stands and never probed
+  constexpr bool kUser = !std::is_same<std::decay_t<UHook>, NoHook>::value;
   BWords<C> cur;
   split_units<0, 0, NU, BF>(in, cur, m);
   static_for<ksteps(M)>([&](auto si) __attribute__((always_inline)) {
@@ -467,8 +470,14 @@ __device__ __forceinline__ void gemm_f16(WS& ws, const f32x4 (&in)[C][NIN], f32x
       gemm_f16_panel<M, s, C, NWAVES, false, STREAM>(ws, b, out, wrap, [&](auto ti) __attribute__((always_inline)) {
         constexpr int to = decltype(ti)::value;
         split_units<s + 1, to * NU / n_out, (to + 1) * NU / n_out, BF>(in, nxt, m);
+        if constexpr (kUser) uhook(std::integral_constant<int, s * n_out + to>{});
       });
       cur = nxt;
+    } else if constexpr (kUser) {
+      gemm_f16_panel<M, s, C, NWAVES, false, STREAM>(ws, b, out, wrap, [&](auto ti) __attribute__((always_inline)) {
+        uhook(std::integral_constant<int, s * n_out + decltype(ti)::value>{});
+      });
+      if constexpr (s + 1 < ksteps(M)) split_units<s + 1, 0, NU, BF>(in, cur, m);
     } else {
       gemm_f16_panel<M, s, C, NWAVES, false, STREAM>(ws, b, out, wrap);
       if constexpr (s + 1 < ksteps(M)) split_units<s + 1, 0, NU, BF>(in, cur, m);

@@ -162,7 +162,11 @@ def test_cost_reg_2_gradients_match_the_references_autograd():
         # the whole tensor, through its stored sum and squared norm
         assert abs(float(got.sum()) - float(g["gsum." + key])) < 1e-3 * (abs(float(g["gsum." + key])) + scale * n ** 0.5), k
         assert abs(float((got ** 2).sum()) - float(g["gsq." + key])) < 1e-3 * float(g["gsq." + key]) + 1e-30, k
-    bad = {k: e for k, e in worst.items() if not e < 1e-3}
+    # measured round 6 (printed below, per tensor): worst 9.7e-5 (conv7.weight), most 1e-5 .. 6e-5 -- the bound was 1e-3 while
+    # the step's matrix precision was the only thing known about it; 3e-4 leaves the float atomics' reordering its room
+    bad = {k: e for k, e in worst.items() if not e < 3e-4}
     print("cost_reg_2 gradients vs the reference's autograd, worst of each tensor:", max(worst.values()), max(worst, key=worst.get))
+    for k, e in sorted(worst.items(), key=lambda kv: -kv[1]):
+        print(f"   {k:24s} {e:.2e}")
     assert not bad, bad
 

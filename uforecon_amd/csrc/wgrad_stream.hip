@@ -277,7 +277,21 @@ __global__ void __launch_bounds__(256, 2) view_wgrad_kernel(const float* __restr
                                                             int n_blocks, int n_chunks, GradPtrs gp) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int type = blockIdx.x / n_chunks, chunk = blockIdx.x - type * n_chunks;
+#ifndef UFR_VW_XCD
+#define UFR_VW_XCD 0   // measured round 6 (tools/dev/train_lib_ab2.sh, two runs): 0.748 vs 0.708 ms fp32 mode (slower), 0.384 vs 0.391 in the 16-bit mode: off
+#endif
+  int type, chunk;
+  if constexpr (UFR_VW_XCD != 0) {
+    // The three workgroup types of a chunk read overlapping tiles (x: q / k / v and mlp0; d hid, d opre): dispatched
+    // type-major they ran a third of the launch apart and on unrelated XCDs, so every type fetched the chunk from HBM again.
+    // Workgroups go round-robin over the 8 XCDs: in groups of 8 chunks x 3 types, workgroup 24 G + 8 t + c is chunk 8 G + c of
+    // type t on XCD c -- a chunk's three readers share one L2 and start within 24 dispatch slots of each other.
+    const int b = blockIdx.x, full = (n_chunks / 8) * 24;
+    if (b < full) { type = (b % 24) / 8; chunk = (b / 24) * 8 + b % 8; }
+    else { const int rem = n_chunks % 8, w = b - full; type = w / rem; chunk = (n_chunks / 8) * 8 + w % rem; }
+  } else {
+    type = blockIdx.x / n_chunks; chunk = blockIdx.x - type * n_chunks;
+  }
   const int per = (n_blocks + n_chunks - 1) / n_chunks;
   const int blk0 = chunk * per, blk1 = min(n_blocks, blk0 + per);
   switch (__builtin_amdgcn_readfirstlane(type * 4 + wave)) {

@@ -481,8 +481,8 @@ int ufr_conv3d_bwd_weight(const float* in, const float* d_out, float* d_weight, 
                           int32_t W, int32_t cin, int32_t cout, int32_t mode, ufr_stream stream);
 
 /* ---- the same layers on the 16-bit matrix cores (ABI 503) -------------------------------------------------------
- * The stride-1 layers with 8 or 16 input channels (the full- and half-resolution layers of the U-Nets: module.py:502-543
- * conv2, `features` + `weights`; and, with flip != 0, their data gradients) as an implicit GEMM on
+ * The stride-1 layers of the U-Nets (module.py:469-543: conv2, conv4, conv6, `prob`, `features` + `weights`; and, with
+ * flip != 0, their data gradients) as an implicit GEMM on
  * v_mfma_f32_16x16x32_f16 with the input brick staged once through LDS (csrc/conv3d_planes.hip).  Every fp32 product is
  * three fp16 plane products accumulated in fp32 (22 significand bits): not bit-identical to ufr_conv3d, within ~1e-6 of it.
  *   in_absmax   device pointer to ONE float >= max |in| (> 0 unless the tensor is zero): the planes' power-of-two scale.
@@ -491,13 +491,17 @@ int ufr_conv3d_bwd_weight(const float* in, const float* d_out, float* d_weight, 
  *   flip        0: `weight` (cout,cin,3,3,3).  1: the data gradient of a stride-1 layer -- `weight` is that layer's FORWARD
  *               weight (cin of this call, cout of this call, 3,3,3) and the taps are mirrored (ufr_conv3d_bwd_data, S1).
  *   workspace   ufr_conv3d_planes_workspace_bytes(cin, cout, cout2) bytes (the weights' planes); 0 = combination not
- *               supported here (use ufr_conv3d): cin in {8, 16}, cout + cout2 <= 16.
+ *               supported here (use ufr_conv3d): cin in {8, 16} with cout + cout2 <= 16, (32, 32), (64, 64).
+ *   planes_ready  0: the planes are made from `weight` (/ `weight2`) by this call (three small launches).  1: `workspace` still
+ *               holds the planes a call with planes_ready = 0 made from the SAME weights, flip and channel counts (frozen
+ *               weights: once per checkpoint, not once per frame); the caller vouches for that.
  * bias / bn_scale / bn_shift / relu / skip / out_ncdhw / weight2 / out2 as for ufr_conv3d.                              */
 size_t ufr_conv3d_planes_workspace_bytes(int32_t cin, int32_t cout, int32_t cout2);
 int ufr_conv3d_planes(const float* in, const float* in_absmax, const float* weight, const float* weight2, const float* bias,
                       const float* bn_scale, const float* bn_shift, const float* skip, float* out, float* out2,
                       float* out_absmax, int32_t B, int32_t D, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t cout2,
-                      int32_t relu, int32_t out_ncdhw, int32_t flip, void* workspace, size_t workspace_bytes, ufr_stream stream);
+                      int32_t relu, int32_t out_ncdhw, int32_t flip, void* workspace, size_t workspace_bytes, int32_t planes_ready,
+                      ufr_stream stream);
 /* *absmax = max(*absmax, max |x[0..n)|) (device float; zero it first).  One pass at HBM speed.                          */
 int ufr_absmax(const float* x, size_t n, float* absmax, ufr_stream stream);
 

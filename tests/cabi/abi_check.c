@@ -7,22 +7,11 @@
 
 int main(void) {
   /* link-time presence of every entry point */
+  /* every function include/ufr.h declares: the list is GENERATED from the header by tests/test_abi_and_layout.py
+   * (abi_syms.inc in the build directory), so a new entry point cannot be forgotten here */
   const void* syms[] = {
-      (const void*)ufr_version, (const void*)ufr_last_error, (const void*)ufr_set_matrix_precision,
-      (const void*)ufr_get_matrix_precision, (const void*)ufr_status_poll, (const void*)ufr_packed_weights_bytes, (const void*)ufr_weights_pack, (const void*)ufr_weights_pack_for, (const void*)ufr_packed_scale_table_offset,
-      (const void*)ufr_packed_scale_table_entries,
-      (const void*)ufr_pack_plan, (const void*)ufr_packed_fp32_floats, (const void*)ufr_packed_f16_halfwords,
-      (const void*)ufr_pack_plan_f16, (const void*)ufr_frame_workspace_bytes, (const void*)ufr_frame_prepare,
-      (const void*)ufr_sample_fixed, (const void*)ufr_sample_importance_merge, (const void*)ufr_points,
-      (const void*)ufr_project_gather, (const void*)ufr_aggregate_workspace_bytes, (const void*)ufr_aggregate,
-      (const void*)ufr_composite, (const void*)ufr_composite_bwd, (const void*)ufr_render_loss, (const void*)ufr_aggregate_bwd_workspace_bytes,
-      (const void*)ufr_aggregate_bwd, (const void*)ufr_project_gather_bwd, (const void*)ufr_project_gather_bwd_workspace_bytes, (const void*)ufr_sample_importance_pool, (const void*)ufr_view_transform,
-      (const void*)ufr_ray_transform_workspace_bytes, (const void*)ufr_ray_transform, (const void*)ufr_ray_transform_bwd, (const void*)ufr_ray_transform_bwd_workspace_bytes,
-      (const void*)ufr_view_transform_bwd, (const void*)ufr_view_transform_bwd_stages, (const void*)ufr_ray_transform_bwd_stages, (const void*)ufr_view_transform_tape, (const void*)ufr_ray_transform_tape,
-      (const void*)ufr_view_tape_block_points, (const void*)ufr_view_transform_bwd_workspace_bytes, (const void*)ufr_packed_bwd_halfwords, (const void*)ufr_pack_plan_bwd, (const void*)ufr_status_poll_bits, (const void*)ufr_render_workspace_bytes, (const void*)ufr_default_chunk_rays,
-      (const void*)ufr_render_rays, (const void*)ufr_correlate_workspace_bytes, (const void*)ufr_frustum_correlate,
-      (const void*)ufr_conv3d, (const void*)ufr_tsdf_integrate, (const void*)ufr_deform_conv2d_workspace_bytes, (const void*)ufr_deform_conv2d, (const void*)ufr_pixelwise_view_weights, (const void*)ufr_conv2d, (const void*)ufr_upsample_add, (const void*)ufr_deform_conv2d_cl, (const void*)ufr_fmt_layer_workspace_bytes, (const void*)ufr_fmt_layer,
-      (const void*)ufr_profile_enable, (const void*)ufr_profile_read};
+#include "abi_syms.inc"
+  };
   unsigned i, n = sizeof(syms) / sizeof(syms[0]);
   for (i = 0; i < n; ++i)
     if (!syms[i]) return 10;

@@ -24,7 +24,8 @@ def _err(a, ref):
     return float((a.double() - ref).abs().max() / ref.abs().max())
 
 
-@pytest.mark.parametrize("cin,cout,shape", [(8, 8, (2, 4, 12, 70)), (16, 16, (1, 3, 9, 37)), (8, 8, (1, 8, 32, 128)), (16, 16, (3, 2, 16, 64))])
+@pytest.mark.parametrize("cin,cout,shape", [(8, 8, (2, 4, 12, 70)), (16, 16, (1, 3, 9, 37)), (8, 8, (1, 8, 32, 128)), (16, 16, (3, 2, 16, 64)),
+                                            (32, 32, (2, 3, 10, 21)), (64, 64, (1, 2, 9, 20)), (32, 32, (3, 2, 16, 32)), (64, 64, (3, 1, 8, 16))])
 @pytest.mark.parametrize("flip", [False, True])
 def test_planes_layer_matches_fp32_kernel_and_float64(cin, cout, shape, flip):
     from uforecon_amd import ops
@@ -84,7 +85,35 @@ def test_planes_bn_relu_and_zero_input():
 def test_planes_refuses_other_layers():
     from uforecon_amd import ops
 
-    assert ops.conv3d_planes_supported(8, 8, 1) and ops.conv3d_planes_supported(16, 16) and not ops.conv3d_planes_supported(32, 32)
+    assert ops.conv3d_planes_supported(8, 8, 1) and ops.conv3d_planes_supported(16, 16) and ops.conv3d_planes_supported(64, 64)
+    assert not ops.conv3d_planes_supported(32, 64) and not ops.conv3d_planes_supported(1, 8)
     x = torch.randn(1, 2, 8, 8, 32, device=DEV)
     with pytest.raises(ops.UfrError, match="not a layer of this kernel family"):
-        ops.conv3d_planes(x, ops.absmax(x), torch.randn(32, 32, 3, 3, 3, device=DEV))
+        ops.conv3d_planes(x, ops.absmax(x), torch.randn(64, 32, 3, 3, 3, device=DEV))
+
+
+def test_planes_cache_follows_the_weight_tensor():
+    """The weights' planes are kept per weight TENSOR and version: a second call reuses them, an in-place update makes them
+    again, and a different tensor that happens to get the same storage address never sees the old ones."""
+    from uforecon_amd import ops
+
+    torch.manual_seed(5)
+    x = torch.randn(1, 2, 8, 32, 16, device=DEV)
+    am = ops.absmax(x)
+    w = torch.randn(16, 16, 3, 3, 3, device=DEV) * 0.1
+    y1, _ = ops.conv3d_planes(x, am, w)
+    y2, _ = ops.conv3d_planes(x, am, w)                       # planes_ready = 1
+    assert torch.equal(y1, y2)
+    with torch.no_grad():
+        w.mul_(2.0)                                           # version bump: planes re-made
+    y3, _ = ops.conv3d_planes(x, am, w)
+    assert float((y3 - 2.0 * y1).abs().max()) < 1e-5 * float(y1.abs().max())
+    yf, _ = ops.conv3d_planes(x, am, w, flip=True)            # the mirrored planes of the same tensor are another entry state
+    ref = ops.conv3d_bwd_data(x, w, ops.CONV3D_S1, tuple(x.shape))
+    assert float((yf - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+    ptr = w.data_ptr()
+    del w
+    w2 = torch.randn(16, 16, 3, 3, 3, device=DEV) * 0.1        # usually the freed block again
+    y4, _ = ops.conv3d_planes(x, am, w2)
+    ref4 = ops.conv3d(x, w2, ops.CONV3D_S1)
+    assert float((y4 - ref4).abs().max()) < 1e-5 * float(ref4.abs().max()), (ptr, w2.data_ptr())

@@ -24,7 +24,8 @@ def t(fn, reps=5):
 def main():
     dev = "cuda:0"
     for stage, (D, H, W) in (("stage1", (48, 128, 160)), ("stage2", (32, 256, 320)), ("stage3", (8, 512, 640))):
-        for name, cin, cout, cout2, down in (("heads", 8, 8, 1, 1), ("features", 8, 8, 0, 1), ("conv2", 16, 16, 0, 2)):
+        for name, cin, cout, cout2, down in (("heads", 8, 8, 1, 1), ("features", 8, 8, 0, 1), ("conv2", 16, 16, 0, 2), ("conv4", 32, 32, 0, 4),
+                                            ("conv6", 64, 64, 0, 8)):
             d, h, w = D // down, H // down, W // down
             x = torch.randn(3, d, h, w, cin, device=dev)
             wt = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.1

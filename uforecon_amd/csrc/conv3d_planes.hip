@@ -34,7 +34,7 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
-constexpr int kPlanesHeader = 256;   // bytes in front of the weight planes: [0] = 1 / s_w (float)
+constexpr int kPlanesHeader = 256;   // bytes in front of the weight planes: float [0] = 1 / s_w, [1] = max |w|
 
 __host__ __device__ constexpr int planes_ksteps(int cin) { return (27 * cin + 31) / 32; }
 __host__ __device__ constexpr int planes_tiles(int cout_total) { return (cout_total + 15) / 16; }
@@ -50,13 +50,14 @@ __device__ __forceinline__ float plane_scale(float m) {
 }
 
 // (k-step, lane group g, element h) -> (tap 0..26 or -1, input channel)
+// k = 32 per instruction: 4 taps x 8 channels | 2 taps x 16 | 1 tap x 32 | half a tap (32 of 64 channels)
 template <int CIN>
 __host__ __device__ constexpr int planes_tap(int ks, int g) {
-  return CIN == 8 ? 4 * ks + g : 2 * ks + (g >> 1);
+  return CIN == 8 ? 4 * ks + g : CIN == 16 ? 2 * ks + (g >> 1) : CIN == 32 ? ks : (ks >> 1);
 }
 template <int CIN>
-__host__ __device__ constexpr int planes_c0(int g) {
-  return CIN == 8 ? 0 : 8 * (g & 1);
+__host__ __device__ constexpr int planes_c0(int ks, int g) {
+  return CIN == 8 ? 0 : CIN == 16 ? 8 * (g & 1) : CIN == 32 ? 8 * g : 32 * (ks & 1) + 8 * g;
 }
 
 struct PrepArgs {
@@ -66,62 +67,42 @@ struct PrepArgs {
   int cout, cout2, flip;
 };
 
+// grid-parallel (the 64 -> 64 layer has 110 592 weights: as one workgroup this kernel took longer than the convolution it
+// prepares); max |w| has been measured into header word 1 by absmax_kernel launches in front of it
 template <int CIN>
 __global__ void __launch_bounds__(256) conv3d_planes_prep(PrepArgs a) {
   constexpr int KS = planes_ksteps(CIN);
   const int NT = planes_tiles(a.cout + a.cout2);
-  __shared__ float red[256];
-  float m = 0.f;
-  {   // (loads in batches of eight: a plain loop pays one memory round trip per iteration, ~25 us for this one workgroup)
-    const int n1 = a.cout * CIN * 27, n2 = a.weight2 ? a.cout2 * CIN * 27 : 0;
-    for (int i0 = 0; i0 < n1 + n2; i0 += 256 * 8) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = i0 + 256 * u + threadIdx.x;
-        v[u] = i < n1 ? a.weight[i] : (i < n1 + n2 ? a.weight2[i - n1] : 0.f);
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) m = fmaxf(m, fabsf(v[u]));
-    }
-  }
-  red[threadIdx.x] = m;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
-    __syncthreads();
-  }
-  const float sw = plane_scale(red[0]);
-  if (threadIdx.x == 0) *reinterpret_cast<float*>(a.ws) = 1.f / sw;
+  const float sw = plane_scale(reinterpret_cast<const float*>(a.ws)[1]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<float*>(a.ws) = 1.f / sw;
   _Float16* planes = reinterpret_cast<_Float16*>(a.ws + kPlanesHeader);
   const int total = KS * NT * 64 * 8;
-  for (int e0 = 0; e0 < total; e0 += 256 * 8) {
-    float wv[8];
+  const int e0 = blockIdx.x * (256 * 8);
+  float wv[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int e = e0 + 256 * u + threadIdx.x;
-      const int h = e & 7, lane = (e >> 3) & 63, t = (e >> 9) % NT, ks = (e >> 9) / NT;
-      const int g = lane >> 4, i = lane & 15;
-      const int tap = planes_tap<CIN>(ks, g), ci = planes_c0<CIN>(g) + h, co = 16 * t + i;
-      float w = 0.f;
-      if (e < total && tap < 27) {
-        if (co < a.cout) w = a.flip ? a.weight[((size_t)ci * a.cout + co) * 27 + (26 - tap)] : a.weight[((size_t)co * CIN + ci) * 27 + tap];
-        else if (co < a.cout + a.cout2) w = a.weight2[((size_t)(co - a.cout) * CIN + ci) * 27 + tap];
-      }
-      wv[u] = w;
+  for (int u = 0; u < 8; ++u) {
+    const int e = e0 + 256 * u + threadIdx.x;
+    const int h = e & 7, lane = (e >> 3) & 63, t = (e >> 9) % NT, ks = (e >> 9) / NT;
+    const int g = lane >> 4, i = lane & 15;
+    const int tap = planes_tap<CIN>(ks, g), ci = planes_c0<CIN>(ks, g) + h, co = 16 * t + i;
+    float w = 0.f;
+    if (e < total && tap < 27) {
+      if (co < a.cout) w = a.flip ? a.weight[((size_t)ci * a.cout + co) * 27 + (26 - tap)] : a.weight[((size_t)co * CIN + ci) * 27 + tap];
+      else if (co < a.cout + a.cout2) w = a.weight2[((size_t)(co - a.cout) * CIN + ci) * 27 + tap];
     }
+    wv[u] = w;
+  }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int e = e0 + 256 * u + threadIdx.x;
-      if (e >= total) continue;
-      const int h = e & 7, lane = (e >> 3) & 63, t = (e >> 9) % NT, ks = (e >> 9) / NT;
-      const float v = wv[u] * sw;
-      const _Float16 hi = (_Float16)v;
-      const _Float16 lo = (_Float16)(v - (float)hi);
-      const size_t base = ((size_t)(ks * NT + t) * 2) * 512 + lane * 8 + h;     // [ks][t][plane][lane][8]
-      planes[base] = hi;
-      planes[base + 512] = lo;
-    }
+  for (int u = 0; u < 8; ++u) {
+    const int e = e0 + 256 * u + threadIdx.x;
+    if (e >= total) continue;
+    const int h = e & 7, lane = (e >> 3) & 63, t = (e >> 9) % NT, ks = (e >> 9) / NT;
+    const float v = wv[u] * sw;
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    const size_t base = ((size_t)(ks * NT + t) * 2) * 512 + lane * 8 + h;     // [ks][t][plane][lane][8]
+    planes[base] = hi;
+    planes[base + 512] = lo;
   }
 }
 
@@ -151,7 +132,7 @@ __device__ __forceinline__ void split2(float a, float b, float m, unsigned& h, u
 
 template <int CIN>
 struct Brick {   // output brick of a workgroup and its input halo
-  static constexpr int TX = CIN == 8 ? 64 : 32, TY = 4, TZ = CIN == 8 ? 2 : 1;
+  static constexpr int TX = CIN == 8 ? 64 : CIN == 16 ? 32 : 16, TY = 4, TZ = (CIN == 8 || CIN == 32) ? 2 : 1;
   static constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2;
   static constexpr int halo = HX * HY * HZ;
   static constexpr int tiles = TX / 16 * TY * TZ;          // 16-voxel column tiles
@@ -167,17 +148,27 @@ struct Brick {   // output brick of a workgroup and its input halo
 // while the current one computes: as one workgroup per brick the phases of a brick -- load round trip, split + LDS write,
 // MFMAs, stores -- ran one after the other and only two bricks per CU overlapped (ablations on the full-resolution 8 -> 8
 // layer: 0.345 ms = 0.14 fixed + 0.09 MFMA + 0.09 stores + 0.03 loads, a sum, not a maximum).
-template <int CIN, int NT>
+// NT output row tiles in passes of NTG (the 64 -> 64 layer: two passes of two tiles -- four tiles' weight fragments three
+// k-steps deep are 96 registers, and the kernel spilled 800; the halo is staged once, its operands are read per pass)
+template <int CIN, int NT, int NTG = NT>
 __global__ void __launch_bounds__(256, 2) conv3d_planes_kernel(PlanesArgs a) {
   typedef Brick<CIN> Bk;
   constexpr int KS = planes_ksteps(CIN);
   constexpr int VT = Bk::per_wave;
-  constexpr int w_bytes = KS * NT * 2048;
+  // the weights' planes: copied into LDS once per workgroup when they fit beside the halo (<= 32 KiB: the 8- / 16-channel
+  // layers), else every wave reads its fragments from global memory (108 / 432 KiB for 32 -> 32 / 64 -> 64: L2-resident, the
+  // four waves of a workgroup read the same 1 KiB pieces, and those layers' grids are small)
+  constexpr bool kWLds = KS * NT * 2048 <= 32768;
+  constexpr int w_bytes = kWLds ? KS * NT * 2048 : 0;
   constexpr int HR = (Bk::halo + 255) / 256, C8 = CIN / 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const w_lds = smem;                                  // [ks][t][plane][lane] 16 B
-  char* const x_hi = smem + w_bytes;                         // [halo voxel][CIN] fp16
+  // halo planes, 8-channel-chunk major: [chunk c8][halo voxel][8] fp16 -- the 16 lanes of a lane group read 16 consecutive
+  // voxels' chunks = 256 contiguous bytes whatever CIN is (voxel-major, CIN = 16 .. 64 would stride the lanes by 32 .. 128
+  // bytes: 2- to 8-way bank conflicts on every operand read)
+  char* const x_hi = smem + w_bytes;
   char* const x_lo = x_hi + Bk::plane_bytes;
+  const char* const w_glb = a.ws + kPlanesHeader;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
 
   // ---- scales (wave-uniform)
@@ -206,7 +197,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_planes_kernel(PlanesArgs a) {
     x0 = bx * Bk::TX; y0 = by * Bk::TY; z0 = (k % a.nbz) * Bk::TZ;
   };
   // every load of a brick's halo is issued before the first one is used (fully unrolled: a loop waits for each round trip)
-  f32x4 xv[HR][C8][2];
+  f32x4 xv[CIN <= 16 ? HR : 1][C8][2];
   auto halo_load = [&](int k) __attribute__((always_inline)) {
     int bb, x0, y0, z0;
     brick_of(k, bb, x0, y0, z0);
@@ -238,16 +229,51 @@ __global__ void __launch_bounds__(256, 2) conv3d_planes_kernel(PlanesArgs a) {
           split2(v0[2], v0[3], sx, h1, l1);
           split2(v1[0], v1[1], sx, h2, l2);
           split2(v1[2], v1[3], sx, h3, l3);
-          *reinterpret_cast<u32x4v*>(x_hi + (size_t)hv * (CIN * 2) + c8 * 16) = u32x4v{h0, h1, h2, h3};
-          *reinterpret_cast<u32x4v*>(x_lo + (size_t)hv * (CIN * 2) + c8 * 16) = u32x4v{l0, l1, l2, l3};
+          *reinterpret_cast<u32x4v*>(x_hi + ((size_t)c8 * Bk::halo + hv) * 16) = u32x4v{h0, h1, h2, h3};
+          *reinterpret_cast<u32x4v*>(x_lo + ((size_t)c8 * Bk::halo + hv) * 16) = u32x4v{l0, l1, l2, l3};
+        }
+      }
+    }
+  };
+
+  // CIN >= 32 (small grids, a brick or two per workgroup, 128 .. 256 bytes per halo voxel): no prefetch across bricks -- the
+  // halo is staged round by round (256 voxels at a time), so that only one round's loads are live
+  constexpr bool kPrefetch = CIN <= 16;
+  auto halo_direct = [&](int k) __attribute__((always_inline)) {
+    int bb, x0, y0, z0;
+    brick_of(k, bb, x0, y0, z0);
+    const __amdgpu_buffer_rsrc_t rin = buf_rsrc(reinterpret_cast<const char*>(a.in) + (size_t)bb * frame, (unsigned)frame);
+#pragma unroll 1
+    for (int r = 0; r < HR; ++r) {
+      const int hv = tid + 256 * r;
+      const int hx = hv % Bk::HX, hy = (hv / Bk::HX) % Bk::HY, hz = hv / (Bk::HX * Bk::HY);
+      const int ix = x0 + hx - 1, iy = y0 + hy - 1, iz = z0 + hz - 1;
+      const bool ok = hv < Bk::halo && ix >= 0 && ix < a.W && iy >= 0 && iy < a.H && iz >= 0 && iz < a.D;
+      const unsigned off = (unsigned)(((iz * a.H + iy) * a.W + ix) * (CIN * 4));
+      f32x4 t[C8][2];
+#pragma unroll
+      for (int c8 = 0; c8 < C8; ++c8) {
+        t[c8][0] = buf_ld4(rin, ok ? off + c8 * 32 : kBufOut);
+        t[c8][1] = buf_ld4(rin, ok ? off + c8 * 32 + 16 : kBufOut);
+      }
+      if (hv < Bk::halo) {
+#pragma unroll
+        for (int c8 = 0; c8 < C8; ++c8) {
+          unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+          split2(t[c8][0][0], t[c8][0][1], sx, h0, l0);
+          split2(t[c8][0][2], t[c8][0][3], sx, h1, l1);
+          split2(t[c8][1][0], t[c8][1][1], sx, h2, l2);
+          split2(t[c8][1][2], t[c8][1][3], sx, h3, l3);
+          *reinterpret_cast<u32x4v*>(x_hi + ((size_t)c8 * Bk::halo + hv) * 16) = u32x4v{h0, h1, h2, h3};
+          *reinterpret_cast<u32x4v*>(x_lo + ((size_t)c8 * Bk::halo + hv) * 16) = u32x4v{l0, l1, l2, l3};
         }
       }
     }
   };
 
   // ---- prologue: the weights' planes (16-byte copies) and the first brick
-  if (k_begin < k_end) halo_load(k_begin);
-  {
+  if (kPrefetch && k_begin < k_end) halo_load(k_begin);
+  if constexpr (kWLds) {
     constexpr int n16 = w_bytes / 16, WR = (n16 + 255) / 256;
     const u32x4v* src = reinterpret_cast<const u32x4v*>(a.ws + kPlanesHeader);
     u32x4v* dst = reinterpret_cast<u32x4v*>(w_lds);
@@ -258,7 +284,10 @@ __global__ void __launch_bounds__(256, 2) conv3d_planes_kernel(PlanesArgs a) {
     for (int r = 0; r < WR; ++r)
       if (tid + 256 * r < n16) dst[tid + 256 * r] = wv[r];
   }
-  if (k_begin < k_end) halo_to_lds();
+  if (k_begin < k_end) {
+    if constexpr (kPrefetch) halo_to_lds();
+    else halo_direct(k_begin);
+  }
   __syncthreads();
 
   // ---- this wave's column tiles: tile q = wave + 4 v -> (tz, ty, tx16)
@@ -269,42 +298,60 @@ __global__ void __launch_bounds__(256, 2) conv3d_planes_kernel(PlanesArgs a) {
     const int tx16 = q % (Bk::TX / 16), ty = (q / (Bk::TX / 16)) % Bk::TY, tz = q / (Bk::TX / 16 * Bk::TY);
     vbase[v] = (tz * Bk::HY + ty) * Bk::HX + tx16 * 16 + j;
   }
-  int toff[KS];      // halo offset of this lane group's tap at every k-step (padding k: zero weights, any finite operand)
+  // halo offset of this lane group's tap at a k-step (padding k: zero weights, any finite operand) and the 8-channel chunk of
+  // the halo planes it reads there: per-lane tables for CIN <= 16 (the tap depends on the lane group), compile-time
+  // constants + the lane group for CIN >= 32 (one tap per k-step)
+  constexpr int KT = CIN <= 16 ? KS : 1;
+  int toff_t[KT];
+  if constexpr (CIN <= 16) {
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    int tap = planes_tap<CIN>(ks, g);
-    tap = tap < 27 ? tap : 0;
-    toff[ks] = ((tap / 9) * Bk::HY + (tap / 3) % 3) * Bk::HX + tap % 3;
+    for (int ks = 0; ks < KS; ++ks) {
+      int tap = planes_tap<CIN>(ks, g);
+      tap = tap < 27 ? tap : 0;
+      toff_t[ks] = ((tap / 9) * Bk::HY + (tap / 3) % 3) * Bk::HX + tap % 3;
+    }
   }
-  const int cb = planes_c0<CIN>(g) * 2;     // byte offset of this lane group's 8 channels inside a voxel's CIN halves
+  auto operand_off = [&](auto ksi, int vb) __attribute__((always_inline)) -> int {
+    constexpr int ks = decltype(ksi)::value;
+    if constexpr (CIN <= 16) {
+      return ((planes_c0<CIN>(ks, g) / 8) * Bk::halo + vb + toff_t[ks]) * 16;
+    } else {
+      constexpr int tap = planes_tap<CIN>(ks, 0), to = ((tap / 9) * Bk::HY + (tap / 3) % 3) * Bk::HX + tap % 3;
+      return ((planes_c0<CIN>(ks, 0) / 8 + g) * Bk::halo + vb + to) * 16;
+    }
+  };
   float omax = 0.f;
   const int ct = a.cout + a.cout2;
   const size_t plane = (size_t)a.D * a.H * a.W;
 
   for (int k = k_begin; k < k_end; ++k) {
-    if (k + 1 < k_end) halo_load(k + 1);       // in flight under this brick's MFMAs
-    f32x4 acc[VT][NT];
+    if (kPrefetch && k + 1 < k_end) halo_load(k + 1);       // in flight under this brick's MFMAs
+    int bb, x0, y0, z0;
+    brick_of(k, bb, x0, y0, z0);
+#pragma unroll 1
+    for (int pass = 0; pass < NT / NTG; ++pass) {
+    f32x4 acc[VT][NTG];
 #pragma unroll
     for (int v = 0; v < VT; ++v)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[v][t] = splat4(0.f);
+      for (int t = 0; t < NTG; ++t) acc[v][t] = splat4(0.f);
     // One step = (k-step, column tile): two ds_read_b128 for the B planes (+ the A planes at a k-step's first tile) and
     // 3 NT MFMAs.  The operands of step s + 2 are requested before the MFMAs of step s are issued (scheduling fences keep
     // that order: left alone, the scheduler sinks every read to its use and the wave pays the LDS latency 56 times a brick
     // -- 0.31 ms for the full-resolution 8 -> 8 layer, a tenth of it in the matrix pipe).
     constexpr int kSteps = (UFR_C3P_ABL == 1 ? 1 : KS) * VT;
-    f16x8 rb[3][2], ra[3][NT][2];
+    f16x8 rb[3][2], ra[3][NTG][2];
     auto issue = [&](auto si) __attribute__((always_inline)) {
       constexpr int st = decltype(si)::value, ks = st / VT, v = st % VT;
-      const int o = (vbase[v] + toff[ks]) * (CIN * 2) + cb;
+      const int o = operand_off(std::integral_constant<int, ks>{}, vbase[v]);
       rb[st % 3][0] = *reinterpret_cast<const f16x8*>(x_hi + o);
       rb[st % 3][1] = *reinterpret_cast<const f16x8*>(x_lo + o);
       if constexpr (v == 0) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NTG; ++t)
 #pragma unroll
           for (int p = 0; p < 2; ++p)
-            ra[ks % 3][t][p] = *reinterpret_cast<const f16x8*>(w_lds + ((ks * NT + t) * 2 + p) * 1024 + lane * 16);
+            ra[ks % 3][t][p] = *reinterpret_cast<const f16x8*>((kWLds ? w_lds : w_glb) + ((ks * NT + pass * NTG + t) * 2 + p) * 1024 + lane * 16);
       }
     };
     issue(std::integral_constant<int, 0>{});
@@ -314,7 +361,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_planes_kernel(PlanesArgs a) {
       if constexpr (st + 2 < kSteps) issue(std::integral_constant<int, st + 2>{});
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
+      for (int t = 0; t < NTG; ++t) {
         acc[v][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ra[ks % 3][t][1], rb[st % 3][0], acc[v][t], 0, 0, 0);   // small terms first
         acc[v][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ra[ks % 3][t][0], rb[st % 3][1], acc[v][t], 0, 0, 0);
         acc[v][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ra[ks % 3][t][0], rb[st % 3][0], acc[v][t], 0, 0, 0);
@@ -323,8 +370,6 @@ __global__ void __launch_bounds__(256, 2) conv3d_planes_kernel(PlanesArgs a) {
     });
 
     // ---- epilogue: lane (g, j) holds channels 16 t + 4 g + r of voxel j of its tiles
-    int bb, x0, y0, z0;
-    brick_of(k, bb, x0, y0, z0);
 #pragma unroll
     for (int v = 0; v < VT; ++v) {
       const int q = wave + 4 * v;
@@ -334,8 +379,8 @@ __global__ void __launch_bounds__(256, 2) conv3d_planes_kernel(PlanesArgs a) {
       if (UFR_C3P_ABL == 3 && acc[v][0][0] != 12345.f) continue;
       const size_t sp = ((size_t)oz * a.H + oy) * a.W + ox;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int c0 = 16 * t + 4 * g;
+      for (int t = 0; t < NTG; ++t) {
+        const int c0 = 16 * (pass * NTG + t) + 4 * g;
         if (c0 >= ct) continue;
         f32x4 y;
 #pragma unroll
@@ -364,8 +409,12 @@ __global__ void __launch_bounds__(256, 2) conv3d_planes_kernel(PlanesArgs a) {
         }
       }
     }
+    }   // pass
     __syncthreads();                           // every wave is done reading this brick's planes
-    if (k + 1 < k_end) halo_to_lds();
+    if (k + 1 < k_end) {
+      if constexpr (kPrefetch) halo_to_lds();
+      else halo_direct(k + 1);
+    }
     __syncthreads();
   }
   if (a.out_absmax) {
@@ -391,20 +440,22 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x
   if ((threadIdx.x & 63) == 0 && bits > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, bits);
 }
 
-template <int CIN, int NT>
+template <int CIN, int NT, int NTG = NT>
 hipError_t launch_planes_t(const PlanesArgs& a, hipStream_t s) {
   typedef Brick<CIN> Bk;
-  constexpr int lds = planes_ksteps(CIN) * NT * 2048 + 2 * Bk::plane_bytes;
+  constexpr int w_all = planes_ksteps(CIN) * NT * 2048;
+  constexpr int lds = (w_all <= 32768 ? w_all : 0) + 2 * Bk::plane_bytes;
   static LdsAttrOnce lds_attr;
-  if (const hipError_t e = lds_attr.set(reinterpret_cast<const void*>(&conv3d_planes_kernel<CIN, NT>), lds); e != hipSuccess) return e;
+  if (const hipError_t e = lds_attr.set(reinterpret_cast<const void*>(&conv3d_planes_kernel<CIN, NT, NTG>), lds); e != hipSuccess) return e;
   PlanesArgs b = a;
   b.nbx = (a.W + Bk::TX - 1) / Bk::TX; b.nby = (a.H + Bk::TY - 1) / Bk::TY; b.nbz = (a.D + Bk::TZ - 1) / Bk::TZ;
   const long long bricks = (long long)b.nbx * b.nby * b.nbz * a.B;
   if (bricks <= 0 || bricks > 0x7fffffffLL) return hipErrorInvalidValue;
-  // two resident workgroups per CU (LDS), a multiple of the 8 XCDs; fewer when there are fewer bricks than that
-  long long blocks = 2 * 256;
+  // the resident workgroups (LDS: two per CU, one for the 64-channel halo), a multiple of the 8 XCDs; fewer when there are
+  // fewer bricks than that
+  long long blocks = (lds > 80 * 1024 ? 1 : 2) * 256;
   if (bricks < blocks) blocks = ((bricks + 7) / 8) * 8;
-  hipLaunchKernelGGL((conv3d_planes_kernel<CIN, NT>), dim3((unsigned)blocks), dim3(256), lds, s, b);
+  hipLaunchKernelGGL((conv3d_planes_kernel<CIN, NT, NTG>), dim3((unsigned)blocks), dim3(256), lds, s, b);
   return hipGetLastError();
 }
 
@@ -412,7 +463,8 @@ hipError_t launch_planes_t(const PlanesArgs& a, hipStream_t s) {
 
 // which (cin, cout + cout2) the plane kernels take (stride 1 only); 0 = not supported
 size_t conv3d_planes_workspace_bytes(int cin, int cout, int cout2) {
-  if (!((cin == 8 && cout + cout2 <= 16) || (cin == 16 && cout + cout2 <= 16))) return 0;
+  if (!(((cin == 8 || cin == 16) && cout + cout2 <= 16) || (cin == 32 && cout == 32 && cout2 == 0) || (cin == 64 && cout == 64 && cout2 == 0)))
+    return 0;
   if (cout < 1 || cout2 < 0) return 0;
   return kPlanesHeader + (size_t)planes_ksteps(cin) * planes_tiles(cout + cout2) * 2048;
 }
@@ -429,22 +481,35 @@ hipError_t launch_absmax(const float* x, size_t n, float* absmax, hipStream_t s)
 hipError_t launch_conv3d_planes(const float* in, const float* in_absmax, const float* weight, const float* weight2, const float* bias,
                                 const float* scale, const float* shift, const float* skip, float* out, float* out2, float* out_absmax,
                                 int B, int D, int H, int W, int cin, int cout, int cout2, int relu, int ncdhw, int flip, void* ws,
-                                hipStream_t s) {
+                                int planes_ready, hipStream_t s) {
   if (!conv3d_planes_workspace_bytes(cin, cout, cout2)) return hipErrorInvalidValue;
   // one view's tensor is a raw buffer descriptor (31-bit byte offsets, kBufOut = zero fill)
   if ((long long)D * H * W * cin * 4 >= (1ll << 31)) return hipErrorInvalidValue;
-  PrepArgs p;
-  p.weight = weight; p.weight2 = weight2; p.ws = static_cast<char*>(ws); p.cout = cout; p.cout2 = cout2; p.flip = flip;
-  if (cin == 8) hipLaunchKernelGGL(conv3d_planes_prep<8>, dim3(1), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(conv3d_planes_prep<16>, dim3(1), dim3(256), 0, s, p);
-  if (const hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+  if (!planes_ready) {
+    const int ct = cout + cout2, nt = planes_tiles(ct);
+    if (const hipError_t e = hipMemsetAsync(static_cast<char*>(ws) + 4, 0, 4, s); e != hipSuccess) return e;
+    float* wmax = reinterpret_cast<float*>(ws) + 1;
+    if (const hipError_t e = launch_absmax(weight, (size_t)cout * cin * 27, wmax, s); e != hipSuccess) return e;
+    if (weight2)
+      if (const hipError_t e = launch_absmax(weight2, (size_t)cout2 * cin * 27, wmax, s); e != hipSuccess) return e;
+    PrepArgs p;
+    p.weight = weight; p.weight2 = weight2; p.ws = static_cast<char*>(ws); p.cout = cout; p.cout2 = cout2; p.flip = flip;
+    const unsigned pb = (unsigned)((planes_ksteps(cin) * nt * 512 + 2047) / 2048);
+    if (cin == 8) hipLaunchKernelGGL(conv3d_planes_prep<8>, dim3(pb), dim3(256), 0, s, p);
+    else if (cin == 16) hipLaunchKernelGGL(conv3d_planes_prep<16>, dim3(pb), dim3(256), 0, s, p);
+    else if (cin == 32) hipLaunchKernelGGL(conv3d_planes_prep<32>, dim3(pb), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(conv3d_planes_prep<64>, dim3(pb), dim3(256), 0, s, p);
+    if (const hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+  }
   PlanesArgs a;
   a.in = in; a.in_absmax = reinterpret_cast<const unsigned*>(in_absmax); a.ws = static_cast<const char*>(ws); a.bias = bias;
   a.scale = scale; a.shift = shift; a.skip = skip; a.out = out; a.out2 = out2; a.out_absmax = reinterpret_cast<unsigned*>(out_absmax);
   a.B = B; a.D = D; a.H = H; a.W = W; a.cout = cout; a.cout2 = cout2; a.relu = relu; a.ncdhw = ncdhw;
   a.nbx = a.nby = a.nbz = 0;
   if (cin == 8) return launch_planes_t<8, 1>(a, s);
-  return launch_planes_t<16, 1>(a, s);
+  if (cin == 16) return launch_planes_t<16, 1>(a, s);
+  if (cin == 32) return launch_planes_t<32, 2, 1>(a, s);
+  return launch_planes_t<64, 4, 2>(a, s);
 }
 
 }  // namespace ufr

@@ -1162,7 +1162,8 @@ size_t ufr_conv3d_planes_workspace_bytes(int32_t cin, int32_t cout, int32_t cout
 int ufr_conv3d_planes(const float* in, const float* in_absmax, const float* weight, const float* weight2, const float* bias,
                       const float* bn_scale, const float* bn_shift, const float* skip, float* out, float* out2,
                       float* out_absmax, int32_t B, int32_t D, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t cout2,
-                      int32_t relu, int32_t out_ncdhw, int32_t flip, void* workspace, size_t workspace_bytes, ufr_stream stream) {
+                      int32_t relu, int32_t out_ncdhw, int32_t flip, void* workspace, size_t workspace_bytes, int32_t planes_ready,
+                      ufr_stream stream) {
   UFR_REQUIRE(in && in_absmax && weight && out && workspace, "ufr_conv3d_planes: null argument");
   UFR_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "ufr_conv3d_planes: B=%d D=%d H=%d W=%d", B, D, H, W);
   UFR_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "ufr_conv3d_planes: bn_scale and bn_shift go together");
@@ -1176,7 +1177,7 @@ int ufr_conv3d_planes(const float* in, const float* in_absmax, const float* weig
   hipStream_t s = static_cast<hipStream_t>(stream);
   ProfScope p(flip ? "conv3d_dgrad" : "conv3d", s);
   UFR_HIP(launch_conv3d_planes(in, in_absmax, weight, weight2, bias, bn_scale, bn_shift, skip, out, out2, out_absmax, B, D, H, W, cin,
-                               cout, cout2, relu, out_ncdhw, flip, workspace, s));
+                               cout, cout2, relu, out_ncdhw, flip, workspace, planes_ready != 0, s));
   return UFR_OK;
 }
 

@@ -161,7 +161,7 @@ hipError_t launch_absmax(const float* x, size_t n, float* absmax, hipStream_t s)
 hipError_t launch_conv3d_planes(const float* in, const float* in_absmax, const float* weight, const float* weight2, const float* bias,
                                 const float* scale, const float* shift, const float* skip, float* out, float* out2, float* out_absmax,
                                 int B, int D, int H, int W, int cin, int cout, int cout2, int relu, int ncdhw, int flip, void* ws,
-                                hipStream_t s);
+                                int planes_ready, hipStream_t s);
 hipError_t launch_conv3d(const float* in, const float* weight, const float* weight2, const float* bias, const float* scale,
                          const float* shift, const float* skip, float* out, float* out2, int B, int D, int H, int W,
                          int cin, int cout, int cout2, int mode, int relu, int ncdhw, hipStream_t s, int flip = 0);

@@ -761,6 +761,28 @@ def absmax(x: torch.Tensor, into: Optional[torch.Tensor] = None) -> torch.Tensor
     return out
 
 
+# the weights' planes of ufr_conv3d_planes, kept while the weight TENSOR OBJECT lives unchanged: id(weight) -> (weak reference to
+# it, its version counter, the same of weight2, flip, the planes).  Never keyed on an address: the allocator hands a freed
+# tensor's address -- version 0 again -- to the next one.  An in-place update (optimizer.step) bumps the version, and the
+# next call makes the planes again (training: once per layer and step; inference: once per checkpoint).
+_PLANES = {}
+
+
+def _planes_lookup(weight, weight2, flip, nbytes):
+    import weakref
+
+    ent = _PLANES.get(id(weight))
+    sig = (weight._version, None if weight2 is None else (id(weight2), weight2._version), bool(flip), nbytes, weight.device)
+    if ent is not None and ent[0]() is weight and ent[1] == sig and (weight2 is None or ent[2]() is weight2):
+        return ent[3], True
+    if len(_PLANES) > 512:          # tensors that died without being looked up again
+        for k in [k for k, e in _PLANES.items() if e[0]() is None]:
+            del _PLANES[k]
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    _PLANES[id(weight)] = (weakref.ref(weight), sig, None if weight2 is None else weakref.ref(weight2), ws)
+    return ws, False
+
+
 def conv3d_planes_supported(cin: int, cout: int, cout2: int = 0) -> bool:
     return _lib.load().ufr_conv3d_planes_workspace_bytes(cin, cout, cout2) > 0
 
@@ -793,7 +815,7 @@ def conv3d_planes(x_cl: torch.Tensor, x_absmax: torch.Tensor, weight: torch.Tens
     out2 = torch.empty((B, cout2, D, H, W), dtype=torch.float32, device=dev) if cout2 else None
     if skip is not None and tuple(skip.shape) != tuple(out.shape):
         raise UfrError(f"conv3d_planes: skip {tuple(skip.shape)} does not match the output {tuple(out.shape)}")
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ws, ready = _planes_lookup(weight, weight2, flip, nbytes)
     omax = torch.zeros(1, dtype=torch.float32, device=dev) if (want_absmax and not out_ncdhw) else None
     keep = [t.detach().contiguous() for t in (weight, weight2, bias, bn_scale, bn_shift) if t is not None]
     it = iter(keep)
@@ -802,7 +824,8 @@ def conv3d_planes(x_cl: torch.Tensor, x_absmax: torch.Tensor, weight: torch.Tens
         ptr(bn_shift, "bn_shift")
     _lib.check(lib.ufr_conv3d_planes(_dev(x_cl, "x"), _dev(x_absmax, "x_absmax"), w_p, w2_p, b_p, s_p, h_p, _opt(skip, "skip"),
                                      out.data_ptr(), _opt(out2, "out2"), _opt(omax, "out_absmax"), B, D, H, W, cin, cout, cout2,
-                                     int(bool(relu)), int(bool(out_ncdhw)), int(bool(flip)), ws.data_ptr(), nbytes, _stream()),
+                                     int(bool(relu)), int(bool(out_ncdhw)), int(bool(flip)), ws.data_ptr(), nbytes, int(ready),
+                                     _stream()),
                "ufr_conv3d_planes")
     return (out, out2, None) if cout2 else (out, omax)
 

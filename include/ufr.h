@@ -490,17 +490,20 @@ int ufr_conv3d_bwd_weight(const float* in, const float* d_out, float* d_weight, 
  *   out_absmax  (nullable, channel-last outputs only) device float the caller has zeroed; raised to max |out| (skip included)
  *   flip        0: `weight` (cout,cin,3,3,3).  1: the data gradient of a stride-1 layer -- `weight` is that layer's FORWARD
  *               weight (cin of this call, cout of this call, 3,3,3) and the taps are mirrored (ufr_conv3d_bwd_data, S1).
- *   workspace   ufr_conv3d_planes_workspace_bytes(cin, cout, cout2) bytes (the weights' planes); 0 = combination not
- *               supported here (use ufr_conv3d): cin in {8, 16} with cout + cout2 <= 16, (32, 32), (64, 64).
+ *   mode        UFR_CONV3D_S1, or UFR_CONV3D_S2 (conv1 / conv3 / conv5, and -- on the transposed layers' forward weights as
+ *               they stand -- the data gradients of conv11 / conv9 / conv7); no transposed mode here
+ *   workspace   ufr_conv3d_planes_workspace_bytes(cin, cout, cout2, mode) bytes (the weights' planes); 0 = combination not
+ *               supported here (use ufr_conv3d).  S1: cin in {8, 16} with cout + cout2 <= 16, (32, 32), (64, 64); S2: (8, 16),
+ *               (16, 32), (32, 64).
  *   planes_ready  0: the planes are made from `weight` (/ `weight2`) by this call (three small launches).  1: `workspace` still
  *               holds the planes a call with planes_ready = 0 made from the SAME weights, flip and channel counts (frozen
  *               weights: once per checkpoint, not once per frame); the caller vouches for that.
  * bias / bn_scale / bn_shift / relu / skip / out_ncdhw / weight2 / out2 as for ufr_conv3d.                              */
-size_t ufr_conv3d_planes_workspace_bytes(int32_t cin, int32_t cout, int32_t cout2);
+size_t ufr_conv3d_planes_workspace_bytes(int32_t cin, int32_t cout, int32_t cout2, int32_t mode);
 int ufr_conv3d_planes(const float* in, const float* in_absmax, const float* weight, const float* weight2, const float* bias,
                       const float* bn_scale, const float* bn_shift, const float* skip, float* out, float* out2,
                       float* out_absmax, int32_t B, int32_t D, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t cout2,
-                      int32_t relu, int32_t out_ncdhw, int32_t flip, void* workspace, size_t workspace_bytes, int32_t planes_ready,
+                      int32_t mode, int32_t relu, int32_t out_ncdhw, int32_t flip, void* workspace, size_t workspace_bytes, int32_t planes_ready,
                       ufr_stream stream);
 /* *absmax = max(*absmax, max |x[0..n)|) (device float; zero it first).  One pass at HBM speed.                          */
 int ufr_absmax(const float* x, size_t n, float* absmax, ufr_stream stream);

@@ -51,6 +51,33 @@ def test_planes_layer_matches_fp32_kernel_and_float64(cin, cout, shape, flip):
     assert float(ymax) == float(y.abs().max())                    # the bound handed to the next layer is the true maximum
 
 
+@pytest.mark.parametrize("cin,cout,shape", [(8, 16, (2, 4, 12, 70)), (16, 32, (1, 3, 9, 37)), (32, 64, (2, 2, 10, 22)), (8, 16, (1, 8, 32, 128)),
+                                            (16, 32, (3, 4, 16, 64)), (32, 64, (3, 2, 8, 32))])
+def test_planes_stride2_layer_matches_fp32_kernel_and_float64(cin, cout, shape):
+    """conv1 / conv3 / conv5 (and the data gradients of conv11 / conv9 / conv7, which ARE these convolutions)."""
+    from uforecon_amd import ops
+
+    torch.manual_seed(cin + cout)
+    B, D, H, W = shape
+    x = torch.randn(B, D, H, W, cin, device=DEV) * 2.0
+    w = torch.randn(cout, cin, 3, 3, 3, device=DEV) * 0.15
+    bias = torch.randn(cout, device=DEV)
+    ref = torch.nn.functional.conv3d(x.double().permute(0, 4, 1, 2, 3), w.double(), bias.double(), stride=2, padding=1).permute(0, 2, 3, 4, 1)
+    skip = torch.randn(ref.shape, device=DEV)
+    y, ymax = ops.conv3d_planes(x, ops.absmax(x), w, bias=bias, skip=skip, mode=ops.CONV3D_S2)
+    y32 = ops.conv3d(x, w, ops.CONV3D_S2, bias=bias, skip=skip)
+    assert y.shape == y32.shape == ref.shape
+    ref = ref + skip.double()
+    e16, e32 = _err(y, ref), _err(y32, ref)
+    print(f"stride 2, cin {cin} cout {cout} {shape}: planes {e16:.2e}  fp32 kernel {e32:.2e} of the output scale")
+    assert e16 < max(4 * e32, 1e-6) and float(ymax) == float(y.abs().max())
+    if shape[1] % 2 == 0 and shape[2] % 2 == 0 and shape[3] % 2 == 0:
+        # as the data gradient of the transposed layer with forward weight (cin_fwd = cout here, cout_fwd = cin here)
+        d = ops.conv3d_bwd_data(x, w, ops.CONV3D_T2, (B, D // 2, H // 2, W // 2, cout))
+        y0, _ = ops.conv3d_planes(x, ops.absmax(x), w, mode=ops.CONV3D_S2)
+        assert float((d - y0).abs().max()) < 2e-5 * float(d.abs().max())
+
+
 def test_planes_heads_write_the_reference_layout():
     """features (8) + sigmoid(weights (1)) in one pass, (B,C,D,H,W) outputs (module.py:541-543)."""
     from uforecon_amd import ops

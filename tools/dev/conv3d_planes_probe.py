@@ -24,6 +24,14 @@ def t(fn, reps=5):
 def main():
     dev = "cuda:0"
     for stage, (D, H, W) in (("stage1", (48, 128, 160)), ("stage2", (32, 256, 320)), ("stage3", (8, 512, 640))):
+        for name, cin, cout, down in (("conv1", 8, 16, 1), ("conv3", 16, 32, 2), ("conv5", 32, 64, 4)):
+            d, h, w = D // down, H // down, W // down
+            x = torch.randn(3, d, h, w, cin, device=dev)
+            wt = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.1
+            am = ops.absmax(x)
+            t32 = t(lambda: ops.conv3d(x, wt, ops.CONV3D_S2))
+            t16 = t(lambda: ops.conv3d_planes(x, am, wt, mode=ops.CONV3D_S2))
+            print(f"{stage} {name:9s} {cin:3d}->{cout} s2 @ {d}x{h}x{w}: fp32 {t32:7.3f}  planes {t16:7.3f} ms")
         for name, cin, cout, cout2, down in (("heads", 8, 8, 1, 1), ("features", 8, 8, 0, 1), ("conv2", 16, 16, 0, 2), ("conv4", 32, 32, 0, 4),
                                             ("conv6", 64, 64, 0, 8)):
             d, h, w = D // down, H // down, W // down

@@ -121,8 +121,8 @@ SIGNATURES = {
     "ufr_correlate_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "ufr_frustum_correlate": (C.c_int, [vp, vp, C.POINTER(C.c_float), vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
     "ufr_conv3d": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
-    "ufr_conv3d_planes_workspace_bytes": (sz, [i32, i32, i32]),
-    "ufr_conv3d_planes": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp,
+    "ufr_conv3d_planes_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "ufr_conv3d_planes": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp,
                                     sz, i32, vp]),
     "ufr_absmax": (C.c_int, [vp, sz, vp, vp]),
     "ufr_conv3d_bwd_data": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),

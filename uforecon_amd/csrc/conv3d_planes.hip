@@ -117,7 +117,8 @@ struct PlanesArgs {
   float* out;                 // channel-last [B][D][H][W][cout], or (B,cout,D,H,W) when ncdhw
   float* out2;                // heads: (B,cout2,D,H,W), sigmoid applied
   unsigned* out_absmax;       // raised to max |out| (nullable)
-  int B, D, H, W;
+  int B, D, H, W;         // input extent
+  int Do, Ho, Wo;         // output extent (stride 2: ceil(n / 2))
   int cout, cout2, relu, ncdhw;
   int nbx, nby, nbz;
 };
@@ -130,10 +131,11 @@ __device__ __forceinline__ void split2(float a, float b, float m, unsigned& h, u
   asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(b), "s"(m), "v"(h));
 }
 
-template <int CIN>
-struct Brick {   // output brick of a workgroup and its input halo
-  static constexpr int TX = CIN == 8 ? 64 : CIN == 16 ? 32 : 16, TY = 4, TZ = (CIN == 8 || CIN == 32) ? 2 : 1;
-  static constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2;
+template <int CIN, int S = 1>
+struct Brick {   // output brick of a workgroup and its input halo (stride S: input extent S (T - 1) + 3 per axis)
+  static constexpr int TX = S == 2 ? (CIN == 8 ? 32 : 16) : (CIN == 8 ? 64 : CIN == 16 ? 32 : 16), TY = 4,
+                       TZ = (S == 1 && (CIN == 8 || CIN == 32)) ? 2 : 1;
+  static constexpr int HX = S * (TX - 1) + 3, HY = S * (TY - 1) + 3, HZ = S * (TZ - 1) + 3;
   static constexpr int halo = HX * HY * HZ;
   static constexpr int tiles = TX / 16 * TY * TZ;          // 16-voxel column tiles
   static constexpr int per_wave = tiles / 4;
@@ -150,9 +152,9 @@ struct Brick {   // output brick of a workgroup and its input halo
 // layer: 0.345 ms = 0.14 fixed + 0.09 MFMA + 0.09 stores + 0.03 loads, a sum, not a maximum).
 // NT output row tiles in passes of NTG (the 64 -> 64 layer: two passes of two tiles -- four tiles' weight fragments three
 // k-steps deep are 96 registers, and the kernel spilled 800; the halo is staged once, its operands are read per pass)
-template <int CIN, int NT, int NTG = NT>
+template <int CIN, int NT, int NTG = NT, int S = 1>
 __global__ void __launch_bounds__(256, 2) conv3d_planes_kernel(PlanesArgs a) {
-  typedef Brick<CIN> Bk;
+  typedef Brick<CIN, S> Bk;
   constexpr int KS = planes_ksteps(CIN);
   constexpr int VT = Bk::per_wave;
   // the weights' planes: copied into LDS once per workgroup when they fit beside the halo (<= 32 KiB: the 8- / 16-channel
@@ -206,7 +208,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_planes_kernel(PlanesArgs a) {
     for (int r = 0; r < HR; ++r) {
       const int hv = tid + 256 * r;
       const int hx = hv % Bk::HX, hy = (hv / Bk::HX) % Bk::HY, hz = hv / (Bk::HX * Bk::HY);
-      const int ix = x0 + hx - 1, iy = y0 + hy - 1, iz = z0 + hz - 1;
+      const int ix = S * x0 + hx - 1, iy = S * y0 + hy - 1, iz = S * z0 + hz - 1;
       const bool ok = UFR_C3P_ABL != 2 && hv < Bk::halo && ix >= 0 && ix < a.W && iy >= 0 && iy < a.H && iz >= 0 && iz < a.D;
       const unsigned off = (unsigned)(((iz * a.H + iy) * a.W + ix) * (CIN * 4));
 #pragma unroll
@@ -247,7 +249,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_planes_kernel(PlanesArgs a) {
     for (int r = 0; r < HR; ++r) {
       const int hv = tid + 256 * r;
       const int hx = hv % Bk::HX, hy = (hv / Bk::HX) % Bk::HY, hz = hv / (Bk::HX * Bk::HY);
-      const int ix = x0 + hx - 1, iy = y0 + hy - 1, iz = z0 + hz - 1;
+      const int ix = S * x0 + hx - 1, iy = S * y0 + hy - 1, iz = S * z0 + hz - 1;
       const bool ok = hv < Bk::halo && ix >= 0 && ix < a.W && iy >= 0 && iy < a.H && iz >= 0 && iz < a.D;
       const unsigned off = (unsigned)(((iz * a.H + iy) * a.W + ix) * (CIN * 4));
       f32x4 t[C8][2];
@@ -296,7 +298,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_planes_kernel(PlanesArgs a) {
   for (int v = 0; v < VT; ++v) {
     const int q = wave + 4 * v;
     const int tx16 = q % (Bk::TX / 16), ty = (q / (Bk::TX / 16)) % Bk::TY, tz = q / (Bk::TX / 16 * Bk::TY);
-    vbase[v] = (tz * Bk::HY + ty) * Bk::HX + tx16 * 16 + j;
+    vbase[v] = (S * tz * Bk::HY + S * ty) * Bk::HX + S * (tx16 * 16 + j);
   }
   // halo offset of this lane group's tap at a k-step (padding k: zero weights, any finite operand) and the 8-channel chunk of
   // the halo planes it reads there: per-lane tables for CIN <= 16 (the tap depends on the lane group), compile-time
@@ -322,7 +324,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_planes_kernel(PlanesArgs a) {
   };
   float omax = 0.f;
   const int ct = a.cout + a.cout2;
-  const size_t plane = (size_t)a.D * a.H * a.W;
+  const size_t plane = (size_t)a.Do * a.Ho * a.Wo;
 
   for (int k = k_begin; k < k_end; ++k) {
     if (kPrefetch && k + 1 < k_end) halo_load(k + 1);       // in flight under this brick's MFMAs
@@ -375,9 +377,9 @@ __global__ void __launch_bounds__(256, 2) conv3d_planes_kernel(PlanesArgs a) {
       const int q = wave + 4 * v;
       const int tx16 = q % (Bk::TX / 16), ty = (q / (Bk::TX / 16)) % Bk::TY, tz = q / (Bk::TX / 16 * Bk::TY);
       const int ox = x0 + tx16 * 16 + j, oy = y0 + ty, oz = z0 + tz;
-      if (ox >= a.W || oy >= a.H || oz >= a.D) continue;
+      if (ox >= a.Wo || oy >= a.Ho || oz >= a.Do) continue;
       if (UFR_C3P_ABL == 3 && acc[v][0][0] != 12345.f) continue;
-      const size_t sp = ((size_t)oz * a.H + oy) * a.W + ox;
+      const size_t sp = ((size_t)oz * a.Ho + oy) * a.Wo + ox;
 #pragma unroll
       for (int t = 0; t < NTG; ++t) {
         const int c0 = 16 * (pass * NTG + t) + 4 * g;
@@ -440,31 +442,33 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x
   if ((threadIdx.x & 63) == 0 && bits > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, bits);
 }
 
-template <int CIN, int NT, int NTG = NT>
+template <int CIN, int NT, int NTG = NT, int S = 1>
 hipError_t launch_planes_t(const PlanesArgs& a, hipStream_t s) {
-  typedef Brick<CIN> Bk;
+  typedef Brick<CIN, S> Bk;
   constexpr int w_all = planes_ksteps(CIN) * NT * 2048;
   constexpr int lds = (w_all <= 32768 ? w_all : 0) + 2 * Bk::plane_bytes;
   static LdsAttrOnce lds_attr;
-  if (const hipError_t e = lds_attr.set(reinterpret_cast<const void*>(&conv3d_planes_kernel<CIN, NT, NTG>), lds); e != hipSuccess) return e;
+  if (const hipError_t e = lds_attr.set(reinterpret_cast<const void*>(&conv3d_planes_kernel<CIN, NT, NTG, S>), lds); e != hipSuccess) return e;
   PlanesArgs b = a;
-  b.nbx = (a.W + Bk::TX - 1) / Bk::TX; b.nby = (a.H + Bk::TY - 1) / Bk::TY; b.nbz = (a.D + Bk::TZ - 1) / Bk::TZ;
+  b.nbx = (a.Wo + Bk::TX - 1) / Bk::TX; b.nby = (a.Ho + Bk::TY - 1) / Bk::TY; b.nbz = (a.Do + Bk::TZ - 1) / Bk::TZ;
   const long long bricks = (long long)b.nbx * b.nby * b.nbz * a.B;
   if (bricks <= 0 || bricks > 0x7fffffffLL) return hipErrorInvalidValue;
   // the resident workgroups (LDS: two per CU, one for the 64-channel halo), a multiple of the 8 XCDs; fewer when there are
   // fewer bricks than that
   long long blocks = (lds > 80 * 1024 ? 1 : 2) * 256;
   if (bricks < blocks) blocks = ((bricks + 7) / 8) * 8;
-  hipLaunchKernelGGL((conv3d_planes_kernel<CIN, NT, NTG>), dim3((unsigned)blocks), dim3(256), lds, s, b);
+  hipLaunchKernelGGL((conv3d_planes_kernel<CIN, NT, NTG, S>), dim3((unsigned)blocks), dim3(256), lds, s, b);
   return hipGetLastError();
 }
 
 }  // namespace
 
 // which (cin, cout + cout2) the plane kernels take (stride 1 only); 0 = not supported
-size_t conv3d_planes_workspace_bytes(int cin, int cout, int cout2) {
-  if (!(((cin == 8 || cin == 16) && cout + cout2 <= 16) || (cin == 32 && cout == 32 && cout2 == 0) || (cin == 64 && cout == 64 && cout2 == 0)))
-    return 0;
+size_t conv3d_planes_workspace_bytes(int cin, int cout, int cout2, int mode) {
+  const bool s1 = mode == 0 && (((cin == 8 || cin == 16) && cout + cout2 <= 16) || (cin == 32 && cout == 32 && cout2 == 0) ||
+                                (cin == 64 && cout == 64 && cout2 == 0));
+  const bool s2 = mode == 1 && cout2 == 0 && ((cin == 8 && cout == 16) || (cin == 16 && cout == 32) || (cin == 32 && cout == 64));
+  if (!s1 && !s2) return 0;
   if (cout < 1 || cout2 < 0) return 0;
   return kPlanesHeader + (size_t)planes_ksteps(cin) * planes_tiles(cout + cout2) * 2048;
 }
@@ -480,9 +484,9 @@ hipError_t launch_absmax(const float* x, size_t n, float* absmax, hipStream_t s)
 
 hipError_t launch_conv3d_planes(const float* in, const float* in_absmax, const float* weight, const float* weight2, const float* bias,
                                 const float* scale, const float* shift, const float* skip, float* out, float* out2, float* out_absmax,
-                                int B, int D, int H, int W, int cin, int cout, int cout2, int relu, int ncdhw, int flip, void* ws,
-                                int planes_ready, hipStream_t s) {
-  if (!conv3d_planes_workspace_bytes(cin, cout, cout2)) return hipErrorInvalidValue;
+                                int B, int D, int H, int W, int cin, int cout, int cout2, int mode, int relu, int ncdhw, int flip,
+                                void* ws, int planes_ready, hipStream_t s) {
+  if (!conv3d_planes_workspace_bytes(cin, cout, cout2, mode) || (mode == 1 && flip)) return hipErrorInvalidValue;
   // one view's tensor is a raw buffer descriptor (31-bit byte offsets, kBufOut = zero fill)
   if ((long long)D * H * W * cin * 4 >= (1ll << 31)) return hipErrorInvalidValue;
   if (!planes_ready) {
@@ -505,7 +509,13 @@ hipError_t launch_conv3d_planes(const float* in, const float* in_absmax, const f
   a.in = in; a.in_absmax = reinterpret_cast<const unsigned*>(in_absmax); a.ws = static_cast<const char*>(ws); a.bias = bias;
   a.scale = scale; a.shift = shift; a.skip = skip; a.out = out; a.out2 = out2; a.out_absmax = reinterpret_cast<unsigned*>(out_absmax);
   a.B = B; a.D = D; a.H = H; a.W = W; a.cout = cout; a.cout2 = cout2; a.relu = relu; a.ncdhw = ncdhw;
+  a.Do = mode == 1 ? (D + 1) / 2 : D; a.Ho = mode == 1 ? (H + 1) / 2 : H; a.Wo = mode == 1 ? (W + 1) / 2 : W;   // k3 p1 s2: floor((n - 1) / 2) + 1
   a.nbx = a.nby = a.nbz = 0;
+  if (mode == 1) {
+    if (cin == 8) return launch_planes_t<8, 1, 1, 2>(a, s);
+    if (cin == 16) return launch_planes_t<16, 2, 1, 2>(a, s);
+    return launch_planes_t<32, 4, 2, 2>(a, s);
+  }
   if (cin == 8) return launch_planes_t<8, 1>(a, s);
   if (cin == 16) return launch_planes_t<16, 1>(a, s);
   if (cin == 32) return launch_planes_t<32, 2, 1>(a, s);

@@ -1157,12 +1157,14 @@ int ufr_conv3d(const float* in, const float* weight, const float* weight2, const
 }
 
 // the stride-1 8 / 16-channel layers on the 16-bit matrix cores (conv3d_planes.hip)
-size_t ufr_conv3d_planes_workspace_bytes(int32_t cin, int32_t cout, int32_t cout2) { return conv3d_planes_workspace_bytes(cin, cout, cout2); }
+size_t ufr_conv3d_planes_workspace_bytes(int32_t cin, int32_t cout, int32_t cout2, int32_t mode) {
+  return conv3d_planes_workspace_bytes(cin, cout, cout2, mode);
+}
 
 int ufr_conv3d_planes(const float* in, const float* in_absmax, const float* weight, const float* weight2, const float* bias,
                       const float* bn_scale, const float* bn_shift, const float* skip, float* out, float* out2,
                       float* out_absmax, int32_t B, int32_t D, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t cout2,
-                      int32_t relu, int32_t out_ncdhw, int32_t flip, void* workspace, size_t workspace_bytes, int32_t planes_ready,
+                      int32_t mode, int32_t relu, int32_t out_ncdhw, int32_t flip, void* workspace, size_t workspace_bytes, int32_t planes_ready,
                       ufr_stream stream) {
   UFR_REQUIRE(in && in_absmax && weight && out && workspace, "ufr_conv3d_planes: null argument");
   UFR_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "ufr_conv3d_planes: B=%d D=%d H=%d W=%d", B, D, H, W);
@@ -1170,14 +1172,15 @@ int ufr_conv3d_planes(const float* in, const float* in_absmax, const float* weig
   UFR_REQUIRE(cout2 == 0 || (weight2 && out2 && out_ncdhw && !flip), "ufr_conv3d_planes: a second head needs weight2, out2, out_ncdhw");
   UFR_REQUIRE(out_ncdhw || (cout % 4 == 0 && cout2 == 0), "ufr_conv3d_planes: channel-last outputs need cout %% 4 == 0 (got %d)", cout);
   UFR_REQUIRE(!(out_ncdhw && (skip || out_absmax)), "ufr_conv3d_planes: skip / out_absmax go with channel-last outputs");
-  const size_t need = conv3d_planes_workspace_bytes(cin, cout, cout2);
-  if (!need) return fail(UFR_ERR_ARG, "ufr_conv3d_planes: (cin %d, cout %d+%d) is not a layer of this kernel family", cin, cout, cout2);
+  UFR_REQUIRE(!(mode == UFR_CONV3D_S2 && flip), "ufr_conv3d_planes: flip is the stride-1 data gradient");
+  const size_t need = conv3d_planes_workspace_bytes(cin, cout, cout2, mode);
+  if (!need) return fail(UFR_ERR_ARG, "ufr_conv3d_planes: (cin %d, cout %d+%d, mode %d) is not a layer of this kernel family", cin, cout, cout2, mode);
   if (workspace_bytes < need) return fail(UFR_ERR_WORKSPACE, "ufr_conv3d_planes: workspace %zu < %zu", workspace_bytes, need);
   UFR_REQUIRE((long long)D * H * W * cin * 4 < (1ll << 31), "ufr_conv3d_planes: one batch element reaches 2 GiB");
   hipStream_t s = static_cast<hipStream_t>(stream);
   ProfScope p(flip ? "conv3d_dgrad" : "conv3d", s);
   UFR_HIP(launch_conv3d_planes(in, in_absmax, weight, weight2, bias, bn_scale, bn_shift, skip, out, out2, out_absmax, B, D, H, W, cin,
-                               cout, cout2, relu, out_ncdhw, flip, workspace, planes_ready != 0, s));
+                               cout, cout2, mode, relu, out_ncdhw, flip, workspace, planes_ready != 0, s));
   return UFR_OK;
 }
 

@@ -773,6 +773,7 @@ def _planes_lookup(weight, weight2, flip, nbytes):
 
     ent = _PLANES.get(id(weight))
     sig = (weight._version, None if weight2 is None else (id(weight2), weight2._version), bool(flip), nbytes, weight.device)
+    # (the planes' layout depends on the channel counts and the mirroring only, not on the stride)
     if ent is not None and ent[0]() is weight and ent[1] == sig and (weight2 is None or ent[2]() is weight2):
         return ent[3], True
     if len(_PLANES) > 512:          # tensors that died without being looked up again
@@ -783,14 +784,14 @@ def _planes_lookup(weight, weight2, flip, nbytes):
     return ws, False
 
 
-def conv3d_planes_supported(cin: int, cout: int, cout2: int = 0) -> bool:
-    return _lib.load().ufr_conv3d_planes_workspace_bytes(cin, cout, cout2) > 0
+def conv3d_planes_supported(cin: int, cout: int, cout2: int = 0, mode: int = 0) -> bool:
+    return _lib.load().ufr_conv3d_planes_workspace_bytes(cin, cout, cout2, int(mode)) > 0
 
 
 def conv3d_planes(x_cl: torch.Tensor, x_absmax: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
                   bn_scale: Optional[torch.Tensor] = None, bn_shift: Optional[torch.Tensor] = None, relu: bool = False,
                   skip: Optional[torch.Tensor] = None, out_ncdhw: bool = False, weight2: Optional[torch.Tensor] = None,
-                  flip: bool = False, want_absmax: bool = True):
+                  flip: bool = False, want_absmax: bool = True, mode: int = 0):
     """A stride-1 3x3x3 layer with 8 or 16 input channels on the 16-bit matrix cores (ufr_conv3d_planes: fp16 plane
     products, fp32 accumulate, the input brick staged through LDS).  ``x_absmax``: one-element device tensor >= max |x_cl|
     (`absmax`, or the previous layer's returned bound).  ``flip``: the data gradient of a stride-1 layer -- ``weight`` is
@@ -807,12 +808,14 @@ def conv3d_planes(x_cl: torch.Tensor, x_absmax: torch.Tensor, weight: torch.Tens
         cout = weight.shape[0]
     cout2 = 0 if weight2 is None else weight2.shape[0]
     lib = _lib.load()
-    nbytes = lib.ufr_conv3d_planes_workspace_bytes(cin, cout, cout2)
+    mode = int(mode)
+    nbytes = lib.ufr_conv3d_planes_workspace_bytes(cin, cout, cout2, mode)
     if not nbytes:
-        raise UfrError(f"conv3d_planes: (cin {cin}, cout {cout}+{cout2}) is not a layer of this kernel family")
+        raise UfrError(f"conv3d_planes: (cin {cin}, cout {cout}+{cout2}, mode {mode}) is not a layer of this kernel family")
     dev = x_cl.device
-    out = torch.empty((B, cout, D, H, W) if out_ncdhw else (B, D, H, W, cout), dtype=torch.float32, device=dev)
-    out2 = torch.empty((B, cout2, D, H, W), dtype=torch.float32, device=dev) if cout2 else None
+    Do, Ho, Wo = ((D + 1) // 2, (H + 1) // 2, (W + 1) // 2) if mode == CONV3D_S2 else (D, H, W)
+    out = torch.empty((B, cout, Do, Ho, Wo) if out_ncdhw else (B, Do, Ho, Wo, cout), dtype=torch.float32, device=dev)
+    out2 = torch.empty((B, cout2, Do, Ho, Wo), dtype=torch.float32, device=dev) if cout2 else None
     if skip is not None and tuple(skip.shape) != tuple(out.shape):
         raise UfrError(f"conv3d_planes: skip {tuple(skip.shape)} does not match the output {tuple(out.shape)}")
     ws, ready = _planes_lookup(weight, weight2, flip, nbytes)
@@ -824,7 +827,7 @@ def conv3d_planes(x_cl: torch.Tensor, x_absmax: torch.Tensor, weight: torch.Tens
         ptr(bn_shift, "bn_shift")
     _lib.check(lib.ufr_conv3d_planes(_dev(x_cl, "x"), _dev(x_absmax, "x_absmax"), w_p, w2_p, b_p, s_p, h_p, _opt(skip, "skip"),
                                      out.data_ptr(), _opt(out2, "out2"), _opt(omax, "out_absmax"), B, D, H, W, cin, cout, cout2,
-                                     int(bool(relu)), int(bool(out_ncdhw)), int(bool(flip)), ws.data_ptr(), nbytes, int(ready),
+                                     mode, int(bool(relu)), int(bool(out_ncdhw)), int(bool(flip)), ws.data_ptr(), nbytes, int(ready),
                                      _stream()),
                "ufr_conv3d_planes")
     return (out, out2, None) if cout2 else (out, omax)

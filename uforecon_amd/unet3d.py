@@ -46,19 +46,43 @@ def _input_cl(x: torch.Tensor) -> torch.Tensor:
 
 def _s1(t, weight, planes: bool, **kw):
     """One stride-1 layer: on the 16-bit matrix cores (ufr_conv3d_planes: fp16 plane products, fp32 accumulate, the input
-    brick staged through LDS -- the full- and half-resolution layers run 2 .. 2.4 x faster there, csrc/conv3d_planes.hip)
-    when `planes` and the kernel family has the layer, else the fp32 kernel.  The planes' scale comes from the input's
-    measured |max| (one pass at HBM speed).  Returns what ops.conv3d returns."""
+    brick staged through LDS -- 2 .. 5 x the fp32 kernels, csrc/conv3d_planes.hip) when `planes` and the kernel family has
+    the layer, else the fp32 kernel.  The planes' scale comes from the input's measured |max| (one pass at HBM speed).
+    Returns what ops.conv3d returns."""
     cin = t.shape[-1]
     flip = kw.pop("flip", False)
     w2 = kw.get("weight2")
     cout = weight.shape[1] if flip else weight.shape[0]
-    if planes and ops.conv3d_planes_supported(cin, cout, 0 if w2 is None else w2.shape[0]):
+    if planes and ops.conv3d_planes_supported(cin, cout, 0 if w2 is None else w2.shape[0], S1):
         r = ops.conv3d_planes(t, ops.absmax(t), weight, flip=flip, want_absmax=False, **kw)
         return (r[0], r[1]) if w2 is not None else r[0]
     if flip:
         return ops.conv3d_bwd_data(t, weight, S1, (*t.shape[:4], cout), accumulate=kw.get("skip"))
     return ops.conv3d(t, weight, S1, **kw)
+
+
+def _s2(t, weight, planes: bool, **kw):
+    """One stride-2 layer (conv1 / conv3 / conv5), the same way.  ``weight`` (cout, cin, 3,3,3)."""
+    if planes and ops.conv3d_planes_supported(t.shape[-1], weight.shape[0], 0, S2):
+        return ops.conv3d_planes(t, ops.absmax(t), weight, want_absmax=False, mode=S2, **kw)[0]
+    return ops.conv3d(t, weight, S2, **kw)
+
+
+def _layer(t, weight, mode, planes: bool, **kw):
+    if mode == S1:
+        return _s1(t, weight, planes, **kw)
+    if mode == S2:
+        return _s2(t, weight, planes, **kw)
+    return ops.conv3d(t, weight, mode, **kw)
+
+
+def _t2_bwd_data(d_out, weight, in_shape, accumulate=None):
+    """Data gradient of a transposed stride-2 layer = the stride-2 convolution of d_out with the layer's forward weight
+    (cin, cout, 3,3,3) read as a convolution weight (rows = cin): on the plane kernels where they have the shape."""
+    cin, cout = weight.shape[0], weight.shape[1]
+    if ops.conv3d_planes_supported(cout, cin, 0, S2):
+        return ops.conv3d_planes(d_out, ops.absmax(d_out), weight, skip=accumulate, want_absmax=False, mode=S2)[0]
+    return ops.conv3d_bwd_data(d_out, weight, T2, in_shape, accumulate=accumulate)
 
 
 def _unet(x_cl, layer):
@@ -83,9 +107,7 @@ def cost_reg_net(m, x: torch.Tensor, planes: bool = True) -> torch.Tensor:
     def layer(name, t, mode, skip):
         blk = getattr(m, name)
         scale, shift = _bn_fold(blk.bn)
-        if mode == S1:
-            return _s1(t, blk.conv.weight, planes, bn_scale=scale, bn_shift=shift, relu=True, skip=skip)
-        return ops.conv3d(t, blk.conv.weight, mode, bn_scale=scale, bn_shift=shift, relu=True, skip=skip)
+        return _layer(t, blk.conv.weight, mode, planes, bn_scale=scale, bn_shift=shift, relu=True, skip=skip)
 
     x = _unet(_input_cl(x), layer)
     return _s1(x, m.prob.weight, planes, out_ncdhw=True)
@@ -120,9 +142,7 @@ class CostRegNetWeightFn(torch.autograd.Function):
 
         def layer(name, t, mode, skip):
             acts["in." + name] = t
-            if mode == S1:
-                return _s1(t, P[name + ".weight"], True, bias=P[name + ".bias"], skip=skip)
-            return ops.conv3d(t, P[name + ".weight"], mode, bias=P[name + ".bias"], skip=skip)
+            return _layer(t, P[name + ".weight"], mode, True, bias=P[name + ".bias"], skip=skip)
 
         y = _unet(x_cl, layer)
         feat, wsig = _s1(y, P["features.weight"], True, out_ncdhw=True, weight2=P["weights.weight"])
@@ -156,6 +176,8 @@ class CostRegNetWeightFn(torch.autograd.Function):
                 return None
             if mode == S1 and t.shape[-1] > 1:
                 return _s1(d_out, P[name + ".weight"], True, flip=True, skip=accumulate)
+            if mode == T2:
+                return _t2_bwd_data(d_out, P[name + ".weight"], tuple(t.shape), accumulate)
             return ops.conv3d_bwd_data(d_out, P[name + ".weight"], mode, tuple(t.shape), accumulate=accumulate)
 
         # y = c0 + conv11(x9), x9 = c2 + conv9(x7), x7 = c4 + conv7(x6), x6 = conv6(conv5(c4)), c4 = conv4(conv3(c2)), ...
@@ -191,9 +213,7 @@ def cost_reg_net_weight(m, x: torch.Tensor):
 def _cost_reg_net_weight_hip(m, x: torch.Tensor, planes: bool = True):
     def layer(name, t, mode, skip):
         conv = getattr(m, name)
-        if mode == S1:
-            return _s1(t, conv.weight, planes, bias=conv.bias, skip=skip)
-        return ops.conv3d(t, conv.weight, mode, bias=conv.bias, skip=skip)
+        return _layer(t, conv.weight, mode, planes, bias=conv.bias, skip=skip)
 
     x = _unet(_input_cl(x), layer)
     return _s1(x, m.features.weight, planes, out_ncdhw=True, weight2=m.weights.weight)

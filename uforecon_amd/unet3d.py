@@ -44,44 +44,73 @@ def _input_cl(x: torch.Tensor) -> torch.Tensor:
     return x.detach().float().contiguous().view(B, D, H, W, 1)
 
 
-def _s1(t, weight, planes: bool, **kw):
+class _Bounds:
+    """max |t| of the activations that feed a plane kernel, as one-element device tensors: a plane layer hands its output's
+    bound on (ufr_conv3d_planes raises it in its store), so only tensors that come from an fp32 kernel cost a pass
+    (ufr_absmax: 251 MB at full resolution = 0.07 ms; six of them per U-Net before the bounds were chained)."""
+
+    def __init__(self):
+        self._b = {}
+
+    def of(self, t):
+        hit = self._b.get(id(t))
+        if hit is not None and hit[0] is t:
+            return hit[1]
+        return ops.absmax(t)
+
+    def put(self, t, bound):
+        if bound is not None:
+            self._b[id(t)] = (t, bound)
+
+
+def _s1(t, weight, planes: bool, bounds: "_Bounds" = None, **kw):
     """One stride-1 layer: on the 16-bit matrix cores (ufr_conv3d_planes: fp16 plane products, fp32 accumulate, the input
     brick staged through LDS -- 2 .. 5 x the fp32 kernels, csrc/conv3d_planes.hip) when `planes` and the kernel family has
-    the layer, else the fp32 kernel.  The planes' scale comes from the input's measured |max| (one pass at HBM speed).
-    Returns what ops.conv3d returns."""
+    the layer, else the fp32 kernel.  The planes' scale comes from the input's |max| (`_Bounds`).  Returns what ops.conv3d
+    returns."""
     cin = t.shape[-1]
     flip = kw.pop("flip", False)
     w2 = kw.get("weight2")
     cout = weight.shape[1] if flip else weight.shape[0]
     if planes and ops.conv3d_planes_supported(cin, cout, 0 if w2 is None else w2.shape[0], S1):
-        r = ops.conv3d_planes(t, ops.absmax(t), weight, flip=flip, want_absmax=False, **kw)
-        return (r[0], r[1]) if w2 is not None else r[0]
+        b = bounds if bounds is not None else _Bounds()
+        r = ops.conv3d_planes(t, b.of(t), weight, flip=flip, want_absmax=bounds is not None, **kw)
+        if w2 is not None:
+            return r[0], r[1]
+        b.put(r[0], r[1])
+        return r[0]
     if flip:
         return ops.conv3d_bwd_data(t, weight, S1, (*t.shape[:4], cout), accumulate=kw.get("skip"))
     return ops.conv3d(t, weight, S1, **kw)
 
 
-def _s2(t, weight, planes: bool, **kw):
+def _s2(t, weight, planes: bool, bounds: "_Bounds" = None, **kw):
     """One stride-2 layer (conv1 / conv3 / conv5), the same way.  ``weight`` (cout, cin, 3,3,3)."""
     if planes and ops.conv3d_planes_supported(t.shape[-1], weight.shape[0], 0, S2):
-        return ops.conv3d_planes(t, ops.absmax(t), weight, want_absmax=False, mode=S2, **kw)[0]
+        b = bounds if bounds is not None else _Bounds()
+        out, omax = ops.conv3d_planes(t, b.of(t), weight, want_absmax=bounds is not None, mode=S2, **kw)
+        b.put(out, omax)
+        return out
     return ops.conv3d(t, weight, S2, **kw)
 
 
-def _layer(t, weight, mode, planes: bool, **kw):
+def _layer(t, weight, mode, planes: bool, bounds: "_Bounds" = None, **kw):
     if mode == S1:
-        return _s1(t, weight, planes, **kw)
+        return _s1(t, weight, planes, bounds, **kw)
     if mode == S2:
-        return _s2(t, weight, planes, **kw)
+        return _s2(t, weight, planes, bounds, **kw)
     return ops.conv3d(t, weight, mode, **kw)
 
 
-def _t2_bwd_data(d_out, weight, in_shape, accumulate=None):
+def _t2_bwd_data(d_out, weight, in_shape, accumulate=None, bounds: "_Bounds" = None):
     """Data gradient of a transposed stride-2 layer = the stride-2 convolution of d_out with the layer's forward weight
     (cin, cout, 3,3,3) read as a convolution weight (rows = cin): on the plane kernels where they have the shape."""
     cin, cout = weight.shape[0], weight.shape[1]
     if ops.conv3d_planes_supported(cout, cin, 0, S2):
-        return ops.conv3d_planes(d_out, ops.absmax(d_out), weight, skip=accumulate, want_absmax=False, mode=S2)[0]
+        b = bounds if bounds is not None else _Bounds()
+        out, omax = ops.conv3d_planes(d_out, b.of(d_out), weight, skip=accumulate, want_absmax=bounds is not None, mode=S2)
+        b.put(out, omax)
+        return out
     return ops.conv3d_bwd_data(d_out, weight, T2, in_shape, accumulate=accumulate)
 
 
@@ -104,13 +133,15 @@ def cost_reg_net(m, x: torch.Tensor, planes: bool = True) -> torch.Tensor:
     if m.training:
         raise UfrError("CostRegNet: inference only (BatchNorm in eval mode)")
 
+    bounds = _Bounds()
+
     def layer(name, t, mode, skip):
         blk = getattr(m, name)
         scale, shift = _bn_fold(blk.bn)
-        return _layer(t, blk.conv.weight, mode, planes, bn_scale=scale, bn_shift=shift, relu=True, skip=skip)
+        return _layer(t, blk.conv.weight, mode, planes, bounds, bn_scale=scale, bn_shift=shift, relu=True, skip=skip)
 
     x = _unet(_input_cl(x), layer)
-    return _s1(x, m.prob.weight, planes, out_ncdhw=True)
+    return _s1(x, m.prob.weight, planes, bounds, out_ncdhw=True)
 
 
 def _needs_grad(m, x: torch.Tensor) -> bool:
@@ -140,12 +171,14 @@ class CostRegNetWeightFn(torch.autograd.Function):
         x_cl = _input_cl(x)
         acts = {"x": x_cl}
 
+        bounds = _Bounds()
+
         def layer(name, t, mode, skip):
             acts["in." + name] = t
-            return _layer(t, P[name + ".weight"], mode, True, bias=P[name + ".bias"], skip=skip)
+            return _layer(t, P[name + ".weight"], mode, True, bounds, bias=P[name + ".bias"], skip=skip)
 
         y = _unet(x_cl, layer)
-        feat, wsig = _s1(y, P["features.weight"], True, out_ncdhw=True, weight2=P["weights.weight"])
+        feat, wsig = _s1(y, P["features.weight"], True, bounds, out_ncdhw=True, weight2=P["weights.weight"])
         ctx.acts, ctx.y, ctx.params = acts, y, params
         ctx.save_for_backward(wsig)
         ctx.x_needs_grad = x.requires_grad
@@ -166,8 +199,9 @@ class CostRegNetWeightFn(torch.autograd.Function):
         grads["features.weight"] = ops.conv3d_bwd_weight(y, d_f, S1, P["features.weight"].shape, want_bias=False)[0]
         grads["weights.weight"] = ops.conv3d_bwd_weight(y, d_w, S1, P["weights.weight"].shape, want_bias=False)[0]
         # the 1-channel head's adjoint on the fp32 kernel, then the 8-channel one on the matrix cores with the sum fused
+        bounds = _Bounds()
         d_y = ops.conv3d_bwd_data(d_w, P["weights.weight"], S1, tuple(y.shape))
-        d_y = _s1(d_f, P["features.weight"], True, flip=True, skip=d_y)
+        d_y = _s1(d_f, P["features.weight"], True, bounds, flip=True, skip=d_y)
 
         def back(name, mode, d_out, accumulate=None, need_data=True):
             t = acts["in." + name]
@@ -175,9 +209,9 @@ class CostRegNetWeightFn(torch.autograd.Function):
             if not need_data:
                 return None
             if mode == S1 and t.shape[-1] > 1:
-                return _s1(d_out, P[name + ".weight"], True, flip=True, skip=accumulate)
+                return _s1(d_out, P[name + ".weight"], True, bounds, flip=True, skip=accumulate)
             if mode == T2:
-                return _t2_bwd_data(d_out, P[name + ".weight"], tuple(t.shape), accumulate)
+                return _t2_bwd_data(d_out, P[name + ".weight"], tuple(t.shape), accumulate, bounds)
             return ops.conv3d_bwd_data(d_out, P[name + ".weight"], mode, tuple(t.shape), accumulate=accumulate)
 
         # y = c0 + conv11(x9), x9 = c2 + conv9(x7), x7 = c4 + conv7(x6), x6 = conv6(conv5(c4)), c4 = conv4(conv3(c2)), ...
@@ -211,9 +245,11 @@ def cost_reg_net_weight(m, x: torch.Tensor):
 
 
 def _cost_reg_net_weight_hip(m, x: torch.Tensor, planes: bool = True):
+    bounds = _Bounds()
+
     def layer(name, t, mode, skip):
         conv = getattr(m, name)
-        return _layer(t, conv.weight, mode, planes, bias=conv.bias, skip=skip)
+        return _layer(t, conv.weight, mode, planes, bounds, bias=conv.bias, skip=skip)
 
     x = _unet(_input_cl(x), layer)
-    return _s1(x, m.features.weight, planes, out_ncdhw=True, weight2=m.weights.weight)
+    return _s1(x, m.features.weight, planes, bounds, out_ncdhw=True, weight2=m.weights.weight)

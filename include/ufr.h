@@ -490,11 +490,14 @@ int ufr_conv3d_bwd_weight(const float* in, const float* d_out, float* d_weight, 
  *   out_absmax  (nullable, channel-last outputs only) device float the caller has zeroed; raised to max |out| (skip included)
  *   flip        0: `weight` (cout,cin,3,3,3).  1: the data gradient of a stride-1 layer -- `weight` is that layer's FORWARD
  *               weight (cin of this call, cout of this call, 3,3,3) and the taps are mirrored (ufr_conv3d_bwd_data, S1).
- *   mode        UFR_CONV3D_S1, or UFR_CONV3D_S2 (conv1 / conv3 / conv5, and -- on the transposed layers' forward weights as
- *               they stand -- the data gradients of conv11 / conv9 / conv7); no transposed mode here
+ *   mode        UFR_CONV3D_S1; UFR_CONV3D_S2 (conv1 / conv3 / conv5, and -- on the transposed layers' forward weights as they
+ *               stand -- the data gradients of conv11 / conv9 / conv7); UFR_CONV3D_T2 (conv7 / conv9 / conv11 -- `weight`
+ *               (cin,cout,3,3,3) -- and, on the strided layers' forward weights, the data gradients of conv5 / conv3 / conv1):
+ *               the transposed layer runs as a 2 x 2 x 2 convolution of the input grid with 8 x cout output rows, one group
+ *               per output parity class
  *   workspace   ufr_conv3d_planes_workspace_bytes(cin, cout, cout2, mode) bytes (the weights' planes); 0 = combination not
  *               supported here (use ufr_conv3d).  S1: cin in {8, 16} with cout + cout2 <= 16, (32, 32), (64, 64); S2: (8, 16),
- *               (16, 32), (32, 64).
+ *               (16, 32), (32, 64); T2: (16, 8), (32, 16), (64, 32).
  *   planes_ready  0: the planes are made from `weight` (/ `weight2`) by this call (three small launches).  1: `workspace` still
  *               holds the planes a call with planes_ready = 0 made from the SAME weights, flip and channel counts (frozen
  *               weights: once per checkpoint, not once per frame); the caller vouches for that.

@@ -78,6 +78,33 @@ def test_planes_stride2_layer_matches_fp32_kernel_and_float64(cin, cout, shape):
         assert float((d - y0).abs().max()) < 2e-5 * float(d.abs().max())
 
 
+@pytest.mark.parametrize("cin,cout,shape", [(16, 8, (2, 3, 6, 35)), (32, 16, (1, 3, 5, 18)), (64, 32, (2, 2, 5, 17)), (16, 8, (1, 4, 16, 64)),
+                                            (32, 16, (3, 2, 8, 32)), (64, 32, (3, 1, 4, 16))])
+def test_planes_transposed_layer_matches_fp32_kernel_and_float64(cin, cout, shape):
+    """conv7 / conv9 / conv11 (and the data gradients of conv5 / conv3 / conv1)."""
+    from uforecon_amd import ops
+
+    torch.manual_seed(3 * cin + cout)
+    B, D, H, W = shape
+    x = torch.randn(B, D, H, W, cin, device=DEV) * 2.0
+    w = torch.randn(cin, cout, 3, 3, 3, device=DEV) * 0.15
+    bias = torch.randn(cout, device=DEV)
+    ref = torch.nn.functional.conv_transpose3d(x.double().permute(0, 4, 1, 2, 3), w.double(), bias.double(), stride=2, padding=1,
+                                               output_padding=1).permute(0, 2, 3, 4, 1)
+    skip = torch.randn(ref.shape, device=DEV)
+    y, ymax = ops.conv3d_planes(x, ops.absmax(x), w, bias=bias, skip=skip, mode=ops.CONV3D_T2)
+    y32 = ops.conv3d(x, w, ops.CONV3D_T2, bias=bias, skip=skip)
+    assert y.shape == y32.shape == ref.shape == (B, 2 * D, 2 * H, 2 * W, cout)
+    ref = ref + skip.double()
+    e16, e32 = _err(y, ref), _err(y32, ref)
+    print(f"transposed, cin {cin} cout {cout} {shape}: planes {e16:.2e}  fp32 kernel {e32:.2e} of the output scale")
+    assert e16 < max(4 * e32, 1e-6) and float(ymax) == float(y.abs().max())
+    # as the data gradient of the strided layer whose forward weight this is (cout_fwd = cin here)
+    d = ops.conv3d_bwd_data(x, w, ops.CONV3D_S2, (B, 2 * D, 2 * H, 2 * W, cout))
+    y0, _ = ops.conv3d_planes(x, ops.absmax(x), w, mode=ops.CONV3D_T2)
+    assert float((d - y0).abs().max()) < 2e-5 * float(d.abs().max())
+
+
 def test_planes_heads_write_the_reference_layout():
     """features (8) + sigmoid(weights (1)) in one pass, (B,C,D,H,W) outputs (module.py:541-543)."""
     from uforecon_amd import ops

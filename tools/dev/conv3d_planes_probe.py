@@ -32,6 +32,15 @@ def main():
             t32 = t(lambda: ops.conv3d(x, wt, ops.CONV3D_S2))
             t16 = t(lambda: ops.conv3d_planes(x, am, wt, mode=ops.CONV3D_S2))
             print(f"{stage} {name:9s} {cin:3d}->{cout} s2 @ {d}x{h}x{w}: fp32 {t32:7.3f}  planes {t16:7.3f} ms")
+        for name, cin, cout, down in (("conv7", 64, 32, 8), ("conv9", 32, 16, 4), ("conv11", 16, 8, 2)):
+            d, h, w = D // down, H // down, W // down
+            x = torch.randn(3, d, h, w, cin, device=dev)
+            wt = torch.randn(cin, cout, 3, 3, 3, device=dev) * 0.1
+            sk = torch.randn(3, 2 * d, 2 * h, 2 * w, cout, device=dev)
+            am = ops.absmax(x)
+            t32 = t(lambda: ops.conv3d(x, wt, ops.CONV3D_T2, skip=sk))
+            t16 = t(lambda: ops.conv3d_planes(x, am, wt, skip=sk, mode=ops.CONV3D_T2))
+            print(f"{stage} {name:9s} {cin:3d}->{cout} t2 @ {d}x{h}x{w}: fp32 {t32:7.3f}  planes {t16:7.3f} ms")
         for name, cin, cout, cout2, down in (("heads", 8, 8, 1, 1), ("features", 8, 8, 0, 1), ("conv2", 16, 16, 0, 2), ("conv4", 32, 32, 0, 4),
                                             ("conv6", 64, 64, 0, 8)):
             d, h, w = D // down, H // down, W // down

@@ -36,7 +36,10 @@ typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int kPlanesHeader = 256;   // bytes in front of the weight planes: float [0] = 1 / s_w, [1] = max |w|
 
-__host__ __device__ constexpr int planes_ksteps(int cin) { return (27 * cin + 31) / 32; }
+// taps of the implicit GEMM: 27 (convolutions); 8 for the TRANSPOSED stride-2 layer written as a 2 x 2 x 2 convolution of the
+// input grid with 8 x cout output rows (one group per output parity class, structural zeros where a class has no such tap)
+__host__ __device__ constexpr int planes_ntaps(int mode) { return mode == 2 ? 8 : 27; }
+__host__ __device__ constexpr int planes_ksteps(int cin, int mode = 0) { return (planes_ntaps(mode) * cin + 31) / 32; }
 __host__ __device__ constexpr int planes_tiles(int cout_total) { return (cout_total + 15) / 16; }
 
 // the power of two s with s * m in [2^14, 2^15) (m > 0, finite); 1 for m == 0 / not finite
@@ -61,18 +64,22 @@ __host__ __device__ constexpr int planes_c0(int ks, int g) {
 }
 
 struct PrepArgs {
-  const float* weight;   // conv layout [cout][cin][27]; flip: the layer's FORWARD weight [cin of this launch][cout][27], taps mirrored
+  const float* weight;   // conv layout [cout][cin][27]; flip: the layer's FORWARD weight [cin of this launch][cout][27], taps mirrored;
+                         // transposed: [cin][cout][27]
   const float* weight2;  // heads: [cout2][cin][27] (rows cout .. cout + cout2 - 1), nullable
   char* ws;
   int cout, cout2, flip;
 };
+// transposed stride 2, one axis: the kernel index that links output parity p with input offset o (0 / +1), or -1
+// (conv3d.hip: parity 0 <- {k = 1, i = m}; parity 1 <- {k = 0, i = m + 1}, {k = 2, i = m})
+__host__ __device__ constexpr int t2_k(int p, int o) { return p == 0 ? (o == 0 ? 1 : -1) : (o == 0 ? 2 : 0); }
 
 // grid-parallel (the 64 -> 64 layer has 110 592 weights: as one workgroup this kernel took longer than the convolution it
 // prepares); max |w| has been measured into header word 1 by absmax_kernel launches in front of it
-template <int CIN>
+template <int CIN, int MODE = 0>
 __global__ void __launch_bounds__(256) conv3d_planes_prep(PrepArgs a) {
-  constexpr int KS = planes_ksteps(CIN);
-  const int NT = planes_tiles(a.cout + a.cout2);
+  constexpr int KS = planes_ksteps(CIN, MODE);
+  const int NT = MODE == 2 ? a.cout / 2 : planes_tiles(a.cout + a.cout2);      // transposed: 8 classes x cout rows
   const float sw = plane_scale(reinterpret_cast<const float*>(a.ws)[1]);
   if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<float*>(a.ws) = 1.f / sw;
   _Float16* planes = reinterpret_cast<_Float16*>(a.ws + kPlanesHeader);
@@ -86,7 +93,13 @@ __global__ void __launch_bounds__(256) conv3d_planes_prep(PrepArgs a) {
     const int g = lane >> 4, i = lane & 15;
     const int tap = planes_tap<CIN>(ks, g), ci = planes_c0<CIN>(ks, g) + h, co = 16 * t + i;
     float w = 0.f;
-    if (e < total && tap < 27) {
+    if constexpr (MODE == 2) {
+      if (e < total && tap < 8) {
+        const int cls = co / a.cout, cr = co - cls * a.cout;
+        const int kz = t2_k((cls >> 2) & 1, (tap >> 2) & 1), ky = t2_k((cls >> 1) & 1, (tap >> 1) & 1), kx = t2_k(cls & 1, tap & 1);
+        if (kz >= 0 && ky >= 0 && kx >= 0) w = a.weight[((size_t)ci * a.cout + cr) * 27 + (kz * 3 + ky) * 3 + kx];
+      }
+    } else if (e < total && tap < 27) {
       if (co < a.cout) w = a.flip ? a.weight[((size_t)ci * a.cout + co) * 27 + (26 - tap)] : a.weight[((size_t)co * CIN + ci) * 27 + tap];
       else if (co < a.cout + a.cout2) w = a.weight2[((size_t)(co - a.cout) * CIN + ci) * 27 + tap];
     }
@@ -131,11 +144,14 @@ __device__ __forceinline__ void split2(float a, float b, float m, unsigned& h, u
   asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(b), "s"(m), "v"(h));
 }
 
-template <int CIN, int S = 1>
-struct Brick {   // output brick of a workgroup and its input halo (stride S: input extent S (T - 1) + 3 per axis)
-  static constexpr int TX = S == 2 ? (CIN == 8 ? 32 : 16) : (CIN == 8 ? 64 : CIN == 16 ? 32 : 16), TY = 4,
-                       TZ = (S == 1 && (CIN == 8 || CIN == 32)) ? 2 : 1;
-  static constexpr int HX = S * (TX - 1) + 3, HY = S * (TY - 1) + 3, HZ = S * (TZ - 1) + 3;
+template <int CIN, int MODE = 0>
+struct Brick {   // the brick of a workgroup -- output voxels (transposed: INPUT voxels, 8 outputs each) -- and its input halo
+  static constexpr int S = MODE == 1 ? 2 : 1;
+  static constexpr int TX = MODE == 1 ? (CIN == 8 ? 32 : 16) : (CIN == 8 ? 64 : CIN == 16 ? 32 : 16), TY = 4,
+                       TZ = (MODE == 0 && (CIN == 8 || CIN == 32)) || (MODE == 2 && CIN == 32) ? 2 : 1;
+  // stride S: S (T - 1) + 3 inputs per axis from -1; transposed: offsets 0 / +1 only
+  static constexpr int HX = MODE == 2 ? TX + 1 : S * (TX - 1) + 3, HY = MODE == 2 ? TY + 1 : S * (TY - 1) + 3,
+                       HZ = MODE == 2 ? TZ + 1 : S * (TZ - 1) + 3;
   static constexpr int halo = HX * HY * HZ;
   static constexpr int tiles = TX / 16 * TY * TZ;          // 16-voxel column tiles
   static constexpr int per_wave = tiles / 4;
@@ -152,10 +168,12 @@ struct Brick {   // output brick of a workgroup and its input halo (stride S: in
 // layer: 0.345 ms = 0.14 fixed + 0.09 MFMA + 0.09 stores + 0.03 loads, a sum, not a maximum).
 // NT output row tiles in passes of NTG (the 64 -> 64 layer: two passes of two tiles -- four tiles' weight fragments three
 // k-steps deep are 96 registers, and the kernel spilled 800; the halo is staged once, its operands are read per pass)
-template <int CIN, int NT, int NTG = NT, int S = 1>
+template <int CIN, int NT, int NTG = NT, int MODE = 0>
 __global__ void __launch_bounds__(256, 2) conv3d_planes_kernel(PlanesArgs a) {
-  typedef Brick<CIN, S> Bk;
-  constexpr int KS = planes_ksteps(CIN);
+  typedef Brick<CIN, MODE> Bk;
+  constexpr int S = Bk::S, O = MODE == 2 ? 0 : 1;          // stride; the halo starts O voxels in front of the brick
+  constexpr bool T2 = MODE == 2;
+  constexpr int KS = planes_ksteps(CIN, MODE), NTAPS = planes_ntaps(MODE);
   constexpr int VT = Bk::per_wave;
   // the weights' planes: copied into LDS once per workgroup when they fit beside the halo (<= 32 KiB: the 8- / 16-channel
   // layers), else every wave reads its fragments from global memory (108 / 432 KiB for 32 -> 32 / 64 -> 64: L2-resident, the
@@ -208,7 +226,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_planes_kernel(PlanesArgs a) {
     for (int r = 0; r < HR; ++r) {
       const int hv = tid + 256 * r;
       const int hx = hv % Bk::HX, hy = (hv / Bk::HX) % Bk::HY, hz = hv / (Bk::HX * Bk::HY);
-      const int ix = S * x0 + hx - 1, iy = S * y0 + hy - 1, iz = S * z0 + hz - 1;
+      const int ix = S * x0 + hx - O, iy = S * y0 + hy - O, iz = S * z0 + hz - O;
       const bool ok = UFR_C3P_ABL != 2 && hv < Bk::halo && ix >= 0 && ix < a.W && iy >= 0 && iy < a.H && iz >= 0 && iz < a.D;
       const unsigned off = (unsigned)(((iz * a.H + iy) * a.W + ix) * (CIN * 4));
 #pragma unroll
@@ -249,7 +267,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_planes_kernel(PlanesArgs a) {
     for (int r = 0; r < HR; ++r) {
       const int hv = tid + 256 * r;
       const int hx = hv % Bk::HX, hy = (hv / Bk::HX) % Bk::HY, hz = hv / (Bk::HX * Bk::HY);
-      const int ix = S * x0 + hx - 1, iy = S * y0 + hy - 1, iz = S * z0 + hz - 1;
+      const int ix = S * x0 + hx - O, iy = S * y0 + hy - O, iz = S * z0 + hz - O;
       const bool ok = hv < Bk::halo && ix >= 0 && ix < a.W && iy >= 0 && iy < a.H && iz >= 0 && iz < a.D;
       const unsigned off = (unsigned)(((iz * a.H + iy) * a.W + ix) * (CIN * 4));
       f32x4 t[C8][2];
@@ -309,8 +327,8 @@ __global__ void __launch_bounds__(256, 2) conv3d_planes_kernel(PlanesArgs a) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       int tap = planes_tap<CIN>(ks, g);
-      tap = tap < 27 ? tap : 0;
-      toff_t[ks] = ((tap / 9) * Bk::HY + (tap / 3) % 3) * Bk::HX + tap % 3;
+      tap = tap < NTAPS ? tap : 0;
+      toff_t[ks] = T2 ? ((tap >> 2) * Bk::HY + ((tap >> 1) & 1)) * Bk::HX + (tap & 1) : ((tap / 9) * Bk::HY + (tap / 3) % 3) * Bk::HX + tap % 3;
     }
   }
   auto operand_off = [&](auto ksi, int vb) __attribute__((always_inline)) -> int {
@@ -318,7 +336,8 @@ __global__ void __launch_bounds__(256, 2) conv3d_planes_kernel(PlanesArgs a) {
     if constexpr (CIN <= 16) {
       return ((planes_c0<CIN>(ks, g) / 8) * Bk::halo + vb + toff_t[ks]) * 16;
     } else {
-      constexpr int tap = planes_tap<CIN>(ks, 0), to = ((tap / 9) * Bk::HY + (tap / 3) % 3) * Bk::HX + tap % 3;
+      constexpr int tap = planes_tap<CIN>(ks, 0);
+      constexpr int to = T2 ? ((tap >> 2) * Bk::HY + ((tap >> 1) & 1)) * Bk::HX + (tap & 1) : ((tap / 9) * Bk::HY + (tap / 3) % 3) * Bk::HX + tap % 3;
       return ((planes_c0<CIN>(ks, 0) / 8 + g) * Bk::halo + vb + to) * 16;
     }
   };
@@ -377,6 +396,30 @@ __global__ void __launch_bounds__(256, 2) conv3d_planes_kernel(PlanesArgs a) {
       const int q = wave + 4 * v;
       const int tx16 = q % (Bk::TX / 16), ty = (q / (Bk::TX / 16)) % Bk::TY, tz = q / (Bk::TX / 16 * Bk::TY);
       const int ox = x0 + tx16 * 16 + j, oy = y0 + ty, oz = z0 + tz;
+      if constexpr (T2) {
+        // rows 16 tile + 4 g + r = class * cout + channel: this lane's four rows are four consecutive channels of ONE parity
+        // class; a wave's store covers both x parities and all channels of 32 consecutive output x: whole lines
+        if (ox >= a.W || oy >= a.H || oz >= a.D) continue;
+#pragma unroll
+        for (int t = 0; t < NTG; ++t) {
+          const int row0 = 16 * (pass * NTG + t) + 4 * g;
+          const int cls = row0 / a.cout, c0 = row0 - cls * a.cout;
+          const size_t vox = (size_t)bb * plane + ((size_t)(2 * oz + ((cls >> 2) & 1)) * a.Ho + 2 * oy + ((cls >> 1) & 1)) * a.Wo + 2 * ox + (cls & 1);
+          f32x4 y;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float q2 = acc[v][t][r] * dsc;
+            if (a.bias) q2 += a.bias[c0 + r];
+            if (a.scale) q2 = fmaf(q2, a.scale[c0 + r], a.shift[c0 + r]);
+            if (a.relu) q2 = fmaxf(q2, 0.f);
+            y[r] = q2;
+          }
+          if (a.skip) y += ld4(a.skip + vox * a.cout + c0);
+          st4(a.out + vox * a.cout + c0, y);
+          omax = fmaxf(omax, fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3]))));
+        }
+        continue;
+      }
       if (ox >= a.Wo || oy >= a.Ho || oz >= a.Do) continue;
       if (UFR_C3P_ABL == 3 && acc[v][0][0] != 12345.f) continue;
       const size_t sp = ((size_t)oz * a.Ho + oy) * a.Wo + ox;
@@ -442,22 +485,24 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x
   if ((threadIdx.x & 63) == 0 && bits > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, bits);
 }
 
-template <int CIN, int NT, int NTG = NT, int S = 1>
+template <int CIN, int NT, int NTG = NT, int MODE = 0>
 hipError_t launch_planes_t(const PlanesArgs& a, hipStream_t s) {
-  typedef Brick<CIN, S> Bk;
-  constexpr int w_all = planes_ksteps(CIN) * NT * 2048;
+  typedef Brick<CIN, MODE> Bk;
+  constexpr int w_all = planes_ksteps(CIN, MODE) * NT * 2048;
   constexpr int lds = (w_all <= 32768 ? w_all : 0) + 2 * Bk::plane_bytes;
   static LdsAttrOnce lds_attr;
-  if (const hipError_t e = lds_attr.set(reinterpret_cast<const void*>(&conv3d_planes_kernel<CIN, NT, NTG, S>), lds); e != hipSuccess) return e;
+  if (const hipError_t e = lds_attr.set(reinterpret_cast<const void*>(&conv3d_planes_kernel<CIN, NT, NTG, MODE>), lds); e != hipSuccess) return e;
   PlanesArgs b = a;
-  b.nbx = (a.Wo + Bk::TX - 1) / Bk::TX; b.nby = (a.Ho + Bk::TY - 1) / Bk::TY; b.nbz = (a.Do + Bk::TZ - 1) / Bk::TZ;
+  // bricks tile the output grid (transposed: the input grid, eight outputs per voxel)
+  const int gx = MODE == 2 ? a.W : a.Wo, gy = MODE == 2 ? a.H : a.Ho, gz = MODE == 2 ? a.D : a.Do;
+  b.nbx = (gx + Bk::TX - 1) / Bk::TX; b.nby = (gy + Bk::TY - 1) / Bk::TY; b.nbz = (gz + Bk::TZ - 1) / Bk::TZ;
   const long long bricks = (long long)b.nbx * b.nby * b.nbz * a.B;
   if (bricks <= 0 || bricks > 0x7fffffffLL) return hipErrorInvalidValue;
   // the resident workgroups (LDS: two per CU, one for the 64-channel halo), a multiple of the 8 XCDs; fewer when there are
   // fewer bricks than that
   long long blocks = (lds > 80 * 1024 ? 1 : 2) * 256;
   if (bricks < blocks) blocks = ((bricks + 7) / 8) * 8;
-  hipLaunchKernelGGL((conv3d_planes_kernel<CIN, NT, NTG, S>), dim3((unsigned)blocks), dim3(256), lds, s, b);
+  hipLaunchKernelGGL((conv3d_planes_kernel<CIN, NT, NTG, MODE>), dim3((unsigned)blocks), dim3(256), lds, s, b);
   return hipGetLastError();
 }
 
@@ -468,6 +513,8 @@ size_t conv3d_planes_workspace_bytes(int cin, int cout, int cout2, int mode) {
   const bool s1 = mode == 0 && (((cin == 8 || cin == 16) && cout + cout2 <= 16) || (cin == 32 && cout == 32 && cout2 == 0) ||
                                 (cin == 64 && cout == 64 && cout2 == 0));
   const bool s2 = mode == 1 && cout2 == 0 && ((cin == 8 && cout == 16) || (cin == 16 && cout == 32) || (cin == 32 && cout == 64));
+  const bool t2 = mode == 2 && cout2 == 0 && ((cin == 16 && cout == 8) || (cin == 32 && cout == 16) || (cin == 64 && cout == 32));
+  if (t2) return kPlanesHeader + (size_t)planes_ksteps(cin, 2) * (cout / 2) * 2048;
   if (!s1 && !s2) return 0;
   if (cout < 1 || cout2 < 0) return 0;
   return kPlanesHeader + (size_t)planes_ksteps(cin) * planes_tiles(cout + cout2) * 2048;
@@ -486,11 +533,11 @@ hipError_t launch_conv3d_planes(const float* in, const float* in_absmax, const f
                                 const float* scale, const float* shift, const float* skip, float* out, float* out2, float* out_absmax,
                                 int B, int D, int H, int W, int cin, int cout, int cout2, int mode, int relu, int ncdhw, int flip,
                                 void* ws, int planes_ready, hipStream_t s) {
-  if (!conv3d_planes_workspace_bytes(cin, cout, cout2, mode) || (mode == 1 && flip)) return hipErrorInvalidValue;
+  if (!conv3d_planes_workspace_bytes(cin, cout, cout2, mode) || (mode != 0 && flip) || (mode == 2 && ncdhw)) return hipErrorInvalidValue;
   // one view's tensor is a raw buffer descriptor (31-bit byte offsets, kBufOut = zero fill)
   if ((long long)D * H * W * cin * 4 >= (1ll << 31)) return hipErrorInvalidValue;
   if (!planes_ready) {
-    const int ct = cout + cout2, nt = planes_tiles(ct);
+    const int ct = cout + cout2, nt = mode == 2 ? cout / 2 : planes_tiles(ct);
     if (const hipError_t e = hipMemsetAsync(static_cast<char*>(ws) + 4, 0, 4, s); e != hipSuccess) return e;
     float* wmax = reinterpret_cast<float*>(ws) + 1;
     if (const hipError_t e = launch_absmax(weight, (size_t)cout * cin * 27, wmax, s); e != hipSuccess) return e;
@@ -498,8 +545,11 @@ hipError_t launch_conv3d_planes(const float* in, const float* in_absmax, const f
       if (const hipError_t e = launch_absmax(weight2, (size_t)cout2 * cin * 27, wmax, s); e != hipSuccess) return e;
     PrepArgs p;
     p.weight = weight; p.weight2 = weight2; p.ws = static_cast<char*>(ws); p.cout = cout; p.cout2 = cout2; p.flip = flip;
-    const unsigned pb = (unsigned)((planes_ksteps(cin) * nt * 512 + 2047) / 2048);
-    if (cin == 8) hipLaunchKernelGGL(conv3d_planes_prep<8>, dim3(pb), dim3(256), 0, s, p);
+    const unsigned pb = (unsigned)((planes_ksteps(cin, mode) * nt * 512 + 2047) / 2048);
+    if (mode == 2 && cin == 16) hipLaunchKernelGGL((conv3d_planes_prep<16, 2>), dim3(pb), dim3(256), 0, s, p);
+    else if (mode == 2 && cin == 32) hipLaunchKernelGGL((conv3d_planes_prep<32, 2>), dim3(pb), dim3(256), 0, s, p);
+    else if (mode == 2) hipLaunchKernelGGL((conv3d_planes_prep<64, 2>), dim3(pb), dim3(256), 0, s, p);
+    else if (cin == 8) hipLaunchKernelGGL(conv3d_planes_prep<8>, dim3(pb), dim3(256), 0, s, p);
     else if (cin == 16) hipLaunchKernelGGL(conv3d_planes_prep<16>, dim3(pb), dim3(256), 0, s, p);
     else if (cin == 32) hipLaunchKernelGGL(conv3d_planes_prep<32>, dim3(pb), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(conv3d_planes_prep<64>, dim3(pb), dim3(256), 0, s, p);
@@ -510,11 +560,17 @@ hipError_t launch_conv3d_planes(const float* in, const float* in_absmax, const f
   a.scale = scale; a.shift = shift; a.skip = skip; a.out = out; a.out2 = out2; a.out_absmax = reinterpret_cast<unsigned*>(out_absmax);
   a.B = B; a.D = D; a.H = H; a.W = W; a.cout = cout; a.cout2 = cout2; a.relu = relu; a.ncdhw = ncdhw;
   a.Do = mode == 1 ? (D + 1) / 2 : D; a.Ho = mode == 1 ? (H + 1) / 2 : H; a.Wo = mode == 1 ? (W + 1) / 2 : W;   // k3 p1 s2: floor((n - 1) / 2) + 1
+  if (mode == 2) { a.Do = 2 * D; a.Ho = 2 * H; a.Wo = 2 * W; }                                                   // k3 p1 s2 output_padding 1
   a.nbx = a.nby = a.nbz = 0;
+  if (mode == 2) {
+    if (cin == 16) return launch_planes_t<16, 4, 2, 2>(a, s);
+    if (cin == 32) return launch_planes_t<32, 8, 2, 2>(a, s);
+    return launch_planes_t<64, 16, 2, 2>(a, s);
+  }
   if (mode == 1) {
-    if (cin == 8) return launch_planes_t<8, 1, 1, 2>(a, s);
-    if (cin == 16) return launch_planes_t<16, 2, 1, 2>(a, s);
-    return launch_planes_t<32, 4, 2, 2>(a, s);
+    if (cin == 8) return launch_planes_t<8, 1, 1, 1>(a, s);
+    if (cin == 16) return launch_planes_t<16, 2, 1, 1>(a, s);
+    return launch_planes_t<32, 4, 2, 1>(a, s);
   }
   if (cin == 8) return launch_planes_t<8, 1>(a, s);
   if (cin == 16) return launch_planes_t<16, 1>(a, s);

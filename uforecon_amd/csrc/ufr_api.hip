@@ -1172,7 +1172,9 @@ int ufr_conv3d_planes(const float* in, const float* in_absmax, const float* weig
   UFR_REQUIRE(cout2 == 0 || (weight2 && out2 && out_ncdhw && !flip), "ufr_conv3d_planes: a second head needs weight2, out2, out_ncdhw");
   UFR_REQUIRE(out_ncdhw || (cout % 4 == 0 && cout2 == 0), "ufr_conv3d_planes: channel-last outputs need cout %% 4 == 0 (got %d)", cout);
   UFR_REQUIRE(!(out_ncdhw && (skip || out_absmax)), "ufr_conv3d_planes: skip / out_absmax go with channel-last outputs");
-  UFR_REQUIRE(!(mode == UFR_CONV3D_S2 && flip), "ufr_conv3d_planes: flip is the stride-1 data gradient");
+  UFR_REQUIRE(mode == UFR_CONV3D_S1 || mode == UFR_CONV3D_S2 || mode == UFR_CONV3D_T2, "ufr_conv3d_planes: unknown mode %d", mode);
+  UFR_REQUIRE(!(mode != UFR_CONV3D_S1 && flip), "ufr_conv3d_planes: flip is the stride-1 data gradient");
+  UFR_REQUIRE(!(mode == UFR_CONV3D_T2 && out_ncdhw), "ufr_conv3d_planes: the transposed layers write channel-last");
   const size_t need = conv3d_planes_workspace_bytes(cin, cout, cout2, mode);
   if (!need) return fail(UFR_ERR_ARG, "ufr_conv3d_planes: (cin %d, cout %d+%d, mode %d) is not a layer of this kernel family", cin, cout, cout2, mode);
   if (workspace_bytes < need) return fail(UFR_ERR_WORKSPACE, "ufr_conv3d_planes: workspace %zu < %zu", workspace_bytes, need);

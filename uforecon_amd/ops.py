@@ -768,12 +768,11 @@ def absmax(x: torch.Tensor, into: Optional[torch.Tensor] = None) -> torch.Tensor
 _PLANES = {}
 
 
-def _planes_lookup(weight, weight2, flip, nbytes):
+def _planes_lookup(weight, weight2, flip, nbytes, transposed=False):
     import weakref
 
     ent = _PLANES.get(id(weight))
-    sig = (weight._version, None if weight2 is None else (id(weight2), weight2._version), bool(flip), nbytes, weight.device)
-    # (the planes' layout depends on the channel counts and the mirroring only, not on the stride)
+    sig = (weight._version, None if weight2 is None else (id(weight2), weight2._version), bool(flip), nbytes, weight.device, transposed)
     if ent is not None and ent[0]() is weight and ent[1] == sig and (weight2 is None or ent[2]() is weight2):
         return ent[3], True
     if len(_PLANES) > 512:          # tensors that died without being looked up again
@@ -798,9 +797,9 @@ def conv3d_planes(x_cl: torch.Tensor, x_absmax: torch.Tensor, weight: torch.Tens
     that layer's forward weight (cin of this call = its cout).  Returns ``(out, out_absmax or None)``, with a second head
     ``(out, sigmoid(out2), None)``."""
     B, D, H, W, cin = x_cl.shape
-    if flip:
+    if flip or int(mode) == CONV3D_T2:
         if tuple(weight.shape[2:]) != (3, 3, 3) or weight.shape[0] != cin:
-            raise UfrError(f"conv3d_planes(flip): weight {tuple(weight.shape)} does not match {cin} input channels")
+            raise UfrError(f"conv3d_planes(flip / transposed): weight {tuple(weight.shape)} does not match {cin} input channels")
         cout = weight.shape[1]
     else:
         if tuple(weight.shape[1:]) != (cin, 3, 3, 3):
@@ -813,12 +812,12 @@ def conv3d_planes(x_cl: torch.Tensor, x_absmax: torch.Tensor, weight: torch.Tens
     if not nbytes:
         raise UfrError(f"conv3d_planes: (cin {cin}, cout {cout}+{cout2}, mode {mode}) is not a layer of this kernel family")
     dev = x_cl.device
-    Do, Ho, Wo = ((D + 1) // 2, (H + 1) // 2, (W + 1) // 2) if mode == CONV3D_S2 else (D, H, W)
+    Do, Ho, Wo = ((D + 1) // 2, (H + 1) // 2, (W + 1) // 2) if mode == CONV3D_S2 else (2 * D, 2 * H, 2 * W) if mode == CONV3D_T2 else (D, H, W)
     out = torch.empty((B, cout, Do, Ho, Wo) if out_ncdhw else (B, Do, Ho, Wo, cout), dtype=torch.float32, device=dev)
     out2 = torch.empty((B, cout2, Do, Ho, Wo), dtype=torch.float32, device=dev) if cout2 else None
     if skip is not None and tuple(skip.shape) != tuple(out.shape):
         raise UfrError(f"conv3d_planes: skip {tuple(skip.shape)} does not match the output {tuple(out.shape)}")
-    ws, ready = _planes_lookup(weight, weight2, flip, nbytes)
+    ws, ready = _planes_lookup(weight, weight2, flip, nbytes, mode == CONV3D_T2)
     omax = torch.zeros(1, dtype=torch.float32, device=dev) if (want_absmax and not out_ncdhw) else None
     keep = [t.detach().contiguous() for t in (weight, weight2, bias, bn_scale, bn_shift) if t is not None]
     it = iter(keep)

@@ -94,12 +94,34 @@ def _s2(t, weight, planes: bool, bounds: "_Bounds" = None, **kw):
     return ops.conv3d(t, weight, S2, **kw)
 
 
+def _t2(t, weight, planes: bool, bounds: "_Bounds" = None, **kw):
+    """One transposed stride-2 layer (conv7 / conv9 / conv11); ``weight`` (cin, cout, 3,3,3)."""
+    if planes and ops.conv3d_planes_supported(t.shape[-1], weight.shape[1], 0, T2):
+        b = bounds if bounds is not None else _Bounds()
+        out, omax = ops.conv3d_planes(t, b.of(t), weight, want_absmax=bounds is not None, mode=T2, **kw)
+        b.put(out, omax)
+        return out
+    return ops.conv3d(t, weight, T2, **kw)
+
+
 def _layer(t, weight, mode, planes: bool, bounds: "_Bounds" = None, **kw):
     if mode == S1:
         return _s1(t, weight, planes, bounds, **kw)
     if mode == S2:
         return _s2(t, weight, planes, bounds, **kw)
-    return ops.conv3d(t, weight, mode, **kw)
+    return _t2(t, weight, planes, bounds, **kw)
+
+
+def _s2_bwd_data(d_out, weight, in_shape, accumulate=None, bounds: "_Bounds" = None):
+    """Data gradient of a stride-2 layer = the transposed stride-2 convolution of d_out with the layer's forward weight
+    (cout, cin, 3,3,3) read as a transposed-convolution weight (its layout as it stands)."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    if ops.conv3d_planes_supported(cout, cin, 0, T2) and tuple(in_shape[1:4]) == tuple(2 * n for n in d_out.shape[1:4]):
+        b = bounds if bounds is not None else _Bounds()
+        out, omax = ops.conv3d_planes(d_out, b.of(d_out), weight, skip=accumulate, want_absmax=bounds is not None, mode=T2)
+        b.put(out, omax)
+        return out
+    return ops.conv3d_bwd_data(d_out, weight, S2, in_shape, accumulate=accumulate)
 
 
 def _t2_bwd_data(d_out, weight, in_shape, accumulate=None, bounds: "_Bounds" = None):
@@ -212,6 +234,8 @@ class CostRegNetWeightFn(torch.autograd.Function):
                 return _s1(d_out, P[name + ".weight"], True, bounds, flip=True, skip=accumulate)
             if mode == T2:
                 return _t2_bwd_data(d_out, P[name + ".weight"], tuple(t.shape), accumulate, bounds)
+            if mode == S2:
+                return _s2_bwd_data(d_out, P[name + ".weight"], tuple(t.shape), accumulate, bounds)
             return ops.conv3d_bwd_data(d_out, P[name + ".weight"], mode, tuple(t.shape), accumulate=accumulate)
 
         # y = c0 + conv11(x9), x9 = c2 + conv9(x7), x7 = c4 + conv7(x6), x6 = conv6(conv5(c4)), c4 = conv4(conv3(c2)), ...

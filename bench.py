@@ -585,7 +585,7 @@ def digest(line):
 HEADLINE_MAX_BYTES = 4096
 
 
-def _r(x, nd=6):
+def _r(x, nd=8):
     """Numbers of the stdout line: enough digits to recompute every ratio, no 17-digit tails."""
     if isinstance(x, float):
         return float(f"{x:.{nd}g}")

@@ -300,8 +300,8 @@ def test_bench_line_contract(tmp_path):
     assert d["data"] == "synthetic" and d["dtype"] == "f32" and "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - 64 * 96 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     rf = d["roofline"]
-    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
-    assert abs(rf["peak"] - 2516.6 / 3) < 1e-6 and rf["kernel"] == "view_transformer_kernel" and rf["avg_launch_ms"] > 0
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6 * rf["frac"]
+    assert abs(rf["peak"] - 2516.6 / 3) < 1e-4 and rf["kernel"] == "view_transformer_kernel" and rf["avg_launch_ms"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "rays/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert d["gpu_eager_baseline"]["value"] > 0 and abs(d["vs_baseline"] - d["value"] / d["gpu_eager_baseline"]["value"]) < 1e-6 * d["vs_baseline"]

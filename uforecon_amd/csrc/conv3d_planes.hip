@@ -75,13 +75,38 @@ struct PrepArgs {
 __host__ __device__ constexpr int t2_k(int p, int o) { return p == 0 ? (o == 0 ? 1 : -1) : (o == 0 ? 2 : 0); }
 
 // grid-parallel (the 64 -> 64 layer has 110 592 weights: as one workgroup this kernel took longer than the convolution it
-// prepares); max |w| has been measured into header word 1 by absmax_kernel launches in front of it
+// prepares).  Every workgroup measures max |w| over ALL the weights itself (<= 110 592 floats, L2-resident, loads in batches
+// of eight: a few microseconds) -- one launch per layer instead of memset + measure + prepare, which a training step pays
+// for every layer in both directions.
 template <int CIN, int MODE = 0>
 __global__ void __launch_bounds__(256) conv3d_planes_prep(PrepArgs a) {
   constexpr int KS = planes_ksteps(CIN, MODE);
   const int NT = MODE == 2 ? a.cout / 2 : planes_tiles(a.cout + a.cout2);      // transposed: 8 classes x cout rows
-  const float sw = plane_scale(reinterpret_cast<const float*>(a.ws)[1]);
-  if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<float*>(a.ws) = 1.f / sw;
+  __shared__ float red[4];
+  float m = 0.f;
+  {
+    const int n1 = a.cout * CIN * 27, n2 = a.weight2 ? a.cout2 * CIN * 27 : 0;
+    for (int i0 = 0; i0 < n1 + n2; i0 += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 256 * u + threadIdx.x;
+        v[u] = i < n1 ? a.weight[i] : (i < n1 + n2 ? a.weight2[i - n1] : 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) m = fmaxf(m, fabsf(v[u]));
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  }
+  const float sw = plane_scale(m);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    reinterpret_cast<float*>(a.ws)[0] = 1.f / sw;
+    reinterpret_cast<float*>(a.ws)[1] = m;
+  }
   _Float16* planes = reinterpret_cast<_Float16*>(a.ws + kPlanesHeader);
   const int total = KS * NT * 64 * 8;
   const int e0 = blockIdx.x * (256 * 8);
@@ -538,11 +563,6 @@ hipError_t launch_conv3d_planes(const float* in, const float* in_absmax, const f
   if ((long long)D * H * W * cin * 4 >= (1ll << 31)) return hipErrorInvalidValue;
   if (!planes_ready) {
     const int ct = cout + cout2, nt = mode == 2 ? cout / 2 : planes_tiles(ct);
-    if (const hipError_t e = hipMemsetAsync(static_cast<char*>(ws) + 4, 0, 4, s); e != hipSuccess) return e;
-    float* wmax = reinterpret_cast<float*>(ws) + 1;
-    if (const hipError_t e = launch_absmax(weight, (size_t)cout * cin * 27, wmax, s); e != hipSuccess) return e;
-    if (weight2)
-      if (const hipError_t e = launch_absmax(weight2, (size_t)cout2 * cin * 27, wmax, s); e != hipSuccess) return e;
     PrepArgs p;
     p.weight = weight; p.weight2 = weight2; p.ws = static_cast<char*>(ws); p.cout = cout; p.cout2 = cout2; p.flip = flip;
     const unsigned pb = (unsigned)((planes_ksteps(cin, mode) * nt * 512 + 2047) / 2048);

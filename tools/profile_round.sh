@@ -23,6 +23,8 @@ export UFR_BT_OVERLAP=0
 TRAIN="tools/bench_train.py --steps 3 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o train -- python3 $TRAIN > $OUT/train_line.json 2> $OUT/train_err.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o train16 -- python3 $TRAIN --precision 16bit > $OUT/train16_line.json 2> $OUT/train16_err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o traincr -- python3 $TRAIN --cost-reg > $OUT/traincr_line.json 2> $OUT/traincr_err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o encoder -- python3 tools/bench_encoder.py > $OUT/encoder_out.txt 2> $OUT/encoder_err.txt
 TRAIN_PMC="tools/bench_train.py --steps 2 --warmup 0 --no-cpu-baseline"
 rocprofv3 --kernel-trace --output-format csv --pmc $SQ -d $OUT -o train_pmc_sq -- python3 $TRAIN_PMC > /dev/null 2> $OUT/train_pmc_sq_err.txt
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT -o train_pmc_fetch -- python3 $TRAIN_PMC > /dev/null 2> $OUT/train_pmc_fetch_err.txt
@@ -30,6 +32,7 @@ rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT -o train_p
 unset UFR_BT_OVERLAP
 # configs[3] (5 views, 800x600, 128+128): HBM traffic of the L = 6 kernels
 C4="tools/bench_c4.py --steps 1 --warmup 0 --streams 1 --no-cpu-baseline --no-gpu-eager-baseline"
+rocprofv3 --kernel-trace --output-format csv --pmc $SQ -d $OUT -o c4_pmc_sq -- python3 $C4 > /dev/null 2> $OUT/c4_pmc_sq_err.txt
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT -o c4_pmc_fetch -- python3 $C4 > /dev/null 2> $OUT/c4_pmc_fetch_err.txt
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT -o c4_pmc_write -- python3 $C4 > /dev/null 2> $OUT/c4_pmc_write_err.txt
 # the raw per-dispatch tables are large: keep only what the summariser needs

@@ -77,7 +77,8 @@ def main(src: str, dst_prefix: str):
                 if i:
                     row[0] = short(row[0])
                 w.writerow(row)
-    for tag in ("train", "train16"):   # training step (tools/bench_train.py), fp32 / 16-bit matrix mode
+    # training step (tools/bench_train.py), fp32 / 16-bit matrix mode / with cost_reg_2 in front; the per-frame producers
+    for tag in ("train", "train16", "traincr", "encoder"):
         tstats = os.path.join(src, f"{tag}_kernel_stats.csv")
         if os.path.exists(tstats):
             with open(tstats) as f, open(f"{dst_prefix}_{tag}_kernel_stats.csv", "w", newline="") as g:

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(OUT_DIR, "libufr.so")
 ARCH = "gfx950"
 
 SOURCES = ["ufr_api.hip", "prep.hip", "sampler.hip", "gather.hip", "view_transformer.hip",
-           "ray_transformer.hip", "composite.hip", "render_loss.hip", "view_dgrad.hip", "wgrad_stream.hip", "ray_dgrad.hip", "presim_bwd.hip", "gather_bwd.hip", "frustum.hip", "tsdf.hip", "dcn.hip", "fmt.hip", "conv3d.hip", "conv3d_planes.hip", "conv2d.hip"]
+           "ray_transformer.hip", "composite.hip", "render_loss.hip", "view_dgrad.hip", "wgrad_stream.hip", "ray_dgrad.hip", "presim_bwd.hip", "gather_bwd.hip", "frustum.hip", "tsdf.hip", "dcn.hip", "fmt.hip", "conv3d.hip", "conv3d_planes.hip", "conv3d_wgrad_planes.hip", "conv2d.hip"]
 # -ffp-contract=on: fuse a*b+c only inside one expression.  hipcc's default (fast) also fuses across statements,
 # and did so differently in the two unrolled copies of the per-tile code of the view transformer: a point's result
 # then depended on which column tile it landed in (1 ulp), which breaks "rays are independent -> chunking and the

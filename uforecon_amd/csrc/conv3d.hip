@@ -979,6 +979,21 @@ hipError_t launch_conv3d_bwd_weight(const float* in, const float* d_out, float* 
   a.n_p = (long long)B * a.Dp * a.Hp * a.Wp;
   if (a.n_p >= (1ll << 31) - 65536 || n_out >= (1ll << 40)) return hipErrorInvalidValue;     // the kernels index voxels with 32 bits
   hipError_t e = hipErrorInvalidValue;
+#ifndef UFR_CONV3D_WGRAD_FP32_ONLY
+  // round 6: the 16-bit matrix-core kernels (conv3d_wgrad_planes.hip) where they have the shape; they take the bias gradient
+  // along when TP is d_out (the convolutions)
+  {
+    const bool bias_rides = d_bias != nullptr && mode != kDeconvS2;
+    e = launch_conv3d_wgrad_planes(a.tp, a.tq, a.dw, bias_rides ? d_bias : nullptr, B, a.Dp, a.Hp, a.Wp, a.Dq, a.Hq, a.Wq, ca, cb, S, s);
+    if (e == hipSuccess) {
+      if (!d_bias || bias_rides) return hipSuccess;
+    } else if (e != hipErrorInvalidValue) {
+      return e;
+    }
+  }
+  if (e != hipSuccess) {
+#endif
+  e = hipErrorInvalidValue;
 #define UFR_WG_CASE(A_, B_, S_) if (ca == A_ && cb == B_ && S == S_) e = launch_wgrad_t<A_, B_, S_>(a, s);
   UFR_WG_CASE(8, 1, 1)     // conv0
   UFR_WG_CASE(16, 8, 2)    // conv1, conv11
@@ -990,6 +1005,9 @@ hipError_t launch_conv3d_bwd_weight(const float* in, const float* d_out, float* 
   UFR_WG_CASE(8, 8, 1)     // features head
   UFR_WG_CASE(1, 8, 1)     // weights head
 #undef UFR_WG_CASE
+#ifndef UFR_CONV3D_WGRAD_FP32_ONLY
+  }
+#endif
   if (e != hipSuccess) return e;
   if (d_bias) {
     const int rows = 16384;    // 64 rows per thread, four loads in flight; ~500 blocks: few same-address atomics

@@ -480,6 +480,12 @@ int ufr_conv3d_bwd_data(const float* d_out, const float* weight, const float* ac
 int ufr_conv3d_bwd_weight(const float* in, const float* d_out, float* d_weight, float* d_bias, int32_t B, int32_t D, int32_t H,
                           int32_t W, int32_t cin, int32_t cout, int32_t mode, ufr_stream stream);
 
+/* CostRegNetWeight's two heads (module.py:541-543: `features` 8 -> 8 and `weights` 8 -> 1 on the same input) in one pass:
+ * d_weight (8,8,3,3,3) += d_out x in, d_weight2 (1,8,3,3,3) += d_out2 x in per tap; in (B,D,H,W,8), d_out (B,D,H,W,8),
+ * d_out2 (B,D,H,W,1) channel-last.  Both are ACCUMULATED into.  (ABI 503)                                                  */
+int ufr_conv3d_bwd_weight_heads(const float* in, const float* d_out, const float* d_out2, float* d_weight, float* d_weight2, int32_t B,
+                                int32_t D, int32_t H, int32_t W, ufr_stream stream);
+
 /* ---- the same layers on the 16-bit matrix cores (ABI 503) -------------------------------------------------------
  * The stride-1 layers of the U-Nets (module.py:469-543: conv2, conv4, conv6, `prob`, `features` + `weights`; and, with
  * flip != 0, their data gradients) as an implicit GEMM on

@@ -127,6 +127,7 @@ SIGNATURES = {
     "ufr_absmax": (C.c_int, [vp, sz, vp, vp]),
     "ufr_conv3d_bwd_data": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ufr_conv3d_bwd_weight": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ufr_conv3d_bwd_weight_heads": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ufr_tsdf_integrate": (C.c_int, [vp, vp, vp, C.POINTER(i32), C.POINTER(C.c_float), C.c_float, C.c_float,
                                      C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp, i32, i32, C.c_float, i32, vp]),
     "ufr_pixelwise_view_weights": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),

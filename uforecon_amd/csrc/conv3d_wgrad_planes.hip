@@ -34,6 +34,8 @@ typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
 
 struct WgPlanesArgs {
+  const float* tp2;    // HEADS: a second, one-channel TP tensor [B][Dp][Hp][Wp] = row CA of the product (CostRegNetWeight's
+  float* dw2;          //        `weights` head beside `features`: one pass over the shared input), its gradient [1][CB][27]
   const float* tp;     // [B][Dp][Hp][Wp][CA]
   const float* tq;     // [B][Dq][Hq][Wq][CB]
   float* dw;           // [CA][CB][27], accumulated into
@@ -108,8 +110,9 @@ struct WgCfg {
 #ifndef UFR_WGP_ABL
 #define UFR_WGP_ABL 0   // development ablations (timing only): 1 = no slot loop, 2 = no halo staging, 3 = no flush
 #endif
-template <int CA, int CB, int S, int NA, int NTAP>
+template <int CA, int CB, int S, int NA, int NTAP, bool HEADS = false>
 __global__ void __launch_bounds__(256, 2) conv3d_wgrad_planes_kernel(WgPlanesArgs a) {
+  static_assert(!HEADS || (CA == 8 && NA == 1), "the two heads: 8 + 1 rows of one tile");
   typedef WgCfg<CA, CB, S, NA, NTAP> Cf;
   constexpr int CBL = Cf::CBL, NSLOT = Cf::NSLOT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -203,6 +206,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_wgrad_planes_kernel(WgPlanesArg
     const int by = kk % a.nby; kk /= a.nby;
     const int bz = kk % a.nbz, bi = kk / a.nbz;
     const __amdgpu_buffer_rsrc_t rp = buf_rsrc(reinterpret_cast<const char*>(a.tp) + (size_t)bi * p_frame, (unsigned)p_frame);
+    const __amdgpu_buffer_rsrc_t rp2 = buf_rsrc(reinterpret_cast<const char*>(HEADS ? a.tp2 : a.tp) + (size_t)bi * (p_frame / CA), (unsigned)(p_frame / CA));
 #pragma unroll
     for (int rr = 0; rr < kRows; ++rr) {
       const int row = wave + 4 * rr;
@@ -215,7 +219,12 @@ __global__ void __launch_bounds__(256, 2) conv3d_wgrad_planes_kernel(WgPlanesArg
           const int px = bx * Cf::TX + 16 * c + j;
           const int ch = a0 + 16 * t + 4 * g;
           const unsigned vo = (unsigned)(((pz * a.Hp + py) * a.Wp + px) * CA);
-          if constexpr (CA % 4 == 0) {
+          if constexpr (HEADS) {      // lane groups 0, 1: the 8-channel head; lane group 2, register 0: the 1-channel one
+            f32x4 v = buf_ld4(rp, (rok && px < a.Wp && g < 2) ? (vo + ch) * 4u : kBufOut);
+            const float w1 = buf_ld1(rp2, (rok && px < a.Wp && g == 2) ? (vo / CA) * 4u : kBufOut);
+            if (g == 2) v = f32x4{w1, 0.f, 0.f, 0.f};
+            tpn[rr][t][c] = v;
+          } else if constexpr (CA % 4 == 0) {
             tpn[rr][t][c] = buf_ld4(rp, (rok && px < a.Wp && ch < CA) ? (vo + ch) * 4u : kBufOut);
           } else {      // CA = 1 (the weights head): one channel, in lane group 0
             tpn[rr][t][c] = f32x4{buf_ld1(rp, (rok && px < a.Wp && ch == 0) ? vo * 4u : kBufOut), 0.f, 0.f, 0.f};
@@ -379,15 +388,16 @@ __global__ void __launch_bounds__(256, 2) conv3d_wgrad_planes_kernel(WgPlanesArg
     const int ach = a0 + row, bch = b0 + bl, tap = tap0 + tl;
     const float x = stage[e];
     if (ach < CA && bch < CB && tap < 27 && x != 0.f) atomicAdd(a.dw + ((size_t)ach * CB + bch) * 27 + tap, x);
+    if (HEADS && ach == CA && bch < CB && tap < 27 && x != 0.f) atomicAdd(a.dw2 + (size_t)bch * 27 + tap, x);
   }
   if (do_bias && tid < NA * 16 && a0 + tid < CA) atomicAdd(a.dbias + a0 + tid, stage[kStageF + tid]);
 }
 
-template <int CA, int CB, int S, int NA, int NTAP>
+template <int CA, int CB, int S, int NA, int NTAP, bool HEADS = false>
 hipError_t launch_wgp_t(WgPlanesArgs a, hipStream_t s) {
   typedef WgCfg<CA, CB, S, NA, NTAP> Cf;
   static LdsAttrOnce lds_attr;
-  if (const hipError_t e = lds_attr.set(reinterpret_cast<const void*>(&conv3d_wgrad_planes_kernel<CA, CB, S, NA, NTAP>), Cf::lds); e != hipSuccess)
+  if (const hipError_t e = lds_attr.set(reinterpret_cast<const void*>(&conv3d_wgrad_planes_kernel<CA, CB, S, NA, NTAP, HEADS>), Cf::lds); e != hipSuccess)
     return e;
   a.nbx = (a.Wp + Cf::TX - 1) / Cf::TX; a.nby = (a.Hp + Cf::TY - 1) / Cf::TY; a.nbz = (a.Dp + Cf::TZ - 1) / Cf::TZ;
   const long long bricks = (long long)a.nbx * a.nby * a.nbz * a.B;
@@ -397,7 +407,7 @@ hipError_t launch_wgp_t(WgPlanesArgs a, hipStream_t s) {
   long long bx = 512 / Cf::kinds;
   if (bx > (bricks + 3) / 4) bx = (bricks + 3) / 4;
   bx = (bx + 7) / 8 * 8;                     // a multiple of the 8 XCDs (contiguous runs per XCD)
-  hipLaunchKernelGGL((conv3d_wgrad_planes_kernel<CA, CB, S, NA, NTAP>), dim3((unsigned)bx, Cf::kinds), dim3(256), Cf::lds, s, a);
+  hipLaunchKernelGGL((conv3d_wgrad_planes_kernel<CA, CB, S, NA, NTAP, HEADS>), dim3((unsigned)bx, Cf::kinds), dim3(256), Cf::lds, s, a);
   return hipGetLastError();
 }
 
@@ -409,6 +419,7 @@ hipError_t launch_conv3d_wgrad_planes(const float* tp, const float* tq, float* d
   // both tensors through 31-bit buffer offsets (per batch element)
   if ((long long)Dp * Hp * Wp * ca * 4 >= (1ll << 31) || (long long)Dq * Hq * Wq * cb * 4 >= (1ll << 31)) return hipErrorInvalidValue;
   WgPlanesArgs a;
+  a.tp2 = nullptr; a.dw2 = nullptr;
   a.tp = tp; a.tq = tq; a.dw = dw; a.dbias = dbias; a.B = B; a.Dp = Dp; a.Hp = Hp; a.Wp = Wp; a.Dq = Dq; a.Hq = Hq; a.Wq = Wq;
   a.nbx = a.nby = a.nbz = 0;
 #define UFR_WGP(CA_, CB_, S_, NA_, NT_) if (ca == CA_ && cb == CB_ && S == S_) return launch_wgp_t<CA_, CB_, S_, NA_, NT_>(a, s);
@@ -422,6 +433,18 @@ hipError_t launch_conv3d_wgrad_planes(const float* tp, const float* tq, float* d
   UFR_WGP(64, 32, 2, 2, 9)     // conv5, conv7
 #undef UFR_WGP
   return hipErrorInvalidValue;
+}
+
+// CostRegNetWeight's two heads on one input (module.py:541-543): d `features.weight` [8][8][27] and d `weights.weight`
+// [1][8][27] from d_out (B,D,H,W,8), d_out2 (B,D,H,W,1) and the shared input in ONE pass (the 1-channel head alone costs a
+// whole pass of its own: 0.49 ms at full resolution)
+hipError_t launch_conv3d_wgrad_heads(const float* in, const float* d_out, const float* d_out2, float* dw, float* dw2, int B, int D, int H,
+                                     int W, hipStream_t s) {
+  if ((long long)D * H * W * 8 * 4 >= (1ll << 31)) return hipErrorInvalidValue;
+  WgPlanesArgs a;
+  a.tp = d_out; a.tp2 = d_out2; a.tq = in; a.dw = dw; a.dw2 = dw2; a.dbias = nullptr;
+  a.B = B; a.Dp = D; a.Hp = H; a.Wp = W; a.Dq = D; a.Hq = H; a.Wq = W; a.nbx = a.nby = a.nbz = 0;
+  return launch_wgp_t<8, 8, 1, 1, 27, true>(a, s);
 }
 
 }  // namespace ufr

@@ -1225,6 +1225,17 @@ int ufr_conv3d_bwd_weight(const float* in, const float* d_out, float* d_weight, 
   return UFR_OK;
 }
 
+int ufr_conv3d_bwd_weight_heads(const float* in, const float* d_out, const float* d_out2, float* d_weight, float* d_weight2, int32_t B,
+                                int32_t D, int32_t H, int32_t W, ufr_stream stream) {
+  UFR_REQUIRE(in && d_out && d_out2 && d_weight && d_weight2, "ufr_conv3d_bwd_weight_heads: null argument");
+  UFR_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "ufr_conv3d_bwd_weight_heads: B=%d D=%d H=%d W=%d", B, D, H, W);
+  UFR_REQUIRE((long long)D * H * W * 32 < (1ll << 31), "ufr_conv3d_bwd_weight_heads: one batch element reaches 2 GiB");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ProfScope p("conv3d_wgrad", s);
+  UFR_HIP(launch_conv3d_wgrad_heads(in, d_out, d_out2, d_weight, d_weight2, B, D, H, W, s));
+  return UFR_OK;
+}
+
 // ------------------------------------------------------------------ TSDF fusion
 int ufr_tsdf_integrate(float* tsdf, float* weight, float* color, const int32_t* dim, const float* origin,
                        float voxel_size, float trunc_margin, const float* cam_intr, const float* cam_pose,

@@ -157,6 +157,8 @@ hipError_t launch_deform_conv3x3(const float* in_cl, const float* offset, const 
                                  const float* bias, float* out, int B, int C, int Cout, int H, int W, hipStream_t s,
                                  DcnEpilogue ep = DcnEpilogue{nullptr, nullptr, 0, 0, 0});
 size_t conv3d_planes_workspace_bytes(int cin, int cout, int cout2, int mode);
+hipError_t launch_conv3d_wgrad_heads(const float* in, const float* d_out, const float* d_out2, float* dw, float* dw2, int B, int D, int H,
+                                     int W, hipStream_t s);
 hipError_t launch_conv3d_wgrad_planes(const float* tp, const float* tq, float* dw, float* dbias, int B, int Dp, int Hp, int Wp, int Dq,
                                       int Hq, int Wq, int ca, int cb, int S, hipStream_t s);
 hipError_t launch_absmax(const float* x, size_t n, float* absmax, hipStream_t s);

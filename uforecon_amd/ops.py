@@ -902,6 +902,20 @@ def conv3d_bwd_data(d_out_cl: torch.Tensor, weight: torch.Tensor, mode: int, in_
     return d_in
 
 
+def conv3d_bwd_weight_heads(x_cl: torch.Tensor, d_out_cl: torch.Tensor, d_out2_cl: torch.Tensor):
+    """Weight gradients of CostRegNetWeight's two heads in one pass over the shared input (ufr_conv3d_bwd_weight_heads):
+    ``x_cl`` (B,D,H,W,8), ``d_out_cl`` (B,D,H,W,8), ``d_out2_cl`` (B,D,H,W,1) -> (d features.weight (8,8,3,3,3),
+    d weights.weight (1,8,3,3,3))."""
+    B, D, H, W, cin = x_cl.shape
+    if cin != 8 or tuple(d_out_cl.shape) != (B, D, H, W, 8) or tuple(d_out2_cl.shape) != (B, D, H, W, 1):
+        raise UfrError(f"conv3d_bwd_weight_heads: shapes {tuple(x_cl.shape)}, {tuple(d_out_cl.shape)}, {tuple(d_out2_cl.shape)}")
+    dw = torch.zeros(8, 8, 3, 3, 3, dtype=torch.float32, device=x_cl.device)
+    dw2 = torch.zeros(1, 8, 3, 3, 3, dtype=torch.float32, device=x_cl.device)
+    _lib.check(_lib.load().ufr_conv3d_bwd_weight_heads(_dev(x_cl, "in"), _dev(d_out_cl, "d_out"), _dev(d_out2_cl, "d_out2"), dw.data_ptr(),
+                                                       dw2.data_ptr(), B, D, H, W, _stream()), "ufr_conv3d_bwd_weight_heads")
+    return dw, dw2
+
+
 def conv3d_bwd_weight(x_cl: torch.Tensor, d_out_cl: torch.Tensor, mode: int, weight_shape, want_bias: bool = True):
     """Weight (and bias) gradient of one plain 3x3x3 layer (ufr_conv3d_bwd_weight) -> (d_weight in the checkpoint's
     layout, d_bias or None)."""

@@ -218,8 +218,7 @@ class CostRegNetWeightFn(torch.autograd.Function):
         d_f = cl(d_feat.float()) if d_feat is not None else zeros(8)
         # sigmoid'(z) = s (1 - s)
         d_w = cl((d_wsig.float() * wsig * (1.0 - wsig))) if d_wsig is not None else zeros(1)
-        grads["features.weight"] = ops.conv3d_bwd_weight(y, d_f, S1, P["features.weight"].shape, want_bias=False)[0]
-        grads["weights.weight"] = ops.conv3d_bwd_weight(y, d_w, S1, P["weights.weight"].shape, want_bias=False)[0]
+        grads["features.weight"], grads["weights.weight"] = ops.conv3d_bwd_weight_heads(y, d_f, d_w)     # one pass over y
         # the 1-channel head's adjoint on the fp32 kernel, then the 8-channel one on the matrix cores with the sum fused
         bounds = _Bounds()
         d_y = ops.conv3d_bwd_data(d_w, P["weights.weight"], S1, tuple(y.shape))

@@ -364,7 +364,7 @@ def test_header_is_usable_from_plain_c(lib, tmp_path):
     header = open(os.path.join(root, "include", "ufr.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)                       # declarations only, not the prose around them
     names = sorted(set(re.findall(r"\b(ufr_[a-z0-9_]+)\s*\(", header)))
-    assert len(names) >= 68 and "ufr_conv3d_planes" in names and "ufr_conv3d_bwd_weight" in names and "ufr_weights_fit_frame" in names
+    assert len(names) >= 69 and "ufr_conv3d_bwd_weight_heads" in names and "ufr_conv3d_planes" in names and "ufr_conv3d_bwd_weight" in names and "ufr_weights_fit_frame" in names
     (tmp_path / "abi_syms.inc").write_text(",\n".join(f"(const void*){n}" for n in names) + "\n")
     subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-I", str(tmp_path),
                     os.path.join(root, "tests", "cabi", "abi_check.c"), "-L", libdir, "-lufr", f"-Wl,-rpath,{libdir}",

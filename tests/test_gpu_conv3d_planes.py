@@ -171,3 +171,42 @@ def test_planes_cache_follows_the_weight_tensor():
     y4, _ = ops.conv3d_planes(x, am, w2)
     ref4 = ops.conv3d(x, w2, ops.CONV3D_S1)
     assert float((y4 - ref4).abs().max()) < 1e-5 * float(ref4.abs().max()), (ptr, w2.data_ptr())
+
+
+@pytest.mark.parametrize("cin,cout,mode,shape", [(8, 8, 0, (2, 3, 10, 70)), (16, 16, 0, (1, 4, 9, 37)), (32, 32, 0, (2, 2, 6, 20)), (64, 64, 0, (1, 2, 5, 18)),
+                                                 (8, 16, 1, (1, 4, 8, 64)), (16, 32, 1, (2, 2, 8, 36)), (32, 64, 1, (1, 2, 4, 20)),
+                                                 (16, 8, 2, (1, 2, 4, 32)), (32, 16, 2, (2, 1, 4, 18)), (64, 32, 2, (1, 1, 4, 16)), (8, 1, 0, (2, 3, 10, 70))])
+def test_weight_gradient_on_the_matrix_cores_matches_float64(cin, cout, mode, shape):
+    """ufr_conv3d_bwd_weight now runs csrc/conv3d_wgrad_planes.hip for every layer shape but conv0: d weight (and d bias)
+    against a float64 autograd of the same layer; operands carry 16 significand bits (bf16 hi + lo), the sum is fp32."""
+    from uforecon_amd import ops
+
+    torch.manual_seed(7 * cin + cout + mode)
+    B, D, H, W = shape
+    x = torch.randn(B, D, H, W, cin, device=DEV)
+    wshape = (cin, cout, 3, 3, 3) if mode == 2 else (cout, cin, 3, 3, 3)
+    w = torch.zeros(wshape, dtype=torch.float64, device=DEV, requires_grad=True)
+    b = torch.zeros(cout, dtype=torch.float64, device=DEV, requires_grad=True)
+    xp = x.double().permute(0, 4, 1, 2, 3)
+    F = torch.nn.functional
+    y = (F.conv_transpose3d(xp, w, b, stride=2, padding=1, output_padding=1) if mode == 2 else F.conv3d(xp, w, b, stride=1 + mode, padding=1))
+    dy = torch.randn(y.shape, device=DEV).float()
+    (y * dy.double()).sum().backward()
+    dw, db = ops.conv3d_bwd_weight(x, dy.permute(0, 2, 3, 4, 1).contiguous(), mode, wshape)
+    ew = float((dw.double() - w.grad).abs().max() / w.grad.abs().max())
+    eb = float((db.double() - b.grad).abs().max() / b.grad.abs().max())
+    print(f"wgrad cin {cin} cout {cout} mode {mode} {shape}: d weight {ew:.2e}, d bias {eb:.2e} of scale")
+    assert ew < 2e-5 and eb < 2e-5
+
+
+def test_heads_weight_gradients_in_one_pass():
+    from uforecon_amd import ops
+
+    torch.manual_seed(11)
+    B, D, H, W = 2, 3, 9, 40
+    x = torch.randn(B, D, H, W, 8, device=DEV)
+    df, dw1 = torch.randn(B, D, H, W, 8, device=DEV), torch.randn(B, D, H, W, 1, device=DEV)
+    gf, gw = ops.conv3d_bwd_weight_heads(x, df, dw1)
+    rf = ops.conv3d_bwd_weight(x, df, ops.CONV3D_S1, (8, 8, 3, 3, 3), want_bias=False)[0]
+    rw = ops.conv3d_bwd_weight(x, dw1, ops.CONV3D_S1, (1, 8, 3, 3, 3), want_bias=False)[0]
+    assert float((gf - rf).abs().max()) < 1e-5 * float(rf.abs().max()) and float((gw - rw).abs().max()) < 1e-5 * float(rw.abs().max())

@@ -11,7 +11,7 @@ import sys
 
 
 def short(name: str) -> str:
-    name = name.split("(")[0].strip()
+    name = name.replace("(anonymous namespace)::", "").split("(")[0].strip()
     for pre in ("void ", "ufr::"):
         name = name.replace(pre, "")
     return name[-60:]

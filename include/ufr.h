@@ -455,6 +455,8 @@ int ufr_frustum_correlate(const float* ref_fea, const float* src_fea, const floa
  *   out    channel-last [B][Do][Ho][Wo][cout]; with out_ncdhw != 0 the reference's (B,cout,Do,Ho,Wo) instead, and then
  *          weight2 (cout2,cin,3,3,3) / out2 (B,cout2,Do,Ho,Wo) may name a second head on the same input whose output goes
  *          through a sigmoid (CostRegNetWeight's `features` + `weights`, module.py:541-543) -- both heads in one pass.
+ *   out_absmax (nullable; ABI 503; channel-last outputs with at most 16 channels -- the vector kernel): a device float the
+ *          caller has zeroed, raised to max |out| (skip included): the bound ufr_conv3d_planes wants of its input.
  * Supported (cin, cout + cout2): the layers of the two networks with base_channels 8:
  *   S1: (1,8) (16,16) (32,32) (64,64) (8,1) (8,8) (8,8+1);  S2: (8,16) (16,32) (32,64);  T2: (64,32) (32,16) (16,8).    */
 #define UFR_CONV3D_S1 0
@@ -463,7 +465,7 @@ int ufr_frustum_correlate(const float* ref_fea, const float* src_fea, const floa
 int ufr_conv3d(const float* in, const float* weight, const float* weight2, const float* bias, const float* bn_scale,
                const float* bn_shift, const float* skip, float* out, float* out2, int32_t B, int32_t D, int32_t H,
                int32_t W, int32_t cin, int32_t cout, int32_t cout2, int32_t mode, int32_t relu, int32_t out_ncdhw,
-               ufr_stream stream);
+               float* out_absmax, ufr_stream stream);
 /* Backward of the plain layers (bias, no BatchNorm / activation): CostRegNetWeight, i.e. `feature_volume.cost_reg_2` -- the
  * one producer the reference trains (model.py:72-87; module.py:502-543).  B, D, H, W, cin, cout, mode describe the FORWARD
  * layer (its input extent and channels); tensors are channel-last.

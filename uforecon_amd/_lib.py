@@ -120,7 +120,7 @@ SIGNATURES = {
     "ufr_render_rays": (C.c_int, [C.POINTER(RenderArgs), vp]),
     "ufr_correlate_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "ufr_frustum_correlate": (C.c_int, [vp, vp, C.POINTER(C.c_float), vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
-    "ufr_conv3d": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ufr_conv3d": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "ufr_conv3d_planes_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "ufr_conv3d_planes": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp,
                                     sz, i32, vp]),

@@ -44,6 +44,8 @@ struct Conv3dArgs {
   int Do, Ho, Wo;       // output extent
   int cout_real, cout2; // real output channels of weight / weight2
   int relu, ncdhw;
+  unsigned* out_absmax; // (nullable) raised to max |out| of the channel-last stores of the vector kernel: the bound the plane
+                        // kernels (conv3d_planes.hip) want of their input, taken here instead of in a pass of its own
   int flip;             // stride-1 only: `weight` is the layer's FORWARD weight [cin of this launch][cout_real][27] and the taps
                         // are mirrored -- the data gradient of a stride-1 convolution (launch_conv3d_bwd_data)
 };
@@ -179,6 +181,7 @@ __global__ void __launch_bounds__(256) conv3d_kernel(Conv3dArgs a) {
   }
 
   // ---- epilogue: bias, folded BatchNorm, ReLU, skip, store
+  float omax = 0.f;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     if (!live[r]) continue;
@@ -213,11 +216,19 @@ __global__ void __launch_bounds__(256) conv3d_kernel(Conv3dArgs a) {
           f32x4 v = {y[4 * c4], y[4 * c4 + 1], y[4 * c4 + 2], y[4 * c4 + 3]};
           if (sk) v += ld4(sk + 4 * c4);
           st4(o + 4 * c4, v);
+          omax = fmaxf(omax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
         }
       }
     }
   }
+  if (a.out_absmax) {      // one guarded atomic per wave (prep.hip: wave_abs_max)
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) omax = fmaxf(omax, __shfl_xor(omax, s));
+    const unsigned bits = __builtin_bit_cast(unsigned, omax);
+    if ((threadIdx.x & 63) == 0 && bits > __atomic_load_n(a.out_absmax, __ATOMIC_RELAXED)) atomicMax(a.out_absmax, bits);
+  }
 }
+
 
 template <int CIN, int COUT, int MODE, int R>
 hipError_t launch_conv_t(const Conv3dArgs& a, hipStream_t s) {
@@ -366,9 +377,10 @@ hipError_t launch_conv_mfma_t(const Conv3dArgs& a, hipStream_t s) {
 // cout_pad: COUT of the instantiation (cout_real (+ cout2) rounded up to a multiple of 4)
 hipError_t launch_conv3d(const float* in, const float* weight, const float* weight2, const float* bias, const float* scale,
                          const float* shift, const float* skip, float* out, float* out2, int B, int D, int H, int W,
-                         int cin, int cout, int cout2, int mode, int relu, int ncdhw, hipStream_t s, int flip) {
+                         int cin, int cout, int cout2, int mode, int relu, int ncdhw, hipStream_t s, int flip, float* out_absmax) {
   Conv3dArgs a;
   a.flip = flip;
+  a.out_absmax = reinterpret_cast<unsigned*>(out_absmax);
   a.in = in; a.weight = weight; a.weight2 = weight2; a.bias = bias; a.scale = scale; a.shift = shift; a.skip = skip;
   a.out = out; a.out2 = out2; a.B = B; a.D = D; a.H = H; a.W = W;
   a.cout_real = cout; a.cout2 = cout2; a.relu = relu; a.ncdhw = ncdhw;
@@ -378,7 +390,7 @@ hipError_t launch_conv3d(const float* in, const float* weight, const float* weig
   const int ct = cout + cout2;
 #ifndef UFR_CONV3D_VALU_ONLY
   // whole 16-channel blocks on both sides, channel-last output, one head: the matrix-core kernel
-  if (!ncdhw && cout2 == 0 && weight2 == nullptr) {
+  if (!ncdhw && cout2 == 0 && weight2 == nullptr && out_absmax == nullptr) {
 #define UFR_MFMA_CASE(CI, CO, MO) if (cin == CI && cout == CO && mode == MO) return launch_conv_mfma_t<CI, CO, MO>(a, s);
     // where it wins (per-layer table of tools/dev/conv3d_bwd_probe.py, 3 x 8 x 512 x 640 stage): the stride-1 and stride-2
     // layers from 32 channels up -- 64 -> 64 0.48 -> 0.17 ms, 32 -> 64 0.30 -> 0.09, 32 -> 32 0.22 -> 0.17, 16 -> 32 0.125

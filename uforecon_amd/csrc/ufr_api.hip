@@ -1135,7 +1135,7 @@ int ufr_frustum_correlate(const float* ref_fea, const float* src_fea, const floa
 int ufr_conv3d(const float* in, const float* weight, const float* weight2, const float* bias, const float* bn_scale,
                const float* bn_shift, const float* skip, float* out, float* out2, int32_t B, int32_t D, int32_t H,
                int32_t W, int32_t cin, int32_t cout, int32_t cout2, int32_t mode, int32_t relu, int32_t out_ncdhw,
-               ufr_stream stream) {
+               float* out_absmax, ufr_stream stream) {
   UFR_REQUIRE(in && weight && out, "ufr_conv3d: null argument");
   UFR_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "ufr_conv3d: B=%d D=%d H=%d W=%d", B, D, H, W);
   UFR_REQUIRE(mode == UFR_CONV3D_S1 || mode == UFR_CONV3D_S2 || mode == UFR_CONV3D_T2, "ufr_conv3d: unknown mode %d", mode);
@@ -1147,8 +1147,9 @@ int ufr_conv3d(const float* in, const float* weight, const float* weight2, const
   UFR_REQUIRE((long long)B * D * H * W * (cin > cout ? cin : cout) < (1ll << 40), "ufr_conv3d: volume too large");
   hipStream_t s = static_cast<hipStream_t>(stream);
   ProfScope p("conv3d", s);
+  UFR_REQUIRE(!out_absmax || (!out_ncdhw && cout <= 16), "ufr_conv3d: out_absmax goes with channel-last outputs of at most 16 channels");
   const hipError_t e = launch_conv3d(in, weight, weight2, bias, bn_scale, bn_shift, skip, out, out2, B, D, H, W, cin, cout,
-                                     cout2, mode, relu, out_ncdhw, s);
+                                     cout2, mode, relu, out_ncdhw, s, 0, out_absmax);
   if (e == hipErrorInvalidValue)
     return fail(UFR_ERR_ARG, "ufr_conv3d: (cin %d, cout %d+%d, mode %d) is not a layer of CostRegNet / CostRegNetWeight", cin,
                 cout, cout2, mode);

@@ -168,7 +168,8 @@ hipError_t launch_conv3d_planes(const float* in, const float* in_absmax, const f
                                 void* ws, int planes_ready, hipStream_t s);
 hipError_t launch_conv3d(const float* in, const float* weight, const float* weight2, const float* bias, const float* scale,
                          const float* shift, const float* skip, float* out, float* out2, int B, int D, int H, int W,
-                         int cin, int cout, int cout2, int mode, int relu, int ncdhw, hipStream_t s, int flip = 0);
+                         int cin, int cout, int cout2, int mode, int relu, int ncdhw, hipStream_t s, int flip = 0,
+                         float* out_absmax = nullptr);
 hipError_t launch_conv3d_bwd_data(const float* d_out, const float* weight, const float* accumulate, float* d_in, int B, int D,
                                   int H, int W, int cin, int cout, int mode, hipStream_t s);
 hipError_t launch_conv3d_bwd_weight(const float* in, const float* d_out, float* d_weight, float* d_bias, int B, int D, int H, int W,

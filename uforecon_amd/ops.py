@@ -721,8 +721,10 @@ CONV3D_S1, CONV3D_S2, CONV3D_T2 = 0, 1, 2
 
 def conv3d(x_cl: torch.Tensor, weight: torch.Tensor, mode: int = CONV3D_S1, bias: Optional[torch.Tensor] = None,
            bn_scale: Optional[torch.Tensor] = None, bn_shift: Optional[torch.Tensor] = None, relu: bool = False,
-           skip: Optional[torch.Tensor] = None, out_ncdhw: bool = False, weight2: Optional[torch.Tensor] = None):
-    """One 3x3x3 layer of the frustum U-Nets (ufr_conv3d).  ``x_cl`` (B,D,H,W,cin) channel-last; ``weight`` in the
+           skip: Optional[torch.Tensor] = None, out_ncdhw: bool = False, weight2: Optional[torch.Tensor] = None,
+           want_absmax: bool = False):
+    """One 3x3x3 layer of the frustum U-Nets (ufr_conv3d).  ``want_absmax`` (channel-last outputs of at most 16 channels):
+    returns ``(out, max |out| as a one-element device tensor)`` -- the bound a following plane layer wants.  ``x_cl`` (B,D,H,W,cin) channel-last; ``weight`` in the
     checkpoint's layout (conv (cout,cin,3,3,3); transposed conv, mode CONV3D_T2, (cin,cout,3,3,3)).  Returns the
     channel-last (B,Do,Ho,Wo,cout) output, or with ``out_ncdhw`` the reference's (B,cout,Do,Ho,Wo) -- and, when ``weight2``
     names a second head, the pair (out, sigmoid(second head))."""
@@ -744,9 +746,12 @@ def conv3d(x_cl: torch.Tensor, weight: torch.Tensor, mode: int = CONV3D_S1, bias
     ptr = lambda t, n: None if t is None else _dev(next(it), n)
     w_p, w2_p, b_p, s_p, h_p = ptr(weight, "weight"), ptr(weight2, "weight2"), ptr(bias, "bias"), ptr(bn_scale, "bn_scale"), \
         ptr(bn_shift, "bn_shift")
+    omax = torch.zeros(1, dtype=torch.float32, device=dev) if want_absmax else None
     _lib.check(_lib.load().ufr_conv3d(_dev(x_cl, "x"), w_p, w2_p, b_p, s_p, h_p, _opt(skip, "skip"), out.data_ptr(),
                                       _opt(out2, "out2"), B, D, H, W, cin, cout, cout2, int(mode), int(bool(relu)),
-                                      int(bool(out_ncdhw)), _stream()), "ufr_conv3d")
+                                      int(bool(out_ncdhw)), _opt(omax, "out_absmax"), _stream()), "ufr_conv3d")
+    if want_absmax:
+        return out, omax
     return (out, out2) if cout2 else out
 
 

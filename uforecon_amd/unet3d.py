@@ -81,6 +81,11 @@ def _s1(t, weight, planes: bool, bounds: "_Bounds" = None, **kw):
         return r[0]
     if flip:
         return ops.conv3d_bwd_data(t, weight, S1, (*t.shape[:4], cout), accumulate=kw.get("skip"))
+    if planes and bounds is not None and cout <= 16 and w2 is None and not kw.get("out_ncdhw"):
+        # an fp32-kernel layer in front of plane layers (conv0): its store takes the bound the next layer wants
+        out, omax = ops.conv3d(t, weight, S1, want_absmax=True, **kw)
+        bounds.put(out, omax)
+        return out
     return ops.conv3d(t, weight, S1, **kw)
 
 

@@ -60,3 +60,17 @@ def test_render_loss_is_deterministic_and_rejects_bad_shapes():
         ops.render_loss(t["rgb"][:, :5], t["depth"], t["rgb2"], t["depth2"], t["rgb_gt"], t["depth_gt"], t["nf"])
     with pytest.raises(Exception):
         ops.render_loss(t["rgb"].cpu(), t["depth"].cpu(), t["rgb2"].cpu(), t["depth2"].cpu(), t["rgb_gt"].cpu(), t["depth_gt"].cpu(), t["nf"].cpu())
+
+
+def test_render_loss_second_backward_is_an_error_not_a_type_error():
+    """The node frees its stored cotangents in the first backward (like any saved buffer): differentiating the same loss
+    again says so."""
+    from uforecon_amd import autograd as ag
+
+    t = _case(1, 64, 5)
+    ins = [t[k].clone().requires_grad_(True) for k in ("rgb", "depth", "rgb2", "depth2")]
+    loss, _ = ag.RenderLoss.apply(*ins, t["rgb_gt"], t["depth_gt"], t["nf"], 1.0, 1.0)
+    loss.backward(retain_graph=True)
+    assert all(x.grad is not None for x in ins)
+    with pytest.raises(RuntimeError, match="second time"):
+        loss.backward()

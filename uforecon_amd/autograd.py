@@ -365,6 +365,9 @@ class RenderLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gparts):
         cot, ctx.cot = ctx.cot, None
+        if cot is None:      # the stored cotangents are released by the first backward, like any saved buffer
+            raise RuntimeError("RenderLoss: backward through this loss a second time -- its stored cotangents were freed by the "
+                               "first call (compute the loss again, or differentiate it once)")
         if g is None:
             return (None,) * 9
         need = ctx.needs_input_grad[:4]

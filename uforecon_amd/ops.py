@@ -82,6 +82,11 @@ def status_poll(synchronize: bool = True, mask: int = 7) -> int:
     return int(flags.value)
 
 
+import itertools
+
+_PACK_SERIAL = itertools.count(1)
+
+
 class PackedWeights:
     """ufr_raw_weights (pointers into the live parameters) + the MFMA-ordered packed copy.  ``precision``: the matrix
     precision the calls made with these weights use (None = the process default at call time).  ``input_abs_max``: an
@@ -110,6 +115,7 @@ class PackedWeights:
         C.memmove(C.byref(self.raw), (C.c_void_p * 40)(*ptrs), C.sizeof(self.raw))
         self.device = self._keep[0].device
         self.packed = torch.empty(lib.ufr_packed_weights_bytes() // 4, dtype=torch.float32, device=self.device)
+        self.serial = next(_PACK_SERIAL)
         self.epoch = 0          # bumped by every pack: a frame is fitted once per (frame, epoch)
         self.repack(check=True)
 
@@ -130,7 +136,7 @@ class PackedWeights:
     def fit(self, frame: "FrameHandle") -> None:
         """The activation exponents follow ``frame``'s measured feature bound (ufr_weights_fit_frame): one tiny asynchronous
         kernel, issued once per (frame, pack) -- a no-op on the device unless the frame exceeds the bound the table serves."""
-        key = (id(self), self.epoch)
+        key = (self.serial, self.epoch)       # a process-wide serial number, not id(self): an id is reused after collection
         if key in frame._fitted:
             return
         _lib.check(_lib.load().ufr_weights_fit_frame(self.packed.data_ptr(), C.byref(frame.frame), _stream()), "ufr_weights_fit_frame")

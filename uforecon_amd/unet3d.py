@@ -206,15 +206,17 @@ class CostRegNetWeightFn(torch.autograd.Function):
 
         y = _unet(x_cl, layer)
         feat, wsig = _s1(y, P["features.weight"], True, bounds, out_ncdhw=True, weight2=P["weights.weight"])
-        ctx.acts, ctx.y, ctx.params = acts, y, params
-        ctx.save_for_backward(wsig)
+        ctx.acts, ctx.y = acts, y
+        # the parameters through save_for_backward: an in-place update between this forward and its backward (an optimizer
+        # step in between) is then an error, not a backward on new weights with old activations
+        ctx.save_for_backward(wsig, *params)
         ctx.x_needs_grad = x.requires_grad
         return feat, wsig
 
     @staticmethod
     def backward(ctx, d_feat, d_wsig):
-        (wsig,) = ctx.saved_tensors
-        P = dict(zip(_PARAM_NAMES, ctx.params))
+        wsig, *params = ctx.saved_tensors
+        P = dict(zip(_PARAM_NAMES, params))
         acts, y = ctx.acts, ctx.y
         B, D, H, W, _ = y.shape
         grads = {}
@@ -256,7 +258,7 @@ class CostRegNetWeightFn(torch.autograd.Function):
         if d_x is not None:
             d_x = d_x.view(B, D, H, W, 1).permute(0, 4, 1, 2, 3)
         need = ctx.needs_input_grad[1:]
-        return (d_x, *[(grads[n].reshape(p.shape) if nd else None) for n, p, nd in zip(_PARAM_NAMES, ctx.params, need)])
+        return (d_x, *[(grads[n].reshape(p.shape) if nd else None) for n, p, nd in zip(_PARAM_NAMES, params, need)])
 
 
 def cost_reg_net_weight(m, x: torch.Tensor):

@@ -752,11 +752,12 @@ def conv3d(x_cl: torch.Tensor, weight: torch.Tensor, mode: int = CONV3D_S1, bias
     ptr = lambda t, n: None if t is None else _dev(next(it), n)
     w_p, w2_p, b_p, s_p, h_p = ptr(weight, "weight"), ptr(weight2, "weight2"), ptr(bias, "bias"), ptr(bn_scale, "bn_scale"), \
         ptr(bn_shift, "bn_shift")
-    omax = torch.zeros(1, dtype=torch.float32, device=dev) if want_absmax else None
+    # (want_absmax: True = a fresh zero word; or a caller-owned one-element ZERO tensor, e.g. a slice of a pool zeroed once)
+    omax = want_absmax if isinstance(want_absmax, torch.Tensor) else (torch.zeros(1, dtype=torch.float32, device=dev) if want_absmax else None)
     _lib.check(_lib.load().ufr_conv3d(_dev(x_cl, "x"), w_p, w2_p, b_p, s_p, h_p, _opt(skip, "skip"), out.data_ptr(),
                                       _opt(out2, "out2"), B, D, H, W, cin, cout, cout2, int(mode), int(bool(relu)),
                                       int(bool(out_ncdhw)), _opt(omax, "out_absmax"), _stream()), "ufr_conv3d")
-    if want_absmax:
+    if omax is not None:
         return out, omax
     return (out, out2) if cout2 else out
 
@@ -829,7 +830,9 @@ def conv3d_planes(x_cl: torch.Tensor, x_absmax: torch.Tensor, weight: torch.Tens
     if skip is not None and tuple(skip.shape) != tuple(out.shape):
         raise UfrError(f"conv3d_planes: skip {tuple(skip.shape)} does not match the output {tuple(out.shape)}")
     ws, ready = _planes_lookup(weight, weight2, flip, nbytes, mode == CONV3D_T2)
-    omax = torch.zeros(1, dtype=torch.float32, device=dev) if (want_absmax and not out_ncdhw) else None
+    omax = None
+    if not out_ncdhw:
+        omax = want_absmax if isinstance(want_absmax, torch.Tensor) else (torch.zeros(1, dtype=torch.float32, device=dev) if want_absmax else None)
     keep = [t.detach().contiguous() for t in (weight, weight2, bias, bn_scale, bn_shift) if t is not None]
     it = iter(keep)
     ptr = lambda t, n: None if t is None else _dev(next(it), n)
@@ -913,27 +916,31 @@ def conv3d_bwd_data(d_out_cl: torch.Tensor, weight: torch.Tensor, mode: int, in_
     return d_in
 
 
-def conv3d_bwd_weight_heads(x_cl: torch.Tensor, d_out_cl: torch.Tensor, d_out2_cl: torch.Tensor):
+def conv3d_bwd_weight_heads(x_cl: torch.Tensor, d_out_cl: torch.Tensor, d_out2_cl: torch.Tensor, out=None):
     """Weight gradients of CostRegNetWeight's two heads in one pass over the shared input (ufr_conv3d_bwd_weight_heads):
     ``x_cl`` (B,D,H,W,8), ``d_out_cl`` (B,D,H,W,8), ``d_out2_cl`` (B,D,H,W,1) -> (d features.weight (8,8,3,3,3),
     d weights.weight (1,8,3,3,3))."""
     B, D, H, W, cin = x_cl.shape
     if cin != 8 or tuple(d_out_cl.shape) != (B, D, H, W, 8) or tuple(d_out2_cl.shape) != (B, D, H, W, 1):
         raise UfrError(f"conv3d_bwd_weight_heads: shapes {tuple(x_cl.shape)}, {tuple(d_out_cl.shape)}, {tuple(d_out2_cl.shape)}")
-    dw = torch.zeros(8, 8, 3, 3, 3, dtype=torch.float32, device=x_cl.device)
-    dw2 = torch.zeros(1, 8, 3, 3, 3, dtype=torch.float32, device=x_cl.device)
+    # out = (dw, dw2): caller-owned ZEROED tensors of those shapes (slices of one buffer zeroed once per backward)
+    dw, dw2 = out if out is not None else (torch.zeros(8, 8, 3, 3, 3, dtype=torch.float32, device=x_cl.device),
+                                           torch.zeros(1, 8, 3, 3, 3, dtype=torch.float32, device=x_cl.device))
     _lib.check(_lib.load().ufr_conv3d_bwd_weight_heads(_dev(x_cl, "in"), _dev(d_out_cl, "d_out"), _dev(d_out2_cl, "d_out2"), dw.data_ptr(),
                                                        dw2.data_ptr(), B, D, H, W, _stream()), "ufr_conv3d_bwd_weight_heads")
     return dw, dw2
 
 
-def conv3d_bwd_weight(x_cl: torch.Tensor, d_out_cl: torch.Tensor, mode: int, weight_shape, want_bias: bool = True):
+def conv3d_bwd_weight(x_cl: torch.Tensor, d_out_cl: torch.Tensor, mode: int, weight_shape, want_bias: bool = True, out=None):
     """Weight (and bias) gradient of one plain 3x3x3 layer (ufr_conv3d_bwd_weight) -> (d_weight in the checkpoint's
     layout, d_bias or None)."""
     B, D, H, W, cin = x_cl.shape
     cout = d_out_cl.shape[-1]
-    dw = torch.zeros(weight_shape, dtype=torch.float32, device=x_cl.device)
-    db = torch.zeros(cout, dtype=torch.float32, device=x_cl.device) if want_bias else None
+    if out is not None:      # (dw, db): caller-owned ZEROED tensors (slices of one buffer zeroed once per backward)
+        dw, db = out
+    else:
+        dw = torch.zeros(weight_shape, dtype=torch.float32, device=x_cl.device)
+        db = torch.zeros(cout, dtype=torch.float32, device=x_cl.device) if want_bias else None
     _lib.check(_lib.load().ufr_conv3d_bwd_weight(_dev(x_cl, "in"), _dev(d_out_cl, "d_out"), dw.data_ptr(), _opt(db, "d_bias"),
                                                  B, D, H, W, cin, cout, int(mode), _stream()), "ufr_conv3d_bwd_weight")
     return dw, db

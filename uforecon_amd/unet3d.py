@@ -51,6 +51,15 @@ class _Bounds:
 
     def __init__(self):
         self._b = {}
+        self._pool, self._next = None, 0
+
+    def slot(self, like: torch.Tensor):
+        """A zeroed one-element device tensor for a layer's out_absmax: slices of ONE buffer zeroed once per U-Net call (a
+        `torch.zeros(1)` per layer was 60 fill launches per training step)."""
+        if self._pool is None or self._next >= self._pool.numel():
+            self._pool, self._next = torch.zeros(64, dtype=torch.float32, device=like.device), 0
+        self._next += 1
+        return self._pool[self._next - 1:self._next]
 
     def of(self, t):
         hit = self._b.get(id(t))
@@ -74,7 +83,7 @@ def _s1(t, weight, planes: bool, bounds: "_Bounds" = None, **kw):
     cout = weight.shape[1] if flip else weight.shape[0]
     if planes and ops.conv3d_planes_supported(cin, cout, 0 if w2 is None else w2.shape[0], S1):
         b = bounds if bounds is not None else _Bounds()
-        r = ops.conv3d_planes(t, b.of(t), weight, flip=flip, want_absmax=bounds is not None, **kw)
+        r = ops.conv3d_planes(t, b.of(t), weight, flip=flip, want_absmax=(b.slot(t) if bounds is not None and not kw.get("out_ncdhw") else False), **kw)
         if w2 is not None:
             return r[0], r[1]
         b.put(r[0], r[1])
@@ -83,7 +92,7 @@ def _s1(t, weight, planes: bool, bounds: "_Bounds" = None, **kw):
         return ops.conv3d_bwd_data(t, weight, S1, (*t.shape[:4], cout), accumulate=kw.get("skip"))
     if planes and bounds is not None and cout <= 16 and w2 is None and not kw.get("out_ncdhw"):
         # an fp32-kernel layer in front of plane layers (conv0): its store takes the bound the next layer wants
-        out, omax = ops.conv3d(t, weight, S1, want_absmax=True, **kw)
+        out, omax = ops.conv3d(t, weight, S1, want_absmax=bounds.slot(t), **kw)
         bounds.put(out, omax)
         return out
     return ops.conv3d(t, weight, S1, **kw)
@@ -93,7 +102,7 @@ def _s2(t, weight, planes: bool, bounds: "_Bounds" = None, **kw):
     """One stride-2 layer (conv1 / conv3 / conv5), the same way.  ``weight`` (cout, cin, 3,3,3)."""
     if planes and ops.conv3d_planes_supported(t.shape[-1], weight.shape[0], 0, S2):
         b = bounds if bounds is not None else _Bounds()
-        out, omax = ops.conv3d_planes(t, b.of(t), weight, want_absmax=bounds is not None, mode=S2, **kw)
+        out, omax = ops.conv3d_planes(t, b.of(t), weight, want_absmax=(b.slot(t) if bounds is not None else False), mode=S2, **kw)
         b.put(out, omax)
         return out
     return ops.conv3d(t, weight, S2, **kw)
@@ -103,7 +112,7 @@ def _t2(t, weight, planes: bool, bounds: "_Bounds" = None, **kw):
     """One transposed stride-2 layer (conv7 / conv9 / conv11); ``weight`` (cin, cout, 3,3,3)."""
     if planes and ops.conv3d_planes_supported(t.shape[-1], weight.shape[1], 0, T2):
         b = bounds if bounds is not None else _Bounds()
-        out, omax = ops.conv3d_planes(t, b.of(t), weight, want_absmax=bounds is not None, mode=T2, **kw)
+        out, omax = ops.conv3d_planes(t, b.of(t), weight, want_absmax=(b.slot(t) if bounds is not None else False), mode=T2, **kw)
         b.put(out, omax)
         return out
     return ops.conv3d(t, weight, T2, **kw)
@@ -123,7 +132,7 @@ def _s2_bwd_data(d_out, weight, in_shape, accumulate=None, bounds: "_Bounds" = N
     cout, cin = weight.shape[0], weight.shape[1]
     if ops.conv3d_planes_supported(cout, cin, 0, T2) and tuple(in_shape[1:4]) == tuple(2 * n for n in d_out.shape[1:4]):
         b = bounds if bounds is not None else _Bounds()
-        out, omax = ops.conv3d_planes(d_out, b.of(d_out), weight, skip=accumulate, want_absmax=bounds is not None, mode=T2)
+        out, omax = ops.conv3d_planes(d_out, b.of(d_out), weight, skip=accumulate, want_absmax=(b.slot(d_out) if bounds is not None else False), mode=T2)
         b.put(out, omax)
         return out
     return ops.conv3d_bwd_data(d_out, weight, S2, in_shape, accumulate=accumulate)
@@ -135,7 +144,7 @@ def _t2_bwd_data(d_out, weight, in_shape, accumulate=None, bounds: "_Bounds" = N
     cin, cout = weight.shape[0], weight.shape[1]
     if ops.conv3d_planes_supported(cout, cin, 0, S2):
         b = bounds if bounds is not None else _Bounds()
-        out, omax = ops.conv3d_planes(d_out, b.of(d_out), weight, skip=accumulate, want_absmax=bounds is not None, mode=S2)
+        out, omax = ops.conv3d_planes(d_out, b.of(d_out), weight, skip=accumulate, want_absmax=(b.slot(d_out) if bounds is not None else False), mode=S2)
         b.put(out, omax)
         return out
     return ops.conv3d_bwd_data(d_out, weight, T2, in_shape, accumulate=accumulate)
@@ -225,7 +234,15 @@ class CostRegNetWeightFn(torch.autograd.Function):
         d_f = cl(d_feat.float()) if d_feat is not None else zeros(8)
         # sigmoid'(z) = s (1 - s)
         d_w = cl((d_wsig.float() * wsig * (1.0 - wsig))) if d_wsig is not None else zeros(1)
-        grads["features.weight"], grads["weights.weight"] = ops.conv3d_bwd_weight_heads(y, d_f, d_w)     # one pass over y
+        # every weight / bias gradient of the net as a slice of ONE buffer zeroed once (the kernels accumulate into them)
+        sizes = [p.numel() for p in params]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=y.device)
+        gview, off = {}, 0
+        for n, p, sz in zip(_PARAM_NAMES, params, sizes):
+            gview[n] = flat[off:off + sz].view(p.shape)
+            off += sz
+        grads["features.weight"], grads["weights.weight"] = ops.conv3d_bwd_weight_heads(
+            y, d_f, d_w, out=(gview["features.weight"], gview["weights.weight"]))                      # one pass over y
         # the 1-channel head's adjoint on the fp32 kernel, then the 8-channel one on the matrix cores with the sum fused
         bounds = _Bounds()
         d_y = ops.conv3d_bwd_data(d_w, P["weights.weight"], S1, tuple(y.shape))
@@ -233,7 +250,8 @@ class CostRegNetWeightFn(torch.autograd.Function):
 
         def back(name, mode, d_out, accumulate=None, need_data=True):
             t = acts["in." + name]
-            grads[name + ".weight"], grads[name + ".bias"] = ops.conv3d_bwd_weight(t, d_out, mode, P[name + ".weight"].shape)
+            grads[name + ".weight"], grads[name + ".bias"] = ops.conv3d_bwd_weight(t, d_out, mode, P[name + ".weight"].shape,
+                                                                                   out=(gview[name + ".weight"], gview[name + ".bias"]))
             if not need_data:
                 return None
             if mode == S1 and t.shape[-1] > 1:

@@ -175,7 +175,8 @@ def test_planes_cache_follows_the_weight_tensor():
 
 @pytest.mark.parametrize("cin,cout,mode,shape", [(8, 8, 0, (2, 3, 10, 70)), (16, 16, 0, (1, 4, 9, 37)), (32, 32, 0, (2, 2, 6, 20)), (64, 64, 0, (1, 2, 5, 18)),
                                                  (8, 16, 1, (1, 4, 8, 64)), (16, 32, 1, (2, 2, 8, 36)), (32, 64, 1, (1, 2, 4, 20)),
-                                                 (16, 8, 2, (1, 2, 4, 32)), (32, 16, 2, (2, 1, 4, 18)), (64, 32, 2, (1, 1, 4, 16)), (8, 1, 0, (2, 3, 10, 70))])
+                                                 (16, 8, 2, (1, 2, 4, 32)), (32, 16, 2, (2, 1, 4, 18)), (64, 32, 2, (1, 1, 4, 16)), (8, 1, 0, (2, 3, 10, 70)),
+                                                 (1, 8, 0, (2, 3, 10, 70)), (1, 8, 0, (1, 8, 16, 64))])
 def test_weight_gradient_on_the_matrix_cores_matches_float64(cin, cout, mode, shape):
     """ufr_conv3d_bwd_weight now runs csrc/conv3d_wgrad_planes.hip for every layer shape but conv0: d weight (and d bias)
     against a float64 autograd of the same layer; operands carry 16 significand bits (bf16 hi + lo), the sum is fp32."""

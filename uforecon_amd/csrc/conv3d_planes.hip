@@ -69,6 +69,7 @@ struct PrepArgs {
   const float* weight2;  // heads: [cout2][cin][27] (rows cout .. cout + cout2 - 1), nullable
   char* ws;
   int cout, cout2, flip;
+  int max_ready;         // 1: header word 1 already holds max |w| (measured by absmax_kernel launches: the large layers)
 };
 // transposed stride 2, one axis: the kernel index that links output parity p with input offset o (0 / +1), or -1
 // (conv3d.hip: parity 0 <- {k = 1, i = m}; parity 1 <- {k = 0, i = m + 1}, {k = 2, i = m})
@@ -84,7 +85,9 @@ __global__ void __launch_bounds__(256) conv3d_planes_prep(PrepArgs a) {
   const int NT = MODE == 2 ? a.cout / 2 : planes_tiles(a.cout + a.cout2);      // transposed: 8 classes x cout rows
   __shared__ float red[4];
   float m = 0.f;
-  {
+  if (a.max_ready) {
+    m = reinterpret_cast<const float*>(a.ws)[1];
+  } else {
     const int n1 = a.cout * CIN * 27, n2 = a.weight2 ? a.cout2 * CIN * 27 : 0;
     for (int i0 = 0; i0 < n1 + n2; i0 += 256 * 8) {
       float v[8];
@@ -103,10 +106,7 @@ __global__ void __launch_bounds__(256) conv3d_planes_prep(PrepArgs a) {
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   }
   const float sw = plane_scale(m);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    reinterpret_cast<float*>(a.ws)[0] = 1.f / sw;
-    reinterpret_cast<float*>(a.ws)[1] = m;
-  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<float*>(a.ws)[0] = 1.f / sw;     // (word 1: only the measuring launches write it)
   _Float16* planes = reinterpret_cast<_Float16*>(a.ws + kPlanesHeader);
   const int total = KS * NT * 64 * 8;
   const int e0 = blockIdx.x * (256 * 8);
@@ -565,6 +565,14 @@ hipError_t launch_conv3d_planes(const float* in, const float* in_absmax, const f
     const int ct = cout + cout2, nt = mode == 2 ? cout / 2 : planes_tiles(ct);
     PrepArgs p;
     p.weight = weight; p.weight2 = weight2; p.ws = static_cast<char*>(ws); p.cout = cout; p.cout2 = cout2; p.flip = flip;
+    // small layers: every workgroup of the prep kernel measures max |w| itself (one launch); from 16 K weights up that
+    // redundancy costs more than two small launches in front (64 -> 64: 216 workgroups x 110 592 loads = 0.15 ms)
+    p.max_ready = (long long)cout * cin * 27 > 16384 ? 1 : 0;
+    if (p.max_ready) {
+      float* wmax = reinterpret_cast<float*>(ws) + 1;
+      if (const hipError_t e = hipMemsetAsync(wmax, 0, 4, s); e != hipSuccess) return e;
+      if (const hipError_t e = launch_absmax(weight, (size_t)cout * cin * 27, wmax, s); e != hipSuccess) return e;
+    }
     const unsigned pb = (unsigned)((planes_ksteps(cin, mode) * nt * 512 + 2047) / 2048);
     if (mode == 2 && cin == 16) hipLaunchKernelGGL((conv3d_planes_prep<16, 2>), dim3(pb), dim3(256), 0, s, p);
     else if (mode == 2 && cin == 32) hipLaunchKernelGGL((conv3d_planes_prep<32, 2>), dim3(pb), dim3(256), 0, s, p);

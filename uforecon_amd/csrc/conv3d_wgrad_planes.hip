@@ -95,7 +95,9 @@ template <int CA, int CB, int S, int NA, int NTAP>
 struct WgCfg {
   static constexpr int CBL = CB < 16 ? CB : 16;                 // TQ channels staged per block
   static constexpr bool PAIRS = CB == 8;                        // two taps share a 16-column tile
-  static constexpr int NSLOT = PAIRS ? (NTAP + 1) / 2 : NTAP;   // accumulator tiles per TP tile
+  static constexpr bool ONE = CB == 1;                          // sixteen taps share it (conv0: a one-channel input)
+  static constexpr int TPT = ONE ? 16 : PAIRS ? 2 : 1;          // taps per tile
+  static constexpr int NSLOT = (NTAP + TPT - 1) / TPT;          // accumulator tiles per TP tile
   static constexpr int TX = 32, TY = 4, TZ = S == 1 ? 2 : 1;    // brick of P voxels: TY TZ rows of one chunk
   static constexpr int HX = S * (TX - 1) + 3, HY = S * (TY - 1) + 3, HZ = S * (TZ - 1) + 3;
   static constexpr int halo = HX * HY * HZ;
@@ -142,7 +144,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_wgrad_planes_kernel(WgPlanesArg
 
   const size_t p_frame = (size_t)a.Dp * a.Hp * a.Wp * CA * 4, q_frame = (size_t)a.Dq * a.Hq * a.Wq * CB * 4;
   const int n_bricks = a.nbx * a.nby * a.nbz * a.B;
-  constexpr int G4 = CBL / 4, items = Cf::halo * G4, kRounds = (items + 2047) / 2048;
+  constexpr int G4 = Cf::ONE ? 1 : CBL / 4, items = Cf::halo * G4, kRounds = (items + 2047) / 2048;
   constexpr bool kPre = kRounds == 1;      // (two rounds = 64 more registers: the 16 x 16 layer, whose 27 accumulator tiles are 108, spilled 68)
   f32x4 pre[kPre ? kRounds * 8 : 1];
   auto item_off = [&](int kb, int it, bool& ok) __attribute__((always_inline)) -> unsigned {
@@ -156,6 +158,10 @@ __global__ void __launch_bounds__(256, 2) conv3d_wgrad_planes_kernel(WgPlanesArg
     ok = it < items && ix >= 0 && ix < a.Wq && iy >= 0 && iy < a.Hq && iz >= 0 && iz < a.Dq;
     return (unsigned)((((iz * a.Hq + iy) * a.Wq + ix) * CB + b0 + 4 * c4) * 4);
   };
+  auto ld_item = [&](const __amdgpu_buffer_rsrc_t& rq, unsigned off) __attribute__((always_inline)) -> f32x4 {
+    if constexpr (Cf::ONE) return f32x4{buf_ld1(rq, off), 0.f, 0.f, 0.f};      // one channel per voxel
+    else return buf_ld4(rq, off);
+  };
   auto rq_of = [&](int kb) __attribute__((always_inline)) {
     const int bi = kb / (a.nbx * a.nby * a.nbz);
     return buf_rsrc(reinterpret_cast<const char*>(a.tq) + (size_t)bi * q_frame, (unsigned)q_frame);
@@ -164,8 +170,13 @@ __global__ void __launch_bounds__(256, 2) conv3d_wgrad_planes_kernel(WgPlanesArg
     if (it < items) {
       u32x2w h, l;
       planes_of(v, h, l);
-      *reinterpret_cast<u32x2w*>(q_hi + (size_t)it * 8) = h;       // [voxel][4-channel group] = [voxel][CBL] bf16
-      *reinterpret_cast<u32x2w*>(q_lo + (size_t)it * 8) = l;
+      if constexpr (Cf::ONE) {
+        *reinterpret_cast<unsigned short*>(q_hi + (size_t)it * 2) = (unsigned short)(h[0] & 0xffffu);      // [voxel] bf16
+        *reinterpret_cast<unsigned short*>(q_lo + (size_t)it * 2) = (unsigned short)(l[0] & 0xffffu);
+      } else {
+        *reinterpret_cast<u32x2w*>(q_hi + (size_t)it * 8) = h;       // [voxel][4-channel group] = [voxel][CBL] bf16
+        *reinterpret_cast<u32x2w*>(q_lo + (size_t)it * 8) = l;
+      }
     }
   };
   auto pre_load = [&](int kb) __attribute__((always_inline)) {
@@ -174,7 +185,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_wgrad_planes_kernel(WgPlanesArg
     for (int u = 0; u < (kPre ? kRounds * 8 : 0); ++u) {
       bool ok;
       const unsigned off = item_off(kb, 256 * u + tid, ok);
-      pre[u] = buf_ld4(rq, ok ? off : kBufOut);
+      pre[u] = ld_item(rq, ok ? off : kBufOut);
     }
   };
   auto pre_store = [&]() __attribute__((always_inline)) {
@@ -190,7 +201,7 @@ __global__ void __launch_bounds__(256, 2) conv3d_wgrad_planes_kernel(WgPlanesArg
       for (int u = 0; u < 8; ++u) {
         bool ok;
         const unsigned off = item_off(kb, i0 + 256 * u + tid, ok);
-        v[u] = buf_ld4(rq, ok ? off : kBufOut);
+        v[u] = ld_item(rq, ok ? off : kBufOut);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) put_item(i0 + 256 * u + tid, v[u]);
@@ -298,6 +309,23 @@ __global__ void __launch_bounds__(256, 2) conv3d_wgrad_planes_kernel(WgPlanesArg
       WTr trs[2];
       auto read_slot = [&](auto si) __attribute__((always_inline)) {
         constexpr int s = decltype(si)::value;
+        if constexpr (Cf::ONE) {
+          // lane group g, element i <-> tap 16 s + 4 g + i of the one input channel: four 2-byte reads per plane and column tile
+          unsigned short hh[2][4], ll[2][4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int tap = tap0 + 16 * s + 4 * g + i;
+            const int tt = tap < 27 ? tap : 0;
+            const int toff = ((tt / 9) * Cf::HY + (tt / 3) % 3) * Cf::HX + tt % 3;
+            hh[0][i] = *reinterpret_cast<const unsigned short*>(q_hi + (vb0 + toff) * 2);
+            ll[0][i] = *reinterpret_cast<const unsigned short*>(q_lo + (vb0 + toff) * 2);
+            hh[1][i] = *reinterpret_cast<const unsigned short*>(q_hi + (vb1 + toff) * 2);
+            ll[1][i] = *reinterpret_cast<const unsigned short*>(q_lo + (vb1 + toff) * 2);
+          }
+          auto pk = [](const unsigned short (&v)[4]) { return u32x2w{(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16)}; };
+          rd[s % 3][0] = pk(hh[0]); rd[s % 3][1] = pk(ll[0]); rd[s % 3][2] = pk(hh[1]); rd[s % 3][3] = pk(ll[1]);
+          return;
+        }
         int tap, cofs;
         if constexpr (Cf::PAIRS) { tap = tap0 + 2 * s + (g >> 1); cofs = 4 * (g & 1); }
         else { tap = tap0 + s; cofs = 4 * g; }
@@ -369,7 +397,8 @@ __global__ void __launch_bounds__(256, 2) conv3d_wgrad_planes_kernel(WgPlanesArg
 #pragma unroll
       for (int s = 0; s < NSLOT; ++s) {
         int tl, bl;                                   // tap within the block's group, TQ channel within the block
-        if constexpr (Cf::PAIRS) { tl = 2 * s + (j >> 3); bl = j & 7; }
+        if constexpr (Cf::ONE) { tl = 16 * s + j; bl = 0; }
+        else if constexpr (Cf::PAIRS) { tl = 2 * s + (j >> 3); bl = j & 7; }
         else { tl = s; bl = j; }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -423,6 +452,7 @@ hipError_t launch_conv3d_wgrad_planes(const float* tp, const float* tq, float* d
   a.tp = tp; a.tq = tq; a.dw = dw; a.dbias = dbias; a.B = B; a.Dp = Dp; a.Hp = Hp; a.Wp = Wp; a.Dq = Dq; a.Hq = Hq; a.Wq = Wq;
   a.nbx = a.nby = a.nbz = 0;
 #define UFR_WGP(CA_, CB_, S_, NA_, NT_) if (ca == CA_ && cb == CB_ && S == S_) return launch_wgp_t<CA_, CB_, S_, NA_, NT_>(a, s);
+  UFR_WGP(8, 1, 1, 1, 27)      // conv0 (one input channel: sixteen taps per tile)
   UFR_WGP(8, 8, 1, 1, 27)      // features head
   UFR_WGP(1, 8, 1, 1, 27)      // weights head
   UFR_WGP(16, 16, 1, 1, 27)    // conv2

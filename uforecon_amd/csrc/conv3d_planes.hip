@@ -1,26 +1,31 @@
-// The 8- and 16-channel 3x3x3 layers of the frustum U-Nets on the 16-bit matrix cores, activations staged through LDS.
+// The 3x3x3 layers of the frustum U-Nets (every layer with at least 8 input channels: stride 1, stride 2, transposed stride 2)
+// on the 16-bit matrix cores, activations staged through LDS.
 //   CostRegNetWeight  code1/encoder_utils/fmt/module.py:502-543   (`feature_volume.cost_reg_2`: plain Conv3d with bias)
-//   CostRegNet        code1/encoder_utils/fmt/module.py:469-500   (Conv3d + BatchNorm + ReLU; opt-in, see unet3d.py)
+//   CostRegNet        code1/encoder_utils/fmt/module.py:469-500   (Conv3d + BatchNorm + ReLU)
 //
 // Why a second kernel family.  The fp32 kernels of conv3d.hip run the full- and half-resolution layers (8 / 16 channels:
 // two thirds of a U-Net's time) at a third of the vector peak, and neither halving their FMA instructions nor their LDS
 // weight reads changes that (conv3d.hip, conv3d_kernel): every output voxel asks the L1 for its 27 neighbours again, one
 // bounds-checked 16-byte load per four channels and tap.  An implicit GEMM that fetches its operands the same way inherits
 // the same bound.  So here
-//  * a workgroup owns a BRICK of TZ x TY x TX output voxels and stages the brick's input halo ONCE: coalesced row loads
-//    through a bounded buffer descriptor (zero padding = an offset past the extent), each value split into two fp16
-//    planes hi = fp16(s x), lo = fp16(s x - hi) on the way (s = a power of two from the tensor's MEASURED |max|, handed
-//    over by the producing layer: `in_absmax`), 3.1 .. 4.6 fetched voxels per output instead of 27;
+//  * a workgroup owns a BRICK of output voxels and stages the brick's input halo ONCE: coalesced row loads through a
+//    bounded buffer descriptor (zero padding = an offset past the extent), each value split into two fp16 planes
+//    hi = fp16(s x), lo = fp16(s x - hi) on the way (s = a power of two from the tensor's MEASURED |max|, handed over by
+//    the producing layer: `in_absmax`), 3 .. 5 fetched voxels per output instead of 27; halo planes are 8-channel-chunk
+//    major, so a lane group's 16 lanes read 256 contiguous bytes whatever the channel count;
 //  * the convolution is an implicit GEMM on v_mfma_f32_16x16x32_f16: rows = 16 output channels, columns = 16 consecutive
-//    x of the brick, k = 32 = (4 taps x 8 channels | 2 taps x 16 channels): lane group g reads ITS tap's neighbour of
-//    voxel j as one ds_read_b128 per plane, no address arithmetic beyond one add per k-step;
+//    x of the brick, k = 32 = 4 taps x 8 channels | 2 x 16 | 1 x 32 | half a tap of 64: a lane reads ITS tap's neighbour
+//    of voxel j as one ds_read_b128 per plane; the operands of step s + 2 are requested before the MFMAs of step s;
 //  * a product is three plane pairs accumulated in fp32 (w_lo x_hi + w_hi x_lo + w_hi x_hi: 22 significand bits, the
 //    scheme of the transformer kernels, ufr_layout_f16.h); the weights' planes [k-step][row tile][plane][lane] are made once
-//    per layer call by conv3d_planes_prep (scale 2^e from max |w|) and copied into LDS by every workgroup;
+//    per weight version by conv3d_planes_prep (scale 2^e from max |w|) and sit in LDS (<= 32 KiB) or are read from L2;
+//  * stride 2 = the same with a 2T + 1 halo; TRANSPOSED stride 2 = a 2 x 2 x 2 convolution of the INPUT grid with 8 x cout
+//    output rows, one group per output parity class (structural zeros where a class has no such tap);
+//  * persistent workgroups walk contiguous, XCD-aware runs of bricks with the next brick's halo loads in flight;
 //  * the exact power-of-two descale, bias, folded BatchNorm, ReLU, the U-Net's skip addition, the two heads' (B,C,D,H,W)
 //    layout + sigmoid ride in the store, which also raises `out_absmax` for the next layer (one guarded atomic per wave).
-// Stride-1 layers only (forward, and -- with mirrored taps on the swapped weight, `flip` -- their data gradients); the
-// strided / transposed layers and everything from 32 channels up stay on conv3d.hip.
+// The data gradients are the same kernels (stride 1: mirrored taps on the swapped weight, `flip`; strided <-> transposed on
+// the forward weight as it stands).  conv0 (one input channel) stays on conv3d.hip; weight gradients: conv3d_wgrad_planes.hip.
 #include <hip/hip_runtime.h>
 
 #include "ufr_device.h"

@@ -74,6 +74,9 @@ __device__ __forceinline__ void sample_volume_buf(__amdgpu_buffer_rsrc_t r, int 
   for (int k = 0; k < 8; ++k) {
     v0[k] = buf_ld4(r, off[k]);
     v1[k] = buf_ld4(r, off[k] + 16u);
+#ifdef UFR_GABL_FIVE   // development ablation (timing only, wrong results): five instead of six 16-byte accesses per x pair
+    if (k & 1) v2[k] = v1[k][3]; else
+#endif
     v2[k] = buf_ld1(r, off[k] + 32u);
   }
   f32x4 a0 = splat4(0.f), a1 = splat4(0.f);

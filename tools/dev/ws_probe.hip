@@ -9,10 +9,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int NFRAG, int NVALU>
+template <int NFRAG, int NVALU, bool VALU_FIRST = false>
 __device__ __forceinline__ void slice(const f16x8 (&w)[NFRAG][2], const char* in, char* out, int lane, f32x4& sink, float& vsink) {
   constexpr int C = 2;
   f32x4 acc[C][5];
+  if constexpr (VALU_FIRST) {     // staggered variant: this slice's VALU (of the previous step's output) in front of its MFMAs
+    float v = vsink;
+#pragma unroll
+    for (int i = 0; i < NVALU; ++i) v = __builtin_fmaf(v, 1.0001f, sink[i & 3] * 1e-9f);
+    vsink = v;
+    __builtin_amdgcn_sched_barrier(0);
+  }
 #pragma unroll
   for (int c = 0; c < C; ++c)
 #pragma unroll
@@ -29,10 +36,12 @@ __device__ __forceinline__ void slice(const f16x8 (&w)[NFRAG][2], const char* in
       acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[f][0], bh, acc[c][t], 0, 0, 0);
     }
   }
-  float v = vsink;
+  if constexpr (!VALU_FIRST) {
+    float v = vsink;
 #pragma unroll
-  for (int i = 0; i < NVALU; ++i) v = __builtin_fmaf(v, 1.0001f, acc[i & 1][i % 5][i & 3] * 1e-9f);
-  vsink = v;
+    for (int i = 0; i < NVALU; ++i) v = __builtin_fmaf(v, 1.0001f, acc[i & 1][i % 5][i & 3] * 1e-9f);
+    vsink = v;
+  }
   // hand the slice's output on: 3 k-steps x 2 planes per column tile (converted, not exactly split: the VALU count is NVALU's job)
 #pragma unroll
   for (int c = 0; c < C; ++c)
@@ -64,6 +73,7 @@ __device__ __forceinline__ void init_w(f16x8 (&w)[NFRAG][2], unsigned seed) {
 }
 
 // slices: fragments / VALU per wave (two waves per SIMD: w and w + 4 share one)
+template <bool STAGGER>
 __global__ void __launch_bounds__(512, 1) ws_kernel(float* out, int steps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];      // 4 hand-off buffers x 2 (double-buffered) x 12 KiB (the probe shares them pairwise: timing only)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -77,7 +87,7 @@ __global__ void __launch_bounds__(512, 1) ws_kernel(float* out, int steps) {
     f16x8 w[NF][2];                                                                        \
     init_w<NF>(w, 12345u + 977u * (threadIdx.x + 512u * blockIdx.x));                      \
     for (int s = 0; s < steps; ++s) {                                                      \
-      slice<NF, NV>(w, bufp(W, s), bufp(W + 1, s + 1), lane, sink, vsink);                 \
+      slice<NF, NV, (STAGGER && W < 4)>(w, bufp(W, s), bufp(W + 1, s + 1), lane, sink, vsink);                 \
       __builtin_amdgcn_s_barrier();                                                        \
     }                                                                                      \
   }
@@ -89,15 +99,17 @@ __global__ void __launch_bounds__(512, 1) ws_kernel(float* out, int steps) {
   out[blockIdx.x * 512 + threadIdx.x] = sink[0] + sink[1] + sink[2] + sink[3] + vsink;
 }
 
-extern "C" float ws_run(int blocks, int steps, float* out) {
+extern "C" float ws_run(int blocks, int steps, float* out, int stagger) {
   const int lds = 4 * 2 * 12288;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ws_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ws_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   float ms = 0.f;
   for (int rep = 0; rep < 3; ++rep) {
     (void)hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(ws_kernel, dim3(blocks), dim3(512), lds, 0, out, steps);
+    if (stagger) hipLaunchKernelGGL(ws_kernel<true>, dim3(blocks), dim3(512), lds, 0, out, steps);
+    else hipLaunchKernelGGL(ws_kernel<false>, dim3(blocks), dim3(512), lds, 0, out, steps);
     (void)hipEventRecord(e1, 0);
     (void)hipEventSynchronize(e1);
     (void)hipEventElapsedTime(&ms, e0, e1);

@@ -13,7 +13,8 @@ if not os.path.exists(so):
 lib = C.CDLL(so)
 lib.ws_run.restype = C.c_float
 out = torch.empty(256 * 512, device="cuda")
-for steps in (128, 512, 2048):
-    ms = lib.ws_run(256, steps, C.c_void_p(out.data_ptr()))
+for stagger in (0, 1):
+  for steps in (128, 512, 2048):
+    ms = lib.ws_run(256, steps, C.c_void_p(out.data_ptr()), stagger)
     torch.cuda.synchronize()
-    print(f"steps {steps}: {ms:.3f} ms -> {ms * 1e6 / steps:.0f} ns per step (8 points) = {ms * 1e6 / steps / 8:.0f} ns per point and CU")
+    print(f"stagger {stagger} steps {steps}: {ms:.3f} ms -> {ms * 1e6 / steps:.0f} ns per step (8 points) = {ms * 1e6 / steps / 8:.0f} ns per point and CU")

@@ -194,7 +194,13 @@ int ufr_frame_prepare(const ufr_frame_desc* d, void* workspace, size_t workspace
  * next ufr_weights_pack, so the backward of an earlier forward stays in range whatever frames are fitted in between.
  * ufr_render_rays does this itself; callers of the stepwise entry points (ufr_project_gather -> ufr_aggregate ...) call it
  * once per (frame, pack) -- uforecon_amd.ops does, in FrameHandle-taking calls.  Replaces "state input_abs_max for this
- * checkpoint": the reference loads any checkpoint without side information (main.py:186-190). */
+ * checkpoint": the reference loads any checkpoint without side information (main.py:186-190).
+ * OWNERSHIP: the refit WRITES the scale table inside `packed` (ufr_render_rays does too, although it takes the blob as
+ * const void*: the planes are const, the table is not).  A packed blob therefore belongs to ONE stream at a time: kernels of
+ * another stream, or of an earlier call on another stream, that still read the table while a refit runs would race.  Fit on
+ * the stream the render / aggregate calls use (stream order then serialises refit and readers), and give every
+ * concurrently rendered frame stream its own packed copy.  Activations taped under an older, smaller table stay valid:
+ * the bound only grows, and a backward recomputes with the table it finds. */
 int ufr_weights_fit_frame(void* packed, const ufr_frame* frame, ufr_stream stream);
 
 /* ------------------------------------------------------------------ per-op entry points
